@@ -1,0 +1,138 @@
+"""ctypes binding of libgrove_hip.so (include/grove_hip.h).
+
+The product path has no fallback: if the shared library is missing this module raises at the
+first op, and every non-zero status becomes a RuntimeError carrying grove_last_error().
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libgrove_hip.so")
+
+c_i32, c_i64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_QUICKGELU, ACT_SILU, ACT_SIGMOID = range(6)
+BF16, F32 = 0, 1
+
+
+class GemmParams(C.Structure):
+    _fields_ = [("A", c_vp), ("B", c_vp), ("C", c_vp), ("bias", c_vp), ("residual", c_vp), ("aux", c_vp),
+                ("scale_ptr", c_vp), ("a_idx", c_vp), ("c_idx", c_vp), ("r_idx", c_vp),
+                ("sA1", c_i64), ("sA2", c_i64), ("sB1", c_i64), ("sB2", c_i64),
+                ("sC1", c_i64), ("sC2", c_i64), ("sR1", c_i64), ("sR2", c_i64),
+                ("M", c_i32), ("N", c_i32), ("K", c_i32),
+                ("lda", c_i32), ("ldb", c_i32), ("ldc", c_i32), ("ldr", c_i32),
+                ("batch1", c_i32), ("batch2", c_i32), ("a_taps", c_i32), ("act", c_i32),
+                ("c_dtype", c_i32), ("accumulate", c_i32), ("scale_tanh", c_i32), ("alpha", c_f32)]
+
+
+class TransposeParams(C.Structure):
+    _fields_ = [("inp", c_vp), ("out", c_vp), ("s_in1", c_i64), ("s_in2", c_i64), ("s_out1", c_i64), ("s_out2", c_i64),
+                ("rows", c_i32), ("cols", c_i32), ("ld_in", c_i32), ("ld_out", c_i32), ("pad_to", c_i32),
+                ("batch1", c_i32), ("batch2", c_i32)]
+
+
+class NormParams(C.Structure):
+    _fields_ = [("x", c_vp), ("weight", c_vp), ("bias", c_vp), ("y", c_vp), ("mean", c_vp), ("rstd", c_vp),
+                ("out_idx", c_vp), ("rows", c_i32), ("C", c_i32), ("ld_x", c_i32), ("ld_y", c_i32),
+                ("y_dtype", c_i32), ("eps", c_f32)]
+
+
+class NormBwdParams(C.Structure):
+    _fields_ = [("x", c_vp), ("weight", c_vp), ("dy", c_vp), ("dx", c_vp), ("mean", c_vp), ("rstd", c_vp),
+                ("dweight", c_vp), ("dbias", c_vp), ("in_idx", c_vp),
+                ("rows", c_i32), ("C", c_i32), ("ld_x", c_i32), ("ld_dy", c_i32), ("ld_dx", c_i32),
+                ("accumulate", c_i32), ("eps", c_f32)]
+
+
+class SoftmaxParams(C.Structure):
+    _fields_ = [("scores", c_vp), ("probs", c_vp), ("kv_len", c_vp), ("rel", c_vp),
+                ("batch", c_i32), ("heads", c_i32), ("Lq", c_i32), ("Lk", c_i32), ("ld_s", c_i32), ("ld_p", c_i32),
+                ("causal", c_i32), ("rel_kh", c_i32), ("rel_kw", c_i32)]
+
+
+class SoftmaxBwdParams(C.Structure):
+    _fields_ = [("dprobs", c_vp), ("probs", c_vp), ("dscores", c_vp), ("drel", c_vp),
+                ("batch", c_i32), ("Lq", c_i32), ("Lk", c_i32), ("ld_s", c_i32), ("ld_p", c_i32),
+                ("rel_kh", c_i32), ("rel_kw", c_i32), ("scale", c_f32)]
+
+
+class RelposParams(C.Structure):
+    _fields_ = [("q", c_vp), ("Rh", c_vp), ("Rw", c_vp), ("rel", c_vp), ("dq", c_vp),
+                ("batch", c_i32), ("heads", c_i32), ("qh", c_i32), ("qw", c_i32), ("kh", c_i32), ("kw", c_i32),
+                ("hd", c_i32), ("hd_stride", c_i32), ("ld_q", c_i32)]
+
+
+class RopeParams(C.Structure):
+    _fields_ = [("x", c_vp), ("pos", c_vp), ("rows", c_i32), ("ld", c_i32), ("col0", c_i32), ("nheads", c_i32),
+                ("hd", c_i32), ("inverse", c_i32), ("theta", c_f32)]
+
+
+class RowsParams(C.Structure):
+    _fields_ = [("src", c_vp), ("dst", c_vp), ("idx_src", c_vp), ("idx_dst", c_vp),
+                ("rows", c_i32), ("C", c_i32), ("ld_src", c_i32), ("ld_dst", c_i32), ("accumulate", c_i32)]
+
+
+class SmallAttnParams(C.Structure):
+    _fields_ = [("q", c_vp), ("k", c_vp), ("v", c_vp), ("o", c_vp), ("d_o", c_vp), ("dq", c_vp), ("dk", c_vp), ("dv", c_vp),
+                ("inst", c_i32), ("heads", c_i32), ("d", c_i32), ("Lq", c_i32), ("Lk", c_i32),
+                ("ld_q", c_i32), ("ld_k", c_i32), ("ld_v", c_i32), ("ld_o", c_i32)]
+
+
+class BoxHeadParams(C.Structure):
+    _fields_ = [("x", c_vp), ("W1", c_vp), ("b1", c_vp), ("W2", c_vp), ("b2", c_vp), ("Wo", c_vp), ("bo", c_vp),
+                ("hidden", c_vp), ("box", c_vp), ("obj", c_vp), ("N", c_i32), ("D", c_i32)]
+
+
+class BoxHeadBwdParams(C.Structure):
+    _fields_ = [("x", c_vp), ("W1", c_vp), ("W2", c_vp), ("Wo", c_vp), ("hidden", c_vp), ("box", c_vp),
+                ("dbox", c_vp), ("dobj", c_vp), ("dx", c_vp),
+                ("dW1", c_vp), ("db1", c_vp), ("dW2", c_vp), ("db2", c_vp), ("dWo", c_vp), ("dbo", c_vp),
+                ("N", c_i32), ("D", c_i32)]
+
+
+STRUCTS = {
+    "grove_gemm_params": GemmParams, "grove_transpose_params": TransposeParams, "grove_norm_params": NormParams,
+    "grove_norm_bwd_params": NormBwdParams, "grove_softmax_params": SoftmaxParams,
+    "grove_softmax_bwd_params": SoftmaxBwdParams, "grove_relpos_params": RelposParams, "grove_rope_params": RopeParams,
+    "grove_rows_params": RowsParams, "grove_small_attn_params": SmallAttnParams, "grove_box_head_params": BoxHeadParams,
+    "grove_box_head_bwd_params": BoxHeadBwdParams,
+}
+
+# every symbol include/grove_hip.h declares (tests/test_abi.py checks the header against this list)
+SYMBOLS = [
+    "grove_version", "grove_last_error", "grove_sizeof", "grove_gemm_bf16", "grove_gemm_set_staging",
+    "grove_transpose_bf16", "grove_layernorm_fwd", "grove_rmsnorm_fwd", "grove_layernorm_bwd", "grove_rmsnorm_bwd",
+    "grove_softmax_fwd", "grove_softmax_bwd", "grove_relpos_fwd", "grove_relpos_bwd", "grove_rope_inplace",
+    "grove_swiglu_fwd", "grove_swiglu_bwd", "grove_act_bwd", "grove_add_bf16", "grove_add_bcast_rows",
+    "grove_copy_rows", "grove_scatter_add_f32", "grove_colsum_f32", "grove_cast_f32_to_bf16", "grove_cast_bf16_to_f32",
+    "grove_im2col_patch", "grove_clip_pool", "grove_cross_entropy", "grove_small_attn_fwd", "grove_small_attn_bwd",
+    "grove_box_head_fwd", "grove_box_head_bwd", "grove_box_losses", "grove_adamw_step", "grove_sumsq_f32",
+]
+
+_lib = None
+
+
+def lib():
+    """Load libgrove_hip.so once. Raises (never falls back) if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C grove_amd/csrc`). grove_amd has no non-HIP fallback.")
+        _lib = C.CDLL(LIB_PATH)
+        for name in SYMBOLS:
+            getattr(_lib, name).restype = C.c_int
+    return _lib
+
+
+def last_error():
+    buf = C.create_string_buffer(512)
+    lib().grove_last_error(buf, C.c_size_t(512))
+    return buf.value.decode("utf-8", "replace")
+
+
+def check(status, what):
+    if status != 0:
+        raise RuntimeError(f"{what} failed with status {status}: {last_error()}")

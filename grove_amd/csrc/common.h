@@ -1,0 +1,121 @@
+// Common device helpers for the gfx950 (CDNA4 / MI355X) kernels of grove_amd.
+// Wave size is 64; all kernels here are written for gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/grove_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+typedef unsigned short bf16_raw;
+
+__device__ __forceinline__ float bf2f(bf16_raw x) { return __uint_as_float(((unsigned)x) << 16); }
+__device__ __forceinline__ bf16_raw f2bf(float f) {
+  __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+  return __builtin_bit_cast(bf16_raw, b);
+}
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
+  return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+}
+__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Block-wide sum for blockDim.x == NT (multiple of 64); scratch: NT/64 floats in LDS.
+template <int NT>
+__device__ __forceinline__ float block_sum(float v, float* scratch) {
+  v = wave_sum(v);
+  constexpr int NW = NT / 64;
+  if constexpr (NW == 1) return v;
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  __syncthreads();
+  if (l == 0) scratch[w] = v;
+  __syncthreads();
+  float r = 0.f;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) r += scratch[i];
+  return r;
+}
+template <int NT>
+__device__ __forceinline__ float block_max(float v, float* scratch) {
+  v = wave_max(v);
+  constexpr int NW = NT / 64;
+  if constexpr (NW == 1) return v;
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  __syncthreads();
+  if (l == 0) scratch[w] = v;
+  __syncthreads();
+  float r = scratch[0];
+#pragma unroll
+  for (int i = 1; i < NW; ++i) r = fmaxf(r, scratch[i]);
+  return r;
+}
+
+__device__ __forceinline__ float act_apply(int act, float x) {
+  switch (act) {
+    case GROVE_ACT_RELU: return fmaxf(x, 0.f);
+    case GROVE_ACT_GELU: return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));
+    case GROVE_ACT_QUICKGELU: return x / (1.f + __expf(-1.702f * x));
+    case GROVE_ACT_SILU: return x / (1.f + __expf(-x));
+    case GROVE_ACT_SIGMOID: return 1.f / (1.f + __expf(-x));
+    default: return x;
+  }
+}
+// d act(x) / dx
+__device__ __forceinline__ float act_grad(int act, float x) {
+  switch (act) {
+    case GROVE_ACT_RELU: return x > 0.f ? 1.f : 0.f;
+    case GROVE_ACT_GELU: {
+      const float c = 0.70710678118654752440f;
+      float cdf = 0.5f * (1.f + erff(x * c));
+      float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+      return cdf + x * pdf;
+    }
+    case GROVE_ACT_QUICKGELU: {
+      float s = 1.f / (1.f + __expf(-1.702f * x));
+      return s + 1.702f * x * s * (1.f - s);
+    }
+    case GROVE_ACT_SILU: {
+      float s = 1.f / (1.f + __expf(-x));
+      return s + x * s * (1.f - s);
+    }
+    case GROVE_ACT_SIGMOID: {
+      float s = 1.f / (1.f + __expf(-x));
+      return s * (1.f - s);
+    }
+    default: return 1.f;
+  }
+}
+
+// error plumbing (host)
+void grove_set_error(const char* fmt, ...);
+#define GROVE_CHECK(cond, code, ...)         \
+  do {                                       \
+    if (!(cond)) {                           \
+      grove_set_error(__VA_ARGS__);          \
+      return (code);                         \
+    }                                        \
+  } while (0)
+#define GROVE_LAUNCH_CHECK()                                          \
+  do {                                                                \
+    hipError_t e_ = hipGetLastError();                                \
+    if (e_ != hipSuccess) {                                           \
+      grove_set_error("HIP launch failed: %s", hipGetErrorString(e_)); \
+      return GROVE_E_HIP;                                             \
+    }                                                                 \
+  } while (0)

@@ -1,0 +1,301 @@
+// Elementwise / data-movement kernels for gfx950. All HBM-bound: 16-byte accesses per lane,
+// grid capped at 2048 blocks with a grid-stride loop (cdna_hip_programming.md Guideline 11/13).
+#include "common.h"
+
+namespace {
+
+constexpr int EB = 256;
+inline dim3 grid_for(int64_t nvec) {
+  int64_t g = (nvec + EB - 1) / EB;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  return dim3((unsigned)g);
+}
+
+__device__ __forceinline__ void unpack8(const u32x4_t u, float* f) {
+  f[0] = bf_lo(u.x); f[1] = bf_hi(u.x); f[2] = bf_lo(u.y); f[3] = bf_hi(u.y);
+  f[4] = bf_lo(u.z); f[5] = bf_hi(u.z); f[6] = bf_lo(u.w); f[7] = bf_hi(u.w);
+}
+__device__ __forceinline__ u32x4_t pack8(const float* f) {
+  return u32x4_t{pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7])};
+}
+
+// y[r, i] = silu(gu[r, i]) * gu[r, I + i]
+__global__ __launch_bounds__(EB) void swiglu_fwd_kernel(const bf16_raw* __restrict__ gu, bf16_raw* __restrict__ y, int rows, int I) {
+  const int ipv = I >> 3;
+  const int64_t n = (int64_t)rows * ipv;
+  for (int64_t t = (int64_t)blockIdx.x * EB + threadIdx.x; t < n; t += (int64_t)gridDim.x * EB) {
+    const int r = (int)(t / ipv), c = (int)(t - (int64_t)r * ipv) * 8;
+    float g[8], u[8], o[8];
+    unpack8(*(const u32x4_t*)(gu + (int64_t)r * 2 * I + c), g);
+    unpack8(*(const u32x4_t*)(gu + (int64_t)r * 2 * I + I + c), u);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = g[e] / (1.f + __expf(-g[e])) * u[e];
+    *(u32x4_t*)(y + (int64_t)r * I + c) = pack8(o);
+  }
+}
+
+__global__ __launch_bounds__(EB) void swiglu_bwd_kernel(const bf16_raw* __restrict__ gu, const bf16_raw* __restrict__ dy,
+                                                        bf16_raw* __restrict__ dgu, int rows, int I) {
+  const int ipv = I >> 3;
+  const int64_t n = (int64_t)rows * ipv;
+  for (int64_t t = (int64_t)blockIdx.x * EB + threadIdx.x; t < n; t += (int64_t)gridDim.x * EB) {
+    const int r = (int)(t / ipv), c = (int)(t - (int64_t)r * ipv) * 8;
+    float g[8], u[8], d[8], dg[8], du[8];
+    unpack8(*(const u32x4_t*)(gu + (int64_t)r * 2 * I + c), g);
+    unpack8(*(const u32x4_t*)(gu + (int64_t)r * 2 * I + I + c), u);
+    unpack8(*(const u32x4_t*)(dy + (int64_t)r * I + c), d);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float s = 1.f / (1.f + __expf(-g[e]));
+      dg[e] = d[e] * u[e] * (s + g[e] * s * (1.f - s));
+      du[e] = d[e] * g[e] * s;
+    }
+    *(u32x4_t*)(dgu + (int64_t)r * 2 * I + c) = pack8(dg);
+    *(u32x4_t*)(dgu + (int64_t)r * 2 * I + I + c) = pack8(du);
+  }
+}
+
+__global__ __launch_bounds__(EB) void act_bwd_kernel(const bf16_raw* __restrict__ pre, const bf16_raw* __restrict__ dy,
+                                                     bf16_raw* __restrict__ dx, int64_t nvec, int act) {
+  for (int64_t t = (int64_t)blockIdx.x * EB + threadIdx.x; t < nvec; t += (int64_t)gridDim.x * EB) {
+    float x[8], d[8], o[8];
+    unpack8(*(const u32x4_t*)(pre + t * 8), x);
+    unpack8(*(const u32x4_t*)(dy + t * 8), d);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = d[e] * act_grad(act, x[e]);
+    *(u32x4_t*)(dx + t * 8) = pack8(o);
+  }
+}
+
+__global__ __launch_bounds__(EB) void add_kernel(const bf16_raw* __restrict__ a, const bf16_raw* __restrict__ b, bf16_raw* __restrict__ y, int64_t nvec) {
+  for (int64_t t = (int64_t)blockIdx.x * EB + threadIdx.x; t < nvec; t += (int64_t)gridDim.x * EB) {
+    float x[8], z[8];
+    unpack8(*(const u32x4_t*)(a + t * 8), x);
+    if (b) {
+      unpack8(*(const u32x4_t*)(b + t * 8), z);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] += z[e];
+    }
+    *(u32x4_t*)(y + t * 8) = pack8(x);
+  }
+}
+
+__global__ __launch_bounds__(EB) void add_bcast_kernel(const bf16_raw* __restrict__ a, const bf16_raw* __restrict__ b, bf16_raw* __restrict__ y,
+                                                       int rows, int C, int period) {
+  const int cpv = C >> 3;
+  const int64_t n = (int64_t)rows * cpv;
+  for (int64_t t = (int64_t)blockIdx.x * EB + threadIdx.x; t < n; t += (int64_t)gridDim.x * EB) {
+    const int r = (int)(t / cpv), c = (int)(t - (int64_t)r * cpv) * 8;
+    float x[8], z[8];
+    unpack8(*(const u32x4_t*)(a + (int64_t)r * C + c), x);
+    unpack8(*(const u32x4_t*)(b + (int64_t)(r % period) * C + c), z);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] += z[e];
+    *(u32x4_t*)(y + (int64_t)r * C + c) = pack8(x);
+  }
+}
+
+__global__ __launch_bounds__(EB) void copy_rows_kernel(const grove_rows_params p) {
+  const int cpv = p.C >> 3;
+  const int64_t n = (int64_t)p.rows * cpv;
+  const bf16_raw* __restrict__ src = (const bf16_raw*)p.src;
+  bf16_raw* __restrict__ dst = (bf16_raw*)p.dst;
+  for (int64_t t = (int64_t)blockIdx.x * EB + threadIdx.x; t < n; t += (int64_t)gridDim.x * EB) {
+    const int r = (int)(t / cpv), c = (int)(t - (int64_t)r * cpv) * 8;
+    const int sr = p.idx_src ? p.idx_src[r] : r;
+    const int dr = p.idx_dst ? p.idx_dst[r] : r;
+    if (dr < 0) continue;
+    u32x4_t v = u32x4_t{0u, 0u, 0u, 0u};
+    if (sr >= 0) v = *(const u32x4_t*)(src + (int64_t)sr * p.ld_src + c);
+    bf16_raw* d = dst + (int64_t)dr * p.ld_dst + c;
+    if (p.accumulate) {
+      float x[8], z[8];
+      unpack8(v, x);
+      unpack8(*(const u32x4_t*)d, z);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] += z[e];
+      v = pack8(x);
+    }
+    *(u32x4_t*)d = v;
+  }
+}
+
+__global__ __launch_bounds__(EB) void scatter_add_kernel(const bf16_raw* __restrict__ src, float* __restrict__ dst, const int32_t* __restrict__ idx,
+                                                         int rows, int C, int ld_src, int ld_dst) {
+  const int cp2 = C >> 1;
+  const int64_t n = (int64_t)rows * cp2;
+  for (int64_t t = (int64_t)blockIdx.x * EB + threadIdx.x; t < n; t += (int64_t)gridDim.x * EB) {
+    const int r = (int)(t / cp2), c = (int)(t - (int64_t)r * cp2) * 2;
+    const int d = idx ? idx[r] : r;
+    if (d < 0) continue;
+    const unsigned u = *(const unsigned*)(src + (int64_t)r * ld_src + c);
+    atomicAdd(dst + (int64_t)d * ld_dst + c, bf_lo(u));
+    atomicAdd(dst + (int64_t)d * ld_dst + c + 1, bf_hi(u));
+  }
+}
+
+// column sums: block (64 column-pairs x 4 row lanes); each thread sums 2 adjacent columns over a
+// row slice, LDS-combine the 4 row lanes, one atomic per column per block.
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_raw* __restrict__ x, float* __restrict__ out, int rows, int C, int ld, int rows_per_block) {
+  __shared__ float red[4][128];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int c = (blockIdx.x * 64 + cx) * 2;
+  const int r0 = blockIdx.y * rows_per_block;
+  const int r1 = min(rows, r0 + rows_per_block);
+  float s0 = 0.f, s1 = 0.f;
+  if (c < C) {
+    for (int r = r0 + ry; r < r1; r += 4) {
+      const unsigned u = *(const unsigned*)(x + (int64_t)r * ld + c);
+      s0 += bf_lo(u);
+      s1 += bf_hi(u);
+    }
+  }
+  red[ry][cx * 2] = s0;
+  red[ry][cx * 2 + 1] = s1;
+  __syncthreads();
+  if (ry == 0 && c < C) {
+    s0 = red[0][cx * 2] + red[1][cx * 2] + red[2][cx * 2] + red[3][cx * 2];
+    s1 = red[0][cx * 2 + 1] + red[1][cx * 2 + 1] + red[2][cx * 2 + 1] + red[3][cx * 2 + 1];
+    atomicAdd(out + c, s0);
+    if (c + 1 < C) atomicAdd(out + c + 1, s1);
+  }
+}
+
+__global__ __launch_bounds__(EB) void cast_f2b_kernel(const float* __restrict__ x, bf16_raw* __restrict__ y, int64_t n) {
+  const int64_t nvec = n >> 2;
+  for (int64_t t = (int64_t)blockIdx.x * EB + threadIdx.x; t < nvec; t += (int64_t)gridDim.x * EB) {
+    const f32x4_t v = *(const f32x4_t*)(x + t * 4);
+    *(u32x2_t*)(y + t * 4) = u32x2_t{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const int64_t i = (n & ~(int64_t)3) + threadIdx.x;
+    y[i] = f2bf(x[i]);
+  }
+}
+__global__ __launch_bounds__(EB) void cast_b2f_kernel(const bf16_raw* __restrict__ x, float* __restrict__ y, int64_t n) {
+  const int64_t nvec = n >> 2;
+  for (int64_t t = (int64_t)blockIdx.x * EB + threadIdx.x; t < nvec; t += (int64_t)gridDim.x * EB) {
+    const u32x2_t u = *(const u32x2_t*)(x + t * 4);
+    *(f32x4_t*)(y + t * 4) = f32x4_t{bf_lo(u.x), bf_hi(u.x), bf_lo(u.y), bf_hi(u.y)};
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const int64_t i = (n & ~(int64_t)3) + threadIdx.x;
+    y[i] = bf2f(x[i]);
+  }
+}
+
+// Batched 2-D transpose through a 64x64 LDS tile (+1 pad): coalesced on both sides.
+__global__ __launch_bounds__(256) void transpose_kernel(const grove_transpose_params p) {
+  __shared__ bf16_raw tile[64][66];
+  const int bz = blockIdx.z;
+  const int b1 = bz / p.batch2, b2 = bz - b1 * p.batch2;
+  const bf16_raw* __restrict__ in = (const bf16_raw*)p.in + (int64_t)b1 * p.s_in1 + (int64_t)b2 * p.s_in2;
+  bf16_raw* __restrict__ out = (bf16_raw*)p.out + (int64_t)b1 * p.s_out1 + (int64_t)b2 * p.s_out2;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;  // input row / col origin
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < p.rows && c < p.cols) ? in[(int64_t)r * p.ld_in + c] : (bf16_raw)0;
+  }
+  __syncthreads();
+  // output row = input col, output col = input row; columns [rows, pad_to) are zero filled
+  for (int i = ty; i < 64; i += 4) {
+    const int oc = r0 + tx, orow = c0 + i;
+    if (orow < p.cols && oc < p.pad_to) out[(int64_t)orow * p.ld_out + oc] = tile[tx][i];
+  }
+}
+
+}  // namespace
+
+#define CHECK_VEC8(n, name) GROVE_CHECK((n) % 8 == 0, GROVE_E_ALIGN, "%s: size must be a multiple of 8 elements", name)
+
+extern "C" int grove_swiglu_fwd(const void* gu, void* y, int32_t rows, int32_t I, void* stream) {
+  GROVE_CHECK(rows > 0 && I > 0, GROVE_E_SHAPE, "swiglu_fwd: bad shape");
+  CHECK_VEC8(I, "swiglu_fwd");
+  hipLaunchKernelGGL(swiglu_fwd_kernel, grid_for((int64_t)rows * (I / 8)), dim3(EB), 0, (hipStream_t)stream, (const bf16_raw*)gu, (bf16_raw*)y, rows, I);
+  GROVE_LAUNCH_CHECK();
+  return GROVE_OK;
+}
+extern "C" int grove_swiglu_bwd(const void* gu, const void* dy, void* dgu, int32_t rows, int32_t I, void* stream) {
+  GROVE_CHECK(rows > 0 && I > 0, GROVE_E_SHAPE, "swiglu_bwd: bad shape");
+  CHECK_VEC8(I, "swiglu_bwd");
+  hipLaunchKernelGGL(swiglu_bwd_kernel, grid_for((int64_t)rows * (I / 8)), dim3(EB), 0, (hipStream_t)stream, (const bf16_raw*)gu, (const bf16_raw*)dy,
+                     (bf16_raw*)dgu, rows, I);
+  GROVE_LAUNCH_CHECK();
+  return GROVE_OK;
+}
+extern "C" int grove_act_bwd(const void* pre, const void* dy, void* dx, int64_t n, int32_t act, void* stream) {
+  GROVE_CHECK(n > 0, GROVE_E_SHAPE, "act_bwd: bad size");
+  CHECK_VEC8(n, "act_bwd");
+  hipLaunchKernelGGL(act_bwd_kernel, grid_for(n / 8), dim3(EB), 0, (hipStream_t)stream, (const bf16_raw*)pre, (const bf16_raw*)dy, (bf16_raw*)dx, n / 8, act);
+  GROVE_LAUNCH_CHECK();
+  return GROVE_OK;
+}
+extern "C" int grove_add_bf16(const void* a, const void* b, void* y, int64_t n, void* stream) {
+  GROVE_CHECK(n > 0, GROVE_E_SHAPE, "add: bad size");
+  CHECK_VEC8(n, "add");
+  hipLaunchKernelGGL(add_kernel, grid_for(n / 8), dim3(EB), 0, (hipStream_t)stream, (const bf16_raw*)a, (const bf16_raw*)b, (bf16_raw*)y, n / 8);
+  GROVE_LAUNCH_CHECK();
+  return GROVE_OK;
+}
+extern "C" int grove_add_bcast_rows(const void* a, const void* b, void* y, int32_t rows, int32_t C, int32_t period, void* stream) {
+  GROVE_CHECK(rows > 0 && C > 0 && period > 0, GROVE_E_SHAPE, "add_bcast_rows: bad shape");
+  CHECK_VEC8(C, "add_bcast_rows");
+  hipLaunchKernelGGL(add_bcast_kernel, grid_for((int64_t)rows * (C / 8)), dim3(EB), 0, (hipStream_t)stream, (const bf16_raw*)a, (const bf16_raw*)b,
+                     (bf16_raw*)y, rows, C, period);
+  GROVE_LAUNCH_CHECK();
+  return GROVE_OK;
+}
+extern "C" int grove_copy_rows(const grove_rows_params* p, void* stream) {
+  GROVE_CHECK(p && p->rows > 0 && p->C > 0, GROVE_E_SHAPE, "copy_rows: bad shape");
+  GROVE_CHECK(p->C % 8 == 0 && p->ld_src % 8 == 0 && p->ld_dst % 8 == 0, GROVE_E_ALIGN, "copy_rows: C/ld must be multiples of 8");
+  hipLaunchKernelGGL(copy_rows_kernel, grid_for((int64_t)p->rows * (p->C / 8)), dim3(EB), 0, (hipStream_t)stream, *p);
+  GROVE_LAUNCH_CHECK();
+  return GROVE_OK;
+}
+extern "C" int grove_scatter_add_f32(const void* src, float* dst, const int32_t* idx, int32_t rows, int32_t C, int32_t ld_src, int32_t ld_dst,
+                                     void* stream) {
+  GROVE_CHECK(rows > 0 && C > 0 && C % 2 == 0 && ld_src % 2 == 0, GROVE_E_SHAPE, "scatter_add: bad shape");
+  hipLaunchKernelGGL(scatter_add_kernel, grid_for((int64_t)rows * (C / 2)), dim3(EB), 0, (hipStream_t)stream, (const bf16_raw*)src, dst, idx, rows, C,
+                     ld_src, ld_dst);
+  GROVE_LAUNCH_CHECK();
+  return GROVE_OK;
+}
+extern "C" int grove_colsum_f32(const void* x, float* out, int32_t rows, int32_t C, int32_t ld, int32_t accumulate, void* stream) {
+  GROVE_CHECK(rows > 0 && C > 0 && ld % 2 == 0, GROVE_E_SHAPE, "colsum: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  if (!accumulate) {
+    hipError_t e = hipMemsetAsync(out, 0, (size_t)C * sizeof(float), s);
+    GROVE_CHECK(e == hipSuccess, GROVE_E_HIP, "colsum: memset failed");
+  }
+  const int rpb = 256;
+  dim3 grid((C + 127) / 128, (rows + rpb - 1) / rpb);
+  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, s, (const bf16_raw*)x, out, rows, C, ld, rpb);
+  GROVE_LAUNCH_CHECK();
+  return GROVE_OK;
+}
+extern "C" int grove_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream) {
+  GROVE_CHECK(n > 0, GROVE_E_SHAPE, "cast: bad size");
+  hipLaunchKernelGGL(cast_f2b_kernel, grid_for(n / 4 + 1), dim3(EB), 0, (hipStream_t)stream, x, (bf16_raw*)y, n);
+  GROVE_LAUNCH_CHECK();
+  return GROVE_OK;
+}
+extern "C" int grove_cast_bf16_to_f32(const void* x, float* y, int64_t n, void* stream) {
+  GROVE_CHECK(n > 0, GROVE_E_SHAPE, "cast: bad size");
+  hipLaunchKernelGGL(cast_b2f_kernel, grid_for(n / 4 + 1), dim3(EB), 0, (hipStream_t)stream, (const bf16_raw*)x, y, n);
+  GROVE_LAUNCH_CHECK();
+  return GROVE_OK;
+}
+extern "C" int grove_transpose_bf16(const grove_transpose_params* pp, void* stream) {
+  GROVE_CHECK(pp && pp->rows > 0 && pp->cols > 0, GROVE_E_SHAPE, "transpose: bad shape");
+  grove_transpose_params p = *pp;
+  if (p.batch1 <= 0) p.batch1 = 1;
+  if (p.batch2 <= 0) p.batch2 = 1;
+  if (p.pad_to < p.rows) p.pad_to = p.rows;
+  GROVE_CHECK(p.ld_out >= p.pad_to && p.ld_in >= p.cols, GROVE_E_SHAPE, "transpose: leading dims too small");
+  dim3 grid((p.cols + 63) / 64, (p.pad_to + 63) / 64, p.batch1 * p.batch2);
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+  GROVE_LAUNCH_CHECK();
+  return GROVE_OK;
+}

@@ -1,0 +1,361 @@
+// bf16 "NT" GEMM with fused epilogue and gather/scatter row maps for gfx950 (MI355X).
+//
+//   C[m, n] = epi( alpha * sum_k A[row_a(m, k), k] * B[n, k] )
+//
+// Tiling (wave64, v_mfma_f32_16x16x32_bf16):
+//   workgroup = 256 threads = 4 waves laid out 2 (M) x 2 (N); macro tile 128 x 128 x BK
+//   (BK = 64, or 32 when K % 64 != 0); each wave owns 64 x 64 = 4 x 4 MFMA tiles.
+//   A and B tiles are staged global -> LDS either with LDS-DMA (global_load_lds_dwordx4,
+//   lane-linear destination, swizzle applied to the per-lane SOURCE address) or through
+//   registers (global_load_dwordx4 + ds_write_b128); both produce the same XOR-swizzled image
+//   that ds_read_b128 fragment reads hit conflict-free (cdna_hip_programming.md T2, rule 21).
+//   LDS is double buffered: the next K tile is in flight while the current one feeds the MFMAs.
+//   The MFMA is issued with swapped operands (D = Btile . Atile^T) so that each lane ends up
+//   with 4 consecutive n for one m -> 8-byte (bf16) / 16-byte (f32) epilogue accesses.
+//   blockIdx is remapped XCD-aware (bijective, cdna_hip_programming.md §5) and grouped so that
+//   tiles sharing an A row panel / B column panel run on the same XCD L2.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128;
+constexpr int BN = 128;
+constexpr int NT = 256;
+
+__device__ __attribute__((aligned(16))) unsigned int g_zero_page[64];  // 256 B of zeros
+
+// physical 16-byte chunk of logical chunk c in LDS row r
+template <int BK>
+__device__ __forceinline__ int swz(int r, int c) {
+  if constexpr (BK == 64) {
+    return c ^ ((r >> 1) & 7);
+  } else {
+    // 64-byte rows: 4 rows share one 256-byte bank row; band permutation {0,2,3,1}
+    const int band = (r >> 2) & 3;
+    return c ^ ((0x1320 >> (4 * band)) & 3);
+  }
+}
+
+struct TileCoord {
+  int tm, tn;
+};
+
+__device__ __forceinline__ TileCoord map_block(int tiles_m, int tiles_n) {
+  const int nwg = gridDim.x;
+  const int orig = blockIdx.x;
+  const int xcd = orig & 7;
+  const int q = nwg >> 3, r = nwg & 7;
+  const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  constexpr int GM = 8;
+  const int per_band = GM * tiles_n;
+  const int band = wgid / per_band;
+  const int first_m = band * GM;
+  const int gm = min(tiles_m - first_m, GM);
+  const int in_band = wgid - band * per_band;
+  TileCoord t;
+  t.tm = first_m + in_band % gm;
+  t.tn = in_band / gm;
+  return t;
+}
+
+template <int BK, bool GLDS>
+__global__ __launch_bounds__(NT) void gemm_nt_kernel(const grove_gemm_params p, const int vec_ok) {
+  constexpr int CPR = BK / 8;                   // 16-byte chunks per LDS row
+  constexpr int ROW_BYTES = BK * 2;
+  constexpr int TILE_BYTES = BM * ROW_BYTES;    // A tile == B tile size (BM == BN)
+  constexpr int LPT = (BM * CPR) / NT;          // 16-byte loads per thread per operand tile
+  constexpr int ROWS_PER_PASS = NT / CPR;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // layout: [buf0: A | B][buf1: A | B]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const TileCoord tc = map_block(tiles_m, tiles_n);
+  const int m0 = tc.tm * BM, n0 = tc.tn * BN;
+
+  const int bz = blockIdx.y;
+  const int b1 = bz / p.batch2, b2 = bz - b1 * p.batch2;
+  const bf16_raw* __restrict__ Ab = (const bf16_raw*)p.A + (int64_t)b1 * p.sA1 + (int64_t)b2 * p.sA2;
+  const bf16_raw* __restrict__ Bb = (const bf16_raw*)p.B + (int64_t)b1 * p.sB1 + (int64_t)b2 * p.sB2;
+
+  // ---- staging geometry (fixed per thread) ----
+  const int st_c = tid % CPR;          // logical chunk within the row
+  const int st_r0 = tid / CPR;         // first row, + ROWS_PER_PASS per pass
+  int a_m[LPT];                        // clamped global m of each staged A row
+  const bf16_raw* b_ptr[LPT];
+  int lds_off[LPT];                    // byte offset inside a tile for the reg-staged write
+  // For LDS-DMA the destination is lane-linear: lane -> (row, physical chunk); the lane must
+  // therefore FETCH the logical chunk that belongs at that physical slot (swz is an involution).
+  int src_c[LPT];
+#pragma unroll
+  for (int i = 0; i < LPT; ++i) {
+    const int r = st_r0 + i * ROWS_PER_PASS;
+    a_m[i] = min(m0 + r, p.M - 1);
+    const int n = min(n0 + r, p.N - 1);
+    src_c[i] = GLDS ? swz<BK>(r, st_c) : st_c;
+    b_ptr[i] = Bb + (int64_t)n * p.ldb + src_c[i] * 8;
+    lds_off[i] = r * ROW_BYTES + swz<BK>(r, st_c) * 16;
+  }
+
+  const int taps = p.a_taps;
+  const int k_per_tap = p.K / taps;
+  const bf16_raw* a_ptr[LPT];
+  int cur_tap = -1;
+  auto resolve_a_rows = [&](int tap) {
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) {
+      int row = a_m[i];
+      if (p.a_idx) row = p.a_idx[(int64_t)tap * p.M + row];
+      a_ptr[i] = row < 0 ? nullptr : Ab + (int64_t)row * p.lda + src_c[i] * 8;
+    }
+  };
+
+  const int nk = p.K / BK;
+  u32x4_t ra[LPT], rb[LPT];
+
+  auto issue_loads = [&](int kt, char* buf) {
+    const int k0 = kt * BK;
+    const int tap = k0 / k_per_tap;
+    if (tap != cur_tap) {
+      resolve_a_rows(tap);
+      cur_tap = tap;
+    }
+    if constexpr (GLDS) {
+      char* la = buf + wave * (64 * 16);
+      char* lb = buf + TILE_BYTES + wave * (64 * 16);
+#pragma unroll
+      for (int i = 0; i < LPT; ++i) {
+        const bf16_raw* src = a_ptr[i] ? a_ptr[i] + k0 : (const bf16_raw*)g_zero_page;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(la + i * (NT * 16)), 16, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < LPT; ++i) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_ptr[i] + k0),
+                                         (__attribute__((address_space(3))) void*)(lb + i * (NT * 16)), 16, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < LPT; ++i) {
+        if (a_ptr[i]) ra[i] = *(const u32x4_t*)(a_ptr[i] + k0);
+        else ra[i] = u32x4_t{0u, 0u, 0u, 0u};
+      }
+#pragma unroll
+      for (int i = 0; i < LPT; ++i) rb[i] = *(const u32x4_t*)(b_ptr[i] + k0);
+    }
+  };
+  auto commit_loads = [&](char* buf) {
+    if constexpr (!GLDS) {
+#pragma unroll
+      for (int i = 0; i < LPT; ++i) *(u32x4_t*)(buf + lds_off[i]) = ra[i];
+#pragma unroll
+      for (int i = 0; i < LPT; ++i) *(u32x4_t*)(buf + TILE_BYTES + lds_off[i]) = rb[i];
+    }
+  };
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // fragment read offsets (bytes within a tile), per k-step
+  const int fr = lane & 15, fq = lane >> 4;
+  auto compute = [&](const char* buf) {
+    const char* As = buf;
+    const char* Bs = buf + TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      bf16x8_t af[4], bfg[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = wm * 64 + i * 16 + fr;
+        af[i] = *(const bf16x8_t*)(As + r * ROW_BYTES + swz<BK>(r, ks * 4 + fq) * 16);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = wn * 64 + j * 16 + fr;
+        bfg[j] = *(const bf16x8_t*)(Bs + r * ROW_BYTES + swz<BK>(r, ks * 4 + fq) * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfg[j], af[i], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  char* buf0 = smem;
+  char* buf1 = smem + 2 * TILE_BYTES;
+
+  // ---- prologue ----
+  issue_loads(0, buf0);
+  if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  commit_loads(buf0);
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    char* cur = (kt & 1) ? buf1 : buf0;
+    char* nxt = (kt & 1) ? buf0 : buf1;
+    const bool more = kt + 1 < nk;
+    if (more) issue_loads(kt + 1, nxt);
+    compute(cur);
+    if (more) commit_loads(nxt);
+    if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- epilogue ----
+  float scale = 1.f;
+  if (p.scale_ptr) {
+    scale = *p.scale_ptr;
+    if (p.scale_tanh) scale = tanhf(scale);
+  }
+  const bf16_raw* __restrict__ bias = (const bf16_raw*)p.bias;
+  const int64_t c_boff = (int64_t)b1 * p.sC1 + (int64_t)b2 * p.sC2;
+  const int64_t r_boff = (int64_t)b1 * p.sR1 + (int64_t)b2 * p.sR2;
+  const bool vec4 = vec_ok && ((p.ldc & 3) == 0) && (!p.residual || (p.ldr & 3) == 0);
+
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + fr;
+    if (m >= p.M) continue;
+    int crow = m;
+    if (p.c_idx) {
+      crow = p.c_idx[m];
+      if (crow < 0) continue;
+    }
+    int rrow = crow;
+    if (p.r_idx) rrow = p.r_idx[m];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + fq * 4;
+      if (n >= p.N) continue;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] * p.alpha;
+      const bool full = vec4 && (n + 3 < p.N);
+      if (bias) {
+        if (full) {
+          const u32x2_t bb = *(const u32x2_t*)(bias + n);
+          v[0] += bf_lo(bb.x); v[1] += bf_hi(bb.x); v[2] += bf_lo(bb.y); v[3] += bf_hi(bb.y);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (n + e < p.N) v[e] += bf2f(bias[n + e]);
+        }
+      }
+      if (p.aux) {
+        bf16_raw* aux = (bf16_raw*)p.aux + c_boff + (int64_t)crow * p.ldc + n;
+        if (full) {
+          *(u32x2_t*)aux = u32x2_t{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (n + e < p.N) aux[e] = f2bf(v[e]);
+        }
+      }
+      if (p.act != GROVE_ACT_NONE) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = act_apply(p.act, v[e]);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= scale;
+      if (p.residual && rrow >= 0) {
+        const bf16_raw* res = (const bf16_raw*)p.residual + r_boff + (int64_t)rrow * p.ldr + n;
+        if (full) {
+          const u32x2_t rr = *(const u32x2_t*)res;
+          v[0] += bf_lo(rr.x); v[1] += bf_hi(rr.x); v[2] += bf_lo(rr.y); v[3] += bf_hi(rr.y);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (n + e < p.N) v[e] += bf2f(res[e]);
+        }
+      }
+      if (p.c_dtype == GROVE_BF16) {
+        bf16_raw* c = (bf16_raw*)p.C + c_boff + (int64_t)crow * p.ldc + n;
+        if (full) {
+          *(u32x2_t*)c = u32x2_t{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (n + e < p.N) c[e] = f2bf(v[e]);
+        }
+      } else {
+        float* c = (float*)p.C + c_boff + (int64_t)crow * p.ldc + n;
+        if (full) {
+          f32x4_t o = f32x4_t{v[0], v[1], v[2], v[3]};
+          if (p.accumulate) {
+            const f32x4_t old = *(const f32x4_t*)c;
+            o += old;
+          }
+          *(f32x4_t*)c = o;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (n + e < p.N) c[e] = p.accumulate ? c[e] + v[e] : v[e];
+        }
+      }
+    }
+  }
+}
+
+template <int BK, bool GLDS>
+int launch(const grove_gemm_params& p, int vec_ok, hipStream_t s) {
+  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+  dim3 grid(tiles_m * tiles_n, p.batch1 * p.batch2, 1);
+  const size_t lds = 2 * 2 * BM * BK * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)gemm_nt_kernel<BK, GLDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_nt_kernel<BK, GLDS>), grid, dim3(NT), lds, s, p, vec_ok);
+  GROVE_LAUNCH_CHECK();
+  return GROVE_OK;
+}
+
+}  // namespace
+
+// staging variant: 1 = LDS-DMA (default), 0 = register staged (kept for A/B and as the
+// conservative path); switchable at run time for in-process A/B (cdna guide §5.4 rule 24).
+static int g_gemm_glds = 1;
+extern "C" int grove_gemm_set_staging(int use_lds_dma) {
+  g_gemm_glds = use_lds_dma ? 1 : 0;
+  return GROVE_OK;
+}
+
+extern "C" int grove_gemm_bf16(const grove_gemm_params* pp, void* stream) {
+  GROVE_CHECK(pp != nullptr, GROVE_E_SHAPE, "gemm: null params");
+  grove_gemm_params p = *pp;
+  if (p.batch1 <= 0) p.batch1 = 1;
+  if (p.batch2 <= 0) p.batch2 = 1;
+  if (p.a_taps <= 0) p.a_taps = 1;
+  GROVE_CHECK(p.M > 0 && p.N > 0 && p.K > 0, GROVE_E_SHAPE, "gemm: M,N,K must be > 0 (got %d,%d,%d)", p.M, p.N, p.K);
+  GROVE_CHECK(p.K % 32 == 0, GROVE_E_SHAPE, "gemm: K=%d must be a multiple of 32 (pad the operands)", p.K);
+  GROVE_CHECK(p.K % p.a_taps == 0 && (p.K / p.a_taps) % 32 == 0, GROVE_E_SHAPE,
+              "gemm: K/a_taps must be a multiple of 32 (K=%d taps=%d)", p.K, p.a_taps);
+  GROVE_CHECK(p.lda % 8 == 0 && p.ldb % 8 == 0, GROVE_E_ALIGN, "gemm: lda=%d ldb=%d must be multiples of 8", p.lda, p.ldb);
+  GROVE_CHECK(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.B & 15) == 0, GROVE_E_ALIGN, "gemm: A/B must be 16-byte aligned");
+  GROVE_CHECK((p.sA1 % 8) == 0 && (p.sA2 % 8) == 0 && (p.sB1 % 8) == 0 && (p.sB2 % 8) == 0, GROVE_E_ALIGN,
+              "gemm: A/B batch strides must be multiples of 8 elements");
+  GROVE_CHECK(p.c_dtype == GROVE_BF16 || p.c_dtype == GROVE_F32, GROVE_E_DTYPE, "gemm: bad c_dtype %d", p.c_dtype);
+  GROVE_CHECK(!(p.accumulate && p.c_dtype != GROVE_F32), GROVE_E_DTYPE, "gemm: accumulate needs f32 C");
+  GROVE_CHECK(!(p.aux && p.c_dtype != GROVE_BF16), GROVE_E_DTYPE, "gemm: aux needs bf16 C");
+  if (!p.residual) p.ldr = 0;
+  // vector epilogue needs 8-byte aligned rows for every epilogue operand; otherwise force the
+  // scalar path by making ldc look unaligned to the kernel's vec4 test (handled via flag below).
+  const bool c_al = p.c_dtype == GROVE_BF16 ? (((uintptr_t)p.C & 7) == 0) : (((uintptr_t)p.C & 15) == 0);
+  const int vec_ok = c_al && (p.sC1 % 4 == 0) && (p.sC2 % 4 == 0) &&
+                      (!p.aux || ((uintptr_t)p.aux & 7) == 0) &&
+                      (!p.residual || ((((uintptr_t)p.residual & 7) == 0) && p.sR1 % 4 == 0 && p.sR2 % 4 == 0)) &&
+                      (!p.bias || ((uintptr_t)p.bias & 7) == 0);
+  hipStream_t s = (hipStream_t)stream;
+  const bool bk64 = (p.K % 64 == 0) && ((p.K / p.a_taps) % 64 == 0);
+  if (g_gemm_glds) return bk64 ? launch<64, true>(p, vec_ok, s) : launch<32, true>(p, vec_ok, s);
+  return bk64 ? launch<64, false>(p, vec_ok, s) : launch<32, false>(p, vec_ok, s);
+}

@@ -1,0 +1,711 @@
+// Stem im2col, CLIP token pooling, cross entropy, the wavefront-reduced kernels of the SAM
+// two-way decoder / box heads, GROVE box losses and the fused AdamW step (gfx950).
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------- patch im2col
+// img [B, C, T, H, W] -> col [(b t py px), ld_col], k = (c, dy, dx)
+__global__ __launch_bounds__(256) void im2col_kernel(const bf16_raw* __restrict__ img, bf16_raw* __restrict__ col, int B, int C, int T, int H, int W, int P,
+                                                     int ld_col) {
+  const int nh = H / P, nw = W / P;
+  const int64_t rows = (int64_t)B * T * nh * nw;
+  const int K = C * P * P;
+  const int64_t n = rows * ld_col;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (int64_t)gridDim.x * 256) {
+    const int64_t row = t / ld_col;
+    const int k = (int)(t - row * ld_col);
+    bf16_raw v = 0;
+    if (k < K) {
+      const int c = k / (P * P), rem = k - c * P * P, dy = rem / P, dx = rem - dy * P;
+      const int px = (int)(row % nw);
+      const int64_t r2 = row / nw;
+      const int py = (int)(r2 % nh);
+      const int64_t bt = r2 / nh;
+      const int tt = (int)(bt % T), b = (int)(bt / T);
+      v = img[((((int64_t)b * C + c) * T + tt) * H + (py * P + dy)) * W + (px * P + dx)];
+    }
+    col[t] = v;
+  }
+}
+
+// ---------------------------------------------------------------- CLIP adaptive 3-D pool
+// x [G*8, 577, C] (CLS at token 0 skipped) -> y [G, 8*8*9, C]; 24 -> 8 rows (exact 3-bins),
+// 24 -> 9 cols (start = floor(i*24/9), end = ceil((i+1)*24/9)).
+__global__ __launch_bounds__(256) void clip_pool_kernel(const bf16_raw* __restrict__ x, bf16_raw* __restrict__ y, int G, int C) {
+  const int cpv = C >> 3;
+  const int64_t n = (int64_t)G * 576 * cpv;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (int64_t)gridDim.x * 256) {
+    const int c = (int)(t % cpv) * 8;
+    const int64_t tok = t / cpv;  // g*576 + (tt*8 + oh)*9 + ow
+    const int ow = (int)(tok % 9);
+    const int oh = (int)((tok / 9) % 8);
+    const int tt = (int)((tok / 72) % 8);
+    const int g = (int)(tok / 576);
+    const int w0 = (ow * 24) / 9, w1 = ((ow + 1) * 24 + 8) / 9;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bf16_raw* base = x + ((int64_t)(g * 8 + tt) * 577 + 1) * C + c;
+    for (int h = oh * 3; h < oh * 3 + 3; ++h)
+      for (int w = w0; w < w1; ++w) {
+        const u32x4_t u = *(const u32x4_t*)(base + (int64_t)(h * 24 + w) * C);
+        acc[0] += bf_lo(u.x); acc[1] += bf_hi(u.x); acc[2] += bf_lo(u.y); acc[3] += bf_hi(u.y);
+        acc[4] += bf_lo(u.z); acc[5] += bf_hi(u.z); acc[6] += bf_lo(u.w); acc[7] += bf_hi(u.w);
+      }
+    const float inv = 1.f / (float)(3 * (w1 - w0));
+    *(u32x4_t*)(y + tok * C + c) = u32x4_t{pack2bf(acc[0] * inv, acc[1] * inv), pack2bf(acc[2] * inv, acc[3] * inv),
+                                            pack2bf(acc[4] * inv, acc[5] * inv), pack2bf(acc[6] * inv, acc[7] * inv)};
+  }
+}
+
+// ---------------------------------------------------------------- cross entropy
+// one block per row; fp32 log-sum-exp; writes dlogits = (softmax - onehot) * grad_scale
+__global__ __launch_bounds__(256) void ce_kernel(const bf16_raw* __restrict__ logits, const int32_t* __restrict__ labels, float* __restrict__ loss_sum,
+                                                 bf16_raw* __restrict__ dlogits, const float* __restrict__ grad_scale, int V, int ld) {
+  __shared__ float scratch[4];
+  const int r = blockIdx.x;
+  const bf16_raw* x = logits + (int64_t)r * ld;
+  float mx = -INFINITY;
+  for (int j = threadIdx.x; j < V; j += 256) mx = fmaxf(mx, bf2f(x[j]));
+  mx = block_max<256>(mx, scratch);
+  float s = 0.f;
+  for (int j = threadIdx.x; j < V; j += 256) s += __expf(bf2f(x[j]) - mx);
+  s = block_sum<256>(s, scratch);
+  const int lab = labels[r];
+  const float lse = mx + __logf(s);
+  if (threadIdx.x == 0) atomicAdd(loss_sum, lse - bf2f(x[lab]));
+  if (dlogits) {
+    const float gs = grad_scale ? *grad_scale : 1.f;
+    const float inv = 1.f / s;
+    bf16_raw* d = dlogits + (int64_t)r * ld;
+    for (int j = threadIdx.x; j < V; j += 256) {
+      const float pj = __expf(bf2f(x[j]) - mx) * inv;
+      d[j] = f2bf((pj - (j == lab ? 1.f : 0.f)) * gs);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- small attention (decoder)
+// "few queries": one wave per (instance, head), loops the <= 8 queries; lanes own keys.
+constexpr int MAXD = 32;
+constexpr int MAXQ = 8;
+
+__global__ __launch_bounds__(64) void attn_fewq_fwd_kernel(const grove_small_attn_params p) {
+  const int inst = blockIdx.x / p.heads, h = blockIdx.x - inst * p.heads;
+  const int lane = threadIdx.x;
+  const int d = p.d;
+  const float scale = rsqrtf((float)d);
+  const bf16_raw* q = (const bf16_raw*)p.q + (int64_t)inst * p.Lq * p.ld_q + h * d;
+  const bf16_raw* k = (const bf16_raw*)p.k + (int64_t)inst * p.Lk * p.ld_k + h * d;
+  const bf16_raw* v = (const bf16_raw*)p.v + (int64_t)inst * p.Lk * p.ld_v + h * d;
+  bf16_raw* o = (bf16_raw*)p.o + (int64_t)inst * p.Lq * p.ld_o + h * d;
+  for (int qi = 0; qi < p.Lq; ++qi) {
+    float qv[MAXD];
+#pragma unroll
+    for (int c = 0; c < MAXD; ++c) qv[c] = c < d ? bf2f(q[(int64_t)qi * p.ld_q + c]) * scale : 0.f;
+    // pass 1: max
+    float mx = -INFINITY;
+    for (int j = lane; j < p.Lk; j += 64) {
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < MAXD; ++c)
+        if (c < d) s += qv[c] * bf2f(k[(int64_t)j * p.ld_k + c]);
+      mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    float l = 0.f;
+    float acc[MAXD];
+#pragma unroll
+    for (int c = 0; c < MAXD; ++c) acc[c] = 0.f;
+    for (int j = lane; j < p.Lk; j += 64) {
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < MAXD; ++c)
+        if (c < d) s += qv[c] * bf2f(k[(int64_t)j * p.ld_k + c]);
+      const float e = __expf(s - mx);
+      l += e;
+#pragma unroll
+      for (int c = 0; c < MAXD; ++c)
+        if (c < d) acc[c] += e * bf2f(v[(int64_t)j * p.ld_v + c]);
+    }
+    l = wave_sum(l);
+    const float inv = 1.f / l;
+#pragma unroll
+    for (int c = 0; c < MAXD; ++c) {
+      if (c < d) {
+        const float r = wave_sum(acc[c]) * inv;
+        if (lane == 0) o[(int64_t)qi * p.ld_o + c] = f2bf(r);
+      }
+    }
+  }
+}
+
+// backward, few queries: lanes own keys -> dk/dv need no atomics; dq wave-reduced.
+// dq, dk, dv are f32 [inst, L, heads*d] dense (ld = heads*d).
+__global__ __launch_bounds__(64) void attn_fewq_bwd_kernel(const grove_small_attn_params p) {
+  __shared__ float qs[MAXQ][MAXD], dos[MAXQ][MAXD], ms[MAXQ], ls[MAXQ], deltas[MAXQ];
+  const int inst = blockIdx.x / p.heads, h = blockIdx.x - inst * p.heads;
+  const int lane = threadIdx.x;
+  const int d = p.d;
+  const int HD = p.heads * d;
+  const float scale = rsqrtf((float)d);
+  const bf16_raw* q = (const bf16_raw*)p.q + (int64_t)inst * p.Lq * p.ld_q + h * d;
+  const bf16_raw* k = (const bf16_raw*)p.k + (int64_t)inst * p.Lk * p.ld_k + h * d;
+  const bf16_raw* v = (const bf16_raw*)p.v + (int64_t)inst * p.Lk * p.ld_v + h * d;
+  const bf16_raw* o = (const bf16_raw*)p.o + (int64_t)inst * p.Lq * p.ld_o + h * d;
+  const bf16_raw* dO = (const bf16_raw*)p.d_o + (int64_t)inst * p.Lq * p.ld_o + h * d;
+  for (int t = lane; t < p.Lq * d; t += 64) {
+    const int qi = t / d, c = t - qi * d;
+    qs[qi][c] = bf2f(q[(int64_t)qi * p.ld_q + c]);
+    dos[qi][c] = bf2f(dO[(int64_t)qi * p.ld_o + c]);
+  }
+  __syncthreads();
+  // softmax statistics + delta per query
+  for (int qi = 0; qi < p.Lq; ++qi) {
+    float mx = -INFINITY;
+    for (int j = lane; j < p.Lk; j += 64) {
+      float s = 0.f;
+      for (int c = 0; c < d; ++c) s += qs[qi][c] * bf2f(k[(int64_t)j * p.ld_k + c]);
+      mx = fmaxf(mx, s * scale);
+    }
+    mx = wave_max(mx);
+    float l = 0.f;
+    for (int j = lane; j < p.Lk; j += 64) {
+      float s = 0.f;
+      for (int c = 0; c < d; ++c) s += qs[qi][c] * bf2f(k[(int64_t)j * p.ld_k + c]);
+      l += __expf(s * scale - mx);
+    }
+    l = wave_sum(l);
+    float dl = 0.f;
+    for (int c = lane; c < d; c += 64) dl += dos[qi][c] * bf2f(o[(int64_t)qi * p.ld_o + c]);
+    dl = wave_sum(dl);
+    if (lane == 0) { ms[qi] = mx; ls[qi] = l; deltas[qi] = dl; }
+  }
+  __syncthreads();
+  float dq[MAXQ][MAXD];
+#pragma unroll
+  for (int qi = 0; qi < MAXQ; ++qi)
+#pragma unroll
+    for (int c = 0; c < MAXD; ++c) dq[qi][c] = 0.f;
+  float* dk = (float*)p.dk + (int64_t)inst * p.Lk * HD + h * d;
+  float* dv = (float*)p.dv + (int64_t)inst * p.Lk * HD + h * d;
+  for (int j = lane; j < p.Lk; j += 64) {
+    float kv[MAXD], vv[MAXD], dkk[MAXD], dvv[MAXD];
+#pragma unroll
+    for (int c = 0; c < MAXD; ++c) {
+      kv[c] = c < d ? bf2f(k[(int64_t)j * p.ld_k + c]) : 0.f;
+      vv[c] = c < d ? bf2f(v[(int64_t)j * p.ld_v + c]) : 0.f;
+      dkk[c] = 0.f;
+      dvv[c] = 0.f;
+    }
+#pragma unroll
+    for (int qi = 0; qi < MAXQ; ++qi) {
+      if (qi < p.Lq) {
+        float s = 0.f, dp = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXD; ++c) {
+          if (c < d) {
+            s += qs[qi][c] * kv[c];
+            dp += dos[qi][c] * vv[c];
+          }
+        }
+        const float pr = __expf(s * scale - ms[qi]) / ls[qi];
+        const float ds = pr * (dp - deltas[qi]) * scale;
+#pragma unroll
+        for (int c = 0; c < MAXD; ++c) {
+          if (c < d) {
+            dkk[c] += ds * qs[qi][c];
+            dvv[c] += pr * dos[qi][c];
+            dq[qi][c] += ds * kv[c];
+          }
+        }
+      }
+    }
+    for (int c = 0; c < d; ++c) {
+      dk[(int64_t)j * HD + c] = dkk[c];
+      dv[(int64_t)j * HD + c] = dvv[c];
+    }
+  }
+  float* dqo = (float*)p.dq + (int64_t)inst * p.Lq * HD + h * d;
+#pragma unroll
+  for (int qi = 0; qi < MAXQ; ++qi) {
+    if (qi < p.Lq) {
+#pragma unroll
+      for (int c = 0; c < MAXD; ++c) {
+        if (c < d) {
+          const float r = wave_sum(dq[qi][c]);
+          if (lane == 0) dqo[(int64_t)qi * HD + c] = r;
+        }
+      }
+    }
+  }
+}
+
+// "few keys" (Lk <= 8): thread per (instance, head, query); a wave = 64 consecutive queries of
+// one (instance, head) so that k/v loads are wave-uniform broadcasts.
+constexpr int MAXK = 8;
+__global__ __launch_bounds__(64) void attn_fewk_fwd_kernel(const grove_small_attn_params p) {
+  const int qblocks = (p.Lq + 63) / 64;
+  const int qb = blockIdx.x % qblocks;
+  const int ih = blockIdx.x / qblocks;
+  const int inst = ih / p.heads, h = ih - inst * p.heads;
+  const int qi = qb * 64 + threadIdx.x;
+  if (qi >= p.Lq) return;
+  const int d = p.d;
+  const float scale = rsqrtf((float)d);
+  const bf16_raw* q = (const bf16_raw*)p.q + ((int64_t)inst * p.Lq + qi) * p.ld_q + h * d;
+  const bf16_raw* k = (const bf16_raw*)p.k + (int64_t)inst * p.Lk * p.ld_k + h * d;
+  const bf16_raw* v = (const bf16_raw*)p.v + (int64_t)inst * p.Lk * p.ld_v + h * d;
+  float qv[MAXD];
+#pragma unroll
+  for (int c = 0; c < MAXD; ++c) qv[c] = c < d ? bf2f(q[c]) * scale : 0.f;
+  float s[MAXK];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < MAXK; ++j) {
+    s[j] = -INFINITY;
+    if (j < p.Lk) {
+      float a = 0.f;
+#pragma unroll
+      for (int c = 0; c < MAXD; ++c)
+        if (c < d) a += qv[c] * bf2f(k[(int64_t)j * p.ld_k + c]);
+      s[j] = a;
+      mx = fmaxf(mx, a);
+    }
+  }
+  float l = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXK; ++j) {
+    s[j] = j < p.Lk ? __expf(s[j] - mx) : 0.f;
+    l += s[j];
+  }
+  const float inv = 1.f / l;
+  bf16_raw* o = (bf16_raw*)p.o + ((int64_t)inst * p.Lq + qi) * p.ld_o + h * d;
+#pragma unroll
+  for (int c = 0; c < MAXD; ++c) {
+    if (c < d) {
+      float a = 0.f;
+#pragma unroll
+      for (int j = 0; j < MAXK; ++j)
+        if (j < p.Lk) a += s[j] * bf2f(v[(int64_t)j * p.ld_v + c]);
+      o[c] = f2bf(a * inv);
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void attn_fewk_bwd_kernel(const grove_small_attn_params p) {
+  const int qblocks = (p.Lq + 63) / 64;
+  const int qb = blockIdx.x % qblocks;
+  const int ih = blockIdx.x / qblocks;
+  const int inst = ih / p.heads, h = ih - inst * p.heads;
+  const int qi = qb * 64 + threadIdx.x;
+  const bool active = qi < p.Lq;
+  const int qc = active ? qi : p.Lq - 1;
+  const int d = p.d;
+  const int HD = p.heads * d;
+  const float scale = rsqrtf((float)d);
+  const bf16_raw* q = (const bf16_raw*)p.q + ((int64_t)inst * p.Lq + qc) * p.ld_q + h * d;
+  const bf16_raw* dO = (const bf16_raw*)p.d_o + ((int64_t)inst * p.Lq + qc) * p.ld_o + h * d;
+  const bf16_raw* k = (const bf16_raw*)p.k + (int64_t)inst * p.Lk * p.ld_k + h * d;
+  const bf16_raw* v = (const bf16_raw*)p.v + (int64_t)inst * p.Lk * p.ld_v + h * d;
+  float qv[MAXD], dov[MAXD];
+#pragma unroll
+  for (int c = 0; c < MAXD; ++c) {
+    qv[c] = c < d ? bf2f(q[c]) : 0.f;
+    dov[c] = (c < d && active) ? bf2f(dO[c]) : 0.f;
+  }
+  float s[MAXK], dp[MAXK];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < MAXK; ++j) {
+    s[j] = -INFINITY;
+    dp[j] = 0.f;
+    if (j < p.Lk) {
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int c = 0; c < MAXD; ++c) {
+        if (c < d) {
+          a += qv[c] * bf2f(k[(int64_t)j * p.ld_k + c]);
+          b += dov[c] * bf2f(v[(int64_t)j * p.ld_v + c]);
+        }
+      }
+      s[j] = a * scale;
+      dp[j] = b;
+      mx = fmaxf(mx, s[j]);
+    }
+  }
+  float l = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXK; ++j) {
+    s[j] = j < p.Lk ? __expf(s[j] - mx) : 0.f;
+    l += s[j];
+  }
+  float delta = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXK; ++j) {
+    s[j] /= l;
+    delta += s[j] * dp[j];
+  }
+  float dqv[MAXD];
+#pragma unroll
+  for (int c = 0; c < MAXD; ++c) dqv[c] = 0.f;
+  float* dk = (float*)p.dk + (int64_t)inst * p.Lk * HD + h * d;
+  float* dv = (float*)p.dv + (int64_t)inst * p.Lk * HD + h * d;
+#pragma unroll
+  for (int j = 0; j < MAXK; ++j) {
+    if (j < p.Lk) {
+      const float ds = active ? s[j] * (dp[j] - delta) * scale : 0.f;
+      const float pj = active ? s[j] : 0.f;
+#pragma unroll
+      for (int c = 0; c < MAXD; ++c) {
+        if (c < d) {
+          dqv[c] += ds * bf2f(k[(int64_t)j * p.ld_k + c]);
+          const float a = wave_sum(ds * qv[c]);
+          const float b = wave_sum(pj * dov[c]);
+          if (threadIdx.x == 0) {
+            atomicAdd(&dk[(int64_t)j * HD + c], a);
+            atomicAdd(&dv[(int64_t)j * HD + c], b);
+          }
+        }
+      }
+    }
+  }
+  if (active) {
+    float* dqo = (float*)p.dq + ((int64_t)inst * p.Lq + qi) * HD + h * d;
+    for (int c = 0; c < d; ++c) dqo[c] = dqv[c];
+  }
+}
+
+// ---------------------------------------------------------------- box / objectness heads (fp32)
+// one block of 256 threads (4 waves) per instance; each output neuron is a wave-reduced dot.
+__global__ __launch_bounds__(256) void box_head_fwd_kernel(const grove_box_head_params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* xs = (float*)smem_raw;  // [D]
+  float* hs = xs + p.D;          // [D]
+  const int n = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int D = p.D;
+  for (int c = threadIdx.x; c < D; c += 256) xs[c] = p.x[(int64_t)n * D + c];
+  __syncthreads();
+  const bf16_raw* W1 = (const bf16_raw*)p.W1;
+  const bf16_raw* b1 = (const bf16_raw*)p.b1;
+  for (int j = wave; j < D; j += 4) {
+    float a = 0.f;
+    for (int c = lane; c < D; c += 64) a += bf2f(W1[(int64_t)j * D + c]) * xs[c];
+    a = wave_sum(a) + bf2f(b1[j]);
+    a = fmaxf(a, 0.f);
+    if (lane == 0) {
+      hs[j] = a;
+      if (p.hidden) p.hidden[(int64_t)n * D + j] = a;
+    }
+  }
+  __syncthreads();
+  const bf16_raw* W2 = (const bf16_raw*)p.W2;
+  const bf16_raw* b2 = (const bf16_raw*)p.b2;
+  {
+    const int j = wave;  // 4 box outputs, one per wave
+    float a = 0.f;
+    for (int c = lane; c < D; c += 64) a += bf2f(W2[(int64_t)j * D + c]) * hs[c];
+    a = wave_sum(a) + bf2f(b2[j]);
+    if (lane == 0) p.box[(int64_t)n * 4 + j] = 1.f / (1.f + __expf(-a));
+  }
+  if (wave == 0 && p.obj) {
+    const bf16_raw* Wo = (const bf16_raw*)p.Wo;
+    float a = 0.f;
+    for (int c = lane; c < D; c += 64) a += bf2f(Wo[c]) * xs[c];
+    a = wave_sum(a) + bf2f(((const bf16_raw*)p.bo)[0]);
+    if (lane == 0) p.obj[n] = a;
+  }
+}
+
+
+// backward of the heads: one block per instance; weight gradients accumulated with f32 atomics.
+__global__ __launch_bounds__(256) void box_head_bwd_kernel(const grove_box_head_bwd_params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* xs = (float*)smem_raw;  // [D]
+  float* hs = xs + p.D;          // [D] hidden (post-relu)
+  float* dh = hs + p.D;          // [D]
+  __shared__ float dz2[4];
+  const int n = blockIdx.x;
+  const int D = p.D;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int c = threadIdx.x; c < D; c += 256) {
+    xs[c] = p.x[(int64_t)n * D + c];
+    hs[c] = p.hidden[(int64_t)n * D + c];
+  }
+  if (threadIdx.x < 4) {
+    const float b = p.box[(int64_t)n * 4 + threadIdx.x];
+    dz2[threadIdx.x] = p.dbox[(int64_t)n * 4 + threadIdx.x] * b * (1.f - b);
+  }
+  __syncthreads();
+  const float dobj = p.dobj ? p.dobj[n] : 0.f;
+  const bf16_raw* W1 = (const bf16_raw*)p.W1;
+  const bf16_raw* W2 = (const bf16_raw*)p.W2;
+  const bf16_raw* Wo = (const bf16_raw*)p.Wo;
+  // dW2, db2, dh
+  for (int c = threadIdx.x; c < D; c += 256) {
+    float a = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      a += bf2f(W2[(int64_t)j * D + c]) * dz2[j];
+      atomicAdd(&p.dW2[(int64_t)j * D + c], dz2[j] * hs[c]);
+    }
+    a = hs[c] > 0.f ? a : 0.f;
+    dh[c] = a;
+    atomicAdd(&p.db1[c], a);
+    if (p.dWo) atomicAdd(&p.dWo[c], dobj * xs[c]);
+  }
+  if (threadIdx.x < 4) atomicAdd(&p.db2[threadIdx.x], dz2[threadIdx.x]);
+  if (threadIdx.x == 0 && p.dbo) atomicAdd(p.dbo, dobj);
+  __syncthreads();
+  // dW1[j, c] += dh[j] * x[c];   dx[c] = sum_j W1[j, c] * dh[j] + Wo[c] * dobj
+  for (int j = wave; j < D; j += 4) {
+    const float g = dh[j];
+    if (g != 0.f)
+      for (int c = lane; c < D; c += 64) atomicAdd(&p.dW1[(int64_t)j * D + c], g * xs[c]);
+  }
+  for (int c = threadIdx.x; c < D; c += 256) {
+    float a = p.dobj ? bf2f(Wo[c]) * dobj : 0.f;
+    for (int j = 0; j < D; ++j) a += bf2f(W1[(int64_t)j * D + c]) * dh[j];
+    p.dx[(int64_t)n * D + c] = a;
+  }
+}
+
+// ---------------------------------------------------------------- box losses (forward-mode AD)
+struct Dual {
+  float v, d[4];
+};
+__device__ __forceinline__ Dual dconst(float v) { return Dual{v, {0.f, 0.f, 0.f, 0.f}}; }
+__device__ __forceinline__ Dual dvar(float v, int i) {
+  Dual r = dconst(v);
+  r.d[i] = 1.f;
+  return r;
+}
+__device__ __forceinline__ Dual operator+(Dual a, Dual b) {
+  Dual r; r.v = a.v + b.v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r.d[i] = a.d[i] + b.d[i];
+  return r;
+}
+__device__ __forceinline__ Dual operator-(Dual a, Dual b) {
+  Dual r; r.v = a.v - b.v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r.d[i] = a.d[i] - b.d[i];
+  return r;
+}
+__device__ __forceinline__ Dual operator*(Dual a, Dual b) {
+  Dual r; r.v = a.v * b.v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i];
+  return r;
+}
+__device__ __forceinline__ Dual operator/(Dual a, Dual b) {
+  Dual r; r.v = a.v / b.v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) / b.v;
+  return r;
+}
+__device__ __forceinline__ Dual dmax(Dual a, Dual b) { return a.v >= b.v ? a : b; }  // torch.max: grad to first on ties
+__device__ __forceinline__ Dual dmin(Dual a, Dual b) { return a.v <= b.v ? a : b; }
+__device__ __forceinline__ Dual dscale(Dual a, float s) {
+  Dual r; r.v = a.v * s;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r.d[i] = a.d[i] * s;
+  return r;
+}
+
+__global__ __launch_bounds__(256) void box_losses_kernel(const float* __restrict__ pb, const float* __restrict__ ol, const float* __restrict__ gb,
+                                                         const float* __restrict__ vis, float* __restrict__ sums, float* __restrict__ dbox,
+                                                         float* __restrict__ dobj, int N, float wb, float wo) {
+  __shared__ float scratch[4];
+  float giou = 0.f, l1 = 0.f, bce = 0.f;
+  const float eps = 1e-7f;
+  for (int n = blockIdx.x * 256 + threadIdx.x; n < N; n += gridDim.x * 256) {
+    float g4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (vis[n] > 0.5f) {
+      const Dual cx = dvar(pb[n * 4 + 0], 0), cy = dvar(pb[n * 4 + 1], 1), w = dvar(pb[n * 4 + 2], 2), h = dvar(pb[n * 4 + 3], 3);
+      const Dual x1 = cx - dscale(w, 0.5f), y1 = cy - dscale(h, 0.5f), x2 = cx + dscale(w, 0.5f), y2 = cy + dscale(h, 0.5f);
+      const float gcx = gb[n * 4 + 0], gcy = gb[n * 4 + 1], gw = gb[n * 4 + 2], gh = gb[n * 4 + 3];
+      const Dual x1g = dconst(gcx - gw / 2), y1g = dconst(gcy - gh / 2), x2g = dconst(gcx + gw / 2), y2g = dconst(gcy + gh / 2);
+      const Dual xk1 = dmax(x1, x1g), yk1 = dmax(y1, y1g), xk2 = dmin(x2, x2g), yk2 = dmin(y2, y2g);
+      Dual inter = dconst(0.f);
+      if (yk2.v > yk1.v && xk2.v > xk1.v) inter = (xk2 - xk1) * (yk2 - yk1);
+      const Dual uni = (x2 - x1) * (y2 - y1) + (x2g - x1g) * (y2g - y1g) - inter;
+      const Dual iou = inter / (uni + dconst(eps));
+      const Dual xc1 = dmin(x1, x1g), yc1 = dmin(y1, y1g), xc2 = dmax(x2, x2g), yc2 = dmax(y2, y2g);
+      const Dual areac = (xc2 - xc1) * (yc2 - yc1);
+      const Dual miou = iou - (areac - uni) / (areac + dconst(eps));
+      giou += 1.f - miou.v;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) g4[i] = -miou.d[i];
+      const float pv[4] = {cx.v, cy.v, w.v, h.v};
+      const float gv[4] = {gcx, gcy, gw, gh};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float df = pv[i] - gv[i];
+        l1 += fabsf(df);
+        g4[i] += df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
+      }
+    }
+    if (dbox) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dbox[n * 4 + i] = g4[i] * wb;
+    }
+    if (ol) {
+      const float z = ol[n], y = vis[n];
+      // BCE with logits: max(z,0) - z*y + log(1 + exp(-|z|))
+      bce += fmaxf(z, 0.f) - z * y + log1pf(__expf(-fabsf(z)));
+      if (dobj) dobj[n] = (1.f / (1.f + __expf(-z)) - y) * wo;
+    }
+  }
+  giou = block_sum<256>(giou, scratch);
+  l1 = block_sum<256>(l1, scratch);
+  bce = block_sum<256>(bce, scratch);
+  if (threadIdx.x == 0) {
+    atomicAdd(sums + 0, giou);
+    atomicAdd(sums + 1, l1);
+    atomicAdd(sums + 2, bce);
+  }
+}
+
+// ---------------------------------------------------------------- AdamW
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, bf16_raw* __restrict__ model, const float* __restrict__ grad,
+                                                    float* __restrict__ m, float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
+                                                    float wd, float gs, float bc1, float bc2) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float g = grad[i] * gs;
+    float w = master[i];
+    const float mi = b1 * m[i] + (1.f - b1) * g;
+    const float vi = b2 * v[i] + (1.f - b2) * g * g;
+    m[i] = mi;
+    v[i] = vi;
+    w -= lr * wd * w;  // decoupled weight decay (torch.optim.AdamW / DeepSpeed FusedAdam adam_w_mode)
+    w -= lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
+    master[i] = w;
+    if (model) model[i] = f2bf(w);
+  }
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n) {
+  __shared__ float scratch[4];
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += x[i] * x[i];
+  s = block_sum<256>(s, scratch);
+  if (threadIdx.x == 0) atomicAdd(out, s);
+}
+
+inline dim3 cap_grid(int64_t n) {
+  int64_t g = (n + 255) / 256;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  return dim3((unsigned)g);
+}
+
+}  // namespace
+
+extern "C" int grove_im2col_patch(const void* img, void* col, int32_t B, int32_t C, int32_t T, int32_t H, int32_t W, int32_t P, int32_t ld_col,
+                                  void* stream) {
+  GROVE_CHECK(B > 0 && C > 0 && T > 0 && H % P == 0 && W % P == 0 && ld_col >= C * P * P, GROVE_E_SHAPE, "im2col_patch: bad shape");
+  const int64_t n = (int64_t)B * T * (H / P) * (W / P) * ld_col;
+  hipLaunchKernelGGL(im2col_kernel, cap_grid(n), dim3(256), 0, (hipStream_t)stream, (const bf16_raw*)img, (bf16_raw*)col, B, C, T, H, W, P, ld_col);
+  GROVE_LAUNCH_CHECK();
+  return GROVE_OK;
+}
+
+extern "C" int grove_clip_pool(const void* x, void* y, int32_t G, int32_t C, void* stream) {
+  GROVE_CHECK(G > 0 && C > 0 && C % 8 == 0, GROVE_E_SHAPE, "clip_pool: bad shape");
+  hipLaunchKernelGGL(clip_pool_kernel, cap_grid((int64_t)G * 576 * (C / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_raw*)x, (bf16_raw*)y, G, C);
+  GROVE_LAUNCH_CHECK();
+  return GROVE_OK;
+}
+
+extern "C" int grove_cross_entropy(const void* logits, const int32_t* labels, float* loss_sum, void* dlogits, const float* grad_scale, int32_t R,
+                                   int32_t V, int32_t ld, void* stream) {
+  GROVE_CHECK(R > 0 && V > 0 && ld >= V, GROVE_E_SHAPE, "cross_entropy: bad shape");
+  hipLaunchKernelGGL(ce_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, (const bf16_raw*)logits, labels, loss_sum, (bf16_raw*)dlogits, grad_scale, V,
+                     ld);
+  GROVE_LAUNCH_CHECK();
+  return GROVE_OK;
+}
+
+static int small_attn_check(const grove_small_attn_params* p, const char* name) {
+  GROVE_CHECK(p && p->inst > 0 && p->heads > 0 && p->Lq > 0 && p->Lk > 0, GROVE_E_SHAPE, "%s: bad shape", name);
+  GROVE_CHECK(p->d > 0 && p->d <= MAXD, GROVE_E_SHAPE, "%s: head dim %d > %d", name, p->d, MAXD);
+  GROVE_CHECK(p->Lk <= MAXK || p->Lq <= MAXQ, GROVE_E_SHAPE, "%s: needs Lq <= %d or Lk <= %d", name, MAXQ, MAXK);
+  return GROVE_OK;
+}
+
+extern "C" int grove_small_attn_fwd(const grove_small_attn_params* p, void* stream) {
+  int rc = small_attn_check(p, "small_attn_fwd");
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  if (p->Lk <= MAXK) {
+    const int qblocks = (p->Lq + 63) / 64;
+    hipLaunchKernelGGL(attn_fewk_fwd_kernel, dim3(p->inst * p->heads * qblocks), dim3(64), 0, s, *p);
+  } else {
+    hipLaunchKernelGGL(attn_fewq_fwd_kernel, dim3(p->inst * p->heads), dim3(64), 0, s, *p);
+  }
+  GROVE_LAUNCH_CHECK();
+  return GROVE_OK;
+}
+
+extern "C" int grove_small_attn_bwd(const grove_small_attn_params* p, void* stream) {
+  int rc = small_attn_check(p, "small_attn_bwd");
+  if (rc) return rc;
+  GROVE_CHECK(p->d_o && p->dq && p->dk && p->dv && p->o, GROVE_E_SHAPE, "small_attn_bwd: d_o/dq/dk/dv/o required");
+  hipStream_t s = (hipStream_t)stream;
+  if (p->Lk <= MAXK) {
+    // dk/dv accumulate with atomics -> zero them first
+    const size_t bytes = (size_t)p->inst * p->Lk * p->heads * p->d * sizeof(float);
+    hipError_t e = hipMemsetAsync(p->dk, 0, bytes, s);
+    if (e == hipSuccess) e = hipMemsetAsync(p->dv, 0, bytes, s);
+    GROVE_CHECK(e == hipSuccess, GROVE_E_HIP, "small_attn_bwd: memset failed");
+    const int qblocks = (p->Lq + 63) / 64;
+    hipLaunchKernelGGL(attn_fewk_bwd_kernel, dim3(p->inst * p->heads * qblocks), dim3(64), 0, s, *p);
+  } else {
+    hipLaunchKernelGGL(attn_fewq_bwd_kernel, dim3(p->inst * p->heads), dim3(64), 0, s, *p);
+  }
+  GROVE_LAUNCH_CHECK();
+  return GROVE_OK;
+}
+
+extern "C" int grove_box_head_fwd(const grove_box_head_params* p, void* stream) {
+  GROVE_CHECK(p && p->N > 0 && p->D > 0 && p->D <= 4096, GROVE_E_SHAPE, "box_head_fwd: bad shape");
+  hipLaunchKernelGGL(box_head_fwd_kernel, dim3(p->N), dim3(256), (size_t)2 * p->D * sizeof(float), (hipStream_t)stream, *p);
+  GROVE_LAUNCH_CHECK();
+  return GROVE_OK;
+}
+
+
+extern "C" int grove_box_head_bwd(const grove_box_head_bwd_params* p, void* stream) {
+  GROVE_CHECK(p && p->N > 0 && p->D > 0 && p->D <= 4096, GROVE_E_SHAPE, "box_head_bwd: bad shape");
+  GROVE_CHECK(p->dW1 && p->db1 && p->dW2 && p->db2 && p->dx && p->hidden && p->box && p->dbox, GROVE_E_SHAPE, "box_head_bwd: missing buffers");
+  hipLaunchKernelGGL(box_head_bwd_kernel, dim3(p->N), dim3(256), (size_t)3 * p->D * sizeof(float), (hipStream_t)stream, *p);
+  GROVE_LAUNCH_CHECK();
+  return GROVE_OK;
+}
+
+extern "C" int grove_box_losses(const float* pred_box, const float* obj_logit, const float* gt_box, const float* visible, float* sums, float* dbox,
+                                float* dobj, int32_t N, float w_box_over_ngt, float w_obj_over_n, void* stream) {
+  GROVE_CHECK(N > 0 && pred_box && gt_box && visible && sums, GROVE_E_SHAPE, "box_losses: bad args");
+  hipLaunchKernelGGL(box_losses_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, pred_box, obj_logit, gt_box, visible, sums, dbox, dobj,
+                     N, w_box_over_ngt, w_obj_over_n);
+  GROVE_LAUNCH_CHECK();
+  return GROVE_OK;
+}
+
+extern "C" int grove_adamw_step(float* master, void* model_bf16, const float* grad, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                                float eps, float weight_decay, float grad_scale, int32_t step, void* stream) {
+  GROVE_CHECK(n > 0 && step >= 1, GROVE_E_SHAPE, "adamw: bad args");
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adamw_kernel, cap_grid(n), dim3(256), 0, (hipStream_t)stream, master, (bf16_raw*)model_bf16, grad, m, v, n, lr, beta1, beta2, eps,
+                     weight_decay, grad_scale, bc1, bc2);
+  GROVE_LAUNCH_CHECK();
+  return GROVE_OK;
+}
+
+extern "C" int grove_sumsq_f32(const float* x, float* out, int64_t n, void* stream) {
+  GROVE_CHECK(n > 0, GROVE_E_SHAPE, "sumsq: bad size");
+  hipLaunchKernelGGL(sumsq_kernel, cap_grid(n), dim3(256), 0, (hipStream_t)stream, x, out, n);
+  GROVE_LAUNCH_CHECK();
+  return GROVE_OK;
+}

@@ -1,0 +1,380 @@
+"""Torch-tensor front end of the C-ABI in include/grove_hip.h.
+
+PyTorch is plumbing here: it owns device memory and the stream; all arithmetic is done by the
+hand-written gfx950 kernels in grove_amd/csrc. Nothing in this module falls back to torch ops.
+Tensors are bf16 unless stated; every function launches on torch's current stream.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_GELU, ACT_NONE, ACT_QUICKGELU, ACT_RELU, ACT_SIGMOID, ACT_SILU, BF16, F32)  # noqa: F401
+
+bf16 = torch.bfloat16
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _chk_dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("grove_amd ops need device tensors (no CPU fallback exists)")
+
+
+def pad_to(n, m):
+    return (n + m - 1) // m * m
+
+
+def gemm_raw(A, B, Cout, M, N, K, lda, ldb, ldc, *, bias=None, residual=None, ldr=0, aux=None, scale_ptr=None,
+             scale_tanh=False, a_idx=None, a_taps=1, c_idx=None, r_idx=None, batch=(1, 1), sA=(0, 0), sB=(0, 0),
+             sC=(0, 0), sR=(0, 0), act=ACT_NONE, accumulate=False, alpha=1.0):
+    """Direct call of grove_gemm_bf16; A/B/Cout are tensors whose storage the pointers refer to."""
+    _chk_dev(A, B, Cout)
+    p = _lib.GemmParams()
+    p.A, p.B, p.C = _p(A), _p(B), _p(Cout)
+    p.bias, p.residual, p.aux = _p(bias), _p(residual), _p(aux)
+    p.scale_ptr, p.a_idx, p.c_idx, p.r_idx = _p(scale_ptr), _p(a_idx), _p(c_idx), _p(r_idx)
+    p.sA1, p.sA2, p.sB1, p.sB2 = sA[0], sA[1], sB[0], sB[1]
+    p.sC1, p.sC2, p.sR1, p.sR2 = sC[0], sC[1], sR[0], sR[1]
+    p.M, p.N, p.K = M, N, K
+    p.lda, p.ldb, p.ldc, p.ldr = lda, ldb, ldc, ldr
+    p.batch1, p.batch2 = batch
+    p.a_taps, p.act = a_taps, act
+    p.c_dtype = F32 if Cout.dtype == torch.float32 else BF16
+    p.accumulate, p.scale_tanh, p.alpha = int(accumulate), int(scale_tanh), float(alpha)
+    _lib.check(_lib.lib().grove_gemm_bf16(C.byref(p), _stream()), "grove_gemm_bf16")
+    return Cout
+
+
+def linear(x, w, bias=None, *, act=ACT_NONE, residual=None, out=None, out_dtype=bf16, aux=None, alpha=1.0,
+           scale_ptr=None, scale_tanh=False, a_idx=None, a_taps=1, c_idx=None, r_idx=None, M=None, out_rows=None,
+           accumulate=False):
+    """y = epilogue(x @ w.T): x [*, K] (row stride lda), w [N, K] (nn.Linear layout)."""
+    K = w.shape[1]
+    N = w.shape[0]
+    x2 = x.reshape(-1, x.shape[-1]) if x.dim() != 2 else x
+    if M is None:
+        M = x2.shape[0]
+    assert x2.stride(1) == 1 and w.stride(1) == 1
+    if a_idx is None:
+        assert x2.shape[1] == K, f"linear: x has K={x2.shape[1]}, weight has K={K}"
+    if out is None:
+        rows = out_rows if out_rows is not None else M
+        out = torch.empty((rows, N), dtype=out_dtype, device=x.device)
+    ldr = residual.stride(0) if residual is not None else 0
+    gemm_raw(x2, w, out, M, N, K, x2.stride(0), w.stride(0), out.stride(0), bias=bias, residual=residual, ldr=ldr,
+             aux=aux, scale_ptr=scale_ptr, scale_tanh=scale_tanh, a_idx=a_idx, a_taps=a_taps, c_idx=c_idx, r_idx=r_idx,
+             act=act, accumulate=accumulate, alpha=alpha)
+    return out
+
+
+def gemm_set_staging(use_lds_dma: bool):
+    _lib.check(_lib.lib().grove_gemm_set_staging(int(use_lds_dma)), "grove_gemm_set_staging")
+
+
+def transpose(x, rows, cols, ld_in, out, ld_out, *, pad_to_cols=None, batch=(1, 1), s_in=(0, 0), s_out=(0, 0)):
+    _chk_dev(x, out)
+    p = _lib.TransposeParams()
+    p.inp, p.out = _p(x), _p(out)
+    p.s_in1, p.s_in2, p.s_out1, p.s_out2 = s_in[0], s_in[1], s_out[0], s_out[1]
+    p.rows, p.cols, p.ld_in, p.ld_out = rows, cols, ld_in, ld_out
+    p.pad_to = pad_to_cols if pad_to_cols is not None else rows
+    p.batch1, p.batch2 = batch
+    _lib.check(_lib.lib().grove_transpose_bf16(C.byref(p), _stream()), "grove_transpose_bf16")
+    return out
+
+
+def transpose2d(x, pad_cols_to=None):
+    """[R, C] -> [C, R(pad)] contiguous"""
+    R, Cc = x.shape
+    ld_out = pad_cols_to if pad_cols_to is not None else R
+    out = torch.empty((Cc, ld_out), dtype=bf16, device=x.device)
+    return transpose(x, R, Cc, x.stride(0), out, ld_out, pad_to_cols=ld_out)
+
+
+def _norm_fwd(fn, name, x, weight, bias, eps, out, out_idx, save_stats, out_dtype, out_rows):
+    _chk_dev(x, weight)
+    rows, Cc = x.shape
+    if out is None:
+        orows = out_rows if out_rows is not None else rows
+        if out_idx is not None:
+            out = torch.zeros((orows, Cc), dtype=out_dtype, device=x.device)
+        else:
+            out = torch.empty((orows, Cc), dtype=out_dtype, device=x.device)
+    mean = rstd = None
+    if save_stats:
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    p = _lib.NormParams()
+    p.x, p.weight, p.bias, p.y = _p(x), _p(weight), _p(bias), _p(out)
+    p.mean, p.rstd, p.out_idx = _p(mean), _p(rstd), _p(out_idx)
+    p.rows, p.C, p.ld_x, p.ld_y = rows, Cc, x.stride(0), out.stride(0)
+    p.y_dtype = F32 if out.dtype == torch.float32 else BF16
+    p.eps = eps
+    _lib.check(fn(C.byref(p), _stream()), name)
+    return out, mean, rstd
+
+
+def layernorm(x, weight, bias, eps, *, out=None, out_idx=None, save_stats=False, out_dtype=bf16, out_rows=None):
+    return _norm_fwd(_lib.lib().grove_layernorm_fwd, "grove_layernorm_fwd", x, weight, bias, eps, out, out_idx,
+                     save_stats, out_dtype, out_rows)
+
+
+def rmsnorm(x, weight, eps, *, out=None):
+    return _norm_fwd(_lib.lib().grove_rmsnorm_fwd, "grove_rmsnorm_fwd", x, weight, None, eps, out, None, False, bf16,
+                     None)[0]
+
+
+def _norm_bwd(fn, name, x, weight, dy, mean, rstd, eps, dx, dweight, dbias, in_idx, accumulate):
+    rows, Cc = x.shape
+    if dx is None:
+        dx = torch.empty((rows, Cc), dtype=bf16, device=x.device)
+    p = _lib.NormBwdParams()
+    p.x, p.weight, p.dy, p.dx = _p(x), _p(weight), _p(dy), _p(dx)
+    p.mean, p.rstd, p.dweight, p.dbias, p.in_idx = _p(mean), _p(rstd), _p(dweight), _p(dbias), _p(in_idx)
+    p.rows, p.C, p.ld_x, p.ld_dy, p.ld_dx = rows, Cc, x.stride(0), dy.stride(0), dx.stride(0)
+    p.accumulate, p.eps = int(accumulate), eps
+    _lib.check(fn(C.byref(p), _stream()), name)
+    return dx
+
+
+def layernorm_bwd(x, weight, dy, mean, rstd, *, dx=None, dweight=None, dbias=None, in_idx=None, accumulate=False):
+    return _norm_bwd(_lib.lib().grove_layernorm_bwd, "grove_layernorm_bwd", x, weight, dy, mean, rstd, 0.0, dx,
+                     dweight, dbias, in_idx, accumulate)
+
+
+def rmsnorm_bwd(x, weight, dy, eps, *, dx=None, dweight=None, accumulate=False):
+    return _norm_bwd(_lib.lib().grove_rmsnorm_bwd, "grove_rmsnorm_bwd", x, weight, dy, None, None, eps, dx, dweight,
+                     None, None, accumulate)
+
+
+def softmax(scores, Lk, *, heads=1, causal=False, kv_len=None, rel=None, rel_hw=(0, 0), ld_p=None, out=None):
+    """scores f32 [batch, Lq, ld_s] -> probs bf16 [batch, Lq, ld_p] (pad columns zeroed)."""
+    batch, Lq, ld_s = scores.shape
+    if ld_p is None:
+        ld_p = pad_to(Lk, 32)
+    if out is None:
+        out = torch.empty((batch, Lq, ld_p), dtype=bf16, device=scores.device)
+    p = _lib.SoftmaxParams()
+    p.scores, p.probs, p.kv_len, p.rel = _p(scores), _p(out), _p(kv_len), _p(rel)
+    p.batch, p.heads, p.Lq, p.Lk, p.ld_s, p.ld_p = batch, heads, Lq, Lk, ld_s, ld_p
+    p.causal, p.rel_kh, p.rel_kw = int(causal), rel_hw[0], rel_hw[1]
+    _lib.check(_lib.lib().grove_softmax_fwd(C.byref(p), _stream()), "grove_softmax_fwd")
+    return out
+
+
+def softmax_bwd(dprobs, probs, Lk, scale, *, drel=None, rel_hw=(0, 0), out=None):
+    batch, Lq, ld_s = dprobs.shape
+    ld_p = probs.shape[2]
+    if out is None:
+        out = torch.empty_like(probs)
+    p = _lib.SoftmaxBwdParams()
+    p.dprobs, p.probs, p.dscores, p.drel = _p(dprobs), _p(probs), _p(out), _p(drel)
+    p.batch, p.Lq, p.Lk, p.ld_s, p.ld_p = batch, Lq, Lk, ld_s, ld_p
+    p.rel_kh, p.rel_kw, p.scale = rel_hw[0], rel_hw[1], scale
+    _lib.check(_lib.lib().grove_softmax_bwd(C.byref(p), _stream()), "grove_softmax_bwd")
+    return out
+
+
+def relpos(q, Rh, Rw, batch, heads, qhw, khw, hd, hd_stride, ld_q, *, rel=None, dq=None, backward=False):
+    p = _lib.RelposParams()
+    L = qhw[0] * qhw[1]
+    if rel is None:
+        rel = torch.empty((batch * heads, L, khw[0] + khw[1]), dtype=torch.float32, device=q.device)
+    p.q, p.Rh, p.Rw, p.rel, p.dq = _p(q), _p(Rh), _p(Rw), _p(rel), _p(dq)
+    p.batch, p.heads, p.qh, p.qw, p.kh, p.kw = batch, heads, qhw[0], qhw[1], khw[0], khw[1]
+    p.hd, p.hd_stride, p.ld_q = hd, hd_stride, ld_q
+    fn = _lib.lib().grove_relpos_bwd if backward else _lib.lib().grove_relpos_fwd
+    _lib.check(fn(C.byref(p), _stream()), "grove_relpos")
+    return rel
+
+
+def rope_(x, pos, col0, nheads, hd, theta, inverse=False):
+    p = _lib.RopeParams()
+    p.x, p.pos = _p(x), _p(pos)
+    p.rows, p.ld, p.col0, p.nheads, p.hd = x.shape[0], x.stride(0), col0, nheads, hd
+    p.inverse, p.theta = int(inverse), theta
+    _lib.check(_lib.lib().grove_rope_inplace(C.byref(p), _stream()), "grove_rope_inplace")
+    return x
+
+
+def swiglu(gu, I):
+    rows = gu.shape[0]
+    y = torch.empty((rows, I), dtype=bf16, device=gu.device)
+    _lib.check(_lib.lib().grove_swiglu_fwd(_p(gu), _p(y), rows, I, _stream()), "grove_swiglu_fwd")
+    return y
+
+
+def swiglu_bwd(gu, dy, I):
+    rows = gu.shape[0]
+    dgu = torch.empty_like(gu)
+    _lib.check(_lib.lib().grove_swiglu_bwd(_p(gu), _p(dy), _p(dgu), rows, I, _stream()), "grove_swiglu_bwd")
+    return dgu
+
+
+def act_bwd(pre, dy, act, out=None):
+    if out is None:
+        out = torch.empty_like(dy)
+    _lib.check(_lib.lib().grove_act_bwd(_p(pre), _p(dy), _p(out), C.c_int64(dy.numel()), act, _stream()), "grove_act_bwd")
+    return out
+
+
+def add(a, b, out=None):
+    if out is None:
+        out = torch.empty_like(a)
+    _lib.check(_lib.lib().grove_add_bf16(_p(a), _p(b), _p(out), C.c_int64(a.numel()), _stream()), "grove_add_bf16")
+    return out
+
+
+def add_bcast_rows(a, b, period, out=None):
+    rows, Cc = a.shape
+    if out is None:
+        out = torch.empty_like(a)
+    _lib.check(_lib.lib().grove_add_bcast_rows(_p(a), _p(b), _p(out), rows, Cc, period, _stream()), "grove_add_bcast_rows")
+    return out
+
+
+def copy_rows(src, dst, rows, Cc, *, idx_src=None, idx_dst=None, accumulate=False):
+    p = _lib.RowsParams()
+    p.src, p.dst, p.idx_src, p.idx_dst = _p(src), _p(dst), _p(idx_src), _p(idx_dst)
+    p.rows, p.C, p.ld_src, p.ld_dst, p.accumulate = rows, Cc, src.stride(-2), dst.stride(-2), int(accumulate)
+    _lib.check(_lib.lib().grove_copy_rows(C.byref(p), _stream()), "grove_copy_rows")
+    return dst
+
+
+def scatter_add_f32(src, dst, idx, rows, Cc):
+    _lib.check(_lib.lib().grove_scatter_add_f32(_p(src), _p(dst), _p(idx), rows, Cc, src.stride(0), dst.stride(0), _stream()),
+               "grove_scatter_add_f32")
+    return dst
+
+
+def colsum(x, out=None, accumulate=False):
+    rows, Cc = x.shape
+    if out is None:
+        out = torch.empty(Cc, dtype=torch.float32, device=x.device)
+        accumulate = False
+    _lib.check(_lib.lib().grove_colsum_f32(_p(x), _p(out), rows, Cc, x.stride(0), int(accumulate), _stream()), "grove_colsum_f32")
+    return out
+
+
+def to_bf16(x, out=None):
+    if out is None:
+        out = torch.empty(x.shape, dtype=bf16, device=x.device)
+    _lib.check(_lib.lib().grove_cast_f32_to_bf16(_p(x), _p(out), C.c_int64(x.numel()), _stream()), "grove_cast_f32_to_bf16")
+    return out
+
+
+def to_f32(x, out=None):
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().grove_cast_bf16_to_f32(_p(x), _p(out), C.c_int64(x.numel()), _stream()), "grove_cast_bf16_to_f32")
+    return out
+
+
+def im2col_patch(img, P, ld_col):
+    B, Cc, T, H, W = img.shape
+    assert img.is_contiguous()
+    rows = B * T * (H // P) * (W // P)
+    col = torch.empty((rows, ld_col), dtype=bf16, device=img.device)
+    _lib.check(_lib.lib().grove_im2col_patch(_p(img), _p(col), B, Cc, T, H, W, P, ld_col, _stream()), "grove_im2col_patch")
+    return col
+
+
+def clip_pool(x, G):
+    Cc = x.shape[-1]
+    y = torch.empty((G, 576, Cc), dtype=bf16, device=x.device)
+    _lib.check(_lib.lib().grove_clip_pool(_p(x), _p(y), G, Cc, _stream()), "grove_clip_pool")
+    return y
+
+
+def cross_entropy(logits, labels, V, *, loss_sum=None, dlogits=None, grad_scale=None):
+    R, ld = logits.shape[0], logits.stride(0)
+    if loss_sum is None:
+        loss_sum = torch.zeros(1, dtype=torch.float32, device=logits.device)
+    _lib.check(_lib.lib().grove_cross_entropy(_p(logits), _p(labels), _p(loss_sum), _p(dlogits), _p(grad_scale), R, V, ld, _stream()),
+               "grove_cross_entropy")
+    return loss_sum
+
+
+def small_attn(q, k, v, inst, heads, d, Lq, Lk, *, out=None):
+    if out is None:
+        out = torch.empty((inst * Lq, heads * d), dtype=bf16, device=q.device)
+    p = _lib.SmallAttnParams()
+    p.q, p.k, p.v, p.o = _p(q), _p(k), _p(v), _p(out)
+    p.inst, p.heads, p.d, p.Lq, p.Lk = inst, heads, d, Lq, Lk
+    p.ld_q, p.ld_k, p.ld_v, p.ld_o = q.stride(-2), k.stride(-2), v.stride(-2), out.stride(-2)
+    _lib.check(_lib.lib().grove_small_attn_fwd(C.byref(p), _stream()), "grove_small_attn_fwd")
+    return out
+
+
+def small_attn_bwd(q, k, v, o, d_o, inst, heads, d, Lq, Lk):
+    dev = q.device
+    dq = torch.empty((inst * Lq, heads * d), dtype=torch.float32, device=dev)
+    dk = torch.empty((inst * Lk, heads * d), dtype=torch.float32, device=dev)
+    dv = torch.empty((inst * Lk, heads * d), dtype=torch.float32, device=dev)
+    p = _lib.SmallAttnParams()
+    p.q, p.k, p.v, p.o, p.d_o = _p(q), _p(k), _p(v), _p(o), _p(d_o)
+    p.dq, p.dk, p.dv = _p(dq), _p(dk), _p(dv)
+    p.inst, p.heads, p.d, p.Lq, p.Lk = inst, heads, d, Lq, Lk
+    p.ld_q, p.ld_k, p.ld_v, p.ld_o = q.stride(-2), k.stride(-2), v.stride(-2), o.stride(-2)
+    assert d_o.stride(-2) == o.stride(-2)
+    _lib.check(_lib.lib().grove_small_attn_bwd(C.byref(p), _stream()), "grove_small_attn_bwd")
+    return dq, dk, dv
+
+
+def box_head(x, W1, b1, W2, b2, Wo, bo):
+    N, D = x.shape
+    dev = x.device
+    hidden = torch.empty((N, D), dtype=torch.float32, device=dev)
+    box = torch.empty((N, 4), dtype=torch.float32, device=dev)
+    obj = torch.empty(N, dtype=torch.float32, device=dev) if Wo is not None else None
+    p = _lib.BoxHeadParams()
+    p.x, p.W1, p.b1, p.W2, p.b2, p.Wo, p.bo = _p(x), _p(W1), _p(b1), _p(W2), _p(b2), _p(Wo), _p(bo)
+    p.hidden, p.box, p.obj, p.N, p.D = _p(hidden), _p(box), _p(obj), N, D
+    _lib.check(_lib.lib().grove_box_head_fwd(C.byref(p), _stream()), "grove_box_head_fwd")
+    return box, obj, hidden
+
+
+def box_head_bwd(x, W1, W2, Wo, hidden, box, dbox, dobj, grads):
+    """grads: dict of f32 accumulators dW1, db1, dW2, db2, dWo, dbo. Returns dx f32 [N, D]."""
+    N, D = x.shape
+    dx = torch.empty((N, D), dtype=torch.float32, device=x.device)
+    p = _lib.BoxHeadBwdParams()
+    p.x, p.W1, p.W2, p.Wo, p.hidden, p.box = _p(x), _p(W1), _p(W2), _p(Wo), _p(hidden), _p(box)
+    p.dbox, p.dobj, p.dx = _p(dbox), _p(dobj), _p(dx)
+    p.dW1, p.db1, p.dW2, p.db2 = _p(grads["dW1"]), _p(grads["db1"]), _p(grads["dW2"]), _p(grads["db2"])
+    p.dWo, p.dbo = _p(grads.get("dWo")), _p(grads.get("dbo"))
+    p.N, p.D = N, D
+    _lib.check(_lib.lib().grove_box_head_bwd(C.byref(p), _stream()), "grove_box_head_bwd")
+    return dx
+
+
+def box_losses(pred_box, obj_logit, gt_box, visible, w_box_over_ngt, w_obj_over_n, want_grad=True):
+    N = pred_box.shape[0]
+    dev = pred_box.device
+    sums = torch.zeros(3, dtype=torch.float32, device=dev)
+    dbox = torch.empty((N, 4), dtype=torch.float32, device=dev) if want_grad else None
+    dobj = torch.empty(N, dtype=torch.float32, device=dev) if (want_grad and obj_logit is not None) else None
+    _lib.check(_lib.lib().grove_box_losses(_p(pred_box), _p(obj_logit), _p(gt_box), _p(visible), _p(sums), _p(dbox), _p(dobj), N,
+                                           C.c_float(w_box_over_ngt), C.c_float(w_obj_over_n), _stream()), "grove_box_losses")
+    return sums, dbox, dobj
+
+
+def adamw_step(master, model_bf16, grad, m, v, lr, beta1, beta2, eps, weight_decay, grad_scale, step):
+    _lib.check(_lib.lib().grove_adamw_step(_p(master), _p(model_bf16), _p(grad), _p(m), _p(v), C.c_int64(master.numel()),
+                                           C.c_float(lr), C.c_float(beta1), C.c_float(beta2), C.c_float(eps),
+                                           C.c_float(weight_decay), C.c_float(grad_scale), int(step), _stream()), "grove_adamw_step")
+
+
+def sumsq(x, out=None):
+    if out is None:
+        out = torch.zeros(1, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().grove_sumsq_f32(_p(x), _p(out), C.c_int64(x.numel()), _stream()), "grove_sumsq_f32")
+    return out

@@ -1,0 +1,328 @@
+/*
+ * grove_hip.h — C-ABI of libgrove_hip.so, the MI355X (gfx950) kernel library behind
+ * grove_amd's GROVEForCausalLM hot path.
+ *
+ * The reference (ekazakos/grove) has NO native layer: every device kernel it runs comes from
+ * PyTorch/cuBLAS/cuDNN, flash-attn and DeepSpeed (SURVEY.md §2 "Third-party native/fused ops").
+ * Each entry point below therefore cites the reference op sequence (file:line under
+ * /root/reference) that it replaces, not a reference FFI symbol.
+ *
+ * Conventions
+ *  - plain pointers + sizes only; every buffer is caller-owned device memory (in practice a
+ *    torch tensor); the library never allocates, frees or retains pointers across calls.
+ *  - all calls are asynchronous on `stream` (a hipStream_t passed as void*), graph-capturable.
+ *  - return 0 on success, negative GROVE_E_* otherwise; grove_last_error() has the text.
+ *  - bf16 tensors are raw uint16 storage ("bf16"); accumulation is always fp32.
+ */
+#ifndef GROVE_HIP_H
+#define GROVE_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GROVE_OK 0
+#define GROVE_E_SHAPE (-1)
+#define GROVE_E_DTYPE (-2)
+#define GROVE_E_ALIGN (-3)
+#define GROVE_E_WORKSPACE (-4)
+#define GROVE_E_HIP (-5)
+
+enum grove_act {
+  GROVE_ACT_NONE = 0,
+  GROVE_ACT_RELU = 1,      /* SAM adapters / decoder MLP / text_hidden_fcs / bbox head */
+  GROVE_ACT_GELU = 2,      /* erf GELU: mm_projector (llava_with_region_arch.py:17), SAM MLPBlock */
+  GROVE_ACT_QUICKGELU = 3, /* CLIP MLP (modeling_clip.py:336-348) */
+  GROVE_ACT_SILU = 4,      /* LLaMA SwiGLU gate */
+  GROVE_ACT_SIGMOID = 5
+};
+
+enum grove_dtype { GROVE_BF16 = 0, GROVE_F32 = 1 };
+
+int grove_version(void);
+/* copies the last error message of the calling thread into buf (NUL-terminated) */
+int grove_last_error(char* buf, size_t n);
+/* sizeof(struct <name>) as compiled into the library (binding self-check), -1 if unknown */
+int grove_sizeof(const char* name);
+
+/* ------------------------------------------------------------------------------------------
+ * GEMM:  C[m, n] = epilogue( alpha * sum_k A[row_a(m,k), k] * B[n, k] )
+ *   A: bf16 [*, lda] row-major (activations), B: bf16 [N, ldb] row-major (nn.Linear weight
+ *   layout, i.e. "NT" GEMM), fp32 accumulate on v_mfma_f32_16x16x32_bf16.
+ *   epilogue(v):  v += bias[n];  aux[m,n] = v (optional pre-activation copy for backward);
+ *                 v = act(v);  v *= scale (scale = *scale_ptr, tanh'd if scale_tanh);
+ *                 v += residual[row_r(m), n];  (C += v if accumulate)  store as bf16 / f32.
+ *   Gather/scatter row maps (int32, -1 = zero row on A / skipped row on C):
+ *     a_idx[tap*M + m] with tap = k / (K / a_taps)  -> implicit-GEMM convolution and window
+ *     partition without materialising im2col; c_idx[m], r_idx[m] for scatter / broadcast.
+ *   Batched over batch1*batch2 with independent element strides.
+ * Replaces: every nn.Linear / torch.bmm / `@` / Conv2d(k=stride) / Conv3d 3x3x3 on the path:
+ *   modeling_clip.py:174-180,269-271,279,319,331,344-348,594; image_encoder.py:43,152-168,
+ *   305-326,484-486; common.py:21-26; transformer.py:205-242; llava_with_region_arch.py:16-19;
+ *   HF LlamaAttention/LlamaMLP (llava_llama.py:100-112); GROVE.py:75-79; mask_decoder.py:80-84.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct grove_gemm_params {
+  const void* A;
+  const void* B;
+  void* C;
+  const void* bias;       /* bf16 [N] or NULL */
+  const void* residual;   /* bf16 [*, ldr] or NULL */
+  void* aux;              /* bf16 [*, ldc] pre-activation copy or NULL (same row map as C) */
+  const float* scale_ptr; /* device scalar or NULL */
+  const int32_t* a_idx;   /* [a_taps, M] or NULL */
+  const int32_t* c_idx;   /* [M] or NULL */
+  const int32_t* r_idx;   /* [M] or NULL (NULL -> residual uses the C row) */
+  int64_t sA1, sA2, sB1, sB2, sC1, sC2, sR1, sR2; /* batch strides in elements */
+  int32_t M, N, K;
+  int32_t lda, ldb, ldc, ldr;
+  int32_t batch1, batch2;
+  int32_t a_taps;     /* >=1 */
+  int32_t act;        /* enum grove_act */
+  int32_t c_dtype;    /* enum grove_dtype */
+  int32_t accumulate; /* C += result (c_dtype f32 only) */
+  int32_t scale_tanh; /* scale = tanh(*scale_ptr) */
+  float alpha;
+} grove_gemm_params;
+int grove_gemm_bf16(const grove_gemm_params* p, void* stream);
+/* A/B staging variant: 1 = LDS-DMA (global_load_lds, default), 0 = register staged */
+int grove_gemm_set_staging(int use_lds_dma);
+
+/* out[c, r] = in[r, c] for a batch of 2-D bf16 matrices (used for V^T, dY^T, X^T, NCHW<->NHWC).
+ * rows beyond `rows` in the output's padded leading dim (ld_out > rows) are zero filled up to
+ * pad_to columns. Replaces .transpose().contiguous() / .permute() copies
+ * (modeling_clip.py:255; image_encoder.py:305-323; transformer.py:83-84). */
+typedef struct grove_transpose_params {
+  const void* in;
+  void* out;
+  int64_t s_in1, s_in2, s_out1, s_out2;
+  int32_t rows, cols;     /* input is [rows, cols] with leading dim ld_in */
+  int32_t ld_in, ld_out;  /* output is [cols, ld_out], columns [rows, pad_to) zero-filled */
+  int32_t pad_to;
+  int32_t batch1, batch2;
+} grove_transpose_params;
+int grove_transpose_bf16(const grove_transpose_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Norms. x: bf16 [rows, ld_x]; y: bf16 or f32 [*, ld_y]; statistics fp32.
+ * layernorm: nn.LayerNorm (modeling_clip.py:381-395,915; image_encoder.py:243-259;
+ *   transformer.py:151-182) and LayerNorm2d in channels-last (common.py:32-43).
+ *   out_idx (optional) scatters row r of the input to row out_idx[r] of y (SAM window partition,
+ *   image_encoder.py:329-352; rows never written keep their caller-provided zero padding).
+ * rmsnorm: HF LlamaRMSNorm (fp32 normalise, cast, times weight).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct grove_norm_params {
+  const void* x;
+  const void* weight; /* bf16 [C] */
+  const void* bias;   /* bf16 [C] or NULL (rmsnorm) */
+  void* y;
+  float* mean;        /* [rows] or NULL (layernorm only; saved for backward) */
+  float* rstd;        /* [rows] or NULL */
+  const int32_t* out_idx;
+  int32_t rows, C, ld_x, ld_y;
+  int32_t y_dtype;
+  float eps;
+} grove_norm_params;
+int grove_layernorm_fwd(const grove_norm_params* p, void* stream);
+int grove_rmsnorm_fwd(const grove_norm_params* p, void* stream);
+
+typedef struct grove_norm_bwd_params {
+  const void* x;      /* bf16 [rows, ld_x] forward input */
+  const void* weight; /* bf16 [C] */
+  const void* dy;     /* bf16 [*, ld_dy]; row r read at in_idx[r] if in_idx */
+  void* dx;           /* bf16 [rows, ld_dx]; dx (+)= ... when accumulate */
+  const float* mean;  /* layernorm: saved stats; rmsnorm: NULL */
+  const float* rstd;
+  float* dweight;     /* f32 [C] accumulated with atomics, or NULL */
+  float* dbias;       /* f32 [C] or NULL */
+  const int32_t* in_idx;
+  int32_t rows, C, ld_x, ld_dy, ld_dx;
+  int32_t accumulate; /* dx += */
+  float eps;
+} grove_norm_bwd_params;
+int grove_layernorm_bwd(const grove_norm_bwd_params* p, void* stream);
+int grove_rmsnorm_bwd(const grove_norm_bwd_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Row softmax over attention scores, fp32 in -> bf16 probabilities, with the masks / biases the
+ * three towers need. scores: f32 [batch, Lq, ld_s]; probs: bf16 [batch, Lq, ld_p], columns
+ * [Lk, ld_p) are written as zero so that P can feed the PV GEMM with a padded K.
+ *   causal: key j allowed iff j <= i + (Lk - Lq)           (HF Llama eager mask)
+ *   kv_len[batch / heads]: keys >= kv_len masked            (right padding, llava arch :392-418)
+ *   rel-pos: s[i, j] += relh[b, i, j / kw] + relw[b, i, j % kw]
+ *            (image_encoder.py:420-458 add_decomposed_rel_pos)
+ * Replaces nn.functional.softmax at modeling_clip.py:305, image_encoder.py:317,
+ * transformer.py:235 and the fp32 softmax of HF eager Llama attention.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct grove_softmax_params {
+  const float* scores;
+  void* probs;
+  const int32_t* kv_len; /* [batch / heads] or NULL */
+  const float* rel;      /* f32 [batch, Lq, rel_kh + rel_kw] or NULL */
+  int32_t batch, heads, Lq, Lk, ld_s, ld_p;
+  int32_t causal;
+  int32_t rel_kh, rel_kw;
+} grove_softmax_params;
+int grove_softmax_fwd(const grove_softmax_params* p, void* stream);
+
+/* dS = P * (dP - rowsum(P * dP)) * scale; optionally reduces dS over kw / kh into drel.
+ * dP: f32 [batch, Lq, ld_s]; P: bf16; dS: bf16 [batch, Lq, ld_p] (pad columns zero). */
+typedef struct grove_softmax_bwd_params {
+  const float* dprobs;
+  const void* probs;
+  void* dscores;
+  float* drel; /* f32 [batch, Lq, rel_kh + rel_kw] or NULL */
+  int32_t batch, Lq, Lk, ld_s, ld_p;
+  int32_t rel_kh, rel_kw;
+  float scale;
+} grove_softmax_bwd_params;
+int grove_softmax_bwd(const grove_softmax_bwd_params* p, void* stream);
+
+/* Decomposed relative-position terms of SAM attention (image_encoder.py:420-458):
+ * rel[b*heads + h, q, 0:kh]     = sum_c qv[q, h, c] * Rh[qh(q), :, c]
+ * rel[b*heads + h, q, kh:kh+kw] = sum_c qv[q, h, c] * Rw[qw(q), :, c]
+ * q: bf16 rows [b, q] with leading dim ld_q, head h at column offset h*hd_stride; hd = real head
+ * dim; Rh: f32 [qh, kh, hd]; Rw: f32 [qw, kw, hd]. bwd adds  dq += drel . R  into dq (bf16). */
+typedef struct grove_relpos_params {
+  const void* q;
+  const float* Rh;
+  const float* Rw;
+  float* rel;        /* fwd: out; bwd: d rel in */
+  void* dq;          /* bwd only: bf16, accumulated */
+  int32_t batch, heads, qh, qw, kh, kw, hd, hd_stride, ld_q;
+} grove_relpos_params;
+int grove_relpos_fwd(const grove_relpos_params* p, void* stream);
+int grove_relpos_bwd(const grove_relpos_params* p, void* stream);
+
+/* Rotary embedding, HF rotate_half convention, applied in place to q and k heads inside a fused
+ * qkv activation: x: bf16 [rows, ld]; row r has position pos[r]; heads at columns
+ * col0 + h*hd for h < nheads. inverse=1 applies the transpose rotation (backward).
+ * cos/sin are computed in fp32 from theta (HF LlamaRotaryEmbedding) and applied in fp32. */
+typedef struct grove_rope_params {
+  void* x;
+  const int32_t* pos;
+  int32_t rows, ld, col0, nheads, hd;
+  int32_t inverse;
+  float theta;
+} grove_rope_params;
+int grove_rope_inplace(const grove_rope_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Elementwise / data-movement kernels (all bf16, vectorised 16 B per lane).
+ * ------------------------------------------------------------------------------------------ */
+/* y = silu(gate) * up over a fused [rows, 2*I] gate|up activation (HF LlamaMLP) */
+int grove_swiglu_fwd(const void* gu, void* y, int32_t rows, int32_t I, void* stream);
+/* dgu = [dy*up*silu'(gate) | dy*silu(gate)] */
+int grove_swiglu_bwd(const void* gu, const void* dy, void* dgu, int32_t rows, int32_t I, void* stream);
+/* dx = dy * act'(pre) (in place allowed) */
+int grove_act_bwd(const void* pre, const void* dy, void* dx, int64_t n, int32_t act, void* stream);
+/* y = a + b (bf16), n elements; b may be NULL (copy) */
+int grove_add_bf16(const void* a, const void* b, void* y, int64_t n, void* stream);
+/* y[r, :] = a[r, :] + b[r % period, :]   (keys + key_pe, transformer.py:168-170) */
+int grove_add_bcast_rows(const void* a, const void* b, void* y, int32_t rows, int32_t C, int32_t period, void* stream);
+/* dst[idx_dst[r] or r, :] = src[idx_src[r] or r, :]; idx_src -1 -> zero row; bf16 rows of C elems.
+ * accumulate=1: dst row += (fp32 add, rows must be unique or use grove_scatter_add_f32) */
+typedef struct grove_rows_params {
+  const void* src;
+  void* dst;
+  const int32_t* idx_src;
+  const int32_t* idx_dst;
+  int32_t rows, C, ld_src, ld_dst;
+  int32_t accumulate;
+} grove_rows_params;
+int grove_copy_rows(const grove_rows_params* p, void* stream);
+/* dst_f32[idx[r], :] += src_bf16[r, :] with float atomics (embed_tokens / broadcast-row grads) */
+int grove_scatter_add_f32(const void* src, float* dst, const int32_t* idx, int32_t rows, int32_t C,
+                          int32_t ld_src, int32_t ld_dst, void* stream);
+/* column sums of a bf16 [rows, ld] matrix into f32 out[C] (bias gradients); accumulate adds */
+int grove_colsum_f32(const void* x, float* out, int32_t rows, int32_t C, int32_t ld, int32_t accumulate, void* stream);
+/* casts */
+int grove_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
+int grove_cast_bf16_to_f32(const void* x, float* y, int64_t n, void* stream);
+
+/* Patch im2col for the two ViT stems: images bf16 [B, C, T, H, W] (the reference's 'b c t h w'
+ * clip layout, clip_encoder.py:70 / image_encoder.py:174) -> col bf16 [B*T*(H/P)*(W/P), ld_col]
+ * with k = (c, py, px) matching Conv2d weight.flatten(1), columns [C*P*P, ld_col) zeroed.
+ * Replaces the strided Conv2d at modeling_clip.py:174-180,190 and image_encoder.py:484-492. */
+int grove_im2col_patch(const void* img, void* col, int32_t B, int32_t C, int32_t T, int32_t H, int32_t W,
+                       int32_t P, int32_t ld_col, void* stream);
+/* d img not needed (inputs carry no gradient). */
+
+/* CLIP token pooling: AdaptiveAvgPool3d((8,8,9)) over (t=8, 24, 24) patch tokens, skipping CLS
+ * (pooling.py:6-25, clip_encoder.py:45-50,74-76). x: bf16 [G*8, 577, C] -> y: bf16 [G, 576, C]. */
+int grove_clip_pool(const void* x, void* y, int32_t G, int32_t C, void* stream);
+
+/* Cross entropy over rows of bf16 logits [R, ld] with V valid columns, labels int32 [R]
+ * (every label valid; rows are pre-gathered). loss_sum += sum_r (lse_r - logit[r, label_r]);
+ * dlogits (bf16, may alias logits) = (softmax - onehot) * (*grad_scale).
+ * Replaces CrossEntropyLoss at llava_llama.py:115-125. */
+int grove_cross_entropy(const void* logits, const int32_t* labels, float* loss_sum, void* dlogits,
+                        const float* grad_scale, int32_t R, int32_t V, int32_t ld, void* stream);
+
+/* Small attention for the SAM two-way decoder (transformer.py:185-242): per (instance, head)
+ * softmax(q k^T / sqrt(d)) v with Lq*Lk small on one side (6 tokens x 1024 image tokens, either
+ * direction). q: bf16 [inst, Lq, ld_q], k/v: bf16 [inst, Lk, ld_k]/[.., ld_v], heads packed
+ * along columns with head dim d (16 or 32). out bf16 [inst, Lq, ld_o]. Wavefront-reduced
+ * (no MFMA: the products are <= 6 rows). bwd recomputes the probabilities. */
+typedef struct grove_small_attn_params {
+  const void* q;
+  const void* k;
+  const void* v;
+  void* o;
+  const void* d_o; /* bwd */
+  void* dq; /* bwd outputs are f32, dense [inst, L, heads*d] */
+  void* dk;
+  void* dv;
+  int32_t inst, heads, d, Lq, Lk, ld_q, ld_k, ld_v, ld_o;
+} grove_small_attn_params;
+int grove_small_attn_fwd(const grove_small_attn_params* p, void* stream);
+int grove_small_attn_bwd(const grove_small_attn_params* p, void* stream);
+
+/* Box + temporal-objectness heads in fp32 (mask_decoder.py:80-84,198-203): x f32 [N, D];
+ * box = sigmoid(W2 relu(W1 x + b1) + b2) [N,4]; obj = Wo x + bo [N]. Weights bf16.
+ * hidden (f32 [N, D]) is saved for backward. */
+typedef struct grove_box_head_params {
+  const float* x;
+  const void* W1; const void* b1; const void* W2; const void* b2; const void* Wo; const void* bo;
+  float* hidden;
+  float* box;
+  float* obj;
+  int32_t N, D;
+} grove_box_head_params;
+int grove_box_head_fwd(const grove_box_head_params* p, void* stream);
+/* backward of the heads. dbox/dobj: f32 upstream grads; dx f32 [N,D]; weight grads f32,
+ * ACCUMULATED (+=) with atomics: dW1 [D,D], db1 [D], dW2 [4,D], db2 [4], dWo [D], dbo [1]. */
+typedef struct grove_box_head_bwd_params {
+  const float* x;
+  const void* W1; const void* W2; const void* Wo;
+  const float* hidden;
+  const float* box;
+  const float* dbox;
+  const float* dobj; /* may be NULL */
+  float* dx;
+  float* dW1; float* db1; float* dW2; float* db2; float* dWo; float* dbo;
+  int32_t N, D;
+} grove_box_head_bwd_params;
+int grove_box_head_bwd(const grove_box_head_bwd_params* p, void* stream);
+
+/* GROVE losses on device in fp32 (GROVE.py:339-381; torchvision generalized_box_iou_loss eps 1e-7):
+ * pred_box f32 [N,4] cxcywh, obj_logit f32 [N], gt_box f32 [N,4] (rows with visible==0 ignored),
+ * visible f32 [N] in {0,1}. sums[0..2] += (giou_sum, l1_sum, bce_sum); dbox/dobj = gradients of
+ * w_box*(giou+l1)/n_gt + w_obj*bce/N  when dbox != NULL. */
+int grove_box_losses(const float* pred_box, const float* obj_logit, const float* gt_box, const float* visible,
+                     float* sums, float* dbox, float* dobj, int32_t N, float w_box_over_ngt, float w_obj_over_n,
+                     void* stream);
+
+/* Fused AdamW step over a flat fp32 master / bf16 model-weight pair (DeepSpeed AdamW config,
+ * train.py:466-475). grad is the (already all-reduced) fp32 flat gradient. */
+int grove_adamw_step(float* master, void* model_bf16, const float* grad, float* m, float* v, int64_t n,
+                     float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                     int32_t step, void* stream);
+/* sum of squares of a flat f32 buffer into out[0] (+=), for grad clipping */
+int grove_sumsq_f32(const float* x, float* out, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GROVE_HIP_H */

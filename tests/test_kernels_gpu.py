@@ -1,0 +1,464 @@
+"""Per-kernel numerics of libgrove_hip.so against plain PyTorch fp32 references on the CPU.
+
+Every test calls through the C-ABI (grove_amd.ops -> ctypes -> include/grove_hip.h). Inputs are
+rounded to bf16 first, so the fp32 reference sees exactly the values the kernel sees; the
+tolerance is the bf16 output rounding (2^-8 relative) unless the output is fp32.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+bf16 = torch.bfloat16
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(bf16)
+
+
+def close(out, ref, rtol, what=""):
+    out = out.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert out.shape == ref.shape, f"{what}: shape {tuple(out.shape)} vs {tuple(ref.shape)}"
+    assert torch.isfinite(out).all(), f"{what}: non-finite output"
+    err = (out - ref).abs().max().item()
+    lim = rtol * max(ref.abs().max().item(), 1e-6)
+    assert err <= lim, f"{what}: max abs err {err:.4g} > {lim:.4g}"
+
+
+def act_ref(x, act):
+    from grove_amd import ops
+    if act == ops.ACT_RELU:
+        return F.relu(x)
+    if act == ops.ACT_GELU:
+        return F.gelu(x)
+    if act == ops.ACT_QUICKGELU:
+        return x * torch.sigmoid(1.702 * x)
+    if act == ops.ACT_SILU:
+        return F.silu(x)
+    return x
+
+
+# ----------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("staging", [1, 0])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (577, 1024, 1024), (100, 72, 96), (1, 4, 256),
+                                   (300, 1000, 608), (130, 257, 32)])
+def test_gemm_plain(dev, M, N, K, staging):
+    from grove_amd import ops
+    ops.gemm_set_staging(bool(staging))
+    try:
+        a, b = rnd(M, K, seed=1), rnd(N, K, seed=2)
+        ref = a.float() @ b.float().t()
+        out32 = ops.linear(a.to(dev), b.to(dev), out_dtype=torch.float32)
+        close(out32, ref, 2e-5, "f32 out")
+        out16 = ops.linear(a.to(dev), b.to(dev))
+        close(out16, ref, 6e-3, "bf16 out")
+    finally:
+        ops.gemm_set_staging(True)
+
+
+def test_gemm_asymmetric_identity(dev):
+    # A = I with an asymmetric B catches a transposed C write (cdna guide §3)
+    from grove_amd import ops
+    K = 128
+    a = torch.eye(K).to(bf16)
+    b = (torch.arange(K * K).reshape(K, K) % 251).float().to(bf16)
+    out = ops.linear(a.to(dev), b.to(dev), out_dtype=torch.float32)
+    close(out, b.float().t(), 0.0 + 1e-7, "A=I")
+
+
+@pytest.mark.parametrize("act", [0, 1, 2, 3, 4])
+def test_gemm_epilogue(dev, act):
+    from grove_amd import ops
+    M, N, K = 200, 320, 192
+    a, b = rnd(M, K, seed=3), rnd(N, K, seed=4, scale=0.1)
+    bias, res = rnd(N, seed=5), rnd(M, N, seed=6)
+    alpha_t = torch.tensor([0.37])
+    pre = a.float() @ b.float().t() + bias.float()
+    ref = act_ref(pre, act) * math.tanh(0.37) + res.float()
+    aux = torch.empty(M, N, dtype=bf16, device=dev)
+    out = ops.linear(a.to(dev), b.to(dev), bias.to(dev), act=act, residual=res.to(dev), aux=aux,
+                     scale_ptr=alpha_t.to(dev), scale_tanh=True)
+    close(out, ref, 8e-3, "epilogue out")
+    close(aux, pre, 6e-3, "aux pre-activation")
+
+
+def test_gemm_accumulate_and_alpha(dev):
+    from grove_amd import ops
+    M, N, K = 96, 160, 64
+    a, b = rnd(M, K, seed=7), rnd(N, K, seed=8)
+    c0 = torch.randn(M, N, generator=torch.Generator().manual_seed(9))
+    out = c0.clone().to(dev)
+    ops.linear(a.to(dev), b.to(dev), out=out, accumulate=True, alpha=0.5)
+    close(out, c0 + 0.5 * (a.float() @ b.float().t()), 2e-5, "accumulate")
+
+
+def test_gemm_batched_strided(dev):
+    # attention-shaped: q/k packed as [B, S, 3, H, d]; scores[b,h] = q k^T
+    from grove_amd import ops
+    B, S, H, d = 2, 77, 4, 64
+    qkv = rnd(B, S, 3 * H * d, seed=10)
+    q = qkv[..., :H * d].reshape(B, S, H, d)
+    k = qkv[..., H * d:2 * H * d].reshape(B, S, H, d)
+    ref = torch.einsum("bshd,bthd->bhst", q.float(), k.float()) * 0.125
+    ld_s = ops.pad_to(S, 4)
+    x = qkv.to(dev)
+    scores = torch.empty(B * H, S, ld_s, dtype=torch.float32, device=dev)
+    ops.gemm_raw(x, x[:, :, H * d:], scores, S, S, d, 3 * H * d, 3 * H * d, ld_s, batch=(B, H),
+                 sA=(S * 3 * H * d, d), sB=(S * 3 * H * d, d), sC=(H * S * ld_s, S * ld_s), alpha=0.125)
+    close(scores[:, :, :S].reshape(B, H, S, S), ref, 2e-5, "batched scores")
+
+
+def test_gemm_gather_conv3d(dev):
+    # implicit-GEMM Conv3d 3x3x3 'same' over channels-last tokens (SAM / CLIP adapters)
+    from grove_amd import ops
+    from grove_amd.model.indexing import conv3d_gather_index
+    G, T, H, W, Ci, Co = 1, 3, 4, 5, 64, 48
+    x = rnd(G * T * H * W, Ci, seed=11)
+    w = rnd(Co, Ci, 3, 3, 3, seed=12, scale=0.05)
+    bias = rnd(Co, seed=13)
+    xr = x.float().reshape(G, T, H, W, Ci).permute(0, 4, 1, 2, 3)
+    ref = F.conv3d(xr, w.float(), bias.float(), padding=1).permute(0, 2, 3, 4, 1).reshape(-1, Co)
+    ref = torch.relu(ref) * math.tanh(0.3) + x.float()[:, :Co]
+    idx = conv3d_gather_index(G, T, H, W).to(dev)          # [27, M]
+    wp = w.permute(0, 2, 3, 4, 1).reshape(Co, 27 * Ci).contiguous()  # [Co, tap, Ci]
+    res = x[:, :Co].contiguous()
+    out = ops.linear(x.to(dev), wp.to(dev), bias.to(dev), act=ops.ACT_RELU, residual=res.to(dev),
+                     scale_ptr=torch.tensor([0.3]).to(dev), scale_tanh=True, a_idx=idx, a_taps=27, M=x.shape[0])
+    close(out, ref, 8e-3, "conv3d implicit gemm")
+
+
+def test_gemm_scatter_rows(dev):
+    from grove_amd import ops
+    M, N, K = 70, 64, 64
+    a, b = rnd(M, K, seed=14), rnd(N, K, seed=15)
+    perm = torch.randperm(M, generator=torch.Generator().manual_seed(1)).int()
+    c_idx = perm.clone()
+    c_idx[::7] = -1
+    r_idx = (torch.arange(M) % 5).int()
+    res = rnd(5, N, seed=16)
+    out = torch.zeros(M, N, dtype=bf16, device=dev)
+    ops.linear(a.to(dev), b.to(dev), out=out, c_idx=c_idx.to(dev), r_idx=r_idx.to(dev), residual=res.to(dev))
+    ref = torch.zeros(M, N)
+    full = a.float() @ b.float().t() + res.float()[r_idx.long()]
+    for m in range(M):
+        if c_idx[m] >= 0:
+            ref[c_idx[m]] = full[m]
+    close(out, ref, 6e-3, "scatter")
+
+
+def test_transpose(dev):
+    from grove_amd import ops
+    x = rnd(3, 77, 130, seed=17)
+    out = torch.full((3, 130, 96), 7.0, dtype=bf16, device=dev)
+    ops.transpose(x.to(dev), 77, 130, 130, out, 96, pad_to_cols=96, batch=(3, 1), s_in=(77 * 130, 0), s_out=(130 * 96, 0))
+    ref = torch.zeros(3, 130, 96)
+    ref[:, :, :77] = x.float().transpose(1, 2)
+    close(out, ref, 1e-7, "transpose")
+
+
+# ----------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("C", [64, 256, 1024, 1280, 4096])
+def test_layernorm_fwd_bwd(dev, C):
+    from grove_amd import ops
+    rows = 37
+    x, w, b, dy = rnd(rows, C, seed=18), rnd(C, seed=19), rnd(C, seed=20), rnd(rows, C, seed=21)
+    xr = x.float().requires_grad_(True)
+    wr, br = w.float().requires_grad_(True), b.float().requires_grad_(True)
+    y_ref = F.layer_norm(xr, (C,), wr, br, 1e-5)
+    y_ref.backward(dy.float())
+    y, mean, rstd = ops.layernorm(x.to(dev), w.to(dev), b.to(dev), 1e-5, save_stats=True)
+    close(y, y_ref, 8e-3, "ln fwd")
+    if C <= 2048:
+        dw = torch.zeros(C, dtype=torch.float32, device=dev)
+        db = torch.zeros(C, dtype=torch.float32, device=dev)
+    else:
+        dw = db = None
+    dx = ops.layernorm_bwd(x.to(dev), w.to(dev), dy.to(dev), mean, rstd, dweight=dw, dbias=db)
+    close(dx, xr.grad, 1e-2, "ln dx")
+    if dw is not None:
+        close(dw, wr.grad, 1e-4, "ln dw")
+        close(db, br.grad, 1e-4, "ln db")
+
+
+def test_layernorm_scatter_f32(dev):
+    from grove_amd import ops
+    rows, C = 20, 256
+    x, w, b = rnd(rows, C, seed=22), rnd(C, seed=23), rnd(C, seed=24)
+    idx = (torch.arange(rows) * 2 % 31).int()
+    y, _, _ = ops.layernorm(x.to(dev), w.to(dev), b.to(dev), 1e-6, out_idx=idx.to(dev), out_rows=31, out_dtype=torch.float32)
+    ref = torch.zeros(31, C)
+    ref[idx.long()] = F.layer_norm(x.float(), (C,), w.float(), b.float(), 1e-6)
+    close(y, ref, 1e-5, "ln scatter f32")
+
+
+@pytest.mark.parametrize("C", [128, 4096])
+def test_rmsnorm_fwd_bwd(dev, C):
+    from grove_amd import ops
+    rows = 19
+    x, w, dy = rnd(rows, C, seed=25), rnd(C, seed=26), rnd(rows, C, seed=27)
+    xr = x.float().requires_grad_(True)
+    y_ref = xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-5) * w.float()
+    y_ref.backward(dy.float())
+    y = ops.rmsnorm(x.to(dev), w.to(dev), 1e-5)
+    close(y, y_ref, 8e-3, "rms fwd")
+    dx = ops.rmsnorm_bwd(x.to(dev), w.to(dev), dy.to(dev), 1e-5)
+    close(dx, xr.grad, 1e-2, "rms dx")
+
+
+# ----------------------------------------------------------------------------- softmax family
+@pytest.mark.parametrize("Lq,Lk,causal", [(6, 6, False), (577, 577, False), (50, 50, True), (1, 700, True), (196, 196, False)])
+def test_softmax_fwd_bwd(dev, Lq, Lk, causal):
+    from grove_amd import ops
+    batch, heads = 6, 3
+    g = torch.Generator().manual_seed(28)
+    ld_s = ops.pad_to(Lk, 4)
+    s = torch.randn(batch, Lq, ld_s, generator=g) * 3
+    kv_len = torch.tensor([Lk, max(1, Lk - 3)], dtype=torch.int32)
+    sr = s[:, :, :Lk].clone().requires_grad_(True)
+    mask = torch.zeros(batch, Lq, Lk, dtype=torch.bool)
+    for b in range(batch):
+        mask[b, :, kv_len[b // heads]:] = True
+    if causal:
+        i = torch.arange(Lq)[:, None]
+        j = torch.arange(Lk)[None, :]
+        mask |= (j > i + (Lk - Lq))[None]
+    p_ref = torch.softmax(sr.masked_fill(mask, float("-inf")), -1)
+    p = ops.softmax(s.to(dev), Lk, heads=heads, causal=causal, kv_len=kv_len.to(dev))
+    close(p[:, :, :Lk], p_ref, 6e-3, "softmax fwd")
+    assert (p[:, :, Lk:].float() == 0).all()
+    dp = torch.randn(batch, Lq, ld_s, generator=g)
+    # backward reference uses the bf16 probabilities the kernel saw
+    pb = p[:, :, :Lk].float().cpu()
+    ds_ref = pb * (dp[:, :, :Lk] - (pb * dp[:, :, :Lk]).sum(-1, keepdim=True)) * 0.25
+    ds = ops.softmax_bwd(dp.to(dev), p, Lk, 0.25)
+    close(ds[:, :, :Lk], ds_ref, 8e-3, "softmax bwd")
+
+
+def test_softmax_relpos(dev):
+    from grove_amd import ops
+    B, heads, qh, qw, hd = 2, 2, 5, 7, 16
+    L = qh * qw
+    g = torch.Generator().manual_seed(29)
+    q = rnd(B * L, heads * 32, seed=30)  # head stride 32, real hd 16
+    Rh = torch.randn(qh, qh, hd, generator=g)
+    Rw = torch.randn(qw, qw, hd, generator=g)
+    qr = q.float().reshape(B, qh, qw, heads, 32)[..., :hd]
+    rel_h = torch.einsum("bhwnc,hkc->bnhwk", qr, Rh).reshape(B * heads, L, qh)
+    rel_w = torch.einsum("bhwnc,wkc->bnhwk", qr, Rw).reshape(B * heads, L, qw)
+    rel = ops.relpos(q.to(dev), Rh.to(dev), Rw.to(dev), B, heads, (qh, qw), (qh, qw), hd, 32, heads * 32)
+    close(rel[:, :, :qh], rel_h, 1e-5, "rel_h")
+    close(rel[:, :, qh:], rel_w, 1e-5, "rel_w")
+    ld_s = ops.pad_to(L, 4)
+    s = torch.randn(B * heads, L, ld_s, generator=g)
+    bias = (rel_h[:, :, :, None] + rel_w[:, :, None, :]).reshape(B * heads, L, L)
+    p_ref = torch.softmax(s[:, :, :L] + bias, -1)
+    p = ops.softmax(s.to(dev), L, heads=heads, rel=rel, rel_hw=(qh, qw))
+    close(p[:, :, :L], p_ref, 6e-3, "softmax+rel")
+    # backward: drel and dq
+    dp = torch.randn(B * heads, L, ld_s, generator=g)
+    pb = p[:, :, :L].float().cpu()
+    dS = pb * (dp[:, :, :L] - (pb * dp[:, :, :L]).sum(-1, keepdim=True))
+    drel_ref = torch.cat([dS.reshape(-1, L, qh, qw).sum(-1), dS.reshape(-1, L, qh, qw).sum(-2)], -1)
+    drel = torch.empty(B * heads, L, qh + qw, dtype=torch.float32, device=dev)
+    ops.softmax_bwd(dp.to(dev), p, L, 1.0, drel=drel, rel_hw=(qh, qw))
+    close(drel, drel_ref, 1e-4, "drel")
+    dq0 = rnd(B * L, heads * 32, seed=31)
+    dq = dq0.clone().to(dev)
+    ops.relpos(q.to(dev), Rh.to(dev), Rw.to(dev), B, heads, (qh, qw), (qh, qw), hd, 32, heads * 32, rel=drel, dq=dq, backward=True)
+    d = drel_ref.reshape(B, heads, qh, qw, qh + qw)
+    dq_ref = torch.einsum("bnhwk,hkc->bhwnc", d[..., :qh], Rh) + torch.einsum("bnhwk,wkc->bhwnc", d[..., qh:], Rw)
+    full = dq0.float().reshape(B, qh, qw, heads, 32).clone()
+    full[..., :hd] += dq_ref
+    close(dq, full.reshape(B * L, heads * 32), 1e-2, "relpos dq")
+
+
+def test_rope(dev):
+    from grove_amd import ops
+    rows, nh, hd = 33, 3, 64
+    x = rnd(rows, 3 * nh * hd, seed=32)
+    pos = (torch.arange(rows) * 3 % 29).int()
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2).float() / hd))
+    ang = pos.float()[:, None] * inv[None]
+    cos, sin = torch.cat([ang.cos(), ang.cos()], -1), torch.cat([ang.sin(), ang.sin()], -1)
+    ref = x.float().clone()
+    for col0 in (0, nh * hd):
+        t = x.float()[:, col0:col0 + nh * hd].reshape(rows, nh, hd)
+        rot = torch.cat([-t[..., hd // 2:], t[..., :hd // 2]], -1)
+        ref[:, col0:col0 + nh * hd] = (t * cos[:, None] + rot * sin[:, None]).reshape(rows, nh * hd)
+    y = x.clone().to(dev)
+    ops.rope_(y, pos.to(dev), 0, 2 * nh, hd, 10000.0)
+    close(y, ref, 6e-3, "rope")
+    ops.rope_(y, pos.to(dev), 0, 2 * nh, hd, 10000.0, inverse=True)
+    close(y, x.float(), 1.2e-2, "rope inverse")
+
+
+# ----------------------------------------------------------------------------- elementwise
+def test_swiglu_actbwd_add(dev):
+    from grove_amd import ops
+    rows, I = 21, 88
+    gu, dy = rnd(rows, 2 * I, seed=33), rnd(rows, I, seed=34)
+    gr = gu.float().requires_grad_(True)
+    y_ref = F.silu(gr[:, :I]) * gr[:, I:]
+    y_ref.backward(dy.float())
+    close(ops.swiglu(gu.to(dev), I), y_ref, 6e-3, "swiglu")
+    close(ops.swiglu_bwd(gu.to(dev), dy.to(dev), I), gr.grad, 8e-3, "swiglu bwd")
+    for act in (ops.ACT_RELU, ops.ACT_GELU, ops.ACT_QUICKGELU, ops.ACT_SILU):
+        pre = rnd(rows, I, seed=35 + act)
+        pr = pre.float().requires_grad_(True)
+        act_ref(pr, act).backward(dy.float())
+        close(ops.act_bwd(pre.to(dev), dy.to(dev), act), pr.grad, 8e-3, f"act_bwd {act}")
+    a, b = rnd(rows, I, seed=40), rnd(rows, I, seed=41)
+    close(ops.add(a.to(dev), b.to(dev)), a.float() + b.float(), 6e-3, "add")
+    pe = rnd(7, I, seed=42)
+    close(ops.add_bcast_rows(a.to(dev), pe.to(dev), 7), a.float() + pe.float()[torch.arange(rows) % 7], 6e-3, "add bcast")
+
+
+def test_rows_scatter_colsum_cast(dev):
+    from grove_amd import ops
+    src = rnd(30, 64, seed=43)
+    idx_s = torch.tensor([3, -1, 5, 29, 0, 0, 7], dtype=torch.int32)
+    idx_d = torch.tensor([0, 1, 2, 3, 9, -1, 4], dtype=torch.int32)
+    dst = torch.ones(10, 64, dtype=bf16, device=dev)
+    ops.copy_rows(src.to(dev), dst, 7, 64, idx_src=idx_s.to(dev), idx_dst=idx_d.to(dev))
+    ref = torch.ones(10, 64)
+    for s_, d_ in zip(idx_s.tolist(), idx_d.tolist()):
+        if d_ >= 0:
+            ref[d_] = src[s_].float() if s_ >= 0 else 0
+    close(dst, ref, 1e-7, "copy_rows")
+    acc = torch.zeros(5, 64, dtype=torch.float32, device=dev)
+    idx = (torch.arange(30) % 5).int()
+    ops.scatter_add_f32(src.to(dev), acc, idx.to(dev), 30, 64)
+    close(acc, torch.zeros(5, 64).index_add_(0, idx.long(), src.float()), 1e-5, "scatter_add")
+    x = rnd(777, 130, seed=44)
+    close(ops.colsum(x.to(dev)), x.float().sum(0), 1e-4, "colsum")
+    f = torch.randn(1003, generator=torch.Generator().manual_seed(45))
+    close(ops.to_bf16(f.to(dev)), f.to(bf16).float(), 1e-7, "cast f2b")
+    close(ops.to_f32(f.to(bf16).to(dev)), f.to(bf16).float(), 1e-7, "cast b2f")
+
+
+def test_im2col_and_pool(dev):
+    from grove_amd import ops
+    B, C, T, H, W, P = 1, 3, 2, 28, 42, 14
+    img = rnd(B, C, T, H, W, seed=46)
+    col = ops.im2col_patch(img.to(dev), P, 608)
+    ref = img.float().permute(0, 2, 1, 3, 4).reshape(B * T, C, H // P, P, W // P, P).permute(0, 2, 4, 1, 3, 5).reshape(-1, C * P * P)
+    close(col[:, :C * P * P], ref, 1e-7, "im2col")
+    assert (col[:, C * P * P:].float() == 0).all()
+    G, Cc = 2, 64
+    x = rnd(G * 8, 577, Cc, seed=47)
+    xr = x.float()[:, 1:].reshape(G, 8, 24, 24, Cc).permute(0, 4, 1, 2, 3)
+    pref = F.adaptive_avg_pool3d(xr, (8, 8, 9)).permute(0, 2, 3, 4, 1).reshape(G, 576, Cc)
+    close(ops.clip_pool(x.to(dev), G), pref, 6e-3, "clip_pool")
+
+
+def test_cross_entropy(dev):
+    from grove_amd import ops
+    R, V, ld = 9, 1003, 1008
+    logits = torch.zeros(R, ld, dtype=bf16)
+    logits[:, :V] = rnd(R, V, seed=48, scale=3)
+    labels = torch.randint(0, V, (R,), generator=torch.Generator().manual_seed(49))
+    lr = logits[:, :V].float().requires_grad_(True)
+    loss_ref = F.cross_entropy(lr, labels, reduction="sum")
+    (loss_ref * 0.1).backward()
+    dl = torch.zeros(R, ld, dtype=bf16, device=dev)
+    gs = torch.tensor([0.1], device=dev)
+    loss = ops.cross_entropy(logits.to(dev), labels.int().to(dev), V, dlogits=dl, grad_scale=gs)
+    close(loss, loss_ref.reshape(1), 1e-4, "ce loss")
+    close(dl[:, :V], lr.grad, 1e-2, "ce grad")
+
+
+# ----------------------------------------------------------------------------- decoder kernels
+@pytest.mark.parametrize("Lq,Lk,heads,d", [(6, 6, 8, 32), (6, 1024, 8, 16), (1024, 6, 8, 16), (5, 100, 2, 16)])
+def test_small_attn(dev, Lq, Lk, heads, d):
+    from grove_amd import ops
+    inst = 3
+    q, k, v = rnd(inst * Lq, heads * d, seed=50), rnd(inst * Lk, heads * d, seed=51), rnd(inst * Lk, heads * d, seed=52)
+    do = rnd(inst * Lq, heads * d, seed=53)
+    qr, kr, vr = (t.float().requires_grad_(True) for t in (q, k, v))
+
+    def heads_(t, L):
+        return t.reshape(inst, L, heads, d).transpose(1, 2)
+    att = torch.softmax(heads_(qr, Lq) @ heads_(kr, Lk).transpose(-1, -2) / math.sqrt(d), -1)
+    o_ref = (att @ heads_(vr, Lk)).transpose(1, 2).reshape(inst * Lq, heads * d)
+    o_ref.backward(do.float())
+    o = ops.small_attn(q.to(dev), k.to(dev), v.to(dev), inst, heads, d, Lq, Lk)
+    close(o, o_ref, 8e-3, "small attn fwd")
+    dq, dk, dv = ops.small_attn_bwd(q.to(dev), k.to(dev), v.to(dev), o, do.to(dev), inst, heads, d, Lq, Lk)
+    close(dq, qr.grad, 2e-2, "dq")
+    close(dk, kr.grad, 2e-2, "dk")
+    close(dv, vr.grad, 2e-2, "dv")
+
+
+def test_box_head_and_losses(dev):
+    from grove_amd import ops
+    N, D = 11, 256
+    g = torch.Generator().manual_seed(54)
+    x = torch.randn(N, D, generator=g)
+    W1, b1, W2, b2, Wo, bo = (rnd(D, D, seed=55, scale=0.05), rnd(D, seed=56, scale=0.1), rnd(4, D, seed=57, scale=0.05),
+                              rnd(4, seed=58, scale=0.1), rnd(1, D, seed=59, scale=0.05), rnd(1, seed=60))
+    xr = x.clone().requires_grad_(True)
+    params = [t.float().requires_grad_(True) for t in (W1, b1, W2, b2, Wo, bo)]
+    h_ref = torch.relu(xr @ params[0].t() + params[1])
+    box_ref = torch.sigmoid(h_ref @ params[2].t() + params[3])
+    obj_ref = (xr @ params[4].t() + params[5]).squeeze(-1)
+    dW = [t.to(dev) for t in (W1, b1, W2, b2, Wo, bo)]
+    box, obj, hidden = ops.box_head(x.to(dev), *dW)
+    close(box, box_ref, 1e-5, "box")
+    close(obj, obj_ref, 1e-5, "obj")
+    # losses vs autograd of the published torchvision GIoU formula
+    gt = torch.rand(N, 4, generator=g) * 0.5 + 0.2
+    vis = (torch.rand(N, generator=g) > 0.3).float()
+    vis[0] = 1
+
+    def to_xyxy(b):
+        cx, cy, w, h = b.unbind(-1)
+        return torch.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], -1)
+
+    def giou_sum(b1_, b2_, eps=1e-7):
+        x1, y1, x2, y2 = b1_.unbind(-1)
+        x1g, y1g, x2g, y2g = b2_.unbind(-1)
+        xk1, yk1, xk2, yk2 = torch.max(x1, x1g), torch.max(y1, y1g), torch.min(x2, x2g), torch.min(y2, y2g)
+        inter = torch.where((yk2 > yk1) & (xk2 > xk1), (xk2 - xk1) * (yk2 - yk1), torch.zeros_like(x1))
+        union = (x2 - x1) * (y2 - y1) + (x2g - x1g) * (y2g - y1g) - inter
+        iou = inter / (union + eps)
+        xc1, yc1, xc2, yc2 = torch.min(x1, x1g), torch.min(y1, y1g), torch.max(x2, x2g), torch.max(y2, y2g)
+        ac = (xc2 - xc1) * (yc2 - yc1)
+        return (1 - (iou - (ac - union) / (ac + eps))).sum()
+    m = vis.bool()
+    ngt = float(m.sum())
+    gi = giou_sum(to_xyxy(box_ref[m]), to_xyxy(gt[m]))
+    l1 = (box_ref[m] - gt[m]).abs().sum()
+    bce = F.binary_cross_entropy_with_logits(obj_ref, vis, reduction="sum")
+    total = 2.0 * (gi + l1) / ngt + 0.5 * bce / N
+    total.backward()
+    sums, dbox, dobj = ops.box_losses(box, obj, gt.to(dev), vis.to(dev), 2.0 / ngt, 0.5 / N)
+    close(sums, torch.stack([gi, l1, bce]), 1e-4, "loss sums")
+    grads = {k_: torch.zeros(s_, dtype=torch.float32, device=dev) for k_, s_ in
+             dict(dW1=(D, D), db1=(D,), dW2=(4, D), db2=(4,), dWo=(D,), dbo=(1,)).items()}
+    dx = ops.box_head_bwd(x.to(dev), dW[0], dW[2], dW[4], hidden, box, dbox, dobj, grads)
+    close(dx, xr.grad, 1e-3, "head dx")
+    for name, pr in zip(["dW1", "db1", "dW2", "db2", "dWo", "dbo"], params):
+        close(grads[name].reshape(pr.grad.shape), pr.grad, 1e-3, name)
+
+
+def test_adamw_sumsq(dev):
+    from grove_amd import ops
+    n = 1000
+    g = torch.Generator().manual_seed(61)
+    w, gr = torch.randn(n, generator=g), torch.randn(n, generator=g)
+    p = torch.nn.Parameter(w.clone())
+    opt = torch.optim.AdamW([p], lr=3e-4, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.01)
+    master, m, v = w.clone().to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    model = torch.empty(n, dtype=bf16, device=dev)
+    for step in (1, 2, 3):
+        p.grad = gr * 0.5
+        opt.step()
+        ops.adamw_step(master, model, gr.to(dev), m, v, 3e-4, 0.9, 0.95, 1e-8, 0.01, 0.5, step)
+    close(master, p.detach(), 1e-5, "adamw")
+    close(model, p.detach().to(bf16), 1e-7 + 4e-3, "adamw bf16 copy")
+    close(ops.sumsq(gr.to(dev)), (gr * gr).sum().reshape(1), 1e-5, "sumsq")
