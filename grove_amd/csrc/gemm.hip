@@ -124,12 +124,13 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(const grove_gemm_params p, 
       resolve_a_rows(tap);
       cur_tap = tap;
     }
+    const int ka = k0 - tap * k_per_tap;  // column inside the gathered A row
     if constexpr (GLDS) {
       char* la = buf + wave * (64 * 16);
       char* lb = buf + TILE_BYTES + wave * (64 * 16);
 #pragma unroll
       for (int i = 0; i < LPT; ++i) {
-        const bf16_raw* src = a_ptr[i] ? a_ptr[i] + k0 : (const bf16_raw*)g_zero_page;
+        const bf16_raw* src = a_ptr[i] ? a_ptr[i] + ka : (const bf16_raw*)g_zero_page;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(la + i * (NT * 16)), 16, 0, 0);
       }
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(const grove_gemm_params p, 
     } else {
 #pragma unroll
       for (int i = 0; i < LPT; ++i) {
-        if (a_ptr[i]) ra[i] = *(const u32x4_t*)(a_ptr[i] + k0);
+        if (a_ptr[i]) ra[i] = *(const u32x4_t*)(a_ptr[i] + ka);
         else ra[i] = u32x4_t{0u, 0u, 0u, 0u};
       }
 #pragma unroll
