@@ -245,6 +245,8 @@ def init_spec(name: str, shape, d: GroveDims):
         return (1.0, 0.05)
     if "neck.1." in name or "neck.3." in name:
         return ((1.0, 0.05) if leaf == "weight" else (0.0, 0.02))
+    if name.endswith("temporal_objectness_head.bias"):
+        return (1.9, 0.0)  # centres the synthetic objectness logits on the 0.5 threshold
     if leaf == "bias":
         return (0.0, 0.02)
     if "positional_encoding_gaussian_matrix" in name:

@@ -1,0 +1,218 @@
+"""Generates tests/golden/*.npz by running the REFERENCE (/root/reference, imported in this container
+only) on the deterministic synthetic weights/inputs of grove_amd/synthetic.py, and checks the oracle
+(oracle/grove_oracle.py) against it on the spot.
+
+    python oracle/refgen/make_goldens.py            # writes tests/golden/, prints oracle-vs-reference errors
+
+Fixtures hold OUTPUTS only (inputs and weights are regenerated from their names); large tensors are
+stored sub-sampled with the sampling rule recorded beside them.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, REPO)
+
+import ref_harness as R  # noqa: E402
+from grove_amd.synthetic import TINY, synthetic_batch  # noqa: E402
+from oracle import grove_oracle as O  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+TOK_STRIDE = 7      # CLIP / LLaMA token sub-sampling
+PIX_STRIDE = 4      # SAM embedding spatial sub-sampling
+
+
+def npf(t):
+    return t.detach().float().cpu().numpy()
+
+
+def flat_list(ll):
+    return torch.cat([x.reshape(-1) for l_ in ll for x in l_]) if any(x.numel() for l_ in ll for x in l_) else torch.zeros(0)
+
+
+def report(name, a, b):
+    a, b = torch.as_tensor(a).float(), torch.as_tensor(b).float()
+    err = (a - b).abs().max().item() if a.numel() else 0.0
+    ref = b.abs().max().item() if b.numel() else 0.0
+    print(f"  oracle vs reference  {name:28s} max|diff| {err:.3e}  (max|ref| {ref:.3e})")
+    return err
+
+
+def reference_greedy(model, d, feats, fouts, dtype, ids, max_new):
+    """Manual greedy loop over LlavaLlamaForCausalLM.forward (.generate()
+    is broken under transformers 5.x for this model)."""
+    from model.llava.model.language_model.llava_llama import LlavaLlamaForCausalLM
+    B = ids.shape[0]
+    finished = torch.zeros(B, dtype=torch.bool)
+    hidden = None
+    for _ in range(max_new):
+        out = LlavaLlamaForCausalLM.forward(model, input_ids=ids, image_features=feats, image_forward_outs=fouts,
+                                            images_dtype=dtype, use_cache=False, output_hidden_states=True)
+        hidden = out.hidden_states
+        nxt = out.logits[:, -1].argmax(-1)
+        nxt = torch.where(finished, torch.full_like(nxt, d.pad_token_id), nxt)
+        ids = torch.cat([ids, nxt[:, None]], 1)
+        finished |= nxt == d.eos_token_id
+        if finished.all():
+            break
+    return ids, hidden
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    d = TINY
+    model, sd = R.build_reference_model(d)
+    worst = 0.0
+
+    # ------------------------------------------------------------------ case A: training, ragged batch
+    batch = synthetic_batch(d, B=2, T=8, L=48, n_det=2, seed=1, ragged=True)
+    model.train()
+    out = model(**batch.as_kwargs(inference=False))
+    model.zero_grad()
+    out["loss"].backward()
+    named = dict(model.named_parameters())
+    grad_names = ["model.mm_projector.0.weight", "model.mm_projector.2.bias", "model.text_hidden_fcs.0.0.weight",
+                  "model.text_hidden_fcs.0.2.weight", "lm_head.weight", "model.embed_tokens.weight",
+                  "model.grounding_encoder.image_encoder.adapters.0.conv3d.weight",
+                  "model.grounding_encoder.image_encoder.adapters.1.alpha",
+                  "model.grounding_encoder.mask_decoder.transformer.layers.0.cross_attn_token_to_image.q_proj.weight",
+                  "model.grounding_encoder.mask_decoder.transformer.layers.1.norm4.weight",
+                  "model.grounding_encoder.mask_decoder.transformer.layers.1.mlp.lin1.weight",
+                  "model.grounding_encoder.mask_decoder.bbox_prediction_head.0.weight",
+                  "model.grounding_encoder.mask_decoder.temporal_objectness_head.weight",
+                  "model.grounding_encoder.mask_decoder.iou_token.weight"]
+    gold = {k: npf(v) for k, v in out.items()}
+    for n in grad_names:
+        g = named[n].grad
+        assert g is not None, n
+        gold["grad/" + n] = npf(g)
+    clip_grads = [n for n, p in named.items() if "vision_tower" in n and p.grad is not None]
+    assert not clip_grads, "CLIP tower is @torch.no_grad in the reference"
+    np.savez_compressed(os.path.join(OUT, "tiny_train_B2_T8_ragged_seed1.npz"), **gold)
+    # oracle check (values and gradients)
+    sdg = {k: v.clone().requires_grad_(k in grad_names) for k, v in sd.items()}
+    o = O.model_forward(sdg, d, **batch.as_kwargs(inference=False))
+    o["loss"].backward()
+    print("case A (train, ragged):")
+    for k in ("loss", "ce_loss", "giou_loss", "l1_loss", "temp_objectness_loss"):
+        worst = max(worst, report(k, o[k], out[k]))
+    for n in grad_names:
+        e = report("grad " + ".".join(n.split(".")[-3:]), sdg[n].grad, named[n].grad)
+        worst = max(worst, e / max(named[n].grad.abs().max().item(), 1e-12) * 1e-3)
+
+    # ------------------------------------------------------------------ case B: inference path + module taps
+    model.eval()
+    batch = synthetic_batch(d, B=2, T=8, L=40, n_det=3, seed=2)
+    with torch.no_grad():
+        res = model(**batch.as_kwargs(inference=True))
+        feats, fouts = model(mode="encode_images", images=batch.global_enc_images)
+        emb = model(mode="get_grounding_encoder_embs", images=batch.grounding_enc_images)
+        pe = model(mode="get_dense_pe")
+        hs = fouts.hidden_states
+        ro = model.get_model().grounding_encoder
+        # teacher-forced hidden states for a tap of the LLaMA output
+        lo = super(type(model), model).forward(images=batch.global_enc_images, input_ids=batch.input_ids,
+                                               output_hidden_states=True)
+        # raw (normalised cxcywh, un-thresholded) boxes of every (frame, DET) instance
+        dmask = model._create_det_token_mask(batch.input_ids)
+        _, pemb = model._process_hidden_states([lo.hidden_states], dmask, None)
+        nb, nl = model._generate_and_postprocess_masks(pemb, emb, batch.original_size_list, pe, infer=False)
+    gold = {
+        "pred_bboxes": npf(flat_list(res["pred_bboxes"])),
+        "pred_bboxes_counts": np.array([[x.shape[0] for x in l_] for l_ in res["pred_bboxes"]]),
+        "logits_temp_objectness": npf(flat_list(res["logits_temp_objectness"])),
+        "flat_boxes_normalised": npf(flat_list(nb).reshape(-1, 4)),
+        "image_features": npf(feats[:, ::TOK_STRIDE]),
+        "clip_hidden_m2": npf(hs[-2][:, ::TOK_STRIDE]),
+        "clip_hidden_1": npf(hs[1][:, ::TOK_STRIDE]),
+        "clip_hidden_4": npf(hs[4][:, ::TOK_STRIDE]),
+        "sam_embeddings": npf(emb[:, :, ::PIX_STRIDE, ::PIX_STRIDE]),
+        "dense_pe": npf(pe),
+        "llama_hidden": npf(lo.hidden_states[:, ::TOK_STRIDE]),
+        "tok_stride": np.array(TOK_STRIDE), "pix_stride": np.array(PIX_STRIDE),
+    }
+    np.savez_compressed(os.path.join(OUT, "tiny_infer_B2_T8_seed2.npz"), **gold)
+    with torch.no_grad():
+        o = O.model_forward(sd, d, **batch.as_kwargs(inference=True))
+        of, ohs = O.encode_images(sd, d, batch.global_enc_images)
+    print("case B (inference):")
+    worst = max(worst, report("pred_bboxes (pixels)", flat_list(o["pred_bboxes"]), flat_list(res["pred_bboxes"])) / 640)
+    worst = max(worst, report("objectness logits", flat_list(o["logits_temp_objectness"]), flat_list(res["logits_temp_objectness"])))
+    worst = max(worst, report("normalised boxes", o["flat_boxes"], flat_list(nb).reshape(-1, 4)))
+    worst = max(worst, report("image_features", of, feats))
+    worst = max(worst, report("clip hidden[-2]", ohs[-1], hs[-2]))
+    worst = max(worst, report("clip hidden[1]", ohs[1], hs[1]))
+    worst = max(worst, report("sam embeddings", o["image_embeddings"], emb))
+    worst = max(worst, report("dense_pe", O.dense_pe(sd, d), pe))
+    worst = max(worst, report("llama hidden", o["hidden"], lo.hidden_states))
+
+    # ------------------------------------------------------------------ case C: greedy evaluate
+    batch = synthetic_batch(d, B=2, T=8, L=24, n_det=1, seed=3)
+    prompt = batch.input_ids[:, :14].clone()  # un-padded, equal-length prompts (quirk Q9)
+    with torch.no_grad():
+        feats, fouts = model(mode="encode_images", images=batch.global_enc_images)
+        emb = model(mode="get_grounding_encoder_embs", images=batch.grounding_enc_images)
+        pe = model(mode="get_dense_pe")
+        ids, hidden = reference_greedy(model, d, feats, fouts, torch.float32, prompt, 12)
+        # make sure a [DET] is present so that boxes are decoded: force one token to DET and re-run teacher-forced
+        ids[:, prompt.shape[1] + 2] = d.det_token_idx
+        ids2 = ids[:, :-1]
+        from model.llava.model.language_model.llava_llama import LlavaLlamaForCausalLM
+        out2 = LlavaLlamaForCausalLM.forward(model, input_ids=ids2, image_features=feats, image_forward_outs=fouts,
+                                             images_dtype=torch.float32, use_cache=False, output_hidden_states=True)
+        mask = ids[:, 1:] == d.det_token_idx
+        mask = torch.cat([torch.zeros((2, 575), dtype=torch.bool), mask], 1)
+        _, pred_emb = model._process_hidden_states([out2.hidden_states], mask, None, infer=True)
+        boxes, logits = model._generate_and_postprocess_masks(pred_emb, emb, batch.original_size_list, pe, infer=True)
+    gold = {"prompt_len": np.array(prompt.shape[1]), "generated_ids": ids.numpy(), "greedy_ids": ids.numpy().copy(),
+            "pred_bboxes": npf(flat_list(boxes)), "logits_temp_objectness": npf(flat_list(logits)),
+            "pred_bboxes_counts": np.array([[x.shape[0] for x in l_] for l_ in boxes])}
+    with torch.no_grad():
+        of, _ = O.encode_images(sd, d, batch.global_enc_images)
+        oemb = O.sam_image_encoder(sd, d, batch.grounding_enc_images)
+        oids, _, _, _, _ = O.evaluate(sd, d, of, oemb, prompt, batch.original_size_list, max_tokens_new=12)
+    # the pure greedy stream (before the forced DET) must agree token for token
+    ids_ref_greedy, _ = reference_greedy(model, d, feats, fouts, torch.float32, prompt, 12)
+    gold["greedy_ids"] = ids_ref_greedy.numpy()
+    np.savez_compressed(os.path.join(OUT, "tiny_evaluate_B2_T8_seed3.npz"), **gold)
+    print("case C (greedy):")
+    same = bool((oids == ids_ref_greedy).all()) if oids.shape == ids_ref_greedy.shape else False
+    print(f"  oracle vs reference  greedy token ids equal: {same}  ({oids.shape[1] - prompt.shape[1]} new tokens)")
+    assert same
+    with torch.no_grad():
+        hid = O.llama_forward(sd, d, O.splice(sd, ids2, None, None, of)[0], None)
+        pe_o = O.dense_pe(sd, d)
+        embl = O.pred_embeddings(sd, d, hid, O.det_token_mask(d, ids, trailing_pad=False))
+        ob, ol, _, _ = O.decode_boxes(sd, d, embl, oemb, batch.original_size_list, pe_o, True)
+    worst = max(worst, report("forced-DET boxes (pixels)", flat_list(ob), flat_list(boxes)) / 640)
+    worst = max(worst, report("forced-DET logits", flat_list(ol), flat_list(logits)))
+
+    # ------------------------------------------------------------------ case D: literal T=16 (quirk Q1)
+    model.config.num_frames = 16
+    batch = synthetic_batch(d, B=2, T=16, L=32, n_det=1, seed=4)
+    with torch.no_grad():
+        res = model(**batch.as_kwargs(inference=True))
+    gold = {"flat_logits": npf(flat_list(res["logits_temp_objectness"])),
+            "pred_bboxes_counts": np.array([[x.shape[0] for x in l_] for l_ in res["pred_bboxes"]])}
+    np.savez_compressed(os.path.join(OUT, "tiny_infer_literalT16_seed4.npz"), **gold)
+    from dataclasses import replace
+    d16 = replace(d, num_frames=16)
+    with torch.no_grad():
+        o = O.model_forward(sd, d16, **batch.as_kwargs(inference=True))
+    print("case D (literal T=16):")
+    worst = max(worst, report("objectness logits", flat_list(o["logits_temp_objectness"]), flat_list(res["logits_temp_objectness"])))
+    model.config.num_frames = 8
+    print(f"worst normalised oracle-vs-reference error: {worst:.3e}")
+    assert worst < 2e-3, "oracle does not reproduce the reference"
+    sizes = {f: os.path.getsize(os.path.join(OUT, f)) for f in sorted(os.listdir(OUT)) if f.endswith(".npz")}
+    print("fixtures:", sizes)
+
+
+if __name__ == "__main__":
+    main()

@@ -51,7 +51,8 @@ def build_reference_model(d: GroveDims, dtype=torch.float32):
     semantics), and loads the deterministic synthetic state dict. Returns (model, state_dict)."""
     _install()
     import model.GROVE as G
-    import model.SAM.build_sam as BS
+    import importlib
+    BS = importlib.import_module("model.SAM.build_sam")
     import model.llava.model.multimodal_encoder.clip_encoder as CE
     from model.llava.model.language_model.llava_llama import Llava1Config
 

@@ -1,0 +1,96 @@
+"""Pins the CPU oracle (oracle/grove_oracle.py) to the golden vectors that oracle/refgen/make_goldens.py
+produced by running the reference itself (model/GROVE.py) on the same deterministic weights/inputs."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from grove_amd.synthetic import TINY, synthetic_batch, synthetic_state_dict
+from oracle import grove_oracle as O
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+TOL = 2e-5  # fp32 CPU vs fp32 CPU, different op order only
+
+
+def flat(ll):
+    xs = [x.reshape(-1) for l_ in ll for x in l_]
+    return torch.cat(xs) if xs else torch.zeros(0)
+
+
+def near(a, b, tol=TOL, what=""):
+    a, b = torch.as_tensor(a).float(), torch.as_tensor(b).float()
+    assert a.shape == b.shape, f"{what}: {tuple(a.shape)} vs {tuple(b.shape)}"
+    if a.numel():
+        err = (a - b).abs().max().item()
+        lim = tol * max(1.0, b.abs().max().item())
+        assert err <= lim, f"{what}: {err} > {lim}"
+
+
+@pytest.fixture(scope="module")
+def sd():
+    return synthetic_state_dict(TINY)
+
+
+def test_train_losses_and_grads(sd):
+    g = np.load(os.path.join(G, "tiny_train_B2_T8_ragged_seed1.npz"))
+    names = [k[5:] for k in g.files if k.startswith("grad/")]
+    sdg = {k: v.clone().requires_grad_(k in names) for k, v in sd.items()}
+    batch = synthetic_batch(TINY, B=2, T=8, L=48, n_det=2, seed=1, ragged=True)
+    out = O.model_forward(sdg, TINY, **batch.as_kwargs(inference=False))
+    for k in ("loss", "ce_loss", "giou_loss", "l1_loss", "temp_objectness_loss"):
+        near(out[k], g[k], what=k)
+    out["loss"].backward()
+    for n in names:
+        ref = torch.from_numpy(g["grad/" + n])
+        near(sdg[n].grad / ref.abs().max(), ref / ref.abs().max(), 1e-4, "grad " + n)
+    assert all(v.grad is None for k, v in sdg.items() if "vision_tower" in k)
+
+
+def test_inference_taps(sd):
+    g = np.load(os.path.join(G, "tiny_infer_B2_T8_seed2.npz"))
+    ts, ps = int(g["tok_stride"]), int(g["pix_stride"])
+    batch = synthetic_batch(TINY, B=2, T=8, L=40, n_det=3, seed=2)
+    with torch.no_grad():
+        out = O.model_forward(sd, TINY, **batch.as_kwargs(inference=True))
+        feats, hs = O.encode_images(sd, TINY, batch.global_enc_images)
+    near(feats[:, ::ts], g["image_features"], what="image_features")
+    near(hs[-1][:, ::ts], g["clip_hidden_m2"], what="clip hidden[-2]")
+    near(hs[1][:, ::ts], g["clip_hidden_1"], what="clip hidden[1]")
+    near(hs[4][:, ::ts], g["clip_hidden_4"], what="clip hidden[4]")
+    near(out["image_embeddings"][:, :, ::ps, ::ps], g["sam_embeddings"], what="sam embeddings")
+    near(O.dense_pe(sd, TINY), g["dense_pe"], what="dense_pe")
+    near(out["hidden"][:, ::ts], g["llama_hidden"], what="llama hidden")
+    near(out["flat_boxes"], g["flat_boxes_normalised"], what="normalised boxes")
+    near(flat(out["logits_temp_objectness"]), g["logits_temp_objectness"], what="objectness")
+    counts = np.array([[x.shape[0] for x in l_] for l_ in out["pred_bboxes"]])
+    assert (counts == g["pred_bboxes_counts"]).all()
+    near(flat(out["pred_bboxes"]) / 640, g["pred_bboxes"] / 640, what="thresholded boxes")
+
+
+def test_greedy_evaluate(sd):
+    g = np.load(os.path.join(G, "tiny_evaluate_B2_T8_seed3.npz"))
+    batch = synthetic_batch(TINY, B=2, T=8, L=24, n_det=1, seed=3)
+    prompt = batch.input_ids[:, :int(g["prompt_len"])].clone()
+    with torch.no_grad():
+        feats, _ = O.encode_images(sd, TINY, batch.global_enc_images)
+        emb = O.sam_image_encoder(sd, TINY, batch.grounding_enc_images)
+        ids, _, _, _, _ = O.evaluate(sd, TINY, feats, emb, prompt, batch.original_size_list, max_tokens_new=12)
+        assert (ids.numpy() == g["greedy_ids"]).all()
+        forced = torch.from_numpy(g["generated_ids"])
+        hid = O.llama_forward(sd, TINY, O.splice(sd, forced[:, :-1], None, None, feats)[0], None)
+        embl = O.pred_embeddings(sd, TINY, hid, O.det_token_mask(TINY, forced, trailing_pad=False))
+        boxes, logits, _, _ = O.decode_boxes(sd, TINY, embl, emb, batch.original_size_list, O.dense_pe(sd, TINY), True)
+    near(flat(logits), g["logits_temp_objectness"], what="forced-DET logits")
+    near(flat(boxes) / 640, g["pred_bboxes"] / 640, what="forced-DET boxes")
+
+
+def test_literal_T16_row_indexing(sd):
+    """Quirk Q1: at T=16 the reference feeds sample b the b-th 8-frame group of the pooled features."""
+    from dataclasses import replace
+    g = np.load(os.path.join(G, "tiny_infer_literalT16_seed4.npz"))
+    d16 = replace(TINY, num_frames=16)
+    batch = synthetic_batch(TINY, B=2, T=16, L=32, n_det=1, seed=4)
+    with torch.no_grad():
+        out = O.model_forward(sd, d16, **batch.as_kwargs(inference=True))
+    near(flat(out["logits_temp_objectness"]), g["flat_logits"], what="literal T=16 logits")
