@@ -185,6 +185,39 @@ __global__ __launch_bounds__(EB) void cast_b2f_kernel(const bf16_raw* __restrict
   }
 }
 
+
+// out += f(scale) * sum_i a[i] * b[i]   (bf16 inputs, fp32 accumulate); mode 1: f = 1 - tanh(s)^2
+__global__ __launch_bounds__(EB) void dot_kernel(const bf16_raw* __restrict__ a, const bf16_raw* __restrict__ b, float* __restrict__ out, int64_t nvec,
+                                                 const float* __restrict__ scale_ptr, int mode) {
+  __shared__ float scratch[4];
+  float s = 0.f;
+  for (int64_t t = (int64_t)blockIdx.x * EB + threadIdx.x; t < nvec; t += (int64_t)gridDim.x * EB) {
+    float x[8], y[8];
+    unpack8(*(const u32x4_t*)(a + t * 8), x);
+    unpack8(*(const u32x4_t*)(b + t * 8), y);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += x[e] * y[e];
+  }
+  s = block_sum<EB>(s, scratch);
+  if (threadIdx.x == 0) {
+    float f = 1.f;
+    if (scale_ptr) {
+      const float v = *scale_ptr;
+      if (mode == 1) { const float t = tanhf(v); f = 1.f - t * t; }
+      else if (mode == 2) f = tanhf(v);
+      else f = v;
+    }
+    atomicAdd(out, s * f);
+  }
+}
+
+// y[i] += f(scale) * x[i]  (fp32); mode 2: f = tanh(*scale_ptr), mode 0: f = *scale_ptr (or 1)
+__global__ __launch_bounds__(EB) void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, int64_t n, const float* __restrict__ scale_ptr, int mode) {
+  float f = 1.f;
+  if (scale_ptr) f = mode == 2 ? tanhf(*scale_ptr) : *scale_ptr;
+  for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < n; i += (int64_t)gridDim.x * EB) y[i] += f * x[i];
+}
+
 // Batched 2-D transpose through a 64x64 LDS tile (+1 pad): coalesced on both sides.
 __global__ __launch_bounds__(256) void transpose_kernel(const grove_transpose_params p) {
   __shared__ bf16_raw tile[64][66];
@@ -284,6 +317,20 @@ extern "C" int grove_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* 
 extern "C" int grove_cast_bf16_to_f32(const void* x, float* y, int64_t n, void* stream) {
   GROVE_CHECK(n > 0, GROVE_E_SHAPE, "cast: bad size");
   hipLaunchKernelGGL(cast_b2f_kernel, grid_for(n / 4 + 1), dim3(EB), 0, (hipStream_t)stream, (const bf16_raw*)x, y, n);
+  GROVE_LAUNCH_CHECK();
+  return GROVE_OK;
+}
+
+extern "C" int grove_dot_bf16(const void* a, const void* b, float* out, int64_t n, const float* scale_ptr, int32_t mode, void* stream) {
+  GROVE_CHECK(n > 0 && out, GROVE_E_SHAPE, "dot: bad args");
+  CHECK_VEC8(n, "dot");
+  hipLaunchKernelGGL(dot_kernel, grid_for(n / 8), dim3(EB), 0, (hipStream_t)stream, (const bf16_raw*)a, (const bf16_raw*)b, out, n / 8, scale_ptr, mode);
+  GROVE_LAUNCH_CHECK();
+  return GROVE_OK;
+}
+extern "C" int grove_axpy_f32(float* y, const float* x, int64_t n, const float* scale_ptr, int32_t mode, void* stream) {
+  GROVE_CHECK(n > 0 && y && x, GROVE_E_SHAPE, "axpy: bad args");
+  hipLaunchKernelGGL(axpy_kernel, grid_for(n), dim3(EB), 0, (hipStream_t)stream, y, x, n, scale_ptr, mode);
   GROVE_LAUNCH_CHECK();
   return GROVE_OK;
 }

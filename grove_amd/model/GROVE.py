@@ -1,0 +1,557 @@
+"""GROVEForCausalLM — the drop-in boundary of the hot path (mirror of model/GROVE.py:101-451).
+
+Same construction kwargs, the same kwargs-dispatching forward(**kwargs) (GROVE.py:138-154), the same
+return values and loss-dict keys, and a state dict with the reference's parameter names
+(SURVEY.md §8(b)). Every tensor op underneath is a hand-written gfx950 kernel reached through
+include/grove_hip.h; this file is host logic (index tables, dispatch, list plumbing) only.
+
+Frames per sequence: the reference is self-consistent only at T = 8 (quirk Q1). For T = 8*G this
+implementation defaults to the reference's own sliding-window semantics (infer_iground.py:245-259):
+every 8-frame group of a clip is an independent window with the same text. `literal_T=True`
+reproduces the reference's row indexing at T != 8 bit-for-bit in structure (sample b reads pooled
+feature row b).
+"""
+import math
+from types import SimpleNamespace
+
+import torch
+
+from .. import ops
+from ..synthetic import GroveDims, IGNORE_INDEX, IMAGE_TOKEN_INDEX, param_shapes
+from .clip import ClipTower
+from .decoder import BoxDecoder, M_ as DEC_PREFIX
+from .llama import LlamaStack
+from .sam import SamEncoder, S as SAM_PREFIX
+from .tape import Param, Tape, Var
+
+bf = torch.bfloat16
+
+
+def trainable_names(d: GroveDims):
+    """The parameters that receive gradients under the shipped freeze policy
+    (train.py::prepare_model_for_training :234-333 with --lora_r 0 --pretrained --train_mask_decoder).
+    CLIP adapters are flagged trainable there too but the tower runs under no_grad (clip_encoder.py:55),
+    so they never get a gradient and are excluded."""
+    names = []
+    for n in param_shapes(d):
+        if n in ("model.embed_tokens.weight", "lm_head.weight") or n.startswith("model.mm_projector.") \
+                or n.startswith("model.text_hidden_fcs.") or n.startswith(DEC_PREFIX) \
+                or n.startswith(SAM_PREFIX + "adapters."):
+            names.append(n)
+    return names
+
+
+class GROVEForCausalLM(torch.nn.Module):
+    def __init__(self, config=None, dims: GroveDims = None, device="cuda", state_dict=None, train=False, **kwargs):
+        super().__init__()
+        self.det_token_idx = kwargs.pop("det_token_idx")                        # GROVE.py:120 (required)
+        self.ce_loss_weight = kwargs.pop("ce_loss_weight", 1.0)                 # GROVE.py:122-125
+        self.giou_loss_weight = kwargs.pop("giou_loss_weight", 1.0)
+        self.temp_objectness_loss_weight = kwargs.pop("temp_objectness_loss_weight", 1.0)
+        d = dims if dims is not None else GroveDims()
+        d = d.__class__(**{**d.__dict__, "det_token_idx": self.det_token_idx, "out_dim": kwargs.get("out_dim", d.out_dim)})
+        self.dims = d
+        self.config = config if config is not None else SimpleNamespace()
+        self.config.num_frames = kwargs.get("num_frames", 8) or 8              # GROVE.py:117
+        self.config.temp_objectness_threshold = kwargs.get("temp_objectness_threshold", 0.5)
+        self.config.use_temp_objectness = kwargs.get("use_temp_objectness", True)
+        self.config.train_mask_decoder = kwargs.get("train_mask_decoder", False)
+        self.config.out_dim = d.out_dim
+        self.literal_T = kwargs.get("literal_T", False)
+        # dense positional encoding dtype: bf16 reproduces the reference under model.to(bf16) (quirk Q10)
+        self.pe_dtype = kwargs.get("pe_dtype", torch.bfloat16)
+        self.dev = torch.device(device)
+        if self.dev.type != "cuda":
+            raise RuntimeError("grove_amd runs on MI355X only: there is no CPU path (use oracle/ for a CPU check)")
+        self._train_mode = train
+        self._sd = {}
+        self._grad = {}
+        self._flat_grad = None
+        self._alloc_params(state_dict)
+        self._build_engines()
+        self._ctx = None
+
+    # ------------------------------------------------------------------ parameters / state dict
+    def _alloc_params(self, state_dict):
+        d = self.dims
+        for name, shape in param_shapes(d).items():
+            src = state_dict[name] if state_dict is not None and name in state_dict else None
+            if name.startswith(SAM_PREFIX + "adapters.") and name.endswith("conv3d.weight"):
+                # stored tap-major [Co, kt, kh, kw, Ci]; the canonical Conv3d layout is a permuted VIEW of it
+                Co, Ci = shape[0], shape[1]
+                packed = torch.zeros((Co, 3, 3, 3, Ci), dtype=bf, device=self.dev)
+                if src is not None:
+                    packed.copy_(src.to(self.dev).permute(0, 2, 3, 4, 1))
+                self._sd[name] = packed.permute(0, 4, 1, 2, 3)
+            else:
+                t = torch.zeros(shape, dtype=bf, device=self.dev)
+                if src is not None:
+                    t.copy_(src.to(self.dev))
+                self._sd[name] = t
+        if self._train_mode:
+            names = trainable_names(d)
+            total = sum(self._sd[n].numel() for n in names)
+            self._flat_grad = torch.zeros(total, dtype=torch.float32, device=self.dev)
+            off = 0
+            for n in names:
+                k = self._sd[n].numel()
+                shape = tuple(self._sd[n].shape)
+                if n.endswith("conv3d.weight"):
+                    shape = (shape[0], 27 * shape[1])  # gradient lives in the packed (tap-major) layout
+                self._grad[n] = self._flat_grad[off:off + k].view(shape)
+                off += k
+            self.trainable = names
+
+    def state_dict(self, *a, **k):
+        return dict(self._sd)
+
+    def load_state_dict(self, sd, strict=False, **k):
+        missing = [n for n in self._sd if n not in sd]
+        unexpected = [n for n in sd if n not in self._sd]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"missing {missing[:3]} unexpected {unexpected[:3]}")
+        for n, v in sd.items():
+            if n in self._sd:
+                self._sd[n].copy_(v.to(self.dev))
+        self._build_engines()
+        return SimpleNamespace(missing_keys=missing, unexpected_keys=unexpected)
+
+    def named_parameters(self, *a, **k):
+        return iter(self._sd.items())
+
+    def parameters(self, *a, **k):
+        return iter(self._sd.values())
+
+    def _build_engines(self):
+        d, sd, dev, tr = self.dims, self._sd, self.dev, self._train_mode
+        self.clip = ClipTower(sd, d, dev)
+        self.llama = LlamaStack(sd, d, dev, train=tr)
+        self.sam = SamEncoder(sd, d, dev, train=tr, grads=self._grad)
+        self.decoder = BoxDecoder(sd, d, dev, grads=self._grad, pe_dtype=self.pe_dtype)
+
+    def P(self, name):
+        return Param(self._sd[name], self._grad.get(name))
+
+    # ------------------------------------------------------------------ modes (GROVE.py:138-154)
+    def forward(self, **kwargs):
+        if "past_key_values" in kwargs:
+            raise NotImplementedError("cached single-step LM forward is reached through evaluate()/generate() in grove_amd")
+        mode = kwargs.get("mode")
+        if mode == "encode_images":
+            return self.encode_images(kwargs["images"])
+        if mode == "get_grounding_encoder_embs":
+            return self.get_grounding_encoder_embs(kwargs["images"])
+        if mode == "get_dense_pe":
+            return self.decoder.pe_nchw
+        if mode == "evaluate":
+            return self.evaluate(kwargs["image_features"], kwargs.get("image_forward_outs"), kwargs.get("images_dtype"),
+                                 kwargs["image_embeddings"], kwargs["input_ids"], kwargs["original_size_list"],
+                                 max_tokens_new=kwargs["max_tokens_new"], bboxes=kwargs.get("bboxes"),
+                                 token_embeddings=kwargs.get("token_embeddings"), dense_pe=kwargs.get("dense_pe"),
+                                 device=kwargs.get("device"))
+        return self.model_forward(**kwargs)
+
+    def encode_images(self, images, tape=None):
+        """llava_with_region_arch.py:79-82 -> (image_features [B*T/8, 576, hidden], hidden_states[-2])."""
+        pooled, hs = self.clip.forward(images.to(bf))
+        G = pooled.shape[0]
+        tp = tape if tape is not None else Tape(enabled=False)
+        x = Var(pooled.view(G * 576, -1), needs_grad=False)
+        h = tp.linear(x, self.P("model.mm_projector.0.weight"), self.P("model.mm_projector.0.bias"), act=ops.ACT_GELU)
+        y = tp.linear(h, self.P("model.mm_projector.2.weight"), self.P("model.mm_projector.2.bias"))
+        if tape is not None:
+            return y, hs
+        return y.data.view(G, 576, -1), SimpleNamespace(hidden_states=(hs,))
+
+    def get_grounding_encoder_embs(self, images):
+        """GROVE.py:134-136 -> [B*T, 256, g, g] (NCHW like the reference; internally channels-last)."""
+        rows, _ = self.sam.forward(images.to(bf))
+        F, g = rows.shape[0], self.dims.sam_grid
+        out = torch.empty((F, rows.shape[2], g * g), dtype=bf, device=self.dev)
+        ops.transpose(rows, g * g, rows.shape[2], rows.shape[2], out, g * g, batch=(F, 1), s_in=(g * g * rows.shape[2], 0),
+                      s_out=(rows.shape[2] * g * g, 0))
+        return out.view(F, rows.shape[2], g, g)
+
+    # ------------------------------------------------------------------ host-side index construction
+    def _splice_plan(self, input_ids, labels, attention_masks, feat_row_of_seq):
+        """llava_with_region_arch.py:127-438 as index tables: for every row of the padded [B, S] embedding
+        matrix, which embedding-table row or which projected visual token it is."""
+        ids = input_ids.cpu()
+        B, L = ids.shape
+        lab = labels.cpu() if labels is not None else None
+        am = attention_masks.cpu() if attention_masks is not None else None
+        seq_tok, seq_lab, seq_mask, vis_pos = [], [], [], []
+        for b in range(B):
+            row = ids[b]
+            pos = (row == IMAGE_TOKEN_INDEX).nonzero().flatten()
+            if pos.numel() == 0:
+                seq_tok.append(row.clone())
+                seq_lab.append(lab[b].clone() if lab is not None else None)
+                seq_mask.append(am[b].clone() if am is not None else None)
+                vis_pos.append(-1)
+                continue
+            s = int(pos[0])
+            seq_tok.append(torch.cat([row[:s], torch.full((576,), -1, dtype=row.dtype), row[s + 1:]]))
+            if lab is not None:
+                seq_lab.append(torch.cat([lab[b, :s], torch.full((576,), IGNORE_INDEX, dtype=lab.dtype), lab[b, s + 1:]]))
+            if am is not None:
+                seq_mask.append(torch.cat([torch.ones(575, dtype=torch.bool), am[b]]))
+            vis_pos.append(s)
+        S = max(t.numel() for t in seq_tok)
+        tok = torch.full((B, S), -1, dtype=torch.int32)
+        new_lab = torch.full((B, S), IGNORE_INDEX, dtype=torch.int64)
+        kv = torch.full((B,), S, dtype=torch.int32)
+        vis_dst, vis_src = [], []
+        for b in range(B):
+            n = seq_tok[b].numel()
+            tok[b, :n] = seq_tok[b].to(torch.int32)
+            if lab is not None:
+                new_lab[b, :n] = seq_lab[b]
+            if am is not None:
+                # right padding => valid length = last True + 1 (mask is a prefix in every caller, dataset.py:22-35)
+                m = torch.zeros(S, dtype=torch.bool)
+                m[:n] = seq_mask[b]
+                nz = m.nonzero().flatten()
+                kv[b] = int(nz[-1]) + 1 if nz.numel() else 1
+            if vis_pos[b] >= 0:
+                vis_dst.append(b * S + vis_pos[b] + torch.arange(576))
+                vis_src.append(int(feat_row_of_seq[b]) * 576 + torch.arange(576))
+        plan = SimpleNamespace(B=B, S=S, L=L)
+        plan.tok = tok.reshape(-1).to(self.dev)
+        plan.labels = new_lab if lab is not None else None
+        plan.kv_len = kv.to(self.dev) if am is not None else None
+        plan.vis_dst = torch.cat(vis_dst).to(torch.int32).to(self.dev) if vis_dst else None
+        plan.vis_src = torch.cat(vis_src).to(torch.int32).to(self.dev) if vis_src else None
+        return plan
+
+    def _embed(self, plan, feats_rows, token_embeddings=None):
+        table = token_embeddings if token_embeddings is not None else self._sd["model.embed_tokens.weight"]
+        H = self.dims.hidden
+        x = torch.empty((plan.B * plan.S, H), dtype=bf, device=self.dev)
+        ops.copy_rows(table, x, plan.B * plan.S, H, idx_src=plan.tok)
+        if plan.vis_dst is not None:
+            ops.copy_rows(feats_rows, x, plan.vis_dst.numel(), H, idx_src=plan.vis_src, idx_dst=plan.vis_dst)
+        return x
+
+    def _det_rows(self, ids_cpu, S, trailing_pad=True):
+        """GROVE.py:200-205 / :427-430: hidden row (b, 575 + j) for every j with ids[b, j+1] == [DET]."""
+        B = ids_cpu.shape[0]
+        rows, counts = [], []
+        for b in range(B):
+            j = (ids_cpu[b, 1:] == self.det_token_idx).nonzero().flatten()
+            rows.append(b * S + 575 + j)
+            counts.append(int(j.numel()))
+        return torch.cat(rows).to(torch.int32), counts
+
+    # ------------------------------------------------------------------ the per-clip hot path
+    def _windows(self, global_enc_images, grounding_enc_images, input_ids, labels, attention_masks, lists):
+        """T = 8*G -> B*G independent 8-frame windows (default semantics for T != 8)."""
+        B, C, T, H, W = global_enc_images.shape
+        G = T // 8
+        if G == 1 or self.literal_T:
+            return global_enc_images, grounding_enc_images, input_ids, labels, attention_masks, lists, T, 1
+        gi = global_enc_images.reshape(B, C, G, 8, H, W).permute(0, 2, 1, 3, 4, 5).reshape(B * G, C, 8, H, W).contiguous()
+        s = grounding_enc_images
+        si = s.reshape(B, s.shape[1], G, 8, s.shape[3], s.shape[4]).permute(0, 2, 1, 3, 4, 5).reshape(B * G, s.shape[1], 8, s.shape[3], s.shape[4]).contiguous()
+        rep = lambda t: t.repeat_interleave(G, 0) if t is not None else None  # noqa: E731
+        new_lists = []
+        for lst in lists:
+            if lst is None:
+                new_lists.append(None)
+            else:
+                new_lists.append([lst[b][g * 8:(g + 1) * 8] for b in range(B) for g in range(G)])
+        return gi, si, rep(input_ids), rep(labels), rep(attention_masks), new_lists, 8, G
+
+    def model_forward(self, global_enc_images, grounding_enc_images, bboxes_region=None, input_ids=None, labels=None,
+                      attention_masks=None, offset=None, bboxes_list=None, temp_objectness_labels_list=None,
+                      original_size_list=None, inference=False, **kwargs):
+        """GROVE.py:156-198. Training returns the loss dict (keys :380-381) and keeps what backward() needs;
+        inference returns {"pred_bboxes", "logits_temp_objectness"}."""
+        assert bboxes_region is None, "the region encoder is dead on GROVE's path (SURVEY.md §2 row 10)"
+        d = self.dims
+        B0, T0 = global_enc_images.shape[0], global_enc_images.shape[2]
+        (gimg, simg, ids, labs, amask, (boxes_l, vis_l), Tseq, G) = self._windows(
+            global_enc_images, grounding_enc_images, input_ids, labels, attention_masks,
+            [bboxes_list, temp_objectness_labels_list])
+        B = ids.shape[0]
+        train = (not inference) and self._train_mode
+        tp = Tape(enabled=train)
+        # 1. grounding encoder (GROVE.py:162)
+        emb_rows, sam_ctx = self.sam.forward(simg.to(bf), save=train)
+        F = emb_rows.shape[0]
+        emb_rows2 = emb_rows.view(F * d.sam_grid ** 2, -1)
+        # 2-3. global encoder + projector, splice, LLaMA (GROVE.py:170-176; llava_llama.py:88-109)
+        feats, _ = self.encode_images(gimg, tape=tp)
+        feat_row = list(range(B))  # image_features[cur_image_idx] (llava_with_region_arch.py:156): row b
+        plan = self._splice_plan(ids, None if inference else labs, None if inference else amask, feat_row)
+        x = self._embed(plan, feats.data)
+        hidden, llama_ctx = self.llama.forward(x, plan.B, plan.S, kv_len=plan.kv_len, save=train)
+        S = plan.S
+        H = d.hidden
+        out = {}
+        ce_state = None
+        if not inference:
+            # 4. lm_head + shifted CE on the labelled rows only (llava_llama.py:111-125)
+            lab = plan.labels
+            valid = (lab[:, 1:] != IGNORE_INDEX)
+            bi, ti = valid.nonzero(as_tuple=True)
+            rows = (bi * S + ti).to(torch.int32).to(self.dev)
+            tgt = lab[bi, ti + 1].to(torch.int32).to(self.dev)
+            R = int(rows.numel())
+            hrows = torch.empty((max(R, 1), H), dtype=bf, device=self.dev)
+            ops.copy_rows(hidden, hrows, R, H, idx_src=rows)
+            hv = Var(hrows[:R])
+            Vp = ops.pad_to(d.vocab, 8)
+            logits = torch.empty((R, Vp), dtype=bf, device=self.dev)
+            gs = torch.full((1,), self.ce_loss_weight / max(R, 1), dtype=torch.float32, device=self.dev)
+            dlogits = torch.zeros_like(logits) if train else None
+            if R > 0:
+                ops.linear(hv.data, self._sd["lm_head.weight"], out=logits)
+                loss_sum = ops.cross_entropy(logits, tgt, d.vocab, dlogits=dlogits, grad_scale=gs)
+            else:
+                loss_sum = torch.zeros(1, dtype=torch.float32, device=self.dev)
+            ce_loss = loss_sum[0] * (self.ce_loss_weight / max(R, 1))
+            ce_state = (hv, dlogits, rows, R)
+        # 5. [DET] rows -> text_hidden_fcs -> per-frame instances (GROVE.py:248-268)
+        det_rows, counts = self._det_rows(ids.cpu(), S)
+        det_rows = det_rows.to(self.dev)
+        n_det = int(det_rows.numel())
+        pred_boxes, pred_logits = [], []
+        if n_det == 0:
+            box = torch.zeros((0, 4), dtype=torch.float32, device=self.dev)
+            obj = torch.zeros((0,), dtype=torch.float32, device=self.dev)
+            dec_state = None
+            N = 0
+        else:
+            drows = torch.empty((n_det, H), dtype=bf, device=self.dev)
+            ops.copy_rows(hidden, drows, n_det, H, idx_src=det_rows)
+            dv = Var(drows)
+            h1 = tp.linear(dv, self.P("model.text_hidden_fcs.0.0.weight"), self.P("model.text_hidden_fcs.0.0.bias"), act=ops.ACT_RELU)
+            te = tp.linear(h1, self.P("model.text_hidden_fcs.0.2.weight"), self.P("model.text_hidden_fcs.0.2.bias"))
+            # instance order = (sequence b, frame t, det k)  (repeat_interleave + boolean gather, GROVE.py:254-257)
+            inst_det, inst_frame = [], []
+            base = 0
+            for b in range(B):
+                for t in range(Tseq):
+                    inst_det += list(range(base, base + counts[b]))
+                    inst_frame += [b * Tseq + t] * counts[b]
+                base += counts[b]
+            inst_det_t = torch.tensor(inst_det, dtype=torch.int32, device=self.dev)
+            inst_frame_t = torch.tensor(inst_frame, dtype=torch.int32, device=self.dev)
+            N = len(inst_det)
+            text = torch.empty((N, d.out_dim), dtype=bf, device=self.dev)
+            ops.copy_rows(te.data, text, N, d.out_dim, idx_src=inst_det_t)
+            text_var = Var(text)
+            box, obj, dec_state = self.decoder.forward(emb_rows2, text_var, inst_frame_t, train=train)
+        # 6. split per clip / frame (GROVE.py:297-331)
+        flat_box, flat_obj = box, obj
+        off = 0
+        box_c, obj_c = box.cpu() if inference else None, obj.cpu() if inference else None
+        thr = self.config.temp_objectness_threshold
+        for b in range(B):
+            bl, ll = [], []
+            for t in range(Tseq):
+                n = counts[b]
+                if inference:
+                    Wd, Hd = original_size_list[b // G]
+                    bb = box_c[off:off + n]
+                    ub = torch.stack([bb[:, 0] * Wd, bb[:, 1] * Hd, bb[:, 2] * Wd, bb[:, 3] * Hd], -1)
+                    xy = torch.stack([ub[:, 0] - ub[:, 2] / 2, ub[:, 1] - ub[:, 3] / 2, ub[:, 0] + ub[:, 2] / 2, ub[:, 1] + ub[:, 3] / 2], -1)
+                    lo = obj_c[off:off + n]
+                    bl.append(xy[torch.sigmoid(lo) > thr] if self.config.use_temp_objectness else xy)
+                    ll.append(lo)
+                else:
+                    bl.append(box[off:off + n])
+                    ll.append(obj[off:off + n])
+                off += n
+            pred_boxes.append(bl)
+            pred_logits.append(ll)
+        # regroup windows into clips
+        if G > 1:
+            pred_boxes = [sum((pred_boxes[b * G + g] for g in range(G)), []) for b in range(B0)]
+            pred_logits = [sum((pred_logits[b * G + g] for g in range(G)), []) for b in range(B0)]
+        if inference:
+            return {"pred_bboxes": pred_boxes, "logits_temp_objectness": pred_logits if self.config.use_temp_objectness else None,
+                    "flat_boxes": flat_box, "flat_logits": flat_obj, "hidden": hidden.view(B, S, H),
+                    "image_embeddings": emb_rows}
+        # 7. losses (GROVE.py:339-381) in fp32 on device
+        gt = torch.zeros((max(N, 1), 4), dtype=torch.float32)
+        vis = torch.zeros((max(N, 1),), dtype=torch.float32)
+        n_gt = 0
+        off = 0
+        for b in range(B):
+            for t in range(Tseq):
+                v = vis_l[b][t].float().cpu()
+                gb = boxes_l[b][t].float().cpu()
+                assert gb.shape[0] == int(v.sum()), "Number of ground truth bboxes and objectness labels do not match"
+                n = counts[b]
+                vis[off:off + n] = v
+                if gb.shape[0]:
+                    gt[off:off + n][v.bool()] = gb
+                n_gt += gb.shape[0]
+                off += n
+        wb = self.giou_loss_weight / (n_gt + 1e-8)
+        wo = self.temp_objectness_loss_weight / (N + 1e-8)
+        if N > 0:
+            sums, dbox, dobj = ops.box_losses(box, obj if self.config.use_temp_objectness else None, gt.to(self.dev), vis.to(self.dev),
+                                              wb, wo, want_grad=train)
+        else:
+            sums, dbox, dobj = torch.zeros(3, device=self.dev), None, None
+        giou, l1, bce = sums[0] * wb, sums[1] * wb, sums[2] * wo
+        out = {"loss": ce_loss + giou + l1 + bce, "ce_loss": ce_loss, "giou_loss": giou, "l1_loss": l1,
+               "temp_objectness_loss": bce}
+        if not self.config.use_temp_objectness:
+            out.pop("temp_objectness_loss")
+            out["loss"] = ce_loss + giou + l1
+        out["flat_boxes"], out["flat_logits"] = flat_box, flat_obj
+        if train:
+            self._ctx = SimpleNamespace(tp=tp, sam_ctx=sam_ctx, llama_ctx=llama_ctx, plan=plan, feats=feats, ce_state=ce_state,
+                                        det=(dv, te, inst_det_t, det_rows, n_det) if n_det else None, dec_state=dec_state,
+                                        dbox=dbox, dobj=dobj, N=N, F=F, hidden_shape=(plan.B * plan.S, H))
+        return out
+
+    # ------------------------------------------------------------------ backward of the last training forward
+    def zero_grad(self, set_to_none=False):
+        if self._flat_grad is not None:
+            self._flat_grad.zero_()
+
+    def backward(self, loss=None):
+        """Back-propagates the loss of the last training forward (the reference's model_engine.backward(loss),
+        train.py:770). Gradients are ACCUMULATED into the flat fp32 buffer (self._flat_grad)."""
+        c = self._ctx
+        assert c is not None, "backward() needs a preceding training forward"
+        d = self.dims
+        H = d.hidden
+        g2 = d.sam_grid ** 2
+        rowsN, _ = c.hidden_shape
+        d_hidden = torch.zeros((rowsN, H), dtype=bf, device=self.dev)
+        d_emb = torch.zeros((c.F * g2, d.sam_out), dtype=torch.float32, device=self.dev)
+        # decoder + heads
+        if c.dec_state is not None:
+            self.decoder.backward(c.dec_state, c.dbox, c.dobj, d_emb)
+            dv, te, inst_det_t, det_rows, n_det = c.det
+            dte = torch.zeros((n_det, d.out_dim), dtype=torch.float32, device=self.dev)
+            ops.scatter_add_f32(c.dec_state["text"].grad, dte, inst_det_t, c.N, d.out_dim)
+            te.grad = ops.to_bf16(dte)
+        # lm_head: wgrad + dgrad on the labelled rows
+        hv, dlogits, rows, R = c.ce_state
+        if R > 0:
+            Vv = d.vocab
+            Mp = ops.pad_to(R, 32)
+            dlT = torch.empty((Vv, Mp), dtype=bf, device=self.dev)
+            ops.transpose(dlogits, R, Vv, dlogits.stride(0), dlT, Mp, pad_to_cols=Mp)
+            hT = torch.empty((H, Mp), dtype=bf, device=self.dev)
+            ops.transpose(hv.data, R, H, H, hT, Mp, pad_to_cols=Mp)
+            ops.gemm_raw(dlT, hT, self._grad["lm_head.weight"], Vv, H, Mp, Mp, Mp, H, accumulate=True)
+            Vk = ops.pad_to(Vv, 32)
+            wT = torch.zeros((H, Vk), dtype=bf, device=self.dev)
+            ops.transpose(self._sd["lm_head.weight"], Vv, H, H, wT, Vk, pad_to_cols=Vk)
+            dl = dlogits
+            if dlogits.shape[1] != Vk:
+                dl = torch.zeros((R, Vk), dtype=bf, device=self.dev)
+                dl[:, :dlogits.shape[1]].copy_(dlogits)  # column re-pad of a tiny [R, V] matrix (plumbing)
+            dh = ops.linear(dl, wT)
+            ops.copy_rows(dh, d_hidden, R, H, idx_dst=rows, accumulate=True)
+        # text_hidden_fcs (tape) -> d hidden at the DET rows;  projector closures run later with feats.grad set
+        c.tp_fns = c.tp.fns
+        if c.det is not None:
+            dv, te, inst_det_t, det_rows, n_det = c.det
+            # run only the text_hidden_fcs closures now (they were pushed last)
+            fns = c.tp.fns[-2:]
+            c.tp.fns = c.tp.fns[:-2]
+            for fn in reversed(fns):
+                fn()
+            ops.copy_rows(dv.grad, d_hidden, n_det, H, idx_dst=det_rows, accumulate=True)
+        # LLaMA (dgrad only)
+        dx = self.llama.backward(c.llama_ctx, d_hidden)
+        # splice backward: visual rows -> projector; text rows -> embed_tokens
+        plan = c.plan
+        if plan.vis_dst is not None:
+            nv = plan.vis_dst.numel()
+            dfe = torch.zeros_like(c.feats.data)
+            ops.copy_rows(dx, dfe, nv, H, idx_src=plan.vis_dst, idx_dst=plan.vis_src)
+            c.feats.grad = dfe
+        ops.scatter_add_f32(dx, self._grad["model.embed_tokens.weight"], plan.tok, plan.B * plan.S, H)
+        c.tp.backward()  # mm_projector
+        # SAM adapters
+        self.sam.backward(c.sam_ctx, ops.to_bf16(d_emb))
+        self._ctx = None
+
+    # ------------------------------------------------------------------ generation (GROVE.py:412-451)
+    @torch.no_grad()
+    def generate_greedy(self, image_features, input_ids, max_new_tokens, token_embeddings=None, eos_token_id=None, pad_token_id=None):
+        """HF greedy decoding (num_beams=1, do_sample=False) restated: rows finish at eos and are padded with
+        pad; returns (sequences incl. -200, hidden of every fed position [B, L+575+new-1, H])."""
+        d = self.dims
+        eos = d.eos_token_id if eos_token_id is None else eos_token_id
+        pad = d.pad_token_id if pad_token_id is None else pad_token_id
+        ids = input_ids.clone()
+        B = ids.shape[0]
+        finished = torch.zeros(B, dtype=torch.bool, device=ids.device)
+        feats = image_features.reshape(-1, image_features.shape[-1])
+        hidden = None
+        S = 0
+        for _ in range(max_new_tokens):
+            plan = self._splice_plan(ids, None, None, list(range(B)))
+            x = self._embed(plan, feats, token_embeddings)
+            hidden, _ = self.llama.forward(x, plan.B, plan.S)
+            S = plan.S
+            last = torch.empty((B, d.hidden), dtype=bf, device=self.dev)
+            ops.copy_rows(hidden, last, B, d.hidden, idx_src=(torch.arange(B, dtype=torch.int32, device=self.dev) * S + S - 1))
+            logits = ops.linear(last, self._sd["lm_head.weight"], out_dtype=torch.float32)
+            nxt = logits.argmax(-1).to(ids.device)  # argmax over one [B, V] row block (index selection, not arithmetic)
+            nxt = torch.where(finished, torch.full_like(nxt, pad), nxt)
+            ids = torch.cat([ids, nxt[:, None]], 1)
+            finished = finished | (nxt == eos)
+            if bool(finished.all()):
+                break
+        return ids, hidden.view(B, S, d.hidden)
+
+    @torch.no_grad()
+    def evaluate(self, image_features, image_forward_outs, images_dtype, image_embeddings, input_ids, orig_sizes,
+                 max_tokens_new=32, bboxes=None, token_embeddings=None, dense_pe=None, device=None):
+        d = self.dims
+        ids, hidden = self.generate_greedy(image_features, input_ids, max_tokens_new, token_embeddings)
+        B, S, H = hidden.shape
+        det_rows, counts = self._det_rows(ids.cpu(), S, trailing_pad=False)
+        Tseq = self.config.num_frames
+        # image_embeddings arrive NCHW [F,256,g,g] (mode get_grounding_encoder_embs) -> channels-last rows
+        F = image_embeddings.shape[0]
+        g2 = d.sam_grid ** 2
+        emb_rows = torch.empty((F, g2, d.sam_out), dtype=bf, device=self.dev)
+        ops.transpose(image_embeddings.contiguous(), d.sam_out, g2, g2, emb_rows, d.sam_out, batch=(F, 1), s_in=(d.sam_out * g2, 0),
+                      s_out=(g2 * d.sam_out, 0))
+        n_det = int(det_rows.numel())
+        boxes, logits = [[torch.zeros(0, 4) for _ in range(Tseq)] for _ in range(B)], [[torch.zeros(0) for _ in range(Tseq)] for _ in range(B)]
+        if n_det:
+            det_rows = det_rows.to(self.dev)
+            drows = torch.empty((n_det, H), dtype=bf, device=self.dev)
+            ops.copy_rows(hidden.view(B * S, H), drows, n_det, H, idx_src=det_rows)
+            h1 = ops.linear(drows, self._sd["model.text_hidden_fcs.0.0.weight"], self._sd["model.text_hidden_fcs.0.0.bias"], act=ops.ACT_RELU)
+            te = ops.linear(h1, self._sd["model.text_hidden_fcs.0.2.weight"], self._sd["model.text_hidden_fcs.0.2.bias"])
+            inst_det, inst_frame, base = [], [], 0
+            for b in range(B):
+                for t in range(Tseq):
+                    inst_det += list(range(base, base + counts[b]))
+                    inst_frame += [b * Tseq + t] * counts[b]
+                base += counts[b]
+            N = len(inst_det)
+            text = torch.empty((N, d.out_dim), dtype=bf, device=self.dev)
+            ops.copy_rows(te, text, N, d.out_dim, idx_src=torch.tensor(inst_det, dtype=torch.int32, device=self.dev))
+            box, obj, _ = self.decoder.forward(emb_rows.view(F * g2, -1), Var(text), torch.tensor(inst_frame, dtype=torch.int32, device=self.dev))
+            box_c, obj_c, off = box.cpu(), obj.cpu(), 0
+            thr = self.config.temp_objectness_threshold
+            for b in range(B):
+                for t in range(Tseq):
+                    n = counts[b]
+                    Wd, Hd = orig_sizes[b]
+                    bb = box_c[off:off + n]
+                    ub = torch.stack([bb[:, 0] * Wd, bb[:, 1] * Hd, bb[:, 2] * Wd, bb[:, 3] * Hd], -1)
+                    xy = torch.stack([ub[:, 0] - ub[:, 2] / 2, ub[:, 1] - ub[:, 3] / 2, ub[:, 0] + ub[:, 2] / 2, ub[:, 1] + ub[:, 3] / 2], -1)
+                    lo = obj_c[off:off + n]
+                    boxes[b][t] = xy[torch.sigmoid(lo) > thr] if self.config.use_temp_objectness else xy
+                    logits[b][t] = lo
+                    off += n
+        if self.config.use_temp_objectness:
+            return ids, boxes, logits
+        return ids, boxes

@@ -1,0 +1,152 @@
+"""Prompt encoder + two-way transformer + box / temporal-objectness heads on the HIP kernels.
+
+Host-side mirror of model/SAM/modeling/{prompt_encoder,transformer,mask_decoder}.py for the "query"
+branch GROVE uses (mask_decoder.py:164-205). All N = sum(reps) (frame, [DET]) instances are batched:
+tokens [N*6, 256], image keys [N*g*g, 256] (channels-last rows gathered per instance straight from
+the SAM embeddings — the reference's index_select + dense-embedding add at :181-186). Projections are
+MFMA GEMMs; the 6-token attentions are wavefront-reduced kernels; the last LayerNorm, the box MLP,
+the sigmoid and the objectness logit stay in fp32 (SURVEY.md §7 vii).
+"""
+import math
+
+import torch
+
+from .. import ops
+from .tape import Param, Tape, Var
+
+M_ = "model.grounding_encoder.mask_decoder."
+PE_ = "model.grounding_encoder.prompt_encoder."
+bf = torch.bfloat16
+
+
+def dense_pe_rows(gauss, g, dtype):
+    """PositionEmbeddingRandom.forward (prompt_encoder.py:216-229) evaluated once with the identical torch
+    op sequence in the model dtype (quirk Q10: the reference computes it in bf16 under model.to(bf16));
+    input-independent, so it is an init-time constant, returned as token rows [g*g, 256]."""
+    G = gauss.to(dtype)
+    grid = torch.ones((g, g), device=G.device, dtype=dtype)
+    y = (grid.cumsum(dim=0) - 0.5) / g
+    x = (grid.cumsum(dim=1) - 0.5) / g
+    c = 2 * torch.stack([x, y], dim=-1) - 1
+    c = 2 * math.pi * (c @ G)
+    pe = torch.cat([torch.sin(c), torch.cos(c)], dim=-1)  # [g, g, 256]
+    return pe.reshape(g * g, -1)
+
+
+class BoxDecoder:
+    def __init__(self, sd, d, device, grads=None, pe_dtype=torch.bfloat16):
+        self.d, self.dev = d, device
+        self.grads = grads or {}
+        self.sd = sd
+        g = d.sam_grid
+        self.key_pe = dense_pe_rows(sd[PE_ + "pe_layer.positional_encoding_gaussian_matrix"], g, pe_dtype).to(bf).contiguous()
+        self.pe_nchw = self.key_pe.float().reshape(g, g, -1).permute(2, 0, 1).unsqueeze(0).to(pe_dtype)
+
+    def P(self, name):
+        return Param(self.sd[name], self.grads.get(name))
+
+    def _attn(self, tp, prefix, q, k, v, inst, Lq, Lk, internal, residual=None):
+        d = self.d
+        qp = tp.linear(q, self.P(prefix + "q_proj.weight"), self.P(prefix + "q_proj.bias"))
+        kp = tp.linear(k, self.P(prefix + "k_proj.weight"), self.P(prefix + "k_proj.bias"))
+        vp = tp.linear(v, self.P(prefix + "v_proj.weight"), self.P(prefix + "v_proj.bias"))
+        o = tp.small_attn(qp, kp, vp, inst, d.dec_heads, internal // d.dec_heads, Lq, Lk)
+        return tp.linear(o, self.P(prefix + "out_proj.weight"), self.P(prefix + "out_proj.bias"), residual=residual)
+
+    def forward(self, image_emb_rows, text_embeds, frame_of_instance, train=False):
+        """image_emb_rows: bf16 [F*g*g, 256] channels-last SAM embeddings; text_embeds: Var bf16 [N, 256]
+        ([DET] embeddings, one per (frame, DET) instance); frame_of_instance: int32 [N] frame index.
+        Returns (box f32 [N,4], obj f32 [N], state for backward)."""
+        d = self.d
+        D, g2 = d.dec_dim, d.sam_grid ** 2
+        N = text_embeds.data.shape[0]
+        tp = Tape(enabled=train)
+        # tokens = [iou | 4 mask | text]  (mask_decoder.py:166-173)
+        out_tok = torch.cat([self.sd[M_ + "iou_token.weight"], self.sd[M_ + "mask_tokens.weight"]], 0)  # [5, D] (tiny concat of weights)
+        tokens_data = torch.empty((N * 6, D), dtype=bf, device=self.dev)
+        t_idx = torch.arange(N * 6, device=self.dev, dtype=torch.int32)
+        src5 = torch.where(t_idx % 6 < 5, t_idx % 6, torch.full_like(t_idx, -1))
+        dst5 = torch.where(t_idx % 6 < 5, t_idx, torch.full_like(t_idx, -1))
+        ops.copy_rows(out_tok, tokens_data, N * 6, D, idx_src=src5, idx_dst=dst5)
+        text_dst = (torch.arange(N, device=self.dev, dtype=torch.int32) * 6 + 5)
+        ops.copy_rows(text_embeds.data, tokens_data, N, D, idx_dst=text_dst)
+        tokens = Var(tokens_data)
+        # keys = image_embeddings[idx] + no_mask_embed  (:181-186; prompt_encoder.py:182-184)
+        key_src = (frame_of_instance.to(torch.int64)[:, None] * g2 + torch.arange(g2, device=self.dev)[None]).reshape(-1).to(torch.int32)
+        keys0 = torch.empty((N * g2, D), dtype=bf, device=self.dev)
+        ops.copy_rows(image_emb_rows, keys0, N * g2, D, idx_src=key_src)
+        ops.add_bcast_rows(keys0, self.sd[PE_ + "no_mask_embed.weight"], 1, out=keys0)
+        keys = Var(keys0)
+        keys_init = keys
+        queries = tokens
+        t = M_ + "transformer."
+        for i in range(d.dec_depth):
+            p = t + f"layers.{i}."
+            if i == 0:  # skip_first_layer_pe (transformer.py:153-155)
+                queries = self._attn(tp, p + "self_attn.", queries, queries, queries, N, 6, 6, D)
+            else:
+                q = tp.add(queries, tokens)
+                queries = self._attn(tp, p + "self_attn.", q, q, queries, N, 6, 6, D, residual=queries)
+            queries = tp.layernorm(queries, self.P(p + "norm1.weight"), self.P(p + "norm1.bias"), 1e-5)
+            q = tp.add(queries, tokens)
+            k = tp.add_const_rows(keys, self.key_pe, g2)
+            queries = self._attn(tp, p + "cross_attn_token_to_image.", q, k, keys, N, 6, g2, D // 2, residual=queries)
+            queries = tp.layernorm(queries, self.P(p + "norm2.weight"), self.P(p + "norm2.bias"), 1e-5)
+            h = tp.linear(queries, self.P(p + "mlp.lin1.weight"), self.P(p + "mlp.lin1.bias"), act=ops.ACT_RELU)
+            queries = tp.linear(h, self.P(p + "mlp.lin2.weight"), self.P(p + "mlp.lin2.bias"), residual=queries)
+            queries = tp.layernorm(queries, self.P(p + "norm3.weight"), self.P(p + "norm3.bias"), 1e-5)
+            q = tp.add(queries, tokens)
+            keys = self._attn(tp, p + "cross_attn_image_to_token.", k, q, queries, N, g2, 6, D // 2, residual=keys)
+            keys = tp.layernorm(keys, self.P(p + "norm4.weight"), self.P(p + "norm4.bias"), 1e-5)
+        q = tp.add(queries, tokens)
+        k = tp.add_const_rows(keys, self.key_pe, g2)
+        queries = self._attn(tp, t + "final_attn_token_to_image.", q, k, keys, N, 6, g2, D // 2, residual=queries)
+        # last LayerNorm only matters for token 5 of every instance; gather first, then normalise in fp32
+        q5 = torch.empty((N, D), dtype=bf, device=self.dev)
+        ops.copy_rows(queries.data, q5, N, D, idx_src=text_dst)
+        nw, nb = self.sd[t + "norm_final_attn.weight"], self.sd[t + "norm_final_attn.bias"]
+        hs, mean, rstd = ops.layernorm(q5, nw, nb, 1e-5, save_stats=train, out_dtype=torch.float32)
+        hp = M_ + "bbox_prediction_head."
+        box, obj, hidden = ops.box_head(hs, self.sd[hp + "0.weight"], self.sd[hp + "0.bias"], self.sd[hp + "2.weight"],
+                                        self.sd[hp + "2.bias"], self.sd[M_ + "temporal_objectness_head.weight"],
+                                        self.sd[M_ + "temporal_objectness_head.bias"])
+        state = None
+        if train:
+            state = dict(tp=tp, queries=queries, q5=q5, hs=hs, mean=mean, rstd=rstd, hidden=hidden, box=box, text_dst=text_dst,
+                         tokens=tokens, keys_init=keys_init, key_src=key_src, N=N, text=text_embeds)
+        return box, obj, state
+
+    def backward(self, state, dbox, dobj, d_image_emb_rows):
+        """dbox f32 [N,4], dobj f32 [N]. Accumulates decoder weight grads; adds the gradient w.r.t. the SAM
+        embeddings into d_image_emb_rows (f32 [F*g*g, 256]) and sets state['text'].grad (bf16 [N, 256])."""
+        d = self.d
+        D, g2 = d.dec_dim, d.sam_grid ** 2
+        N = state["N"]
+        G = self.grads
+        hp = M_ + "bbox_prediction_head."
+        t = M_ + "transformer."
+        grads = {"dW1": G[hp + "0.weight"], "db1": G[hp + "0.bias"], "dW2": G[hp + "2.weight"], "db2": G[hp + "2.bias"],
+                 "dWo": G[M_ + "temporal_objectness_head.weight"].view(-1), "dbo": G[M_ + "temporal_objectness_head.bias"]}
+        dhs = ops.box_head_bwd(state["hs"], self.sd[hp + "0.weight"], self.sd[hp + "2.weight"],
+                               self.sd[M_ + "temporal_objectness_head.weight"], state["hidden"], state["box"], dbox, dobj, grads)
+        dq5 = ops.layernorm_bwd(state["q5"], self.sd[t + "norm_final_attn.weight"], ops.to_bf16(dhs), state["mean"], state["rstd"],
+                                dweight=G[t + "norm_final_attn.weight"], dbias=G[t + "norm_final_attn.bias"])
+        dqueries = torch.zeros((N * 6, D), dtype=bf, device=self.dev)
+        ops.copy_rows(dq5, dqueries, N, D, idx_dst=state["text_dst"])
+        state["queries"].grad = dqueries
+        tokens = state["tokens"]
+        state["tp"].backward()
+        # gradient of the gathered image keys -> SAM embeddings (prompt_encoder.no_mask_embed is frozen, train.py:279-296)
+        ops.scatter_add_f32(state["keys_init"].grad, d_image_emb_rows, state["key_src"], N * g2, D)
+        # tokens.grad: rows 0..4 of every instance -> iou/mask token weights; row 5 -> text embeddings
+        tg = tokens.grad
+        dtext = torch.empty((N, D), dtype=bf, device=self.dev)
+        ops.copy_rows(tg, dtext, N, D, idx_src=state["text_dst"])
+        state["text"].grad = dtext
+        t_idx = torch.arange(N * 6, device=self.dev, dtype=torch.int32)
+        tok_of_row = torch.where(t_idx % 6 < 5, t_idx % 6, torch.full_like(t_idx, -1))
+        tokg = torch.zeros((5, D), dtype=torch.float32, device=self.dev)
+        ops.scatter_add_f32(tg, tokg, tok_of_row, N * 6, D)
+        ops.axpy(G[M_ + "iou_token.weight"].view(-1), tokg[0])
+        ops.axpy(G[M_ + "mask_tokens.weight"].view(-1), tokg[1:5].reshape(-1))
+        return None

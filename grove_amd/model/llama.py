@@ -1,0 +1,80 @@
+"""LLaMA decoder stack on the HIP kernels (the HF `LlamaModel` the reference calls at
+llava_llama.py:100-109 with flash-attention-2; transformers is third party and un-vendored).
+
+Per layer: RMSNorm -> fused q|k|v GEMM -> RoPE in place -> causal attention with right-padding
+lengths -> o_proj (+residual in the epilogue) -> RMSNorm -> fused gate|up GEMM -> SwiGLU ->
+down_proj (+residual). Weights are frozen in the shipped fine-tune (train.py:254-255, lora_r 0),
+so the backward is dgrad only and uses pre-transposed weight copies (HBM is 288 GB; the 13.5 GB of
+W^T buys NT-form GEMMs for every dgrad). Activations of all layers are kept (no recompute).
+Layout: hidden [B*S, H] bf16 row-major, sequence b at rows b*S .. b*S+S-1, right padded.
+"""
+import torch
+
+from .. import ops
+from .attention import attention_bwd, attention_fwd
+
+
+class LlamaStack:
+    def __init__(self, sd, d, device, train=False):
+        self.d, self.dev, self.train = d, device, train
+        self.layers = []
+        for i in range(d.n_layers):
+            p = f"model.layers.{i}."
+            wqkv = torch.cat([sd[p + f"self_attn.{n}_proj.weight"] for n in "qkv"], 0).contiguous()
+            wgu = torch.cat([sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"]], 0).contiguous()
+            L = {"ln1": sd[p + "input_layernorm.weight"], "ln2": sd[p + "post_attention_layernorm.weight"],
+                 "wqkv": wqkv, "wo": sd[p + "self_attn.o_proj.weight"], "wgu": wgu, "wd": sd[p + "mlp.down_proj.weight"]}
+            if train:
+                for k in ("wqkv", "wo", "wgu", "wd"):
+                    L[k + "_t"] = ops.transpose2d(L[k])
+            self.layers.append(L)
+        self.norm = sd["model.norm.weight"]
+
+    def forward(self, x, B, S, kv_len=None, save=False):
+        """x: bf16 [B*S, H] input embeddings (consumed / overwritten). kv_len: int32 [B] valid lengths or None.
+        Returns (final-norm hidden [B*S, H], ctx)."""
+        d = self.d
+        H, nh, hd, I = d.hidden, d.n_heads, d.head_dim, d.mlp
+        pos = torch.arange(S, dtype=torch.int32, device=self.dev).repeat(B)
+        saved = []
+        for L in self.layers:
+            h = ops.rmsnorm(x, L["ln1"], d.rms_eps)
+            qkv = ops.linear(h, L["wqkv"])
+            ops.rope_(qkv, pos, 0, 2 * nh, hd, d.rope_theta)
+            o, actx = attention_fwd(qkv, B, S, nh, hd, 0, H, 2 * H, hd ** -0.5, causal=True, kv_len=kv_len, save=save)
+            x1 = ops.linear(o, L["wo"], residual=x)
+            h2 = ops.rmsnorm(x1, L["ln2"], d.rms_eps)
+            gu = ops.linear(h2, L["wgu"])
+            a = ops.swiglu(gu, I)
+            x2 = ops.linear(a, L["wd"], residual=x1)
+            if save:
+                saved.append((x, qkv, actx, x1, gu))
+            x = x2
+        out = ops.rmsnorm(x, self.norm, d.rms_eps)
+        ctx = (saved, x, pos, B, S) if save else None
+        return out, ctx
+
+    def backward(self, ctx, d_out):
+        """dgrad through the frozen stack. d_out: bf16 [B*S, H] gradient of the post-norm hidden.
+        Returns the gradient w.r.t. the input embeddings."""
+        d = self.d
+        saved, x_last, pos, B, S = ctx
+        H, nh, hd, I = d.hidden, d.n_heads, d.head_dim, d.mlp
+        dx = ops.rmsnorm_bwd(x_last, self.norm, d_out, d.rms_eps)
+        for L, (x, qkv, actx, x1, gu) in zip(reversed(self.layers), reversed(saved)):
+            # x2 = x1 + down(swiglu(gu));  dx is d x2
+            da = ops.linear(dx, L["wd_t"])                      # [B*S, I]
+            dgu = ops.swiglu_bwd(gu, da, I)
+            del da
+            dh2 = ops.linear(dgu, L["wgu_t"])                   # [B*S, H]
+            del dgu
+            ops.rmsnorm_bwd(x1, L["ln2"], dh2, d.rms_eps, dx=dx, accumulate=True)   # dx now d x1
+            # x1 = x + o_proj(attn(rope(qkv(rms(x)))))
+            do = ops.linear(dx, L["wo_t"])                      # [B*S, H]
+            dqkv = torch.empty_like(qkv)
+            attention_bwd(actx, qkv, do, dqkv)
+            ops.rope_(dqkv, pos, 0, 2 * nh, hd, d.rope_theta, inverse=True)
+            dh = ops.linear(dqkv, L["wqkv_t"])
+            del dqkv, do
+            ops.rmsnorm_bwd(x, L["ln1"], dh, d.rms_eps, dx=dx, accumulate=True)     # dx now d x
+        return dx

@@ -1,0 +1,252 @@
+"""SAM ViT-H image encoder (+4 Conv3d adapters, + neck) on the HIP kernels.
+
+Host-side mirror of model/SAM/modeling/image_encoder.py. Layout: tokens [F*g*g, C] bf16, frame-major
+(channels-last everywhere, so Conv3d / Conv2d / LayerNorm2d become row kernels and implicit GEMMs).
+Window attention never materialises the padded/partitioned tensor: LayerNorm scatters rows into the
+window layout (pad rows stay zero, so they act as bias-only keys exactly like the reference, quirk
+Q4) and the proj GEMM scatters back while adding the residual. Head dim 80 is zero-padded to 96 inside
+the packed qkv / proj weights so every attention GEMM has K % 32 == 0.
+Backward (shipped freeze policy, train.py:279-280): only the adapters train; gradients flow
+neck -> adapter 3 -> blocks 31..24 -> ... -> adapter 0, i.e. dgrad through blocks first_global+1..depth-1.
+"""
+import torch
+
+from .. import ops
+from .attention import attention_bwd, attention_fwd
+from .indexing import conv3d_gather_index, window_partition_index
+
+S = "model.grounding_encoder.image_encoder."
+
+
+def _rel_table(size, rel_pos):
+    """get_rel_pos (image_encoder.py:387-417) for q_size == k_size: f32 [size, size, hd]."""
+    c = torch.arange(size, device=rel_pos.device)
+    return rel_pos.float()[(c[:, None] - c[None, :]) + (size - 1)].contiguous()
+
+
+class SamEncoder:
+    def __init__(self, sd, d, device, train=False, grads=None):
+        self.d, self.dev, self.train = d, device, train
+        self.grads = grads  # name -> f32 gradient accumulator (trainable adapters)
+        C, nh = d.sam_dim, d.sam_heads
+        self.hd = C // nh
+        self.hp = ops.pad_to(self.hd, 32)
+        bf = torch.bfloat16
+        P = d.sam_patch
+        self.w_patch = sd[S + "patch_embed.proj.weight"].reshape(C, 3 * P * P).contiguous()
+        assert (3 * P * P) % 32 == 0
+        self.b_patch = sd[S + "patch_embed.proj.bias"]
+        self.pos = sd[S + "pos_embed"].reshape(d.sam_grid * d.sam_grid, C).contiguous()
+        self.first_bwd_block = min(d.sam_global) + 1
+        self.blocks = []
+        hd, hp = self.hd, self.hp
+        for i in range(d.sam_depth):
+            p = S + f"blocks.{i}."
+            size = d.sam_grid if i in d.sam_global else d.sam_window
+            wq = sd[p + "attn.qkv.weight"].reshape(3, nh, hd, C)
+            wqkv = torch.zeros((3, nh, hp, C), dtype=bf, device=device)
+            wqkv[:, :, :hd] = wq
+            bqkv = torch.zeros((3, nh, hp), dtype=bf, device=device)
+            bqkv[:, :, :hd] = sd[p + "attn.qkv.bias"].reshape(3, nh, hd)
+            wproj = torch.zeros((C, nh, hp), dtype=bf, device=device)
+            wproj[:, :, :hd] = sd[p + "attn.proj.weight"].reshape(C, nh, hd)
+            Bk = {"ln1": (sd[p + "norm1.weight"], sd[p + "norm1.bias"]), "ln2": (sd[p + "norm2.weight"], sd[p + "norm2.bias"]),
+                  "wqkv": wqkv.reshape(3 * nh * hp, C), "bqkv": bqkv.reshape(-1), "wproj": wproj.reshape(C, nh * hp),
+                  "bproj": sd[p + "attn.proj.bias"], "w1": sd[p + "mlp.lin1.weight"], "b1": sd[p + "mlp.lin1.bias"],
+                  "w2": sd[p + "mlp.lin2.weight"], "b2": sd[p + "mlp.lin2.bias"],
+                  "Rh": _rel_table(size, sd[p + "attn.rel_pos_h"]), "Rw": _rel_table(size, sd[p + "attn.rel_pos_w"]),
+                  "window": 0 if i in d.sam_global else d.sam_window}
+            if train and i >= self.first_bwd_block:
+                for k in ("wqkv", "wproj", "w1", "w2"):
+                    Bk[k + "_t"] = ops.transpose2d(Bk[k])
+            self.blocks.append(Bk)
+        self.adapters = []
+        for j in range(len(d.sam_global)):
+            p = S + f"adapters.{j}."
+            # packed [Co, (kt kh kw), Ci]; the canonical Conv3d weight is a permuted view of this storage
+            wp = sd[p + "conv3d.weight"].permute(0, 2, 3, 4, 1).reshape(C, 27 * C)
+            assert wp.is_contiguous() or not train, "adapter weights must be stored tap-major (GROVEForCausalLM packs them)"
+            self.adapters.append({"w": wp.contiguous(), "b": sd[p + "conv3d.bias"], "alpha": sd[p + "alpha"], "name": p})
+        O = d.sam_out
+        self.neck_w0 = sd[S + "neck.0.weight"].reshape(O, C).contiguous()
+        self.neck_ln1 = (sd[S + "neck.1.weight"], sd[S + "neck.1.bias"])
+        self.neck_w2 = sd[S + "neck.2.weight"].permute(0, 2, 3, 1).reshape(O, 9 * O).contiguous()
+        self.neck_ln2 = (sd[S + "neck.3.weight"], sd[S + "neck.3.bias"])
+        if train:
+            self.neck_w0_t = ops.transpose2d(self.neck_w0)
+            # dgrad of the 3x3 conv = conv with flipped taps and swapped channels: [Ci, (kh kw flipped), Co]
+            w2 = sd[S + "neck.2.weight"]  # [Co, Ci, 3, 3]
+            self.neck_w2_d = w2.flip(2, 3).permute(1, 2, 3, 0).reshape(O, 9 * O).contiguous()
+        self._idx = {}
+
+    def refresh_adapter_scalars(self):
+        """alpha is read on device by the GEMM epilogue (fp32 scalar)."""
+        for A in self.adapters:
+            A["alpha_f32"] = A["alpha"].float().contiguous()
+
+    def _indices(self, F):
+        if F not in self._idx:
+            d = self.d
+            g = d.sam_grid
+            tok2win, win2tok, nwin, _, _ = window_partition_index(F, g, g, d.sam_window)
+            conv = conv3d_gather_index(F // 8, 8, g, g)
+            neck = conv3d_gather_index(F, 1, g, g, kt=1)
+            pos_rows = (torch.arange(F * g * g, dtype=torch.int32) % (g * g))
+            self._idx[F] = tuple(t.to(self.dev) for t in (tok2win, win2tok, conv, neck, pos_rows)) + (nwin,)
+        return self._idx[F]
+
+    # ------------------------------------------------------------------ forward
+    def _attn_block(self, Bk, x, F, idx, save):
+        d = self.d
+        C, nh, hp, hd = d.sam_dim, d.sam_heads, self.hp, self.hd
+        tok2win, win2tok, _, _, _, nwin = idx
+        g = d.sam_grid
+        ws = Bk["window"]
+        ctx = {}
+        if ws > 0:
+            rows_w = F * nwin * ws * ws
+            h, mean, rstd = ops.layernorm(x, Bk["ln1"][0], Bk["ln1"][1], 1e-6, out_idx=tok2win, out_rows=rows_w, save_stats=save)
+            nb, L, qhw = F * nwin, ws * ws, (ws, ws)
+        else:
+            h, mean, rstd = ops.layernorm(x, Bk["ln1"][0], Bk["ln1"][1], 1e-6, save_stats=save)
+            nb, L, qhw = F, g * g, (g, g)
+        qkv = ops.linear(h, Bk["wqkv"], Bk["bqkv"])
+        rel = ops.relpos(qkv, Bk["Rh"], Bk["Rw"], nb, nh, qhw, qhw, hd, hp, qkv.stride(0))
+        o, actx = attention_fwd(qkv, nb, L, nh, hp, 0, nh * hp, 2 * nh * hp, hd ** -0.5, rel=rel, rel_hw=qhw, save=save)
+        del rel
+        x1 = ops.linear(o, Bk["wproj"], Bk["bproj"], residual=x, c_idx=(win2tok if ws > 0 else None), out_rows=x.shape[0])
+        h2, mean2, rstd2 = ops.layernorm(x1, Bk["ln2"][0], Bk["ln2"][1], 1e-6, save_stats=save)
+        pre = torch.empty((x.shape[0], 4 * C), dtype=torch.bfloat16, device=self.dev) if save else None
+        f = ops.linear(h2, Bk["w1"], Bk["b1"], act=ops.ACT_GELU, aux=pre)
+        x2 = ops.linear(f, Bk["w2"], Bk["b2"], residual=x1)
+        if save:
+            ctx = dict(x=x, mean=mean, rstd=rstd, qkv=qkv, actx=actx, x1=x1, mean2=mean2, rstd2=rstd2, pre=pre, nb=nb, L=L, qhw=qhw)
+        return x2, ctx
+
+    def _adapter(self, A, x, conv_idx, save):
+        pre = torch.empty_like(x) if save else None
+        y = ops.linear(x, A["w"], A["b"], act=ops.ACT_RELU, scale_ptr=A["alpha_f32"], scale_tanh=True, a_idx=conv_idx, a_taps=27,
+                       M=x.shape[0], residual=x, aux=pre)
+        return y, (x, pre)
+
+    def forward(self, images, save=False, upto=None):
+        """images bf16 [B, 3, T, 512, 512] -> channels-last embeddings [F, g*g, 256] (the reference returns
+        NCHW [F,256,g,g]; the boundary transposes on request). save=True keeps what backward needs."""
+        d = self.d
+        B, _, T, _, _ = images.shape
+        F = B * T
+        assert F % 8 == 0, "SAM adapters treat frames as groups of 8 (image_encoder.py:52)"
+        g, C, O = d.sam_grid, d.sam_dim, d.sam_out
+        if "alpha_f32" not in self.adapters[0]:
+            self.refresh_adapter_scalars()
+        idx = self._indices(F)
+        _, _, conv_idx, neck_idx, pos_rows, _ = idx
+        col = ops.im2col_patch(images.contiguous(), d.sam_patch, 3 * d.sam_patch * d.sam_patch)
+        x = ops.linear(col, self.w_patch, self.b_patch, residual=self.pos, r_idx=pos_rows)
+        del col
+        saved = {"blocks": {}, "adapters": {}, "F": F}
+        nblocks = d.sam_depth if upto is None else upto
+        for i in range(nblocks):
+            keep = save and i >= self.first_bwd_block
+            x, ctx = self._attn_block(self.blocks[i], x, F, idx, keep)
+            if keep:
+                saved["blocks"][i] = ctx
+            if i in d.sam_global:
+                j = d.sam_global.index(i)
+                x, actx = self._adapter(self.adapters[j], x, conv_idx, save)
+                if save:
+                    saved["adapters"][j] = actx
+        if upto is not None:
+            return x, None
+        n0 = ops.linear(x, self.neck_w0)
+        n1, m1, r1 = ops.layernorm(n0, self.neck_ln1[0], self.neck_ln1[1], 1e-6, save_stats=save)
+        n2 = ops.linear(n1, self.neck_w2, a_idx=neck_idx, a_taps=9, M=n1.shape[0])
+        out, m2, r2 = ops.layernorm(n2, self.neck_ln2[0], self.neck_ln2[1], 1e-6, save_stats=save)
+        if save:
+            saved["neck"] = (n0, m1, r1, n2, m2, r2)
+        return out.view(F, g * g, O), (saved if save else None)
+
+    # ------------------------------------------------------------------ backward
+    def _wgrad(self, name, dy, x_rows_T, K_pad):
+        raise NotImplementedError
+
+    def backward(self, saved, d_out):
+        """d_out: bf16 [F*g*g, 256] gradient of the channels-last embeddings. Accumulates adapter
+        gradients into self.grads (f32) and returns nothing (the image carries no gradient)."""
+        d = self.d
+        F = saved["F"]
+        C, nh, hp, hd = d.sam_dim, d.sam_heads, self.hp, self.hd
+        idx = self._indices(F)
+        tok2win, win2tok, conv_idx, neck_idx, _, nwin = idx
+        n0, m1, r1, n2, m2, r2 = saved["neck"]
+        dn2 = ops.layernorm_bwd(n2, self.neck_ln2[0], d_out, m2, r2)
+        dn1 = ops.linear(dn2, self.neck_w2_d, a_idx=neck_idx, a_taps=9, M=dn2.shape[0])
+        dn0 = ops.layernorm_bwd(n0, self.neck_ln1[0], dn1, m1, r1)
+        dx = ops.linear(dn0, self.neck_w0_t)
+        del dn2, dn1, dn0
+        for i in range(d.sam_depth - 1, self.first_bwd_block - 2, -1):
+            if i in d.sam_global:
+                j = d.sam_global.index(i)
+                dx = self._adapter_bwd(self.adapters[j], saved["adapters"][j], dx, conv_idx, need_dx=(i >= self.first_bwd_block))
+            if i < self.first_bwd_block:
+                break
+            Bk, c = self.blocks[i], saved["blocks"][i]
+            ws = Bk["window"]
+            # x2 = x1 + lin2(gelu(lin1(ln2(x1))))
+            df = ops.linear(dx, Bk["w2_t"])
+            ops.act_bwd(c["pre"], df, ops.ACT_GELU, out=df)
+            dh2 = ops.linear(df, Bk["w1_t"])
+            del df
+            ops.layernorm_bwd(c["x1"], Bk["ln2"][0], dh2, c["mean2"], c["rstd2"], dx=dx, accumulate=True)   # dx = d x1
+            del dh2
+            # x1 = x + unpartition(proj(attn(qkv(partition(ln1(x))))))
+            if ws > 0:
+                do = ops.linear(dx, Bk["wproj_t"], a_idx=win2tok, a_taps=1, M=win2tok.shape[0])
+            else:
+                do = ops.linear(dx, Bk["wproj_t"])
+            qkv = c["qkv"]
+            dqkv = torch.empty_like(qkv)
+            drel = attention_bwd(c["actx"], qkv, do, dqkv, want_drel=True)
+            ops.relpos(qkv, Bk["Rh"], Bk["Rw"], c["nb"], nh, c["qhw"], c["qhw"], hd, hp, qkv.stride(0), rel=drel, dq=dqkv, backward=True)
+            dh = ops.linear(dqkv, Bk["wqkv_t"])
+            del dqkv, do, drel
+            ops.layernorm_bwd(c["x"], Bk["ln1"][0], dh, c["mean"], c["rstd"], dx=dx, accumulate=True,
+                              in_idx=(tok2win if ws > 0 else None))
+            del dh
+        return None
+
+    def _adapter_bwd(self, A, actx, dy, conv_idx, need_dx):
+        """y = tanh(alpha) * relu(conv(x) + b) + x. Accumulates dW (tap-major), db, dalpha; returns dx."""
+        x, pre = actx
+        C = self.d.sam_dim
+        M = x.shape[0]
+        g = self.grads
+        name = A["name"]
+        a = A["alpha_f32"]
+        r = ops.act_bwd(pre, pre, ops.ACT_RELU)             # relu(pre) = pre * relu'(pre)
+        prod = ops.act_bwd(pre, dy, ops.ACT_RELU)           # dy * relu'(pre)
+        # d alpha = (1 - tanh(alpha)^2) * sum(dy * relu(pre))
+        ops.dot(dy, r, g[name + "alpha"], scale_ptr=a, mode=1)
+        del r
+        # bias grad: tanh(alpha) * colsum(dy * relu')
+        ops.axpy(g[name + "conv3d.bias"], ops.colsum(prod), scale_ptr=a, mode=2)
+        # weight grad, tap-major: dW[co, tap, ci] = tanh(alpha) * sum_m (dy relu')[m, co] * x[gather(tap, m), ci]
+        Mp = ops.pad_to(M, 32)
+        dzT = torch.empty((C, Mp), dtype=torch.bfloat16, device=self.dev)
+        ops.transpose(prod, M, C, C, dzT, Mp, pad_to_cols=Mp)
+        gw = g[name + "conv3d.weight"].view(C, 27 * C)
+        xT = torch.empty((C, Mp), dtype=torch.bfloat16, device=self.dev)
+        xg = torch.empty((M, C), dtype=torch.bfloat16, device=self.dev)
+        for tap in range(27):
+            ops.copy_rows(x, xg, M, C, idx_src=conv_idx[tap])
+            ops.transpose(xg, M, C, C, xT, Mp, pad_to_cols=Mp)
+            ops.gemm_raw(dzT, xT, gw[:, tap * C:], C, C, Mp, Mp, Mp, 27 * C, accumulate=True, scale_ptr=a, scale_tanh=True)
+        del dzT, xT, xg
+        dx = None
+        if need_dx:
+            # dx = dy + conv^T(dz): flipped taps, swapped channels
+            if "w_d" not in A or self.train:
+                w5 = A["w"].view(C, 3, 3, 3, C)
+                A["w_d"] = w5.flip(1, 2, 3).permute(4, 1, 2, 3, 0).reshape(C, 27 * C).contiguous()
+            dx = ops.linear(prod, A["w_d"], a_idx=conv_idx, a_taps=27, M=M, residual=dy, scale_ptr=a, scale_tanh=True)
+        return dx

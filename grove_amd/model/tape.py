@@ -1,0 +1,138 @@
+"""A minimal reverse-mode tape over the HIP kernels, used for the small trainable parts of the path
+(mm_projector, text_hidden_fcs, prompt/mask decoder): forward code reads like the reference module,
+every op pushes the closure that back-propagates through the matching backward kernels, weight
+gradients are accumulated in fp32 straight into the caller's flat gradient buffer views.
+
+The big towers (LLaMA, SAM) do not use the tape: their backward is written out explicitly so that
+activation lifetime in HBM stays under control.
+"""
+import torch
+
+from .. import ops
+
+bf = torch.bfloat16
+
+
+class Var:
+    __slots__ = ("data", "grad", "needs_grad")
+
+    def __init__(self, data, needs_grad=True):
+        self.data = data
+        self.grad = None
+        self.needs_grad = needs_grad
+
+
+class Param:
+    """A bf16 weight plus (optionally) the f32 view that receives its gradient."""
+    __slots__ = ("w", "g")
+
+    def __init__(self, w, g=None):
+        self.w, self.g = w, g
+
+
+class Tape:
+    def __init__(self, enabled=True):
+        self.enabled = enabled
+        self.fns = []
+
+    def push(self, fn):
+        if self.enabled:
+            self.fns.append(fn)
+
+    def backward(self):
+        for fn in reversed(self.fns):
+            fn()
+        self.fns = []
+
+    # ---- helpers
+    @staticmethod
+    def acc(v, g):
+        if not v.needs_grad:
+            return
+        if v.grad is None:
+            v.grad = g
+        else:
+            ops.add(v.grad, g, out=v.grad)
+
+    # ---- ops
+    def linear(self, x: Var, W: Param, b: Param = None, act=ops.ACT_NONE, residual: Var = None):
+        """y = act(x W^T + b) (+ residual)."""
+        need_pre = self.enabled and act != ops.ACT_NONE
+        M = x.data.shape[0]
+        pre = torch.empty((M, W.w.shape[0]), dtype=bf, device=x.data.device) if need_pre else None
+        y = Var(ops.linear(x.data, W.w, b.w if b is not None else None, act=act, aux=pre,
+                           residual=residual.data if residual is not None else None))
+
+        def bwd():
+            dy = y.grad
+            if dy is None:
+                return
+            if residual is not None:
+                Tape.acc(residual, dy if act == ops.ACT_NONE else dy.clone())
+            dz = ops.act_bwd(pre, dy, act) if act != ops.ACT_NONE else dy
+            if residual is not None and act == ops.ACT_NONE:
+                dz = dy  # shared with the residual branch: treated read-only below
+            N, K = W.w.shape
+            if W.g is not None:
+                Mp = ops.pad_to(M, 32)
+                dzT = torch.empty((N, Mp), dtype=bf, device=dz.device)
+                ops.transpose(dz, M, N, dz.stride(0), dzT, Mp, pad_to_cols=Mp)
+                xT = torch.empty((K, Mp), dtype=bf, device=dz.device)
+                ops.transpose(x.data, M, K, x.data.stride(0), xT, Mp, pad_to_cols=Mp)
+                ops.gemm_raw(dzT, xT, W.g, N, K, Mp, Mp, Mp, K, accumulate=True)
+            if b is not None and b.g is not None:
+                ops.colsum(dz, out=b.g, accumulate=True)
+            if x.needs_grad:
+                assert N % 32 == 0, "tape.linear dgrad needs out_features % 32 == 0"
+                wT = ops.transpose2d(W.w)  # [K, N]
+                Tape.acc(x, ops.linear(dz, wT))
+        self.push(bwd)
+        return y
+
+    def layernorm(self, x: Var, W: Param, b: Param, eps, out_f32=False):
+        y_data, mean, rstd = ops.layernorm(x.data, W.w, b.w, eps, save_stats=self.enabled,
+                                           out_dtype=torch.float32 if out_f32 else bf)
+        y = Var(y_data)
+
+        def bwd():
+            if y.grad is None:
+                return
+            dy = y.grad if y.grad.dtype == bf else ops.to_bf16(y.grad)
+            dx = ops.layernorm_bwd(x.data, W.w, dy, mean, rstd, dweight=W.g, dbias=b.g)
+            Tape.acc(x, dx)
+        self.push(bwd)
+        return y
+
+    def add(self, a: Var, b_: Var):
+        y = Var(ops.add(a.data, b_.data))
+
+        def bwd():
+            if y.grad is None:
+                return
+            Tape.acc(a, y.grad)
+            Tape.acc(b_, y.grad.clone() if (a.needs_grad and b_.needs_grad) else y.grad)
+        self.push(bwd)
+        return y
+
+    def add_const_rows(self, a: Var, const_rows, period):
+        """y[r] = a[r] + const[r % period] (positional encodings: no gradient to the constant)."""
+        y = Var(ops.add_bcast_rows(a.data, const_rows, period))
+
+        def bwd():
+            if y.grad is not None:
+                Tape.acc(a, y.grad)
+        self.push(bwd)
+        return y
+
+    def small_attn(self, q: Var, k: Var, v: Var, inst, heads, d, Lq, Lk):
+        o = Var(ops.small_attn(q.data, k.data, v.data, inst, heads, d, Lq, Lk))
+
+        def bwd():
+            if o.grad is None:
+                return
+            dq, dk, dv = ops.small_attn_bwd(q.data, k.data, v.data, o.data, o.grad, inst, heads, d, Lq, Lk)
+            Tape.acc(q, ops.to_bf16(dq))
+            Tape.acc(k, ops.to_bf16(dk))
+            Tape.acc(v, ops.to_bf16(dv))
+        self.push(bwd)
+        return o

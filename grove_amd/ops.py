@@ -264,6 +264,16 @@ def colsum(x, out=None, accumulate=False):
     return out
 
 
+def dot(a, b, out, scale_ptr=None, mode=0):
+    _lib.check(_lib.lib().grove_dot_bf16(_p(a), _p(b), _p(out), C.c_int64(a.numel()), _p(scale_ptr), mode, _stream()), "grove_dot_bf16")
+    return out
+
+
+def axpy(y, x, scale_ptr=None, mode=0):
+    _lib.check(_lib.lib().grove_axpy_f32(_p(y), _p(x), C.c_int64(y.numel()), _p(scale_ptr), mode, _stream()), "grove_axpy_f32")
+    return y
+
+
 def to_bf16(x, out=None):
     if out is None:
         out = torch.empty(x.shape, dtype=bf16, device=x.device)

@@ -237,6 +237,11 @@ int grove_scatter_add_f32(const void* src, float* dst, const int32_t* idx, int32
                           int32_t ld_src, int32_t ld_dst, void* stream);
 /* column sums of a bf16 [rows, ld] matrix into f32 out[C] (bias gradients); accumulate adds */
 int grove_colsum_f32(const void* x, float* out, int32_t rows, int32_t C, int32_t ld, int32_t accumulate, void* stream);
+/* out[0] += f * sum_i a[i]*b[i] (bf16 in, fp32 accumulate). scale_ptr NULL: f=1; mode 0: f=*scale_ptr;
+ * mode 1: f = 1 - tanh(*scale_ptr)^2 (d tanh(alpha), adapter gate gradient); mode 2: f = tanh(*scale_ptr) */
+int grove_dot_bf16(const void* a, const void* b, float* out, int64_t n, const float* scale_ptr, int32_t mode, void* stream);
+/* y += f * x over n fp32 elements, f as for grove_dot_bf16 (modes 0 and 2) */
+int grove_axpy_f32(float* y, const float* x, int64_t n, const float* scale_ptr, int32_t mode, void* stream);
 /* casts */
 int grove_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
 int grove_cast_bf16_to_f32(const void* x, float* y, int64_t n, void* stream);

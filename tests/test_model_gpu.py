@@ -1,0 +1,112 @@
+"""Parity of the HIP path (through GROVEForCausalLM -> grove_amd.ops -> C-ABI) against the CPU oracle on
+the same deterministic weights and inputs, at tiny dimensions (real 336/512 px inputs, real token
+counts), plus the committed golden vectors of the reference itself.
+
+Tolerances: the product computes in bf16 with fp32 accumulation; the oracle is fp32. Boxes are compared
+in normalised cxcywh (target <= 1e-3 mean L1); hidden states relative to their scale.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+bf = torch.bfloat16
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-6)).item()
+
+
+def to_dev(batch, dev):
+    kw = batch.as_kwargs()
+    for k in ("global_enc_images", "grounding_enc_images"):
+        kw[k] = kw[k].to(dev).to(bf)
+    for k in ("input_ids", "labels", "attention_masks", "offset"):
+        kw[k] = kw[k].to(dev)
+    return kw
+
+
+@pytest.fixture(scope="module")
+def setup(dev):
+    from grove_amd import GROVEForCausalLM
+    from grove_amd.synthetic import TINY, synthetic_state_dict
+    sd = synthetic_state_dict(TINY)
+    # the oracle sees the SAME bf16-rounded weights as the kernels
+    sd_r = {k: v.to(bf).float() for k, v in sd.items()}
+    model = GROVEForCausalLM(dims=TINY, device=dev, state_dict=sd, det_token_idx=TINY.det_token_idx, num_frames=8,
+                             pe_dtype=torch.float32)
+    return model, sd_r, TINY
+
+
+def test_towers_match_oracle(setup, dev):
+    from grove_amd.synthetic import synthetic_batch
+    from oracle import grove_oracle as O
+    model, sd, d = setup
+    batch = synthetic_batch(d, B=1, T=8, L=40, n_det=2, seed=2)
+    gi = batch.global_enc_images.to(bf)
+    si = batch.grounding_enc_images.to(bf)
+    with torch.no_grad():
+        feats_o, hs_o = O.encode_images(sd, d, gi.float())
+        emb_o = O.sam_image_encoder(sd, d, si.float())
+    feats, outs = model(mode="encode_images", images=gi.to(dev))
+    assert rel(outs.hidden_states[-1], hs_o[-1]) < 3e-2, "clip hidden[-2]"
+    assert rel(feats, feats_o) < 3e-2, "projected features"
+    emb = model(mode="get_grounding_encoder_embs", images=si.to(dev))
+    assert emb.shape == emb_o.shape
+    assert rel(emb, emb_o) < 4e-2, "sam embeddings"
+    pe = model(mode="get_dense_pe")
+    assert rel(pe, O.dense_pe(sd, d)) < 1e-2
+
+
+def test_inference_matches_oracle_and_golden(setup, dev):
+    from grove_amd.synthetic import synthetic_batch
+    from oracle import grove_oracle as O
+    model, sd, d = setup
+    batch = synthetic_batch(d, B=2, T=8, L=40, n_det=3, seed=2)
+    kw = to_dev(batch, dev)
+    kw["inference"] = True
+    out = model(**kw)
+    kwo = batch.as_kwargs(inference=True)
+    kwo["global_enc_images"] = kwo["global_enc_images"].to(bf).float()
+    kwo["grounding_enc_images"] = kwo["grounding_enc_images"].to(bf).float()
+    with torch.no_grad():
+        ref = O.model_forward(sd, d, **kwo)
+    assert rel(out["hidden"], ref["hidden"]) < 4e-2, "llama hidden"
+    l1 = (out["flat_boxes"].cpu() - ref["flat_boxes"]).abs().mean().item()
+    assert l1 < 2e-3, f"box L1 {l1}"
+    dl = (out["flat_logits"].cpu() - ref["flat_logits"]).abs().max().item()
+    assert dl < 5e-2, f"objectness logit err {dl}"
+    # golden vectors of the reference itself (fp32 weights): same bounds + bf16 weight rounding
+    g = np.load(os.path.join(G, "tiny_infer_B2_T8_seed2.npz"))
+    l1g = np.abs(out["flat_boxes"].cpu().numpy() - g["flat_boxes_normalised"]).mean()
+    assert l1g < 4e-3, f"box L1 vs reference golden {l1g}"
+    # structure of the returned lists (GROVE.py:297-331)
+    assert len(out["pred_bboxes"]) == 2 and len(out["pred_bboxes"][0]) == 8
+    for b in range(2):
+        for t in range(8):
+            lo = out["logits_temp_objectness"][b][t]
+            assert out["pred_bboxes"][b][t].shape[0] == int((torch.sigmoid(lo) > 0.5).sum())
+
+
+def test_training_losses_match_oracle(setup, dev):
+    from grove_amd.synthetic import synthetic_batch
+    from oracle import grove_oracle as O
+    model, sd, d = setup
+    batch = synthetic_batch(d, B=2, T=8, L=48, n_det=2, seed=1, ragged=True)
+    kw = to_dev(batch, dev)
+    out = model(**kw)
+    kwo = batch.as_kwargs()
+    kwo["global_enc_images"] = kwo["global_enc_images"].to(bf).float()
+    kwo["grounding_enc_images"] = kwo["grounding_enc_images"].to(bf).float()
+    with torch.no_grad():
+        ref = O.model_forward(sd, d, **kwo)
+    for k in ("ce_loss", "giou_loss", "l1_loss", "temp_objectness_loss", "loss"):
+        a, b = float(out[k]), float(ref[k])
+        assert abs(a - b) <= 2e-2 * max(1.0, abs(b)), f"{k}: {a} vs {b}"
+    g = np.load(os.path.join(G, "tiny_train_B2_T8_ragged_seed1.npz"))
+    for k in ("ce_loss", "giou_loss", "l1_loss", "temp_objectness_loss"):
+        assert abs(float(out[k]) - float(g[k])) <= 3e-2 * max(1.0, abs(float(g[k]))), k
