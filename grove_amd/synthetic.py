@@ -102,7 +102,7 @@ class GroveDims:
 
 
 FULL = GroveDims()
-TINY = GroveDims(hidden=128, n_layers=2, n_heads=4, mlp=256, vocab=320, clip_dim=64, clip_layers=6, clip_heads=4,
+TINY = GroveDims(hidden=128, n_layers=2, n_heads=4, mlp=256, vocab=320, clip_dim=64, clip_layers=6, clip_heads=2,
                  clip_mlp=128, sam_dim=64, sam_depth=4, sam_heads=4, sam_global=(1, 3), det_token_idx=319)
 
 
