@@ -1,0 +1,51 @@
+"""N>1 path on CPU: two gloo processes exercise the bucketed gradient all-reduce, the clip sharding and the
+folded meter all-reduce of grove_amd.train exactly as the RCCL path uses them."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from grove_amd.train import allreduce_buckets, shard_clips
+    g = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+    allreduce_buckets(g, 96)  # 11 buckets, last one ragged
+    ok = torch.equal(g, torch.arange(1000, dtype=torch.float32) * 3)
+    mine = shard_clips(7, rank, world)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)
+    t = torch.tensor([1.0 + rank, 1.0, 2.0 * rank, 1.0])  # (sum, count) x 2 meters in ONE collective
+    dist.all_reduce(t)
+    out[rank] = (ok, gathered, t.tolist())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_exchange_and_sharding():
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    for r in range(world):
+        ok, gathered, meters = out[r]
+        assert ok
+        assert sorted(i for part in gathered for i in part) == [0, 0, 1, 2, 3, 4, 5, 6]  # padded by wrap-around
+        assert len(gathered[0]) == len(gathered[1]) == 4
+        assert meters == [3.0, 2.0, 2.0, 2.0]
+
+
+def test_warmup_decay_lr():
+    from grove_amd.train import WarmupDecayLR
+    s = WarmupDecayLR(3e-4, 1000, 100)
+    assert s.get(0) == 0.0 and abs(s.get(50) - 1.5e-4) < 1e-12 and abs(s.get(100) - 3e-4) < 1e-12
+    assert abs(s.get(550) - 1.5e-4) < 1e-12 and s.get(1000) == 0.0

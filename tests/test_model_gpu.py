@@ -110,3 +110,44 @@ def test_training_losses_match_oracle(setup, dev):
     g = np.load(os.path.join(G, "tiny_train_B2_T8_ragged_seed1.npz"))
     for k in ("ce_loss", "giou_loss", "l1_loss", "temp_objectness_loss"):
         assert abs(float(out[k]) - float(g[k])) <= 3e-2 * max(1.0, abs(float(g[k]))), k
+
+
+def test_backward_matches_oracle_autograd(dev):
+    """Gradients of the full training step (shipped freeze policy) vs torch autograd through the oracle."""
+    from grove_amd import GROVEForCausalLM
+    from grove_amd.model.GROVE import trainable_names
+    from grove_amd.synthetic import TINY, synthetic_batch, synthetic_state_dict
+    from oracle import grove_oracle as O
+    d = TINY
+    sd = synthetic_state_dict(d)
+    names = trainable_names(d)
+    model = GROVEForCausalLM(dims=d, device=dev, state_dict=sd, det_token_idx=d.det_token_idx, num_frames=8,
+                             pe_dtype=torch.float32, train=True)
+    batch = synthetic_batch(d, B=2, T=8, L=48, n_det=2, seed=1, ragged=True)
+    kw = to_dev(batch, dev)
+    model.zero_grad()
+    out = model(**kw)
+    model.backward(out["loss"])
+    sdg = {k: v.to(bf).float().requires_grad_(k in names) for k, v in sd.items()}
+    kwo = batch.as_kwargs()
+    kwo["global_enc_images"] = kwo["global_enc_images"].to(bf).float()
+    kwo["grounding_enc_images"] = kwo["grounding_enc_images"].to(bf).float()
+    ref = O.model_forward(sdg, d, **kwo)
+    ref["loss"].backward()
+    bad = []
+    for n in names:
+        g = model._grad[n].detach().float().cpu()
+        r = sdg[n].grad
+        if n.endswith("conv3d.weight"):  # gradient is kept tap-major [Co, (kt kh kw), Ci]
+            Co, Ci = r.shape[0], r.shape[1]
+            g = g.view(Co, 3, 3, 3, Ci).permute(0, 4, 1, 2, 3)
+        g = g.reshape(r.shape)
+        if r.norm() < 1e-6:
+            # mathematically zero gradients (key-projection biases: softmax is shift invariant) — only noise
+            assert g.norm() < 1e-3, (n, float(g.norm()))
+            continue
+        cos = torch.nn.functional.cosine_similarity(g.flatten(), r.flatten(), dim=0).item()
+        scale = (g.norm() / r.norm().clamp_min(1e-12)).item()
+        if not (cos > 0.98 and 0.9 < scale < 1.1):
+            bad.append((n, round(cos, 4), round(scale, 4), float(r.norm())))
+    assert not bad, f"{len(bad)}/{len(names)} gradients off: {bad[:12]}"
