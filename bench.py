@@ -60,7 +60,7 @@ def instrumented_gemm_pass(engine, batch):
         r = orig(A, B, C, M, N, K, *a, **k)
         e1.record()
         b = k.get("batch", (1, 1))
-        recs.append((e0, e1, 2.0 * M * N * K * b[0] * b[1]))
+        recs.append((e0, e1, 2.0 * M * N * K * b[0] * b[1], (M, N, K, b[0] * b[1], k.get("a_taps", 1))))
         return r
     ops.gemm_raw = timed
     try:
@@ -70,8 +70,18 @@ def instrumented_gemm_pass(engine, batch):
         torch.cuda.synchronize()
     finally:
         ops.gemm_raw = orig
-    secs = sum(e0.elapsed_time(e1) for e0, e1, _ in recs) * 1e-3
-    return len(recs), sum(f for _, _, f in recs), secs
+    secs = sum(r[0].elapsed_time(r[1]) for r in recs) * 1e-3
+    report = os.environ.get("GROVE_GEMM_REPORT")
+    if report:
+        agg = {}
+        for e0, e1, f, key in recs:
+            t, n, fl = agg.get(key, (0.0, 0, 0.0))
+            agg[key] = (t + e0.elapsed_time(e1), n + 1, fl + f)
+        with open(report, "w") as fh:
+            fh.write("M N K batch taps | launches total_ms TF/s\n")
+            for key, (t, n, fl) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+                fh.write(f"{key} | {n} {t:.3f} {fl / t / 1e9:.1f}\n")
+    return len(recs), sum(r[2] for r in recs), secs
 
 
 def cpu_baseline(args):
@@ -80,7 +90,7 @@ def cpu_baseline(args):
     from grove_amd.synthetic import FULL, det_tensor, param_shapes, synthetic_state_dict
     from oracle import grove_oracle as O
     d = FULL
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 64)  # torch CPU kernels stop scaling (and oversubscribe) beyond ~64 threads
     torch.set_num_threads(cores)
     want = [n for n in param_shapes(d) if any(s in n for s in (
         "vision_model.encoder.layers.1.", "image_encoder.blocks.6.", "image_encoder.blocks.7.", "image_encoder.adapters.0.",

@@ -114,7 +114,12 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(const grove_gemm_params p, 
     }
   };
 
-  const int nk = p.K / BK;
+  const int nk_total = p.K / BK;
+  const int nsplit = gridDim.z;
+  const int nk_per = (nk_total + nsplit - 1) / nsplit;
+  const int kt0 = blockIdx.z * nk_per;
+  const int nk = min(nk_total, kt0 + nk_per);  // exclusive end tile of this split
+  if (kt0 >= nk) return;                         // empty split (uniform for the whole block)
   u32x4_t ra[LPT], rb[LPT];
 
   auto issue_loads = [&](int kt, char* buf) {
@@ -194,14 +199,14 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(const grove_gemm_params p, 
   char* buf1 = smem + 2 * TILE_BYTES;
 
   // ---- prologue ----
-  issue_loads(0, buf0);
+  issue_loads(kt0, buf0);
   if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   commit_loads(buf0);
   __syncthreads();
 
-  for (int kt = 0; kt < nk; ++kt) {
-    char* cur = (kt & 1) ? buf1 : buf0;
-    char* nxt = (kt & 1) ? buf0 : buf1;
+  for (int kt = kt0; kt < nk; ++kt) {
+    char* cur = ((kt - kt0) & 1) ? buf1 : buf0;
+    char* nxt = ((kt - kt0) & 1) ? buf0 : buf1;
     const bool more = kt + 1 < nk;
     if (more) issue_loads(kt + 1, nxt);
     compute(cur);
@@ -288,7 +293,12 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(const grove_gemm_params p, 
         }
       } else {
         float* c = (float*)p.C + c_boff + (int64_t)crow * p.ldc + n;
-        if (full) {
+        if (nsplit > 1) {
+          // split-K partials meet in C through fp32 atomics (C pre-initialised by the caller: accumulate semantics)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (n + e < p.N) atomicAdd(c + e, v[e]);
+        } else if (full) {
           f32x4_t o = f32x4_t{v[0], v[1], v[2], v[3]};
           if (p.accumulate) {
             const f32x4_t old = *(const f32x4_t*)c;
@@ -308,7 +318,25 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(const grove_gemm_params p, 
 template <int BK, bool GLDS>
 int launch(const grove_gemm_params& p, int vec_ok, hipStream_t s) {
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
-  dim3 grid(tiles_m * tiles_n, p.batch1 * p.batch2, 1);
+  int split = p.split_k;
+  const bool can_split = p.accumulate && p.c_dtype == GROVE_F32 && !p.bias && !p.residual && !p.aux && p.act == GROVE_ACT_NONE;
+  if (split == 0) {
+    // auto: pure accumulating GEMMs (weight gradients) that cannot fill 256 CUs get their K range split
+    split = 1;
+    const long tiles = (long)tiles_m * tiles_n * p.batch1 * p.batch2;
+    const int nk = p.K / BK;
+    if (can_split && tiles < 256 && nk >= 16) {
+      split = (int)((768 + tiles - 1) / tiles);
+      if (split > nk / 4) split = nk / 4;
+      if (split > 128) split = 128;
+      if (split < 1) split = 1;
+    }
+  }
+  if (split > 1 && !can_split) {
+    grove_set_error("gemm: split_k needs an accumulating f32 C without bias/act/residual/aux");
+    return GROVE_E_SHAPE;
+  }
+  dim3 grid(tiles_m * tiles_n, p.batch1 * p.batch2, split);
   const size_t lds = 2 * 2 * BM * BK * 2;
   static bool attr_set = false;
   if (!attr_set) {

@@ -68,14 +68,16 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const grove_softmax_pa
 // ---------------------------------------------------------------- softmax backward
 template <int NCH>
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(const grove_softmax_bwd_params p) {
-  __shared__ float relbuf[4][64];
+  // drel: each wave parks its (unscaled) dS row in LDS, then lane t < kh sums stripe t over kw and lane
+  // kh + t sums column t over kh: (kh + kw) short reads instead of two LDS atomics per element.
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* rowbuf = (float*)smem_raw;  // [4][NCH * 256] when drel is requested
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int64_t row = (int64_t)blockIdx.x * 4 + wave;
   const int64_t nrows = (int64_t)p.batch * p.Lq;
   const bool active = row < nrows;
   const int nrel = p.rel_kh + p.rel_kw;
-  if (p.drel) relbuf[wave][lane] = 0.f;
   float g[NCH][4], pr[NCH][4];
   float dot = 0.f;
   if (active) {
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const grove_softmax_bw
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int j0 = (lane + c * 64) * 4;
-      if (j0 < p.ld_s && j0 < p.ld_p && j0 < p.Lk + 3) {
+      if (j0 < p.ld_s && j0 < p.ld_p && j0 < p.Lk) {
         const f32x4_t x = *(const f32x4_t*)(dp + j0);
         const u32x2_t u = *(const u32x2_t*)(pb + j0);
         pr[c][0] = bf_lo(u.x); pr[c][1] = bf_hi(u.x); pr[c][2] = bf_lo(u.y); pr[c][3] = bf_hi(u.y);
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const grove_softmax_bw
     }
   }
   dot = wave_sum(dot);
-  if (p.drel) __syncthreads();
+  float* myrow = rowbuf + wave * (NCH * 256);
   if (active) {
     bf16_raw* ds = (bf16_raw*)p.dscores + row * p.ld_p;
 #pragma unroll
@@ -109,21 +111,24 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const grove_softmax_bw
       const int j0 = (lane + c * 64) * 4;
       float o[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        o[e] = pr[c][e] * (g[c][e] - dot);
-        if (p.drel && j0 + e < p.Lk && o[e] != 0.f) {
-          const int j = j0 + e;
-          atomicAdd(&relbuf[wave][j / p.rel_kw], o[e]);
-          atomicAdd(&relbuf[wave][p.rel_kh + j % p.rel_kw], o[e]);
-        }
-        o[e] *= p.scale;
-      }
-      if (j0 < p.ld_p) *(u32x2_t*)(ds + j0) = u32x2_t{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+      for (int e = 0; e < 4; ++e) o[e] = pr[c][e] * (g[c][e] - dot);
+      if (p.drel) *(f32x4_t*)(myrow + j0) = f32x4_t{o[0], o[1], o[2], o[3]};
+      if (j0 < p.ld_p) *(u32x2_t*)(ds + j0) = u32x2_t{pack2bf(o[0] * p.scale, o[1] * p.scale), pack2bf(o[2] * p.scale, o[3] * p.scale)};
     }
   }
   if (p.drel) {
     __syncthreads();
-    if (active && lane < nrel) p.drel[row * nrel + lane] = relbuf[wave][lane];
+    if (active && lane < nrel) {
+      float acc = 0.f;
+      if (lane < p.rel_kh) {
+        const float* r = myrow + lane * p.rel_kw;
+        for (int w = 0; w < p.rel_kw; ++w) acc += r[w];
+      } else {
+        const float* r = myrow + (lane - p.rel_kh);
+        for (int h = 0; h < p.rel_kh; ++h) acc += r[h * p.rel_kw];
+      }
+      p.drel[row * nrel + lane] = acc;
+    }
   }
 }
 
@@ -232,11 +237,11 @@ extern "C" int grove_softmax_bwd(const grove_softmax_bwd_params* p, void* stream
   const int w = p->ld_p > p->ld_s ? p->ld_p : p->ld_s;
   const int nch = (w + 255) / 256;
   hipStream_t s = (hipStream_t)stream;
-  if (nch <= 1) hipLaunchKernelGGL((softmax_bwd_kernel<1>), grid, dim3(256), 0, s, *p);
-  else if (nch <= 2) hipLaunchKernelGGL((softmax_bwd_kernel<2>), grid, dim3(256), 0, s, *p);
-  else if (nch <= 3) hipLaunchKernelGGL((softmax_bwd_kernel<3>), grid, dim3(256), 0, s, *p);
-  else if (nch <= 4) hipLaunchKernelGGL((softmax_bwd_kernel<4>), grid, dim3(256), 0, s, *p);
-  else hipLaunchKernelGGL((softmax_bwd_kernel<8>), grid, dim3(256), 0, s, *p);
+  if (nch <= 1) hipLaunchKernelGGL((softmax_bwd_kernel<1>), grid, dim3(256), p->drel ? (size_t)4 * 1 * 256 * sizeof(float) : 0, s, *p);
+  else if (nch <= 2) hipLaunchKernelGGL((softmax_bwd_kernel<2>), grid, dim3(256), p->drel ? (size_t)4 * 2 * 256 * sizeof(float) : 0, s, *p);
+  else if (nch <= 3) hipLaunchKernelGGL((softmax_bwd_kernel<3>), grid, dim3(256), p->drel ? (size_t)4 * 3 * 256 * sizeof(float) : 0, s, *p);
+  else if (nch <= 4) hipLaunchKernelGGL((softmax_bwd_kernel<4>), grid, dim3(256), p->drel ? (size_t)4 * 4 * 256 * sizeof(float) : 0, s, *p);
+  else hipLaunchKernelGGL((softmax_bwd_kernel<8>), grid, dim3(256), p->drel ? (size_t)4 * 8 * 256 * sizeof(float) : 0, s, *p);
   GROVE_LAUNCH_CHECK();
   return GROVE_OK;
 }

@@ -34,7 +34,7 @@ def pad_to(n, m):
 
 def gemm_raw(A, B, Cout, M, N, K, lda, ldb, ldc, *, bias=None, residual=None, ldr=0, aux=None, scale_ptr=None,
              scale_tanh=False, a_idx=None, a_taps=1, c_idx=None, r_idx=None, batch=(1, 1), sA=(0, 0), sB=(0, 0),
-             sC=(0, 0), sR=(0, 0), act=ACT_NONE, accumulate=False, alpha=1.0):
+             sC=(0, 0), sR=(0, 0), act=ACT_NONE, accumulate=False, alpha=1.0, split_k=0):
     """Direct call of grove_gemm_bf16; A/B/Cout are tensors whose storage the pointers refer to."""
     _chk_dev(A, B, Cout)
     p = _lib.GemmParams()
@@ -49,6 +49,7 @@ def gemm_raw(A, B, Cout, M, N, K, lda, ldb, ldc, *, bias=None, residual=None, ld
     p.a_taps, p.act = a_taps, act
     p.c_dtype = F32 if Cout.dtype == torch.float32 else BF16
     p.accumulate, p.scale_tanh, p.alpha = int(accumulate), int(scale_tanh), float(alpha)
+    p.split_k = split_k
     _lib.check(_lib.lib().grove_gemm_bf16(C.byref(p), _stream()), "grove_gemm_bf16")
     return Cout
 

@@ -84,6 +84,8 @@ typedef struct grove_gemm_params {
   int32_t accumulate; /* C += result (c_dtype f32 only) */
   int32_t scale_tanh; /* scale = tanh(*scale_ptr) */
   float alpha;
+  int32_t split_k;    /* 0 = auto (accumulating f32 GEMMs only), 1 = off, >1 = K range split over blockIdx.z,
+                         partials combined with fp32 atomics into the pre-initialised C */
 } grove_gemm_params;
 int grove_gemm_bf16(const grove_gemm_params* p, void* stream);
 /* A/B staging variant: 1 = LDS-DMA (global_load_lds, default), 0 = register staged */

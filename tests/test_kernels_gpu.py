@@ -462,3 +462,16 @@ def test_adamw_sumsq(dev):
     close(master, p.detach(), 1e-5, "adamw")
     close(model, p.detach().to(bf16), 1e-7 + 4e-3, "adamw bf16 copy")
     close(ops.sumsq(gr.to(dev)), (gr * gr).sum().reshape(1), 1e-5, "sumsq")
+
+
+def test_gemm_split_k_atomics(dev):
+    """Accumulating f32 GEMMs (weight gradients) with K split over blockIdx.z, partials met by fp32 atomics."""
+    from grove_amd import ops
+    M, N, K = 128, 256, 32 * 96
+    a, b = rnd(M, K, seed=70), rnd(N, K, seed=71)
+    c0 = torch.randn(M, N, generator=torch.Generator().manual_seed(72))
+    ref = c0 + a.float() @ b.float().t()
+    for split in (0, 1, 5, 24):
+        out = c0.clone().to(dev)
+        ops.gemm_raw(a.to(dev), b.to(dev), out, M, N, K, K, K, N, accumulate=True, split_k=split)
+        close(out, ref, 3e-5, f"split_k={split}")
