@@ -91,19 +91,28 @@ class BoxHeadBwdParams(C.Structure):
                 ("N", c_i32), ("D", c_i32)]
 
 
+class FlashAttnParams(C.Structure):
+    _fields_ = [("q", c_vp), ("k", c_vp), ("v", c_vp), ("o", c_vp), ("d_o", c_vp), ("dq", c_vp), ("dk", c_vp), ("dv", c_vp),
+                ("lse", c_vp), ("delta", c_vp), ("kv_len", c_vp), ("rel", c_vp), ("drel", c_vp),
+                ("sq", c_i64), ("sk", c_i64), ("sv", c_i64), ("so", c_i64), ("sdo", c_i64), ("sdq", c_i64), ("sdk", c_i64), ("sdv", c_i64),
+                ("B", c_i32), ("H", c_i32), ("Lq", c_i32), ("Lk", c_i32), ("hs", c_i32),
+                ("ld_q", c_i32), ("ld_k", c_i32), ("ld_v", c_i32), ("ld_o", c_i32), ("ld_do", c_i32), ("ld_dq", c_i32),
+                ("ld_dk", c_i32), ("ld_dv", c_i32), ("causal", c_i32), ("rel_kh", c_i32), ("rel_kw", c_i32), ("alpha", c_f32)]
+
+
 STRUCTS = {
     "grove_gemm_params": GemmParams, "grove_transpose_params": TransposeParams, "grove_norm_params": NormParams,
     "grove_norm_bwd_params": NormBwdParams, "grove_softmax_params": SoftmaxParams,
     "grove_softmax_bwd_params": SoftmaxBwdParams, "grove_relpos_params": RelposParams, "grove_rope_params": RopeParams,
     "grove_rows_params": RowsParams, "grove_small_attn_params": SmallAttnParams, "grove_box_head_params": BoxHeadParams,
-    "grove_box_head_bwd_params": BoxHeadBwdParams,
+    "grove_box_head_bwd_params": BoxHeadBwdParams, "grove_flash_attn_params": FlashAttnParams,
 }
 
 # every symbol include/grove_hip.h declares (tests/test_abi.py checks the header against this list)
 SYMBOLS = [
     "grove_version", "grove_last_error", "grove_sizeof", "grove_gemm_bf16", "grove_gemm_set_staging",
     "grove_transpose_bf16", "grove_layernorm_fwd", "grove_rmsnorm_fwd", "grove_layernorm_bwd", "grove_rmsnorm_bwd",
-    "grove_softmax_fwd", "grove_softmax_bwd", "grove_relpos_fwd", "grove_relpos_bwd", "grove_rope_inplace",
+    "grove_flash_attn_fwd", "grove_flash_attn_bwd", "grove_softmax_fwd", "grove_softmax_bwd", "grove_relpos_fwd", "grove_relpos_bwd", "grove_rope_inplace",
     "grove_swiglu_fwd", "grove_swiglu_bwd", "grove_act_bwd", "grove_add_bf16", "grove_add_bcast_rows",
     "grove_copy_rows", "grove_dot_bf16", "grove_axpy_f32", "grove_scatter_add_f32", "grove_colsum_f32", "grove_cast_f32_to_bf16", "grove_cast_bf16_to_f32",
     "grove_im2col_patch", "grove_clip_pool", "grove_cross_entropy", "grove_small_attn_fwd", "grove_small_attn_bwd",

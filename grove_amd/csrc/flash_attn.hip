@@ -1,0 +1,572 @@
+// Fused (flash-style) multi-head attention for gfx950: forward, and backward as two kernels
+// (dK/dV per key block, dQ per query block) — no score matrix ever reaches HBM.
+//
+// Layout conventions (v_mfma_f32_16x16x32_bf16, wave64; lane l: fr = l & 15, g = l >> 4):
+//   * operands live in LDS as plain row-major [row][HS] bf16 tiles with a row stride of HS*2 + 32 bytes:
+//     that stride is conflict-free both for ds_read_b128 row reads (MFMA A/B fragments along the head dim)
+//     and for ds_read_b64_tr_b16 transposed reads (fragments along the token dim).
+//   * a 16x16 accumulator tile holds D[row = 4g + r][col = fr]. Products are oriented so that the NEXT
+//     product sums over the accumulator's ROW index: the bf16-packed accumulator then is an MFMA operand
+//     with no cross-lane movement (k-order inside a 32-step is permuted identically on both operands:
+//     element j of lane group g is row 4g + j (j < 4) of tile 2s and row 4g + j - 4 of tile 2s + 1).
+//   * forward / dQ kernels compute S^T[key][q] (lane = query: softmax statistics are per lane, reduced
+//     over the 4 lane groups with two shuffles); the dK/dV kernel computes S[q][key] (lane = key).
+// Masks: causal (key j visible iff j <= i + Lk - Lq), per-batch kv_len (right padding), and SAM's
+// decomposed relative-position bias rel[q][j / kw] + rel[q][kh + j % kw] (image_encoder.py:420-458).
+// Replaces: modeling_clip.py:279-319, image_encoder.py:310-319, HF LlamaAttention / flash-attn-2 varlen.
+#include "common.h"
+
+namespace {
+
+constexpr int NTHR = 256;
+constexpr int BKV = 64;  // keys (or queries, in the dK/dV kernel) staged per LDS tile
+
+template <int HS>
+struct Cfg {
+  static constexpr int KS = HS / 32;          // 32-deep k-steps along the head dim
+  static constexpr int DT = HS / 16;          // 16-wide tiles along the head dim
+  static constexpr int ROWB = HS * 2 + 32;    // LDS row stride in bytes
+  static constexpr int TILEB = BKV * ROWB;    // one staged tile
+  static constexpr int CPR = HS / 8;          // 16-byte chunks per row
+};
+
+__device__ __forceinline__ bf16x8_t lds_row_frag(const char* tile, int rowb, int row, int kchunk) {
+  return *(const bf16x8_t*)(tile + row * rowb + kchunk * 16);
+}
+
+// two transposed reads -> the 8-element fragment {rows 4g..4g+3, rows 16+4g..16+4g+3} of column (c0 + fr)
+__device__ __forceinline__ bf16x8_t lds_tr_frag(const char* tile, int rowb, int row0, int c0, int lane) {
+  const int fr = lane & 15, g = lane >> 4;
+  const int qq = fr >> 2, pp = fr & 3;
+  const char* a0 = tile + (row0 + 4 * g + qq) * rowb + (c0 + 4 * pp) * 2;
+  typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(a0));
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(a0 + 16 * rowb));
+  typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+  const s16x8_t v = s16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
+__device__ __forceinline__ bf16x8_t pack_frag(const f32x4_t a, const f32x4_t b) {
+  const u32x4_t u = u32x4_t{pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(b[0], b[1]), pack2bf(b[2], b[3])};
+  return __builtin_bit_cast(bf16x8_t, u);
+}
+
+// stage `rows` rows (clamped to [0, nrows_valid-1]) of a [*, ld] bf16 matrix into an LDS tile
+template <int HS>
+__device__ __forceinline__ void stage_tile(char* tile, const bf16_raw* __restrict__ src, int ld, int row0, int nrows_valid, int tid) {
+  using C = Cfg<HS>;
+  constexpr int PER = (BKV * C::CPR) / NTHR;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int q = tid + i * NTHR;
+    const int r = q / C::CPR, c = q - r * C::CPR;
+    const int gr = min(row0 + r, nrows_valid - 1);
+    const u32x4_t v = *(const u32x4_t*)(src + (int64_t)gr * ld + c * 8);
+    *(u32x4_t*)(tile + r * C::ROWB + c * 16) = v;
+  }
+}
+
+__device__ __forceinline__ float group_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float group_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
+
+// ================================================================================ forward
+template <int HS>
+__global__ __launch_bounds__(NTHR) void flash_fwd_kernel(const grove_flash_attn_params p) {
+  using C = Cfg<HS>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ks = smem;
+  char* Vs = smem + C::TILEB;
+  float* rels = (float*)(smem + 2 * C::TILEB);  // [128][nrel]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, g = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int qblk = blockIdx.x * 128;
+  const int q0 = qblk + wave * 32;
+  const bf16_raw* Q = (const bf16_raw*)p.q + (int64_t)b * p.sq + h * HS;
+  const bf16_raw* K = (const bf16_raw*)p.k + (int64_t)b * p.sk + h * HS;
+  const bf16_raw* V = (const bf16_raw*)p.v + (int64_t)b * p.sv + h * HS;
+  const int nrel = p.rel_kh + p.rel_kw;
+
+  bf16x8_t qf[2][C::KS];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int qi = min(q0 + mi * 16 + fr, p.Lq - 1);
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) qf[mi][ks] = *(const bf16x8_t*)(Q + (int64_t)qi * p.ld_q + ks * 32 + g * 8);
+  }
+  if (p.rel) {
+    const float* R = p.rel + ((int64_t)(b * p.H + h) * p.Lq) * nrel;
+    for (int t = tid; t < 128 * nrel; t += NTHR) {
+      const int r = t / nrel, c = t - r * nrel;
+      rels[t] = R[(int64_t)min(qblk + r, p.Lq - 1) * nrel + c];
+    }
+  }
+  f32x4_t oacc[2][C::DT];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt) oacc[mi][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+
+  int kv_end = p.Lk;
+  if (p.kv_len) kv_end = min(kv_end, p.kv_len[b]);
+  int kv_lim = kv_end;
+  if (p.causal) kv_lim = min(kv_lim, min(qblk + 127, p.Lq - 1) + (p.Lk - p.Lq) + 1);
+  const float sc = p.alpha * 1.4426950408889634f;  // exp2 domain
+
+  for (int kv0 = 0; kv0 < kv_lim; kv0 += BKV) {
+    __syncthreads();
+    stage_tile<HS>(Ks, K, p.ld_k, kv0, p.Lk, tid);
+    stage_tile<HS>(Vs, V, p.ld_v, kv0, p.Lk, tid);
+    __syncthreads();
+    f32x4_t s[2][4];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) s[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) {
+        const bf16x8_t kf = lds_row_frag(Ks, C::ROWB, ni * 16 + fr, ks * 4 + g);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) s[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[mi][ks], s[mi][ni], 0, 0, 0);
+      }
+    bf16x8_t pf[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int qi = q0 + mi * 16 + fr;
+      int lim = kv_end;
+      if (p.causal) lim = min(lim, qi + (p.Lk - p.Lq) + 1);
+      const float* rr = rels + (wave * 32 + mi * 16 + fr) * nrel;
+      float mx = -INFINITY;
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = kv0 + ni * 16 + g * 4 + r;
+          float v = s[mi][ni][r] * sc;
+          if (p.rel && j < p.Lk) v += (rr[j / p.rel_kw] + rr[p.rel_kh + j % p.rel_kw]) * 1.4426950408889634f;
+          v = j < lim ? v : -INFINITY;
+          s[mi][ni][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      mx = group_max(mx);
+      const float m_new = fmaxf(m_run[mi], mx);
+      const float m_use = m_new == -INFINITY ? 0.f : m_new;
+      const float corr = exp2f(m_run[mi] - m_use);  // m_run = -inf -> 0
+      float rs = 0.f;
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = exp2f(s[mi][ni][r] - m_use);
+          s[mi][ni][r] = e;
+          rs += e;
+        }
+      rs = group_sum(rs);
+      l_run[mi] = l_run[mi] * corr + rs;
+      m_run[mi] = m_new;
+#pragma unroll
+      for (int dt = 0; dt < C::DT; ++dt) oacc[mi][dt] *= corr;
+      pf[mi][0] = pack_frag(s[mi][0], s[mi][1]);
+      pf[mi][1] = pack_frag(s[mi][2], s[mi][3]);
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int dt = 0; dt < C::DT; ++dt) {
+        const bf16x8_t vf = lds_tr_frag(Vs, C::ROWB, s2 * 32, dt * 16, lane);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) oacc[mi][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[mi][s2], oacc[mi][dt], 0, 0, 0);
+      }
+  }
+  // epilogue: lane holds O^T[d = dt*16 + 4g + r][q = fr]
+  bf16_raw* O = (bf16_raw*)p.o + (int64_t)b * p.so + h * HS;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int qi = q0 + mi * 16 + fr;
+    if (qi >= p.Lq) continue;
+    const float inv = l_run[mi] > 0.f ? 1.f / l_run[mi] : 0.f;
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt) {
+      const f32x4_t o = oacc[mi][dt] * inv;
+      *(u32x2_t*)(O + (int64_t)qi * p.ld_o + dt * 16 + g * 4) = u32x2_t{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+    }
+    if (p.lse && g == 0) {
+      // natural-log LSE of the scaled + biased scores
+      const float mm = m_run[mi] == -INFINITY ? 0.f : m_run[mi];
+      p.lse[(int64_t)(b * p.H + h) * p.Lq + qi] = (mm + log2f(fmaxf(l_run[mi], 1e-30f))) * 0.6931471805599453f;
+    }
+  }
+}
+
+// ================================================================================ delta = rowsum(dO * O)
+__global__ __launch_bounds__(NTHR) void flash_delta_kernel(const grove_flash_attn_params p) {
+  // one 16-lane group per (b, h, q) row
+  const int64_t t = (int64_t)blockIdx.x * (NTHR / 16) + (threadIdx.x >> 4);
+  const int l16 = threadIdx.x & 15;
+  const int64_t n = (int64_t)p.B * p.H * p.Lq;
+  float acc = 0.f;
+  if (t < n) {
+    const int qi = (int)(t % p.Lq);
+    const int bh = (int)(t / p.Lq);
+    const int b = bh / p.H, h = bh - b * p.H;
+    const bf16_raw* O = (const bf16_raw*)p.o + (int64_t)b * p.so + (int64_t)qi * p.ld_o + h * p.hs;
+    const bf16_raw* dO = (const bf16_raw*)p.d_o + (int64_t)b * p.sdo + (int64_t)qi * p.ld_do + h * p.hs;
+    for (int c = l16 * 2; c < p.hs; c += 32) {
+      const unsigned a = *(const unsigned*)(O + c), d = *(const unsigned*)(dO + c);
+      acc += bf_lo(a) * bf_lo(d) + bf_hi(a) * bf_hi(d);
+    }
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (t < n && l16 == 0) p.delta[t] = acc;
+}
+
+// ================================================================================ backward: dK, dV
+// block = 128 keys (wave = 32 keys, K/V fragments in registers); loops over 64-query tiles of Q and dO in LDS.
+template <int HS>
+__global__ __launch_bounds__(NTHR) void flash_bwd_dkv_kernel(const grove_flash_attn_params p) {
+  using C = Cfg<HS>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Qs = smem;
+  char* dOs = smem + C::TILEB;
+  float* lse_s = (float*)(smem + 2 * C::TILEB);  // [64]
+  float* del_s = lse_s + BKV;                    // [64]
+  float* rels = del_s + BKV;                     // [64][nrel]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, g = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int kblk = blockIdx.x * 128;
+  const int k0 = kblk + wave * 32;
+  const bf16_raw* Q = (const bf16_raw*)p.q + (int64_t)b * p.sq + h * HS;
+  const bf16_raw* K = (const bf16_raw*)p.k + (int64_t)b * p.sk + h * HS;
+  const bf16_raw* V = (const bf16_raw*)p.v + (int64_t)b * p.sv + h * HS;
+  const bf16_raw* dO = (const bf16_raw*)p.d_o + (int64_t)b * p.sdo + h * HS;
+  const float* LSE = p.lse + (int64_t)(b * p.H + h) * p.Lq;
+  const float* DEL = p.delta + (int64_t)(b * p.H + h) * p.Lq;
+  const int nrel = p.rel_kh + p.rel_kw;
+  const float* REL = p.rel ? p.rel + ((int64_t)(b * p.H + h) * p.Lq) * nrel : nullptr;
+
+  // K, V fragments of this wave's 32 keys as MFMA B operands: B[k = d][col = key = fr]
+  bf16x8_t kf[2][C::KS], vf[2][C::KS];
+#pragma unroll
+  for (int nj = 0; nj < 2; ++nj) {
+    const int kj = min(k0 + nj * 16 + fr, p.Lk - 1);
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+      kf[nj][ks] = *(const bf16x8_t*)(K + (int64_t)kj * p.ld_k + ks * 32 + g * 8);
+      vf[nj][ks] = *(const bf16x8_t*)(V + (int64_t)kj * p.ld_v + ks * 32 + g * 8);
+    }
+  }
+  f32x4_t dk[2][C::DT], dv[2][C::DT];
+#pragma unroll
+  for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt) { dk[nj][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dv[nj][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+
+  int kv_end = p.Lk;
+  if (p.kv_len) kv_end = min(kv_end, p.kv_len[b]);
+  // causal: queries i with i + (Lk - Lq) >= key are the only ones that see this block's first key
+  int qstart = 0;
+  if (p.causal) qstart = max(0, kblk - (p.Lk - p.Lq));
+  qstart = (qstart / BKV) * BKV;
+  const float sc = p.alpha * 1.4426950408889634f;
+
+  for (int qt0 = qstart; qt0 < p.Lq; qt0 += BKV) {
+    __syncthreads();
+    stage_tile<HS>(Qs, Q, p.ld_q, qt0, p.Lq, tid);
+    stage_tile<HS>(dOs, dO, p.ld_do, qt0, p.Lq, tid);
+    if (tid < BKV) {
+      const int qi = min(qt0 + tid, p.Lq - 1);
+      lse_s[tid] = LSE[qi] * 1.4426950408889634f;
+      del_s[tid] = DEL[qi];
+    }
+    if (REL) {
+      for (int t = tid; t < BKV * nrel; t += NTHR) {
+        const int r = t / nrel, c = t - r * nrel;
+        rels[t] = REL[(int64_t)min(qt0 + r, p.Lq - 1) * nrel + c];
+      }
+    }
+    __syncthreads();
+    // two 32-query k-steps per staged tile
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      // S[q][key] and dP[q][key] for q tiles 2*s2, 2*s2+1 and this wave's 2 key tiles
+      f32x4_t sacc[2][2], pacc[2][2];
+#pragma unroll
+      for (int qi_ = 0; qi_ < 2; ++qi_)
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj) { sacc[qi_][nj] = f32x4_t{0.f, 0.f, 0.f, 0.f}; pacc[qi_][nj] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int qi_ = 0; qi_ < 2; ++qi_)
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) {
+          const int row = (s2 * 2 + qi_) * 16 + fr;
+          const bf16x8_t qa = lds_row_frag(Qs, C::ROWB, row, ks * 4 + g);
+          const bf16x8_t da = lds_row_frag(dOs, C::ROWB, row, ks * 4 + g);
+#pragma unroll
+          for (int nj = 0; nj < 2; ++nj) {
+            sacc[qi_][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[nj][ks], sacc[qi_][nj], 0, 0, 0);
+            pacc[qi_][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[nj][ks], pacc[qi_][nj], 0, 0, 0);
+          }
+        }
+      // P and dS (lane: key = fr of tile nj; rows q = 4g + r of tile qi_)
+      bf16x8_t pfr[2], dsfr[2];
+#pragma unroll
+      for (int nj = 0; nj < 2; ++nj) {
+        const int j = k0 + nj * 16 + fr;
+        f32x4_t pp[2], dd[2];
+#pragma unroll
+        for (int qi_ = 0; qi_ < 2; ++qi_)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int ql = (s2 * 2 + qi_) * 16 + g * 4 + r;
+            const int qi = qt0 + ql;
+            int lim = kv_end;
+            if (p.causal) lim = min(lim, qi + (p.Lk - p.Lq) + 1);
+            float v = sacc[qi_][nj][r] * sc;
+            if (REL && j < p.Lk) v += (rels[ql * nrel + j / p.rel_kw] + rels[ql * nrel + p.rel_kh + j % p.rel_kw]) * 1.4426950408889634f;
+            const bool ok = (j < lim) && (qi < p.Lq);
+            const float pr = ok ? exp2f(v - lse_s[ql]) : 0.f;
+            pp[qi_][r] = pr;
+            dd[qi_][r] = pr * (pacc[qi_][nj][r] - del_s[ql]) * p.alpha;
+          }
+        pfr[nj] = pack_frag(pp[0], pp[1]);
+        dsfr[nj] = pack_frag(dd[0], dd[1]);
+      }
+      // dV[key][d] += sum_q P[q][key] dO[q][d];  dK[key][d] += sum_q dS[q][key] Q[q][d]
+#pragma unroll
+      for (int dt = 0; dt < C::DT; ++dt) {
+        const bf16x8_t dob = lds_tr_frag(dOs, C::ROWB, s2 * 32, dt * 16, lane);
+        const bf16x8_t qb = lds_tr_frag(Qs, C::ROWB, s2 * 32, dt * 16, lane);
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj) {
+          dv[nj][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pfr[nj], dob, dv[nj][dt], 0, 0, 0);
+          dk[nj][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsfr[nj], qb, dk[nj][dt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // lane holds dK/dV[key = 4g + r][d = dt*16 + fr]
+  bf16_raw* DK = (bf16_raw*)p.dk + (int64_t)b * p.sdk + h * HS;
+  bf16_raw* DV = (bf16_raw*)p.dv + (int64_t)b * p.sdv + h * HS;
+#pragma unroll
+  for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int kj = k0 + nj * 16 + g * 4 + r;
+      if (kj >= p.Lk) continue;
+#pragma unroll
+      for (int dt = 0; dt < C::DT; ++dt) {
+        DK[(int64_t)kj * p.ld_dk + dt * 16 + fr] = f2bf(dk[nj][dt][r]);
+        DV[(int64_t)kj * p.ld_dv + dt * 16 + fr] = f2bf(dv[nj][dt][r]);
+      }
+    }
+}
+
+// ================================================================================ backward: dQ (+ d rel)
+template <int HS>
+__global__ __launch_bounds__(NTHR) void flash_bwd_dq_kernel(const grove_flash_attn_params p) {
+  using C = Cfg<HS>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ks = smem;
+  char* Vs = smem + C::TILEB;
+  float* rels = (float*)(smem + 2 * C::TILEB);  // [128][nrel]
+  const int nrel = p.rel_kh + p.rel_kw;
+  float* drels = rels + 128 * nrel;             // [128][nrel]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, g = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int qblk = blockIdx.x * 128;
+  const int q0 = qblk + wave * 32;
+  const bf16_raw* Q = (const bf16_raw*)p.q + (int64_t)b * p.sq + h * HS;
+  const bf16_raw* K = (const bf16_raw*)p.k + (int64_t)b * p.sk + h * HS;
+  const bf16_raw* V = (const bf16_raw*)p.v + (int64_t)b * p.sv + h * HS;
+  const bf16_raw* dO = (const bf16_raw*)p.d_o + (int64_t)b * p.sdo + h * HS;
+
+  bf16x8_t qf[2][C::KS], dof[2][C::KS];
+  float lse2[2], del[2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int qi = min(q0 + mi * 16 + fr, p.Lq - 1);
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+      qf[mi][ks] = *(const bf16x8_t*)(Q + (int64_t)qi * p.ld_q + ks * 32 + g * 8);
+      dof[mi][ks] = *(const bf16x8_t*)(dO + (int64_t)qi * p.ld_do + ks * 32 + g * 8);
+    }
+    lse2[mi] = p.lse[(int64_t)(b * p.H + h) * p.Lq + qi] * 1.4426950408889634f;
+    del[mi] = p.delta[(int64_t)(b * p.H + h) * p.Lq + qi];
+  }
+  if (p.rel) {
+    const float* R = p.rel + ((int64_t)(b * p.H + h) * p.Lq) * nrel;
+    for (int t = tid; t < 128 * nrel; t += NTHR) {
+      const int r = t / nrel, c = t - r * nrel;
+      rels[t] = R[(int64_t)min(qblk + r, p.Lq - 1) * nrel + c];
+      drels[t] = 0.f;
+    }
+  }
+  f32x4_t dq[2][C::DT];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt) dq[mi][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  int kv_end = p.Lk;
+  if (p.kv_len) kv_end = min(kv_end, p.kv_len[b]);
+  int kv_lim = kv_end;
+  if (p.causal) kv_lim = min(kv_lim, min(qblk + 127, p.Lq - 1) + (p.Lk - p.Lq) + 1);
+  const float sc = p.alpha * 1.4426950408889634f;
+
+  for (int kv0 = 0; kv0 < kv_lim; kv0 += BKV) {
+    __syncthreads();
+    stage_tile<HS>(Ks, K, p.ld_k, kv0, p.Lk, tid);
+    stage_tile<HS>(Vs, V, p.ld_v, kv0, p.Lk, tid);
+    __syncthreads();
+    f32x4_t s[2][4], dp[2][4];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) { s[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dp[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) {
+        const bf16x8_t ka = lds_row_frag(Ks, C::ROWB, ni * 16 + fr, ks * 4 + g);
+        const bf16x8_t va = lds_row_frag(Vs, C::ROWB, ni * 16 + fr, ks * 4 + g);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          s[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[mi][ks], s[mi][ni], 0, 0, 0);
+          dp[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, dof[mi][ks], dp[mi][ni], 0, 0, 0);
+        }
+      }
+    bf16x8_t dsf[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int qi = q0 + mi * 16 + fr;
+      int lim = kv_end;
+      if (p.causal) lim = min(lim, qi + (p.Lk - p.Lq) + 1);
+      const int ql = wave * 32 + mi * 16 + fr;
+      const float* rr = rels + ql * nrel;
+      float* dr = drels + ql * nrel;
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = kv0 + ni * 16 + g * 4 + r;
+          float v = s[mi][ni][r] * sc;
+          if (p.rel && j < p.Lk) v += (rr[j / p.rel_kw] + rr[p.rel_kh + j % p.rel_kw]) * 1.4426950408889634f;
+          const float pr = j < lim ? exp2f(v - lse2[mi]) : 0.f;
+          const float ds = pr * (dp[mi][ni][r] - del[mi]);
+          if (p.drel && ds != 0.f && qi < p.Lq) {
+            atomicAdd(&dr[j / p.rel_kw], ds);
+            atomicAdd(&dr[p.rel_kh + j % p.rel_kw], ds);
+          }
+          s[mi][ni][r] = ds * p.alpha;
+        }
+      dsf[mi][0] = pack_frag(s[mi][0], s[mi][1]);
+      dsf[mi][1] = pack_frag(s[mi][2], s[mi][3]);
+    }
+    // dQ^T[d][q] += sum_key K^T[d][key] dS^T[key][q]
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int dt = 0; dt < C::DT; ++dt) {
+        const bf16x8_t kt = lds_tr_frag(Ks, C::ROWB, s2 * 32, dt * 16, lane);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) dq[mi][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, dsf[mi][s2], dq[mi][dt], 0, 0, 0);
+      }
+  }
+  bf16_raw* DQ = (bf16_raw*)p.dq + (int64_t)b * p.sdq + h * HS;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int qi = q0 + mi * 16 + fr;
+    if (qi >= p.Lq) continue;
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt) {
+      const f32x4_t o = dq[mi][dt];
+      *(u32x2_t*)(DQ + (int64_t)qi * p.ld_dq + dt * 16 + g * 4) = u32x2_t{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+    }
+  }
+  if (p.drel) {
+    __syncthreads();
+    float* DR = p.drel + ((int64_t)(b * p.H + h) * p.Lq) * nrel;
+    for (int t = tid; t < 128 * nrel; t += NTHR) {
+      const int r = t / nrel, c = t - r * nrel;
+      if (qblk + r < p.Lq) DR[(int64_t)(qblk + r) * nrel + c] = drels[t];
+    }
+  }
+}
+
+int check(const grove_flash_attn_params* p, const char* name) {
+  GROVE_CHECK(p && p->B > 0 && p->H > 0 && p->Lq > 0 && p->Lk > 0, GROVE_E_SHAPE, "%s: bad shape", name);
+  GROVE_CHECK(p->hs == 32 || p->hs == 64 || p->hs == 96 || p->hs == 128, GROVE_E_SHAPE, "%s: head dim %d not in {32,64,96,128}", name, p->hs);
+  GROVE_CHECK(p->ld_q % 8 == 0 && p->ld_k % 8 == 0 && p->ld_v % 8 == 0 && p->ld_o % 4 == 0, GROVE_E_ALIGN, "%s: leading dims must be multiples of 8", name);
+  GROVE_CHECK(((uintptr_t)p->q & 15) == 0 && ((uintptr_t)p->k & 15) == 0 && ((uintptr_t)p->v & 15) == 0, GROVE_E_ALIGN, "%s: q/k/v must be 16-byte aligned", name);
+  GROVE_CHECK(!p->rel || (p->rel_kh * p->rel_kw == p->Lk && p->rel_kh + p->rel_kw <= 64 && p->rel_kw > 0), GROVE_E_SHAPE, "%s: rel dims mismatch", name);
+  return GROVE_OK;
+}
+
+template <int HS>
+size_t lds_fwd(const grove_flash_attn_params* p) { return 2 * Cfg<HS>::TILEB + (p->rel ? (size_t)128 * (p->rel_kh + p->rel_kw) * 4 : 0); }
+
+#define DISPATCH_HS(p, FN)                 \
+  switch ((p)->hs) {                       \
+    case 32: FN(32); break;                \
+    case 64: FN(64); break;                \
+    case 96: FN(96); break;                \
+    default: FN(128); break;               \
+  }
+
+}  // namespace
+
+extern "C" int grove_flash_attn_fwd(const grove_flash_attn_params* p, void* stream) {
+  int rc = check(p, "flash_attn_fwd");
+  if (rc) return rc;
+  GROVE_CHECK(p->o, GROVE_E_SHAPE, "flash_attn_fwd: o required");
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((p->Lq + 127) / 128, p->H, p->B);
+#define FWD(HS)                                                                                           \
+  {                                                                                                       \
+    const size_t lds = lds_fwd<HS>(p);                                                                    \
+    hipFuncSetAttribute((const void*)flash_fwd_kernel<HS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((flash_fwd_kernel<HS>), grid, dim3(NTHR), lds, s, *p);                              \
+  }
+  DISPATCH_HS(p, FWD)
+#undef FWD
+  GROVE_LAUNCH_CHECK();
+  return GROVE_OK;
+}
+
+extern "C" int grove_flash_attn_bwd(const grove_flash_attn_params* p, void* stream) {
+  int rc = check(p, "flash_attn_bwd");
+  if (rc) return rc;
+  GROVE_CHECK(p->o && p->d_o && p->lse && p->delta && p->dq && p->dk && p->dv, GROVE_E_SHAPE, "flash_attn_bwd: o, d_o, lse, delta, dq, dk, dv required");
+  GROVE_CHECK(!p->drel || p->rel, GROVE_E_SHAPE, "flash_attn_bwd: drel needs rel");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t nrows = (int64_t)p->B * p->H * p->Lq;
+  hipLaunchKernelGGL(flash_delta_kernel, dim3((unsigned)((nrows + 15) / 16)), dim3(NTHR), 0, s, *p);
+  const int nrel = p->rel ? p->rel_kh + p->rel_kw : 0;
+  dim3 gk((p->Lk + 127) / 128, p->H, p->B), gq((p->Lq + 127) / 128, p->H, p->B);
+#define BWD(HS)                                                                                            \
+  {                                                                                                        \
+    const size_t l1 = 2 * Cfg<HS>::TILEB + 2 * BKV * 4 + (size_t)BKV * nrel * 4;                            \
+    const size_t l2 = 2 * Cfg<HS>::TILEB + (size_t)2 * 128 * nrel * 4;                                      \
+    hipFuncSetAttribute((const void*)flash_bwd_dkv_kernel<HS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1); \
+    hipFuncSetAttribute((const void*)flash_bwd_dq_kernel<HS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);  \
+    hipLaunchKernelGGL((flash_bwd_dkv_kernel<HS>), gk, dim3(NTHR), l1, s, *p);                              \
+    hipLaunchKernelGGL((flash_bwd_dq_kernel<HS>), gq, dim3(NTHR), l2, s, *p);                               \
+  }
+  DISPATCH_HS(p, BWD)
+#undef BWD
+  GROVE_LAUNCH_CHECK();
+  return GROVE_OK;
+}

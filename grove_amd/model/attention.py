@@ -6,13 +6,20 @@ and no .transpose().contiguous() copies of q/k. Replaces the bmm/softmax/bmm seq
 modeling_clip.py:279-319, image_encoder.py:310-319 and HF eager LlamaAttention; the backward is the
 explicit five-product form (dP, dS, dV, dQ, dK).
 """
+import os
+
 import torch
 
 from .. import ops
 
+# "flash" (default): fused kernels of csrc/flash_attn.hip. "materialized": the round-1 GEMM + softmax path, kept
+# as an in-process A/B arm and as a second implementation for the tests (GROVE_ATTN=materialized).
+MODE = os.environ.get("GROVE_ATTN", "flash")
+
 
 class AttnCtx:
-    __slots__ = ("probs", "B", "H", "L", "hs", "ld", "q_off", "k_off", "v_off", "alpha", "ld_p", "rel", "rel_hw")
+    __slots__ = ("probs", "B", "H", "L", "hs", "ld", "q_off", "k_off", "v_off", "alpha", "ld_p", "rel", "rel_hw",
+                 "out", "lse", "causal", "kv_len", "flash")
 
 
 def attention_fwd(qkv, B, L, H, hs, q_off, k_off, v_off, alpha, *, causal=False, kv_len=None, rel=None, rel_hw=(0, 0),
@@ -21,6 +28,16 @@ def attention_fwd(qkv, B, L, H, hs, q_off, k_off, v_off, alpha, *, causal=False,
     columns are exact zeros). Returns (out [B*L, H*hs], ctx or None)."""
     dev = qkv.device
     ld = qkv.stride(0)
+    if MODE == "flash":
+        out, lse = ops.flash_attn(qkv, B, L, H, hs, q_off, k_off, v_off, alpha, causal=causal, kv_len=kv_len, rel=rel,
+                                  rel_hw=rel_hw, out=out, want_lse=save)
+        ctx = None
+        if save:
+            ctx = AttnCtx()
+            ctx.flash, ctx.out, ctx.lse, ctx.B, ctx.H, ctx.L, ctx.hs, ctx.ld = True, out, lse, B, H, L, hs, ld
+            ctx.q_off, ctx.k_off, ctx.v_off, ctx.alpha = q_off, k_off, v_off, alpha
+            ctx.rel, ctx.rel_hw, ctx.causal, ctx.kv_len = rel, rel_hw, causal, kv_len
+        return out, ctx
     ld_s = ops.pad_to(L, 4)
     ld_p = ops.pad_to(L, 32)
     scores = torch.empty((B * H, L, ld_s), dtype=torch.float32, device=dev)
@@ -38,6 +55,7 @@ def attention_fwd(qkv, B, L, H, hs, q_off, k_off, v_off, alpha, *, causal=False,
     ctx = None
     if save:
         ctx = AttnCtx()
+        ctx.flash = False
         ctx.probs, ctx.B, ctx.H, ctx.L, ctx.hs, ctx.ld = probs, B, H, L, hs, ld
         ctx.q_off, ctx.k_off, ctx.v_off, ctx.alpha, ctx.ld_p = q_off, k_off, v_off, alpha, ld_p
         ctx.rel, ctx.rel_hw = rel, rel_hw
@@ -47,6 +65,9 @@ def attention_fwd(qkv, B, L, H, hs, q_off, k_off, v_off, alpha, *, causal=False,
 def attention_bwd(ctx, qkv, d_out, dqkv, want_drel=False):
     """d_out: bf16 [B*L, H*hs]. Writes dq/dk/dv into the matching column blocks of dqkv (bf16, same
     layout as qkv; every column of the three blocks is overwritten). Returns drel (f32) if asked."""
+    if ctx.flash:
+        return ops.flash_attn_bwd(qkv, ctx.out, d_out, ctx.lse, dqkv, ctx.B, ctx.L, ctx.H, ctx.hs, ctx.q_off, ctx.k_off, ctx.v_off,
+                                  ctx.alpha, causal=ctx.causal, kv_len=ctx.kv_len, rel=ctx.rel, rel_hw=ctx.rel_hw, want_drel=want_drel)
     B, H, L, hs, ld, ld_p = ctx.B, ctx.H, ctx.L, ctx.hs, ctx.ld, ctx.ld_p
     dev = qkv.device
     bf = torch.bfloat16

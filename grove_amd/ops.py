@@ -184,6 +184,49 @@ def softmax_bwd(dprobs, probs, Lk, scale, *, drel=None, rel_hw=(0, 0), out=None)
     return out
 
 
+def flash_attn(qkv, B, L, H, hs, q_off, k_off, v_off, alpha, *, causal=False, kv_len=None, rel=None, rel_hw=(0, 0), out=None,
+               want_lse=False):
+    """Fused attention over a fused qkv activation [B*L, ld]; returns (out [B*L, H*hs], lse or None)."""
+    dev = qkv.device
+    ld = qkv.stride(0)
+    if out is None:
+        out = torch.empty((B * L, H * hs), dtype=bf16, device=dev)
+    lse = torch.empty((B * H, L), dtype=torch.float32, device=dev) if want_lse else None
+    p = _lib.FlashAttnParams()
+    p.q, p.k, p.v, p.o = _p(qkv[:, q_off:]), _p(qkv[:, k_off:]), _p(qkv[:, v_off:]), _p(out)
+    p.lse, p.kv_len, p.rel = _p(lse), _p(kv_len), _p(rel)
+    p.sq = p.sk = p.sv = L * ld
+    p.so = L * out.stride(0)
+    p.B, p.H, p.Lq, p.Lk, p.hs = B, H, L, L, hs
+    p.ld_q = p.ld_k = p.ld_v = ld
+    p.ld_o = out.stride(0)
+    p.causal, p.rel_kh, p.rel_kw, p.alpha = int(causal), rel_hw[0], rel_hw[1], alpha
+    _lib.check(_lib.lib().grove_flash_attn_fwd(C.byref(p), _stream()), "grove_flash_attn_fwd")
+    return out, lse
+
+
+def flash_attn_bwd(qkv, out, d_out, lse, dqkv, B, L, H, hs, q_off, k_off, v_off, alpha, *, causal=False, kv_len=None, rel=None,
+                   rel_hw=(0, 0), want_drel=False):
+    dev = qkv.device
+    ld, ldd = qkv.stride(0), dqkv.stride(0)
+    delta = torch.empty((B * H, L), dtype=torch.float32, device=dev)
+    drel = torch.empty((B * H, L, rel_hw[0] + rel_hw[1]), dtype=torch.float32, device=dev) if want_drel else None
+    p = _lib.FlashAttnParams()
+    p.q, p.k, p.v, p.o, p.d_o = _p(qkv[:, q_off:]), _p(qkv[:, k_off:]), _p(qkv[:, v_off:]), _p(out), _p(d_out)
+    p.dq, p.dk, p.dv = _p(dqkv[:, q_off:]), _p(dqkv[:, k_off:]), _p(dqkv[:, v_off:])
+    p.lse, p.delta, p.kv_len, p.rel, p.drel = _p(lse), _p(delta), _p(kv_len), _p(rel), _p(drel)
+    p.sq = p.sk = p.sv = L * ld
+    p.so, p.sdo = L * out.stride(0), L * d_out.stride(0)
+    p.sdq = p.sdk = p.sdv = L * ldd
+    p.B, p.H, p.Lq, p.Lk, p.hs = B, H, L, L, hs
+    p.ld_q = p.ld_k = p.ld_v = ld
+    p.ld_o, p.ld_do = out.stride(0), d_out.stride(0)
+    p.ld_dq = p.ld_dk = p.ld_dv = ldd
+    p.causal, p.rel_kh, p.rel_kw, p.alpha = int(causal), rel_hw[0], rel_hw[1], alpha
+    _lib.check(_lib.lib().grove_flash_attn_bwd(C.byref(p), _stream()), "grove_flash_attn_bwd")
+    return drel
+
+
 def relpos(q, Rh, Rw, batch, heads, qhw, khw, hd, hd_stride, ld_q, *, rel=None, dq=None, backward=False):
     p = _lib.RelposParams()
     L = qhw[0] * qhw[1]

@@ -475,3 +475,64 @@ def test_gemm_split_k_atomics(dev):
         out = c0.clone().to(dev)
         ops.gemm_raw(a.to(dev), b.to(dev), out, M, N, K, K, K, N, accumulate=True, split_k=split)
         close(out, ref, 3e-5, f"split_k={split}")
+
+
+@pytest.mark.parametrize("B,H,L,hs,hd,causal,use_len,rel_hw", [
+    (2, 3, 77, 64, 64, False, False, None),
+    (2, 2, 200, 128, 128, True, True, None),
+    (3, 2, 196, 96, 80, False, False, (14, 14)),
+    (1, 2, 1024, 96, 80, False, False, (32, 32)),
+    (2, 4, 50, 32, 16, False, False, (5, 10)),
+    (1, 2, 703, 128, 128, True, False, None),
+])
+def test_flash_attention_fwd_bwd(dev, B, H, L, hs, hd, causal, use_len, rel_hw):
+    """Fused attention (fwd, dQ/dK/dV, d rel) against torch autograd in fp32 on the same bf16 inputs.
+    hd < hs exercises the zero-padded head layout used for SAM (80 -> 96)."""
+    from grove_amd import ops
+    g = torch.Generator().manual_seed(80)
+    qkv = torch.zeros(B * L, 3 * H * hs)
+    qkv.view(B * L, 3, H, hs)[..., :hd] = torch.randn(B * L, 3, H, hd, generator=g)
+    qkv = qkv.to(bf16)
+    do = torch.zeros(B * L, H * hs)
+    do.view(B * L, H, hs)[..., :hd] = torch.randn(B * L, H, hd, generator=g)
+    do = do.to(bf16)
+    alpha = hd ** -0.5
+    kv_len = torch.tensor([L, max(1, L - 37)][:B] + [L] * max(0, B - 2), dtype=torch.int32) if use_len else None
+    rel = None
+    if rel_hw is not None:
+        rel = torch.randn(B * H, L, rel_hw[0] + rel_hw[1], generator=g)
+    t = qkv.float().view(B, L, 3, H, hs).requires_grad_(True)
+    q, k, v = t[:, :, 0].transpose(1, 2), t[:, :, 1].transpose(1, 2), t[:, :, 2].transpose(1, 2)  # [B,H,L,hs]
+    s = q @ k.transpose(-1, -2) * alpha
+    relr = None
+    if rel is not None:
+        relr = rel.clone().requires_grad_(True)
+        kh, kw = rel_hw
+        bias = relr[..., :kh, None] + relr[..., None, kh:]
+        s = s + bias.reshape(B, H, L, L)
+    mask = torch.zeros(B, 1, L, L, dtype=torch.bool)
+    if causal:
+        mask |= torch.ones(L, L, dtype=torch.bool).triu(1)[None, None]
+    if kv_len is not None:
+        for b in range(B):
+            mask[b, :, :, kv_len[b]:] = True
+    s = s.masked_fill(mask, float("-inf"))
+    p = torch.softmax(s, -1)
+    o_ref = (p @ v).transpose(1, 2).reshape(B * L, H * hs)
+    o_ref.backward(do.float())
+    lse_ref = torch.logsumexp(s, -1).reshape(B * H, L)
+    dev_qkv = qkv.to(dev)
+    rel_d = rel.to(dev) if rel is not None else None
+    kvl = kv_len.to(dev) if kv_len is not None else None
+    out, lse = ops.flash_attn(dev_qkv, B, L, H, hs, 0, H * hs, 2 * H * hs, alpha, causal=causal, kv_len=kvl, rel=rel_d,
+                              rel_hw=rel_hw or (0, 0), want_lse=True)
+    close(out, o_ref, 1e-2, "flash fwd")
+    close(lse, lse_ref, 2e-3, "lse")
+    dqkv = torch.full_like(dev_qkv, float("nan"))
+    drel = ops.flash_attn_bwd(dev_qkv, out, do.to(dev), lse, dqkv, B, L, H, hs, 0, H * hs, 2 * H * hs, alpha, causal=causal,
+                              kv_len=kvl, rel=rel_d, rel_hw=rel_hw or (0, 0), want_drel=rel is not None)
+    gref = t.grad.reshape(B * L, 3 * H * hs)
+    for name, c0 in (("dq", 0), ("dk", H * hs), ("dv", 2 * H * hs)):
+        close(dqkv[:, c0:c0 + H * hs], gref[:, c0:c0 + H * hs], 2e-2, name)
+    if rel is not None:
+        close(drel, relr.grad, 2e-2, "drel")
