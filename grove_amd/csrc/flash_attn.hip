@@ -67,6 +67,33 @@ __device__ __forceinline__ void stage_tile(char* tile, const bf16_raw* __restric
   }
 }
 
+// ---- decomposed rel-pos bias on the matrix cores ------------------------------------------------------
+// bias[q][j] = rel[q][kh(j)] + rel[q][KH + kw(j)] = sum_bin rel[q][bin] * E[bin][j] with the 0/1 indicator
+// E[bin][j] = (bin == kh(j)) | (bin == KH + kw(j)). rel is pre-divided by alpha and rounded to bf16 (the
+// reference computes rel_h / rel_w in bf16 as well), so ONE extra 32-deep MFMA per score tile adds the bias into
+// the QK^T accumulator, and in backward d rel = dS . E^T is one MFMA per (32 keys, 16 bins) — no LDS traffic,
+// no atomics. kbin[j] = kh(j) | kw(j) << 8 (0xFFFF beyond Lk) is a small LDS table built once per block.
+__device__ __forceinline__ void build_kbin(unsigned short* tab, int Lk, int n, int kw, int tid) {
+  for (int j = tid; j < n; j += NTHR) tab[j] = j < Lk ? (unsigned short)((j / kw) | ((j % kw) << 8)) : (unsigned short)0xFFFF;
+}
+// indicator fragment of ONE key over bins bin0 .. bin0+7
+__device__ __forceinline__ bf16x8_t efrag_key(unsigned kb, int bin0, int KH) {
+  const int kh = kb & 0xff, kwb = KH + (kb >> 8);
+  typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+  s16x8_t e;
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) e[jj] = ((bin0 + jj) == kh || (bin0 + jj) == kwb) ? (short)0x3F80 : (short)0;
+  return __builtin_bit_cast(bf16x8_t, e);
+}
+// rel[q][bin0 .. bin0+7] / alpha as a bf16 fragment (bins >= nrel -> 0)
+__device__ __forceinline__ bf16x8_t relfrag(const float* relrow, int bin0, int nrel, float inv_alpha) {
+  float v[8];
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) v[jj] = (bin0 + jj) < nrel ? relrow[bin0 + jj] * inv_alpha : 0.f;
+  const u32x4_t u = u32x4_t{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+  return __builtin_bit_cast(bf16x8_t, u);
+}
+
 __device__ __forceinline__ float group_max(float v) {
   v = fmaxf(v, __shfl_xor(v, 16, 64));
   return fmaxf(v, __shfl_xor(v, 32, 64));
@@ -83,7 +110,7 @@ __global__ __launch_bounds__(NTHR) void flash_fwd_kernel(const grove_flash_attn_
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;
   char* Vs = smem + C::TILEB;
-  float* rels = (float*)(smem + 2 * C::TILEB);  // [128][nrel]
+  unsigned short* kbin = (unsigned short*)(smem + 2 * C::TILEB);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, g = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
@@ -93,8 +120,10 @@ __global__ __launch_bounds__(NTHR) void flash_fwd_kernel(const grove_flash_attn_
   const bf16_raw* K = (const bf16_raw*)p.k + (int64_t)b * p.sk + h * HS;
   const bf16_raw* V = (const bf16_raw*)p.v + (int64_t)b * p.sv + h * HS;
   const int nrel = p.rel_kh + p.rel_kw;
+  const int nrk = (nrel + 31) >> 5;  // 32-bin k-steps of the bias MFMA (0 without rel)
 
   bf16x8_t qf[2][C::KS];
+  bf16x8_t relf[2][2];
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi) {
     const int qi = min(q0 + mi * 16 + fr, p.Lq - 1);
@@ -102,10 +131,13 @@ __global__ __launch_bounds__(NTHR) void flash_fwd_kernel(const grove_flash_attn_
     for (int ks = 0; ks < C::KS; ++ks) qf[mi][ks] = *(const bf16x8_t*)(Q + (int64_t)qi * p.ld_q + ks * 32 + g * 8);
   }
   if (p.rel) {
-    const float* R = p.rel + ((int64_t)(b * p.H + h) * p.Lq) * nrel;
-    for (int t = tid; t < 128 * nrel; t += NTHR) {
-      const int r = t / nrel, c = t - r * nrel;
-      rels[t] = R[(int64_t)min(qblk + r, p.Lq - 1) * nrel + c];
+    build_kbin(kbin, p.Lk, ((p.Lk + BKV - 1) / BKV) * BKV, p.rel_kw, tid);
+    const float inv_alpha = 1.f / p.alpha;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const float* rrow = p.rel + ((int64_t)(b * p.H + h) * p.Lq + min(q0 + mi * 16 + fr, p.Lq - 1)) * nrel;
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) relf[mi][k2] = relfrag(rrow, k2 * 32 + g * 8, nrel, inv_alpha);
     }
   }
   f32x4_t oacc[2][C::DT];
@@ -132,20 +164,31 @@ __global__ __launch_bounds__(NTHR) void flash_fwd_kernel(const grove_flash_attn_
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) s[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
+    for (int ni = 0; ni < 4; ++ni) {
 #pragma unroll
       for (int ks = 0; ks < C::KS; ++ks) {
         const bf16x8_t kf = lds_row_frag(Ks, C::ROWB, ni * 16 + fr, ks * 4 + g);
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) s[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[mi][ks], s[mi][ni], 0, 0, 0);
       }
+      if (nrk > 0) {
+        const unsigned kb = kbin[kv0 + ni * 16 + fr];
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+          if (k2 < nrk) {
+            const bf16x8_t ef = efrag_key(kb, k2 * 32 + g * 8, p.rel_kh);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) s[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ef, relf[mi][k2], s[mi][ni], 0, 0, 0);
+          }
+        }
+      }
+    }
     bf16x8_t pf[2][2];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
       const int qi = q0 + mi * 16 + fr;
       int lim = kv_end;
       if (p.causal) lim = min(lim, qi + (p.Lk - p.Lq) + 1);
-      const float* rr = rels + (wave * 32 + mi * 16 + fr) * nrel;
       float mx = -INFINITY;
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni)
@@ -153,7 +196,6 @@ __global__ __launch_bounds__(NTHR) void flash_fwd_kernel(const grove_flash_attn_
         for (int r = 0; r < 4; ++r) {
           const int j = kv0 + ni * 16 + g * 4 + r;
           float v = s[mi][ni][r] * sc;
-          if (p.rel && j < p.Lk) v += (rr[j / p.rel_kw] + rr[p.rel_kh + j % p.rel_kw]) * 1.4426950408889634f;
           v = j < lim ? v : -INFINITY;
           s[mi][ni][r] = v;
           mx = fmaxf(mx, v);
@@ -241,7 +283,8 @@ __global__ __launch_bounds__(NTHR) void flash_bwd_dkv_kernel(const grove_flash_a
   char* dOs = smem + C::TILEB;
   float* lse_s = (float*)(smem + 2 * C::TILEB);  // [64]
   float* del_s = lse_s + BKV;                    // [64]
-  float* rels = del_s + BKV;                     // [64][nrel]
+  char* relq = (char*)(del_s + BKV);             // bf16 [64 q][64 bins], row stride RELB (rel / alpha)
+  constexpr int RELB = 64 * 2 + 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, g = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
@@ -255,9 +298,20 @@ __global__ __launch_bounds__(NTHR) void flash_bwd_dkv_kernel(const grove_flash_a
   const float* DEL = p.delta + (int64_t)(b * p.H + h) * p.Lq;
   const int nrel = p.rel_kh + p.rel_kw;
   const float* REL = p.rel ? p.rel + ((int64_t)(b * p.H + h) * p.Lq) * nrel : nullptr;
+  const int nrk = (nrel + 31) >> 5;
+  const float inv_alpha = 1.f / p.alpha;
 
   // K, V fragments of this wave's 32 keys as MFMA B operands: B[k = d][col = key = fr]
   bf16x8_t kf[2][C::KS], vf[2][C::KS];
+  // indicator fragments E^T[bin][key] of this wave's keys (constant for the whole kernel)
+  bf16x8_t ekf[2][2];
+#pragma unroll
+  for (int nj = 0; nj < 2; ++nj) {
+    const int kj = k0 + nj * 16 + fr;
+    const unsigned kb = (REL && kj < p.Lk) ? (unsigned)((kj / p.rel_kw) | ((kj % p.rel_kw) << 8)) : 0xFFFFu;
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) ekf[nj][k2] = efrag_key(kb, k2 * 32 + g * 8, p.rel_kh);
+  }
 #pragma unroll
   for (int nj = 0; nj < 2; ++nj) {
     const int kj = min(k0 + nj * 16 + fr, p.Lk - 1);
@@ -291,9 +345,10 @@ __global__ __launch_bounds__(NTHR) void flash_bwd_dkv_kernel(const grove_flash_a
       del_s[tid] = DEL[qi];
     }
     if (REL) {
-      for (int t = tid; t < BKV * nrel; t += NTHR) {
-        const int r = t / nrel, c = t - r * nrel;
-        rels[t] = REL[(int64_t)min(qt0 + r, p.Lq - 1) * nrel + c];
+      for (int t = tid; t < BKV * 64; t += NTHR) {
+        const int r = t >> 6, c = t & 63;
+        const float v = c < nrel ? REL[(int64_t)min(qt0 + r, p.Lq - 1) * nrel + c] * inv_alpha : 0.f;
+        *(bf16_raw*)(relq + r * RELB + c * 2) = f2bf(v);
       }
     }
     __syncthreads();
@@ -319,6 +374,18 @@ __global__ __launch_bounds__(NTHR) void flash_bwd_dkv_kernel(const grove_flash_a
             pacc[qi_][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[nj][ks], pacc[qi_][nj], 0, 0, 0);
           }
         }
+      if (nrk > 0) {
+#pragma unroll
+        for (int qi_ = 0; qi_ < 2; ++qi_)
+#pragma unroll
+          for (int k2 = 0; k2 < 2; ++k2) {
+            if (k2 < nrk) {
+              const bf16x8_t ra = lds_row_frag(relq, RELB, (s2 * 2 + qi_) * 16 + fr, k2 * 4 + g);
+#pragma unroll
+              for (int nj = 0; nj < 2; ++nj) sacc[qi_][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ra, ekf[nj][k2], sacc[qi_][nj], 0, 0, 0);
+            }
+          }
+      }
       // P and dS (lane: key = fr of tile nj; rows q = 4g + r of tile qi_)
       bf16x8_t pfr[2], dsfr[2];
 #pragma unroll
@@ -333,8 +400,7 @@ __global__ __launch_bounds__(NTHR) void flash_bwd_dkv_kernel(const grove_flash_a
             const int qi = qt0 + ql;
             int lim = kv_end;
             if (p.causal) lim = min(lim, qi + (p.Lk - p.Lq) + 1);
-            float v = sacc[qi_][nj][r] * sc;
-            if (REL && j < p.Lk) v += (rels[ql * nrel + j / p.rel_kw] + rels[ql * nrel + p.rel_kh + j % p.rel_kw]) * 1.4426950408889634f;
+            const float v = sacc[qi_][nj][r] * sc;
             const bool ok = (j < lim) && (qi < p.Lq);
             const float pr = ok ? exp2f(v - lse_s[ql]) : 0.f;
             pp[qi_][r] = pr;
@@ -380,9 +446,10 @@ __global__ __launch_bounds__(NTHR) void flash_bwd_dq_kernel(const grove_flash_at
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;
   char* Vs = smem + C::TILEB;
-  float* rels = (float*)(smem + 2 * C::TILEB);  // [128][nrel]
+  unsigned short* kbin = (unsigned short*)(smem + 2 * C::TILEB);
   const int nrel = p.rel_kh + p.rel_kw;
-  float* drels = rels + 128 * nrel;             // [128][nrel]
+  const int nrk = (nrel + 31) >> 5;
+  const int nbt = (nrel + 15) >> 4;  // 16-bin tiles of d rel
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, g = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
@@ -394,6 +461,12 @@ __global__ __launch_bounds__(NTHR) void flash_bwd_dq_kernel(const grove_flash_at
   const bf16_raw* dO = (const bf16_raw*)p.d_o + (int64_t)b * p.sdo + h * HS;
 
   bf16x8_t qf[2][C::KS], dof[2][C::KS];
+  bf16x8_t relf[2][2];
+  f32x4_t drl[2][4];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int bt = 0; bt < 4; ++bt) drl[mi][bt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   float lse2[2], del[2];
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi) {
@@ -407,11 +480,13 @@ __global__ __launch_bounds__(NTHR) void flash_bwd_dq_kernel(const grove_flash_at
     del[mi] = p.delta[(int64_t)(b * p.H + h) * p.Lq + qi];
   }
   if (p.rel) {
-    const float* R = p.rel + ((int64_t)(b * p.H + h) * p.Lq) * nrel;
-    for (int t = tid; t < 128 * nrel; t += NTHR) {
-      const int r = t / nrel, c = t - r * nrel;
-      rels[t] = R[(int64_t)min(qblk + r, p.Lq - 1) * nrel + c];
-      drels[t] = 0.f;
+    build_kbin(kbin, p.Lk, ((p.Lk + BKV - 1) / BKV) * BKV, p.rel_kw, tid);
+    const float inv_alpha = 1.f / p.alpha;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const float* rrow = p.rel + ((int64_t)(b * p.H + h) * p.Lq + min(q0 + mi * 16 + fr, p.Lq - 1)) * nrel;
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) relf[mi][k2] = relfrag(rrow, k2 * 32 + g * 8, nrel, inv_alpha);
     }
   }
   f32x4_t dq[2][C::DT];
@@ -437,7 +512,7 @@ __global__ __launch_bounds__(NTHR) void flash_bwd_dq_kernel(const grove_flash_at
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) { s[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dp[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
+    for (int ni = 0; ni < 4; ++ni) {
 #pragma unroll
       for (int ks = 0; ks < C::KS; ++ks) {
         const bf16x8_t ka = lds_row_frag(Ks, C::ROWB, ni * 16 + fr, ks * 4 + g);
@@ -448,29 +523,32 @@ __global__ __launch_bounds__(NTHR) void flash_bwd_dq_kernel(const grove_flash_at
           dp[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, dof[mi][ks], dp[mi][ni], 0, 0, 0);
         }
       }
+      if (nrk > 0) {
+        const unsigned kb = kbin[kv0 + ni * 16 + fr];
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+          if (k2 < nrk) {
+            const bf16x8_t ef = efrag_key(kb, k2 * 32 + g * 8, p.rel_kh);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) s[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ef, relf[mi][k2], s[mi][ni], 0, 0, 0);
+          }
+        }
+      }
+    }
     bf16x8_t dsf[2][2];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
       const int qi = q0 + mi * 16 + fr;
       int lim = kv_end;
       if (p.causal) lim = min(lim, qi + (p.Lk - p.Lq) + 1);
-      const int ql = wave * 32 + mi * 16 + fr;
-      const float* rr = rels + ql * nrel;
-      float* dr = drels + ql * nrel;
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int j = kv0 + ni * 16 + g * 4 + r;
-          float v = s[mi][ni][r] * sc;
-          if (p.rel && j < p.Lk) v += (rr[j / p.rel_kw] + rr[p.rel_kh + j % p.rel_kw]) * 1.4426950408889634f;
+          const float v = s[mi][ni][r] * sc;
           const float pr = j < lim ? exp2f(v - lse2[mi]) : 0.f;
-          const float ds = pr * (dp[mi][ni][r] - del[mi]);
-          if (p.drel && ds != 0.f && qi < p.Lq) {
-            atomicAdd(&dr[j / p.rel_kw], ds);
-            atomicAdd(&dr[p.rel_kh + j % p.rel_kw], ds);
-          }
-          s[mi][ni][r] = ds * p.alpha;
+          s[mi][ni][r] = pr * (dp[mi][ni][r] - del[mi]) * p.alpha;
         }
       dsf[mi][0] = pack_frag(s[mi][0], s[mi][1]);
       dsf[mi][1] = pack_frag(s[mi][2], s[mi][3]);
@@ -484,6 +562,31 @@ __global__ __launch_bounds__(NTHR) void flash_bwd_dq_kernel(const grove_flash_at
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) dq[mi][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, dsf[mi][s2], dq[mi][dt], 0, 0, 0);
       }
+    // d rel^T[bin][q] += sum_key E[bin][key] dS^T[key][q]   (dsf carries alpha; divided out at the end)
+    if (p.drel) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        unsigned kb8[8];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) kb8[jj] = kbin[kv0 + s2 * 32 + (jj < 4 ? 4 * g + jj : 16 + 4 * g + jj - 4)];
+#pragma unroll
+        for (int bt = 0; bt < 4; ++bt) {
+          if (bt < nbt) {
+            const int bin = bt * 16 + fr;
+            typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+            s16x8_t e;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+              const bool hit = bin < p.rel_kh ? ((int)(kb8[jj] & 0xff) == bin) : ((int)(kb8[jj] >> 8) == bin - p.rel_kh);
+              e[jj] = hit ? (short)0x3F80 : (short)0;
+            }
+            const bf16x8_t ea = __builtin_bit_cast(bf16x8_t, e);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) drl[mi][bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ea, dsf[mi][s2], drl[mi][bt], 0, 0, 0);
+          }
+        }
+      }
+    }
   }
   bf16_raw* DQ = (bf16_raw*)p.dq + (int64_t)b * p.sdq + h * HS;
 #pragma unroll
@@ -497,11 +600,20 @@ __global__ __launch_bounds__(NTHR) void flash_bwd_dq_kernel(const grove_flash_at
     }
   }
   if (p.drel) {
-    __syncthreads();
-    float* DR = p.drel + ((int64_t)(b * p.H + h) * p.Lq) * nrel;
-    for (int t = tid; t < 128 * nrel; t += NTHR) {
-      const int r = t / nrel, c = t - r * nrel;
-      if (qblk + r < p.Lq) DR[(int64_t)(qblk + r) * nrel + c] = drels[t];
+    // lane holds d rel^T[bin = bt*16 + 4g + r][q = fr]
+    const float inv_alpha = 1.f / p.alpha;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int qi = q0 + mi * 16 + fr;
+      if (qi >= p.Lq) continue;
+      float* DR = p.drel + ((int64_t)(b * p.H + h) * p.Lq + qi) * nrel;
+#pragma unroll
+      for (int bt = 0; bt < 4; ++bt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int bin = bt * 16 + g * 4 + r;
+          if (bt < nbt && bin < nrel) DR[bin] = drl[mi][bt][r] * inv_alpha;
+        }
     }
   }
 }
@@ -516,7 +628,7 @@ int check(const grove_flash_attn_params* p, const char* name) {
 }
 
 template <int HS>
-size_t lds_fwd(const grove_flash_attn_params* p) { return 2 * Cfg<HS>::TILEB + (p->rel ? (size_t)128 * (p->rel_kh + p->rel_kw) * 4 : 0); }
+size_t lds_fwd(const grove_flash_attn_params* p) { return 2 * Cfg<HS>::TILEB + (p->rel ? (size_t)(((p->Lk + BKV - 1) / BKV) * BKV) * 2 : 0); }
 
 #define DISPATCH_HS(p, FN)                 \
   switch ((p)->hs) {                       \
@@ -558,8 +670,8 @@ extern "C" int grove_flash_attn_bwd(const grove_flash_attn_params* p, void* stre
   dim3 gk((p->Lk + 127) / 128, p->H, p->B), gq((p->Lq + 127) / 128, p->H, p->B);
 #define BWD(HS)                                                                                            \
   {                                                                                                        \
-    const size_t l1 = 2 * Cfg<HS>::TILEB + 2 * BKV * 4 + (size_t)BKV * nrel * 4;                            \
-    const size_t l2 = 2 * Cfg<HS>::TILEB + (size_t)2 * 128 * nrel * 4;                                      \
+    const size_t l1 = 2 * Cfg<HS>::TILEB + 2 * BKV * 4 + (nrel ? (size_t)BKV * (64 * 2 + 32) : 0);          \
+    const size_t l2 = lds_fwd<HS>(p);                                                                       \
     hipFuncSetAttribute((const void*)flash_bwd_dkv_kernel<HS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1); \
     hipFuncSetAttribute((const void*)flash_bwd_dq_kernel<HS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);  \
     hipLaunchKernelGGL((flash_bwd_dkv_kernel<HS>), gk, dim3(NTHR), l1, s, *p);                              \
