@@ -91,6 +91,12 @@ class BoxHeadBwdParams(C.Structure):
                 ("N", c_i32), ("D", c_i32)]
 
 
+class GemmTnParams(C.Structure):
+    _fields_ = [("A", c_vp), ("B", c_vp), ("C", c_vp), ("scale_ptr", c_vp), ("b_idx", c_vp),
+                ("M", c_i32), ("N", c_i32), ("K", c_i32), ("lda", c_i32), ("ldb", c_i32), ("ldc", c_i32),
+                ("b_taps", c_i32), ("scale_tanh", c_i32), ("split_k", c_i32), ("alpha", c_f32)]
+
+
 class FlashAttnParams(C.Structure):
     _fields_ = [("q", c_vp), ("k", c_vp), ("v", c_vp), ("o", c_vp), ("d_o", c_vp), ("dq", c_vp), ("dk", c_vp), ("dv", c_vp),
                 ("lse", c_vp), ("delta", c_vp), ("kv_len", c_vp), ("rel", c_vp), ("drel", c_vp),
@@ -106,11 +112,12 @@ STRUCTS = {
     "grove_softmax_bwd_params": SoftmaxBwdParams, "grove_relpos_params": RelposParams, "grove_rope_params": RopeParams,
     "grove_rows_params": RowsParams, "grove_small_attn_params": SmallAttnParams, "grove_box_head_params": BoxHeadParams,
     "grove_box_head_bwd_params": BoxHeadBwdParams, "grove_flash_attn_params": FlashAttnParams,
+    "grove_gemm_tn_params": GemmTnParams,
 }
 
 # every symbol include/grove_hip.h declares (tests/test_abi.py checks the header against this list)
 SYMBOLS = [
-    "grove_version", "grove_last_error", "grove_sizeof", "grove_gemm_bf16", "grove_gemm_set_staging",
+    "grove_version", "grove_last_error", "grove_sizeof", "grove_gemm_bf16", "grove_gemm_set_staging", "grove_gemm_tn_bf16",
     "grove_transpose_bf16", "grove_layernorm_fwd", "grove_rmsnorm_fwd", "grove_layernorm_bwd", "grove_rmsnorm_bwd",
     "grove_flash_attn_fwd", "grove_flash_attn_bwd", "grove_softmax_fwd", "grove_softmax_bwd", "grove_relpos_fwd", "grove_relpos_bwd", "grove_rope_inplace",
     "grove_swiglu_fwd", "grove_swiglu_bwd", "grove_act_bwd", "grove_add_bf16", "grove_add_bcast_rows",

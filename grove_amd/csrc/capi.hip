@@ -38,6 +38,7 @@ extern "C" int grove_sizeof(const char* name) {
   SZ(grove_box_head_params);
   SZ(grove_box_head_bwd_params);
   SZ(grove_flash_attn_params);
+  SZ(grove_gemm_tn_params);
 #undef SZ
   return -1;
 }

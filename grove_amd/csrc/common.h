@@ -66,10 +66,20 @@ __device__ __forceinline__ float block_max(float v, float* scratch) {
   return r;
 }
 
+// erf via Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7): one v_rcp, one v_exp and five FMAs instead of libm's
+// erff polynomial ladder — the GELU epilogue is ~20 % of a K=1280 GEMM tile otherwise.
+__device__ __forceinline__ float fast_erf(float x) {
+  const float ax = fabsf(x);
+  const float t = __frcp_rn(1.f + 0.3275911f * ax);
+  const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+  const float r = 1.f - poly * __expf(-ax * ax);
+  return copysignf(r, x);
+}
+
 __device__ __forceinline__ float act_apply(int act, float x) {
   switch (act) {
     case GROVE_ACT_RELU: return fmaxf(x, 0.f);
-    case GROVE_ACT_GELU: return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));
+    case GROVE_ACT_GELU: return 0.5f * x * (1.f + fast_erf(x * 0.70710678118654752440f));
     case GROVE_ACT_QUICKGELU: return x / (1.f + __expf(-1.702f * x));
     case GROVE_ACT_SILU: return x / (1.f + __expf(-x));
     case GROVE_ACT_SIGMOID: return 1.f / (1.f + __expf(-x));
@@ -82,7 +92,7 @@ __device__ __forceinline__ float act_grad(int act, float x) {
     case GROVE_ACT_RELU: return x > 0.f ? 1.f : 0.f;
     case GROVE_ACT_GELU: {
       const float c = 0.70710678118654752440f;
-      float cdf = 0.5f * (1.f + erff(x * c));
+      float cdf = 0.5f * (1.f + fast_erf(x * c));
       float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
       return cdf + x * pdf;
     }

@@ -90,16 +90,19 @@ class GROVEForCausalLM(torch.nn.Module):
                 self._sd[name] = t
         if self._train_mode:
             names = trainable_names(d)
-            total = sum(self._sd[n].numel() for n in names)
-            self._flat_grad = torch.zeros(total, dtype=torch.float32, device=self.dev)
-            off = 0
+            # every parameter starts on a 16-byte boundary of the flat fp32 buffer (vector / atomic epilogues)
+            offs, off = {}, 0
+            for n in names:
+                offs[n] = off
+                off += (self._sd[n].numel() + 3) // 4 * 4
+            self._flat_grad = torch.zeros(off, dtype=torch.float32, device=self.dev)
+            self._grad_off = offs
             for n in names:
                 k = self._sd[n].numel()
                 shape = tuple(self._sd[n].shape)
                 if n.endswith("conv3d.weight"):
                     shape = (shape[0], 27 * shape[1])  # gradient lives in the packed (tap-major) layout
-                self._grad[n] = self._flat_grad[off:off + k].view(shape)
-                off += k
+                self._grad[n] = self._flat_grad[offs[n]:offs[n] + k].view(shape)
             self.trainable = names
 
     def state_dict(self, *a, **k):
@@ -437,12 +440,7 @@ class GROVEForCausalLM(torch.nn.Module):
         hv, dlogits, rows, R = c.ce_state
         if R > 0:
             Vv = d.vocab
-            Mp = ops.pad_to(R, 32)
-            dlT = torch.empty((Vv, Mp), dtype=bf, device=self.dev)
-            ops.transpose(dlogits, R, Vv, dlogits.stride(0), dlT, Mp, pad_to_cols=Mp)
-            hT = torch.empty((H, Mp), dtype=bf, device=self.dev)
-            ops.transpose(hv.data, R, H, H, hT, Mp, pad_to_cols=Mp)
-            ops.gemm_raw(dlT, hT, self._grad["lm_head.weight"], Vv, H, Mp, Mp, Mp, H, accumulate=True)
+            ops.wgrad(dlogits, hv.data, self._grad["lm_head.weight"], K=R)
             Vk = ops.pad_to(Vv, 32)
             wT = torch.zeros((H, Vk), dtype=bf, device=self.dev)
             ops.transpose(self._sd["lm_head.weight"], Vv, H, H, wT, Vk, pad_to_cols=Vk)

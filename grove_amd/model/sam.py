@@ -231,17 +231,13 @@ class SamEncoder:
         # bias grad: tanh(alpha) * colsum(dy * relu')
         ops.axpy(g[name + "conv3d.bias"], ops.colsum(prod), scale_ptr=a, mode=2)
         # weight grad, tap-major: dW[co, tap, ci] = tanh(alpha) * sum_m (dy relu')[m, co] * x[gather(tap, m), ci]
-        Mp = ops.pad_to(M, 32)
-        dzT = torch.empty((C, Mp), dtype=torch.bfloat16, device=self.dev)
-        ops.transpose(prod, M, C, C, dzT, Mp, pad_to_cols=Mp)
+        # one TN GEMM over the K-major operands with the per-tap row gather on x (no im2col, no transposes)
         gw = g[name + "conv3d.weight"].view(C, 27 * C)
-        xT = torch.empty((C, Mp), dtype=torch.bfloat16, device=self.dev)
-        xg = torch.empty((M, C), dtype=torch.bfloat16, device=self.dev)
-        for tap in range(27):
-            ops.copy_rows(x, xg, M, C, idx_src=conv_idx[tap])
-            ops.transpose(xg, M, C, C, xT, Mp, pad_to_cols=Mp)
-            ops.gemm_raw(dzT, xT, gw[:, tap * C:], C, C, Mp, Mp, Mp, 27 * C, accumulate=True, scale_ptr=a, scale_tanh=True)
-        del dzT, xT, xg
+        if C % 128 == 0:
+            ops.wgrad(prod, x, gw, b_idx=conv_idx, b_taps=27, scale_ptr=a, scale_tanh=True, K=M)
+        else:  # tiny test dims: a 128-wide tile would straddle taps -> one launch per tap
+            for tap in range(27):
+                ops.wgrad(prod, x, gw[:, tap * C:(tap + 1) * C], b_idx=conv_idx[tap:tap + 1], scale_ptr=a, scale_tanh=True, K=M)
         dx = None
         if need_dx:
             # dx = dy + conv^T(dz): flipped taps, swapped channels

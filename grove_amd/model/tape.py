@@ -74,12 +74,7 @@ class Tape:
                 dz = dy  # shared with the residual branch: treated read-only below
             N, K = W.w.shape
             if W.g is not None:
-                Mp = ops.pad_to(M, 32)
-                dzT = torch.empty((N, Mp), dtype=bf, device=dz.device)
-                ops.transpose(dz, M, N, dz.stride(0), dzT, Mp, pad_to_cols=Mp)
-                xT = torch.empty((K, Mp), dtype=bf, device=dz.device)
-                ops.transpose(x.data, M, K, x.data.stride(0), xT, Mp, pad_to_cols=Mp)
-                ops.gemm_raw(dzT, xT, W.g, N, K, Mp, Mp, Mp, K, accumulate=True)
+                ops.wgrad(dz, x.data, W.g, K=M)  # dW[N, K] += dz^T x on the K-major operands as they lie in HBM
             if b is not None and b.g is not None:
                 ops.colsum(dz, out=b.g, accumulate=True)
             if x.needs_grad:

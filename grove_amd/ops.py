@@ -76,6 +76,19 @@ def linear(x, w, bias=None, *, act=ACT_NONE, residual=None, out=None, out_dtype=
     return out
 
 
+def wgrad(dy, x, grad, *, b_idx=None, b_taps=1, scale_ptr=None, scale_tanh=False, alpha=1.0, split_k=0, K=None):
+    """grad[M, N] (fp32) += alpha * dy[K, M]^T @ x[K, N]  (x rows optionally gathered per tap)."""
+    _chk_dev(dy, x, grad)
+    p = _lib.GemmTnParams()
+    p.A, p.B, p.C, p.scale_ptr, p.b_idx = _p(dy), _p(x), _p(grad), _p(scale_ptr), _p(b_idx)
+    p.M, p.N = grad.shape[0], grad.shape[1]
+    p.K = K if K is not None else dy.shape[0]
+    p.lda, p.ldb, p.ldc = dy.stride(0), x.stride(0), grad.stride(0)
+    p.b_taps, p.scale_tanh, p.split_k, p.alpha = b_taps, int(scale_tanh), split_k, float(alpha)
+    _lib.check(_lib.lib().grove_gemm_tn_bf16(C.byref(p), _stream()), "grove_gemm_tn_bf16")
+    return grad
+
+
 def gemm_set_staging(use_lds_dma: bool):
     _lib.check(_lib.lib().grove_gemm_set_staging(int(use_lds_dma)), "grove_gemm_set_staging")
 

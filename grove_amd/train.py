@@ -122,12 +122,12 @@ class GroveEngine:
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.names = model.trainable
         g = model._flat_grad
-        self.master = torch.empty_like(g)
+        self.master = torch.zeros_like(g)
         self.m = torch.zeros_like(g)
         self.v = torch.zeros_like(g)
-        off = 0
         self.slices = []
         for n in self.names:
+            off = model._grad_off[n]
             k = model._sd[n].numel()
             w = model._sd[n]
             if n.endswith("conv3d.weight"):
@@ -135,7 +135,6 @@ class GroveEngine:
             assert w.is_contiguous(), n
             ops.to_f32(w.reshape(-1), out=self.master[off:off + k])
             self.slices.append((n, off, k, w))
-            off += k
         total = total_steps if total_steps is not None else args.epochs * args.steps_per_epoch
         self.scheduler = WarmupDecayLR(args.lr, total, 100)
         self.global_step = 0

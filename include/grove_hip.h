@@ -91,6 +91,29 @@ int grove_gemm_bf16(const grove_gemm_params* p, void* stream);
 /* A/B staging variant: 1 = LDS-DMA (global_load_lds, default), 0 = register staged */
 int grove_gemm_set_staging(int use_lds_dma);
 
+/* ------------------------------------------------------------------------------------------
+ * "TN" GEMM for weight gradients:  C[m, n] += f * sum_k A[k, m] * B[row_b(k, n), n mod (N / b_taps)]
+ *   A: bf16 [K, lda] (dY: tokens x out-features), B: bf16 [K, ldb] (X: tokens x in-features), both K-major as
+ *   the backward pass holds them; C: fp32 [M, ldc], always accumulated (fp32 atomics when K is split).
+ *   b_idx[tap*K + k] (-1 = zero row): per-tap row gather of B — Conv3d/Conv2d weight gradient in one launch.
+ *   f = alpha * (scale_ptr ? (scale_tanh ? tanh(*scale_ptr) : *scale_ptr) : 1).
+ * Replaces autograd's weight-gradient GEMMs/convs of every trainable layer (train.py:279-316 freeze policy).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct grove_gemm_tn_params {
+  const void* A;
+  const void* B;
+  float* C;
+  const float* scale_ptr;
+  const int32_t* b_idx; /* [b_taps, K] or NULL */
+  int32_t M, N, K;
+  int32_t lda, ldb, ldc;
+  int32_t b_taps;       /* >= 1; N / b_taps must be a multiple of 128 when > 1 */
+  int32_t scale_tanh;
+  int32_t split_k;      /* 0 = auto */
+  float alpha;
+} grove_gemm_tn_params;
+int grove_gemm_tn_bf16(const grove_gemm_tn_params* p, void* stream);
+
 /* out[c, r] = in[r, c] for a batch of 2-D bf16 matrices (used for V^T, dY^T, X^T, NCHW<->NHWC).
  * rows beyond `rows` in the output's padded leading dim (ld_out > rows) are zero filled up to
  * pad_to columns. Replaces .transpose().contiguous() / .permute() copies

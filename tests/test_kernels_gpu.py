@@ -536,3 +536,32 @@ def test_flash_attention_fwd_bwd(dev, B, H, L, hs, hd, causal, use_len, rel_hw):
         close(dqkv[:, c0:c0 + H * hs], gref[:, c0:c0 + H * hs], 2e-2, name)
     if rel is not None:
         close(drel, relr.grad, 2e-2, "drel")
+
+
+@pytest.mark.parametrize("K,M,N,split", [(100, 64, 128, 0), (3000, 256, 128, 0), (777, 128, 256, 7), (64, 8, 8, 1)])
+def test_wgrad_tn_gemm(dev, K, M, N, split):
+    """dW += dY^T X on K-major operands (no transposed copies), incl. K tails and split-K atomics."""
+    from grove_amd import ops
+    dy, x = rnd(K, M, seed=90), rnd(K, N, seed=91)
+    g0 = torch.randn(M, N, generator=torch.Generator().manual_seed(92))
+    out = g0.clone().to(dev)
+    ops.wgrad(dy.to(dev), x.to(dev), out, split_k=split, alpha=0.5)
+    close(out, g0 + 0.5 * dy.float().t() @ x.float(), 3e-5, "wgrad")
+
+
+def test_wgrad_conv3d_gather(dev):
+    """Conv3d weight gradient as ONE gathered TN GEMM, against autograd of F.conv3d."""
+    from grove_amd import ops
+    from grove_amd.model.indexing import conv3d_gather_index
+    G, T, H, W, Ci, Co = 1, 2, 5, 6, 128, 64
+    x = rnd(G * T * H * W, Ci, seed=93)
+    dy = rnd(G * T * H * W, Co, seed=94)
+    w = torch.zeros(Co, Ci, 3, 3, 3, requires_grad=True)
+    xr = x.float().reshape(G, T, H, W, Ci).permute(0, 4, 1, 2, 3)
+    y = F.conv3d(xr, w, padding=1).permute(0, 2, 3, 4, 1).reshape(-1, Co)
+    y.backward(dy.float())
+    ref = w.grad.permute(0, 2, 3, 4, 1).reshape(Co, 27 * Ci)  # tap-major
+    idx = conv3d_gather_index(G, T, H, W).to(dev)
+    out = torch.zeros(Co, 27 * Ci, dtype=torch.float32, device=dev)
+    ops.wgrad(dy.to(dev), x.to(dev), out, b_idx=idx, b_taps=27)
+    close(out, ref, 3e-5, "conv3d wgrad")
