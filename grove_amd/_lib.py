@@ -103,7 +103,7 @@ class FlashAttnParams(C.Structure):
                 ("sq", c_i64), ("sk", c_i64), ("sv", c_i64), ("so", c_i64), ("sdo", c_i64), ("sdq", c_i64), ("sdk", c_i64), ("sdv", c_i64),
                 ("B", c_i32), ("H", c_i32), ("Lq", c_i32), ("Lk", c_i32), ("hs", c_i32),
                 ("ld_q", c_i32), ("ld_k", c_i32), ("ld_v", c_i32), ("ld_o", c_i32), ("ld_do", c_i32), ("ld_dq", c_i32),
-                ("ld_dk", c_i32), ("ld_dv", c_i32), ("causal", c_i32), ("rel_kh", c_i32), ("rel_kw", c_i32), ("alpha", c_f32)]
+                ("ld_dk", c_i32), ("ld_dv", c_i32), ("causal", c_i32), ("rel_kh", c_i32), ("rel_kw", c_i32), ("rel_ld", c_i32), ("alpha", c_f32)]
 
 
 STRUCTS = {

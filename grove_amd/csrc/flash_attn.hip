@@ -85,13 +85,11 @@ __device__ __forceinline__ bf16x8_t efrag_key(unsigned kb, int bin0, int KH) {
   for (int jj = 0; jj < 8; ++jj) e[jj] = ((bin0 + jj) == kh || (bin0 + jj) == kwb) ? (short)0x3F80 : (short)0;
   return __builtin_bit_cast(bf16x8_t, e);
 }
-// rel[q][bin0 .. bin0+7] / alpha as a bf16 fragment (bins >= nrel -> 0)
-__device__ __forceinline__ bf16x8_t relfrag(const float* relrow, int bin0, int nrel, float inv_alpha) {
-  float v[8];
-#pragma unroll
-  for (int jj = 0; jj < 8; ++jj) v[jj] = (bin0 + jj) < nrel ? relrow[bin0 + jj] * inv_alpha : 0.f;
-  const u32x4_t u = u32x4_t{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
-  return __builtin_bit_cast(bf16x8_t, u);
+// rel'[q][bin0 .. bin0+7] (bf16, already divided by alpha; rows are rel_ld wide, rel_ld % 8 == 0)
+__device__ __forceinline__ bf16x8_t relfrag(const bf16_raw* relrow, int bin0, int rel_ld) {
+  if (bin0 < rel_ld) return *(const bf16x8_t*)(relrow + bin0);
+  const u32x4_t z = u32x4_t{0u, 0u, 0u, 0u};
+  return __builtin_bit_cast(bf16x8_t, z);
 }
 
 __device__ __forceinline__ float group_max(float v) {
@@ -119,7 +117,7 @@ __global__ __launch_bounds__(NTHR) void flash_fwd_kernel(const grove_flash_attn_
   const bf16_raw* Q = (const bf16_raw*)p.q + (int64_t)b * p.sq + h * HS;
   const bf16_raw* K = (const bf16_raw*)p.k + (int64_t)b * p.sk + h * HS;
   const bf16_raw* V = (const bf16_raw*)p.v + (int64_t)b * p.sv + h * HS;
-  const int nrel = p.rel_kh + p.rel_kw;
+  const int nrel = p.rel ? p.rel_ld : 0;
   const int nrk = (nrel + 31) >> 5;  // 32-bin k-steps of the bias MFMA (0 without rel)
 
   bf16x8_t qf[2][C::KS];
@@ -132,12 +130,11 @@ __global__ __launch_bounds__(NTHR) void flash_fwd_kernel(const grove_flash_attn_
   }
   if (p.rel) {
     build_kbin(kbin, p.Lk, ((p.Lk + BKV - 1) / BKV) * BKV, p.rel_kw, tid);
-    const float inv_alpha = 1.f / p.alpha;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
-      const float* rrow = p.rel + ((int64_t)(b * p.H + h) * p.Lq + min(q0 + mi * 16 + fr, p.Lq - 1)) * nrel;
+      const bf16_raw* rrow = (const bf16_raw*)p.rel + ((int64_t)(b * p.H + h) * p.Lq + min(q0 + mi * 16 + fr, p.Lq - 1)) * nrel;
 #pragma unroll
-      for (int k2 = 0; k2 < 2; ++k2) relf[mi][k2] = relfrag(rrow, k2 * 32 + g * 8, nrel, inv_alpha);
+      for (int k2 = 0; k2 < 2; ++k2) relf[mi][k2] = relfrag(rrow, k2 * 32 + g * 8, nrel);
     }
   }
   f32x4_t oacc[2][C::DT];
@@ -296,10 +293,9 @@ __global__ __launch_bounds__(NTHR) void flash_bwd_dkv_kernel(const grove_flash_a
   const bf16_raw* dO = (const bf16_raw*)p.d_o + (int64_t)b * p.sdo + h * HS;
   const float* LSE = p.lse + (int64_t)(b * p.H + h) * p.Lq;
   const float* DEL = p.delta + (int64_t)(b * p.H + h) * p.Lq;
-  const int nrel = p.rel_kh + p.rel_kw;
-  const float* REL = p.rel ? p.rel + ((int64_t)(b * p.H + h) * p.Lq) * nrel : nullptr;
+  const int nrel = p.rel ? p.rel_ld : 0;
+  const bf16_raw* REL = p.rel ? (const bf16_raw*)p.rel + ((int64_t)(b * p.H + h) * p.Lq) * nrel : nullptr;
   const int nrk = (nrel + 31) >> 5;
-  const float inv_alpha = 1.f / p.alpha;
 
   // K, V fragments of this wave's 32 keys as MFMA B operands: B[k = d][col = key = fr]
   bf16x8_t kf[2][C::KS], vf[2][C::KS];
@@ -345,10 +341,11 @@ __global__ __launch_bounds__(NTHR) void flash_bwd_dkv_kernel(const grove_flash_a
       del_s[tid] = DEL[qi];
     }
     if (REL) {
-      for (int t = tid; t < BKV * 64; t += NTHR) {
-        const int r = t >> 6, c = t & 63;
-        const float v = c < nrel ? REL[(int64_t)min(qt0 + r, p.Lq - 1) * nrel + c] * inv_alpha : 0.f;
-        *(bf16_raw*)(relq + r * RELB + c * 2) = f2bf(v);
+      for (int t = tid; t < BKV * 8; t += NTHR) {  // 16-byte chunks of the 64 bf16 rows
+        const int r = t >> 3, c = t & 7;
+        u32x4_t v = u32x4_t{0u, 0u, 0u, 0u};
+        if (c * 8 < nrel) v = *(const u32x4_t*)(REL + (int64_t)min(qt0 + r, p.Lq - 1) * nrel + c * 8);
+        *(u32x4_t*)(relq + r * RELB + c * 16) = v;
       }
     }
     __syncthreads();
@@ -447,7 +444,7 @@ __global__ __launch_bounds__(NTHR) void flash_bwd_dq_kernel(const grove_flash_at
   char* Ks = smem;
   char* Vs = smem + C::TILEB;
   unsigned short* kbin = (unsigned short*)(smem + 2 * C::TILEB);
-  const int nrel = p.rel_kh + p.rel_kw;
+  const int nrel = p.rel ? p.rel_ld : 0;
   const int nrk = (nrel + 31) >> 5;
   const int nbt = (nrel + 15) >> 4;  // 16-bin tiles of d rel
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -481,12 +478,11 @@ __global__ __launch_bounds__(NTHR) void flash_bwd_dq_kernel(const grove_flash_at
   }
   if (p.rel) {
     build_kbin(kbin, p.Lk, ((p.Lk + BKV - 1) / BKV) * BKV, p.rel_kw, tid);
-    const float inv_alpha = 1.f / p.alpha;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
-      const float* rrow = p.rel + ((int64_t)(b * p.H + h) * p.Lq + min(q0 + mi * 16 + fr, p.Lq - 1)) * nrel;
+      const bf16_raw* rrow = (const bf16_raw*)p.rel + ((int64_t)(b * p.H + h) * p.Lq + min(q0 + mi * 16 + fr, p.Lq - 1)) * nrel;
 #pragma unroll
-      for (int k2 = 0; k2 < 2; ++k2) relf[mi][k2] = relfrag(rrow, k2 * 32 + g * 8, nrel, inv_alpha);
+      for (int k2 = 0; k2 < 2; ++k2) relf[mi][k2] = relfrag(rrow, k2 * 32 + g * 8, nrel);
     }
   }
   f32x4_t dq[2][C::DT];
@@ -600,20 +596,19 @@ __global__ __launch_bounds__(NTHR) void flash_bwd_dq_kernel(const grove_flash_at
     }
   }
   if (p.drel) {
-    // lane holds d rel^T[bin = bt*16 + 4g + r][q = fr]
-    const float inv_alpha = 1.f / p.alpha;
+    // lane holds d rel'^T[bin = bt*16 + 4g + r][q = fr]; rel' = rel / alpha, and dsf carried alpha: no rescale
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
       const int qi = q0 + mi * 16 + fr;
       if (qi >= p.Lq) continue;
-      float* DR = p.drel + ((int64_t)(b * p.H + h) * p.Lq + qi) * nrel;
+      bf16_raw* DR = (bf16_raw*)p.drel + ((int64_t)(b * p.H + h) * p.Lq + qi) * nrel;
 #pragma unroll
-      for (int bt = 0; bt < 4; ++bt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int bin = bt * 16 + g * 4 + r;
-          if (bt < nbt && bin < nrel) DR[bin] = drl[mi][bt][r] * inv_alpha;
+      for (int bt = 0; bt < 4; ++bt) {
+        if (bt < nbt) {
+          const f32x4_t o = drl[mi][bt];
+          *(u32x2_t*)(DR + bt * 16 + g * 4) = u32x2_t{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
         }
+      }
     }
   }
 }
@@ -623,7 +618,9 @@ int check(const grove_flash_attn_params* p, const char* name) {
   GROVE_CHECK(p->hs == 32 || p->hs == 64 || p->hs == 96 || p->hs == 128, GROVE_E_SHAPE, "%s: head dim %d not in {32,64,96,128}", name, p->hs);
   GROVE_CHECK(p->ld_q % 8 == 0 && p->ld_k % 8 == 0 && p->ld_v % 8 == 0 && p->ld_o % 4 == 0, GROVE_E_ALIGN, "%s: leading dims must be multiples of 8", name);
   GROVE_CHECK(((uintptr_t)p->q & 15) == 0 && ((uintptr_t)p->k & 15) == 0 && ((uintptr_t)p->v & 15) == 0, GROVE_E_ALIGN, "%s: q/k/v must be 16-byte aligned", name);
-  GROVE_CHECK(!p->rel || (p->rel_kh * p->rel_kw == p->Lk && p->rel_kh + p->rel_kw <= 64 && p->rel_kw > 0), GROVE_E_SHAPE, "%s: rel dims mismatch", name);
+  GROVE_CHECK(!p->rel || (p->rel_kw > 0 && (p->Lk + p->rel_kw - 1) / p->rel_kw <= p->rel_kh && p->rel_kh + p->rel_kw <= p->rel_ld &&
+                          p->rel_ld <= 64 && p->rel_ld % 16 == 0 && ((uintptr_t)p->rel & 15) == 0),
+              GROVE_E_SHAPE, "%s: rel dims mismatch (rows of Lk/rel_kw h-bins at 0.., w-bins at rel_kh.., row length rel_ld <= 64)", name);
   return GROVE_OK;
 }
 
@@ -666,7 +663,7 @@ extern "C" int grove_flash_attn_bwd(const grove_flash_attn_params* p, void* stre
   hipStream_t s = (hipStream_t)stream;
   const int64_t nrows = (int64_t)p->B * p->H * p->Lq;
   hipLaunchKernelGGL(flash_delta_kernel, dim3((unsigned)((nrows + 15) / 16)), dim3(NTHR), 0, s, *p);
-  const int nrel = p->rel ? p->rel_kh + p->rel_kw : 0;
+  const int nrel = p->rel ? p->rel_ld : 0;
   dim3 gk((p->Lk + 127) / 128, p->H, p->B), gq((p->Lq + 127) / 128, p->H, p->B);
 #define BWD(HS)                                                                                            \
   {                                                                                                        \

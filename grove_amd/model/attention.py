@@ -28,7 +28,7 @@ def attention_fwd(qkv, B, L, H, hs, q_off, k_off, v_off, alpha, *, causal=False,
     columns are exact zeros). Returns (out [B*L, H*hs], ctx or None)."""
     dev = qkv.device
     ld = qkv.stride(0)
-    if MODE == "flash":
+    if MODE == "flash" or rel is not None:  # the rel-pos bias exists only in the fused kernels
         out, lse = ops.flash_attn(qkv, B, L, H, hs, q_off, k_off, v_off, alpha, causal=causal, kv_len=kv_len, rel=rel,
                                   rel_hw=rel_hw, out=out, want_lse=save)
         ctx = None

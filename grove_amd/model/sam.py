@@ -24,6 +24,22 @@ def _rel_table(size, rel_pos):
     return rel_pos.float()[(c[:, None] - c[None, :]) + (size - 1)].contiguous()
 
 
+def _rcat_tables(size, rel_pos_h, rel_pos_w, hd, hp, alpha):
+    """Per query position q = (qy, qx) the stacked table R_cat[q] = [Rh[qy] ; Rw[qx]] / alpha as the B operand of
+    the rel-pos GEMMs (add_decomposed_rel_pos, image_encoder.py:420-458): rel'[., q, :] = q_vec . R_cat[q]^T.
+    h-bins occupy columns 0..size-1, w-bins columns khp..khp+size-1 (khp = size rounded up to 16).
+    Returns (R_cat bf16 [L, rel_ld, hp], R_cat^T bf16 [L, hp, rel_ld], khp, rel_ld). Init-time only."""
+    Rh, Rw = _rel_table(size, rel_pos_h), _rel_table(size, rel_pos_w)
+    khp = (size + 15) // 16 * 16
+    rel_ld = 2 * khp
+    L = size * size
+    R = torch.zeros((size, size, rel_ld, hp), dtype=torch.float32, device=rel_pos_h.device)
+    R[:, :, :size, :hd] = Rh[:, None]
+    R[:, :, khp:khp + size, :hd] = Rw[None, :]
+    R = (R / alpha).reshape(L, rel_ld, hp)
+    return R.to(torch.bfloat16).contiguous(), R.transpose(1, 2).to(torch.bfloat16).contiguous(), khp, rel_ld
+
+
 class SamEncoder:
     def __init__(self, sd, d, device, train=False, grads=None):
         self.d, self.dev, self.train = d, device, train
@@ -54,8 +70,9 @@ class SamEncoder:
                   "wqkv": wqkv.reshape(3 * nh * hp, C), "bqkv": bqkv.reshape(-1), "wproj": wproj.reshape(C, nh * hp),
                   "bproj": sd[p + "attn.proj.bias"], "w1": sd[p + "mlp.lin1.weight"], "b1": sd[p + "mlp.lin1.bias"],
                   "w2": sd[p + "mlp.lin2.weight"], "b2": sd[p + "mlp.lin2.bias"],
-                  "Rh": _rel_table(size, sd[p + "attn.rel_pos_h"]), "Rw": _rel_table(size, sd[p + "attn.rel_pos_w"]),
-                  "window": 0 if i in d.sam_global else d.sam_window}
+                  "window": 0 if i in d.sam_global else d.sam_window, "size": size}
+            Bk["Rcat"], Bk["RcatT"], Bk["khp"], Bk["rel_ld"] = _rcat_tables(size, sd[p + "attn.rel_pos_h"], sd[p + "attn.rel_pos_w"],
+                                                                             hd, hp, hd ** -0.5)
             if train and i >= self.first_bwd_block:
                 for k in ("wqkv", "wproj", "w1", "w2"):
                     Bk[k + "_t"] = ops.transpose2d(Bk[k])
@@ -95,6 +112,17 @@ class SamEncoder:
             self._idx[F] = tuple(t.to(self.dev) for t in (tok2win, win2tok, conv, neck, pos_rows)) + (nwin,)
         return self._idx[F]
 
+    def _head_rows(self, nb, L):
+        """int32 [nb*heads]: row (b*L)*3*heads + h of the fused qkv activation viewed as [rows*3*heads, hp] — the q
+        vector of head h at query position 0 of batch b (the position is added through the batch stride)."""
+        key = (nb, L)
+        if key not in self._idx:
+            nh = self.d.sam_heads
+            b = torch.arange(nb).view(nb, 1)
+            h = torch.arange(nh).view(1, nh)
+            self._idx[key] = (b * L * 3 * nh + h).reshape(-1).to(torch.int32).to(self.dev)
+        return self._idx[key]
+
     # ------------------------------------------------------------------ forward
     def _attn_block(self, Bk, x, F, idx, save):
         d = self.d
@@ -111,8 +139,14 @@ class SamEncoder:
             h, mean, rstd = ops.layernorm(x, Bk["ln1"][0], Bk["ln1"][1], 1e-6, save_stats=save)
             nb, L, qhw = F, g * g, (g, g)
         qkv = ops.linear(h, Bk["wqkv"], Bk["bqkv"])
-        rel = ops.relpos(qkv, Bk["Rh"], Bk["Rw"], nb, nh, qhw, qhw, hd, hp, qkv.stride(0))
-        o, actx = attention_fwd(qkv, nb, L, nh, hp, 0, nh * hp, 2 * nh * hp, hd ** -0.5, rel=rel, rel_hw=qhw, save=save)
+        # rel'[(b h), q, :] = q_vec . R_cat[q]^T as ONE GEMM batched over the L query positions
+        ld = qkv.stride(0)
+        rel_ld = Bk["rel_ld"]
+        hrow = self._head_rows(nb, L)
+        rel = torch.empty((nb * nh, L, rel_ld), dtype=torch.bfloat16, device=self.dev)
+        ops.gemm_raw(qkv, Bk["Rcat"], rel, nb * nh, rel_ld, hp, hp, hp, L * rel_ld, a_idx=hrow, batch=(L, 1),
+                     sA=(ld, 0), sB=(rel_ld * hp, 0), sC=(rel_ld, 0))
+        o, actx = attention_fwd(qkv, nb, L, nh, hp, 0, nh * hp, 2 * nh * hp, hd ** -0.5, rel=rel, rel_hw=(Bk["khp"], qhw[1]), save=save)
         del rel
         x1 = ops.linear(o, Bk["wproj"], Bk["bproj"], residual=x, c_idx=(win2tok if ws > 0 else None), out_rows=x.shape[0])
         h2, mean2, rstd2 = ops.layernorm(x1, Bk["ln2"][0], Bk["ln2"][1], 1e-6, save_stats=save)
@@ -207,7 +241,11 @@ class SamEncoder:
             qkv = c["qkv"]
             dqkv = torch.empty_like(qkv)
             drel = attention_bwd(c["actx"], qkv, do, dqkv, want_drel=True)
-            ops.relpos(qkv, Bk["Rh"], Bk["Rw"], c["nb"], nh, c["qhw"], c["qhw"], hd, hp, qkv.stride(0), rel=drel, dq=dqkv, backward=True)
+            # dq[(b q), h, :] += d rel'[(b h), q, :] . R_cat[q]  (one GEMM batched over q, accumulating in place)
+            L, rel_ld, ldd = c["L"], Bk["rel_ld"], dqkv.stride(0)
+            hrow = self._head_rows(c["nb"], L)
+            ops.gemm_raw(drel, Bk["RcatT"], dqkv, c["nb"] * nh, hp, rel_ld, L * rel_ld, rel_ld, hp, c_idx=hrow, residual=dqkv, ldr=hp,
+                         batch=(L, 1), sA=(rel_ld, 0), sB=(hp * rel_ld, 0), sC=(ldd, 0), sR=(ldd, 0))
             dh = ops.linear(dqkv, Bk["wqkv_t"])
             del dqkv, do, drel
             ops.layernorm_bwd(c["x"], Bk["ln1"][0], dh, c["mean"], c["rstd"], dx=dx, accumulate=True,

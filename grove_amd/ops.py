@@ -214,6 +214,7 @@ def flash_attn(qkv, B, L, H, hs, q_off, k_off, v_off, alpha, *, causal=False, kv
     p.ld_q = p.ld_k = p.ld_v = ld
     p.ld_o = out.stride(0)
     p.causal, p.rel_kh, p.rel_kw, p.alpha = int(causal), rel_hw[0], rel_hw[1], alpha
+    p.rel_ld = rel.shape[-1] if rel is not None else 0
     _lib.check(_lib.lib().grove_flash_attn_fwd(C.byref(p), _stream()), "grove_flash_attn_fwd")
     return out, lse
 
@@ -223,7 +224,7 @@ def flash_attn_bwd(qkv, out, d_out, lse, dqkv, B, L, H, hs, q_off, k_off, v_off,
     dev = qkv.device
     ld, ldd = qkv.stride(0), dqkv.stride(0)
     delta = torch.empty((B * H, L), dtype=torch.float32, device=dev)
-    drel = torch.empty((B * H, L, rel_hw[0] + rel_hw[1]), dtype=torch.float32, device=dev) if want_drel else None
+    drel = torch.empty_like(rel) if want_drel else None
     p = _lib.FlashAttnParams()
     p.q, p.k, p.v, p.o, p.d_o = _p(qkv[:, q_off:]), _p(qkv[:, k_off:]), _p(qkv[:, v_off:]), _p(out), _p(d_out)
     p.dq, p.dk, p.dv = _p(dqkv[:, q_off:]), _p(dqkv[:, k_off:]), _p(dqkv[:, v_off:])
@@ -236,6 +237,7 @@ def flash_attn_bwd(qkv, out, d_out, lse, dqkv, B, L, H, hs, q_off, k_off, v_off,
     p.ld_o, p.ld_do = out.stride(0), d_out.stride(0)
     p.ld_dq = p.ld_dk = p.ld_dv = ldd
     p.causal, p.rel_kh, p.rel_kw, p.alpha = int(causal), rel_hw[0], rel_hw[1], alpha
+    p.rel_ld = rel.shape[-1] if rel is not None else 0
     _lib.check(_lib.lib().grove_flash_attn_bwd(C.byref(p), _stream()), "grove_flash_attn_bwd")
     return drel
 

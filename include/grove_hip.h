@@ -208,10 +208,10 @@ int grove_softmax_bwd(const grove_softmax_bwd_params* p, void* stream);
  * Fused (flash-style) attention, forward and backward; no score matrix in HBM.
  * q/k/v/o (+ gradients): bf16, row r of batch b at base + b*s? + r*ld_?, head h at column h*hs,
  * hs in {32, 64, 96, 128} (zero-padded head dims: pad columns must be exact zeros).
- *   S = alpha * Q K^T (+ rel[q][j / rel_kw] + rel[q][rel_kh + j % rel_kw]), causal / kv_len masks as
+ *   S = alpha * (Q K^T + rel[q][j / rel_kw] + rel[q][rel_kh + j % rel_kw]), causal / kv_len masks as
  *   grove_softmax_fwd; O = softmax(S) V; lse[b*H+h, q] = log sum_j exp(S[q, j]).
  * bwd: needs o, d_o, lse and a delta scratch [B*H, Lq] f32; writes dq, dk, dv (bf16, every valid element)
- * and optionally drel = d S summed over kw / kh (f32 [B*H, Lq, rel_kh + rel_kw]).
+ * and optionally drel (bf16), the gradient of the pre-scaled rel table (bias and d rel run on the matrix cores).
  * Replaces bmm+softmax+bmm at modeling_clip.py:279-319, image_encoder.py:310-319 (+ add_decomposed_rel_pos
  * :420-458) and flash-attn-2 inside HF LlamaAttention (llava_llama.py:100-109), forward and backward.
  * ------------------------------------------------------------------------------------------ */
@@ -223,12 +223,12 @@ typedef struct grove_flash_attn_params {
   float* lse;
   float* delta;
   const int32_t* kv_len; /* [B] or NULL */
-  const float* rel;      /* f32 [B*H, Lq, rel_kh + rel_kw] or NULL */
-  float* drel;           /* bwd, or NULL */
+  const void* rel;       /* bf16 [B*H, Lq, rel_ld] or NULL: rel / alpha; h-bins at columns 0.., w-bins at rel_kh.. */
+  void* drel;            /* bwd: bf16 [B*H, Lq, rel_ld] gradient w.r.t. rel / alpha, or NULL */
   int64_t sq, sk, sv, so, sdo, sdq, sdk, sdv; /* batch strides in elements */
   int32_t B, H, Lq, Lk, hs;
   int32_t ld_q, ld_k, ld_v, ld_o, ld_do, ld_dq, ld_dk, ld_dv;
-  int32_t causal, rel_kh, rel_kw;
+  int32_t causal, rel_kh, rel_kw, rel_ld; /* key j -> bins j / rel_kw and rel_kh + j % rel_kw */
   float alpha;
 } grove_flash_attn_params;
 int grove_flash_attn_fwd(const grove_flash_attn_params* p, void* stream);

@@ -498,17 +498,23 @@ def test_flash_attention_fwd_bwd(dev, B, H, L, hs, hd, causal, use_len, rel_hw):
     do = do.to(bf16)
     alpha = hd ** -0.5
     kv_len = torch.tensor([L, max(1, L - 37)][:B] + [L] * max(0, B - 2), dtype=torch.int32) if use_len else None
-    rel = None
+    rel = relp = None
     if rel_hw is not None:
-        rel = torch.randn(B * H, L, rel_hw[0] + rel_hw[1], generator=g)
+        kh, kw = rel_hw
+        khp = (kh + 15) // 16 * 16
+        rel_ld = khp + (kw + 15) // 16 * 16
+        # the kernel consumes rel' = rel / alpha in bf16, h-bins at 0.., w-bins at khp..
+        relp = torch.zeros(B * H, L, rel_ld)
+        relp[..., :kh] = torch.randn(B * H, L, kh, generator=g) / alpha
+        relp[..., khp:khp + kw] = torch.randn(B * H, L, kw, generator=g) / alpha
+        relp = relp.to(bf16)
     t = qkv.float().view(B, L, 3, H, hs).requires_grad_(True)
     q, k, v = t[:, :, 0].transpose(1, 2), t[:, :, 1].transpose(1, 2), t[:, :, 2].transpose(1, 2)  # [B,H,L,hs]
     s = q @ k.transpose(-1, -2) * alpha
     relr = None
-    if rel is not None:
-        relr = rel.clone().requires_grad_(True)
-        kh, kw = rel_hw
-        bias = relr[..., :kh, None] + relr[..., None, kh:]
+    if relp is not None:
+        relr = relp.float().clone().requires_grad_(True)
+        bias = (relr[..., :kh, None] + relr[..., None, khp:khp + kw]) * alpha
         s = s + bias.reshape(B, H, L, L)
     mask = torch.zeros(B, 1, L, L, dtype=torch.bool)
     if causal:
@@ -522,19 +528,20 @@ def test_flash_attention_fwd_bwd(dev, B, H, L, hs, hd, causal, use_len, rel_hw):
     o_ref.backward(do.float())
     lse_ref = torch.logsumexp(s, -1).reshape(B * H, L)
     dev_qkv = qkv.to(dev)
-    rel_d = rel.to(dev) if rel is not None else None
+    rel_d = relp.to(dev) if relp is not None else None
+    rel_arg = (khp, kw) if relp is not None else (0, 0)
     kvl = kv_len.to(dev) if kv_len is not None else None
     out, lse = ops.flash_attn(dev_qkv, B, L, H, hs, 0, H * hs, 2 * H * hs, alpha, causal=causal, kv_len=kvl, rel=rel_d,
-                              rel_hw=rel_hw or (0, 0), want_lse=True)
+                              rel_hw=rel_arg, want_lse=True)
     close(out, o_ref, 1e-2, "flash fwd")
     close(lse, lse_ref, 2e-3, "lse")
     dqkv = torch.full_like(dev_qkv, float("nan"))
     drel = ops.flash_attn_bwd(dev_qkv, out, do.to(dev), lse, dqkv, B, L, H, hs, 0, H * hs, 2 * H * hs, alpha, causal=causal,
-                              kv_len=kvl, rel=rel_d, rel_hw=rel_hw or (0, 0), want_drel=rel is not None)
+                              kv_len=kvl, rel=rel_d, rel_hw=rel_arg, want_drel=relp is not None)
     gref = t.grad.reshape(B * L, 3 * H * hs)
     for name, c0 in (("dq", 0), ("dk", H * hs), ("dv", 2 * H * hs)):
         close(dqkv[:, c0:c0 + H * hs], gref[:, c0:c0 + H * hs], 2e-2, name)
-    if rel is not None:
+    if relp is not None:
         close(drel, relr.grad, 2e-2, "drel")
 
 
