@@ -67,6 +67,36 @@ __device__ __forceinline__ void stage_tile(char* tile, const bf16_raw* __restric
   }
 }
 
+// split form (T14: issue the global loads early, write LDS late): the next tile's loads are in flight while the
+// current tile feeds the MFMAs
+template <int HS>
+struct TileRegs {
+  u32x4_t v[(BKV * (HS / 8)) / NTHR];
+};
+template <int HS>
+__device__ __forceinline__ void load_tile(TileRegs<HS>& t, const bf16_raw* __restrict__ src, int ld, int row0, int nrows_valid, int tid) {
+  using C = Cfg<HS>;
+  constexpr int PER = (BKV * C::CPR) / NTHR;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int q = tid + i * NTHR;
+    const int r = q / C::CPR, c = q - r * C::CPR;
+    const int gr = min(row0 + r, nrows_valid - 1);
+    t.v[i] = *(const u32x4_t*)(src + (int64_t)gr * ld + c * 8);
+  }
+}
+template <int HS>
+__device__ __forceinline__ void store_tile(char* tile, const TileRegs<HS>& t, int tid) {
+  using C = Cfg<HS>;
+  constexpr int PER = (BKV * C::CPR) / NTHR;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int q = tid + i * NTHR;
+    const int r = q / C::CPR, c = q - r * C::CPR;
+    *(u32x4_t*)(tile + r * C::ROWB + c * 16) = t.v[i];
+  }
+}
+
 // ---- decomposed rel-pos bias on the matrix cores ------------------------------------------------------
 // bias[q][j] = rel[q][kh(j)] + rel[q][KH + kw(j)] = sum_bin rel[q][bin] * E[bin][j] with the 0/1 indicator
 // E[bin][j] = (bin == kh(j)) | (bin == KH + kw(j)). rel is pre-divided by alpha and rounded to bf16 (the
@@ -150,11 +180,18 @@ __global__ __launch_bounds__(NTHR) void flash_fwd_kernel(const grove_flash_attn_
   if (p.causal) kv_lim = min(kv_lim, min(qblk + 127, p.Lq - 1) + (p.Lk - p.Lq) + 1);
   const float sc = p.alpha * 1.4426950408889634f;  // exp2 domain
 
+  TileRegs<HS> kreg, vreg;
+  load_tile<HS>(kreg, K, p.ld_k, 0, p.Lk, tid);
+  load_tile<HS>(vreg, V, p.ld_v, 0, p.Lk, tid);
   for (int kv0 = 0; kv0 < kv_lim; kv0 += BKV) {
     __syncthreads();
-    stage_tile<HS>(Ks, K, p.ld_k, kv0, p.Lk, tid);
-    stage_tile<HS>(Vs, V, p.ld_v, kv0, p.Lk, tid);
+    store_tile<HS>(Ks, kreg, tid);
+    store_tile<HS>(Vs, vreg, tid);
     __syncthreads();
+    if (kv0 + BKV < kv_lim) {
+      load_tile<HS>(kreg, K, p.ld_k, kv0 + BKV, p.Lk, tid);
+      load_tile<HS>(vreg, V, p.ld_v, kv0 + BKV, p.Lk, tid);
+    }
     f32x4_t s[2][4];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
@@ -331,10 +368,17 @@ __global__ __launch_bounds__(NTHR) void flash_bwd_dkv_kernel(const grove_flash_a
   qstart = (qstart / BKV) * BKV;
   const float sc = p.alpha * 1.4426950408889634f;
 
+  TileRegs<HS> qreg, doreg;
+  load_tile<HS>(qreg, Q, p.ld_q, qstart, p.Lq, tid);
+  load_tile<HS>(doreg, dO, p.ld_do, qstart, p.Lq, tid);
   for (int qt0 = qstart; qt0 < p.Lq; qt0 += BKV) {
     __syncthreads();
-    stage_tile<HS>(Qs, Q, p.ld_q, qt0, p.Lq, tid);
-    stage_tile<HS>(dOs, dO, p.ld_do, qt0, p.Lq, tid);
+    store_tile<HS>(Qs, qreg, tid);
+    store_tile<HS>(dOs, doreg, tid);
+    if (qt0 + BKV < p.Lq) {
+      load_tile<HS>(qreg, Q, p.ld_q, qt0 + BKV, p.Lq, tid);
+      load_tile<HS>(doreg, dO, p.ld_do, qt0 + BKV, p.Lq, tid);
+    }
     if (tid < BKV) {
       const int qi = min(qt0 + tid, p.Lq - 1);
       lse_s[tid] = LSE[qi] * 1.4426950408889634f;
@@ -497,11 +541,18 @@ __global__ __launch_bounds__(NTHR) void flash_bwd_dq_kernel(const grove_flash_at
   if (p.causal) kv_lim = min(kv_lim, min(qblk + 127, p.Lq - 1) + (p.Lk - p.Lq) + 1);
   const float sc = p.alpha * 1.4426950408889634f;
 
+  TileRegs<HS> kreg, vreg;
+  load_tile<HS>(kreg, K, p.ld_k, 0, p.Lk, tid);
+  load_tile<HS>(vreg, V, p.ld_v, 0, p.Lk, tid);
   for (int kv0 = 0; kv0 < kv_lim; kv0 += BKV) {
     __syncthreads();
-    stage_tile<HS>(Ks, K, p.ld_k, kv0, p.Lk, tid);
-    stage_tile<HS>(Vs, V, p.ld_v, kv0, p.Lk, tid);
+    store_tile<HS>(Ks, kreg, tid);
+    store_tile<HS>(Vs, vreg, tid);
     __syncthreads();
+    if (kv0 + BKV < kv_lim) {
+      load_tile<HS>(kreg, K, p.ld_k, kv0 + BKV, p.Lk, tid);
+      load_tile<HS>(vreg, V, p.ld_v, kv0 + BKV, p.Lk, tid);
+    }
     f32x4_t s[2][4], dp[2][4];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)

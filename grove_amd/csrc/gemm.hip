@@ -18,7 +18,6 @@
 
 namespace {
 
-constexpr int BM = 128;
 constexpr int BN = 128;
 constexpr int NT = 256;
 
@@ -58,12 +57,19 @@ __device__ __forceinline__ TileCoord map_block(int tiles_m, int tiles_n) {
   return t;
 }
 
-template <int BK, bool GLDS>
+template <int BK, bool GLDS, int NJ, int MI>
 __global__ __launch_bounds__(NT) void gemm_nt_kernel(const grove_gemm_params p, const int vec_ok) {
+  constexpr int BM_ = 32 * MI;                  // macro tile M: 128 (MI = 4) or 192 (MI = 6, fewer / fuller rounds of blocks)
+  constexpr int WM = 16 * MI;                   // per-wave M extent
+  constexpr int BN_ = 32 * NJ;                  // macro tile N: 128 (NJ = 4) or 64 (NJ = 2, for wave-quantisation-bound shapes)
+  constexpr int WN = 16 * NJ;                   // per-wave N extent
   constexpr int CPR = BK / 8;                   // 16-byte chunks per LDS row
   constexpr int ROW_BYTES = BK * 2;
-  constexpr int TILE_BYTES = BM * ROW_BYTES;    // A tile == B tile size (BM == BN)
-  constexpr int LPT = (BM * CPR) / NT;          // 16-byte loads per thread per operand tile
+  constexpr int TILE_BYTES = BM_ * ROW_BYTES;   // A tile
+  constexpr int B_BYTES = BN_ * ROW_BYTES;      // B tile
+  constexpr int LPT = (BM_ * CPR) / NT;         // 16-byte loads per thread per A tile
+  constexpr int LPTM = LPT > ((32 * NJ) * CPR) / NT ? LPT : ((32 * NJ) * CPR) / NT;
+  constexpr int LPTB = (BN_ * CPR) / NT;        // ... per B tile
   constexpr int ROWS_PER_PASS = NT / CPR;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // layout: [buf0: A | B][buf1: A | B]
@@ -72,10 +78,10 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(const grove_gemm_params p, 
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
 
-  const int tiles_m = (p.M + BM - 1) / BM;
-  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tiles_m = (p.M + BM_ - 1) / BM_;
+  const int tiles_n = (p.N + BN_ - 1) / BN_;
   const TileCoord tc = map_block(tiles_m, tiles_n);
-  const int m0 = tc.tm * BM, n0 = tc.tn * BN;
+  const int m0 = tc.tm * BM_, n0 = tc.tn * BN_;
 
   const int bz = blockIdx.y;
   const int b1 = bz / p.batch2, b2 = bz - b1 * p.batch2;
@@ -86,19 +92,21 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(const grove_gemm_params p, 
   const int st_c = tid % CPR;          // logical chunk within the row
   const int st_r0 = tid / CPR;         // first row, + ROWS_PER_PASS per pass
   int a_m[LPT];                        // clamped global m of each staged A row
-  const bf16_raw* b_ptr[LPT];
-  int lds_off[LPT];                    // byte offset inside a tile for the reg-staged write
+  const bf16_raw* b_ptr[LPTB];
+  int lds_off[LPTM];                   // byte offset inside a tile for the reg-staged write
   // For LDS-DMA the destination is lane-linear: lane -> (row, physical chunk); the lane must
   // therefore FETCH the logical chunk that belongs at that physical slot (swz is an involution).
-  int src_c[LPT];
+  int src_c[LPTM];
 #pragma unroll
-  for (int i = 0; i < LPT; ++i) {
+  for (int i = 0; i < LPTM; ++i) {
     const int r = st_r0 + i * ROWS_PER_PASS;
-    a_m[i] = min(m0 + r, p.M - 1);
-    const int n = min(n0 + r, p.N - 1);
+    if (i < LPT) a_m[i] = min(m0 + r, p.M - 1);
     src_c[i] = GLDS ? swz<BK>(r, st_c) : st_c;
-    b_ptr[i] = Bb + (int64_t)n * p.ldb + src_c[i] * 8;
     lds_off[i] = r * ROW_BYTES + swz<BK>(r, st_c) * 16;
+    if (i < LPTB) {
+      const int n = min(n0 + r, p.N - 1);
+      b_ptr[i] = Bb + (int64_t)n * p.ldb + src_c[i] * 8;
+    }
   }
 
   const int taps = p.a_taps;
@@ -120,7 +128,7 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(const grove_gemm_params p, 
   const int kt0 = blockIdx.z * nk_per;
   const int nk = min(nk_total, kt0 + nk_per);  // exclusive end tile of this split
   if (kt0 >= nk) return;                         // empty split (uniform for the whole block)
-  u32x4_t ra[LPT], rb[LPT];
+  u32x4_t ra[LPT], rb[LPTB];
 
   auto issue_loads = [&](int kt, char* buf) {
     const int k0 = kt * BK;
@@ -140,7 +148,7 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(const grove_gemm_params p, 
                                          (__attribute__((address_space(3))) void*)(la + i * (NT * 16)), 16, 0, 0);
       }
 #pragma unroll
-      for (int i = 0; i < LPT; ++i) {
+      for (int i = 0; i < LPTB; ++i) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_ptr[i] + k0),
                                          (__attribute__((address_space(3))) void*)(lb + i * (NT * 16)), 16, 0, 0);
       }
@@ -151,7 +159,7 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(const grove_gemm_params p, 
         else ra[i] = u32x4_t{0u, 0u, 0u, 0u};
       }
 #pragma unroll
-      for (int i = 0; i < LPT; ++i) rb[i] = *(const u32x4_t*)(b_ptr[i] + k0);
+      for (int i = 0; i < LPTB; ++i) rb[i] = *(const u32x4_t*)(b_ptr[i] + k0);
     }
   };
   auto commit_loads = [&](char* buf) {
@@ -159,15 +167,15 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(const grove_gemm_params p, 
 #pragma unroll
       for (int i = 0; i < LPT; ++i) *(u32x4_t*)(buf + lds_off[i]) = ra[i];
 #pragma unroll
-      for (int i = 0; i < LPT; ++i) *(u32x4_t*)(buf + TILE_BYTES + lds_off[i]) = rb[i];
+      for (int i = 0; i < LPTB; ++i) *(u32x4_t*)(buf + TILE_BYTES + lds_off[i]) = rb[i];
     }
   };
 
-  f32x4_t acc[4][4];
+  f32x4_t acc[MI][NJ];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   // fragment read offsets (bytes within a tile), per k-step
   const int fr = lane & 15, fq = lane >> 4;
@@ -176,27 +184,27 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(const grove_gemm_params p, 
     const char* Bs = buf + TILE_BYTES;
 #pragma unroll
     for (int ks = 0; ks < BK / 32; ++ks) {
-      bf16x8_t af[4], bfg[4];
+      bf16x8_t af[MI], bfg[NJ];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int r = wm * 64 + i * 16 + fr;
+      for (int i = 0; i < MI; ++i) {
+        const int r = wm * WM + i * 16 + fr;
         af[i] = *(const bf16x8_t*)(As + r * ROW_BYTES + swz<BK>(r, ks * 4 + fq) * 16);
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int r = wn * 64 + j * 16 + fr;
+      for (int j = 0; j < NJ; ++j) {
+        const int r = wn * WN + j * 16 + fr;
         bfg[j] = *(const bf16x8_t*)(Bs + r * ROW_BYTES + swz<BK>(r, ks * 4 + fq) * 16);
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfg[j], af[i], acc[i][j], 0, 0, 0);
     }
   };
 
   char* buf0 = smem;
-  char* buf1 = smem + 2 * TILE_BYTES;
+  char* buf1 = smem + TILE_BYTES + B_BYTES;
 
   // ---- prologue ----
   issue_loads(kt0, buf0);
@@ -227,8 +235,8 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(const grove_gemm_params p, 
   const bool vec4 = vec_ok && ((p.ldc & 3) == 0) && (!p.residual || (p.ldr & 3) == 0);
 
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + fr;
+  for (int i = 0; i < MI; ++i) {
+    const int m = m0 + wm * WM + i * 16 + fr;
     if (m >= p.M) continue;
     int crow = m;
     if (p.c_idx) {
@@ -238,8 +246,8 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(const grove_gemm_params p, 
     int rrow = crow;
     if (p.r_idx) rrow = p.r_idx[m];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wn * 64 + j * 16 + fq * 4;
+    for (int j = 0; j < NJ; ++j) {
+      const int n = n0 + wn * WN + j * 16 + fq * 4;
       if (n >= p.N) continue;
       float v[4];
 #pragma unroll
@@ -315,9 +323,11 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(const grove_gemm_params p, 
   }
 }
 
-template <int BK, bool GLDS>
+template <int BK, bool GLDS, int NJ, int MI>
 int launch(const grove_gemm_params& p, int vec_ok, hipStream_t s) {
-  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+  constexpr int BN_ = 32 * NJ;
+  constexpr int BM_ = 32 * MI;
+  const int tiles_m = (p.M + BM_ - 1) / BM_, tiles_n = (p.N + BN_ - 1) / BN_;
   int split = p.split_k;
   const bool can_split = p.accumulate && p.c_dtype == GROVE_F32 && !p.bias && !p.residual && !p.aux && p.act == GROVE_ACT_NONE;
   if (split == 0) {
@@ -337,15 +347,25 @@ int launch(const grove_gemm_params& p, int vec_ok, hipStream_t s) {
     return GROVE_E_SHAPE;
   }
   dim3 grid(tiles_m * tiles_n, p.batch1 * p.batch2, split);
-  const size_t lds = 2 * 2 * BM * BK * 2;
+  const size_t lds = 2 * (size_t)(BM_ + BN_) * BK * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_nt_kernel<BK, GLDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)gemm_nt_kernel<BK, GLDS, NJ, MI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_nt_kernel<BK, GLDS>), grid, dim3(NT), lds, s, p, vec_ok);
+  hipLaunchKernelGGL((gemm_nt_kernel<BK, GLDS, NJ, MI>), grid, dim3(NT), lds, s, p, vec_ok);
   GROVE_LAUNCH_CHECK();
   return GROVE_OK;
+}
+
+// fraction of the 256 CUs' block slots that do useful work when `tiles` equal blocks are spread over them
+inline double wave_util(long tiles, int per_cu) {
+  const double slots = 256.0 * per_cu;
+  if (tiles >= slots) {
+    const double rounds = tiles / slots;
+    return rounds / (double)(long)(rounds + 0.999999);
+  }
+  return tiles >= 256 ? 1.0 : tiles / 256.0;
 }
 
 }  // namespace
@@ -353,6 +373,21 @@ int launch(const grove_gemm_params& p, int vec_ok, hipStream_t s) {
 // staging variant: 1 = LDS-DMA (default), 0 = register staged (kept for A/B and as the
 // conservative path); switchable at run time for in-process A/B (cdna guide §5.4 rule 24).
 static int g_gemm_glds = 1;
+static int g_gemm_bk = 0;      // 0 = auto (64 when K allows), 32 = forced
+extern "C" int grove_gemm_set_bk(int bk) {
+  g_gemm_bk = bk;
+  return GROVE_OK;
+}
+static int g_gemm_tile_m = 0;  // 0 = auto, 128 / 192 = forced
+extern "C" int grove_gemm_set_tile_m(int tile_m) {
+  g_gemm_tile_m = tile_m;
+  return GROVE_OK;
+}
+static int g_gemm_tile_n = 0;  // 0 = auto, 64 / 128 = forced (A/B runs)
+extern "C" int grove_gemm_set_tile_n(int tile_n) {
+  g_gemm_tile_n = tile_n;
+  return GROVE_OK;
+}
 extern "C" int grove_gemm_set_staging(int use_lds_dma) {
   g_gemm_glds = use_lds_dma ? 1 : 0;
   return GROVE_OK;
@@ -384,7 +419,25 @@ extern "C" int grove_gemm_bf16(const grove_gemm_params* pp, void* stream) {
                       (!p.residual || ((((uintptr_t)p.residual & 7) == 0) && p.sR1 % 4 == 0 && p.sR2 % 4 == 0)) &&
                       (!p.bias || ((uintptr_t)p.bias & 7) == 0);
   hipStream_t s = (hipStream_t)stream;
-  const bool bk64 = (p.K % 64 == 0) && ((p.K / p.a_taps) % 64 == 0);
-  if (g_gemm_glds) return bk64 ? launch<64, true>(p, vec_ok, s) : launch<32, true>(p, vec_ok, s);
-  return bk64 ? launch<64, false>(p, vec_ok, s) : launch<32, false>(p, vec_ok, s);
+  const bool bk64 = (p.K % 64 == 0) && ((p.K / p.a_taps) % 64 == 0) && g_gemm_bk != 32;
+  // Tile choice by block-round quantisation. All variants keep 2 blocks per CU resident (512 slots); a block of a
+  // partial last round runs alone on its CU at about half the CU's rate, so time ~ ceil(tiles / 512) * tile_rows.
+  //   128 x 128: the default.   192 x 128: e.g. M = 2812, N = 4096 -> 480 tiles = ONE round instead of 1.375.
+  //   128 x 64 : only when even 128 x 128 tiles cannot fill the chip.
+  const long bt = (long)p.batch1 * p.batch2;
+  const long tn128 = (p.N + 127) / 128;
+  const long t128 = (long)((p.M + 127) / 128) * tn128 * bt;
+  const long t192 = (long)((p.M + 191) / 192) * tn128 * bt;
+  auto rounds_cost = [](long tiles, int rows) { return (double)((tiles + 511) / 512) * rows; };
+  int variant = 128;
+  // measured (tools/bench_gemm2.py): at equal round counts the 192-row tile is ~8 % faster (0.42 vs 0.5 LDS reads per MFMA)
+  if (g_gemm_tile_m == 192 || (g_gemm_tile_m == 0 && t128 > 300 && rounds_cost(t192, 192) / 1.08 <= 1.05 * rounds_cost(t128, 128))) variant = 192;
+  const bool narrow = g_gemm_tile_n == 64 || (g_gemm_tile_n == 0 && t128 < 160 && p.N > 64);
+  if (narrow) {
+    if (g_gemm_glds) return bk64 ? launch<64, true, 2, 4>(p, vec_ok, s) : launch<32, true, 2, 4>(p, vec_ok, s);
+    return bk64 ? launch<64, false, 2, 4>(p, vec_ok, s) : launch<32, false, 2, 4>(p, vec_ok, s);
+  }
+  if (variant == 192 && g_gemm_glds) return bk64 ? launch<64, true, 4, 6>(p, vec_ok, s) : launch<32, true, 4, 6>(p, vec_ok, s);
+  if (g_gemm_glds) return bk64 ? launch<64, true, 4, 4>(p, vec_ok, s) : launch<32, true, 4, 4>(p, vec_ok, s);
+  return bk64 ? launch<64, false, 4, 4>(p, vec_ok, s) : launch<32, false, 4, 4>(p, vec_ok, s);
 }

@@ -89,6 +89,10 @@ def wgrad(dy, x, grad, *, b_idx=None, b_taps=1, scale_ptr=None, scale_tanh=False
     return grad
 
 
+def gemm_set_tile_n(n: int):
+    _lib.check(_lib.lib().grove_gemm_set_tile_n(int(n)), "grove_gemm_set_tile_n")
+
+
 def gemm_set_staging(use_lds_dma: bool):
     _lib.check(_lib.lib().grove_gemm_set_staging(int(use_lds_dma)), "grove_gemm_set_staging")
 

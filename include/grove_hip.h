@@ -90,6 +90,12 @@ typedef struct grove_gemm_params {
 int grove_gemm_bf16(const grove_gemm_params* p, void* stream);
 /* A/B staging variant: 1 = LDS-DMA (global_load_lds, default), 0 = register staged */
 int grove_gemm_set_staging(int use_lds_dma);
+/* macro-tile N: 0 = auto (by wave quantisation), 64 or 128 = forced (for A/B measurements) */
+int grove_gemm_set_tile_n(int tile_n);
+/* macro-tile M: 0 = auto, 128 or 192 = forced */
+int grove_gemm_set_tile_m(int tile_m);
+/* K tile: 0 = auto (64 when K % 64 == 0), 32 = forced (A/B measurements) */
+int grove_gemm_set_bk(int bk);
 
 /* ------------------------------------------------------------------------------------------
  * "TN" GEMM for weight gradients:  C[m, n] += f * sum_k A[k, m] * B[row_b(k, n), n mod (N / b_taps)]

@@ -572,3 +572,21 @@ def test_wgrad_conv3d_gather(dev):
     out = torch.zeros(Co, 27 * Ci, dtype=torch.float32, device=dev)
     ops.wgrad(dy.to(dev), x.to(dev), out, b_idx=idx, b_taps=27)
     close(out, ref, 3e-5, "conv3d wgrad")
+
+
+@pytest.mark.parametrize("tile_n,tile_m", [(64, 128), (128, 128), (128, 192)])
+@pytest.mark.parametrize("M,N,K", [(300, 200, 96), (2812, 520, 128), (130, 64, 64)])
+def test_gemm_tile_variants(dev, M, N, K, tile_n, tile_m):
+    """All macro tiles (128 x 128, 192 x 128, 128 x 64) with a full epilogue."""
+    from grove_amd import ops, _lib
+    ops.gemm_set_tile_n(tile_n)
+    _lib.lib().grove_gemm_set_tile_m(tile_m)
+    try:
+        a, b = rnd(M, K, seed=95), rnd(N, K, seed=96, scale=0.1)
+        bias, res = rnd(N, seed=97), rnd(M, N, seed=98)
+        ref = F.gelu(a.float() @ b.float().t() + bias.float()) + res.float()
+        out = ops.linear(a.to(dev), b.to(dev), bias.to(dev), act=ops.ACT_GELU, residual=res.to(dev))
+        close(out, ref, 8e-3, f"tile_n={tile_n} tile_m={tile_m}")
+    finally:
+        ops.gemm_set_tile_n(0)
+        _lib.lib().grove_gemm_set_tile_m(0)
