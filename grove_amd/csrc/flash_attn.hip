@@ -122,6 +122,8 @@ __device__ __forceinline__ bf16x8_t relfrag(const bf16_raw* relrow, int bin0, in
   return __builtin_bit_cast(bf16x8_t, z);
 }
 
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32 (exp2(-inf) = 0)
+
 __device__ __forceinline__ float group_max(float v) {
   v = fmaxf(v, __shfl_xor(v, 16, 64));
   return fmaxf(v, __shfl_xor(v, 32, 64));
@@ -192,6 +194,15 @@ __global__ __launch_bounds__(NTHR) void flash_fwd_kernel(const grove_flash_attn_
       load_tile<HS>(kreg, K, p.ld_k, kv0 + BKV, p.Lk, tid);
       load_tile<HS>(vreg, V, p.ld_v, kv0 + BKV, p.Lk, tid);
     }
+    // wave-uniform work trimming: dead query waves, key tiles past the last visible key, mask only at edges
+    int lim_hi = kv_end, lim_lo = kv_end;
+    if (p.causal) {
+      lim_hi = min(lim_hi, q0 + 31 + (p.Lk - p.Lq) + 1);
+      lim_lo = min(lim_lo, q0 + (p.Lk - p.Lq) + 1);
+    }
+    if (q0 >= p.Lq || kv0 >= lim_hi) continue;
+    const int nv = min(4, (lim_hi - kv0 + 15) >> 4);
+    const bool need_mask = kv0 + BKV > lim_lo;
     f32x4_t s[2][4];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
@@ -199,20 +210,22 @@ __global__ __launch_bounds__(NTHR) void flash_fwd_kernel(const grove_flash_attn_
       for (int ni = 0; ni < 4; ++ni) s[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
+      if (ni < nv) {
 #pragma unroll
-      for (int ks = 0; ks < C::KS; ++ks) {
-        const bf16x8_t kf = lds_row_frag(Ks, C::ROWB, ni * 16 + fr, ks * 4 + g);
+        for (int ks = 0; ks < C::KS; ++ks) {
+          const bf16x8_t kf = lds_row_frag(Ks, C::ROWB, ni * 16 + fr, ks * 4 + g);
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) s[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[mi][ks], s[mi][ni], 0, 0, 0);
-      }
-      if (nrk > 0) {
-        const unsigned kb = kbin[kv0 + ni * 16 + fr];
+          for (int mi = 0; mi < 2; ++mi) s[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[mi][ks], s[mi][ni], 0, 0, 0);
+        }
+        if (nrk > 0) {
+          const unsigned kb = kbin[kv0 + ni * 16 + fr];
 #pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2) {
-          if (k2 < nrk) {
-            const bf16x8_t ef = efrag_key(kb, k2 * 32 + g * 8, p.rel_kh);
+          for (int k2 = 0; k2 < 2; ++k2) {
+            if (k2 < nrk) {
+              const bf16x8_t ef = efrag_key(kb, k2 * 32 + g * 8, p.rel_kh);
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) s[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ef, relf[mi][k2], s[mi][ni], 0, 0, 0);
+              for (int mi = 0; mi < 2; ++mi) s[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ef, relf[mi][k2], s[mi][ni], 0, 0, 0);
+            }
           }
         }
       }
@@ -220,30 +233,40 @@ __global__ __launch_bounds__(NTHR) void flash_fwd_kernel(const grove_flash_attn_
     bf16x8_t pf[2][2];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
-      const int qi = q0 + mi * 16 + fr;
-      int lim = kv_end;
-      if (p.causal) lim = min(lim, qi + (p.Lk - p.Lq) + 1);
       float mx = -INFINITY;
+      if (need_mask) {
+        const int qi = q0 + mi * 16 + fr;
+        int lim = kv_end;
+        if (p.causal) lim = min(lim, qi + (p.Lk - p.Lq) + 1);
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
+        for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int j = kv0 + ni * 16 + g * 4 + r;
-          float v = s[mi][ni][r] * sc;
-          v = j < lim ? v : -INFINITY;
-          s[mi][ni][r] = v;
-          mx = fmaxf(mx, v);
-        }
+          for (int r = 0; r < 4; ++r) {
+            const int j = kv0 + ni * 16 + g * 4 + r;
+            const float v = j < lim ? s[mi][ni][r] * sc : -INFINITY;
+            s[mi][ni][r] = v;
+            mx = fmaxf(mx, v);
+          }
+      } else {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = s[mi][ni][r] * sc;
+            s[mi][ni][r] = v;
+            mx = fmaxf(mx, v);
+          }
+      }
       mx = group_max(mx);
       const float m_new = fmaxf(m_run[mi], mx);
       const float m_use = m_new == -INFINITY ? 0.f : m_new;
-      const float corr = exp2f(m_run[mi] - m_use);  // m_run = -inf -> 0
+      const float corr = fast_exp2(m_run[mi] - m_use);  // m_run = -inf -> 0
       float rs = 0.f;
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float e = exp2f(s[mi][ni][r] - m_use);
+          const float e = fast_exp2(s[mi][ni][r] - m_use);
           s[mi][ni][r] = e;
           rs += e;
         }
@@ -256,13 +279,16 @@ __global__ __launch_bounds__(NTHR) void flash_fwd_kernel(const grove_flash_attn_
       pf[mi][1] = pack_frag(s[mi][2], s[mi][3]);
     }
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
+    for (int s2 = 0; s2 < 2; ++s2) {
+      if (s2 * 2 < nv) {
 #pragma unroll
-      for (int dt = 0; dt < C::DT; ++dt) {
-        const bf16x8_t vf = lds_tr_frag(Vs, C::ROWB, s2 * 32, dt * 16, lane);
+        for (int dt = 0; dt < C::DT; ++dt) {
+          const bf16x8_t vf = lds_tr_frag(Vs, C::ROWB, s2 * 32, dt * 16, lane);
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) oacc[mi][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[mi][s2], oacc[mi][dt], 0, 0, 0);
+          for (int mi = 0; mi < 2; ++mi) oacc[mi][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[mi][s2], oacc[mi][dt], 0, 0, 0);
+        }
       }
+    }
   }
   // epilogue: lane holds O^T[d = dt*16 + 4g + r][q = fr]
   bf16_raw* O = (bf16_raw*)p.o + (int64_t)b * p.so + h * HS;
@@ -393,9 +419,12 @@ __global__ __launch_bounds__(NTHR) void flash_bwd_dkv_kernel(const grove_flash_a
       }
     }
     __syncthreads();
+    if (k0 >= kv_end) continue;  // wave-uniform: this wave's 32 keys are all padding / masked
     // two 32-query k-steps per staged tile
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
+      if (qt0 + s2 * 32 >= p.Lq) continue;
+      if (p.causal && qt0 + s2 * 32 + 31 + (p.Lk - p.Lq) < k0) continue;  // every query of this half is above the diagonal
       // S[q][key] and dP[q][key] for q tiles 2*s2, 2*s2+1 and this wave's 2 key tiles
       f32x4_t sacc[2][2], pacc[2][2];
 #pragma unroll
@@ -443,7 +472,7 @@ __global__ __launch_bounds__(NTHR) void flash_bwd_dkv_kernel(const grove_flash_a
             if (p.causal) lim = min(lim, qi + (p.Lk - p.Lq) + 1);
             const float v = sacc[qi_][nj][r] * sc;
             const bool ok = (j < lim) && (qi < p.Lq);
-            const float pr = ok ? exp2f(v - lse_s[ql]) : 0.f;
+            const float pr = ok ? fast_exp2(v - lse_s[ql]) : 0.f;
             pp[qi_][r] = pr;
             dd[qi_][r] = pr * (pacc[qi_][nj][r] - del_s[ql]) * p.alpha;
           }
@@ -553,6 +582,10 @@ __global__ __launch_bounds__(NTHR) void flash_bwd_dq_kernel(const grove_flash_at
       load_tile<HS>(kreg, K, p.ld_k, kv0 + BKV, p.Lk, tid);
       load_tile<HS>(vreg, V, p.ld_v, kv0 + BKV, p.Lk, tid);
     }
+    int lim_hi = kv_end;
+    if (p.causal) lim_hi = min(lim_hi, q0 + 31 + (p.Lk - p.Lq) + 1);
+    if (q0 >= p.Lq || kv0 >= lim_hi) continue;  // wave-uniform: dead query wave / nothing visible in this key tile
+    const int nv = min(4, (lim_hi - kv0 + 15) >> 4);
     f32x4_t s[2][4], dp[2][4];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
@@ -560,6 +593,7 @@ __global__ __launch_bounds__(NTHR) void flash_bwd_dq_kernel(const grove_flash_at
       for (int ni = 0; ni < 4; ++ni) { s[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dp[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
+      if (ni >= nv) continue;
 #pragma unroll
       for (int ks = 0; ks < C::KS; ++ks) {
         const bf16x8_t ka = lds_row_frag(Ks, C::ROWB, ni * 16 + fr, ks * 4 + g);
@@ -594,7 +628,7 @@ __global__ __launch_bounds__(NTHR) void flash_bwd_dq_kernel(const grove_flash_at
         for (int r = 0; r < 4; ++r) {
           const int j = kv0 + ni * 16 + g * 4 + r;
           const float v = s[mi][ni][r] * sc;
-          const float pr = j < lim ? exp2f(v - lse2[mi]) : 0.f;
+          const float pr = j < lim ? fast_exp2(v - lse2[mi]) : 0.f;
           s[mi][ni][r] = pr * (dp[mi][ni][r] - del[mi]) * p.alpha;
         }
       dsf[mi][0] = pack_frag(s[mi][0], s[mi][1]);
@@ -602,17 +636,20 @@ __global__ __launch_bounds__(NTHR) void flash_bwd_dq_kernel(const grove_flash_at
     }
     // dQ^T[d][q] += sum_key K^T[d][key] dS^T[key][q]
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
+    for (int s2 = 0; s2 < 2; ++s2) {
+      if (s2 * 2 >= nv) continue;
 #pragma unroll
       for (int dt = 0; dt < C::DT; ++dt) {
         const bf16x8_t kt = lds_tr_frag(Ks, C::ROWB, s2 * 32, dt * 16, lane);
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) dq[mi][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, dsf[mi][s2], dq[mi][dt], 0, 0, 0);
       }
+    }
     // d rel^T[bin][q] += sum_key E[bin][key] dS^T[key][q]   (dsf carries alpha; divided out at the end)
     if (p.drel) {
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
+        if (s2 * 2 >= nv) continue;
         unsigned kb8[8];
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) kb8[jj] = kbin[kv0 + s2 * 32 + (jj < 4 ? 4 * g + jj : 16 + 4 * g + jj - 4)];

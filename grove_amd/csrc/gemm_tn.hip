@@ -56,19 +56,27 @@ __global__ __launch_bounds__(TNT) void gemm_tn_kernel(const grove_gemm_tn_params
   const bool a_col_ok = m0 + st_c * 8 < p.M;
   const bool b_col_ok = n0 + st_c * 8 < p.N && nb0 + st_c * 8 < n_per_tap;
   u32x4_t ra[TLPT], rb[TLPT];
+  // gathered-row indices are fetched ONE tile ahead of the loads that use them, so the dependent
+  // index -> row load chain never sits on the critical path of a K tile
+  int rowidx[TLPT];
+  auto fetch_idx = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < TLPT; ++i) {
+      const int k = kt * TBK + st_r + 16 * i;
+      rowidx[i] = k < p.K ? (bidx ? bidx[k] : k) : -1;
+    }
+  };
   auto issue = [&](int kt) {
 #pragma unroll
     for (int i = 0; i < TLPT; ++i) {
       const int k = kt * TBK + st_r + 16 * i;
       ra[i] = u32x4_t{0u, 0u, 0u, 0u};
       rb[i] = u32x4_t{0u, 0u, 0u, 0u};
-      if (k < p.K) {
-        if (a_col_ok) ra[i] = *(const u32x4_t*)(A + (int64_t)k * p.lda + m0 + st_c * 8);
-        int row = k;
-        if (bidx) row = bidx[k];
-        if (row >= 0 && b_col_ok) rb[i] = *(const u32x4_t*)(B + (int64_t)row * p.ldb + nb0 + st_c * 8);
-      }
+      if (k < p.K && a_col_ok) ra[i] = *(const u32x4_t*)(A + (int64_t)k * p.lda + m0 + st_c * 8);
+      const int row = rowidx[i];
+      if (row >= 0 && b_col_ok) rb[i] = *(const u32x4_t*)(B + (int64_t)row * p.ldb + nb0 + st_c * 8);
     }
+    fetch_idx(kt + 1);
   };
   auto commit = [&](char* buf) {
 #pragma unroll
@@ -101,6 +109,7 @@ __global__ __launch_bounds__(TNT) void gemm_tn_kernel(const grove_gemm_tn_params
   };
   char* buf0 = smem;
   char* buf1 = smem + 2 * TTILEB;
+  fetch_idx(kt0);
   issue(kt0);
   commit(buf0);
   __syncthreads();

@@ -5,7 +5,7 @@ sys.path.insert(0, ".")
 from grove_amd import ops, _lib
 dev = torch.device("cuda:0")
 shapes = [(2812, 12288, 4096), (56448, 1280, 4608), (2812, 4096, 22016), (2812, 4096, 4096), (2812, 4096, 11008), (4096, 4096, 4096), (18464, 4096, 1024), (32768, 5120, 1280), (2812, 22016, 4096)]
-variants = [("128x128", 128, 128), ("192x128", 128, 192), ("auto", 0, 0)]
+variants = [("192x128", 128, 192), ("256x128x32", 128, 256), ("auto", 0, 0)]
 for M, N, K in shapes:
     a = torch.randn(M, K, device=dev).to(torch.bfloat16)
     b = (torch.randn(N, K, device=dev) * 0.05).to(torch.bfloat16)
