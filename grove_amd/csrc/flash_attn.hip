@@ -133,14 +133,52 @@ __device__ __forceinline__ float group_sum(float v) {
   return v + __shfl_xor(v, 32, 64);
 }
 
+// ---- shared pieces of the query-major kernels (forward, dQ) ---------------------------------------------------
+constexpr int ESB = 64 * 2 + 32;        // row stride of the per-tile indicator image E[64 keys][<=64 bins]
+constexpr int ETILEB = BKV * ESB;
+
+// E[key][bin] for the 64 keys of the current tile, built cooperatively (one key x 16 bins per thread)
+__device__ __forceinline__ void build_etile(char* Es, int kv0, int Lk, int kw, int KH, int nrel, int tid) {
+  const int key = tid >> 2, quarter = tid & 3;
+  if (quarter * 16 >= nrel) return;
+  const int j = kv0 + key;
+  const unsigned kb = j < Lk ? (unsigned)((j / kw) | ((j % kw) << 8)) : 0xFFFFu;
+  *(bf16x8_t*)(Es + key * ESB + quarter * 32) = efrag_key(kb, quarter * 16, KH);
+  *(bf16x8_t*)(Es + key * ESB + quarter * 32 + 16) = efrag_key(kb, quarter * 16 + 8, KH);
+}
+
+// x[j] *= s on a bf16x8 fragment (one-time operand pre-scaling: the softmax then runs in the exp2 domain unscaled)
+__device__ __forceinline__ bf16x8_t scale_frag(bf16x8_t f, float sc) {
+  const u32x4_t u = __builtin_bit_cast(u32x4_t, f);
+  const u32x4_t o = u32x4_t{pack2bf(bf_lo(u.x) * sc, bf_hi(u.x) * sc), pack2bf(bf_lo(u.y) * sc, bf_hi(u.y) * sc),
+                            pack2bf(bf_lo(u.z) * sc, bf_hi(u.z) * sc), pack2bf(bf_lo(u.w) * sc, bf_hi(u.w) * sc)};
+  return __builtin_bit_cast(bf16x8_t, o);
+}
+
+// reductions over the 4 lane groups (lanes fr, fr+16, fr+32, fr+48) with the half-swap permutes: no LDS traffic
+__device__ __forceinline__ float group_max4(float v) {
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float group_sum4(float v) {
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 // ================================================================================ forward
-template <int HS>
-__global__ __launch_bounds__(NTHR) void flash_fwd_kernel(const grove_flash_attn_params p) {
+// min 2 waves per SIMD (<= 256 registers): keeps the MFMA accumulators in arch VGPRs — with the 512-register budget
+// hipcc parks them in AGPRs and pays ~350 v_accvgpr moves per tile around the softmax VALU work.
+template <int HS, bool REL>
+__global__ __launch_bounds__(NTHR, 2) void flash_fwd_kernel(const grove_flash_attn_params p) {
   using C = Cfg<HS>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;
   char* Vs = smem + C::TILEB;
-  unsigned short* kbin = (unsigned short*)(smem + 2 * C::TILEB);
+  char* Es = smem + 2 * C::TILEB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, g = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
@@ -149,8 +187,9 @@ __global__ __launch_bounds__(NTHR) void flash_fwd_kernel(const grove_flash_attn_
   const bf16_raw* Q = (const bf16_raw*)p.q + (int64_t)b * p.sq + h * HS;
   const bf16_raw* K = (const bf16_raw*)p.k + (int64_t)b * p.sk + h * HS;
   const bf16_raw* V = (const bf16_raw*)p.v + (int64_t)b * p.sv + h * HS;
-  const int nrel = p.rel ? p.rel_ld : 0;
-  const int nrk = (nrel + 31) >> 5;  // 32-bin k-steps of the bias MFMA (0 without rel)
+  const int nrel = REL ? p.rel_ld : 0;
+  const int nrk = REL ? (nrel + 31) >> 5 : 0;  // 32-bin k-steps of the bias MFMA (compile-time 0 without rel)
+  const float sc = p.alpha * 1.4426950408889634f;  // scores live in the exp2 domain
 
   bf16x8_t qf[2][C::KS];
   bf16x8_t relf[2][2];
@@ -158,15 +197,11 @@ __global__ __launch_bounds__(NTHR) void flash_fwd_kernel(const grove_flash_attn_
   for (int mi = 0; mi < 2; ++mi) {
     const int qi = min(q0 + mi * 16 + fr, p.Lq - 1);
 #pragma unroll
-    for (int ks = 0; ks < C::KS; ++ks) qf[mi][ks] = *(const bf16x8_t*)(Q + (int64_t)qi * p.ld_q + ks * 32 + g * 8);
-  }
-  if (p.rel) {
-    build_kbin(kbin, p.Lk, ((p.Lk + BKV - 1) / BKV) * BKV, p.rel_kw, tid);
+    for (int ks = 0; ks < C::KS; ++ks) qf[mi][ks] = scale_frag(*(const bf16x8_t*)(Q + (int64_t)qi * p.ld_q + ks * 32 + g * 8), sc);
+    if (nrk > 0) {
+      const bf16_raw* rrow = (const bf16_raw*)p.rel + ((int64_t)(b * p.H + h) * p.Lq + qi) * nrel;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-      const bf16_raw* rrow = (const bf16_raw*)p.rel + ((int64_t)(b * p.H + h) * p.Lq + min(q0 + mi * 16 + fr, p.Lq - 1)) * nrel;
-#pragma unroll
-      for (int k2 = 0; k2 < 2; ++k2) relf[mi][k2] = relfrag(rrow, k2 * 32 + g * 8, nrel);
+      for (int k2 = 0; k2 < 2; ++k2) relf[mi][k2] = scale_frag(relfrag(rrow, k2 * 32 + g * 8, nrel), sc);
     }
   }
   f32x4_t oacc[2][C::DT];
@@ -180,7 +215,6 @@ __global__ __launch_bounds__(NTHR) void flash_fwd_kernel(const grove_flash_attn_
   if (p.kv_len) kv_end = min(kv_end, p.kv_len[b]);
   int kv_lim = kv_end;
   if (p.causal) kv_lim = min(kv_lim, min(qblk + 127, p.Lq - 1) + (p.Lk - p.Lq) + 1);
-  const float sc = p.alpha * 1.4426950408889634f;  // exp2 domain
 
   TileRegs<HS> kreg, vreg;
   load_tile<HS>(kreg, K, p.ld_k, 0, p.Lk, tid);
@@ -189,6 +223,7 @@ __global__ __launch_bounds__(NTHR) void flash_fwd_kernel(const grove_flash_attn_
     __syncthreads();
     store_tile<HS>(Ks, kreg, tid);
     store_tile<HS>(Vs, vreg, tid);
+    if (nrk > 0) build_etile(Es, kv0, p.Lk, p.rel_kw, p.rel_kh, nrel, tid);
     __syncthreads();
     if (kv0 + BKV < kv_lim) {
       load_tile<HS>(kreg, K, p.ld_k, kv0 + BKV, p.Lk, tid);
@@ -217,15 +252,12 @@ __global__ __launch_bounds__(NTHR) void flash_fwd_kernel(const grove_flash_attn_
 #pragma unroll
           for (int mi = 0; mi < 2; ++mi) s[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[mi][ks], s[mi][ni], 0, 0, 0);
         }
-        if (nrk > 0) {
-          const unsigned kb = kbin[kv0 + ni * 16 + fr];
 #pragma unroll
-          for (int k2 = 0; k2 < 2; ++k2) {
-            if (k2 < nrk) {
-              const bf16x8_t ef = efrag_key(kb, k2 * 32 + g * 8, p.rel_kh);
+        for (int k2 = 0; k2 < 2; ++k2) {
+          if (k2 < nrk) {
+            const bf16x8_t ef = lds_row_frag(Es, ESB, ni * 16 + fr, k2 * 4 + g);
 #pragma unroll
-              for (int mi = 0; mi < 2; ++mi) s[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ef, relf[mi][k2], s[mi][ni], 0, 0, 0);
-            }
+            for (int mi = 0; mi < 2; ++mi) s[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ef, relf[mi][k2], s[mi][ni], 0, 0, 0);
           }
         }
       }
@@ -233,7 +265,6 @@ __global__ __launch_bounds__(NTHR) void flash_fwd_kernel(const grove_flash_attn_
     bf16x8_t pf[2][2];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
-      float mx = -INFINITY;
       if (need_mask) {
         const int qi = q0 + mi * 16 + fr;
         int lim = kv_end;
@@ -243,24 +274,15 @@ __global__ __launch_bounds__(NTHR) void flash_fwd_kernel(const grove_flash_attn_
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int j = kv0 + ni * 16 + g * 4 + r;
-            const float v = j < lim ? s[mi][ni][r] * sc : -INFINITY;
-            s[mi][ni][r] = v;
-            mx = fmaxf(mx, v);
-          }
-      } else {
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float v = s[mi][ni][r] * sc;
-            s[mi][ni][r] = v;
-            mx = fmaxf(mx, v);
+            if (j >= lim) s[mi][ni][r] = -INFINITY;
           }
       }
-      mx = group_max(mx);
+      float mx = fmaxf(fmaxf(s[mi][0][0], s[mi][0][1]), fmaxf(s[mi][0][2], s[mi][0][3]));
+#pragma unroll
+      for (int ni = 1; ni < 4; ++ni) mx = fmaxf(mx, fmaxf(fmaxf(s[mi][ni][0], s[mi][ni][1]), fmaxf(s[mi][ni][2], s[mi][ni][3])));
+      mx = group_max4(mx);
       const float m_new = fmaxf(m_run[mi], mx);
       const float m_use = m_new == -INFINITY ? 0.f : m_new;
-      const float corr = fast_exp2(m_run[mi] - m_use);  // m_run = -inf -> 0
       float rs = 0.f;
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni)
@@ -270,11 +292,15 @@ __global__ __launch_bounds__(NTHR) void flash_fwd_kernel(const grove_flash_attn_
           s[mi][ni][r] = e;
           rs += e;
         }
-      rs = group_sum(rs);
-      l_run[mi] = l_run[mi] * corr + rs;
-      m_run[mi] = m_new;
+      rs = group_sum4(rs);
+      if (__builtin_amdgcn_ballot_w64(m_new != m_run[mi]) != 0) {  // wave-uniform: rescale only when some row's max moved
+        const float corr = fast_exp2(m_run[mi] - m_use);            // m_run = -inf -> 0
+        l_run[mi] *= corr;
 #pragma unroll
-      for (int dt = 0; dt < C::DT; ++dt) oacc[mi][dt] *= corr;
+        for (int dt = 0; dt < C::DT; ++dt) oacc[mi][dt] *= corr;
+      }
+      l_run[mi] += rs;
+      m_run[mi] = m_new;
       pf[mi][0] = pack_frag(s[mi][0], s[mi][1]);
       pf[mi][1] = pack_frag(s[mi][2], s[mi][3]);
     }
@@ -336,7 +362,7 @@ __global__ __launch_bounds__(NTHR) void flash_delta_kernel(const grove_flash_att
 // ================================================================================ backward: dK, dV
 // block = 128 keys (wave = 32 keys, K/V fragments in registers); loops over 64-query tiles of Q and dO in LDS.
 template <int HS>
-__global__ __launch_bounds__(NTHR) void flash_bwd_dkv_kernel(const grove_flash_attn_params p) {
+__global__ __launch_bounds__(NTHR, (HS <= 96 ? 2 : 1)) void flash_bwd_dkv_kernel(const grove_flash_attn_params p) {
   using C = Cfg<HS>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Qs = smem;
@@ -510,16 +536,18 @@ __global__ __launch_bounds__(NTHR) void flash_bwd_dkv_kernel(const grove_flash_a
 }
 
 // ================================================================================ backward: dQ (+ d rel)
-template <int HS>
-__global__ __launch_bounds__(NTHR) void flash_bwd_dq_kernel(const grove_flash_attn_params p) {
+// The two 16-query tiles of a wave are processed one after the other per key tile (halves the live S / dP
+// accumulators) so that the kernel fits the 256-register budget that keeps MFMA results in arch VGPRs.
+template <int HS, bool REL>
+__global__ __launch_bounds__(NTHR, 2) void flash_bwd_dq_kernel(const grove_flash_attn_params p) {
   using C = Cfg<HS>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;
   char* Vs = smem + C::TILEB;
-  unsigned short* kbin = (unsigned short*)(smem + 2 * C::TILEB);
-  const int nrel = p.rel ? p.rel_ld : 0;
-  const int nrk = (nrel + 31) >> 5;
-  const int nbt = (nrel + 15) >> 4;  // 16-bin tiles of d rel
+  char* Es = smem + 2 * C::TILEB;
+  const int nrel = REL ? p.rel_ld : 0;
+  const int nrk = REL ? (nrel + 31) >> 5 : 0;
+  const int nbt = (REL && p.drel) ? (nrel + 15) >> 4 : 0;  // 16-bin tiles of d rel
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, g = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
@@ -529,46 +557,38 @@ __global__ __launch_bounds__(NTHR) void flash_bwd_dq_kernel(const grove_flash_at
   const bf16_raw* K = (const bf16_raw*)p.k + (int64_t)b * p.sk + h * HS;
   const bf16_raw* V = (const bf16_raw*)p.v + (int64_t)b * p.sv + h * HS;
   const bf16_raw* dO = (const bf16_raw*)p.d_o + (int64_t)b * p.sdo + h * HS;
+  const float sc = p.alpha * 1.4426950408889634f;
 
   bf16x8_t qf[2][C::KS], dof[2][C::KS];
   bf16x8_t relf[2][2];
   f32x4_t drl[2][4];
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-    for (int bt = 0; bt < 4; ++bt) drl[mi][bt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  f32x4_t dq[2][C::DT];
   float lse2[2], del[2];
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi) {
     const int qi = min(q0 + mi * 16 + fr, p.Lq - 1);
 #pragma unroll
     for (int ks = 0; ks < C::KS; ++ks) {
-      qf[mi][ks] = *(const bf16x8_t*)(Q + (int64_t)qi * p.ld_q + ks * 32 + g * 8);
+      qf[mi][ks] = scale_frag(*(const bf16x8_t*)(Q + (int64_t)qi * p.ld_q + ks * 32 + g * 8), sc);
       dof[mi][ks] = *(const bf16x8_t*)(dO + (int64_t)qi * p.ld_do + ks * 32 + g * 8);
+    }
+    if (nrk > 0) {
+      const bf16_raw* rrow = (const bf16_raw*)p.rel + ((int64_t)(b * p.H + h) * p.Lq + qi) * nrel;
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) relf[mi][k2] = scale_frag(relfrag(rrow, k2 * 32 + g * 8, nrel), sc);
     }
     lse2[mi] = p.lse[(int64_t)(b * p.H + h) * p.Lq + qi] * 1.4426950408889634f;
     del[mi] = p.delta[(int64_t)(b * p.H + h) * p.Lq + qi];
-  }
-  if (p.rel) {
-    build_kbin(kbin, p.Lk, ((p.Lk + BKV - 1) / BKV) * BKV, p.rel_kw, tid);
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-      const bf16_raw* rrow = (const bf16_raw*)p.rel + ((int64_t)(b * p.H + h) * p.Lq + min(q0 + mi * 16 + fr, p.Lq - 1)) * nrel;
-#pragma unroll
-      for (int k2 = 0; k2 < 2; ++k2) relf[mi][k2] = relfrag(rrow, k2 * 32 + g * 8, nrel);
-    }
-  }
-  f32x4_t dq[2][C::DT];
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+    for (int bt = 0; bt < 4; ++bt) drl[mi][bt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int dt = 0; dt < C::DT; ++dt) dq[mi][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
 
   int kv_end = p.Lk;
   if (p.kv_len) kv_end = min(kv_end, p.kv_len[b]);
   int kv_lim = kv_end;
   if (p.causal) kv_lim = min(kv_lim, min(qblk + 127, p.Lq - 1) + (p.Lk - p.Lq) + 1);
-  const float sc = p.alpha * 1.4426950408889634f;
 
   TileRegs<HS> kreg, vreg;
   load_tile<HS>(kreg, K, p.ld_k, 0, p.Lk, tid);
@@ -577,6 +597,7 @@ __global__ __launch_bounds__(NTHR) void flash_bwd_dq_kernel(const grove_flash_at
     __syncthreads();
     store_tile<HS>(Ks, kreg, tid);
     store_tile<HS>(Vs, vreg, tid);
+    if (nrk > 0) build_etile(Es, kv0, p.Lk, p.rel_kw, p.rel_kh, nrel, tid);
     __syncthreads();
     if (kv0 + BKV < kv_lim) {
       load_tile<HS>(kreg, K, p.ld_k, kv0 + BKV, p.Lk, tid);
@@ -586,39 +607,29 @@ __global__ __launch_bounds__(NTHR) void flash_bwd_dq_kernel(const grove_flash_at
     if (p.causal) lim_hi = min(lim_hi, q0 + 31 + (p.Lk - p.Lq) + 1);
     if (q0 >= p.Lq || kv0 >= lim_hi) continue;  // wave-uniform: dead query wave / nothing visible in this key tile
     const int nv = min(4, (lim_hi - kv0 + 15) >> 4);
-    f32x4_t s[2][4], dp[2][4];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < 2; ++mi) {
+      f32x4_t s[4], dp[4];
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) { s[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dp[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+      for (int ni = 0; ni < 4; ++ni) { s[ni] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dp[ni] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      if (ni >= nv) continue;
+      for (int ni = 0; ni < 4; ++ni) {
+        if (ni >= nv) continue;
 #pragma unroll
-      for (int ks = 0; ks < C::KS; ++ks) {
-        const bf16x8_t ka = lds_row_frag(Ks, C::ROWB, ni * 16 + fr, ks * 4 + g);
-        const bf16x8_t va = lds_row_frag(Vs, C::ROWB, ni * 16 + fr, ks * 4 + g);
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-          s[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[mi][ks], s[mi][ni], 0, 0, 0);
-          dp[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, dof[mi][ks], dp[mi][ni], 0, 0, 0);
+        for (int ks = 0; ks < C::KS; ++ks) {
+          const bf16x8_t ka = lds_row_frag(Ks, C::ROWB, ni * 16 + fr, ks * 4 + g);
+          const bf16x8_t va = lds_row_frag(Vs, C::ROWB, ni * 16 + fr, ks * 4 + g);
+          s[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[mi][ks], s[ni], 0, 0, 0);
+          dp[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, dof[mi][ks], dp[ni], 0, 0, 0);
         }
-      }
-      if (nrk > 0) {
-        const unsigned kb = kbin[kv0 + ni * 16 + fr];
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
           if (k2 < nrk) {
-            const bf16x8_t ef = efrag_key(kb, k2 * 32 + g * 8, p.rel_kh);
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi) s[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ef, relf[mi][k2], s[mi][ni], 0, 0, 0);
+            const bf16x8_t ef = lds_row_frag(Es, ESB, ni * 16 + fr, k2 * 4 + g);
+            s[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ef, relf[mi][k2], s[ni], 0, 0, 0);
           }
         }
       }
-    }
-    bf16x8_t dsf[2][2];
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
       const int qi = q0 + mi * 16 + fr;
       int lim = kv_end;
       if (p.causal) lim = min(lim, qi + (p.Lk - p.Lq) + 1);
@@ -627,46 +638,25 @@ __global__ __launch_bounds__(NTHR) void flash_bwd_dq_kernel(const grove_flash_at
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int j = kv0 + ni * 16 + g * 4 + r;
-          const float v = s[mi][ni][r] * sc;
-          const float pr = j < lim ? fast_exp2(v - lse2[mi]) : 0.f;
-          s[mi][ni][r] = pr * (dp[mi][ni][r] - del[mi]) * p.alpha;
+          const float pr = j < lim ? fast_exp2(s[ni][r] - lse2[mi]) : 0.f;
+          s[ni][r] = pr * (dp[ni][r] - del[mi]) * p.alpha;
         }
-      dsf[mi][0] = pack_frag(s[mi][0], s[mi][1]);
-      dsf[mi][1] = pack_frag(s[mi][2], s[mi][3]);
-    }
-    // dQ^T[d][q] += sum_key K^T[d][key] dS^T[key][q]
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      if (s2 * 2 >= nv) continue;
-#pragma unroll
-      for (int dt = 0; dt < C::DT; ++dt) {
-        const bf16x8_t kt = lds_tr_frag(Ks, C::ROWB, s2 * 32, dt * 16, lane);
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) dq[mi][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, dsf[mi][s2], dq[mi][dt], 0, 0, 0);
-      }
-    }
-    // d rel^T[bin][q] += sum_key E[bin][key] dS^T[key][q]   (dsf carries alpha; divided out at the end)
-    if (p.drel) {
+      const bf16x8_t dsf0 = pack_frag(s[0], s[1]), dsf1 = pack_frag(s[2], s[3]);
+      // dQ^T[d][q] += sum_key K^T[d][key] dS^T[key][q];   d rel'^T[bin][q] += sum_key E^T[bin][key] dS^T[key][q]
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         if (s2 * 2 >= nv) continue;
-        unsigned kb8[8];
+        const bf16x8_t dsf = s2 == 0 ? dsf0 : dsf1;
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) kb8[jj] = kbin[kv0 + s2 * 32 + (jj < 4 ? 4 * g + jj : 16 + 4 * g + jj - 4)];
+        for (int dt = 0; dt < C::DT; ++dt) {
+          const bf16x8_t kt = lds_tr_frag(Ks, C::ROWB, s2 * 32, dt * 16, lane);
+          dq[mi][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, dsf, dq[mi][dt], 0, 0, 0);
+        }
 #pragma unroll
         for (int bt = 0; bt < 4; ++bt) {
           if (bt < nbt) {
-            const int bin = bt * 16 + fr;
-            typedef __attribute__((ext_vector_type(8))) short s16x8_t;
-            s16x8_t e;
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) {
-              const bool hit = bin < p.rel_kh ? ((int)(kb8[jj] & 0xff) == bin) : ((int)(kb8[jj] >> 8) == bin - p.rel_kh);
-              e[jj] = hit ? (short)0x3F80 : (short)0;
-            }
-            const bf16x8_t ea = __builtin_bit_cast(bf16x8_t, e);
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi) drl[mi][bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ea, dsf[mi][s2], drl[mi][bt], 0, 0, 0);
+            const bf16x8_t et = lds_tr_frag(Es, ESB, s2 * 32, bt * 16, lane);
+            drl[mi][bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(et, dsf, drl[mi][bt], 0, 0, 0);
           }
         }
       }
@@ -682,13 +672,8 @@ __global__ __launch_bounds__(NTHR) void flash_bwd_dq_kernel(const grove_flash_at
       const f32x4_t o = dq[mi][dt];
       *(u32x2_t*)(DQ + (int64_t)qi * p.ld_dq + dt * 16 + g * 4) = u32x2_t{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
     }
-  }
-  if (p.drel) {
-    // lane holds d rel'^T[bin = bt*16 + 4g + r][q = fr]; rel' = rel / alpha, and dsf carried alpha: no rescale
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-      const int qi = q0 + mi * 16 + fr;
-      if (qi >= p.Lq) continue;
+    if (REL && p.drel) {
+      // lane holds d rel'^T[bin = bt*16 + 4g + r][q = fr]; rel' = rel / alpha, and dS carried alpha: no rescale
       bf16_raw* DR = (bf16_raw*)p.drel + ((int64_t)(b * p.H + h) * p.Lq + qi) * nrel;
 #pragma unroll
       for (int bt = 0; bt < 4; ++bt) {
@@ -713,7 +698,7 @@ int check(const grove_flash_attn_params* p, const char* name) {
 }
 
 template <int HS>
-size_t lds_fwd(const grove_flash_attn_params* p) { return 2 * Cfg<HS>::TILEB + (p->rel ? (size_t)(((p->Lk + BKV - 1) / BKV) * BKV) * 2 : 0); }
+size_t lds_fwd(const grove_flash_attn_params* p) { return 2 * Cfg<HS>::TILEB + (p->rel ? (size_t)ETILEB : 0); }
 
 #define DISPATCH_HS(p, FN)                 \
   switch ((p)->hs) {                       \
@@ -734,8 +719,13 @@ extern "C" int grove_flash_attn_fwd(const grove_flash_attn_params* p, void* stre
 #define FWD(HS)                                                                                           \
   {                                                                                                       \
     const size_t lds = lds_fwd<HS>(p);                                                                    \
-    hipFuncSetAttribute((const void*)flash_fwd_kernel<HS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    hipLaunchKernelGGL((flash_fwd_kernel<HS>), grid, dim3(NTHR), lds, s, *p);                              \
+    if (p->rel) {                                                                                         \
+      hipFuncSetAttribute((const void*)flash_fwd_kernel<HS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      hipLaunchKernelGGL((flash_fwd_kernel<HS, true>), grid, dim3(NTHR), lds, s, *p);                      \
+    } else {                                                                                              \
+      hipFuncSetAttribute((const void*)flash_fwd_kernel<HS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      hipLaunchKernelGGL((flash_fwd_kernel<HS, false>), grid, dim3(NTHR), lds, s, *p);                     \
+    }                                                                                                     \
   }
   DISPATCH_HS(p, FWD)
 #undef FWD
@@ -758,9 +748,14 @@ extern "C" int grove_flash_attn_bwd(const grove_flash_attn_params* p, void* stre
     const size_t l1 = 2 * Cfg<HS>::TILEB + 2 * BKV * 4 + (nrel ? (size_t)BKV * (64 * 2 + 32) : 0);          \
     const size_t l2 = lds_fwd<HS>(p);                                                                       \
     hipFuncSetAttribute((const void*)flash_bwd_dkv_kernel<HS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1); \
-    hipFuncSetAttribute((const void*)flash_bwd_dq_kernel<HS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);  \
     hipLaunchKernelGGL((flash_bwd_dkv_kernel<HS>), gk, dim3(NTHR), l1, s, *p);                              \
-    hipLaunchKernelGGL((flash_bwd_dq_kernel<HS>), gq, dim3(NTHR), l2, s, *p);                               \
+    if (p->rel) {                                                                                          \
+      hipFuncSetAttribute((const void*)flash_bwd_dq_kernel<HS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);  \
+      hipLaunchKernelGGL((flash_bwd_dq_kernel<HS, true>), gq, dim3(NTHR), l2, s, *p);                       \
+    } else {                                                                                               \
+      hipFuncSetAttribute((const void*)flash_bwd_dq_kernel<HS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2); \
+      hipLaunchKernelGGL((flash_bwd_dq_kernel<HS, false>), gq, dim3(NTHR), l2, s, *p);                      \
+    }                                                                                                      \
   }
   DISPATCH_HS(p, BWD)
 #undef BWD

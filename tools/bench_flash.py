@@ -1,0 +1,38 @@
+"""Flash-attention micro-benchmark on the four attention shapes of the GROVE step (random data)."""
+import sys
+import torch
+sys.path.insert(0, ".")
+from grove_amd import ops
+dev = torch.device("cuda:0")
+bf = torch.bfloat16
+cases = [("sam window", 288, 16, 196, 96, 80, False, (14, 14)), ("sam global", 32, 16, 1024, 96, 80, False, (32, 32)),
+         ("llama", 4, 32, 703, 128, 128, True, None), ("clip", 32, 16, 577, 64, 64, False, None)]
+for name, B, H, L, hs, hd, causal, rel_hw in cases:
+    qkv = torch.zeros(B * L, 3 * H * hs, device=dev)
+    qkv.view(B * L, 3, H, hs)[..., :hd] = torch.randn(B * L, 3, H, hd, device=dev)
+    qkv = qkv.to(bf)
+    do = torch.randn(B * L, H * hs, device=dev).to(bf)
+    rel, arg = None, (0, 0)
+    if rel_hw:
+        khp = (rel_hw[0] + 15) // 16 * 16
+        rel = torch.randn(B * H, L, 2 * khp, device=dev).to(bf)
+        arg = (khp, rel_hw[1])
+    alpha = hd ** -0.5
+    dq = torch.empty_like(qkv)
+    def fwd():
+        return ops.flash_attn(qkv, B, L, H, hs, 0, H * hs, 2 * H * hs, alpha, causal=causal, rel=rel, rel_hw=arg, want_lse=True)
+    out, lse = fwd()
+    def bwd():
+        ops.flash_attn_bwd(qkv, out, do, lse, dq, B, L, H, hs, 0, H * hs, 2 * H * hs, alpha, causal=causal, rel=rel, rel_hw=arg, want_drel=rel is not None)
+    res = []
+    for fn, mult in ((fwd, 4), (bwd, 10)):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        flops = mult * B * H * L * L * hd * (0.5 if causal else 1.0)
+        res.append((ms, flops / ms / 1e9))
+    print(f"{name:11s} B={B} H={H} L={L} hs={hs}: fwd {res[0][0]:.3f} ms {res[0][1]:6.1f} TF/s | bwd {res[1][0]:.3f} ms {res[1][1]:6.1f} TF/s", flush=True)
