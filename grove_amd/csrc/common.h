@@ -20,7 +20,10 @@ __device__ __forceinline__ bf16_raw f2bf(float f) {
   return __builtin_bit_cast(bf16_raw, b);
 }
 __device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
-  return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+  // one v_cvt_pk_bf16_f32 for the pair (two scalar casts + shift/or otherwise)
+  typedef __attribute__((ext_vector_type(2))) float f32x2_t_;
+  const bf16x2_t v = __builtin_convertvector(f32x2_t_{lo, hi}, bf16x2_t);
+  return __builtin_bit_cast(unsigned, v);
 }
 __device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }

@@ -172,7 +172,7 @@ __device__ __forceinline__ float group_sum4(float v) {
 // ================================================================================ forward
 // min 2 waves per SIMD (<= 256 registers): keeps the MFMA accumulators in arch VGPRs — with the 512-register budget
 // hipcc parks them in AGPRs and pays ~350 v_accvgpr moves per tile around the softmax VALU work.
-template <int HS, bool REL>
+template <int HS, int NRK>
 __global__ __launch_bounds__(NTHR, 2) void flash_fwd_kernel(const grove_flash_attn_params p) {
   using C = Cfg<HS>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -187,12 +187,13 @@ __global__ __launch_bounds__(NTHR, 2) void flash_fwd_kernel(const grove_flash_at
   const bf16_raw* Q = (const bf16_raw*)p.q + (int64_t)b * p.sq + h * HS;
   const bf16_raw* K = (const bf16_raw*)p.k + (int64_t)b * p.sk + h * HS;
   const bf16_raw* V = (const bf16_raw*)p.v + (int64_t)b * p.sv + h * HS;
+  constexpr bool REL = NRK > 0;
   const int nrel = REL ? p.rel_ld : 0;
-  const int nrk = REL ? (nrel + 31) >> 5 : 0;  // 32-bin k-steps of the bias MFMA (compile-time 0 without rel)
+  constexpr int nrk = NRK;  // 32-bin k-steps of the bias MFMA (compile time: 0 without rel, 1 for rel_ld <= 32, else 2)
   const float sc = p.alpha * 1.4426950408889634f;  // scores live in the exp2 domain
 
   bf16x8_t qf[2][C::KS];
-  bf16x8_t relf[2][2];
+  bf16x8_t relf[2][NRK > 0 ? NRK : 1];
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi) {
     const int qi = min(q0 + mi * 16 + fr, p.Lq - 1);
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(NTHR, 2) void flash_fwd_kernel(const grove_flash_at
     if (nrk > 0) {
       const bf16_raw* rrow = (const bf16_raw*)p.rel + ((int64_t)(b * p.H + h) * p.Lq + qi) * nrel;
 #pragma unroll
-      for (int k2 = 0; k2 < 2; ++k2) relf[mi][k2] = scale_frag(relfrag(rrow, k2 * 32 + g * 8, nrel), sc);
+      for (int k2 = 0; k2 < NRK; ++k2) relf[mi][k2] = scale_frag(relfrag(rrow, k2 * 32 + g * 8, nrel), sc);
     }
   }
   f32x4_t oacc[2][C::DT];
@@ -253,12 +254,10 @@ __global__ __launch_bounds__(NTHR, 2) void flash_fwd_kernel(const grove_flash_at
           for (int mi = 0; mi < 2; ++mi) s[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[mi][ks], s[mi][ni], 0, 0, 0);
         }
 #pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2) {
-          if (k2 < nrk) {
-            const bf16x8_t ef = lds_row_frag(Es, ESB, ni * 16 + fr, k2 * 4 + g);
+        for (int k2 = 0; k2 < NRK; ++k2) {
+          const bf16x8_t ef = lds_row_frag(Es, ESB, ni * 16 + fr, k2 * 4 + g);
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) s[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ef, relf[mi][k2], s[mi][ni], 0, 0, 0);
-          }
+          for (int mi = 0; mi < 2; ++mi) s[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ef, relf[mi][k2], s[mi][ni], 0, 0, 0);
         }
       }
     }
@@ -361,7 +360,7 @@ __global__ __launch_bounds__(NTHR) void flash_delta_kernel(const grove_flash_att
 
 // ================================================================================ backward: dK, dV
 // block = 128 keys (wave = 32 keys, K/V fragments in registers); loops over 64-query tiles of Q and dO in LDS.
-template <int HS>
+template <int HS, int NRK>
 __global__ __launch_bounds__(NTHR, (HS <= 96 ? 2 : 1)) void flash_bwd_dkv_kernel(const grove_flash_attn_params p) {
   using C = Cfg<HS>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -382,27 +381,27 @@ __global__ __launch_bounds__(NTHR, (HS <= 96 ? 2 : 1)) void flash_bwd_dkv_kernel
   const bf16_raw* dO = (const bf16_raw*)p.d_o + (int64_t)b * p.sdo + h * HS;
   const float* LSE = p.lse + (int64_t)(b * p.H + h) * p.Lq;
   const float* DEL = p.delta + (int64_t)(b * p.H + h) * p.Lq;
-  const int nrel = p.rel ? p.rel_ld : 0;
-  const bf16_raw* REL = p.rel ? (const bf16_raw*)p.rel + ((int64_t)(b * p.H + h) * p.Lq) * nrel : nullptr;
-  const int nrk = (nrel + 31) >> 5;
+  const int nrel = NRK > 0 ? p.rel_ld : 0;
+  const bf16_raw* REL = NRK > 0 ? (const bf16_raw*)p.rel + ((int64_t)(b * p.H + h) * p.Lq) * nrel : nullptr;
+  constexpr int nrk = NRK;
 
   // K, V fragments of this wave's 32 keys as MFMA B operands: B[k = d][col = key = fr]
   bf16x8_t kf[2][C::KS], vf[2][C::KS];
   // indicator fragments E^T[bin][key] of this wave's keys (constant for the whole kernel)
-  bf16x8_t ekf[2][2];
+  bf16x8_t ekf[2][NRK > 0 ? NRK : 1];
 #pragma unroll
   for (int nj = 0; nj < 2; ++nj) {
     const int kj = k0 + nj * 16 + fr;
     const unsigned kb = (REL && kj < p.Lk) ? (unsigned)((kj / p.rel_kw) | ((kj % p.rel_kw) << 8)) : 0xFFFFu;
 #pragma unroll
-    for (int k2 = 0; k2 < 2; ++k2) ekf[nj][k2] = efrag_key(kb, k2 * 32 + g * 8, p.rel_kh);
+    for (int k2 = 0; k2 < NRK; ++k2) ekf[nj][k2] = efrag_key(kb, k2 * 32 + g * 8, p.rel_kh);
   }
 #pragma unroll
   for (int nj = 0; nj < 2; ++nj) {
     const int kj = min(k0 + nj * 16 + fr, p.Lk - 1);
 #pragma unroll
     for (int ks = 0; ks < C::KS; ++ks) {
-      kf[nj][ks] = *(const bf16x8_t*)(K + (int64_t)kj * p.ld_k + ks * 32 + g * 8);
+      kf[nj][ks] = scale_frag(*(const bf16x8_t*)(K + (int64_t)kj * p.ld_k + ks * 32 + g * 8), p.alpha * 1.4426950408889634f);
       vf[nj][ks] = *(const bf16x8_t*)(V + (int64_t)kj * p.ld_v + ks * 32 + g * 8);
     }
   }
@@ -420,16 +419,25 @@ __global__ __launch_bounds__(NTHR, (HS <= 96 ? 2 : 1)) void flash_bwd_dkv_kernel
   qstart = (qstart / BKV) * BKV;
   const float sc = p.alpha * 1.4426950408889634f;
 
-  TileRegs<HS> qreg, doreg;
-  load_tile<HS>(qreg, Q, p.ld_q, qstart, p.Lq, tid);
-  load_tile<HS>(doreg, dO, p.ld_do, qstart, p.Lq, tid);
+  // register prefetch of the next Q / dO tile only where the 256-register budget has room for it
+  constexpr bool PREFETCH = HS <= 64;
+  TileRegs<PREFETCH ? HS : 32> qreg, doreg;
+  if constexpr (PREFETCH) {
+    load_tile<HS>(qreg, Q, p.ld_q, qstart, p.Lq, tid);
+    load_tile<HS>(doreg, dO, p.ld_do, qstart, p.Lq, tid);
+  }
   for (int qt0 = qstart; qt0 < p.Lq; qt0 += BKV) {
     __syncthreads();
-    store_tile<HS>(Qs, qreg, tid);
-    store_tile<HS>(dOs, doreg, tid);
-    if (qt0 + BKV < p.Lq) {
-      load_tile<HS>(qreg, Q, p.ld_q, qt0 + BKV, p.Lq, tid);
-      load_tile<HS>(doreg, dO, p.ld_do, qt0 + BKV, p.Lq, tid);
+    if constexpr (PREFETCH) {
+      store_tile<HS>(Qs, qreg, tid);
+      store_tile<HS>(dOs, doreg, tid);
+      if (qt0 + BKV < p.Lq) {
+        load_tile<HS>(qreg, Q, p.ld_q, qt0 + BKV, p.Lq, tid);
+        load_tile<HS>(doreg, dO, p.ld_do, qt0 + BKV, p.Lq, tid);
+      }
+    } else {
+      stage_tile<HS>(Qs, Q, p.ld_q, qt0, p.Lq, tid);
+      stage_tile<HS>(dOs, dO, p.ld_do, qt0, p.Lq, tid);
     }
     if (tid < BKV) {
       const int qi = min(qt0 + tid, p.Lq - 1);
@@ -441,7 +449,7 @@ __global__ __launch_bounds__(NTHR, (HS <= 96 ? 2 : 1)) void flash_bwd_dkv_kernel
         const int r = t >> 3, c = t & 7;
         u32x4_t v = u32x4_t{0u, 0u, 0u, 0u};
         if (c * 8 < nrel) v = *(const u32x4_t*)(REL + (int64_t)min(qt0 + r, p.Lq - 1) * nrel + c * 8);
-        *(u32x4_t*)(relq + r * RELB + c * 16) = v;
+        *(bf16x8_t*)(relq + r * RELB + c * 16) = scale_frag(__builtin_bit_cast(bf16x8_t, v), sc);
       }
     }
     __syncthreads();
@@ -470,19 +478,23 @@ __global__ __launch_bounds__(NTHR, (HS <= 96 ? 2 : 1)) void flash_bwd_dkv_kernel
             pacc[qi_][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[nj][ks], pacc[qi_][nj], 0, 0, 0);
           }
         }
-      if (nrk > 0) {
 #pragma unroll
-        for (int qi_ = 0; qi_ < 2; ++qi_)
+      for (int qi_ = 0; qi_ < 2; ++qi_)
 #pragma unroll
-          for (int k2 = 0; k2 < 2; ++k2) {
-            if (k2 < nrk) {
-              const bf16x8_t ra = lds_row_frag(relq, RELB, (s2 * 2 + qi_) * 16 + fr, k2 * 4 + g);
+        for (int k2 = 0; k2 < NRK; ++k2) {
+          const bf16x8_t ra = lds_row_frag(relq, RELB, (s2 * 2 + qi_) * 16 + fr, k2 * 4 + g);
 #pragma unroll
-              for (int nj = 0; nj < 2; ++nj) sacc[qi_][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ra, ekf[nj][k2], sacc[qi_][nj], 0, 0, 0);
-            }
-          }
-      }
+          for (int nj = 0; nj < 2; ++nj) sacc[qi_][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ra, ekf[nj][k2], sacc[qi_][nj], 0, 0, 0);
+        }
       // P and dS (lane: key = fr of tile nj; rows q = 4g + r of tile qi_)
+      f32x4_t lse4[2], del4[2];
+#pragma unroll
+      for (int qi_ = 0; qi_ < 2; ++qi_) {
+        lse4[qi_] = *(const f32x4_t*)(lse_s + (s2 * 2 + qi_) * 16 + g * 4);
+        del4[qi_] = *(const f32x4_t*)(del_s + (s2 * 2 + qi_) * 16 + g * 4);
+      }
+      const int qlo = qt0 + s2 * 32;
+      const bool need_mask = (qlo + 31 >= p.Lq) || (k0 + 31 >= kv_end) || (p.causal && k0 + 31 > qlo + (p.Lk - p.Lq));
       bf16x8_t pfr[2], dsfr[2];
 #pragma unroll
       for (int nj = 0; nj < 2; ++nj) {
@@ -492,15 +504,15 @@ __global__ __launch_bounds__(NTHR, (HS <= 96 ? 2 : 1)) void flash_bwd_dkv_kernel
         for (int qi_ = 0; qi_ < 2; ++qi_)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int ql = (s2 * 2 + qi_) * 16 + g * 4 + r;
-            const int qi = qt0 + ql;
-            int lim = kv_end;
-            if (p.causal) lim = min(lim, qi + (p.Lk - p.Lq) + 1);
-            const float v = sacc[qi_][nj][r] * sc;
-            const bool ok = (j < lim) && (qi < p.Lq);
-            const float pr = ok ? fast_exp2(v - lse_s[ql]) : 0.f;
+            float pr = fast_exp2(sacc[qi_][nj][r] - lse4[qi_][r]);
+            if (need_mask) {
+              const int qi = qlo + qi_ * 16 + g * 4 + r;
+              int lim = kv_end;
+              if (p.causal) lim = min(lim, qi + (p.Lk - p.Lq) + 1);
+              if (!((j < lim) && (qi < p.Lq))) pr = 0.f;
+            }
             pp[qi_][r] = pr;
-            dd[qi_][r] = pr * (pacc[qi_][nj][r] - del_s[ql]) * p.alpha;
+            dd[qi_][r] = pr * (pacc[qi_][nj][r] - del4[qi_][r]) * p.alpha;
           }
         pfr[nj] = pack_frag(pp[0], pp[1]);
         dsfr[nj] = pack_frag(dd[0], dd[1]);
@@ -538,16 +550,17 @@ __global__ __launch_bounds__(NTHR, (HS <= 96 ? 2 : 1)) void flash_bwd_dkv_kernel
 // ================================================================================ backward: dQ (+ d rel)
 // The two 16-query tiles of a wave are processed one after the other per key tile (halves the live S / dP
 // accumulators) so that the kernel fits the 256-register budget that keeps MFMA results in arch VGPRs.
-template <int HS, bool REL>
+template <int HS, int NRK>
 __global__ __launch_bounds__(NTHR, 2) void flash_bwd_dq_kernel(const grove_flash_attn_params p) {
   using C = Cfg<HS>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;
   char* Vs = smem + C::TILEB;
   char* Es = smem + 2 * C::TILEB;
+  constexpr bool REL = NRK > 0;
   const int nrel = REL ? p.rel_ld : 0;
-  const int nrk = REL ? (nrel + 31) >> 5 : 0;
-  const int nbt = (REL && p.drel) ? (nrel + 15) >> 4 : 0;  // 16-bin tiles of d rel
+  constexpr int nrk = NRK;
+  const int nbt = (REL && p.drel) ? (nrel + 15) >> 4 : 0;  // 16-bin tiles of d rel (<= 2 * NRK)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, g = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
@@ -560,8 +573,9 @@ __global__ __launch_bounds__(NTHR, 2) void flash_bwd_dq_kernel(const grove_flash
   const float sc = p.alpha * 1.4426950408889634f;
 
   bf16x8_t qf[2][C::KS], dof[2][C::KS];
-  bf16x8_t relf[2][2];
-  f32x4_t drl[2][4];
+  bf16x8_t relf[2][NRK > 0 ? NRK : 1];
+  constexpr int NBT = NRK > 0 ? 2 * NRK : 1;
+  f32x4_t drl[2][NBT];
   f32x4_t dq[2][C::DT];
   float lse2[2], del[2];
 #pragma unroll
@@ -575,12 +589,12 @@ __global__ __launch_bounds__(NTHR, 2) void flash_bwd_dq_kernel(const grove_flash
     if (nrk > 0) {
       const bf16_raw* rrow = (const bf16_raw*)p.rel + ((int64_t)(b * p.H + h) * p.Lq + qi) * nrel;
 #pragma unroll
-      for (int k2 = 0; k2 < 2; ++k2) relf[mi][k2] = scale_frag(relfrag(rrow, k2 * 32 + g * 8, nrel), sc);
+      for (int k2 = 0; k2 < NRK; ++k2) relf[mi][k2] = scale_frag(relfrag(rrow, k2 * 32 + g * 8, nrel), sc);
     }
     lse2[mi] = p.lse[(int64_t)(b * p.H + h) * p.Lq + qi] * 1.4426950408889634f;
     del[mi] = p.delta[(int64_t)(b * p.H + h) * p.Lq + qi];
 #pragma unroll
-    for (int bt = 0; bt < 4; ++bt) drl[mi][bt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int bt = 0; bt < NBT; ++bt) drl[mi][bt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int dt = 0; dt < C::DT; ++dt) dq[mi][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   }
@@ -590,18 +604,29 @@ __global__ __launch_bounds__(NTHR, 2) void flash_bwd_dq_kernel(const grove_flash
   int kv_lim = kv_end;
   if (p.causal) kv_lim = min(kv_lim, min(qblk + 127, p.Lq - 1) + (p.Lk - p.Lq) + 1);
 
-  TileRegs<HS> kreg, vreg;
-  load_tile<HS>(kreg, K, p.ld_k, 0, p.Lk, tid);
-  load_tile<HS>(vreg, V, p.ld_v, 0, p.Lk, tid);
+  // register prefetch of the next K / V tile only where the 256-register budget has room for it
+  constexpr bool PREFETCH = !(HS >= 96 && NRK > 0);
+  TileRegs<PREFETCH ? HS : 32> kreg, vreg;
+  if constexpr (PREFETCH) {
+    load_tile<HS>(kreg, K, p.ld_k, 0, p.Lk, tid);
+    load_tile<HS>(vreg, V, p.ld_v, 0, p.Lk, tid);
+  }
   for (int kv0 = 0; kv0 < kv_lim; kv0 += BKV) {
     __syncthreads();
-    store_tile<HS>(Ks, kreg, tid);
-    store_tile<HS>(Vs, vreg, tid);
+    if constexpr (PREFETCH) {
+      store_tile<HS>(Ks, kreg, tid);
+      store_tile<HS>(Vs, vreg, tid);
+    } else {
+      stage_tile<HS>(Ks, K, p.ld_k, kv0, p.Lk, tid);
+      stage_tile<HS>(Vs, V, p.ld_v, kv0, p.Lk, tid);
+    }
     if (nrk > 0) build_etile(Es, kv0, p.Lk, p.rel_kw, p.rel_kh, nrel, tid);
     __syncthreads();
-    if (kv0 + BKV < kv_lim) {
-      load_tile<HS>(kreg, K, p.ld_k, kv0 + BKV, p.Lk, tid);
-      load_tile<HS>(vreg, V, p.ld_v, kv0 + BKV, p.Lk, tid);
+    if constexpr (PREFETCH) {
+      if (kv0 + BKV < kv_lim) {
+        load_tile<HS>(kreg, K, p.ld_k, kv0 + BKV, p.Lk, tid);
+        load_tile<HS>(vreg, V, p.ld_v, kv0 + BKV, p.Lk, tid);
+      }
     }
     int lim_hi = kv_end;
     if (p.causal) lim_hi = min(lim_hi, q0 + 31 + (p.Lk - p.Lq) + 1);
@@ -623,11 +648,9 @@ __global__ __launch_bounds__(NTHR, 2) void flash_bwd_dq_kernel(const grove_flash
           dp[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, dof[mi][ks], dp[ni], 0, 0, 0);
         }
 #pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2) {
-          if (k2 < nrk) {
-            const bf16x8_t ef = lds_row_frag(Es, ESB, ni * 16 + fr, k2 * 4 + g);
-            s[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ef, relf[mi][k2], s[ni], 0, 0, 0);
-          }
+        for (int k2 = 0; k2 < NRK; ++k2) {
+          const bf16x8_t ef = lds_row_frag(Es, ESB, ni * 16 + fr, k2 * 4 + g);
+          s[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ef, relf[mi][k2], s[ni], 0, 0, 0);
         }
       }
       const int qi = q0 + mi * 16 + fr;
@@ -653,7 +676,7 @@ __global__ __launch_bounds__(NTHR, 2) void flash_bwd_dq_kernel(const grove_flash
           dq[mi][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, dsf, dq[mi][dt], 0, 0, 0);
         }
 #pragma unroll
-        for (int bt = 0; bt < 4; ++bt) {
+        for (int bt = 0; bt < NBT; ++bt) {
           if (bt < nbt) {
             const bf16x8_t et = lds_tr_frag(Es, ESB, s2 * 32, bt * 16, lane);
             drl[mi][bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(et, dsf, drl[mi][bt], 0, 0, 0);
@@ -676,7 +699,7 @@ __global__ __launch_bounds__(NTHR, 2) void flash_bwd_dq_kernel(const grove_flash
       // lane holds d rel'^T[bin = bt*16 + 4g + r][q = fr]; rel' = rel / alpha, and dS carried alpha: no rescale
       bf16_raw* DR = (bf16_raw*)p.drel + ((int64_t)(b * p.H + h) * p.Lq + qi) * nrel;
 #pragma unroll
-      for (int bt = 0; bt < 4; ++bt) {
+      for (int bt = 0; bt < NBT; ++bt) {
         if (bt < nbt) {
           const f32x4_t o = drl[mi][bt];
           *(u32x2_t*)(DR + bt * 16 + g * 4) = u32x2_t{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
@@ -716,19 +739,19 @@ extern "C" int grove_flash_attn_fwd(const grove_flash_attn_params* p, void* stre
   GROVE_CHECK(p->o, GROVE_E_SHAPE, "flash_attn_fwd: o required");
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((p->Lq + 127) / 128, p->H, p->B);
-#define FWD(HS)                                                                                           \
-  {                                                                                                       \
-    const size_t lds = lds_fwd<HS>(p);                                                                    \
-    if (p->rel) {                                                                                         \
-      hipFuncSetAttribute((const void*)flash_fwd_kernel<HS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      hipLaunchKernelGGL((flash_fwd_kernel<HS, true>), grid, dim3(NTHR), lds, s, *p);                      \
-    } else {                                                                                              \
-      hipFuncSetAttribute((const void*)flash_fwd_kernel<HS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      hipLaunchKernelGGL((flash_fwd_kernel<HS, false>), grid, dim3(NTHR), lds, s, *p);                     \
-    }                                                                                                     \
+#define FWD_L(HS, NRK)                                                                                     \
+  {                                                                                                        \
+    hipFuncSetAttribute((const void*)flash_fwd_kernel<HS, NRK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((flash_fwd_kernel<HS, NRK>), grid, dim3(NTHR), lds, s, *p);                          \
+  }
+#define FWD(HS)                                                                                            \
+  {                                                                                                        \
+    const size_t lds = lds_fwd<HS>(p);                                                                     \
+    if (!p->rel) FWD_L(HS, 0) else if (p->rel_ld <= 32) FWD_L(HS, 1) else FWD_L(HS, 2)                      \
   }
   DISPATCH_HS(p, FWD)
 #undef FWD
+#undef FWD_L
   GROVE_LAUNCH_CHECK();
   return GROVE_OK;
 }
@@ -743,22 +766,22 @@ extern "C" int grove_flash_attn_bwd(const grove_flash_attn_params* p, void* stre
   hipLaunchKernelGGL(flash_delta_kernel, dim3((unsigned)((nrows + 15) / 16)), dim3(NTHR), 0, s, *p);
   const int nrel = p->rel ? p->rel_ld : 0;
   dim3 gk((p->Lk + 127) / 128, p->H, p->B), gq((p->Lq + 127) / 128, p->H, p->B);
+#define BWD_L(HS, NRK)                                                                                     \
+  {                                                                                                        \
+    hipFuncSetAttribute((const void*)flash_bwd_dkv_kernel<HS, NRK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1); \
+    hipFuncSetAttribute((const void*)flash_bwd_dq_kernel<HS, NRK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);  \
+    hipLaunchKernelGGL((flash_bwd_dkv_kernel<HS, NRK>), gk, dim3(NTHR), l1, s, *p);                         \
+    hipLaunchKernelGGL((flash_bwd_dq_kernel<HS, NRK>), gq, dim3(NTHR), l2, s, *p);                          \
+  }
 #define BWD(HS)                                                                                            \
   {                                                                                                        \
     const size_t l1 = 2 * Cfg<HS>::TILEB + 2 * BKV * 4 + (nrel ? (size_t)BKV * (64 * 2 + 32) : 0);          \
     const size_t l2 = lds_fwd<HS>(p);                                                                       \
-    hipFuncSetAttribute((const void*)flash_bwd_dkv_kernel<HS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1); \
-    hipLaunchKernelGGL((flash_bwd_dkv_kernel<HS>), gk, dim3(NTHR), l1, s, *p);                              \
-    if (p->rel) {                                                                                          \
-      hipFuncSetAttribute((const void*)flash_bwd_dq_kernel<HS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);  \
-      hipLaunchKernelGGL((flash_bwd_dq_kernel<HS, true>), gq, dim3(NTHR), l2, s, *p);                       \
-    } else {                                                                                               \
-      hipFuncSetAttribute((const void*)flash_bwd_dq_kernel<HS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2); \
-      hipLaunchKernelGGL((flash_bwd_dq_kernel<HS, false>), gq, dim3(NTHR), l2, s, *p);                      \
-    }                                                                                                      \
+    if (!p->rel) BWD_L(HS, 0) else if (p->rel_ld <= 32) BWD_L(HS, 1) else BWD_L(HS, 2)                       \
   }
   DISPATCH_HS(p, BWD)
 #undef BWD
+#undef BWD_L
   GROVE_LAUNCH_CHECK();
   return GROVE_OK;
 }
