@@ -57,6 +57,111 @@ __device__ __forceinline__ TileCoord map_block(int tiles_m, int tiles_n) {
   return t;
 }
 
+// Fused epilogue shared by all NT kernels. acc[i][j] holds D[n = nw0 + j*16 + 4*fq + e][m = mw0 + i*16 + fr] (contiguous form).
+// MG / NG: fragments per contiguous group and MGS / NGS: the stride between groups (the pipelined 256 x 256 kernel gives
+// each wave two row groups and two column groups, one per staged half-tile).
+template <int MI, int NJ, int MG = MI, int MGS = 0, int NG = NJ, int NGS = 0>
+__device__ __forceinline__ void gemm_epilogue(const grove_gemm_params& p, const int vec_ok, f32x4_t (&acc)[MI][NJ], const int mw0,
+                                              const int nw0, const int fr, const int fq, const int b1, const int b2, const int nsplit) {
+  float scale = 1.f;
+  if (p.scale_ptr) {
+    scale = *p.scale_ptr;
+    if (p.scale_tanh) scale = tanhf(scale);
+  }
+  const bf16_raw* __restrict__ bias = (const bf16_raw*)p.bias;
+  const int64_t c_boff = (int64_t)b1 * p.sC1 + (int64_t)b2 * p.sC2;
+  const int64_t r_boff = (int64_t)b1 * p.sR1 + (int64_t)b2 * p.sR2;
+  const bool vec4 = vec_ok && ((p.ldc & 3) == 0) && (!p.residual || (p.ldr & 3) == 0);
+
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int m = mw0 + (i / MG) * MGS + (i % MG) * 16 + fr;
+    if (m >= p.M) continue;
+    int crow = m;
+    if (p.c_idx) {
+      crow = p.c_idx[m];
+      if (crow < 0) continue;
+    }
+    int rrow = crow;
+    if (p.r_idx) rrow = p.r_idx[m];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int n = nw0 + (j / NG) * NGS + (j % NG) * 16 + fq * 4;
+      if (n >= p.N) continue;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] * p.alpha;
+      const bool full = vec4 && (n + 3 < p.N);
+      if (bias) {
+        if (full) {
+          const u32x2_t bb = *(const u32x2_t*)(bias + n);
+          v[0] += bf_lo(bb.x); v[1] += bf_hi(bb.x); v[2] += bf_lo(bb.y); v[3] += bf_hi(bb.y);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (n + e < p.N) v[e] += bf2f(bias[n + e]);
+        }
+      }
+      if (p.aux) {
+        bf16_raw* aux = (bf16_raw*)p.aux + c_boff + (int64_t)crow * p.ldc + n;
+        if (full) {
+          *(u32x2_t*)aux = u32x2_t{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (n + e < p.N) aux[e] = f2bf(v[e]);
+        }
+      }
+      if (p.act != GROVE_ACT_NONE) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = act_apply(p.act, v[e]);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= scale;
+      if (p.residual && rrow >= 0) {
+        const bf16_raw* res = (const bf16_raw*)p.residual + r_boff + (int64_t)rrow * p.ldr + n;
+        if (full) {
+          const u32x2_t rr = *(const u32x2_t*)res;
+          v[0] += bf_lo(rr.x); v[1] += bf_hi(rr.x); v[2] += bf_lo(rr.y); v[3] += bf_hi(rr.y);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (n + e < p.N) v[e] += bf2f(res[e]);
+        }
+      }
+      if (p.c_dtype == GROVE_BF16) {
+        bf16_raw* c = (bf16_raw*)p.C + c_boff + (int64_t)crow * p.ldc + n;
+        if (full) {
+          *(u32x2_t*)c = u32x2_t{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (n + e < p.N) c[e] = f2bf(v[e]);
+        }
+      } else {
+        float* c = (float*)p.C + c_boff + (int64_t)crow * p.ldc + n;
+        if (nsplit > 1) {
+          // split-K partials meet in C through fp32 atomics (C pre-initialised by the caller: accumulate semantics)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (n + e < p.N) atomicAdd(c + e, v[e]);
+        } else if (full) {
+          f32x4_t o = f32x4_t{v[0], v[1], v[2], v[3]};
+          if (p.accumulate) {
+            const f32x4_t old = *(const f32x4_t*)c;
+            o += old;
+          }
+          *(f32x4_t*)c = o;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (n + e < p.N) c[e] = p.accumulate ? c[e] + v[e] : v[e];
+        }
+      }
+    }
+  }
+}
+
 template <int BK, bool GLDS, int NJ, int MI>
 __global__ __launch_bounds__(NT) void gemm_nt_kernel(const grove_gemm_params p, const int vec_ok) {
   constexpr int BM_ = 32 * MI;                  // macro tile M: 128 (MI = 4) or 192 (MI = 6, fewer / fuller rounds of blocks)
@@ -224,103 +329,7 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(const grove_gemm_params p, 
   }
 
   // ---- epilogue ----
-  float scale = 1.f;
-  if (p.scale_ptr) {
-    scale = *p.scale_ptr;
-    if (p.scale_tanh) scale = tanhf(scale);
-  }
-  const bf16_raw* __restrict__ bias = (const bf16_raw*)p.bias;
-  const int64_t c_boff = (int64_t)b1 * p.sC1 + (int64_t)b2 * p.sC2;
-  const int64_t r_boff = (int64_t)b1 * p.sR1 + (int64_t)b2 * p.sR2;
-  const bool vec4 = vec_ok && ((p.ldc & 3) == 0) && (!p.residual || (p.ldr & 3) == 0);
-
-#pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    const int m = m0 + wm * WM + i * 16 + fr;
-    if (m >= p.M) continue;
-    int crow = m;
-    if (p.c_idx) {
-      crow = p.c_idx[m];
-      if (crow < 0) continue;
-    }
-    int rrow = crow;
-    if (p.r_idx) rrow = p.r_idx[m];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const int n = n0 + wn * WN + j * 16 + fq * 4;
-      if (n >= p.N) continue;
-      float v[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] * p.alpha;
-      const bool full = vec4 && (n + 3 < p.N);
-      if (bias) {
-        if (full) {
-          const u32x2_t bb = *(const u32x2_t*)(bias + n);
-          v[0] += bf_lo(bb.x); v[1] += bf_hi(bb.x); v[2] += bf_lo(bb.y); v[3] += bf_hi(bb.y);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (n + e < p.N) v[e] += bf2f(bias[n + e]);
-        }
-      }
-      if (p.aux) {
-        bf16_raw* aux = (bf16_raw*)p.aux + c_boff + (int64_t)crow * p.ldc + n;
-        if (full) {
-          *(u32x2_t*)aux = u32x2_t{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (n + e < p.N) aux[e] = f2bf(v[e]);
-        }
-      }
-      if (p.act != GROVE_ACT_NONE) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = act_apply(p.act, v[e]);
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] *= scale;
-      if (p.residual && rrow >= 0) {
-        const bf16_raw* res = (const bf16_raw*)p.residual + r_boff + (int64_t)rrow * p.ldr + n;
-        if (full) {
-          const u32x2_t rr = *(const u32x2_t*)res;
-          v[0] += bf_lo(rr.x); v[1] += bf_hi(rr.x); v[2] += bf_lo(rr.y); v[3] += bf_hi(rr.y);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (n + e < p.N) v[e] += bf2f(res[e]);
-        }
-      }
-      if (p.c_dtype == GROVE_BF16) {
-        bf16_raw* c = (bf16_raw*)p.C + c_boff + (int64_t)crow * p.ldc + n;
-        if (full) {
-          *(u32x2_t*)c = u32x2_t{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (n + e < p.N) c[e] = f2bf(v[e]);
-        }
-      } else {
-        float* c = (float*)p.C + c_boff + (int64_t)crow * p.ldc + n;
-        if (nsplit > 1) {
-          // split-K partials meet in C through fp32 atomics (C pre-initialised by the caller: accumulate semantics)
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (n + e < p.N) atomicAdd(c + e, v[e]);
-        } else if (full) {
-          f32x4_t o = f32x4_t{v[0], v[1], v[2], v[3]};
-          if (p.accumulate) {
-            const f32x4_t old = *(const f32x4_t*)c;
-            o += old;
-          }
-          *(f32x4_t*)c = o;
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (n + e < p.N) c[e] = p.accumulate ? c[e] + v[e] : v[e];
-        }
-      }
-    }
-  }
+  gemm_epilogue<MI, NJ>(p, vec_ok, acc, m0 + wm * WM, n0 + wn * WN, fr, fq, b1, b2, nsplit);
 }
 
 template <int BK, bool GLDS, int NJ, int MI>
@@ -354,6 +363,267 @@ int launch(const grove_gemm_params& p, int vec_ok, hipStream_t s) {
     attr_set = true;
   }
   hipLaunchKernelGGL((gemm_nt_kernel<BK, GLDS, NJ, MI>), grid, dim3(NT), lds, s, p, vec_ok);
+  GROVE_LAUNCH_CHECK();
+  return GROVE_OK;
+}
+
+
+// =====================================================================================================
+// 256 x 256 x 64 pipelined kernel for the large plain GEMMs (8 waves = 2 (M) x 4 (N), one block per CU, 128 KB of LDS:
+// two stages of four 16 KB half-tiles). LDS-DMA loads stay in flight across raw s_barriers under COUNTED vmcnt waits
+// (a __syncthreads() would drain the queue) — cdna_hip_programming.md §5 "Pipelining across barriers", T3 + T4 + T5; the
+// phase plan and the hazard argument are spelled out at the kernel below.
+// =====================================================================================================
+constexpr int P_BM = 256, P_BN = 256, P_BK = 64, P_NT = 512;
+constexpr int P_ROWB = P_BK * 2;                 // 128-byte rows, XOR-swizzled like the BK = 64 path above
+constexpr int P_HALF = 128 * P_ROWB;             // one half-tile (128 rows) = 16 KB
+constexpr int P_STAGE = 4 * P_HALF;              // A_lo | A_hi | B_lo | B_hi
+
+// Epilogue of the pipelined 256 x 256 kernel: lane (fr, fq) holds, for row fragment i and column half g, the 8 consecutive
+// columns n = nw0 + 128 g + 8 fq + (0..7) in acc[i][2g][0..3], acc[i][2g+1][0..3] (see the permuted B staging), so every
+// global access of the epilogue is 16 bytes per lane. The host only selects this kernel when every epilogue operand
+// is 16-byte aligned with row strides that keep it so.
+__device__ __forceinline__ void gemm_epilogue_wide(const grove_gemm_params& p, f32x4_t (&acc)[8][4], const int mw0, const int nw0,
+                                                   const int fr, const int fq) {
+  float scale = 1.f;
+  if (p.scale_ptr) {
+    scale = *p.scale_ptr;
+    if (p.scale_tanh) scale = tanhf(scale);
+  }
+  const bf16_raw* __restrict__ bias = (const bf16_raw*)p.bias;
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const int n = nw0 + g * 128 + fq * 8;
+    if (n >= p.N) continue;
+    const bool full = n + 7 < p.N;
+    float bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = 0.f;
+    if (bias) {
+      if (full) {
+        const u32x4_t bb = *(const u32x4_t*)(bias + n);
+        bv[0] = bf_lo(bb.x); bv[1] = bf_hi(bb.x); bv[2] = bf_lo(bb.y); bv[3] = bf_hi(bb.y);
+        bv[4] = bf_lo(bb.z); bv[5] = bf_hi(bb.z); bv[6] = bf_lo(bb.w); bv[7] = bf_hi(bb.w);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (n + e < p.N) bv[e] = bf2f(bias[n + e]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int m = mw0 + (i >> 2) * 128 + (i & 3) * 16 + fr;
+      if (m >= p.M) continue;
+      int crow = m;
+      if (p.c_idx) {
+        crow = p.c_idx[m];
+        if (crow < 0) continue;
+      }
+      int rrow = crow;
+      if (p.r_idx) rrow = p.r_idx[m];
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = acc[i][2 * g][e] * p.alpha + bv[e];
+        v[4 + e] = acc[i][2 * g + 1][e] * p.alpha + bv[4 + e];
+      }
+      if (p.aux) {
+        bf16_raw* aux = (bf16_raw*)p.aux + (int64_t)crow * p.ldc + n;
+        if (full) {
+          *(u32x4_t*)aux = u32x4_t{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (n + e < p.N) aux[e] = f2bf(v[e]);
+        }
+      }
+      if (p.act != GROVE_ACT_NONE) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = act_apply(p.act, v[e]);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= scale;
+      if (p.residual && rrow >= 0) {
+        const bf16_raw* res = (const bf16_raw*)p.residual + (int64_t)rrow * p.ldr + n;
+        if (full) {
+          const u32x4_t rr = *(const u32x4_t*)res;
+          v[0] += bf_lo(rr.x); v[1] += bf_hi(rr.x); v[2] += bf_lo(rr.y); v[3] += bf_hi(rr.y);
+          v[4] += bf_lo(rr.z); v[5] += bf_hi(rr.z); v[6] += bf_lo(rr.w); v[7] += bf_hi(rr.w);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (n + e < p.N) v[e] += bf2f(res[e]);
+        }
+      }
+      if (p.c_dtype == GROVE_BF16) {
+        bf16_raw* c = (bf16_raw*)p.C + (int64_t)crow * p.ldc + n;
+        if (full) {
+          *(u32x4_t*)c = u32x4_t{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (n + e < p.N) c[e] = f2bf(v[e]);
+        }
+      } else {
+        float* c = (float*)p.C + (int64_t)crow * p.ldc + n;
+        if (full) {
+          *(f32x4_t*)c = f32x4_t{v[0], v[1], v[2], v[3]};
+          *(f32x4_t*)(c + 4) = f32x4_t{v[4], v[5], v[6], v[7]};
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (n + e < p.N) c[e] = v[e];
+        }
+      }
+    }
+  }
+}
+
+// ---- fine-grained ("ping-pong") form of the 256 x 256 x 64 kernel ---------------------------------------------------
+// The four half-tiles of a K tile (A_lo, B_lo, B_hi, A_hi: 128 rows x 64 k, 16 KB each) are staged, waited for and freed
+// one at a time. A wave owns 64 rows of each A half and 32 columns of each B half, so the quadrant order
+//   ph1 A_lo x B_lo | ph2 A_lo x B_hi | ph3 A_hi x B_hi | ph4 A_hi x B_lo      (16 MFMAs each, 12 / 4 / 8 / 0 LDS reads)
+// needs the half-tiles exactly in staging order and releases each one phase after its last read. A phase is
+//   { ds_reads of this phase's operands; LDS-DMA of half-tile q + 6; counted vmcnt } barrier { 16 MFMAs } barrier
+// and the wr = 1 waves run one barrier behind the wr = 0 waves, so each SIMD always has one wave in its MFMA segment
+// and the other in its memory segment. Hazards (q = global phase number, h = global half-tile number, h issued at q = h - 6):
+//   WAR  the region of h held half-tile h - 8, last read in phase q = h - 8 (+1 for A_hi/B_hi ...) — at least two phases
+//        (four barriers) before the re-issue, and those reads were retired by the lgkmcnt the compiler places before the
+//        MFMAs that consume them;
+//   RAW  phase q + 1 reads half-tiles <= q + 2; every wave retires them with vmcnt(2 * (issued - (q + 2))) before the first
+//        barrier of phase q, the lagging group included, and the reader passes one more barrier before its ds_reads.
+__device__ __forceinline__ void wait_vm_halves(int halves) {
+  if (halves >= 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (halves == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if (halves == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if (halves == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+__global__ __launch_bounds__(P_NT) void gemm_nt256pp_kernel(const grove_gemm_params p, const int vec_ok) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int tiles_m = (p.M + P_BM - 1) / P_BM, tiles_n = (p.N + P_BN - 1) / P_BN;
+  const TileCoord tc = map_block(tiles_m, tiles_n);
+  const int m0 = tc.tm * P_BM, n0 = tc.tn * P_BN;
+  const bf16_raw* __restrict__ A = (const bf16_raw*)p.A;
+  const bf16_raw* __restrict__ B = (const bf16_raw*)p.B;
+
+  // regions of a stage in staging order: 0 = A_lo, 1 = B_lo, 2 = B_hi, 3 = A_hi
+  const int st_c = tid & 7, st_r = tid >> 3;
+  const bf16_raw* src[4][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = st_r + 64 * i;
+    const int c = swz<64>(r, st_c) * 8;
+    src[0][i] = A + (int64_t)min(m0 + r, p.M - 1) * p.lda + c;
+    src[3][i] = A + (int64_t)min(m0 + 128 + r, p.M - 1) * p.lda + c;
+    // LDS row R of a B half holds column pn(R): fragment j, operand row r of a wave's 32-column group lands on column
+    // 8 * (r >> 2) + 4 * j + (r & 3), so a lane's accumulators for (j = 0, 1) are 8 consecutive columns -> 16-byte stores
+    const int pn = (r & ~31) | (((r & 15) >> 2) * 8 + ((r >> 4) & 1) * 4 + (r & 3));
+    src[1][i] = B + (int64_t)min(n0 + pn, p.N - 1) * p.ldb + c;
+    src[2][i] = B + (int64_t)min(n0 + 128 + pn, p.N - 1) * p.ldb + c;
+  }
+  const int nk = p.K / P_BK;
+  const int NH = 4 * nk;
+  auto issue = [&](int x, int t) {  // half-tile x of K tile t
+    char* dst = smem + (t & 1) * P_STAGE + x * P_HALF + wave * (64 * 16);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[x][i] + (int64_t)t * P_BK),
+                                       (__attribute__((address_space(3))) void*)(dst + i * (P_NT * 16)), 16, 0, 0);
+  };
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // fragment read offsets inside a region (the swizzle term depends on fr only: the row bases are multiples of 16)
+  const int sw = (fr >> 1) & 7;
+  const int a_off = (wr * 64 + fr) * P_ROWB;
+  const int b_off = (wc * 32 + fr) * P_ROWB;
+  const int kc0 = ((0 + fq) ^ sw) * 16, kc1 = ((4 + fq) ^ sw) * 16;
+
+  bf16x8_t af[4][2], b0[2][2], b1[2][2];
+  auto read_a = [&](const char* st, int x) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      af[i][0] = *(const bf16x8_t*)(st + x * P_HALF + a_off + i * 16 * P_ROWB + kc0);
+      af[i][1] = *(const bf16x8_t*)(st + x * P_HALF + a_off + i * 16 * P_ROWB + kc1);
+    }
+  };
+  auto read_b = [&](const char* st, int x, bf16x8_t (&bb)[2][2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      bb[j][0] = *(const bf16x8_t*)(st + x * P_HALF + b_off + j * 16 * P_ROWB + kc0);
+      bb[j][1] = *(const bf16x8_t*)(st + x * P_HALF + b_off + j * 16 * P_ROWB + kc1);
+    }
+  };
+#define P256_MMA(IO, JO, BB)                                                                                              \
+  __builtin_amdgcn_sched_barrier(0);                                                                                      \
+  __builtin_amdgcn_s_setprio(1);                                                                                          \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) \
+      acc[IO + i][JO + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BB[j][ks], af[i][ks], acc[IO + i][JO + j], 0, 0, 0);   \
+  __builtin_amdgcn_s_setprio(0);                                                                                          \
+  __builtin_amdgcn_sched_barrier(0);
+  // end of a phase's memory segment: stage half-tile q + 6, retire what phase q + 1 reads, meet the other group
+#define P256_MEM_END(Q, X, TOFF, WAIT)                                                                                    \
+  if ((Q) + 6 < NH) issue(X, t + TOFF);                                                                                   \
+  if (WAIT) wait_vm_halves(min((Q) + 6, NH - 1) - ((Q) + 2));                                                             \
+  __builtin_amdgcn_sched_barrier(0);                                                                                      \
+  __builtin_amdgcn_s_barrier();
+
+  // prologue: half-tiles 0..5, the first two landed before anyone reads
+#pragma unroll
+  for (int h = 0; h < 6; ++h)
+    if (h < NH) issue(h & 3, h >> 2);
+  wait_vm_halves(min(5, NH - 1) - 1);
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();  // the stagger
+
+  for (int t = 0; t < nk; ++t) {
+    const char* st = smem + (t & 1) * P_STAGE;
+    const int q = 4 * t;
+    // ph1
+    read_b(st, 1, b0);
+    read_a(st, 0);
+    P256_MEM_END(q, 2, 1, true)
+    P256_MMA(0, 0, b0)
+    __builtin_amdgcn_s_barrier();
+    // ph2
+    read_b(st, 2, b1);
+    P256_MEM_END(q + 1, 3, 1, true)
+    P256_MMA(0, 2, b1)
+    __builtin_amdgcn_s_barrier();
+    // ph3
+    read_a(st, 3);
+    P256_MEM_END(q + 2, 0, 2, false)
+    P256_MMA(4, 2, b1)
+    __builtin_amdgcn_s_barrier();
+    // ph4
+    P256_MEM_END(q + 3, 1, 2, true)
+    P256_MMA(4, 0, b0)
+    __builtin_amdgcn_s_barrier();
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();
+#undef P256_MMA
+#undef P256_MEM_END
+  gemm_epilogue_wide(p, acc, m0 + wr * 64, n0 + wc * 32, fr, fq);
+}
+
+
+int launch256(const grove_gemm_params& p, int vec_ok, hipStream_t s) {
+  const int tiles_m = (p.M + P_BM - 1) / P_BM, tiles_n = (p.N + P_BN - 1) / P_BN;
+  const size_t lds = 2 * (size_t)P_STAGE;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)gemm_nt256pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_nt256pp_kernel, dim3(tiles_m * tiles_n, 1, 1), dim3(P_NT), lds, s, p, vec_ok);
   GROVE_LAUNCH_CHECK();
   return GROVE_OK;
 }
@@ -428,10 +698,26 @@ extern "C" int grove_gemm_bf16(const grove_gemm_params* pp, void* stream) {
   const long tn128 = (p.N + 127) / 128;
   const long t128 = (long)((p.M + 127) / 128) * tn128 * bt;
   const long t192 = (long)((p.M + 191) / 192) * tn128 * bt;
-  auto rounds_cost = [](long tiles, int rows) { return (double)((tiles + 511) / 512) * rows; };
+  // the pipelined 256 x 256 kernel: plain (un-gathered, un-batched, un-split) GEMMs whose epilogue operands allow 16-byte accesses
+  const bool wide_ok = (((uintptr_t)p.C & 15) == 0) && (p.ldc % (p.c_dtype == GROVE_BF16 ? 8 : 4) == 0) &&
+                       (!p.aux || ((uintptr_t)p.aux & 15) == 0) && (!p.bias || ((uintptr_t)p.bias & 15) == 0) &&
+                       (!p.residual || ((((uintptr_t)p.residual & 15) == 0) && p.ldr % 8 == 0));
+  const bool p256_ok = g_gemm_glds && bk64 && !p.a_idx && bt == 1 && p.split_k <= 1 && !p.accumulate && wide_ok;
+  // Tile choice by a measured cost model (tools/bench_gemm4.py, microseconds): time = rounds of resident blocks x
+  // (K tiles x per-K-tile time + fixed prologue/epilogue time). The 128- and 192-row kernels keep 2 blocks per CU (512
+  // slots; a lone block of a partial round still takes a full round), the 256 x 256 kernel one block per CU.
+  const double nk64 = p.K / 64.0;
+  const double out_scale = (p.c_dtype == GROVE_F32 ? 2.0 : 1.0) + (p.aux ? 1.0 : 0.0);
+  auto rounds = [](long tiles, long slots) { return (double)((tiles + slots - 1) / slots); };
+  const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
+  const double c128 = rounds(t128, 512) * (nk64 * 0.88 + 7.0 + 4.7 * out_scale);
+  const double c192 = rounds(t192, 512) * (nk64 * 1.38 + 1.5 * (7.0 + 4.7 * out_scale));
+  const double fill256 = (double)t256 / (rounds(t256, 256) * 256.0);  // a partly filled chip runs each block faster (L2 / clocks)
+  const double c256 = rounds(t256, 256) * (nk64 * 1.5 * (0.6 + 0.4 * fill256) + 2.0 + 8.0 * out_scale);
+  if (p256_ok && (g_gemm_tile_m == 256 || (g_gemm_tile_m == 0 && g_gemm_tile_n == 0 && t256 >= 48 && c256 < (c128 < c192 ? c128 : c192))))
+    return launch256(p, vec_ok, s);
   int variant = 128;
-  // measured (tools/bench_gemm2.py): at equal round counts the 192-row tile is ~8 % faster (0.42 vs 0.5 LDS reads per MFMA)
-  if (g_gemm_tile_m == 192 || (g_gemm_tile_m == 0 && t128 > 300 && rounds_cost(t192, 192) / 1.08 <= 1.05 * rounds_cost(t128, 128))) variant = 192;
+  if (g_gemm_tile_m == 192 || (g_gemm_tile_m == 0 && t128 > 300 && c192 <= c128)) variant = 192;
   const bool narrow = g_gemm_tile_n == 64 || (g_gemm_tile_n == 0 && t128 < 160 && p.N > 64);
   if (narrow) {
     if (g_gemm_glds) return bk64 ? launch<64, true, 2, 4>(p, vec_ok, s) : launch<32, true, 2, 4>(p, vec_ok, s);
