@@ -374,183 +374,206 @@ int launch(const grove_gemm_params& p, int vec_ok, hipStream_t s) {
 // (a __syncthreads() would drain the queue) — cdna_hip_programming.md §5 "Pipelining across barriers", T3 + T4 + T5; the
 // phase plan and the hazard argument are spelled out at the kernel below.
 // =====================================================================================================
-constexpr int P_BM = 256, P_BN = 256, P_BK = 64, P_NT = 512;
+constexpr int P_BN = 256, P_BK = 64, P_NT = 512;
 constexpr int P_ROWB = P_BK * 2;                 // 128-byte rows, XOR-swizzled like the BK = 64 path above
-constexpr int P_HALF = 128 * P_ROWB;             // one half-tile (128 rows) = 16 KB
-constexpr int P_STAGE = 4 * P_HALF;              // A_lo | A_hi | B_lo | B_hi
+constexpr int P_HALF = 128 * P_ROWB;             // region of one half-tile (up to 128 rows) = 16 KB
+constexpr int P_STAGE = 4 * P_HALF;              // A_lo | B_lo | B_hi | A_hi (staging order)
 
-// Epilogue of the pipelined 256 x 256 kernel: lane (fr, fq) holds, for row fragment i and column half g, the 8 consecutive
+// Epilogue of the pipelined kernel: lane (fr, fq) holds, for row fragment i and column half g, the 8 consecutive
 // columns n = nw0 + 128 g + 8 fq + (0..7) in acc[i][2g][0..3], acc[i][2g+1][0..3] (see the permuted B staging), so every
 // global access of the epilogue is 16 bytes per lane. The host only selects this kernel when every epilogue operand
-// is 16-byte aligned with row strides that keep it so.
-__device__ __forceinline__ void gemm_epilogue_wide(const grove_gemm_params& p, f32x4_t (&acc)[8][4], const int mw0, const int nw0,
-                                                   const int fr, const int fq) {
-  float scale = 1.f;
-  if (p.scale_ptr) {
-    scale = *p.scale_ptr;
-    if (p.scale_tanh) scale = tanhf(scale);
-  }
+// is 16-byte aligned with row strides that keep it so and N % 8 == 0 (no partial column groups).
+// ACT is a compile-time activation (GROVE_ACT_*; -1 = "plain": alpha == 1, no activation, no scale): the persistent
+// kernel has no co-resident block to hide epilogue VALU work behind, so the activation must be straight-line code.
+template <int MIH, int BMH, int ACT>
+__device__ __forceinline__ void gemm_epilogue_wide(const grove_gemm_params& p, f32x4_t (&acc)[2 * MIH][4], const int mw0, const int nw0,
+                                                   const int fr, const int fq, const float scale) {
+  constexpr bool PLAIN = ACT < 0;
   const bf16_raw* __restrict__ bias = (const bf16_raw*)p.bias;
 #pragma unroll
   for (int g = 0; g < 2; ++g) {
     const int n = nw0 + g * 128 + fq * 8;
     if (n >= p.N) continue;
-    const bool full = n + 7 < p.N;
     float bv[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bv[e] = 0.f;
     if (bias) {
-      if (full) {
-        const u32x4_t bb = *(const u32x4_t*)(bias + n);
-        bv[0] = bf_lo(bb.x); bv[1] = bf_hi(bb.x); bv[2] = bf_lo(bb.y); bv[3] = bf_hi(bb.y);
-        bv[4] = bf_lo(bb.z); bv[5] = bf_hi(bb.z); bv[6] = bf_lo(bb.w); bv[7] = bf_hi(bb.w);
-      } else {
+      const u32x4_t bb = *(const u32x4_t*)(bias + n);
+      bv[0] = bf_lo(bb.x); bv[1] = bf_hi(bb.x); bv[2] = bf_lo(bb.y); bv[3] = bf_hi(bb.y);
+      bv[4] = bf_lo(bb.z); bv[5] = bf_hi(bb.z); bv[6] = bf_lo(bb.w); bv[7] = bf_hi(bb.w);
+    }
+    // row bookkeeping first, then ALL residual loads of this column group in flight at once (the operand fragments'
+    // registers are free here), then the arithmetic and the stores
+    int crow[2 * MIH], rrow[2 * MIH];
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if (n + e < p.N) bv[e] = bf2f(bias[n + e]);
-      }
+    for (int i = 0; i < 2 * MIH; ++i) {
+      const int m = mw0 + (i / MIH) * BMH + (i % MIH) * 16 + fr;
+      crow[i] = m < p.M ? m : -1;
+      if (p.c_idx && crow[i] >= 0) crow[i] = p.c_idx[m];
+      rrow[i] = crow[i];
+      if (p.r_idx && crow[i] >= 0) rrow[i] = p.r_idx[m];
+    }
+    u32x4_t rr[2 * MIH];
+    if (p.residual) {
+#pragma unroll
+      for (int i = 0; i < 2 * MIH; ++i)
+        rr[i] = *(const u32x4_t*)((const bf16_raw*)p.residual + (int64_t)(rrow[i] >= 0 ? rrow[i] : 0) * p.ldr + n);
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int m = mw0 + (i >> 2) * 128 + (i & 3) * 16 + fr;
-      if (m >= p.M) continue;
-      int crow = m;
-      if (p.c_idx) {
-        crow = p.c_idx[m];
-        if (crow < 0) continue;
-      }
-      int rrow = crow;
-      if (p.r_idx) rrow = p.r_idx[m];
+    for (int i = 0; i < 2 * MIH; ++i) {
+      if (crow[i] < 0) continue;
       float v[8];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        v[e] = acc[i][2 * g][e] * p.alpha + bv[e];
-        v[4 + e] = acc[i][2 * g + 1][e] * p.alpha + bv[4 + e];
-      }
-      if (p.aux) {
-        bf16_raw* aux = (bf16_raw*)p.aux + (int64_t)crow * p.ldc + n;
-        if (full) {
-          *(u32x4_t*)aux = u32x4_t{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+        if (PLAIN) {
+          v[e] = acc[i][2 * g][e] + bv[e];
+          v[4 + e] = acc[i][2 * g + 1][e] + bv[4 + e];
         } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e)
-            if (n + e < p.N) aux[e] = f2bf(v[e]);
+          v[e] = acc[i][2 * g][e] * p.alpha + bv[e];
+          v[4 + e] = acc[i][2 * g + 1][e] * p.alpha + bv[4 + e];
         }
       }
-      if (p.act != GROVE_ACT_NONE) {
+      if (p.aux)
+        *(u32x4_t*)((bf16_raw*)p.aux + (int64_t)crow[i] * p.ldc + n) =
+            u32x4_t{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+      if (!PLAIN) {
+        if (ACT != GROVE_ACT_NONE) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = act_apply(p.act, v[e]);
-      }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] *= scale;
-      if (p.residual && rrow >= 0) {
-        const bf16_raw* res = (const bf16_raw*)p.residual + (int64_t)rrow * p.ldr + n;
-        if (full) {
-          const u32x4_t rr = *(const u32x4_t*)res;
-          v[0] += bf_lo(rr.x); v[1] += bf_hi(rr.x); v[2] += bf_lo(rr.y); v[3] += bf_hi(rr.y);
-          v[4] += bf_lo(rr.z); v[5] += bf_hi(rr.z); v[6] += bf_lo(rr.w); v[7] += bf_hi(rr.w);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e)
-            if (n + e < p.N) v[e] += bf2f(res[e]);
+          for (int e = 0; e < 8; ++e) v[e] = act_apply(ACT, v[e]);
         }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= scale;
+      }
+      if (p.residual && rrow[i] >= 0) {
+        v[0] += bf_lo(rr[i].x); v[1] += bf_hi(rr[i].x); v[2] += bf_lo(rr[i].y); v[3] += bf_hi(rr[i].y);
+        v[4] += bf_lo(rr[i].z); v[5] += bf_hi(rr[i].z); v[6] += bf_lo(rr[i].w); v[7] += bf_hi(rr[i].w);
       }
       if (p.c_dtype == GROVE_BF16) {
-        bf16_raw* c = (bf16_raw*)p.C + (int64_t)crow * p.ldc + n;
-        if (full) {
-          *(u32x4_t*)c = u32x4_t{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e)
-            if (n + e < p.N) c[e] = f2bf(v[e]);
-        }
+        *(u32x4_t*)((bf16_raw*)p.C + (int64_t)crow[i] * p.ldc + n) =
+            u32x4_t{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
       } else {
-        float* c = (float*)p.C + (int64_t)crow * p.ldc + n;
-        if (full) {
-          *(f32x4_t*)c = f32x4_t{v[0], v[1], v[2], v[3]};
-          *(f32x4_t*)(c + 4) = f32x4_t{v[4], v[5], v[6], v[7]};
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e)
-            if (n + e < p.N) c[e] = v[e];
-        }
+        float* c = (float*)p.C + (int64_t)crow[i] * p.ldc + n;
+        *(f32x4_t*)c = f32x4_t{v[0], v[1], v[2], v[3]};
+        *(f32x4_t*)(c + 4) = f32x4_t{v[4], v[5], v[6], v[7]};
       }
     }
   }
 }
 
-// ---- fine-grained ("ping-pong") form of the 256 x 256 x 64 kernel ---------------------------------------------------
-// The four half-tiles of a K tile (A_lo, B_lo, B_hi, A_hi: 128 rows x 64 k, 16 KB each) are staged, waited for and freed
-// one at a time. A wave owns 64 rows of each A half and 32 columns of each B half, so the quadrant order
-//   ph1 A_lo x B_lo | ph2 A_lo x B_hi | ph3 A_hi x B_hi | ph4 A_hi x B_lo      (16 MFMAs each, 12 / 4 / 8 / 0 LDS reads)
-// needs the half-tiles exactly in staging order and releases each one phase after its last read. A phase is
-//   { ds_reads of this phase's operands; LDS-DMA of half-tile q + 6; counted vmcnt } barrier { 16 MFMAs } barrier
-// and the wr = 1 waves run one barrier behind the wr = 0 waves, so each SIMD always has one wave in its MFMA segment
-// and the other in its memory segment. Hazards (q = global phase number, h = global half-tile number, h issued at q = h - 6):
-//   WAR  the region of h held half-tile h - 8, last read in phase q = h - 8 (+1 for A_hi/B_hi ...) — at least two phases
-//        (four barriers) before the re-issue, and those reads were retired by the lgkmcnt the compiler places before the
-//        MFMAs that consume them;
-//   RAW  phase q + 1 reads half-tiles <= q + 2; every wave retires them with vmcnt(2 * (issued - (q + 2))) before the first
-//        barrier of phase q, the lagging group included, and the reader passes one more barrier before its ds_reads.
-__device__ __forceinline__ void wait_vm_halves(int halves) {
-  if (halves >= 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if (halves == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else if (halves == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else if (halves == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+__device__ __forceinline__ void wait_vm_loads(int n) {  // n (even) = vector-memory operations allowed to stay in flight
+  if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-__global__ __launch_bounds__(P_NT) void gemm_nt256pp_kernel(const grove_gemm_params p, const int vec_ok) {
+// ---- the kernel -------------------------------------------------------------------------------------------------------
+// PERSISTENT: one block per CU walks its output tiles (tile L = wgid + k * gridDim, XCD-aware wgid, band-major tile
+// order) and the staging stream runs straight through the tile seams, so a tile's first operands land while the
+// previous tile's epilogue runs.
+//
+// The four half-tiles of a K tile (A_lo, B_lo, B_hi, A_hi: BM/2 or 128 rows x 64 k) are staged, waited for and freed one
+// at a time. A wave owns BM/4 rows of each A half and 32 columns of each B half, so the quadrant order
+//   ph1 A_lo x B_lo | ph2 A_lo x B_hi | ph3 A_hi x B_hi | ph4 A_hi x B_lo      (4 MIH MFMAs each; 12 / 4 / 8 / 0 LDS reads)
+// needs the half-tiles exactly in staging order and releases each one phase after its last read. A phase is
+//   { ds_reads of this phase's operands; LDS-DMA of half-tile q + 6; counted vmcnt } barrier { MFMAs } barrier
+// and the wr = 1 waves run one barrier behind the wr = 0 waves, so each SIMD always has one wave in its MFMA segment
+// and the other in its memory segment. Hazards (q = phase number, h = half-tile number of the block's stream, h issued at q = h - 6):
+//   WAR  the region of h held half-tile h - 8, whose last ds_read is at least two phases (four barriers) before the re-issue,
+//        retired by the lgkmcnt the compiler places before the MFMAs that consume it;
+//   RAW  phase q + 1 reads half-tiles <= q + 2; every wave retires them with a counted vmcnt (the loads of the half-tiles
+//        issued after q + 2 may stay in flight) before the first barrier of phase q, the lagging group included, and the
+//        reader passes one more barrier before its ds_reads. vmcnt retires in issue order, stores included: the epilogue's
+//        stores sit between loads in the queue, so a counted wait after an epilogue is merely conservative (it also waits
+//        for the stores), never early.
+template <int BM>
+__global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_params p, const int tiles_m, const int tiles_n) {
+  constexpr int BMH = BM / 2;    // rows of an A half-tile: 128 or 96
+  constexpr int WRH = BMH / 2;   // ... of which one wave group owns 64 or 48
+  constexpr int MIH = WRH / 16;  // row fragments per half per wave: 4 or 3
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
   const int fr = lane & 15, fq = lane >> 4;
-  const int tiles_m = (p.M + P_BM - 1) / P_BM, tiles_n = (p.N + P_BN - 1) / P_BN;
-  const TileCoord tc = map_block(tiles_m, tiles_n);
-  const int m0 = tc.tm * P_BM, n0 = tc.tn * P_BN;
   const bf16_raw* __restrict__ A = (const bf16_raw*)p.A;
   const bf16_raw* __restrict__ B = (const bf16_raw*)p.B;
 
-  // regions of a stage in staging order: 0 = A_lo, 1 = B_lo, 2 = B_hi, 3 = A_hi
+  // my tiles: L = wgid + k * G; blocks of one XCD (blockIdx % 8) take neighbouring tiles of every round
+  const int G = gridDim.x;
+  const int xcd = blockIdx.x & 7, q8 = G >> 3, r8 = G & 7;
+  const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+  const int tiles = tiles_m * tiles_n;
+  const int my_tiles = (tiles - wgid + G - 1) / G;
+  const int nk = p.K / P_BK;
+  const int NT = my_tiles * nk;  // K tiles of my stream
+  const int NH = 4 * NT;         // half-tiles of my stream
+  auto tile_origin = [&](int L, int& m0, int& n0) {
+    constexpr int GM = 8;
+    const int per_band = GM * tiles_n;
+    const int band = L / per_band;
+    const int first_m = band * GM;
+    const int gm = min(tiles_m - first_m, GM);
+    const int in_band = L - band * per_band;
+    m0 = (first_m + in_band % gm) * BM;
+    n0 = (in_band / gm) * P_BN;
+  };
+
+  // staging: regions of a stage in staging order 0 = A_lo, 1 = B_lo, 2 = B_hi, 3 = A_hi. A half-tile region is 128 rows x 8
+  // chunks = 2 LDS-DMA instructions per thread. (BM = 192 uses 96 rows of an A region; every wave still issues both
+  // instructions — rows 96..127 are fetched and never read — so that the vmcnt arithmetic is the same for all waves.)
   const int st_c = tid & 7, st_r = tid >> 3;
   const bf16_raw* src[4][2];
+  auto set_src = [&](int L) {
+    int m0, n0;
+    tile_origin(L, m0, n0);
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int r = st_r + 64 * i;
-    const int c = swz<64>(r, st_c) * 8;
-    src[0][i] = A + (int64_t)min(m0 + r, p.M - 1) * p.lda + c;
-    src[3][i] = A + (int64_t)min(m0 + 128 + r, p.M - 1) * p.lda + c;
-    // LDS row R of a B half holds column pn(R): fragment j, operand row r of a wave's 32-column group lands on column
-    // 8 * (r >> 2) + 4 * j + (r & 3), so a lane's accumulators for (j = 0, 1) are 8 consecutive columns -> 16-byte stores
-    const int pn = (r & ~31) | (((r & 15) >> 2) * 8 + ((r >> 4) & 1) * 4 + (r & 3));
-    src[1][i] = B + (int64_t)min(n0 + pn, p.N - 1) * p.ldb + c;
-    src[2][i] = B + (int64_t)min(n0 + 128 + pn, p.N - 1) * p.ldb + c;
-  }
-  const int nk = p.K / P_BK;
-  const int NH = 4 * nk;
-  auto issue = [&](int x, int t) {  // half-tile x of K tile t
-    char* dst = smem + (t & 1) * P_STAGE + x * P_HALF + wave * (64 * 16);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[x][i] + (int64_t)t * P_BK),
-                                       (__attribute__((address_space(3))) void*)(dst + i * (P_NT * 16)), 16, 0, 0);
+    for (int i = 0; i < 2; ++i) {
+      const int r = st_r + 64 * i;
+      const int c = swz<64>(r, st_c) * 8;
+      src[0][i] = A + (int64_t)min(m0 + r, p.M - 1) * p.lda + c;
+      src[3][i] = A + (int64_t)min(m0 + BMH + r, p.M - 1) * p.lda + c;
+      // LDS row R of a B half holds column pn(R): fragment j, operand row r of a wave's 32-column group lands on column
+      // 8 * (r >> 2) + 4 * j + (r & 3), so a lane's accumulators for (j = 0, 1) are 8 consecutive columns -> 16-byte stores
+      const int pn = (r & ~31) | (((r & 15) >> 2) * 8 + ((r >> 4) & 1) * 4 + (r & 3));
+      src[1][i] = B + (int64_t)min(n0 + pn, p.N - 1) * p.ldb + c;
+      src[2][i] = B + (int64_t)min(n0 + 128 + pn, p.N - 1) * p.ldb + c;
+    }
   };
-  f32x4_t acc[8][4];
+  int is_L = wgid, is_k = 0;  // output tile and K tile of the half-tile being issued
+  auto issue = [&](int x, int stream_t) {
+    char* dst = smem + (stream_t & 1) * P_STAGE + x * P_HALF + wave * (64 * 16);
+    const int64_t koff = (int64_t)is_k * P_BK;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[x][0] + koff),
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[x][1] + koff),
+                                     (__attribute__((address_space(3))) void*)(dst + P_NT * 16), 16, 0, 0);
+  };
+  auto advance_issue = [&]() {  // before the A_lo of every K tile but the first
+    if (++is_k == nk) {
+      is_k = 0;
+      is_L += G;
+      set_src(is_L);
+    }
+  };
+
+  f32x4_t acc[2 * MIH][4];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < 2 * MIH; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   // fragment read offsets inside a region (the swizzle term depends on fr only: the row bases are multiples of 16)
   const int sw = (fr >> 1) & 7;
-  const int a_off = (wr * 64 + fr) * P_ROWB;
+  const int a_off = (wr * WRH + fr) * P_ROWB;
   const int b_off = (wc * 32 + fr) * P_ROWB;
   const int kc0 = ((0 + fq) ^ sw) * 16, kc1 = ((4 + fq) ^ sw) * 16;
 
-  bf16x8_t af[4][2], b0[2][2], b1[2][2];
+  bf16x8_t af[MIH][2], b0[2][2], b1[2][2];
   auto read_a = [&](const char* st, int x) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MIH; ++i) {
       af[i][0] = *(const bf16x8_t*)(st + x * P_HALF + a_off + i * 16 * P_ROWB + kc0);
       af[i][1] = *(const bf16x8_t*)(st + x * P_HALF + a_off + i * 16 * P_ROWB + kc1);
     }
@@ -562,68 +585,113 @@ __global__ __launch_bounds__(P_NT) void gemm_nt256pp_kernel(const grove_gemm_par
       bb[j][1] = *(const bf16x8_t*)(st + x * P_HALF + b_off + j * 16 * P_ROWB + kc1);
     }
   };
-#define P256_MMA(IO, JO, BB)                                                                                              \
+#define PP_MMA(IO, JO, BB)                                                                                                \
   __builtin_amdgcn_sched_barrier(0);                                                                                      \
   __builtin_amdgcn_s_setprio(1);                                                                                          \
-  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < MIH; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) \
       acc[IO + i][JO + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BB[j][ks], af[i][ks], acc[IO + i][JO + j], 0, 0, 0);   \
   __builtin_amdgcn_s_setprio(0);                                                                                          \
   __builtin_amdgcn_sched_barrier(0);
   // end of a phase's memory segment: stage half-tile q + 6, retire what phase q + 1 reads, meet the other group
-#define P256_MEM_END(Q, X, TOFF, WAIT)                                                                                    \
-  if ((Q) + 6 < NH) issue(X, t + TOFF);                                                                                   \
-  if (WAIT) wait_vm_halves(min((Q) + 6, NH - 1) - ((Q) + 2));                                                             \
+#define PP_MEM_END(Q, X, TOFF, WAIT)                                                                                      \
+  if ((Q) + 6 < NH) {                                                                                                     \
+    if ((X) == 0) advance_issue();                                                                                        \
+    issue(X, T + TOFF);                                                                                                   \
+    if (WAIT) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); /* half-tiles q+3 .. q+6 stay in flight */                 \
+  } else if (WAIT) {                                                                                                      \
+    wait_vm_loads(2 * max(NH - 3 - (Q), 0)); /* the stream's tail: half-tiles q+3 .. NH-1 */                              \
+  }                                                                                                                       \
   __builtin_amdgcn_sched_barrier(0);                                                                                      \
   __builtin_amdgcn_s_barrier();
 
-  // prologue: half-tiles 0..5, the first two landed before anyone reads
-#pragma unroll
-  for (int h = 0; h < 6; ++h)
-    if (h < NH) issue(h & 3, h >> 2);
-  wait_vm_halves(min(5, NH - 1) - 1);
+  // The epilogue scale is fetched and USED here, once: a global load left pending on any path into the K loop makes hipcc
+  // guard the loop's first ds_read with s_waitcnt vmcnt(0), which drains the staging queue every K tile.
+  float scale = 1.f;
+  if (p.scale_ptr) {
+    scale = *p.scale_ptr;
+    if (p.scale_tanh) scale = tanhf(scale);
+  }
+  asm volatile("" ::"v"(scale));
+  // prologue: half-tiles 0..5 of my stream, the first two landed before anyone reads
+  set_src(is_L);
+  issue(0, 0); issue(1, 0); issue(2, 0); issue(3, 0);
+  if (NT > 1) {
+    advance_issue();
+    issue(0, 1); issue(1, 1);
+  }
+  wait_vm_loads(2 * (min(5, NH - 1) - 1));
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();  // the stagger
 
-  for (int t = 0; t < nk; ++t) {
-    const char* st = smem + (t & 1) * P_STAGE;
-    const int q = 4 * t;
+  int c_L = wgid, c_k = 0;  // output tile / K tile being computed
+  for (int T = 0; T < NT; ++T) {
+    const char* st = smem + (T & 1) * P_STAGE;
+    const int q = 4 * T;
     // ph1
     read_b(st, 1, b0);
     read_a(st, 0);
-    P256_MEM_END(q, 2, 1, true)
-    P256_MMA(0, 0, b0)
+    PP_MEM_END(q, 2, 1, true)
+    PP_MMA(0, 0, b0)
     __builtin_amdgcn_s_barrier();
     // ph2
     read_b(st, 2, b1);
-    P256_MEM_END(q + 1, 3, 1, true)
-    P256_MMA(0, 2, b1)
+    PP_MEM_END(q + 1, 3, 1, true)
+    PP_MMA(0, 2, b1)
     __builtin_amdgcn_s_barrier();
     // ph3
     read_a(st, 3);
-    P256_MEM_END(q + 2, 0, 2, false)
-    P256_MMA(4, 2, b1)
+    PP_MEM_END(q + 2, 0, 2, false)
+    PP_MMA(MIH, 2, b1)
     __builtin_amdgcn_s_barrier();
     // ph4
-    P256_MEM_END(q + 3, 1, 2, true)
-    P256_MMA(4, 0, b0)
+    PP_MEM_END(q + 3, 1, 2, true)
+    PP_MMA(MIH, 0, b0)
     __builtin_amdgcn_s_barrier();
+    if (++c_k == nk) {  // tile done: epilogue (no barriers inside), then on to my next tile whose operands are already landing
+      int m0, n0;
+      tile_origin(c_L, m0, n0);
+      const int mw0 = m0 + wr * WRH, nw0 = n0 + wc * 32;
+      if (p.act == GROVE_ACT_NONE) {
+        if (p.alpha == 1.f && !p.scale_ptr) gemm_epilogue_wide<MIH, BMH, -1>(p, acc, mw0, nw0, fr, fq, 1.f);
+        else gemm_epilogue_wide<MIH, BMH, GROVE_ACT_NONE>(p, acc, mw0, nw0, fr, fq, scale);
+      } else if (p.act == GROVE_ACT_GELU) {
+        gemm_epilogue_wide<MIH, BMH, GROVE_ACT_GELU>(p, acc, mw0, nw0, fr, fq, scale);
+      } else {
+        gemm_epilogue_wide<MIH, BMH, GROVE_ACT_QUICKGELU>(p, acc, mw0, nw0, fr, fq, scale);
+      }
+#pragma unroll
+      for (int i = 0; i < 2 * MIH; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      c_k = 0;
+      c_L += G;
+    }
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();
-#undef P256_MMA
-#undef P256_MEM_END
-  gemm_epilogue_wide(p, acc, m0 + wr * 64, n0 + wc * 32, fr, fq);
+#undef PP_MMA
+#undef PP_MEM_END
 }
 
+static int g_num_cus = 0;
 
-int launch256(const grove_gemm_params& p, int vec_ok, hipStream_t s) {
-  const int tiles_m = (p.M + P_BM - 1) / P_BM, tiles_n = (p.N + P_BN - 1) / P_BN;
+template <int BM>
+int launch_pp(const grove_gemm_params& p, hipStream_t s) {
+  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + P_BN - 1) / P_BN;
   const size_t lds = 2 * (size_t)P_STAGE;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_nt256pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<BM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL(gemm_nt256pp_kernel, dim3(tiles_m * tiles_n, 1, 1), dim3(P_NT), lds, s, p, vec_ok);
+  if (g_num_cus == 0) {
+    int dev = 0, n = 0;
+    hipGetDevice(&dev);
+    hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    g_num_cus = n > 0 ? n : 256;
+  }
+  const int tiles = tiles_m * tiles_n;
+  const int grid = tiles < g_num_cus ? tiles : g_num_cus;
+  hipLaunchKernelGGL(gemm_nt_pp_kernel<BM>, dim3(grid, 1, 1), dim3(P_NT), lds, s, p, tiles_m, tiles_n);
   GROVE_LAUNCH_CHECK();
   return GROVE_OK;
 }
@@ -702,20 +770,30 @@ extern "C" int grove_gemm_bf16(const grove_gemm_params* pp, void* stream) {
   const bool wide_ok = (((uintptr_t)p.C & 15) == 0) && (p.ldc % (p.c_dtype == GROVE_BF16 ? 8 : 4) == 0) &&
                        (!p.aux || ((uintptr_t)p.aux & 15) == 0) && (!p.bias || ((uintptr_t)p.bias & 15) == 0) &&
                        (!p.residual || ((((uintptr_t)p.residual & 15) == 0) && p.ldr % 8 == 0));
-  const bool p256_ok = g_gemm_glds && bk64 && !p.a_idx && bt == 1 && p.split_k <= 1 && !p.accumulate && wide_ok;
-  // Tile choice by a measured cost model (tools/bench_gemm4.py, microseconds): time = rounds of resident blocks x
-  // (K tiles x per-K-tile time + fixed prologue/epilogue time). The 128- and 192-row kernels keep 2 blocks per CU (512
-  // slots; a lone block of a partial round still takes a full round), the 256 x 256 kernel one block per CU.
+  const bool pp_act = p.act == GROVE_ACT_NONE || p.act == GROVE_ACT_GELU || p.act == GROVE_ACT_QUICKGELU;  // compiled-in epilogues
+  const bool p256_ok = g_gemm_glds && bk64 && !p.a_idx && bt == 1 && p.split_k <= 1 && !p.accumulate && wide_ok && p.N % 8 == 0 && pp_act;
+  // Tile choice by a measured cost model (tools/bench_gemm5.py, microseconds): time = rounds of resident blocks x
+  // (K tiles x per-K-tile time + fixed per-tile time). The 128- and 192-row kernels keep 2 blocks per CU (512 slots; a
+  // lone block of a partial round still takes a full round); the pipelined kernels are persistent, one block per CU,
+  // and a partly filled chip runs each block faster (L2, clocks).
   const double nk64 = p.K / 64.0;
   const double out_scale = (p.c_dtype == GROVE_F32 ? 2.0 : 1.0) + (p.aux ? 1.0 : 0.0);
   auto rounds = [](long tiles, long slots) { return (double)((tiles + slots - 1) / slots); };
-  const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
   const double c128 = rounds(t128, 512) * (nk64 * 0.88 + 7.0 + 4.7 * out_scale);
   const double c192 = rounds(t192, 512) * (nk64 * 1.38 + 1.5 * (7.0 + 4.7 * out_scale));
-  const double fill256 = (double)t256 / (rounds(t256, 256) * 256.0);  // a partly filled chip runs each block faster (L2 / clocks)
-  const double c256 = rounds(t256, 256) * (nk64 * 1.5 * (0.6 + 0.4 * fill256) + 2.0 + 8.0 * out_scale);
-  if (p256_ok && (g_gemm_tile_m == 256 || (g_gemm_tile_m == 0 && g_gemm_tile_n == 0 && t256 >= 48 && c256 < (c128 < c192 ? c128 : c192))))
-    return launch256(p, vec_ok, s);
+  const long tn256 = (p.N + 255) / 256;
+  const long tp256 = (long)((p.M + 255) / 256) * tn256, tp192 = (long)((p.M + 191) / 192) * tn256;
+  auto pp_cost = [&](long tiles, double kt, double fixed) {
+    const double r = rounds(tiles, 256);
+    const double fill = (double)tiles / (r * 256.0);
+    return r * (nk64 * kt * (0.6 + 0.4 * fill) + fixed);
+  };
+  const double cp256 = pp_cost(tp256, 1.5, 3.0 + 3.0 * out_scale);
+  const double cp192 = pp_cost(tp192, 1.17, 0.8 * (3.0 + 3.0 * out_scale));
+  const double c_old = c128 < c192 ? c128 : c192;
+  if (p256_ok && (g_gemm_tile_m == 193 || g_gemm_tile_m == 256)) return g_gemm_tile_m == 256 ? launch_pp<256>(p, s) : launch_pp<192>(p, s);
+  if (p256_ok && g_gemm_tile_m == 0 && g_gemm_tile_n == 0 && tp192 >= 48 && (cp256 < c_old || cp192 < c_old))
+    return cp256 <= cp192 ? launch_pp<256>(p, s) : launch_pp<192>(p, s);
   int variant = 128;
   if (g_gemm_tile_m == 192 || (g_gemm_tile_m == 0 && t128 > 300 && c192 <= c128)) variant = 192;
   const bool narrow = g_gemm_tile_n == 64 || (g_gemm_tile_n == 0 && t128 < 160 && p.N > 64);
