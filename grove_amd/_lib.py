@@ -106,18 +106,29 @@ class FlashAttnParams(C.Structure):
                 ("ld_dk", c_i32), ("ld_dv", c_i32), ("causal", c_i32), ("rel_kh", c_i32), ("rel_kw", c_i32), ("rel_ld", c_i32), ("alpha", c_f32)]
 
 
+class GemvParams(C.Structure):
+    _fields_ = [("x", c_vp), ("W", c_vp), ("y", c_vp), ("bias", c_vp), ("residual", c_vp), ("norm_weight", c_vp),
+                ("M", c_i32), ("N", c_i32), ("K", c_i32), ("ldx", c_i32), ("ldw", c_i32), ("ldy", c_i32), ("ldr", c_i32),
+                ("act", c_i32), ("y_dtype", c_i32), ("x_mode", c_i32), ("eps", c_f32)]
+
+
+class DecodeAttnParams(C.Structure):
+    _fields_ = [("qkv", c_vp), ("cache", c_vp), ("out", c_vp), ("pos", c_vp), ("B", c_i32), ("H", c_i32), ("hd", c_i32),
+                ("S_max", c_i32), ("ld_qkv", c_i32), ("theta", c_f32), ("alpha", c_f32)]
+
+
 STRUCTS = {
     "grove_gemm_params": GemmParams, "grove_transpose_params": TransposeParams, "grove_norm_params": NormParams,
     "grove_norm_bwd_params": NormBwdParams, "grove_softmax_params": SoftmaxParams,
     "grove_softmax_bwd_params": SoftmaxBwdParams, "grove_relpos_params": RelposParams, "grove_rope_params": RopeParams,
     "grove_rows_params": RowsParams, "grove_small_attn_params": SmallAttnParams, "grove_box_head_params": BoxHeadParams,
     "grove_box_head_bwd_params": BoxHeadBwdParams, "grove_flash_attn_params": FlashAttnParams,
-    "grove_gemm_tn_params": GemmTnParams,
+    "grove_gemm_tn_params": GemmTnParams, "grove_gemv_params": GemvParams, "grove_decode_attn_params": DecodeAttnParams,
 }
 
 # every symbol include/grove_hip.h declares (tests/test_abi.py checks the header against this list)
 SYMBOLS = [
-    "grove_version", "grove_last_error", "grove_sizeof", "grove_gemm_bf16", "grove_gemm_set_staging", "grove_gemm_set_tile_n", "grove_gemm_set_tile_m", "grove_gemm_set_bk", "grove_gemm_tn_bf16",
+    "grove_version", "grove_last_error", "grove_sizeof", "grove_gemm_bf16", "grove_gemm_set_staging", "grove_gemm_set_tile_n", "grove_gemm_set_tile_m", "grove_gemm_set_bk", "grove_gemm_tn_bf16", "grove_gemv_bf16", "grove_decode_attn",
     "grove_transpose_bf16", "grove_layernorm_fwd", "grove_rmsnorm_fwd", "grove_layernorm_bwd", "grove_rmsnorm_bwd",
     "grove_flash_attn_fwd", "grove_flash_attn_bwd", "grove_softmax_fwd", "grove_softmax_bwd", "grove_relpos_fwd", "grove_relpos_bwd", "grove_rope_inplace",
     "grove_swiglu_fwd", "grove_swiglu_bwd", "grove_act_bwd", "grove_add_bf16", "grove_add_bcast_rows",

@@ -39,6 +39,8 @@ extern "C" int grove_sizeof(const char* name) {
   SZ(grove_box_head_bwd_params);
   SZ(grove_flash_attn_params);
   SZ(grove_gemm_tn_params);
+  SZ(grove_gemv_params);
+  SZ(grove_decode_attn_params);
 #undef SZ
   return -1;
 }

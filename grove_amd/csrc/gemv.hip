@@ -1,0 +1,282 @@
+// Weight-streaming GEMV for the greedy-decode step (HF generate with use_cache=True feeds ONE token per
+// sequence after step 0, llava_llama.py:144-180): y[b, n] = epi( sum_k x[b, k] * W[n, k] ), 1 <= b <= 8 rows.
+//
+// HBM-bound: every weight byte is read exactly once per token (13.2 GB per token for the 7B decoder), so the kernel is a
+// pure stream — no LDS staging of W, no MFMA. A wave owns RW consecutive output rows; lane l reads the 16-byte chunk
+// k = 8 (l + 64 i) .. +7 of each row (a wave instruction = 1 KB contiguous), multiplies with the matching chunk of every x
+// row (x sits in LDS, read with ds_read_b128 — every lane a different chunk, conflict-free) and accumulates in fp32;
+// one cross-lane reduction per (row, b) at the end. RW x UNROLL = 8 independent 16-byte loads in flight per lane.
+#include "common.h"
+
+namespace {
+constexpr int GV_THREADS = 256;
+
+template <int MX, int GV_RW>  // GV_RW: output rows per wave (4; 2 when N is too small to fill the chip with 4)
+__global__ __launch_bounds__(GV_THREADS) void gemv_kernel(const grove_gemv_params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_raw* xs = (bf16_raw*)smem;  // [MX][K]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = p.K;
+  const bf16_raw* __restrict__ X = (const bf16_raw*)p.x;
+  __shared__ float red[GV_THREADS / 64];
+  if (p.x_mode == GROVE_GEMV_X_SWIGLU) {
+    // x' = silu(gate) * up of a fused [M, 2K] gate|up row (HF LlamaMLP), rounded to bf16 like grove_swiglu_fwd
+    for (int c = tid; c < MX * (K >> 3); c += GV_THREADS) {
+      const int b = c / (K >> 3), kc = c - b * (K >> 3);
+      const u32x4_t gv = *(const u32x4_t*)(X + (int64_t)b * p.ldx + kc * 8);
+      const u32x4_t uv = *(const u32x4_t*)(X + (int64_t)b * p.ldx + K + kc * 8);
+      const float g[8] = {bf_lo(gv.x), bf_hi(gv.x), bf_lo(gv.y), bf_hi(gv.y), bf_lo(gv.z), bf_hi(gv.z), bf_lo(gv.w), bf_hi(gv.w)};
+      const float u[8] = {bf_lo(uv.x), bf_hi(uv.x), bf_lo(uv.y), bf_hi(uv.y), bf_lo(uv.z), bf_hi(uv.z), bf_lo(uv.w), bf_hi(uv.w)};
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = g[e] / (1.f + __expf(-g[e])) * u[e];
+      *(u32x4_t*)(xs + b * K + kc * 8) = u32x4_t{pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
+    }
+    __syncthreads();
+  } else {
+    for (int c = tid; c < MX * (K >> 3); c += GV_THREADS) {
+      const int b = c / (K >> 3), kc = c - b * (K >> 3);
+      *(u32x4_t*)(xs + b * K + kc * 8) = *(const u32x4_t*)(X + (int64_t)b * p.ldx + kc * 8);
+    }
+    __syncthreads();
+    if (p.x_mode == GROVE_GEMV_X_RMSNORM) {
+      // x' = bf16(x * rsqrt(mean(x^2) + eps) * w): every block normalises its own copy of the rows (K elements: free)
+      const bf16_raw* nw = (const bf16_raw*)p.norm_weight;
+      for (int b = 0; b < MX; ++b) {
+        float ss = 0.f;
+        for (int k = tid; k < K; k += GV_THREADS) {
+          const float v = bf2f(xs[b * K + k]);
+          ss += v * v;
+        }
+        const float rstd = rsqrtf(block_sum<GV_THREADS>(ss, red) / (float)K + p.eps);
+        for (int k = tid; k < K; k += GV_THREADS) xs[b * K + k] = f2bf(bf2f(xs[b * K + k]) * rstd * bf2f(nw[k]));
+        __syncthreads();
+      }
+    }
+  }
+  const int n0 = (blockIdx.x * (GV_THREADS / 64) + wave) * GV_RW;
+  if (n0 >= p.N) return;
+  const bf16_raw* __restrict__ W = (const bf16_raw*)p.W;
+  const bf16_raw* wrow[GV_RW];
+#pragma unroll
+  for (int r = 0; r < GV_RW; ++r) wrow[r] = W + (int64_t)min(n0 + r, p.N - 1) * p.ldw;
+  float acc[GV_RW][MX];
+#pragma unroll
+  for (int r = 0; r < GV_RW; ++r)
+#pragma unroll
+    for (int b = 0; b < MX; ++b) acc[r][b] = 0.f;
+
+  auto step = [&](int k) {  // k: this lane's chunk start
+    u32x4_t wv[GV_RW];
+#pragma unroll
+    for (int r = 0; r < GV_RW; ++r) wv[r] = __builtin_nontemporal_load((const u32x4_t*)(wrow[r] + k));
+#pragma unroll
+    for (int b = 0; b < MX; ++b) {
+      const u32x4_t xv = *(const u32x4_t*)(xs + b * K + k);
+      const float x0 = bf_lo(xv.x), x1 = bf_hi(xv.x), x2 = bf_lo(xv.y), x3 = bf_hi(xv.y);
+      const float x4 = bf_lo(xv.z), x5 = bf_hi(xv.z), x6 = bf_lo(xv.w), x7 = bf_hi(xv.w);
+#pragma unroll
+      for (int r = 0; r < GV_RW; ++r) {
+        float a = acc[r][b];
+        a = fmaf(bf_lo(wv[r].x), x0, a); a = fmaf(bf_hi(wv[r].x), x1, a);
+        a = fmaf(bf_lo(wv[r].y), x2, a); a = fmaf(bf_hi(wv[r].y), x3, a);
+        a = fmaf(bf_lo(wv[r].z), x4, a); a = fmaf(bf_hi(wv[r].z), x5, a);
+        a = fmaf(bf_lo(wv[r].w), x6, a); a = fmaf(bf_hi(wv[r].w), x7, a);
+        acc[r][b] = a;
+      }
+    }
+  };
+  int k = lane * 8;
+  for (; k + 1536 < K; k += 2048) {  // four chunks per trip: 4 * GV_RW 16-byte loads in flight per lane
+    step(k);
+    step(k + 512);
+    step(k + 1024);
+    step(k + 1536);
+  }
+  for (; k < K; k += 512) step(k);
+
+#pragma unroll
+  for (int r = 0; r < GV_RW; ++r)
+#pragma unroll
+    for (int b = 0; b < MX; ++b) acc[r][b] = wave_sum(acc[r][b]);
+  if (lane == 0) {
+    const bf16_raw* bias = (const bf16_raw*)p.bias;
+#pragma unroll
+    for (int r = 0; r < GV_RW; ++r) {
+      const int n = n0 + r;
+      if (n >= p.N) continue;
+#pragma unroll
+      for (int b = 0; b < MX; ++b) {
+        float v = acc[r][b];
+        if (bias) v += bf2f(bias[n]);
+        v = act_apply(p.act, v);
+        if (p.residual) v += bf2f(((const bf16_raw*)p.residual)[(int64_t)b * p.ldr + n]);
+        if (p.y_dtype == GROVE_BF16) ((bf16_raw*)p.y)[(int64_t)b * p.ldy + n] = f2bf(v);
+        else ((float*)p.y)[(int64_t)b * p.ldy + n] = v;
+      }
+    }
+  }
+}
+
+template <int MX, int RW>
+int launch_gemv_rw(const grove_gemv_params& p, hipStream_t s) {
+  const size_t lds = (size_t)MX * p.K * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)gemv_kernel<MX, RW>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);  // + the static reduction scratch
+    attr_set = true;
+  }
+  const int rows_per_block = (GV_THREADS / 64) * RW;
+  hipLaunchKernelGGL((gemv_kernel<MX, RW>), dim3((p.N + rows_per_block - 1) / rows_per_block), dim3(GV_THREADS), lds, s, p);
+  GROVE_LAUNCH_CHECK();
+  return GROVE_OK;
+}
+template <int MX>
+int launch_gemv(const grove_gemv_params& p, hipStream_t s) {
+  // 4 rows per wave amortise the x reads; below ~3 blocks per CU take 2 rows per wave for more loads in flight
+  return p.N >= 12288 ? launch_gemv_rw<MX, 4>(p, s) : launch_gemv_rw<MX, 2>(p, s);
+}
+}  // namespace
+
+extern "C" int grove_gemv_bf16(const grove_gemv_params* pp, void* stream) {
+  GROVE_CHECK(pp != nullptr, GROVE_E_SHAPE, "gemv: null params");
+  const grove_gemv_params& p = *pp;
+  GROVE_CHECK(p.M >= 1 && p.M <= 8, GROVE_E_SHAPE, "gemv: M=%d must be 1..8 (use grove_gemm_bf16 beyond)", p.M);
+  GROVE_CHECK(p.N > 0 && p.K > 0 && p.K % 8 == 0, GROVE_E_SHAPE, "gemv: N=%d K=%d (K must be a multiple of 8)", p.N, p.K);
+  GROVE_CHECK((size_t)(p.M <= 2 ? p.M : p.M <= 4 ? 4 : 8) * p.K * 2 <= 159 * 1024, GROVE_E_SHAPE, "gemv: M*K=%d*%d does not fit the LDS", p.M, p.K);
+  GROVE_CHECK(p.ldx % 8 == 0 && p.ldw % 8 == 0, GROVE_E_ALIGN, "gemv: ldx=%d ldw=%d must be multiples of 8", p.ldx, p.ldw);
+  GROVE_CHECK(((uintptr_t)p.x & 15) == 0 && ((uintptr_t)p.W & 15) == 0, GROVE_E_ALIGN, "gemv: x/W must be 16-byte aligned");
+  GROVE_CHECK(p.y_dtype == GROVE_BF16 || p.y_dtype == GROVE_F32, GROVE_E_DTYPE, "gemv: bad y_dtype %d", p.y_dtype);
+  GROVE_CHECK(p.x_mode >= GROVE_GEMV_X_PLAIN && p.x_mode <= GROVE_GEMV_X_SWIGLU, GROVE_E_SHAPE, "gemv: bad x_mode %d", p.x_mode);
+  GROVE_CHECK(p.x_mode != GROVE_GEMV_X_RMSNORM || p.norm_weight, GROVE_E_SHAPE, "gemv: x_mode rmsnorm needs norm_weight");
+  hipStream_t s = (hipStream_t)stream;
+  switch (p.M) {
+    case 1: return launch_gemv<1>(p, s);
+    case 2: return launch_gemv<2>(p, s);
+    case 3: case 4: return launch_gemv<4>(p, s);
+    default: return launch_gemv<8>(p, s);
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------------------------
+// Fused decode attention: RoPE(q, k) + cache append + one-query attention. One block per (sequence, head).
+// Scores: thread j handles key j (+256 per pass): 16-byte loads of the key row against q in LDS (broadcast reads).
+// Values: 16 lanes cover one value row (16 B each), 16 rows per pass; the 16 partial sums are reduced through LDS.
+// HBM-bound on the cache read (2 * S * H * hd * 2 B per layer per sequence).
+// ----------------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int DA_THREADS = 256;
+constexpr int DA_MAXS = 4096;  // scores kept in LDS
+
+template <int HD>
+__global__ __launch_bounds__(DA_THREADS) void decode_attn_kernel(const grove_decode_attn_params p) {
+  __shared__ float q_s[HD];
+  __shared__ float sc[DA_MAXS];
+  __shared__ float red[DA_THREADS / 64];
+  __shared__ float part[16][HD + 1];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
+  const int t = p.pos[b];  // the new token's position; keys 0..t are visible
+  const int HH = p.H * HD;
+  bf16_raw* qkv = (bf16_raw*)p.qkv + (int64_t)b * p.ld_qkv;
+  bf16_raw* kc = (bf16_raw*)p.cache + ((int64_t)b * p.S_max) * 2 * HH + h * HD;  // key row j at kc + j * 2HH; value at + HH
+  // rotate q (-> LDS, fp32 of the bf16-rounded value, as the unfused path stores it) and k (-> cache), copy v
+  if (tid < HD / 2) {
+    const float inv_freq = powf(p.theta, -2.f * (float)tid / (float)HD);
+    float sn, cs;
+    sincosf((float)t * inv_freq, &sn, &cs);
+    const bf16_raw* q = qkv + h * HD;
+    const float q1 = bf2f(q[tid]), q2 = bf2f(q[tid + HD / 2]);
+    q_s[tid] = bf2f(f2bf(q1 * cs - q2 * sn));
+    q_s[tid + HD / 2] = bf2f(f2bf(q2 * cs + q1 * sn));
+    const bf16_raw* k = qkv + HH + h * HD;
+    const float k1 = bf2f(k[tid]), k2 = bf2f(k[tid + HD / 2]);
+    kc[(int64_t)t * 2 * HH + tid] = f2bf(k1 * cs - k2 * sn);
+    kc[(int64_t)t * 2 * HH + tid + HD / 2] = f2bf(k2 * cs + k1 * sn);
+  } else if (tid < HD / 2 + HD / 8) {
+    const int c = tid - HD / 2;
+    *(u32x4_t*)(kc + (int64_t)t * 2 * HH + HH + c * 8) = *(const u32x4_t*)(qkv + 2 * HH + h * HD + c * 8);
+  }
+  __syncthreads();  // block-wide visibility of the appended row (same block reads it back below)
+  __threadfence_block();
+  const int Lk = t + 1;
+  float mx = -INFINITY;
+  for (int j = tid; j < Lk; j += DA_THREADS) {
+    const bf16_raw* kr = kc + (int64_t)j * 2 * HH;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < HD / 8; ++c) {
+      const u32x4_t kv = *(const u32x4_t*)(kr + c * 8);
+      s = fmaf(bf_lo(kv.x), q_s[c * 8 + 0], s); s = fmaf(bf_hi(kv.x), q_s[c * 8 + 1], s);
+      s = fmaf(bf_lo(kv.y), q_s[c * 8 + 2], s); s = fmaf(bf_hi(kv.y), q_s[c * 8 + 3], s);
+      s = fmaf(bf_lo(kv.z), q_s[c * 8 + 4], s); s = fmaf(bf_hi(kv.z), q_s[c * 8 + 5], s);
+      s = fmaf(bf_lo(kv.w), q_s[c * 8 + 6], s); s = fmaf(bf_hi(kv.w), q_s[c * 8 + 7], s);
+    }
+    s *= p.alpha;
+    sc[j] = s;
+    mx = fmaxf(mx, s);
+  }
+  mx = block_max<DA_THREADS>(mx, red);
+  float sum = 0.f;
+  for (int j = tid; j < Lk; j += DA_THREADS) {
+    const float e = __expf(sc[j] - mx);
+    sc[j] = e;
+    sum += e;
+  }
+  sum = block_sum<DA_THREADS>(sum, red);  // (its barriers also publish sc[])
+  const float inv = 1.f / sum;
+  // o[d] = sum_j p_j v_j[d]: lane group g = tid / (HD/8) takes rows j = g, g + G, ...; chunk c = tid % (HD/8)
+  constexpr int CPR = HD / 8;           // 16-byte chunks per row
+  constexpr int G = DA_THREADS / CPR;   // rows per pass (16 for hd 128, 32 for hd 64)
+  const int g = tid / CPR, c = tid - g * CPR;
+  float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  auto pv = [&](float pj, const u32x4_t vv) {
+    o[0] = fmaf(pj, bf_lo(vv.x), o[0]); o[1] = fmaf(pj, bf_hi(vv.x), o[1]);
+    o[2] = fmaf(pj, bf_lo(vv.y), o[2]); o[3] = fmaf(pj, bf_hi(vv.y), o[3]);
+    o[4] = fmaf(pj, bf_lo(vv.z), o[4]); o[5] = fmaf(pj, bf_hi(vv.z), o[5]);
+    o[6] = fmaf(pj, bf_lo(vv.w), o[6]); o[7] = fmaf(pj, bf_hi(vv.w), o[7]);
+  };
+  const bf16_raw* vbase = kc + HH + c * 8;
+  int j = g;
+  for (; j + 7 * G < Lk; j += 8 * G) {  // 8 value rows in flight per lane
+    u32x4_t vv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) vv[u] = *(const u32x4_t*)(vbase + (int64_t)(j + u * G) * 2 * HH);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) pv(sc[j + u * G], vv[u]);
+  }
+  for (; j < Lk; j += G) pv(sc[j], *(const u32x4_t*)(vbase + (int64_t)j * 2 * HH));
+  // reduce the G row groups, 16 at a time, through the LDS scratch
+  for (int base = 0; base < G; base += 16) {
+    __syncthreads();
+    if (g >= base && g < base + 16) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) part[g - base][c * 8 + e] = o[e];
+    }
+    __syncthreads();
+    if (tid < HD) {
+      float a = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a += part[r][tid];
+      if (base == 0) q_s[tid] = a;  // q is dead: reuse as the accumulator
+      else q_s[tid] += a;
+    }
+  }
+  __syncthreads();
+  if (tid < HD) ((bf16_raw*)p.out)[(int64_t)b * HH + h * HD + tid] = f2bf(q_s[tid] * inv);
+}
+}  // namespace
+
+extern "C" int grove_decode_attn(const grove_decode_attn_params* pp, void* stream) {
+  GROVE_CHECK(pp != nullptr, GROVE_E_SHAPE, "decode_attn: null params");
+  const grove_decode_attn_params& p = *pp;
+  GROVE_CHECK(p.B > 0 && p.H > 0 && (p.hd == 64 || p.hd == 128 || p.hd == 32), GROVE_E_SHAPE, "decode_attn: B=%d H=%d hd=%d (hd must be 32, 64 or 128)", p.B, p.H, p.hd);
+  GROVE_CHECK(p.S_max > 0 && p.S_max <= DA_MAXS, GROVE_E_SHAPE, "decode_attn: S_max=%d must be <= %d", p.S_max, DA_MAXS);
+  GROVE_CHECK(p.ld_qkv % 8 == 0 && ((uintptr_t)p.qkv & 15) == 0 && ((uintptr_t)p.cache & 15) == 0, GROVE_E_ALIGN, "decode_attn: qkv/cache alignment");
+  hipStream_t s = (hipStream_t)stream;
+  if (p.hd == 128) hipLaunchKernelGGL(decode_attn_kernel<128>, dim3(p.B * p.H), dim3(DA_THREADS), 0, s, p);
+  else if (p.hd == 64) hipLaunchKernelGGL(decode_attn_kernel<64>, dim3(p.B * p.H), dim3(DA_THREADS), 0, s, p);
+  else hipLaunchKernelGGL(decode_attn_kernel<32>, dim3(p.B * p.H), dim3(DA_THREADS), 0, s, p);
+  GROVE_LAUNCH_CHECK();
+  return GROVE_OK;
+}

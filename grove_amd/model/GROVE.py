@@ -151,7 +151,7 @@ class GROVEForCausalLM(torch.nn.Module):
                                  kwargs["image_embeddings"], kwargs["input_ids"], kwargs["original_size_list"],
                                  max_tokens_new=kwargs["max_tokens_new"], bboxes=kwargs.get("bboxes"),
                                  token_embeddings=kwargs.get("token_embeddings"), dense_pe=kwargs.get("dense_pe"),
-                                 device=kwargs.get("device"))
+                                 device=kwargs.get("device"), use_cache=kwargs.get("use_cache", True))
         return self.model_forward(**kwargs)
 
     def encode_images(self, images, tape=None):
@@ -477,9 +477,14 @@ class GROVEForCausalLM(torch.nn.Module):
 
     # ------------------------------------------------------------------ generation (GROVE.py:412-451)
     @torch.no_grad()
-    def generate_greedy(self, image_features, input_ids, max_new_tokens, token_embeddings=None, eos_token_id=None, pad_token_id=None):
-        """HF greedy decoding (num_beams=1, do_sample=False) restated: rows finish at eos and are padded with
-        pad; returns (sequences incl. -200, hidden of every fed position [B, L+575+new-1, H])."""
+    def generate_greedy(self, image_features, input_ids, max_new_tokens, token_embeddings=None, eos_token_id=None, pad_token_id=None,
+                        use_cache=True, use_graph=True):
+        """HF greedy decoding (num_beams=1, do_sample=False; GROVE.py:418-422) restated: rows finish at eos and are padded with
+        pad; returns (sequences incl. -200, hidden of every fed position [B, L+575+new-1, H]).
+        use_cache=True (the reference's setting): one prefill over the spliced prompt fills the per-layer KV cache, then every
+        step feeds ONE token per sequence through the weight-streaming GEMV path (llava_llama.py:144-180). use_cache=False
+        recomputes the whole sequence every step (kept as the second implementation for the tests). The generate callers
+        feed un-padded equal-length prompts (quirk Q9), which is what the cached path assumes."""
         d = self.dims
         eos = d.eos_token_id if eos_token_id is None else eos_token_id
         pad = d.pad_token_id if pad_token_id is None else pad_token_id
@@ -487,29 +492,67 @@ class GROVEForCausalLM(torch.nn.Module):
         B = ids.shape[0]
         finished = torch.zeros(B, dtype=torch.bool, device=ids.device)
         feats = image_features.reshape(-1, image_features.shape[-1])
-        hidden = None
-        S = 0
-        for _ in range(max_new_tokens):
-            plan = self._splice_plan(ids, None, None, list(range(B)))
-            x = self._embed(plan, feats, token_embeddings)
-            hidden, _ = self.llama.forward(x, plan.B, plan.S)
-            S = plan.S
-            last = torch.empty((B, d.hidden), dtype=bf, device=self.dev)
-            ops.copy_rows(hidden, last, B, d.hidden, idx_src=(torch.arange(B, dtype=torch.int32, device=self.dev) * S + S - 1))
-            logits = ops.linear(last, self._sd["lm_head.weight"], out_dtype=torch.float32)
+        lm_head = self._sd["lm_head.weight"]
+        embed = token_embeddings if token_embeddings is not None else self._sd["model.embed_tokens.weight"]
+
+        def pick(last):
+            logits = ops.gemv(last, lm_head, out_dtype=torch.float32) if B <= 8 else ops.linear(last, lm_head, out_dtype=torch.float32)
             nxt = logits.argmax(-1).to(ids.device)  # argmax over one [B, V] row block (index selection, not arithmetic)
-            nxt = torch.where(finished, torch.full_like(nxt, pad), nxt)
+            return torch.where(finished, torch.full_like(nxt, pad), nxt)
+
+        if not use_cache or B > 8:
+            hidden, S = None, 0
+            for _ in range(max_new_tokens):
+                plan = self._splice_plan(ids, None, None, list(range(B)))
+                x = self._embed(plan, feats, token_embeddings)
+                hidden, _ = self.llama.forward(x, plan.B, plan.S)
+                S = plan.S
+                last = torch.empty((B, d.hidden), dtype=bf, device=self.dev)
+                ops.copy_rows(hidden, last, B, d.hidden, idx_src=(torch.arange(B, dtype=torch.int32, device=self.dev) * S + S - 1))
+                nxt = pick(last)
+                ids = torch.cat([ids, nxt[:, None]], 1)
+                finished = finished | (nxt == eos)
+                if bool(finished.all()):
+                    break
+            return ids, hidden.view(B, S, d.hidden)
+
+        plan = self._splice_plan(ids, None, None, list(range(B)))
+        S0 = plan.S
+        cache = self.llama.new_kv_cache(B, S0 + max_new_tokens)
+        x = self._embed(plan, feats, token_embeddings)
+        h0, _ = self.llama.forward(x, B, S0, kv_cache=cache)
+        hiddens = [h0.view(B, S0, d.hidden)]
+        last = torch.empty((B, d.hidden), dtype=bf, device=self.dev)
+        ops.copy_rows(h0, last, B, d.hidden, idx_src=(torch.arange(B, dtype=torch.int32, device=self.dev) * S0 + S0 - 1))
+        step_fn = None
+        logits = None
+        for step in range(max_new_tokens):
+            if logits is None:
+                nxt = pick(last)
+            else:
+                nxt = logits.argmax(-1).to(ids.device)
+                nxt = torch.where(finished, torch.full_like(nxt, pad), nxt)
             ids = torch.cat([ids, nxt[:, None]], 1)
             finished = finished | (nxt == eos)
-            if bool(finished.all()):
-                break
-        return ids, hidden.view(B, S, d.hidden)
+            if bool(finished.all()) or step == max_new_tokens - 1:
+                break  # the last generated token is never fed back (quirk Q3)
+            xt = torch.empty((B, d.hidden), dtype=bf, device=self.dev)
+            ops.copy_rows(embed, xt, B, d.hidden, idx_src=nxt.to(self.dev).to(torch.int32))
+            if use_graph:
+                if step_fn is None:
+                    step_fn = self.llama.decode_graph(B, cache, lm_head)
+                last, logits = step_fn(xt, S0 + step)
+            else:
+                last, logits = self.llama.decode_step(xt, S0 + step, cache, lm_head)
+            hiddens.append(last.view(B, 1, d.hidden).clone())
+        return ids, torch.cat(hiddens, 1)
 
     @torch.no_grad()
     def evaluate(self, image_features, image_forward_outs, images_dtype, image_embeddings, input_ids, orig_sizes,
-                 max_tokens_new=32, bboxes=None, token_embeddings=None, dense_pe=None, device=None):
+                 max_tokens_new=32, bboxes=None, token_embeddings=None, dense_pe=None, device=None, use_cache=True):
         d = self.dims
-        ids, hidden = self.generate_greedy(image_features, input_ids, max_tokens_new, token_embeddings)
+        ids, hidden = self.generate_greedy(image_features, input_ids, max_tokens_new, token_embeddings, use_cache=use_cache)
+        hidden = hidden.contiguous()
         B, S, H = hidden.shape
         det_rows, counts = self._det_rows(ids.cpu(), S, trailing_pad=False)
         Tseq = self.config.num_frames

@@ -30,17 +30,20 @@ class LlamaStack:
             self.layers.append(L)
         self.norm = sd["model.norm.weight"]
 
-    def forward(self, x, B, S, kv_len=None, save=False):
+    def forward(self, x, B, S, kv_len=None, save=False, kv_cache=None):
         """x: bf16 [B*S, H] input embeddings (consumed / overwritten). kv_len: int32 [B] valid lengths or None.
-        Returns (final-norm hidden [B*S, H], ctx)."""
+        kv_cache: optional list (one per layer) of bf16 [B, S_max, 2H] tensors that receive the rotated keys | values of
+        positions 0..S-1 (the prefill of a cached decode). Returns (final-norm hidden [B*S, H], ctx)."""
         d = self.d
         H, nh, hd, I = d.hidden, d.n_heads, d.head_dim, d.mlp
         pos = torch.arange(S, dtype=torch.int32, device=self.dev).repeat(B)
         saved = []
-        for L in self.layers:
+        for li, L in enumerate(self.layers):
             h = ops.rmsnorm(x, L["ln1"], d.rms_eps)
             qkv = ops.linear(h, L["wqkv"])
             ops.rope_(qkv, pos, 0, 2 * nh, hd, d.rope_theta)
+            if kv_cache is not None:
+                kv_cache[li][:, :S].copy_(qkv.view(B, S, 3 * H)[:, :, H:])
             o, actx = attention_fwd(qkv, B, S, nh, hd, 0, H, 2 * H, hd ** -0.5, causal=True, kv_len=kv_len, save=save)
             x1 = ops.linear(o, L["wo"], residual=x)
             h2 = ops.rmsnorm(x1, L["ln2"], d.rms_eps)
@@ -53,6 +56,57 @@ class LlamaStack:
         out = ops.rmsnorm(x, self.norm, d.rms_eps)
         ctx = (saved, x, pos, B, S) if save else None
         return out, ctx
+
+    def new_kv_cache(self, B, S_max):
+        d = self.d
+        # zero-filled: the graph-replayed step reads whole 64-key tiles and masks by kv_len; 0 * stale NaN would poison P V
+        return [torch.zeros((B, S_max, 2 * d.hidden), dtype=torch.bfloat16, device=self.dev) for _ in self.layers]
+
+    def _decode_body(self, x, pos, kv_cache, lm_head=None):
+        """The launches of one cached step: five per layer — RMSNorm folded into the q|k|v GEMV, RoPE + cache append +
+        one-query attention in one kernel, o_proj GEMV (+residual), RMSNorm folded into the gate|up GEMV, SwiGLU folded into
+        the down GEMV (+residual). Everything that changes from step to step (the position) is DEVICE data, so the same
+        sequence can be replayed from a captured HIP graph."""
+        d = self.d
+        nh, hd = d.n_heads, d.head_dim
+        for L, kv in zip(self.layers, kv_cache):
+            qkv = ops.gemv(x, L["wqkv"], rms_weight=L["ln1"], eps=d.rms_eps)
+            o = ops.decode_attn(qkv, kv, pos, nh, hd, d.rope_theta, hd ** -0.5)
+            x1 = ops.gemv(o, L["wo"], residual=x)
+            gu = ops.gemv(x1, L["wgu"], rms_weight=L["ln2"], eps=d.rms_eps)
+            x = ops.gemv(gu, L["wd"], residual=x1, swiglu=True)
+        out = ops.rmsnorm(x, self.norm, d.rms_eps)
+        logits = ops.gemv(x, lm_head, out_dtype=torch.float32, rms_weight=self.norm, eps=d.rms_eps) if lm_head is not None else None
+        return out, logits
+
+    def decode_step(self, x, t, kv_cache, lm_head=None):
+        """One cached step (HF use_cache=True): x bf16 [B, H] = embedding of the token at position t (the cache holds positions
+        0..t-1). Every projection is the weight-streaming GEMV; attention is one query row per (sequence, head) against the
+        cache. Returns (final-norm hidden [B, H], fp32 logits or None)."""
+        pos = torch.full((x.shape[0],), t, dtype=torch.int32, device=self.dev)
+        return self._decode_body(x, pos, kv_cache, lm_head)
+
+    def decode_graph(self, B, kv_cache, lm_head=None):
+        """Capture one cached step in a HIP graph (a step is ~420 launches of a few microseconds each: launch-bound from
+        Python) and return step(x, t) -> (hidden, logits) that replays it."""
+        dev, H = self.dev, self.d.hidden
+        x_in = torch.zeros((B, H), dtype=torch.bfloat16, device=dev)
+        pos = torch.zeros(B, dtype=torch.int32, device=dev)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # warm-up outside the capture: first-call attribute setup of every kernel
+            self._decode_body(x_in, pos, kv_cache, lm_head)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out, logits = self._decode_body(x_in, pos, kv_cache, lm_head)
+
+        def step(x, t):
+            x_in.copy_(x)
+            pos.fill_(t)
+            graph.replay()
+            return out, logits
+        return step
 
     def backward(self, ctx, d_out):
         """dgrad through the frozen stack. d_out: bf16 [B*S, H] gradient of the post-norm hidden.

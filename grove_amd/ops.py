@@ -223,6 +223,64 @@ def flash_attn(qkv, B, L, H, hs, q_off, k_off, v_off, alpha, *, causal=False, kv
     return out, lse
 
 
+
+def gemv(x, w, bias=None, *, act=ACT_NONE, residual=None, out_dtype=bf16, out=None, rms_weight=None, eps=0.0, swiglu=False):
+    """y = act(x' @ w.T + bias) + residual for 1..8 rows of x (the cached decode step): the weight-streaming kernel.
+    x' = x, or rmsnorm(x) * rms_weight (rms_weight given), or silu(gate) * up of a fused [M, 2K] row (swiglu=True)."""
+    _chk_dev(x, w)
+    M = x.shape[0]
+    N, K = w.shape
+    assert x.shape[1] == (2 * K if swiglu else K) and x.stride(1) == 1 and w.stride(1) == 1
+    mx = 1 if M == 1 else 2 if M == 2 else 4 if M <= 4 else 8
+    if mx != M:  # the kernel reads mx rows
+        xp = torch.zeros((mx, x.shape[1]), dtype=bf16, device=x.device)
+        xp[:M] = x
+        x = xp
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=x.device)
+    p = _lib.GemvParams()
+    p.x, p.W, p.y, p.bias, p.residual = _p(x), _p(w), _p(out), _p(bias), _p(residual)
+    p.M, p.N, p.K = M, N, K
+    p.ldx, p.ldw, p.ldy = x.stride(0), w.stride(0), out.stride(0)
+    p.ldr = residual.stride(0) if residual is not None else 0
+    p.act = act
+    p.y_dtype = F32 if out.dtype == torch.float32 else BF16
+    p.norm_weight, p.eps = _p(rms_weight), float(eps)
+    p.x_mode = 2 if swiglu else 1 if rms_weight is not None else 0
+    _lib.check(_lib.lib().grove_gemv_bf16(C.byref(p), _stream()), "grove_gemv_bf16")
+    return out
+
+
+def decode_attn(qkv, cache, pos, H, hd, theta, alpha, out=None):
+    """RoPE(q, k) + cache append + one-query attention for the new token of every sequence (grove_decode_attn)."""
+    B, S_max = cache.shape[0], cache.shape[1]
+    if out is None:
+        out = torch.empty((B, H * hd), dtype=bf16, device=qkv.device)
+    p = _lib.DecodeAttnParams()
+    p.qkv, p.cache, p.out, p.pos = _p(qkv), _p(cache), _p(out), _p(pos)
+    p.B, p.H, p.hd, p.S_max, p.ld_qkv = B, H, hd, S_max, qkv.stride(0)
+    p.theta, p.alpha = float(theta), float(alpha)
+    _lib.check(_lib.lib().grove_decode_attn(C.byref(p), _stream()), "grove_decode_attn")
+    return out
+
+
+def flash_attn_kv(q, k, v, B, H, Lq, Lk, hs, alpha, *, sq, sk, sv, ld_q, ld_k, ld_v, causal=False, kv_len=None, out=None):
+    """Fused attention with separate q / k / v views (decode: one query row per sequence against the KV cache).
+    q: [B*Lq rows]; k, v: views whose batch stride is sk / sv elements; returns out [B*Lq, H*hs]."""
+    if out is None:
+        out = torch.empty((B * Lq, H * hs), dtype=bf16, device=q.device)
+    p = _lib.FlashAttnParams()
+    p.q, p.k, p.v, p.o = _p(q), _p(k), _p(v), _p(out)
+    p.kv_len = _p(kv_len)
+    p.sq, p.sk, p.sv = sq, sk, sv
+    p.so = Lq * out.stride(0)
+    p.B, p.H, p.Lq, p.Lk, p.hs = B, H, Lq, Lk, hs
+    p.ld_q, p.ld_k, p.ld_v = ld_q, ld_k, ld_v
+    p.ld_o = out.stride(0)
+    p.causal, p.alpha = int(causal), alpha
+    _lib.check(_lib.lib().grove_flash_attn_fwd(C.byref(p), _stream()), "grove_flash_attn_fwd")
+    return out
+
 def flash_attn_bwd(qkv, out, d_out, lse, dqkv, B, L, H, hs, q_off, k_off, v_off, alpha, *, causal=False, kv_len=None, rel=None,
                    rel_hw=(0, 0), want_drel=False):
     dev = qkv.device

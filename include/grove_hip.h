@@ -270,6 +270,49 @@ typedef struct grove_rope_params {
 int grove_rope_inplace(const grove_rope_params* p, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Weight-streaming GEMV for the cached greedy-decode step (HF `generate(use_cache=True)` feeds one
+ * token per sequence after step 0: llava_llama.py:144-180, GROVE.py:418-422).
+ *   y[b, n] = act( sum_k x[b, k] * W[n, k] + bias[n] ) + residual[b, n],  1 <= M <= 8 rows
+ * x: bf16 [M, ldx]; W: bf16 [N, ldw] (nn.Linear layout); y: bf16 or f32 [M, ldy]. HBM-bound: every
+ * weight byte is read once. For M of 3 (5..7) the kernel reads 4 (8) x rows: x must have that many
+ * addressable rows (the wrapper pads).
+ * ------------------------------------------------------------------------------------------ */
+enum grove_gemv_x_mode {
+  GROVE_GEMV_X_PLAIN = 0,
+  GROVE_GEMV_X_RMSNORM = 1, /* x' = bf16(x * rsqrt(mean(x^2) + eps) * norm_weight): the layer's RMSNorm folded into the load */
+  GROVE_GEMV_X_SWIGLU = 2   /* x is a fused [M, 2K] gate|up row; x' = bf16(silu(gate) * up): LlamaMLP's product folded in */
+};
+typedef struct grove_gemv_params {
+  const void* x;
+  const void* W;
+  void* y;
+  const void* bias;        /* bf16 [N] or NULL */
+  const void* residual;    /* bf16 [M, ldr] or NULL */
+  const void* norm_weight; /* bf16 [K], x_mode RMSNORM */
+  int32_t M, N, K;
+  int32_t ldx, ldw, ldy, ldr;
+  int32_t act;     /* GROVE_ACT_* */
+  int32_t y_dtype; /* GROVE_BF16 / GROVE_F32 */
+  int32_t x_mode;  /* grove_gemv_x_mode */
+  float eps;
+} grove_gemv_params;
+int grove_gemv_bf16(const grove_gemv_params* p, void* stream);
+
+/* One cached decode step of causal self-attention for ONE new token per sequence (HF LlamaAttention with a KV cache):
+ * rotates q and k of the new token in place (rotate-half RoPE at position pos[b], fp32), appends k | v to the cache row
+ * pos[b] and attends the query to cache rows 0..pos[b]. qkv: bf16 [B, ld_qkv] = q | k | v (H heads of hd each);
+ * cache: bf16 [B, S_max, 2*H*hd] = keys | values; out: bf16 [B, H*hd]. hd must be 64 or 128. */
+typedef struct grove_decode_attn_params {
+  void* qkv;
+  void* cache;
+  void* out;
+  const int32_t* pos; /* [B] device */
+  int32_t B, H, hd, S_max, ld_qkv;
+  float theta, alpha;
+} grove_decode_attn_params;
+int grove_decode_attn(const grove_decode_attn_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Elementwise / data-movement kernels (all bf16, vectorised 16 B per lane).
  * ------------------------------------------------------------------------------------------ */
 /* y = silu(gate) * up over a fused [rows, 2*I] gate|up activation (HF LlamaMLP) */

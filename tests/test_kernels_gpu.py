@@ -590,3 +590,73 @@ def test_gemm_tile_variants(dev, M, N, K, tile_n, tile_m):
     finally:
         ops.gemm_set_tile_n(0)
         _lib.lib().grove_gemm_set_tile_m(0)
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 300, 512), (2, 4096, 4096), (3, 1000, 1096), (4, 515, 11008), (7, 64, 256), (8, 320, 128)])
+def test_gemv_decode(dev, M, N, K):
+    """grove_gemv_bf16 (cached decode step) vs fp32 reference, with bias / activation / residual / fp32 output."""
+    from grove_amd import ops
+    x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05)
+    bias, res = rnd(N, seed=3), rnd(M, N, seed=4)
+    ref = x.float() @ w.float().t()
+    y = ops.gemv(x.to(dev), w.to(dev))
+    close(y, ref, 2 ** -7, "gemv plain")
+    y = ops.gemv(x.to(dev), w.to(dev), bias.to(dev), act=ops.ACT_RELU, residual=res.to(dev))
+    close(y, F.relu(ref + bias.float()) + res.float(), 2 ** -7, "gemv bias+relu+residual")
+    y = ops.gemv(x.to(dev), w.to(dev), out_dtype=torch.float32)
+    close(y, ref, 1e-5, "gemv f32")
+    # the tile GEMM on the same operands: both accumulate in fp32, results agree to bf16 rounding
+    close(y, ops.linear(x.to(dev), w.to(dev), out_dtype=torch.float32) if K % 32 == 0 else ref, 1e-5, "gemv vs gemm")
+
+
+@pytest.mark.parametrize("B,H,hd,Lk,Smax", [(2, 4, 32, 37, 64), (1, 8, 128, 700, 768), (3, 2, 64, 1, 16)])
+def test_flash_attention_decode_against_cache(dev, B, H, hd, Lk, Smax):
+    """One query row per sequence against a [B, S_max, 2H] key|value cache (LlamaStack.decode_step)."""
+    from grove_amd import ops
+    Hd = H * hd
+    qkv = rnd(B, 3 * Hd, seed=5)
+    kv = rnd(B, Smax, 2 * Hd, seed=6)
+    o = ops.flash_attn_kv(qkv.to(dev), kv.to(dev), kv.to(dev)[:, :, Hd:], B, H, 1, Lk, hd, hd ** -0.5, sq=3 * Hd, sk=Smax * 2 * Hd,
+                          sv=Smax * 2 * Hd, ld_q=3 * Hd, ld_k=2 * Hd, ld_v=2 * Hd)
+    q = qkv[:, :Hd].float().view(B, H, 1, hd)
+    k = kv[:, :Lk, :Hd].float().view(B, Lk, H, hd).permute(0, 2, 1, 3)
+    v = kv[:, :Lk, Hd:].float().view(B, Lk, H, hd).permute(0, 2, 1, 3)
+    ref = torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, -1) @ v
+    close(o.view(B, H, hd), ref.view(B, H, hd), 2 ** -7, "decode attention")
+
+
+def test_gemv_fused_rmsnorm_and_swiglu(dev):
+    """The decode step's folded input transforms: rmsnorm(x)*w and silu(gate)*up, against the standalone kernels."""
+    from grove_amd import ops
+    M, K, N = 2, 1024, 520
+    x, w, nw = rnd(M, K, seed=1).to(dev), rnd(N, K, seed=2, scale=0.05).to(dev), rnd(K, seed=3).to(dev)
+    y = ops.gemv(x, w, rms_weight=nw, eps=1e-5)
+    y_ref = ops.gemv(ops.rmsnorm(x, nw, 1e-5), w)
+    close(y, y_ref, 2 ** -8, "gemv rmsnorm-fused vs rmsnorm kernel + gemv")
+    xf = x.float().cpu()
+    ref = (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5) * nw.float().cpu()).to(bf16).float() @ w.float().cpu().t()
+    close(y, ref, 2 ** -7, "gemv rmsnorm-fused vs fp32")
+    gu = rnd(M, 2 * K, seed=4).to(dev)
+    y = ops.gemv(gu, w, swiglu=True)
+    close(y, ops.gemv(ops.swiglu(gu, K), w), 2 ** -8, "gemv swiglu-fused vs swiglu kernel + gemv")
+
+
+@pytest.mark.parametrize("B,H,hd,t,Smax", [(2, 4, 32, 36, 64), (1, 8, 128, 699, 768), (3, 2, 64, 0, 16), (2, 32, 128, 1500, 2048)])
+def test_decode_attention_fused(dev, B, H, hd, t, Smax):
+    """grove_decode_attn = rope(q, k) + cache append + one-query attention, vs the unfused kernels and fp32."""
+    from grove_amd import ops
+    Hd = H * hd
+    qkv = rnd(B, 3 * Hd, seed=5).to(dev)
+    cache = rnd(B, Smax, 2 * Hd, seed=6).to(dev)
+    pos = torch.full((B,), t, dtype=torch.int32, device=dev)
+    ref_qkv, ref_cache = qkv.clone(), cache.clone()
+    ops.rope_(ref_qkv, pos, 0, 2 * H, hd, 10000.0)
+    ref_cache[:, t] = ref_qkv[:, Hd:]
+    q = ref_qkv[:, :Hd].float().cpu().view(B, H, 1, hd)
+    k = ref_cache[:, :t + 1, :Hd].float().cpu().view(B, t + 1, H, hd).permute(0, 2, 1, 3)
+    v = ref_cache[:, :t + 1, Hd:].float().cpu().view(B, t + 1, H, hd).permute(0, 2, 1, 3)
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, -1) @ v).view(B, Hd)
+    o = ops.decode_attn(qkv, cache, pos, H, hd, 10000.0, hd ** -0.5)
+    close(o, ref, 2 ** -7, "fused decode attention")
+    assert torch.equal(cache[:, t], ref_cache[:, t]), "appended key|value row"
+    assert torch.equal(cache[:, :t], ref_cache[:, :t]) and torch.equal(cache[:, t + 1:], ref_cache[:, t + 1:])

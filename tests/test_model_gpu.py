@@ -152,3 +152,67 @@ def test_backward_matches_oracle_autograd(dev):
         if not (cos > 0.98 and lo < scale < hi):
             bad.append((n, round(cos, 4), round(scale, 4), float(r.norm())))
     assert not bad, f"{len(bad)}/{len(names)} gradients off: {bad[:12]}"
+
+
+def _flat(ll):
+    xs = [x.reshape(-1).float().cpu() for l_ in ll for x in l_]
+    return torch.cat(xs) if xs else torch.zeros(0)
+
+
+def test_greedy_evaluate_matches_golden(setup, dev):
+    """a17: evaluate() = greedy decode + DET gather (575 offset, no trailing pad) + boxes, against the reference's own
+    token ids (golden) and the oracle's boxes on the same generated ids."""
+    from grove_amd.synthetic import synthetic_batch
+    from oracle import grove_oracle as O
+    model, sd, d = setup
+    g = np.load(os.path.join(G, "tiny_evaluate_B2_T8_seed3.npz"))
+    batch = synthetic_batch(d, B=2, T=8, L=24, n_det=1, seed=3)
+    prompt = batch.input_ids[:, :int(g["prompt_len"])].clone()
+    gi = batch.global_enc_images.to(bf)
+    si = batch.grounding_enc_images.to(bf)
+    feats, outs = model(mode="encode_images", images=gi.to(dev))
+    emb = model(mode="get_grounding_encoder_embs", images=si.to(dev))
+    for cached in (False, True):
+        ids, boxes, logits = model(mode="evaluate", image_features=feats, image_forward_outs=outs, images_dtype=bf,
+                                   image_embeddings=emb, input_ids=prompt.to(dev), original_size_list=batch.original_size_list,
+                                   max_tokens_new=12, use_cache=cached)
+        assert (ids.cpu().numpy() == g["greedy_ids"]).all(), f"greedy ids differ (use_cache={cached})"
+    # cached and uncached decoding produce the same hidden states (every fed position, SURVEY.md §8c)
+    ids_u, hid_u = model.generate_greedy(feats, prompt.to(dev), 12, use_cache=False)
+    ids_c, hid_c = model.generate_greedy(feats, prompt.to(dev), 12, use_cache=True)
+    assert (ids_u == ids_c).all() and hid_u.shape == hid_c.shape
+    assert rel(hid_c, hid_u) < 3e-2
+    # the reference's forced-[DET] continuation: feed it as the prompt (the one generated token is never fed back, Q3), so the
+    # hidden states are the teacher-forced ones the golden boxes were decoded from
+    forced = torch.from_numpy(g["generated_ids"])
+    ids, boxes, logits = model(mode="evaluate", image_features=feats, image_forward_outs=outs, images_dtype=bf,
+                               image_embeddings=emb, input_ids=forced[:, :-1].to(dev), original_size_list=batch.original_size_list,
+                               max_tokens_new=1)
+    counts = np.array([[x.shape[0] for x in l_] for l_ in boxes])
+    assert (counts == g["pred_bboxes_counts"]).all()
+    assert (_flat(logits) - torch.from_numpy(g["logits_temp_objectness"])).abs().max().item() < 5e-2
+    assert (_flat(boxes) / 640 - torch.from_numpy(g["pred_bboxes"]) / 640).abs().mean().item() < 4e-3
+    with torch.no_grad():
+        feats_o, _ = O.encode_images(sd, d, gi.float())
+        emb_o = O.sam_image_encoder(sd, d, si.float())
+        _, boxes_o, logits_o, _, _ = O.evaluate(sd, d, feats_o, emb_o, forced[:, :-1], batch.original_size_list, max_tokens_new=1)
+    assert (_flat(logits) - _flat(logits_o)).abs().max().item() < 5e-2
+    assert (_flat(boxes) / 640 - _flat(boxes_o) / 640).abs().mean().item() < 2e-3
+
+
+def test_literal_T16_row_indexing(dev):
+    """Quirk Q1: with literal_T the b-th sample is fed the b-th 8-frame group of the pooled features."""
+    from dataclasses import replace
+    from grove_amd import GROVEForCausalLM
+    from grove_amd.synthetic import TINY, synthetic_batch, synthetic_state_dict
+    g = np.load(os.path.join(G, "tiny_infer_literalT16_seed4.npz"))
+    sd = synthetic_state_dict(TINY)
+    model = GROVEForCausalLM(dims=replace(TINY, num_frames=16), device=dev, state_dict=sd, det_token_idx=TINY.det_token_idx,
+                             num_frames=16, pe_dtype=torch.float32, literal_T=True)
+    batch = synthetic_batch(TINY, B=2, T=16, L=32, n_det=1, seed=4)
+    kw = to_dev(batch, dev)
+    kw["inference"] = True
+    out = model(**kw)
+    lo = _flat(out["logits_temp_objectness"])
+    assert lo.shape[0] == g["flat_logits"].shape[0]
+    assert (lo - torch.from_numpy(g["flat_logits"])).abs().max().item() < 6e-2

@@ -1,0 +1,52 @@
+"""Greedy-decode throughput of the cached path at full dimensions (1 GPU inference, T=8).
+Per generated token the 7B decoder's weights are read once (HBM-bound): achieved GB/s = weight bytes / time per token.
+Prints one JSON line; the summary is kept under profiles/."""
+import json
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+
+
+def main():
+    from grove_amd import GROVEForCausalLM, ops
+    from grove_amd.synthetic import FULL, synthetic_batch, synthetic_state_dict
+    dev = torch.device("cuda:0")
+    d = FULL
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    new = int(sys.argv[2]) if len(sys.argv) > 2 else 33
+    sd = synthetic_state_dict(d, device=dev, dtype=torch.bfloat16)
+    model = GROVEForCausalLM(dims=d, device=dev, state_dict=sd, det_token_idx=d.det_token_idx, num_frames=8)
+    del sd
+    batch = synthetic_batch(d, B=B, T=8, L=64, n_det=1, seed=5, device=dev, dtype=torch.bfloat16)
+    feats, _ = model(mode="encode_images", images=batch.global_enc_images)
+    prompt = batch.input_ids[:, :40].contiguous()
+
+    def run(n, cached):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ids, hid = model.generate_greedy(feats, prompt, n, eos_token_id=-1, use_cache=cached)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, ids
+
+    run(2, True)
+    t1, _ = run(1, True)          # prefill + first pick
+    t9, _ = run(9, True)          # + graph capture + 8 cached steps
+    tn, ids_c = run(new, True)    # + graph capture + (new - 1) cached steps
+    per_tok = (tn - t9) / (new - 9)
+    tu1, _ = run(1, False)
+    tu, ids_u = run(5, False)
+    per_tok_u = (tu - tu1) / 4
+    wbytes = 2.0 * (d.n_layers * (4 * d.hidden * d.hidden + 3 * d.hidden * d.mlp) + d.vocab * d.hidden)
+    out = {"metric": "greedy decode tokens/s (cached, B=%d, S0=%d)" % (B, 575 + prompt.shape[1]), "value": round(B / per_tok, 2),
+           "ms_per_token": round(per_tok * 1e3, 3), "prefill_ms": round(t1 * 1e3, 1), "graph_capture_ms": round((t9 - t1 - 8 * per_tok) * 1e3, 1), "uncached_ms_per_token": round(per_tok_u * 1e3, 1),
+           "roofline": {"bound": "hbm", "achieved": round(wbytes / per_tok / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                        "frac": round(wbytes / per_tok / 8e12, 3), "weight_bytes_per_token": wbytes},
+           "ids_equal_first5": bool((ids_c[:, :prompt.shape[1] + 5] == ids_u).all())}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

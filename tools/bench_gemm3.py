@@ -1,7 +1,7 @@
 """A/B of the 256x256 pipelined NT GEMM against the auto-selected tiles; checks results first."""
 import sys
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from grove_amd import ops, _lib
 dev = torch.device("cuda:0")
 L = _lib.lib()

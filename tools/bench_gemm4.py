@@ -1,7 +1,7 @@
 """Fixed-cost / per-K-tile fit of the pipelined 256 x 256 kernel: K sweep, with and without the epilogue (alpha == -12345 skips it)."""
 import sys
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from grove_amd import ops, _lib
 dev = torch.device("cuda:0")
 L = _lib.lib()

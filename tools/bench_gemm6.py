@@ -1,7 +1,7 @@
 """Is the 256x256 epilogue chip-bandwidth-bound or per-CU issue-bound? One-round launches at full / half / quarter chip, two K values -> fixed cost c."""
 import sys
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from grove_amd import ops, _lib
 dev = torch.device("cuda:0")
 L = _lib.lib()

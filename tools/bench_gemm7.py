@@ -1,7 +1,7 @@
 """Epilogue variants of the pipelined kernel vs the 128-row kernels: plain / bias+GELU+aux / bias+quickGELU+aux / residual."""
 import sys
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from grove_amd import ops, _lib
 dev = torch.device("cuda:0")
 L = _lib.lib()
