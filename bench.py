@@ -6,8 +6,8 @@ fine-tune, T=16, per-GPU batch=2, bf16"), config[3] for N>1.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One JSON line on rank 0. `value` = total frames/s over all ranks with inputs resident in HBM; `roofline`
-prices the dominant kernel (the bf16 MFMA GEMM) from HIP-event timings of every GEMM launch of one extra,
-untimed, instrumented step; `cpu_baseline` times the CPU oracle (a port, oracle/grove_oracle.py) on a bounded
+prices the dominant kernel (the persistent pipelined bf16 MFMA GEMM) from HIP-event timings of its own launches in one
+extra, untimed, instrumented step (the other GEMM kernels are summarised beside it); `cpu_baseline` times the CPU oracle (a port, oracle/grove_oracle.py) on a bounded
 sample of the same workload on the host cores. Synthetic data and random-init weights of the real
 architecture (no checkpoints offline).
 """
@@ -49,10 +49,13 @@ def make_batch(dims, dev, args, rank):
 
 def instrumented_gemm_pass(engine, batch):
     """One extra step with a HIP-event pair around every grove_gemm_bf16 launch (torch's current stream is the
-    stream the kernels are launched on). Returns (launches, algorithmic flops, device seconds)."""
-    from grove_amd import ops
+    stream the kernels are launched on). Returns per-kernel {variant: (launches, algorithmic flops, device seconds)}
+    keyed by the kernel the library actually launched (grove_gemm_last_variant)."""
+    from grove_amd import _lib, ops
     orig = ops.gemm_raw
     recs = []
+    names = {1: "gemm_nt_kernel<128x128>", 2: "gemm_nt_kernel<192x128>", 3: "gemm_nt_kernel<128x64>", 4: "gemm_nt_pp_kernel<256>",
+             5: "gemm_nt_pp_kernel<192>"}
 
     def timed(A, B, C, M, N, K, *a, **k):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -60,7 +63,8 @@ def instrumented_gemm_pass(engine, batch):
         r = orig(A, B, C, M, N, K, *a, **k)
         e1.record()
         b = k.get("batch", (1, 1))
-        recs.append((e0, e1, 2.0 * M * N * K * b[0] * b[1], (M, N, K, b[0] * b[1], k.get("a_taps", 1))))
+        recs.append((e0, e1, 2.0 * M * N * K * b[0] * b[1], (M, N, K, b[0] * b[1], k.get("a_taps", 1)),
+                     names.get(_lib.lib().grove_gemm_last_variant(), "?")))
         return r
     ops.gemm_raw = timed
     try:
@@ -70,18 +74,21 @@ def instrumented_gemm_pass(engine, batch):
         torch.cuda.synchronize()
     finally:
         ops.gemm_raw = orig
-    secs = sum(r[0].elapsed_time(r[1]) for r in recs) * 1e-3
+    per_kernel = {}
+    for e0, e1, f, key, var in recs:
+        n, fl, t = per_kernel.get(var, (0, 0.0, 0.0))
+        per_kernel[var] = (n + 1, fl + f, t + e0.elapsed_time(e1) * 1e-3)
     report = os.environ.get("GROVE_GEMM_REPORT")
     if report:
         agg = {}
-        for e0, e1, f, key in recs:
-            t, n, fl = agg.get(key, (0.0, 0, 0.0))
-            agg[key] = (t + e0.elapsed_time(e1), n + 1, fl + f)
+        for e0, e1, f, key, var in recs:
+            t, n, fl = agg.get(key + (var,), (0.0, 0, 0.0))
+            agg[key + (var,)] = (t + e0.elapsed_time(e1), n + 1, fl + f)
         with open(report, "w") as fh:
-            fh.write("M N K batch taps | launches total_ms TF/s\n")
+            fh.write("M N K batch taps kernel | launches total_ms TF/s\n")
             for key, (t, n, fl) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
                 fh.write(f"{key} | {n} {t:.3f} {fl / t / 1e9:.1f}\n")
-    return len(recs), sum(r[2] for r in recs), secs
+    return per_kernel
 
 
 def cpu_baseline(args):
@@ -223,7 +230,16 @@ def main():
     frames = world * args.batch * args.frames * args.steps
     loss = float(out["loss"])
 
-    n_launch, flops, secs = instrumented_gemm_pass(engine, batch)
+    per_kernel = instrumented_gemm_pass(engine, batch)
+    dom = max(per_kernel, key=lambda k: per_kernel[k][2])  # the kernel that takes most of the step
+    n_launch, flops, secs = per_kernel[dom]
+    all_n, all_f, all_s = (sum(v[i] for v in per_kernel.values()) for i in range(3))
+    traffic = None
+    try:  # memory-side bytes per launch from the committed PMC passes (profiles/, collected as the microarch guide prescribes)
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_gemm_traffic.json")) as fh:
+            traffic = json.load(fh)["launch_weighted_mean_bytes"].get(dom[dom.index("<"):])
+    except Exception:
+        pass
     if rank == 0:
         res = {
             "metric": "frames/sec (T=16 clip fwd+bwd)", "value": round(frames / dt, 3), "unit": "frames/s", "n_gpus": world,
@@ -235,10 +251,12 @@ def main():
                        "dims": args.dims, "global_batch_clips": world * args.batch, "frames_per_clip": args.frames,
                        "parallelism": f"dp{world}", "frames_per_sec_per_gpu": round(frames / dt / world, 3), "last_loss": round(loss, 4)},
             "roofline": {"bound": "mfma", "achieved": round(flops / secs / 1e12, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(flops / secs / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": None,
-                         "kernel": "gemm_nt_kernel<BK, LDS-DMA> (grove_gemm_bf16)", "launches_per_step": n_launch,
-                         "avg_launch_us": round(secs / n_launch * 1e6, 2), "flops_per_step": flops,
-                         "gemm_share_of_step": round(secs / (dt / args.steps), 3)},
+                         "frac": round(flops / secs / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                         "kernel": dom + " (grove_gemm_bf16)", "launches_per_step": n_launch,
+                         "avg_launch_us": round(secs / n_launch * 1e6, 2), "flops_per_launch": round(flops / n_launch),
+                         "share_of_step": round(secs / (dt / args.steps), 3),
+                         "all_gemm_kernels": {"launches_per_step": all_n, "flops_per_step": all_f, "achieved": round(all_f / all_s / 1e12, 2),
+                                              "share_of_step": round(all_s / (dt / args.steps), 3)}},
         }
         if not args.no_cpu_baseline:
             try:

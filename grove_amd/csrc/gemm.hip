@@ -711,6 +711,7 @@ inline double wave_util(long tiles, int per_cu) {
 // staging variant: 1 = LDS-DMA (default), 0 = register staged (kept for A/B and as the
 // conservative path); switchable at run time for in-process A/B (cdna guide §5.4 rule 24).
 static int g_gemm_glds = 1;
+static int g_gemm_last_variant = 0;  // kernel chosen by the last grove_gemm_bf16 call (see grove_gemm_last_variant)
 static int g_gemm_bk = 0;      // 0 = auto (64 when K allows), 32 = forced
 extern "C" int grove_gemm_set_bk(int bk) {
   g_gemm_bk = bk;
@@ -730,6 +731,8 @@ extern "C" int grove_gemm_set_staging(int use_lds_dma) {
   g_gemm_glds = use_lds_dma ? 1 : 0;
   return GROVE_OK;
 }
+
+extern "C" int grove_gemm_last_variant(void) { return g_gemm_last_variant; }
 
 extern "C" int grove_gemm_bf16(const grove_gemm_params* pp, void* stream) {
   GROVE_CHECK(pp != nullptr, GROVE_E_SHAPE, "gemm: null params");
@@ -791,12 +794,19 @@ extern "C" int grove_gemm_bf16(const grove_gemm_params* pp, void* stream) {
   const double cp256 = pp_cost(tp256, 1.5, 3.0 + 3.0 * out_scale);
   const double cp192 = pp_cost(tp192, 1.17, 0.8 * (3.0 + 3.0 * out_scale));
   const double c_old = c128 < c192 ? c128 : c192;
-  if (p256_ok && (g_gemm_tile_m == 193 || g_gemm_tile_m == 256)) return g_gemm_tile_m == 256 ? launch_pp<256>(p, s) : launch_pp<192>(p, s);
+  if (p256_ok && (g_gemm_tile_m == 193 || g_gemm_tile_m == 256)) {
+    g_gemm_last_variant = g_gemm_tile_m == 256 ? GROVE_GEMM_PP256 : GROVE_GEMM_PP192;
+    return g_gemm_tile_m == 256 ? launch_pp<256>(p, s) : launch_pp<192>(p, s);
+  }
   if (p256_ok && g_gemm_tile_m == 0 && g_gemm_tile_n == 0 && tp192 >= 48 && (cp256 < c_old || cp192 < c_old))
-    return cp256 <= cp192 ? launch_pp<256>(p, s) : launch_pp<192>(p, s);
+    {
+      g_gemm_last_variant = cp256 <= cp192 ? GROVE_GEMM_PP256 : GROVE_GEMM_PP192;
+      return cp256 <= cp192 ? launch_pp<256>(p, s) : launch_pp<192>(p, s);
+    }
   int variant = 128;
   if (g_gemm_tile_m == 192 || (g_gemm_tile_m == 0 && t128 > 300 && c192 <= c128)) variant = 192;
   const bool narrow = g_gemm_tile_n == 64 || (g_gemm_tile_n == 0 && t128 < 160 && p.N > 64);
+  g_gemm_last_variant = narrow ? GROVE_GEMM_T128X64 : variant == 192 && g_gemm_glds ? GROVE_GEMM_T192X128 : GROVE_GEMM_T128X128;
   if (narrow) {
     if (g_gemm_glds) return bk64 ? launch<64, true, 2, 4>(p, vec_ok, s) : launch<32, true, 2, 4>(p, vec_ok, s);
     return bk64 ? launch<64, false, 2, 4>(p, vec_ok, s) : launch<32, false, 2, 4>(p, vec_ok, s);

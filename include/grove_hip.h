@@ -88,6 +88,15 @@ typedef struct grove_gemm_params {
                          partials combined with fp32 atomics into the pre-initialised C */
 } grove_gemm_params;
 int grove_gemm_bf16(const grove_gemm_params* p, void* stream);
+/* Which kernel the last grove_gemm_bf16 call launched (measurement aid: bench.py prices each kernel on its own launches). */
+enum grove_gemm_variant {
+  GROVE_GEMM_T128X128 = 1, /* gemm_nt_kernel, 128 x 128 tile */
+  GROVE_GEMM_T192X128 = 2, /* gemm_nt_kernel, 192 x 128 tile */
+  GROVE_GEMM_T128X64 = 3,  /* gemm_nt_kernel, 128 x 64 tile */
+  GROVE_GEMM_PP256 = 4,    /* gemm_nt_pp_kernel<256>: persistent pipelined 256 x 256 x 64 */
+  GROVE_GEMM_PP192 = 5     /* gemm_nt_pp_kernel<192>: persistent pipelined 192 x 256 x 64 */
+};
+int grove_gemm_last_variant(void);
 /* A/B staging variant: 1 = LDS-DMA (global_load_lds, default), 0 = register staged */
 int grove_gemm_set_staging(int use_lds_dma);
 /* macro-tile N: 0 = auto (by wave quantisation), 64 or 128 = forced (for A/B measurements) */

@@ -216,3 +216,47 @@ def test_literal_T16_row_indexing(dev):
     lo = _flat(out["logits_temp_objectness"])
     assert lo.shape[0] == g["flat_logits"].shape[0]
     assert (lo - torch.from_numpy(g["flat_logits"])).abs().max().item() < 6e-2
+
+
+def test_sliding_window_inference_driver(setup, dev):
+    """(f)1: infer_clip = centre-window evaluate + ONE batched teacher-forced forward over the other windows, against
+    per-window calls of the same model and against the oracle driven the way infer_iground.py:150-288 drives the reference."""
+    from grove_amd.infer import infer_clip, sliding_segment_with_mask
+    from grove_amd.synthetic import synthetic_batch
+    from oracle import grove_oracle as O
+    model, sd, d = setup
+    F = 24
+    b = synthetic_batch(d, B=1, T=F, L=24, n_det=2, seed=11)
+    gi, si = b.global_enc_images.to(bf), b.grounding_enc_images.to(bf)
+    prompt = b.input_ids[0, :20].clone()
+    assert (prompt == d.det_token_idx).sum() >= 1 and (prompt == -200).sum() == 1
+    size = b.original_size_list[0]
+    res = infer_clip(model, gi.to(dev), si.to(dev), prompt, size, max_tokens_new=4)
+    windows, masks = sliding_segment_with_mask(F, 8)
+    assert res["frame_indices"] == list(range(F)) and res["windows"] == windows and res["centre"] == 1
+    # oracle, window by window (batch 1 each, as the reference does)
+    with torch.no_grad():
+        c = res["centre"]
+        feats_o, _ = O.encode_images(sd, d, gi.float()[:, :, windows[c]])
+        emb_o = O.sam_image_encoder(sd, d, si.float()[:, :, windows[c]])
+        ids_o, boxes_o, logits_o, _, _ = O.evaluate(sd, d, feats_o, emb_o, prompt[None], [size], max_tokens_new=4)
+        assert (ids_o[0] == res["output_ids"]).all(), "greedy ids"
+        per = {f: (boxes_o[0][k], logits_o[0][k]) for k, f in enumerate(windows[c])}
+        for j, w in enumerate(windows):
+            if j == c:
+                continue
+            kw = dict(global_enc_images=gi.float()[:, :, w], grounding_enc_images=si.float()[:, :, w], input_ids=res["answer_ids"][None],
+                      labels=None, attention_masks=None, offset=None, bboxes_list=None, temp_objectness_labels_list=None,
+                      original_size_list=[size], inference=True)
+            out_o = O.model_forward(sd, d, **kw)
+            for k, f in enumerate(w):
+                per[f] = (out_o["pred_bboxes"][0][k], out_o["logits_temp_objectness"][0][k])
+    n_box = 0
+    for f in range(F):
+        lo, lo_o = res["logits_temp_objectness"][f].float().cpu(), per[f][1].float()
+        assert lo.shape == lo_o.shape and (lo - lo_o).abs().max().item() < 6e-2, f"frame {f} logits"
+        bx, bx_o = res["pred_bboxes"][f].float().cpu(), per[f][0].float()
+        if bx.shape == bx_o.shape and bx.numel():  # same rows passed the 0.5 threshold
+            assert (bx / 640 - bx_o / 640).abs().mean().item() < 4e-3, f"frame {f} boxes"
+            n_box += bx.shape[0]
+    assert n_box > 0
