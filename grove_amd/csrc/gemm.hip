@@ -487,7 +487,19 @@ __device__ __forceinline__ void wait_vm_loads(int n) {  // n (even) = vector-mem
 //        reader passes one more barrier before its ds_reads. vmcnt retires in issue order, stores included: the epilogue's
 //        stores sit between loads in the queue, so a counted wait after an epilogue is merely conservative (it also waits
 //        for the stores), never early.
-template <int BM>
+// 8 consecutive int32 through the scalar cache (wave-uniform address). The gather indices of the GATHER instance are read
+// this way on purpose: a VECTOR load inside the persistent loop would sit in the vmcnt queue among the LDS-DMA loads and
+// make hipcc's own waits drain the staging stream.
+typedef int i32x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ i32x8_t sload8(const int* p) {
+  i32x8_t v;
+  asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+  return v;
+}
+
+// GATHER: A rows are looked up per (tap, m) in p.a_idx (implicit-GEMM Conv3d: K = taps x C_in; window (un)partition: one tap),
+// -1 = a zero row.
+template <int BM, bool GATHER>
 __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_params p, const int tiles_m, const int tiles_n) {
   constexpr int BMH = BM / 2;    // rows of an A half-tile: 128 or 96
   constexpr int WRH = BMH / 2;   // ... of which one wave group owns 64 or 48
@@ -525,15 +537,46 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
   // instructions — rows 96..127 are fetched and never read — so that the vmcnt arithmetic is the same for all waves.)
   const int st_c = tid & 7, st_r = tid >> 3;
   const bf16_raw* src[4][2];
+  bool a_zero[2][2] = {{false, false}, {false, false}};
+  const int k_per_tap = GATHER ? p.K / p.a_taps : p.K;
+  const int kt_per_tap = k_per_tap / P_BK;
+  int is_m0 = 0, is_tap = 0;  // GATHER: origin row and tap of the A pointers currently loaded
+  // GATHER: my two rows of each A half for tap `tap` of the tile at row m0. The wave's 8 rows per LDS-DMA instruction are 8
+  // consecutive m: one 8-dword scalar load, then a per-lane pick. Positions past the end of the index array belong to
+  // rows >= M (never stored): the load window is shifted back inside the array and those lanes take any entry.
+  auto set_src_a = [&](int m0, int tap) {
+    const int total = p.a_taps * p.M;
+    const int j = lane >> 3;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int P = tap * p.M + m0 + h * BMH + 64 * i + wave * 8;
+        const int Pc = max(min(P, total - 8), 0);
+        const i32x8_t v = sload8(p.a_idx + Pc);
+        const int jj = min(j + (P - Pc), 7);
+        int idx = v[0];
+        idx = jj == 1 ? v[1] : idx; idx = jj == 2 ? v[2] : idx; idx = jj == 3 ? v[3] : idx; idx = jj == 4 ? v[4] : idx;
+        idx = jj == 5 ? v[5] : idx; idx = jj == 6 ? v[6] : idx; idx = jj == 7 ? v[7] : idx;
+        const int r = st_r + 64 * i;
+        src[h ? 3 : 0][i] = idx >= 0 ? A + (int64_t)idx * p.lda + swz<64>(r, st_c) * 8 : (const bf16_raw*)g_zero_page;
+        a_zero[h][i] = idx < 0;
+      }
+    is_m0 = m0;
+    is_tap = tap;
+  };
   auto set_src = [&](int L) {
     int m0, n0;
     tile_origin(L, m0, n0);
+    if constexpr (GATHER) set_src_a(m0, 0);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int r = st_r + 64 * i;
       const int c = swz<64>(r, st_c) * 8;
-      src[0][i] = A + (int64_t)min(m0 + r, p.M - 1) * p.lda + c;
-      src[3][i] = A + (int64_t)min(m0 + BMH + r, p.M - 1) * p.lda + c;
+      if constexpr (!GATHER) {
+        src[0][i] = A + (int64_t)min(m0 + r, p.M - 1) * p.lda + c;
+        src[3][i] = A + (int64_t)min(m0 + BMH + r, p.M - 1) * p.lda + c;
+      }
       // LDS row R of a B half holds column pn(R): fragment j, operand row r of a wave's 32-column group lands on column
       // 8 * (r >> 2) + 4 * j + (r & 3), so a lane's accumulators for (j = 0, 1) are 8 consecutive columns -> 16-byte stores
       const int pn = (r & ~31) | (((r & 15) >> 2) * 8 + ((r >> 4) & 1) * 4 + (r & 3));
@@ -544,10 +587,15 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
   int is_L = wgid, is_k = 0;  // output tile and K tile of the half-tile being issued
   auto issue = [&](int x, int stream_t) {
     char* dst = smem + (stream_t & 1) * P_STAGE + x * P_HALF + wave * (64 * 16);
-    const int64_t koff = (int64_t)is_k * P_BK;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[x][0] + koff),
+    int64_t koff0 = (int64_t)is_k * P_BK, koff1 = koff0;
+    if (GATHER && (x == 0 || x == 3)) {  // A: the K offset is local to the tap; a zero row stays on the zero page
+      const int64_t ka = (int64_t)(is_k - is_tap * kt_per_tap) * P_BK;
+      koff0 = a_zero[x == 3][0] ? 0 : ka;
+      koff1 = a_zero[x == 3][1] ? 0 : ka;
+    }
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[x][0] + koff0),
                                      (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[x][1] + koff),
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[x][1] + koff1),
                                      (__attribute__((address_space(3))) void*)(dst + P_NT * 16), 16, 0, 0);
   };
   auto advance_issue = [&]() {  // before the A_lo of every K tile but the first
@@ -555,6 +603,8 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
       is_k = 0;
       is_L += G;
       set_src(is_L);
+    } else if (GATHER && is_k == (is_tap + 1) * kt_per_tap) {
+      set_src_a(is_m0, is_tap + 1);  // next tap of the same tile: new A rows
     }
   };
 
@@ -656,6 +706,8 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
         else gemm_epilogue_wide<MIH, BMH, GROVE_ACT_NONE>(p, acc, mw0, nw0, fr, fq, scale);
       } else if (p.act == GROVE_ACT_GELU) {
         gemm_epilogue_wide<MIH, BMH, GROVE_ACT_GELU>(p, acc, mw0, nw0, fr, fq, scale);
+      } else if (p.act == GROVE_ACT_RELU) {
+        gemm_epilogue_wide<MIH, BMH, GROVE_ACT_RELU>(p, acc, mw0, nw0, fr, fq, scale);
       } else {
         gemm_epilogue_wide<MIH, BMH, GROVE_ACT_QUICKGELU>(p, acc, mw0, nw0, fr, fq, scale);
       }
@@ -674,13 +726,13 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
 
 static int g_num_cus = 0;
 
-template <int BM>
+template <int BM, bool GATHER>
 int launch_pp(const grove_gemm_params& p, hipStream_t s) {
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + P_BN - 1) / P_BN;
   const size_t lds = 2 * (size_t)P_STAGE;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<BM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<BM, GATHER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   if (g_num_cus == 0) {
@@ -691,7 +743,7 @@ int launch_pp(const grove_gemm_params& p, hipStream_t s) {
   }
   const int tiles = tiles_m * tiles_n;
   const int grid = tiles < g_num_cus ? tiles : g_num_cus;
-  hipLaunchKernelGGL(gemm_nt_pp_kernel<BM>, dim3(grid, 1, 1), dim3(P_NT), lds, s, p, tiles_m, tiles_n);
+  hipLaunchKernelGGL((gemm_nt_pp_kernel<BM, GATHER>), dim3(grid, 1, 1), dim3(P_NT), lds, s, p, tiles_m, tiles_n);
   GROVE_LAUNCH_CHECK();
   return GROVE_OK;
 }
@@ -773,8 +825,8 @@ extern "C" int grove_gemm_bf16(const grove_gemm_params* pp, void* stream) {
   const bool wide_ok = (((uintptr_t)p.C & 15) == 0) && (p.ldc % (p.c_dtype == GROVE_BF16 ? 8 : 4) == 0) &&
                        (!p.aux || ((uintptr_t)p.aux & 15) == 0) && (!p.bias || ((uintptr_t)p.bias & 15) == 0) &&
                        (!p.residual || ((((uintptr_t)p.residual & 15) == 0) && p.ldr % 8 == 0));
-  const bool pp_act = p.act == GROVE_ACT_NONE || p.act == GROVE_ACT_GELU || p.act == GROVE_ACT_QUICKGELU;  // compiled-in epilogues
-  const bool p256_ok = g_gemm_glds && bk64 && !p.a_idx && bt == 1 && p.split_k <= 1 && !p.accumulate && wide_ok && p.N % 8 == 0 && pp_act;
+  const bool pp_act = p.act == GROVE_ACT_NONE || p.act == GROVE_ACT_GELU || p.act == GROVE_ACT_QUICKGELU || p.act == GROVE_ACT_RELU;  // compiled-in epilogues
+  const bool p256_ok = g_gemm_glds && bk64 && (!p.a_idx || (long)p.a_taps * p.M >= 8) && bt == 1 && p.split_k <= 1 && !p.accumulate && wide_ok && p.N % 8 == 0 && pp_act;
   // Tile choice by a measured cost model (tools/bench_gemm5.py, microseconds): time = rounds of resident blocks x
   // (K tiles x per-K-tile time + fixed per-tile time). The 128- and 192-row kernels keep 2 blocks per CU (512 slots; a
   // lone block of a partial round still takes a full round); the pipelined kernels are persistent, one block per CU,
@@ -796,12 +848,14 @@ extern "C" int grove_gemm_bf16(const grove_gemm_params* pp, void* stream) {
   const double c_old = c128 < c192 ? c128 : c192;
   if (p256_ok && (g_gemm_tile_m == 193 || g_gemm_tile_m == 256)) {
     g_gemm_last_variant = g_gemm_tile_m == 256 ? GROVE_GEMM_PP256 : GROVE_GEMM_PP192;
-    return g_gemm_tile_m == 256 ? launch_pp<256>(p, s) : launch_pp<192>(p, s);
+    if (p.a_idx) return g_gemm_tile_m == 256 ? launch_pp<256, true>(p, s) : launch_pp<192, true>(p, s);
+    return g_gemm_tile_m == 256 ? launch_pp<256, false>(p, s) : launch_pp<192, false>(p, s);
   }
   if (p256_ok && g_gemm_tile_m == 0 && g_gemm_tile_n == 0 && tp192 >= 48 && (cp256 < c_old || cp192 < c_old))
     {
       g_gemm_last_variant = cp256 <= cp192 ? GROVE_GEMM_PP256 : GROVE_GEMM_PP192;
-      return cp256 <= cp192 ? launch_pp<256>(p, s) : launch_pp<192>(p, s);
+      if (p.a_idx) return cp256 <= cp192 ? launch_pp<256, true>(p, s) : launch_pp<192, true>(p, s);
+      return cp256 <= cp192 ? launch_pp<256, false>(p, s) : launch_pp<192, false>(p, s);
     }
   int variant = 128;
   if (g_gemm_tile_m == 192 || (g_gemm_tile_m == 0 && t128 > 300 && c192 <= c128)) variant = 192;

@@ -96,12 +96,20 @@ class SamEncoder:
             self.neck_w2_d = w2.flip(2, 3).permute(1, 2, 3, 0).reshape(O, 9 * O).contiguous()
         self._idx = {}
 
+    @property
+    def _zero_row(self):
+        if not hasattr(self, "_zr"):
+            self._zr = torch.zeros((1, 3 * self.d.sam_heads * self.hp), dtype=torch.bfloat16, device=self.dev)
+        return self._zr
+
     def refresh_adapter_scalars(self):
         """alpha is read on device by the GEMM epilogue (fp32 scalar)."""
         for A in self.adapters:
             A["alpha_f32"] = A["alpha"].float().contiguous()
 
     def _indices(self, F):
+        if not hasattr(self, "_pad"):
+            self._pad = {}
         if F not in self._idx:
             d = self.d
             g = d.sam_grid
@@ -109,7 +117,10 @@ class SamEncoder:
             conv = conv3d_gather_index(F // 8, 8, g, g)
             neck = conv3d_gather_index(F, 1, g, g, kt=1)
             pos_rows = (torch.arange(F * g * g, dtype=torch.int32) % (g * g))
+            pad_rows = (win2tok < 0).nonzero().flatten().to(torch.int32)  # window-layout rows that are padding
+            zeros = torch.zeros_like(pad_rows)
             self._idx[F] = tuple(t.to(self.dev) for t in (tok2win, win2tok, conv, neck, pos_rows)) + (nwin,)
+            self._pad[F] = (pad_rows.to(self.dev), zeros.to(self.dev))
         return self._idx[F]
 
     def _head_rows(self, nb, L):
@@ -131,14 +142,19 @@ class SamEncoder:
         g = d.sam_grid
         ws = Bk["window"]
         ctx = {}
+        h, mean, rstd = ops.layernorm(x, Bk["ln1"][0], Bk["ln1"][1], 1e-6, save_stats=save)
         if ws > 0:
+            # Window partition (image_encoder.py:329-353) pads AFTER norm1 with zero tokens, whose q|k|v is the bias alone:
+            # the GEMM runs over the real tokens only and scatters its rows into the windowed layout (c_idx); the padding
+            # rows (42 % of the windowed rows at 32x32 -> 3x3 windows of 14) are filled with the bias row.
             rows_w = F * nwin * ws * ws
-            h, mean, rstd = ops.layernorm(x, Bk["ln1"][0], Bk["ln1"][1], 1e-6, out_idx=tok2win, out_rows=rows_w, save_stats=save)
             nb, L, qhw = F * nwin, ws * ws, (ws, ws)
+            pad_rows, pad_src = self._pad[F]
+            qkv = ops.linear(h, Bk["wqkv"], Bk["bqkv"], c_idx=tok2win, out_rows=rows_w)
+            ops.copy_rows(Bk["bqkv"].view(1, -1), qkv, pad_rows.numel(), qkv.shape[1], idx_src=pad_src, idx_dst=pad_rows)
         else:
-            h, mean, rstd = ops.layernorm(x, Bk["ln1"][0], Bk["ln1"][1], 1e-6, save_stats=save)
             nb, L, qhw = F, g * g, (g, g)
-        qkv = ops.linear(h, Bk["wqkv"], Bk["bqkv"])
+            qkv = ops.linear(h, Bk["wqkv"], Bk["bqkv"])
         # rel'[(b h), q, :] = q_vec . R_cat[q]^T as ONE GEMM batched over the L query positions
         ld = qkv.stride(0)
         rel_ld = Bk["rel_ld"]
@@ -148,7 +164,10 @@ class SamEncoder:
                      sA=(ld, 0), sB=(rel_ld * hp, 0), sC=(rel_ld, 0))
         o, actx = attention_fwd(qkv, nb, L, nh, hp, 0, nh * hp, 2 * nh * hp, hd ** -0.5, rel=rel, rel_hw=(Bk["khp"], qhw[1]), save=save)
         del rel
-        x1 = ops.linear(o, Bk["wproj"], Bk["bproj"], residual=x, c_idx=(win2tok if ws > 0 else None), out_rows=x.shape[0])
+        if ws > 0:  # un-partition = gather the real tokens' rows of the windowed attention output (padding rows are dropped)
+            x1 = ops.linear(o, Bk["wproj"], Bk["bproj"], residual=x, a_idx=tok2win, a_taps=1, M=x.shape[0])
+        else:
+            x1 = ops.linear(o, Bk["wproj"], Bk["bproj"], residual=x)
         h2, mean2, rstd2 = ops.layernorm(x1, Bk["ln2"][0], Bk["ln2"][1], 1e-6, save_stats=save)
         pre = torch.empty((x.shape[0], 4 * C), dtype=torch.bfloat16, device=self.dev) if save else None
         f = ops.linear(h2, Bk["w1"], Bk["b1"], act=ops.ACT_GELU, aux=pre)
@@ -234,8 +253,10 @@ class SamEncoder:
             ops.layernorm_bwd(c["x1"], Bk["ln2"][0], dh2, c["mean2"], c["rstd2"], dx=dx, accumulate=True)   # dx = d x1
             del dh2
             # x1 = x + unpartition(proj(attn(qkv(partition(ln1(x))))))
-            if ws > 0:
-                do = ops.linear(dx, Bk["wproj_t"], a_idx=win2tok, a_taps=1, M=win2tok.shape[0])
+            if ws > 0:  # real tokens only, scattered into the windowed layout; padding rows carry no gradient
+                pad_rows, pad_src = self._pad[F]
+                do = ops.linear(dx, Bk["wproj_t"], c_idx=tok2win, out_rows=win2tok.shape[0])
+                ops.copy_rows(self._zero_row[:, :do.shape[1]], do, pad_rows.numel(), do.shape[1], idx_src=pad_src, idx_dst=pad_rows)
             else:
                 do = ops.linear(dx, Bk["wproj_t"])
             qkv = c["qkv"]
@@ -246,10 +267,12 @@ class SamEncoder:
             hrow = self._head_rows(c["nb"], L)
             ops.gemm_raw(drel, Bk["RcatT"], dqkv, c["nb"] * nh, hp, rel_ld, L * rel_ld, rel_ld, hp, c_idx=hrow, residual=dqkv, ldr=hp,
                          batch=(L, 1), sA=(rel_ld, 0), sB=(hp * rel_ld, 0), sC=(ldd, 0), sR=(ldd, 0))
-            dh = ops.linear(dqkv, Bk["wqkv_t"])
+            if ws > 0:  # only the real tokens' rows of d qkv feed norm1
+                dh = ops.linear(dqkv, Bk["wqkv_t"], a_idx=tok2win, a_taps=1, M=dx.shape[0])
+            else:
+                dh = ops.linear(dqkv, Bk["wqkv_t"])
             del dqkv, do, drel
-            ops.layernorm_bwd(c["x"], Bk["ln1"][0], dh, c["mean"], c["rstd"], dx=dx, accumulate=True,
-                              in_idx=(tok2win if ws > 0 else None))
+            ops.layernorm_bwd(c["x"], Bk["ln1"][0], dh, c["mean"], c["rstd"], dx=dx, accumulate=True)
             del dh
         return None
 

@@ -660,3 +660,43 @@ def test_decode_attention_fused(dev, B, H, hd, t, Smax):
     close(o, ref, 2 ** -7, "fused decode attention")
     assert torch.equal(cache[:, t], ref_cache[:, t]), "appended key|value row"
     assert torch.equal(cache[:, :t], ref_cache[:, :t]) and torch.equal(cache[:, t + 1:], ref_cache[:, t + 1:])
+
+
+@pytest.mark.parametrize("tile_m", [256, 193])
+def test_gemm_pipelined_gather(dev, tile_m):
+    """The gathered-A instance of the persistent pipelined kernel (scalar index loads): 27-tap Conv3d rows with -1 = zero
+    row, and a one-tap row gather with M not a multiple of the tile, against the two-barrier kernel on the same operands."""
+    from grove_amd import _lib, ops
+    from grove_amd.model.indexing import conv3d_gather_index
+    L = _lib.lib()
+    G, T, H, W, Ci, Co = 2, 8, 8, 9, 64, 264
+    M = G * T * H * W
+    x, w, bias = rnd(M, Ci, seed=11).to(dev), rnd(Co, 27 * Ci, seed=12, scale=0.05).to(dev), rnd(Co, seed=13).to(dev)
+    res = rnd(M, Co, seed=14).to(dev)
+    idx = conv3d_gather_index(G, T, H, W).to(dev)
+    kw = dict(act=ops.ACT_RELU, residual=res, scale_ptr=torch.tensor([0.3]).to(dev), scale_tanh=True, a_idx=idx, a_taps=27, M=M)
+    try:
+        L.grove_gemm_set_tile_m(128)
+        ref = ops.linear(x, w, bias, **kw)
+        assert L.grove_gemm_last_variant() in (1, 2, 3)
+        L.grove_gemm_set_tile_m(tile_m)
+        out = ops.linear(x, w, bias, **kw)
+        assert L.grove_gemm_last_variant() == (4 if tile_m == 256 else 5)
+        assert torch.equal(out, ref), (out.float() - ref.float()).abs().max().item()
+        # one tap, rows permuted / dropped (window partition), M = 1000 (edge tile), 8-row groups crossing the array end
+        M2, K2, N2 = 1000, 128, 520
+        a, b2 = rnd(1300, K2, seed=15).to(dev), rnd(N2, K2, seed=16, scale=0.05).to(dev)
+        g = torch.Generator().manual_seed(3)
+        idx2 = torch.randint(0, 1300, (M2,), generator=g, dtype=torch.int32)
+        idx2[::7] = -1
+        idx2 = idx2.to(dev)
+        L.grove_gemm_set_tile_m(128)
+        ref2 = ops.linear(a, b2, a_idx=idx2, a_taps=1, M=M2)
+        L.grove_gemm_set_tile_m(tile_m)
+        out2 = ops.linear(a, b2, a_idx=idx2, a_taps=1, M=M2)
+        assert L.grove_gemm_last_variant() == (4 if tile_m == 256 else 5)
+        assert torch.equal(out2, ref2)
+        gathered = torch.where((idx2 >= 0)[:, None], a.float()[idx2.clamp_min(0).long()], torch.zeros(1, device=dev))
+        close(out2, gathered.cpu() @ b2.float().cpu().t(), 2 ** -7, "one-tap gather vs fp32")
+    finally:
+        L.grove_gemm_set_tile_m(0)
