@@ -12,6 +12,8 @@
 
 namespace {
 
+__device__ __attribute__((aligned(16))) unsigned int g_tn_zero_page[64];  // 256 B of zeros (gathered zero rows)
+
 constexpr int TBM = 128, TBN = 128, TBK = 64, TNT = 256;
 constexpr int TROWB = 128 * 2 + 32;           // LDS row stride (bytes)
 constexpr int TTILEB = TBK * TROWB;           // one operand tile
@@ -150,7 +152,301 @@ __global__ __launch_bounds__(TNT) void gemm_tn_kernel(const grove_gemm_tn_params
   }
 }
 
+
+// =====================================================================================================
+// Persistent pipelined form (the structure of gemm_nt_pp_kernel in gemm.hip, which documents the phase plan and the
+// hazard argument): 256 (M) x 256 (N) x 64 (K) tiles, 8 waves = 2 (M) x 4 (N), one block per CU, two 64 KB stages of four
+// K-major half-tiles [64 k][128 columns] (A_lo, B_lo, B_hi, A_hi) filled by LDS-DMA and read with ds_read_b64_tr_b16.
+//
+// LDS image of a half-tile: plain 256-byte rows (LDS-DMA cannot pad), 16-byte chunk c of row k stored at chunk
+// c ^ ((k & 7) << 1): a transposed fragment read touches 8 rows x 32 bytes per 32-lane group, and the XOR spreads those
+// eight 32-byte pieces over the eight 32-byte bank groups (conflict-free, checked against the §LDS table of
+// MI355X_MICROARCH.md: ds_read_b64_tr_b16 = 2 x 32 lanes, bank = (addr / 4) mod 64). The swizzle is applied on the
+// SOURCE address of the DMA (lane -> physical chunk is fixed).
+// Gathered B rows (Conv3d weight gradient): the 64 row indices of a K tile are fetched with scalar loads (4 consecutive
+// k per wave instruction) when the tile's A_lo is issued — no vector load inside the loop (see sload8 in gemm.hip).
+// =====================================================================================================
+constexpr int Q_NT = 512, Q_BK = 64;
+constexpr int Q_ROWB = 256;                 // bytes per LDS row (128 bf16 columns)
+constexpr int Q_HALF = Q_BK * Q_ROWB;       // 16 KB
+constexpr int Q_STAGE = 4 * Q_HALF;
+
+typedef int i32x4s_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4s_t sload4(const int* p) {
+  i32x4s_t v;
+  asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ void wait_vm_even(int n) {
+  if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// Transposed fragment read as inline asm: through the builtin, hipcc guards every LDS read that may alias an LDS-DMA
+// destination with s_waitcnt vmcnt(0) (it cannot see that the counted waits already ordered them), which drains the
+// staging stream every phase. The asm is invisible to that pass; the lgkmcnt wait before the MFMAs is written by hand,
+// followed by sched_barrier(0) (cdna_hip_programming.md rule 18), and the two halves of an operand are only combined
+// AFTER that wait so that no register move can read them early.
+typedef __attribute__((ext_vector_type(4))) short q_s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short q_s16x8_t;
+template <int OFF>
+__device__ __forceinline__ q_s16x4_t ds_tr16(unsigned addr) {
+  q_s16x4_t v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+struct TrFrag {
+  q_s16x4_t lo, hi;
+};
+template <int OFF>
+__device__ __forceinline__ TrFrag tr_pair(unsigned addr) {  // rows r .. r+3 and r+16 .. r+19 of a 16-column block
+  TrFrag f;
+  f.lo = ds_tr16<OFF>(addr);
+  f.hi = ds_tr16<OFF + 16 * Q_ROWB>(addr);
+  return f;
+}
+__device__ __forceinline__ bf16x8_t tr_join(const TrFrag& f) {
+  return __builtin_bit_cast(bf16x8_t, (q_s16x8_t{f.lo[0], f.lo[1], f.lo[2], f.lo[3], f.hi[0], f.hi[1], f.hi[2], f.hi[3]}));
+}
+
+template <bool GATHER>
+__global__ __launch_bounds__(Q_NT) void gemm_tn_pp_kernel(const grove_gemm_tn_params p, const int tiles_m, const int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int fr = lane & 15, g = lane >> 4;
+  const bf16_raw* __restrict__ A = (const bf16_raw*)p.A;
+  const bf16_raw* __restrict__ B = (const bf16_raw*)p.B;
+  const int G = gridDim.x;
+  const int xcd = blockIdx.x & 7, q8 = G >> 3, r8 = G & 7;
+  const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+  const int tiles = tiles_m * tiles_n;
+  const int my_tiles = (tiles - wgid + G - 1) / G;
+  const int nk = p.K / Q_BK;
+  const int NT = my_tiles * nk, NH = 4 * NT;
+  const int n_per_tap = p.N / p.b_taps;
+
+  // staging: thread -> (row k = 32 i + tid / 16, physical chunk tid % 16) of a half-tile, two instructions per half
+  const int st_k = tid >> 4;                      // + 32 i
+  const int lc = (tid & 15) ^ ((st_k & 7) << 1);  // logical chunk this lane must fetch (st_k + 32 i has the same low 3 bits)
+  const bf16_raw* pa[2];     // A_lo / A_hi column bases (row 0)
+  int colb[2];               // B_lo / B_hi column offsets inside a (gathered) row
+  const bf16_raw* pbrow[2];  // GATHER: my two B rows of the K tile being issued (nullptr = zero row)
+  const int32_t* bidx = nullptr;
+  int is_L = wgid, is_k = 0;
+  auto set_tile = [&](int L) {  // consecutive tiles share the B panel
+    const int tm = L % tiles_m, tn = L / tiles_m;
+    const int m0 = tm * 256, n0 = tn * 256;
+    const int tap = n0 / n_per_tap, nb0 = n0 - tap * n_per_tap;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      pa[h] = A + min(m0 + 128 * h + lc * 8, p.M - 8);
+      colb[h] = min(nb0 + 128 * h + lc * 8, n_per_tap - 8);
+    }
+    if (GATHER) bidx = p.b_idx + (int64_t)tap * p.K;
+  };
+  // GATHER: the 64 row indices of a K tile — 4 consecutive k per wave instruction, so two 4-dword SCALAR loads per wave —
+  // are prefetched one K tile ahead and taken after a wait that is already satisfied (every MFMA segment starts with
+  // lgkmcnt(0)); the "+s" ties make the wait the definition point of the values, so no use can be scheduled before it.
+  i32x4s_t nx0 = {0, 0, 0, 0}, nx1 = {0, 0, 0, 0};
+  auto prefetch_rows = [&](const int32_t* base) {
+    asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dwordx4 %1, %3, 0x0" : "=&s"(nx0), "=&s"(nx1) : "s"(base + 4 * wave), "s"(base + 32 + 4 * wave));
+  };
+  auto take_rows = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(nx0), "+s"(nx1)::"memory");
+    int r0 = nx0[0], r1 = nx1[0];
+    r0 = g == 1 ? nx0[1] : r0; r0 = g == 2 ? nx0[2] : r0; r0 = g == 3 ? nx0[3] : r0;
+    r1 = g == 1 ? nx1[1] : r1; r1 = g == 2 ? nx1[2] : r1; r1 = g == 3 ? nx1[3] : r1;
+    pbrow[0] = r0 >= 0 ? B + (int64_t)r0 * p.ldb : nullptr;
+    pbrow[1] = r1 >= 0 ? B + (int64_t)r1 * p.ldb : nullptr;
+  };
+  auto next_rows_base = [&]() -> const int32_t* {  // index window of the K tile AFTER (is_L, is_k)
+    int k2 = is_k + 1;
+    const int32_t* bb = bidx;
+    if (k2 == nk) {
+      k2 = 0;
+      const int L2 = is_L + G;
+      if (L2 < tiles) bb = p.b_idx + (int64_t)(((L2 / tiles_m) * 256) / n_per_tap) * p.K;
+    }
+    return bb + k2 * Q_BK;
+  };
+  auto issue = [&](int x, int stream_t) {
+    char* dst = smem + (stream_t & 1) * Q_STAGE + x * Q_HALF + wave * (64 * 16);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bf16_raw* src;
+      if (x == 0 || x == 3) {
+        src = pa[x == 3] + (int64_t)(is_k * Q_BK + 32 * i + st_k) * p.lda;
+      } else if (GATHER) {
+        src = pbrow[i] ? pbrow[i] + colb[x == 2] : (const bf16_raw*)g_tn_zero_page;
+      } else {
+        src = B + (int64_t)(is_k * Q_BK + 32 * i + st_k) * p.ldb + colb[x == 2];
+      }
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(dst + i * (Q_NT * 16)), 16, 0, 0);
+    }
+  };
+  auto advance_issue = [&]() {
+    if (++is_k == nk) {
+      is_k = 0;
+      is_L += G;
+      set_tile(is_L);
+    }
+    if (GATHER) {
+      take_rows();
+      prefetch_rows(next_rows_base());
+    }
+  };
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // transposed fragment reads: lane (fr, g) reads 8 bytes of row 4 g + (fr >> 2) (+16) at column 4 (fr & 3) of the fragment
+  const int qq = fr >> 2, pp = fr & 3;
+  const int R2 = ((4 * (g & 1) + qq) & 7) << 1;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + (4 * g + qq) * Q_ROWB + pp * 8;
+  unsigned a_adr[4], b_adr[2];  // LDS byte address of fragment i / j in stage 0, region 0, k-step 0 (swizzled column)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a_adr[i] = lds0 + ((wr * 8 + 2 * i) ^ R2) * 16;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) b_adr[j] = lds0 + ((wc * 4 + 2 * j) ^ R2) * 16;
+  TrFrag af[4][2], b0[2][2], b1[2][2];
+#define QQ_READ_A(X)                                                              \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                \
+    af[i][0] = tr_pair<(X) * Q_HALF>(a_adr[i] + st_off);                         \
+    af[i][1] = tr_pair<(X) * Q_HALF + 32 * Q_ROWB>(a_adr[i] + st_off);           \
+  }
+#define QQ_READ_B(X, BB)                                                          \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                \
+    BB[j][0] = tr_pair<(X) * Q_HALF>(b_adr[j] + st_off);                         \
+    BB[j][1] = tr_pair<(X) * Q_HALF + 32 * Q_ROWB>(b_adr[j] + st_off);           \
+  }
+#define QQ_MMA(IO, JO, BB)                                                                                                \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                      \
+  __builtin_amdgcn_sched_barrier(0);                                                                                      \
+  __builtin_amdgcn_s_setprio(1);                                                                                          \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) \
+      acc[IO + i][JO + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_join(BB[j][ks]), tr_join(af[i][ks]), acc[IO + i][JO + j], 0, 0, 0); \
+  __builtin_amdgcn_s_setprio(0);                                                                                          \
+  __builtin_amdgcn_sched_barrier(0);
+#define QQ_MEM_END(Q, X, TOFF, WAIT)                                                                                      \
+  if ((Q) + 6 < NH) {                                                                                                     \
+    issue(X, T + TOFF);                                                                                                   \
+    if (WAIT) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                            \
+  } else if (WAIT) {                                                                                                      \
+    wait_vm_even(2 * max(NH - 3 - (Q), 0));                                                                               \
+  }                                                                                                                       \
+  __builtin_amdgcn_sched_barrier(0);                                                                                      \
+  __builtin_amdgcn_s_barrier();
+
+  float scale = p.alpha;
+  if (p.scale_ptr) scale *= p.scale_tanh ? tanhf(*p.scale_ptr) : *p.scale_ptr;
+  asm volatile("" ::"v"(scale));  // fetched and used before the loop (see gemm_nt_pp_kernel)
+  set_tile(is_L);
+  if (GATHER) {
+    prefetch_rows(bidx);
+    take_rows();
+    prefetch_rows(next_rows_base());
+  }
+  issue(0, 0); issue(1, 0); issue(2, 0); issue(3, 0);
+  if (NT > 1) {
+    advance_issue();
+    issue(0, 1); issue(1, 1);
+  }
+  wait_vm_even(2 * (min(5, NH - 1) - 1));
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();
+
+  int c_L = wgid, c_k = 0;
+  for (int T = 0; T < NT; ++T) {
+    const unsigned st_off = (T & 1) * Q_STAGE;
+    const int q = 4 * T;
+    QQ_READ_B(1, b0)
+    QQ_READ_A(0)
+    QQ_MEM_END(q, 2, 1, true)
+    QQ_MMA(0, 0, b0)
+    __builtin_amdgcn_s_barrier();
+    QQ_READ_B(2, b1)
+    QQ_MEM_END(q + 1, 3, 1, true)
+    QQ_MMA(0, 2, b1)
+    __builtin_amdgcn_s_barrier();
+    if (q + 8 < NH) advance_issue();  // before this phase's reads: its (already satisfied) lgkmcnt wait must not cover them
+    QQ_READ_A(3)
+    QQ_MEM_END(q + 2, 0, 2, false)
+    QQ_MMA(4, 2, b1)
+    __builtin_amdgcn_s_barrier();
+    QQ_MEM_END(q + 3, 1, 2, true)
+    QQ_MMA(4, 0, b0)
+    __builtin_amdgcn_s_barrier();
+    if (++c_k == nk) {
+      // acc[i][j] holds D[n = 4 g + e][m = fr] of A fragment i (m) and B fragment j (n): C += scale * D, 16 bytes per lane
+      const int tm = c_L % tiles_m, tn = c_L / tiles_m;
+      const int m0 = tm * 256 + wr * 64 + fr, n0 = tn * 256 + wc * 32 + 4 * g;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + (j >> 1) * 128 + (j & 1) * 16;
+        if (n >= p.N) continue;
+        f32x4_t old[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int m = min(m0 + (i >> 2) * 128 + (i & 3) * 16, p.M - 1);
+          old[i] = *(const f32x4_t*)(p.C + (int64_t)m * p.ldc + n);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int m = m0 + (i >> 2) * 128 + (i & 3) * 16;
+          if (m < p.M) *(f32x4_t*)(p.C + (int64_t)m * p.ldc + n) = old[i] + acc[i][j] * scale;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      c_k = 0;
+      c_L += G;
+    }
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();
+#undef QQ_MMA
+#undef QQ_MEM_END
+#undef QQ_READ_A
+#undef QQ_READ_B
+}
+
+template <bool GATHER>
+int launch_tn_pp(const grove_gemm_tn_params& p, hipStream_t s) {
+  const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 255) / 256;
+  const size_t lds = 2 * (size_t)Q_STAGE;
+  static bool attr_set = false;
+  static int num_cus = 0;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)gemm_tn_pp_kernel<GATHER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    int dev = 0;
+    hipGetDevice(&dev);
+    hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (num_cus <= 0) num_cus = 256;
+    attr_set = true;
+  }
+  const int tiles = tiles_m * tiles_n;
+  hipLaunchKernelGGL(gemm_tn_pp_kernel<GATHER>, dim3(tiles < num_cus ? tiles : num_cus), dim3(Q_NT), lds, s, p, tiles_m, tiles_n);
+  GROVE_LAUNCH_CHECK();
+  return GROVE_OK;
+}
+
 }  // namespace
+
+static int g_tn_pipelined = -1;  // -1 auto, 0 never, 1 whenever the problem is eligible (A/B runs and tests)
+extern "C" int grove_gemm_tn_set_pipelined(int mode) {
+  g_tn_pipelined = mode;
+  return GROVE_OK;
+}
 
 extern "C" int grove_gemm_tn_bf16(const grove_gemm_tn_params* pp, void* stream) {
   GROVE_CHECK(pp && pp->M > 0 && pp->N > 0 && pp->K > 0, GROVE_E_SHAPE, "gemm_tn: bad shape");
@@ -172,6 +468,14 @@ extern "C" int grove_gemm_tn_bf16(const grove_gemm_tn_params* pp, void* stream) 
       if (split < 1) split = 1;
     }
   }
+  // the persistent pipelined kernel: un-split problems with enough 256 x 256 tiles whose column tiles stay inside one tap
+  const int g_force = g_tn_pipelined;
+  const int n_per_tap = p.N / p.b_taps;
+  const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
+  const bool pp_ok = p.K % 64 == 0 && p.split_k <= 1 && (p.b_taps == 1 || n_per_tap % 256 == 0) && p.ldc % 4 == 0 && p.M >= 8 &&
+                     n_per_tap >= 8 && (!p.b_idx || p.K >= 64);
+  if (pp_ok && g_force != 0 && (g_force == 1 || (split == 1 && t256 >= 192 && nkt >= 16)))
+    return p.b_idx ? launch_tn_pp<true>(p, (hipStream_t)stream) : launch_tn_pp<false>(p, (hipStream_t)stream);
   static bool attr = false;
   const size_t lds = 4 * TTILEB;
   if (!attr) {

@@ -128,6 +128,9 @@ typedef struct grove_gemm_tn_params {
   float alpha;
 } grove_gemm_tn_params;
 int grove_gemm_tn_bf16(const grove_gemm_tn_params* p, void* stream);
+/* kernel choice of grove_gemm_tn_bf16: -1 = auto (default), 0 = the 128 x 128 kernel always, 1 = the persistent pipelined
+ * 256 x 256 kernel whenever the problem is eligible (K % 64 == 0, no split-K, column tiles inside one tap) */
+int grove_gemm_tn_set_pipelined(int mode);
 
 /* out[c, r] = in[r, c] for a batch of 2-D bf16 matrices (used for V^T, dY^T, X^T, NCHW<->NHWC).
  * rows beyond `rows` in the output's padded leading dim (ld_out > rows) are zero filled up to

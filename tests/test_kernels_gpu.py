@@ -700,3 +700,33 @@ def test_gemm_pipelined_gather(dev, tile_m):
         close(out2, gathered.cpu() @ b2.float().cpu().t(), 2 ** -7, "one-tap gather vs fp32")
     finally:
         L.grove_gemm_set_tile_m(0)
+
+
+def test_wgrad_tn_pipelined(dev):
+    """The persistent pipelined TN kernel (K-major LDS-DMA images, swizzled transposed reads) against the 128 x 128 kernel and
+    fp32: plain operands with edge tiles in M and N, and the gathered Conv3d weight gradient (27 taps, zero rows)."""
+    from grove_amd import _lib, ops
+    from grove_amd.model.indexing import conv3d_gather_index
+    L = _lib.lib()
+    try:
+        K, M, N = 1216, 328, 520
+        dy, x = rnd(K, M, seed=90).to(dev), rnd(K, N, seed=91).to(dev)
+        g0 = torch.randn(M, N, generator=torch.Generator().manual_seed(92))
+        L.grove_gemm_tn_set_pipelined(0)
+        ref = ops.wgrad(dy, x, g0.clone().to(dev), alpha=0.5)
+        L.grove_gemm_tn_set_pipelined(1)
+        out = ops.wgrad(dy, x, g0.clone().to(dev), alpha=0.5)
+        close(out, g0 + 0.5 * dy.float().cpu().t() @ x.float().cpu(), 3e-5, "pipelined wgrad vs fp32")
+        close(out, ref, 2e-6, "pipelined wgrad vs 128x128 kernel")
+        # Conv3d weight gradient: Ci = 256 so that a 256-column tile stays inside one tap
+        G, T, H, W, Ci, Co = 2, 4, 4, 8, 256, 264
+        Mtok = G * T * H * W
+        xx, dz = rnd(Mtok, Ci, seed=93).to(dev), rnd(Mtok, Co, seed=94).to(dev)
+        idx = conv3d_gather_index(G, T, H, W).to(dev)
+        L.grove_gemm_tn_set_pipelined(0)
+        ref = ops.wgrad(dz, xx, torch.zeros(Co, 27 * Ci, dtype=torch.float32, device=dev), b_idx=idx, b_taps=27)
+        L.grove_gemm_tn_set_pipelined(1)
+        out = ops.wgrad(dz, xx, torch.zeros(Co, 27 * Ci, dtype=torch.float32, device=dev), b_idx=idx, b_taps=27)
+        close(out, ref, 2e-6, "pipelined conv3d wgrad vs 128x128 kernel")
+    finally:
+        L.grove_gemm_tn_set_pipelined(-1)
