@@ -14,6 +14,8 @@
 //   with 4 consecutive n for one m -> 8-byte (bf16) / 16-byte (f32) epilogue accesses.
 //   blockIdx is remapped XCD-aware (bijective, cdna_hip_programming.md §5) and grouped so that
 //   tiles sharing an A row panel / B column panel run on the same XCD L2.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -642,9 +644,11 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
       acc[IO + i][JO + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BB[j][ks], af[i][ks], acc[IO + i][JO + j], 0, 0, 0);   \
   __builtin_amdgcn_s_setprio(0);                                                                                          \
   __builtin_amdgcn_sched_barrier(0);
-  // end of a phase's memory segment: stage half-tile q + 6, retire what phase q + 1 reads, meet the other group
-#define PP_MEM_END(Q, X, TOFF, WAIT)                                                                                      \
-  if ((Q) + 6 < NH) {                                                                                                     \
+  // end of a phase's memory segment: stage half-tile q + 6, retire what phase q + 1 reads, meet the other group.
+  // STEADY (every K tile but the stream's last two): the half-tile exists, no tests — the memory segment has to fit
+  // beside the other wave group's MFMA segment (192-256 cycles), scalar branches included.
+#define PP_MEM_END(STEADY, Q, X, TOFF, WAIT)                                                                              \
+  if (STEADY || (Q) + 6 < NH) {                                                                                           \
     if ((X) == 0) advance_issue();                                                                                        \
     issue(X, T + TOFF);                                                                                                   \
     if (WAIT) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); /* half-tiles q+3 .. q+6 stay in flight */                 \
@@ -674,27 +678,28 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
   if (wr == 1) __builtin_amdgcn_s_barrier();  // the stagger
 
   int c_L = wgid, c_k = 0;  // output tile / K tile being computed
-  for (int T = 0; T < NT; ++T) {
+  auto k_tile = [&](auto steady, int T) {
+    constexpr bool STEADY = decltype(steady)::value;
     const char* st = smem + (T & 1) * P_STAGE;
     const int q = 4 * T;
     // ph1
     read_b(st, 1, b0);
     read_a(st, 0);
-    PP_MEM_END(q, 2, 1, true)
+    PP_MEM_END(STEADY, q, 2, 1, true)
     PP_MMA(0, 0, b0)
     __builtin_amdgcn_s_barrier();
     // ph2
     read_b(st, 2, b1);
-    PP_MEM_END(q + 1, 3, 1, true)
+    PP_MEM_END(STEADY, q + 1, 3, 1, true)
     PP_MMA(0, 2, b1)
     __builtin_amdgcn_s_barrier();
     // ph3
     read_a(st, 3);
-    PP_MEM_END(q + 2, 0, 2, false)
+    PP_MEM_END(STEADY, q + 2, 0, 2, false)
     PP_MMA(MIH, 2, b1)
     __builtin_amdgcn_s_barrier();
     // ph4
-    PP_MEM_END(q + 3, 1, 2, true)
+    PP_MEM_END(STEADY, q + 3, 1, 2, true)
     PP_MMA(MIH, 0, b0)
     __builtin_amdgcn_s_barrier();
     if (++c_k == nk) {  // tile done: epilogue (no barriers inside), then on to my next tile whose operands are already landing
@@ -718,7 +723,10 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
       c_k = 0;
       c_L += G;
     }
-  }
+  };
+  int T = 0;
+  for (; T + 2 < NT; ++T) k_tile(std::true_type{}, T);
+  for (; T < NT; ++T) k_tile(std::false_type{}, T);
   if (wr == 0) __builtin_amdgcn_s_barrier();
 #undef PP_MMA
 #undef PP_MEM_END

@@ -103,7 +103,10 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const grove_norm_params p
 // Backward. Each wave walks ROWS_PER_WAVE rows, keeping per-lane partial dweight/dbias in
 // registers; the 4 waves of a block are combined through LDS and added to global with one
 // float atomic per (block, channel).
-constexpr int ROWS_PER_WAVE = 8;
+// Rows per wave: 8 when per-lane dweight/dbias partials are carried across rows (fewer LDS/global combines); 1 otherwise —
+// a frozen norm's backward is a pure stream and 2812 rows x 8 per wave would leave most of the chip idle.
+template <bool need_dw>
+constexpr int rows_per_wave() { return need_dw ? 8 : 1; }
 
 template <bool RMS, int MAXCH, bool need_dw>
 __global__ __launch_bounds__(256) void norm_bwd_kernel(const grove_norm_bwd_params p) {
@@ -132,6 +135,7 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const grove_norm_bwd_para
 #pragma unroll
     for (int e = 0; e < 8; ++e) { dw[i][e] = 0.f; db[i][e] = 0.f; }
 
+  constexpr int ROWS_PER_WAVE = rows_per_wave<need_dw>();
   const int row_base = (blockIdx.x * 4 + wave) * ROWS_PER_WAVE;
   for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
     const int row = row_base + rr;
@@ -265,7 +269,7 @@ static int norm_bwd_launch(const grove_norm_bwd_params* p, bool rms, void* strea
   GROVE_CHECK(p->C % 8 == 0 && p->C <= MAXCH_ALL * 512, GROVE_E_SHAPE, "norm_bwd: C=%d unsupported", p->C);
   GROVE_CHECK(p->ld_x % 8 == 0 && p->ld_dy % 8 == 0 && p->ld_dx % 8 == 0, GROVE_E_ALIGN, "norm_bwd: leading dims must be multiples of 8");
   GROVE_CHECK(rms || (p->mean && p->rstd), GROVE_E_SHAPE, "layernorm_bwd: saved mean/rstd required");
-  const int rows_per_block = 4 * ROWS_PER_WAVE;
+  const int rows_per_block = 4 * (p->dweight ? rows_per_wave<true>() : rows_per_wave<false>());
   const size_t lds = p->dweight ? (size_t)2 * p->C * sizeof(float) : 0;
   dim3 grid((p->rows + rows_per_block - 1) / rows_per_block);
   hipStream_t s_ = (hipStream_t)stream;
