@@ -1,7 +1,7 @@
 """Flash-attention micro-benchmark on the four attention shapes of the GROVE step (random data)."""
 import sys
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from grove_amd import ops
 dev = torch.device("cuda:0")
 bf = torch.bfloat16

@@ -1,0 +1,19 @@
+"""PMC target: SAM window attention fwd + bwd (a few launches)."""
+import sys
+import torch
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+from grove_amd import ops
+dev = torch.device("cuda:0")
+bf = torch.bfloat16
+B, H, L, hs, hd = 288, 16, 196, 96, 80
+qkv = torch.zeros(B * L, 3 * H * hs, device=dev)
+qkv.view(B * L, 3, H, hs)[..., :hd] = torch.randn(B * L, 3, H, hd, device=dev)
+qkv = qkv.to(bf)
+do = torch.randn(B * L, H * hs, device=dev).to(bf)
+rel = torch.randn(B * H, L, 32, device=dev).to(bf)
+dq = torch.empty_like(qkv)
+for _ in range(3):
+    out, lse = ops.flash_attn(qkv, B, L, H, hs, 0, H * hs, 2 * H * hs, hd ** -0.5, rel=rel, rel_hw=(16, 14), want_lse=True)
+    ops.flash_attn_bwd(qkv, out, do, lse, dq, B, L, H, hs, 0, H * hs, 2 * H * hs, hd ** -0.5, rel=rel, rel_hw=(16, 14), want_drel=True)
+torch.cuda.synchronize()
+print("done")
