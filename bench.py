@@ -54,8 +54,8 @@ def instrumented_gemm_pass(engine, batch):
     from grove_amd import _lib, ops
     orig = ops.gemm_raw
     recs = []
-    names = {1: "gemm_nt_kernel<128x128>", 2: "gemm_nt_kernel<192x128>", 3: "gemm_nt_kernel<128x64>", 4: "gemm_nt_pp_kernel<256>",
-             5: "gemm_nt_pp_kernel<192>"}
+    names = {1: "gemm_nt_kernel<128x128>", 2: "gemm_nt_kernel<192x128>", 3: "gemm_nt_kernel<128x64>", 4: "gemm_nt_pp_kernel<256, false>",
+             5: "gemm_nt_pp_kernel<192, false>", 6: "gemm_nt_pp_kernel<256, true>", 7: "gemm_nt_pp_kernel<192, true>"}
 
     def timed(A, B, C, M, N, K, *a, **k):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -237,7 +237,7 @@ def main():
     traffic = None
     try:  # memory-side bytes per launch from the committed PMC passes (profiles/, collected as the microarch guide prescribes)
         with open(os.path.join(ROOT, "profiles", "r01_pmc_gemm_traffic.json")) as fh:
-            traffic = json.load(fh)["launch_weighted_mean_bytes"].get(dom[dom.index("<"):])
+            traffic = json.load(fh)["launch_weighted_mean_bytes"].get(dom[dom.index("<"):dom.index(",")] + ">")
     except Exception:
         pass
     if rank == 0:

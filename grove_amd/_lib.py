@@ -117,18 +117,29 @@ class DecodeAttnParams(C.Structure):
                 ("S_max", c_i32), ("ld_qkv", c_i32), ("theta", c_f32), ("alpha", c_f32)]
 
 
+class ResampleParams(C.Structure):
+    _fields_ = [("src", c_vp), ("dst", c_vp), ("kk", c_vp), ("bounds", c_vp), ("F", c_i32), ("Hin", c_i32), ("Win", c_i32),
+                ("Hout", c_i32), ("Wout", c_i32), ("ksize", c_i32), ("axis", c_i32)]
+
+
+class NormalizeParams(C.Structure):
+    _fields_ = [("src", c_vp), ("dst", c_vp), ("F", c_i32), ("H", c_i32), ("W", c_i32), ("Ho", c_i32), ("Wo", c_i32),
+                ("top", c_i32), ("left", c_i32), ("out_dtype", c_i32), ("rescale", c_f32), ("mean", c_f32 * 3), ("std", c_f32 * 3)]
+
+
 STRUCTS = {
     "grove_gemm_params": GemmParams, "grove_transpose_params": TransposeParams, "grove_norm_params": NormParams,
     "grove_norm_bwd_params": NormBwdParams, "grove_softmax_params": SoftmaxParams,
     "grove_softmax_bwd_params": SoftmaxBwdParams, "grove_relpos_params": RelposParams, "grove_rope_params": RopeParams,
     "grove_rows_params": RowsParams, "grove_small_attn_params": SmallAttnParams, "grove_box_head_params": BoxHeadParams,
     "grove_box_head_bwd_params": BoxHeadBwdParams, "grove_flash_attn_params": FlashAttnParams,
-    "grove_gemm_tn_params": GemmTnParams, "grove_gemv_params": GemvParams, "grove_decode_attn_params": DecodeAttnParams,
+    "grove_gemm_tn_params": GemmTnParams, "grove_gemv_params": GemvParams, "grove_decode_attn_params": DecodeAttnParams, "grove_resample_params": ResampleParams,
+    "grove_normalize_params": NormalizeParams,
 }
 
 # every symbol include/grove_hip.h declares (tests/test_abi.py checks the header against this list)
 SYMBOLS = [
-    "grove_version", "grove_last_error", "grove_sizeof", "grove_gemm_bf16", "grove_gemm_last_variant", "grove_gemm_set_staging", "grove_gemm_set_tile_n", "grove_gemm_set_tile_m", "grove_gemm_set_bk", "grove_gemm_tn_bf16", "grove_gemm_tn_set_pipelined", "grove_gemv_bf16", "grove_decode_attn",
+    "grove_version", "grove_last_error", "grove_sizeof", "grove_gemm_bf16", "grove_gemm_last_variant", "grove_gemm_set_staging", "grove_gemm_set_tile_n", "grove_gemm_set_tile_m", "grove_gemm_set_bk", "grove_gemm_tn_bf16", "grove_gemm_tn_set_pipelined", "grove_gemv_bf16", "grove_decode_attn", "grove_resample_u8", "grove_normalize_pack",
     "grove_transpose_bf16", "grove_layernorm_fwd", "grove_rmsnorm_fwd", "grove_layernorm_bwd", "grove_rmsnorm_bwd",
     "grove_flash_attn_fwd", "grove_flash_attn_bwd", "grove_softmax_fwd", "grove_softmax_bwd", "grove_relpos_fwd", "grove_relpos_bwd", "grove_rope_inplace",
     "grove_swiglu_fwd", "grove_swiglu_bwd", "grove_act_bwd", "grove_add_bf16", "grove_add_bcast_rows",

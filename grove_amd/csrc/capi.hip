@@ -41,6 +41,8 @@ extern "C" int grove_sizeof(const char* name) {
   SZ(grove_gemm_tn_params);
   SZ(grove_gemv_params);
   SZ(grove_decode_attn_params);
+  SZ(grove_resample_params);
+  SZ(grove_normalize_params);
 #undef SZ
   return -1;
 }

@@ -855,13 +855,13 @@ extern "C" int grove_gemm_bf16(const grove_gemm_params* pp, void* stream) {
   const double cp192 = pp_cost(tp192, 1.17, 0.8 * (3.0 + 3.0 * out_scale));
   const double c_old = c128 < c192 ? c128 : c192;
   if (p256_ok && (g_gemm_tile_m == 193 || g_gemm_tile_m == 256)) {
-    g_gemm_last_variant = g_gemm_tile_m == 256 ? GROVE_GEMM_PP256 : GROVE_GEMM_PP192;
+    g_gemm_last_variant = g_gemm_tile_m == 256 ? (p.a_idx ? GROVE_GEMM_PP256_GATHER : GROVE_GEMM_PP256) : (p.a_idx ? GROVE_GEMM_PP192_GATHER : GROVE_GEMM_PP192);
     if (p.a_idx) return g_gemm_tile_m == 256 ? launch_pp<256, true>(p, s) : launch_pp<192, true>(p, s);
     return g_gemm_tile_m == 256 ? launch_pp<256, false>(p, s) : launch_pp<192, false>(p, s);
   }
   if (p256_ok && g_gemm_tile_m == 0 && g_gemm_tile_n == 0 && tp192 >= 48 && (cp256 < c_old || cp192 < c_old))
     {
-      g_gemm_last_variant = cp256 <= cp192 ? GROVE_GEMM_PP256 : GROVE_GEMM_PP192;
+      g_gemm_last_variant = cp256 <= cp192 ? (p.a_idx ? GROVE_GEMM_PP256_GATHER : GROVE_GEMM_PP256) : (p.a_idx ? GROVE_GEMM_PP192_GATHER : GROVE_GEMM_PP192);
       if (p.a_idx) return cp256 <= cp192 ? launch_pp<256, true>(p, s) : launch_pp<192, true>(p, s);
       return cp256 <= cp192 ? launch_pp<256, false>(p, s) : launch_pp<192, false>(p, s);
     }

@@ -93,8 +93,10 @@ enum grove_gemm_variant {
   GROVE_GEMM_T128X128 = 1, /* gemm_nt_kernel, 128 x 128 tile */
   GROVE_GEMM_T192X128 = 2, /* gemm_nt_kernel, 192 x 128 tile */
   GROVE_GEMM_T128X64 = 3,  /* gemm_nt_kernel, 128 x 64 tile */
-  GROVE_GEMM_PP256 = 4,    /* gemm_nt_pp_kernel<256>: persistent pipelined 256 x 256 x 64 */
-  GROVE_GEMM_PP192 = 5     /* gemm_nt_pp_kernel<192>: persistent pipelined 192 x 256 x 64 */
+  GROVE_GEMM_PP256 = 4,        /* gemm_nt_pp_kernel<256, false>: persistent pipelined 256 x 256 x 64 */
+  GROVE_GEMM_PP192 = 5,        /* gemm_nt_pp_kernel<192, false>: persistent pipelined 192 x 256 x 64 */
+  GROVE_GEMM_PP256_GATHER = 6, /* gemm_nt_pp_kernel<256, true>: the same with gathered A rows (a_idx) */
+  GROVE_GEMM_PP192_GATHER = 7  /* gemm_nt_pp_kernel<192, true> */
 };
 int grove_gemm_last_variant(void);
 /* A/B staging variant: 1 = LDS-DMA (global_load_lds, default), 0 = register staged */
@@ -323,6 +325,38 @@ typedef struct grove_decode_attn_params {
   float theta, alpha;
 } grove_decode_attn_params;
 int grove_decode_attn(const grove_decode_attn_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Frame preprocessing on the device. One separable pass of Pillow's 8-bit resampler
+ * (ImagingResample: 22-bit fixed-point coefficients, half-up rounding, uint8 clamp) over uint8 RGB frames
+ * [F, H, W, 3]; the reference runs it on the host through torchvision / transformers:
+ * transforms.py:27-34 (`resize(to_pil_image(image), target_size)`, bilinear) and CLIPImageProcessor.preprocess
+ * (bicubic, HowTo100M.py:309). kk: int32 [out_size, ksize] coefficients, bounds: int32 [out_size, 2] = (first input
+ * index, count) per output index (grove_amd/preprocess.py builds both exactly as Pillow does).
+ * axis 0 = horizontal (Hout == Hin), axis 1 = vertical (Wout == Win).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct grove_resample_params {
+  const void* src; /* u8 [F, Hin, Win, 3] */
+  void* dst;       /* u8 [F, Hout, Wout, 3] */
+  const int32_t* kk;
+  const int32_t* bounds;
+  int32_t F, Hin, Win, Hout, Wout;
+  int32_t ksize, axis;
+} grove_resample_params;
+int grove_resample_u8(const grove_resample_params* p, void* stream);
+
+/* u8 [F, H, W, 3] -> bf16 / f32 [3, F, Ho, Wo] (the `b c t h w` layout the encoders take):
+ * out[c, f, y, x] = (src[f, top + y, left + x, c] * rescale - mean[c]) / std[c], 0 outside the source (SAM pads right /
+ * bottom AFTER normalising: HowTo100M.py:168-178; CLIP centre-crops: top, left > 0). */
+typedef struct grove_normalize_params {
+  const void* src;
+  void* dst;
+  int32_t F, H, W, Ho, Wo, top, left;
+  int32_t out_dtype;
+  float rescale;
+  float mean[3], std[3];
+} grove_normalize_params;
+int grove_normalize_pack(const grove_normalize_params* p, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Elementwise / data-movement kernels (all bf16, vectorised 16 B per lane).
