@@ -524,27 +524,27 @@ __global__ __launch_bounds__(NTHR, (HS <= 96 ? 2 : 1)) void flash_bwd_dkv_kernel
         const bf16x8_t qb = lds_tr_frag(Qs, C::ROWB, s2 * 32, dt * 16, lane);
 #pragma unroll
         for (int nj = 0; nj < 2; ++nj) {
-          dv[nj][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pfr[nj], dob, dv[nj][dt], 0, 0, 0);
-          dk[nj][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsfr[nj], qb, dk[nj][dt], 0, 0, 0);
+          // operands swapped (D^T): the lane then owns 4 CONSECUTIVE d of one key — 8-byte stores below instead of 2-byte ones
+          dv[nj][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dob, pfr[nj], dv[nj][dt], 0, 0, 0);
+          dk[nj][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qb, dsfr[nj], dk[nj][dt], 0, 0, 0);
         }
       }
     }
   }
-  // lane holds dK/dV[key = 4g + r][d = dt*16 + fr]
+  // lane holds dK^T/dV^T[d = dt*16 + 4g + r][key = fr]
   bf16_raw* DK = (bf16_raw*)p.dk + (int64_t)b * p.sdk + h * HS;
   bf16_raw* DV = (bf16_raw*)p.dv + (int64_t)b * p.sdv + h * HS;
 #pragma unroll
-  for (int nj = 0; nj < 2; ++nj)
+  for (int nj = 0; nj < 2; ++nj) {
+    const int kj = k0 + nj * 16 + fr;
+    if (kj >= p.Lk) continue;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int kj = k0 + nj * 16 + g * 4 + r;
-      if (kj >= p.Lk) continue;
-#pragma unroll
-      for (int dt = 0; dt < C::DT; ++dt) {
-        DK[(int64_t)kj * p.ld_dk + dt * 16 + fr] = f2bf(dk[nj][dt][r]);
-        DV[(int64_t)kj * p.ld_dv + dt * 16 + fr] = f2bf(dv[nj][dt][r]);
-      }
+    for (int dt = 0; dt < C::DT; ++dt) {
+      const f32x4_t a = dk[nj][dt], c = dv[nj][dt];
+      *(u32x2_t*)(DK + (int64_t)kj * p.ld_dk + dt * 16 + g * 4) = u32x2_t{pack2bf(a[0], a[1]), pack2bf(a[2], a[3])};
+      *(u32x2_t*)(DV + (int64_t)kj * p.ld_dv + dt * 16 + g * 4) = u32x2_t{pack2bf(c[0], c[1]), pack2bf(c[2], c[3])};
     }
+  }
 }
 
 // ================================================================================ backward: dQ (+ d rel)
