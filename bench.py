@@ -91,6 +91,42 @@ def instrumented_gemm_pass(engine, batch):
     return per_kernel
 
 
+def vit_llama_forward(model, batch, dims, reps=5):
+    """north_star's stage figure: the fused CLIP-ViT + projector + LLaMA FORWARD at the bench batch (no SAM, no heads), timed with
+    HIP events; algorithmic FLOPs per SURVEY.md section 8(d): per frame CLIP 0.69 + 23 x (2*577*12.58e6 + 4*577^2*1024) flop
+    (layer 24's output is never read), 24 GF per 8-frame group for the projector, per sequence S*2*6.476e9 + 2*S^2*4096*32."""
+    from grove_amd.model.GROVE import bf
+    d = dims
+    g = model._windows(batch["global_enc_images"], batch["grounding_enc_images"], batch["input_ids"], None, None, [None, None])
+    gimg, ids = g[0], g[2]
+    B = ids.shape[0]
+
+    def run():
+        feats, _ = model.encode_images(gimg)
+        plan = model._splice_plan(ids, None, None, list(range(B)))
+        x = model._embed(plan, feats.data if hasattr(feats, "data") else feats)
+        hidden, _ = model.llama.forward(x, plan.B, plan.S)
+        return plan.S
+    with torch.no_grad():
+        S = run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    frames = gimg.shape[0] * gimg.shape[2]
+    tok = 577
+    clip = frames * (0.69e9 + (d.clip_layers - 1) * (2 * tok * 12.58e6 + 4 * tok * tok * d.clip_dim))
+    proj = (frames // 8) * 24e9
+    llama = B * (S * 2 * 6.476e9 + 2.0 * S * S * d.hidden * d.n_layers)
+    flops = clip + proj + llama
+    return {"ms": round(ms, 2), "flops": flops, "achieved": round(flops / ms / 1e9, 1), "unit": "TFLOP/s",
+            "frac_of_bf16_peak": round(flops / ms / 1e9 / PEAK_BF16_TFLOPS, 4), "windows": B, "S": S}
+
+
 def cpu_baseline(args):
     """Oracle (CPU port) on a bounded sample of the same workload: one 8-frame window at FULL dimensions, one
     layer of each tower forward (+ backward where the step has one), scaled by the layer counts of the step."""
@@ -258,6 +294,11 @@ def main():
                          "all_gemm_kernels": {"launches_per_step": all_n, "flops_per_step": all_f, "achieved": round(all_f / all_s / 1e12, 2),
                                               "share_of_step": round(all_s / (dt / args.steps), 3)}},
         }
+        if args.dims == "full":
+            try:
+                res["fused_vit_llama_forward"] = vit_llama_forward(model, batch, dims)
+            except Exception as e:
+                res["fused_vit_llama_forward"] = {"error": repr(e)}
         if not args.no_cpu_baseline:
             try:
                 res["box_l1_vs_oracle_tiny"] = round(tiny_box_l1(dev), 6)

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libgrove_hip.so")
 
 c_i32, c_i64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
-ACT_NONE, ACT_RELU, ACT_GELU, ACT_QUICKGELU, ACT_SILU, ACT_SIGMOID = range(6)
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_QUICKGELU, ACT_SILU, ACT_SIGMOID, ACT_SWIGLU_PAIR = range(7)
 BF16, F32 = 0, 1
 
 
@@ -23,7 +23,7 @@ class GemmParams(C.Structure):
                 ("M", c_i32), ("N", c_i32), ("K", c_i32),
                 ("lda", c_i32), ("ldb", c_i32), ("ldc", c_i32), ("ldr", c_i32),
                 ("batch1", c_i32), ("batch2", c_i32), ("a_taps", c_i32), ("act", c_i32),
-                ("c_dtype", c_i32), ("accumulate", c_i32), ("scale_tanh", c_i32), ("alpha", c_f32), ("split_k", c_i32)]
+                ("c_dtype", c_i32), ("accumulate", c_i32), ("scale_tanh", c_i32), ("alpha", c_f32), ("split_k", c_i32), ("ld_aux", c_i32)]
 
 
 class TransposeParams(C.Structure):

@@ -435,11 +435,29 @@ __device__ __forceinline__ void gemm_epilogue_wide(const grove_gemm_params& p, f
           v[4 + e] = acc[i][2 * g + 1][e] * p.alpha + bv[4 + e];
         }
       }
+      if constexpr (ACT == GROVE_ACT_SWIGLU_PAIR) {
+        // v[0..3] = gate, v[4..7] = up of columns (n / 8) * 4 .. + 3 (B rows interleaved by the caller). Rounded to bf16 first:
+        // the same values the unfused path stores and reads back, so the product is bit-identical to grove_swiglu_fwd's.
+        const unsigned g01 = pack2bf(v[0], v[1]), g23 = pack2bf(v[2], v[3]), u01 = pack2bf(v[4], v[5]), u23 = pack2bf(v[6], v[7]);
+        const int half = p.N >> 1, nc = (n >> 3) * 4;
+        if (p.aux) {
+          bf16_raw* ax = (bf16_raw*)p.aux + (int64_t)crow[i] * (p.ld_aux ? p.ld_aux : p.ldc) + nc;
+          *(u32x2_t*)ax = u32x2_t{g01, g23};
+          *(u32x2_t*)(ax + half) = u32x2_t{u01, u23};
+        }
+        const float gg[4] = {bf_lo(g01), bf_hi(g01), bf_lo(g23), bf_hi(g23)};
+        const float uu[4] = {bf_lo(u01), bf_hi(u01), bf_lo(u23), bf_hi(u23)};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = gg[e] / (1.f + __expf(-gg[e])) * uu[e];
+        *(u32x2_t*)((bf16_raw*)p.C + (int64_t)crow[i] * p.ldc + nc) = u32x2_t{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+        continue;
+      }
       if (p.aux)
-        *(u32x4_t*)((bf16_raw*)p.aux + (int64_t)crow[i] * p.ldc + n) =
+        *(u32x4_t*)((bf16_raw*)p.aux + (int64_t)crow[i] * (p.ld_aux ? p.ld_aux : p.ldc) + n) =
             u32x4_t{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
       if (!PLAIN) {
-        if (ACT != GROVE_ACT_NONE) {
+        if (ACT != GROVE_ACT_NONE && ACT != GROVE_ACT_SWIGLU_PAIR) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = act_apply(ACT, v[e]);
         }
@@ -713,6 +731,8 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
         gemm_epilogue_wide<MIH, BMH, GROVE_ACT_GELU>(p, acc, mw0, nw0, fr, fq, scale);
       } else if (p.act == GROVE_ACT_RELU) {
         gemm_epilogue_wide<MIH, BMH, GROVE_ACT_RELU>(p, acc, mw0, nw0, fr, fq, scale);
+      } else if (p.act == GROVE_ACT_SWIGLU_PAIR) {
+        gemm_epilogue_wide<MIH, BMH, GROVE_ACT_SWIGLU_PAIR>(p, acc, mw0, nw0, fr, fq, scale);
       } else {
         gemm_epilogue_wide<MIH, BMH, GROVE_ACT_QUICKGELU>(p, acc, mw0, nw0, fr, fq, scale);
       }
@@ -833,7 +853,8 @@ extern "C" int grove_gemm_bf16(const grove_gemm_params* pp, void* stream) {
   const bool wide_ok = (((uintptr_t)p.C & 15) == 0) && (p.ldc % (p.c_dtype == GROVE_BF16 ? 8 : 4) == 0) &&
                        (!p.aux || ((uintptr_t)p.aux & 15) == 0) && (!p.bias || ((uintptr_t)p.bias & 15) == 0) &&
                        (!p.residual || ((((uintptr_t)p.residual & 15) == 0) && p.ldr % 8 == 0));
-  const bool pp_act = p.act == GROVE_ACT_NONE || p.act == GROVE_ACT_GELU || p.act == GROVE_ACT_QUICKGELU || p.act == GROVE_ACT_RELU;  // compiled-in epilogues
+  const bool pp_act = p.act == GROVE_ACT_NONE || p.act == GROVE_ACT_GELU || p.act == GROVE_ACT_QUICKGELU || p.act == GROVE_ACT_RELU ||
+                      p.act == GROVE_ACT_SWIGLU_PAIR;  // compiled-in epilogues
   const bool p256_ok = g_gemm_glds && bk64 && (!p.a_idx || (long)p.a_taps * p.M >= 8) && bt == 1 && p.split_k <= 1 && !p.accumulate && wide_ok && p.N % 8 == 0 && pp_act;
   // Tile choice by a measured cost model (tools/bench_gemm5.py, microseconds): time = rounds of resident blocks x
   // (K tiles x per-K-tile time + fixed per-tile time). The 128- and 192-row kernels keep 2 blocks per CU (512 slots; a
@@ -858,6 +879,12 @@ extern "C" int grove_gemm_bf16(const grove_gemm_params* pp, void* stream) {
     g_gemm_last_variant = g_gemm_tile_m == 256 ? (p.a_idx ? GROVE_GEMM_PP256_GATHER : GROVE_GEMM_PP256) : (p.a_idx ? GROVE_GEMM_PP192_GATHER : GROVE_GEMM_PP192);
     if (p.a_idx) return g_gemm_tile_m == 256 ? launch_pp<256, true>(p, s) : launch_pp<192, true>(p, s);
     return g_gemm_tile_m == 256 ? launch_pp<256, false>(p, s) : launch_pp<192, false>(p, s);
+  }
+  if (p.act == GROVE_ACT_SWIGLU_PAIR) {  // only the pipelined kernel's epilogue implements it
+    GROVE_CHECK(p256_ok && p.N % 16 == 0 && p.c_dtype == GROVE_BF16 && !p.residual && p.ldc % 4 == 0 && (p.ld_aux % 4 == 0), GROVE_E_SHAPE,
+                "gemm: act SWIGLU_PAIR needs the pipelined kernel (plain un-batched bf16 GEMM, K %% 64 == 0, N %% 16 == 0, aligned operands)");
+    g_gemm_last_variant = cp256 <= cp192 ? GROVE_GEMM_PP256 : GROVE_GEMM_PP192;
+    return cp256 <= cp192 ? launch_pp<256, false>(p, s) : launch_pp<192, false>(p, s);
   }
   if (p256_ok && g_gemm_tile_m == 0 && g_gemm_tile_n == 0 && tp192 >= 48 && (cp256 < c_old || cp192 < c_old))
     {

@@ -184,7 +184,44 @@ __global__ __launch_bounds__(256) void relpos_bwd_kernel(const grove_relpos_para
 }
 
 // ---------------------------------------------------------------- rotary embedding
-// thread = (row, i < hd/2); loops over heads. angle = pos * theta^(-2i/hd).
+// thread = (row, group of 8 heads, 16-byte chunk c of the first half): the 8 angles pos * theta^(-2i/hd), i = 8c .. 8c+7, are
+// evaluated once and reused for the group's heads; every access is 16 bytes (x[i] and its partner x[i + hd/2] live in two
+// chunks of the same head). hd % 16 == 0; any hd with hd/2 % 8 != 0 takes the scalar kernel below.
+constexpr int ROPE_HG = 8;
+__global__ __launch_bounds__(256) void rope_vec_kernel(const grove_rope_params p) {
+  const int half = p.hd >> 1, cph = half >> 3;  // chunks per half head
+  const int ngroups = (p.nheads + ROPE_HG - 1) / ROPE_HG;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)p.rows * ngroups * cph) return;
+  const int c = (int)(t % cph);
+  const int hg = (int)((t / cph) % ngroups);
+  const int row = (int)(t / ((int64_t)cph * ngroups));
+  const float pos = (float)p.pos[row];
+  float cs[8], sn[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float inv_freq = powf(p.theta, -2.f * (float)(c * 8 + j) / (float)p.hd);
+    sincosf(pos * inv_freq, &sn[j], &cs[j]);
+    if (p.inverse) sn[j] = -sn[j];
+  }
+  const int h0 = hg * ROPE_HG, h1 = min(p.nheads, h0 + ROPE_HG);
+  bf16_raw* x = (bf16_raw*)p.x + (int64_t)row * p.ld + p.col0 + (int64_t)h0 * p.hd + c * 8;
+  for (int h = h0; h < h1; ++h, x += p.hd) {
+    const u32x4_t a = *(const u32x4_t*)x, b2 = *(const u32x4_t*)(x + half);
+    const float x1[8] = {bf_lo(a.x), bf_hi(a.x), bf_lo(a.y), bf_hi(a.y), bf_lo(a.z), bf_hi(a.z), bf_lo(a.w), bf_hi(a.w)};
+    const float x2[8] = {bf_lo(b2.x), bf_hi(b2.x), bf_lo(b2.y), bf_hi(b2.y), bf_lo(b2.z), bf_hi(b2.z), bf_lo(b2.w), bf_hi(b2.w)};
+    float o1[8], o2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      o1[j] = x1[j] * cs[j] - x2[j] * sn[j];
+      o2[j] = x2[j] * cs[j] + x1[j] * sn[j];
+    }
+    *(u32x4_t*)x = u32x4_t{pack2bf(o1[0], o1[1]), pack2bf(o1[2], o1[3]), pack2bf(o1[4], o1[5]), pack2bf(o1[6], o1[7])};
+    *(u32x4_t*)(x + half) = u32x4_t{pack2bf(o2[0], o2[1]), pack2bf(o2[2], o2[3]), pack2bf(o2[4], o2[5]), pack2bf(o2[6], o2[7])};
+  }
+}
+
+// scalar form — thread = (row, i < hd/2); loops over heads. angle = pos * theta^(-2i/hd).
 __global__ __launch_bounds__(256) void rope_kernel(const grove_rope_params p) {
   const int half = p.hd >> 1;
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -264,6 +301,13 @@ extern "C" int grove_relpos_bwd(const grove_relpos_params* p, void* stream) {
 
 extern "C" int grove_rope_inplace(const grove_rope_params* p, void* stream) {
   GROVE_CHECK(p && p->rows > 0 && p->nheads > 0 && p->hd > 0 && (p->hd & 1) == 0, GROVE_E_SHAPE, "rope: bad shape");
+  const bool vec = (p->hd % 16 == 0) && (p->ld % 8 == 0) && (p->col0 % 8 == 0) && (((uintptr_t)p->x & 15) == 0);
+  if (vec) {
+    const int64_t nv = (int64_t)p->rows * ((p->nheads + ROPE_HG - 1) / ROPE_HG) * (p->hd / 16);
+    hipLaunchKernelGGL(rope_vec_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *p);
+    GROVE_LAUNCH_CHECK();
+    return GROVE_OK;
+  }
   const int64_t n = (int64_t)p->rows * (p->hd / 2);
   hipLaunchKernelGGL(rope_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *p);
   GROVE_LAUNCH_CHECK();

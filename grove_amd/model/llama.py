@@ -24,6 +24,10 @@ class LlamaStack:
             wgu = torch.cat([sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"]], 0).contiguous()
             L = {"ln1": sd[p + "input_layernorm.weight"], "ln2": sd[p + "post_attention_layernorm.weight"],
                  "wqkv": wqkv, "wo": sd[p + "self_attn.o_proj.weight"], "wgu": wgu, "wd": sd[p + "mlp.down_proj.weight"]}
+            if d.mlp % 4 == 0:
+                # gate / up rows interleaved [4 gate, 4 up]: the gate|up GEMM then applies silu(gate) * up in its epilogue
+                # (ACT_SWIGLU_PAIR) and writes the product directly — no [rows, 2I] round trip, no separate SwiGLU launch
+                L["wgu_sw"] = ops.swiglu_interleave(wgu)
             if train:
                 for k in ("wqkv", "wo", "wgu", "wd"):
                     L[k + "_t"] = ops.transpose2d(L[k])
@@ -47,8 +51,12 @@ class LlamaStack:
             o, actx = attention_fwd(qkv, B, S, nh, hd, 0, H, 2 * H, hd ** -0.5, causal=True, kv_len=kv_len, save=save)
             x1 = ops.linear(o, L["wo"], residual=x)
             h2 = ops.rmsnorm(x1, L["ln2"], d.rms_eps)
-            gu = ops.linear(h2, L["wgu"])
-            a = ops.swiglu(gu, I)
+            if "wgu_sw" in L and h2.shape[0] >= 1024:  # (the fused epilogue lives in the pipelined kernel: big GEMMs only)
+                gu = torch.empty((h2.shape[0], 2 * I), dtype=torch.bfloat16, device=self.dev) if save else None
+                a = ops.linear(h2, L["wgu_sw"], act=ops.ACT_SWIGLU_PAIR, aux=gu, ld_aux=2 * I)
+            else:
+                gu = ops.linear(h2, L["wgu"])
+                a = ops.swiglu(gu, I)
             x2 = ops.linear(a, L["wd"], residual=x1)
             if save:
                 saved.append((x, qkv, actx, x1, gu))

@@ -9,7 +9,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (ACT_GELU, ACT_NONE, ACT_QUICKGELU, ACT_RELU, ACT_SIGMOID, ACT_SILU, BF16, F32)  # noqa: F401
+from ._lib import (ACT_GELU, ACT_NONE, ACT_QUICKGELU, ACT_RELU, ACT_SIGMOID, ACT_SILU, ACT_SWIGLU_PAIR, BF16, F32)  # noqa: F401
 
 bf16 = torch.bfloat16
 
@@ -34,7 +34,7 @@ def pad_to(n, m):
 
 def gemm_raw(A, B, Cout, M, N, K, lda, ldb, ldc, *, bias=None, residual=None, ldr=0, aux=None, scale_ptr=None,
              scale_tanh=False, a_idx=None, a_taps=1, c_idx=None, r_idx=None, batch=(1, 1), sA=(0, 0), sB=(0, 0),
-             sC=(0, 0), sR=(0, 0), act=ACT_NONE, accumulate=False, alpha=1.0, split_k=0):
+             sC=(0, 0), sR=(0, 0), act=ACT_NONE, accumulate=False, alpha=1.0, split_k=0, ld_aux=0):
     """Direct call of grove_gemm_bf16; A/B/Cout are tensors whose storage the pointers refer to."""
     _chk_dev(A, B, Cout)
     p = _lib.GemmParams()
@@ -50,13 +50,14 @@ def gemm_raw(A, B, Cout, M, N, K, lda, ldb, ldc, *, bias=None, residual=None, ld
     p.c_dtype = F32 if Cout.dtype == torch.float32 else BF16
     p.accumulate, p.scale_tanh, p.alpha = int(accumulate), int(scale_tanh), float(alpha)
     p.split_k = split_k
+    p.ld_aux = ld_aux
     _lib.check(_lib.lib().grove_gemm_bf16(C.byref(p), _stream()), "grove_gemm_bf16")
     return Cout
 
 
 def linear(x, w, bias=None, *, act=ACT_NONE, residual=None, out=None, out_dtype=bf16, aux=None, alpha=1.0,
            scale_ptr=None, scale_tanh=False, a_idx=None, a_taps=1, c_idx=None, r_idx=None, M=None, out_rows=None,
-           accumulate=False):
+           accumulate=False, ld_aux=0):
     """y = epilogue(x @ w.T): x [*, K] (row stride lda), w [N, K] (nn.Linear layout)."""
     K = w.shape[1]
     N = w.shape[0]
@@ -68,11 +69,11 @@ def linear(x, w, bias=None, *, act=ACT_NONE, residual=None, out=None, out_dtype=
         assert x2.shape[1] == K, f"linear: x has K={x2.shape[1]}, weight has K={K}"
     if out is None:
         rows = out_rows if out_rows is not None else M
-        out = torch.empty((rows, N), dtype=out_dtype, device=x.device)
+        out = torch.empty((rows, N // 2 if act == ACT_SWIGLU_PAIR else N), dtype=out_dtype, device=x.device)
     ldr = residual.stride(0) if residual is not None else 0
     gemm_raw(x2, w, out, M, N, K, x2.stride(0), w.stride(0), out.stride(0), bias=bias, residual=residual, ldr=ldr,
              aux=aux, scale_ptr=scale_ptr, scale_tanh=scale_tanh, a_idx=a_idx, a_taps=a_taps, c_idx=c_idx, r_idx=r_idx,
-             act=act, accumulate=accumulate, alpha=alpha)
+             act=act, accumulate=accumulate, alpha=alpha, ld_aux=ld_aux)
     return out
 
 
@@ -324,6 +325,14 @@ def rope_(x, pos, col0, nheads, hd, theta, inverse=False):
     p.inverse, p.theta = int(inverse), theta
     _lib.check(_lib.lib().grove_rope_inplace(C.byref(p), _stream()), "grove_rope_inplace")
     return x
+
+
+def swiglu_interleave(wgu):
+    """[gate; up] rows ([2I, K]) -> rows interleaved [4 gate, 4 up] per 8, the B operand of the ACT_SWIGLU_PAIR GEMM."""
+    I = wgu.shape[0] // 2
+    assert I % 4 == 0
+    g, u = wgu[:I].view(I // 4, 4, -1), wgu[I:].view(I // 4, 4, -1)
+    return torch.cat([g, u], 1).reshape(2 * I, -1).contiguous()
 
 
 def swiglu(gu, I):

@@ -36,7 +36,10 @@ enum grove_act {
   GROVE_ACT_GELU = 2,      /* erf GELU: mm_projector (llava_with_region_arch.py:17), SAM MLPBlock */
   GROVE_ACT_QUICKGELU = 3, /* CLIP MLP (modeling_clip.py:336-348) */
   GROVE_ACT_SILU = 4,      /* LLaMA SwiGLU gate */
-  GROVE_ACT_SIGMOID = 5
+  GROVE_ACT_SIGMOID = 5,
+  GROVE_ACT_SWIGLU_PAIR = 6 /* LlamaMLP's silu(gate) * up folded into the gate|up GEMM: B rows interleaved [4 gate, 4 up] per 8, C gets
+                               N / 2 columns (the product), aux (optional, row stride ld_aux) the un-interleaved gate | up pre-activations;
+                               pipelined kernel only */
 };
 
 enum grove_dtype { GROVE_BF16 = 0, GROVE_F32 = 1 };
@@ -86,6 +89,7 @@ typedef struct grove_gemm_params {
   float alpha;
   int32_t split_k;    /* 0 = auto (accumulating f32 GEMMs only), 1 = off, >1 = K range split over blockIdx.z,
                          partials combined with fp32 atomics into the pre-initialised C */
+  int32_t ld_aux;     /* row stride of aux; 0 = ldc */
 } grove_gemm_params;
 int grove_gemm_bf16(const grove_gemm_params* p, void* stream);
 /* Which kernel the last grove_gemm_bf16 call launched (measurement aid: bench.py prices each kernel on its own launches). */

@@ -730,3 +730,22 @@ def test_wgrad_tn_pipelined(dev):
         close(out, ref, 2e-6, "pipelined conv3d wgrad vs 128x128 kernel")
     finally:
         L.grove_gemm_tn_set_pipelined(-1)
+
+
+@pytest.mark.parametrize("M,I,K,save", [(2812, 1024, 256, True), (1500, 2752, 128, False)])
+def test_gemm_swiglu_pair_epilogue(dev, M, I, K, save):
+    """LlamaMLP's silu(gate) * up folded into the gate|up GEMM (interleaved weight rows, ACT_SWIGLU_PAIR): bit-identical to the
+    GEMM + grove_swiglu_fwd pair, and the optional aux output is the un-interleaved gate | up activation."""
+    from grove_amd import ops
+    x, wgu = rnd(M, K, seed=1).to(dev), rnd(2 * I, K, seed=2, scale=0.2).to(dev)
+    gu_ref = ops.linear(x, wgu)
+    a_ref = ops.swiglu(gu_ref, I)
+    gu = torch.empty((M, 2 * I), dtype=bf16, device=dev) if save else None
+    a = ops.linear(x, ops.swiglu_interleave(wgu), act=ops.ACT_SWIGLU_PAIR, aux=gu, ld_aux=2 * I)
+    assert a.shape == (M, I)
+    assert torch.equal(a, a_ref), (a.float() - a_ref.float()).abs().max().item()
+    if save:
+        assert torch.equal(gu, gu_ref)
+    xf, wf = x.float().cpu(), wgu.float().cpu()
+    g, u = xf @ wf[:I].t(), xf @ wf[I:].t()
+    close(a, torch.nn.functional.silu(g) * u, 2 ** -6, "swiglu pair vs fp32")
