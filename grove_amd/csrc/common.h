@@ -79,13 +79,17 @@ __device__ __forceinline__ float fast_erf(float x) {
   return copysignf(r, x);
 }
 
+// logistic function with the hardware reciprocal (v_rcp_f32, 1 ulp) instead of an IEEE division (~10 instructions): every
+// sigmoid-shaped activation of the path goes through it, so fused and unfused forms stay bit-identical to each other.
+__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.f + __expf(-x)); }
+
 __device__ __forceinline__ float act_apply(int act, float x) {
   switch (act) {
     case GROVE_ACT_RELU: return fmaxf(x, 0.f);
     case GROVE_ACT_GELU: return 0.5f * x * (1.f + fast_erf(x * 0.70710678118654752440f));
-    case GROVE_ACT_QUICKGELU: return x / (1.f + __expf(-1.702f * x));
-    case GROVE_ACT_SILU: return x / (1.f + __expf(-x));
-    case GROVE_ACT_SIGMOID: return 1.f / (1.f + __expf(-x));
+    case GROVE_ACT_QUICKGELU: return x * fast_sigmoid(1.702f * x);
+    case GROVE_ACT_SILU: return x * fast_sigmoid(x);
+    case GROVE_ACT_SIGMOID: return fast_sigmoid(x);
     default: return x;
   }
 }
@@ -100,15 +104,15 @@ __device__ __forceinline__ float act_grad(int act, float x) {
       return cdf + x * pdf;
     }
     case GROVE_ACT_QUICKGELU: {
-      float s = 1.f / (1.f + __expf(-1.702f * x));
+      float s = fast_sigmoid(1.702f * x);
       return s + 1.702f * x * s * (1.f - s);
     }
     case GROVE_ACT_SILU: {
-      float s = 1.f / (1.f + __expf(-x));
+      float s = fast_sigmoid(x);
       return s + x * s * (1.f - s);
     }
     case GROVE_ACT_SIGMOID: {
-      float s = 1.f / (1.f + __expf(-x));
+      float s = fast_sigmoid(x);
       return s * (1.f - s);
     }
     default: return 1.f;

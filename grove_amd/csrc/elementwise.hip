@@ -30,7 +30,7 @@ __global__ __launch_bounds__(EB) void swiglu_fwd_kernel(const bf16_raw* __restri
     unpack8(*(const u32x4_t*)(gu + (int64_t)r * 2 * I + c), g);
     unpack8(*(const u32x4_t*)(gu + (int64_t)r * 2 * I + I + c), u);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = g[e] / (1.f + __expf(-g[e])) * u[e];
+    for (int e = 0; e < 8; ++e) o[e] = g[e] * fast_sigmoid(g[e]) * u[e];
     *(u32x4_t*)(y + (int64_t)r * I + c) = pack8(o);
   }
 }
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(EB) void swiglu_bwd_kernel(const bf16_raw* __restri
     unpack8(*(const u32x4_t*)(dy + (int64_t)r * I + c), d);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const float s = 1.f / (1.f + __expf(-g[e]));
+      const float s = fast_sigmoid(g[e]);
       dg[e] = d[e] * u[e] * (s + g[e] * s * (1.f - s));
       du[e] = d[e] * g[e] * s;
     }

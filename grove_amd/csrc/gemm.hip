@@ -449,7 +449,7 @@ __device__ __forceinline__ void gemm_epilogue_wide(const grove_gemm_params& p, f
         const float uu[4] = {bf_lo(u01), bf_hi(u01), bf_lo(u23), bf_hi(u23)};
         float o[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = gg[e] / (1.f + __expf(-gg[e])) * uu[e];
+        for (int e = 0; e < 4; ++e) o[e] = gg[e] * fast_sigmoid(gg[e]) * uu[e];
         *(u32x2_t*)((bf16_raw*)p.C + (int64_t)crow[i] * p.ldc + nc) = u32x2_t{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
         continue;
       }

@@ -29,7 +29,7 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_kernel(const grove_gemv_param
       const float u[8] = {bf_lo(uv.x), bf_hi(uv.x), bf_lo(uv.y), bf_hi(uv.y), bf_lo(uv.z), bf_hi(uv.z), bf_lo(uv.w), bf_hi(uv.w)};
       float o[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = g[e] / (1.f + __expf(-g[e])) * u[e];
+      for (int e = 0; e < 8; ++e) o[e] = g[e] * fast_sigmoid(g[e]) * u[e];
       *(u32x4_t*)(xs + b * K + kc * 8) = u32x4_t{pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
     }
     __syncthreads();
