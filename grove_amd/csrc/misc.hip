@@ -243,6 +243,179 @@ __global__ __launch_bounds__(64) void attn_fewq_bwd_kernel(const grove_small_att
 // "few keys" (Lk <= 8): thread per (instance, head, query); a wave = 64 consecutive queries of
 // one (instance, head) so that k/v loads are wave-uniform broadcasts.
 constexpr int MAXK = 8;
+// ---- vectorised "few queries" kernels for head dim 16 (the decoder's token -> image cross attention: 6 queries x 1024 keys,
+// internal dim 128 = 8 heads x 16). One block of 256 threads per (instance, head); a thread owns keys tid, tid + 256, ... and
+// reads each K / V row ONCE with two 16-byte loads (the generic kernels above read every element 2 x Lq times with 2-byte
+// loads: 0.5-0.7 ms per launch for 0.3 GFLOP); all Lq queries are evaluated against a key while it sits in registers, with a
+// per-thread online softmax that is merged across the block at the end.
+constexpr int FQ_T = 256;
+__device__ __forceinline__ void load_row16(const bf16_raw* p, float (&x)[16]) {
+  const u32x4_t a = *(const u32x4_t*)p, b = *(const u32x4_t*)(p + 8);
+  x[0] = bf_lo(a.x); x[1] = bf_hi(a.x); x[2] = bf_lo(a.y); x[3] = bf_hi(a.y); x[4] = bf_lo(a.z); x[5] = bf_hi(a.z); x[6] = bf_lo(a.w); x[7] = bf_hi(a.w);
+  x[8] = bf_lo(b.x); x[9] = bf_hi(b.x); x[10] = bf_lo(b.y); x[11] = bf_hi(b.y); x[12] = bf_lo(b.z); x[13] = bf_hi(b.z); x[14] = bf_lo(b.w); x[15] = bf_hi(b.w);
+}
+
+template <int NQ>  // compile-time bound on Lq (6 on the path, 8 = MAXQ otherwise): sizes the per-thread accumulators
+__global__ __launch_bounds__(FQ_T) void attn_fewq16_fwd_kernel(const grove_small_attn_params p) {
+  __shared__ float qs[MAXQ][16];
+  __shared__ float red[FQ_T / 64];
+  const int inst = blockIdx.x / p.heads, h = blockIdx.x - inst * p.heads;
+  const int tid = threadIdx.x;
+  const bf16_raw* q = (const bf16_raw*)p.q + (int64_t)inst * p.Lq * p.ld_q + h * 16;
+  const bf16_raw* k = (const bf16_raw*)p.k + (int64_t)inst * p.Lk * p.ld_k + h * 16;
+  const bf16_raw* v = (const bf16_raw*)p.v + (int64_t)inst * p.Lk * p.ld_v + h * 16;
+  if (tid < p.Lq * 16) qs[tid >> 4][tid & 15] = bf2f(q[(int64_t)(tid >> 4) * p.ld_q + (tid & 15)]) * 0.25f;  // 16^-1/2
+  __syncthreads();
+  float m[NQ], l[NQ], acc[NQ][16];
+#pragma unroll
+  for (int qi = 0; qi < NQ; ++qi) {
+    m[qi] = -INFINITY;
+    l[qi] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[qi][c] = 0.f;
+  }
+  for (int j = tid; j < p.Lk; j += FQ_T) {
+    float kr[16], vr[16];
+    load_row16(k + (int64_t)j * p.ld_k, kr);
+    load_row16(v + (int64_t)j * p.ld_v, vr);
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) {
+      if (qi < p.Lq) {
+        float sc = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) sc = fmaf(qs[qi][c], kr[c], sc);
+        const float mn = fmaxf(m[qi], sc);
+        const float corr = __expf(m[qi] - mn), e = __expf(sc - mn);
+        l[qi] = l[qi] * corr + e;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) acc[qi][c] = fmaf(e, vr[c], acc[qi][c] * corr);
+        m[qi] = mn;
+      }
+    }
+  }
+  bf16_raw* o = (bf16_raw*)p.o + (int64_t)inst * p.Lq * p.ld_o + h * 16;
+#pragma unroll
+  for (int qi = 0; qi < NQ; ++qi) {
+    if (qi < p.Lq) {
+      const float M = block_max<FQ_T>(m[qi], red);
+      const float w = m[qi] == -INFINITY ? 0.f : __expf(m[qi] - M);
+      const float L = block_sum<FQ_T>(l[qi] * w, red);
+      const float inv = 1.f / L;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const float r = block_sum<FQ_T>(acc[qi][c] * w, red);
+        if (tid == 0) o[(int64_t)qi * p.ld_o + c] = f2bf(r * inv);
+      }
+    }
+  }
+}
+
+template <int NQ>
+__global__ __launch_bounds__(FQ_T) void attn_fewq16_bwd_kernel(const grove_small_attn_params p) {
+  __shared__ float qs[MAXQ][16], dos[MAXQ][16], Ms[MAXQ], Ls[MAXQ], deltas[MAXQ];
+  __shared__ float red[FQ_T / 64];
+  const int inst = blockIdx.x / p.heads, h = blockIdx.x - inst * p.heads;
+  const int tid = threadIdx.x;
+  const int HD = p.heads * 16;
+  const bf16_raw* q = (const bf16_raw*)p.q + (int64_t)inst * p.Lq * p.ld_q + h * 16;
+  const bf16_raw* k = (const bf16_raw*)p.k + (int64_t)inst * p.Lk * p.ld_k + h * 16;
+  const bf16_raw* v = (const bf16_raw*)p.v + (int64_t)inst * p.Lk * p.ld_v + h * 16;
+  const bf16_raw* o = (const bf16_raw*)p.o + (int64_t)inst * p.Lq * p.ld_o + h * 16;
+  const bf16_raw* dO = (const bf16_raw*)p.d_o + (int64_t)inst * p.Lq * p.ld_o + h * 16;
+  if (tid < p.Lq * 16) {
+    const int qi = tid >> 4, c = tid & 15;
+    qs[qi][c] = bf2f(q[(int64_t)qi * p.ld_q + c]);
+    dos[qi][c] = bf2f(dO[(int64_t)qi * p.ld_o + c]);
+  }
+  if (tid < p.Lq) {
+    float dl = 0.f;
+    for (int c = 0; c < 16; ++c) dl += bf2f(dO[(int64_t)tid * p.ld_o + c]) * bf2f(o[(int64_t)tid * p.ld_o + c]);
+    deltas[tid] = dl;
+  }
+  __syncthreads();
+  // pass 1: softmax statistics of every query (scores scaled by 16^-1/2 = 0.25)
+  float m[NQ], l[NQ];
+#pragma unroll
+  for (int qi = 0; qi < NQ; ++qi) { m[qi] = -INFINITY; l[qi] = 0.f; }
+  for (int j = tid; j < p.Lk; j += FQ_T) {
+    float kk[16];
+    load_row16(k + (int64_t)j * p.ld_k, kk);
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) {
+      if (qi < p.Lq) {
+        float sc = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) sc = fmaf(qs[qi][c], kk[c], sc);
+        sc *= 0.25f;
+        const float mn = fmaxf(m[qi], sc);
+        l[qi] = l[qi] * __expf(m[qi] - mn) + __expf(sc - mn);
+        m[qi] = mn;
+      }
+    }
+  }
+#pragma unroll
+  for (int qi = 0; qi < NQ; ++qi) {
+    if (qi < p.Lq) {
+      const float M = block_max<FQ_T>(m[qi], red);
+      const float L = block_sum<FQ_T>(m[qi] == -INFINITY ? 0.f : l[qi] * __expf(m[qi] - M), red);
+      if (tid == 0) { Ms[qi] = M; Ls[qi] = L; }
+    }
+  }
+  __syncthreads();
+  // pass 2 (K re-read: an L2 hit): dK, dV rows of my keys (written once, 16-byte stores), dQ partials reduced over the block at the end
+  float dq[NQ][16];
+#pragma unroll
+  for (int qi = 0; qi < NQ; ++qi)
+#pragma unroll
+    for (int c = 0; c < 16; ++c) dq[qi][c] = 0.f;
+  float* dk = (float*)p.dk + (int64_t)inst * p.Lk * HD + h * 16;
+  float* dv = (float*)p.dv + (int64_t)inst * p.Lk * HD + h * 16;
+  {
+    for (int j = tid; j < p.Lk; j += FQ_T) {
+      float kk[16], vv[16], dkk[16], dvv[16];
+      load_row16(k + (int64_t)j * p.ld_k, kk);
+      load_row16(v + (int64_t)j * p.ld_v, vv);
+#pragma unroll
+      for (int c = 0; c < 16; ++c) { dkk[c] = 0.f; dvv[c] = 0.f; }
+#pragma unroll
+      for (int qi = 0; qi < NQ; ++qi) {
+        if (qi < p.Lq) {
+          float sc = 0.f, dp = 0.f;
+#pragma unroll
+          for (int c = 0; c < 16; ++c) {
+            sc = fmaf(qs[qi][c], kk[c], sc);
+            dp = fmaf(dos[qi][c], vv[c], dp);
+          }
+          const float pr = __expf(sc * 0.25f - Ms[qi]) / Ls[qi];
+          const float ds = pr * (dp - deltas[qi]) * 0.25f;
+#pragma unroll
+          for (int c = 0; c < 16; ++c) {
+            dkk[c] = fmaf(ds, qs[qi][c], dkk[c]);
+            dvv[c] = fmaf(pr, dos[qi][c], dvv[c]);
+            dq[qi][c] = fmaf(ds, kk[c], dq[qi][c]);
+          }
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 16; c += 4) {
+        *(f32x4_t*)(dk + (int64_t)j * HD + c) = f32x4_t{dkk[c], dkk[c + 1], dkk[c + 2], dkk[c + 3]};
+        *(f32x4_t*)(dv + (int64_t)j * HD + c) = f32x4_t{dvv[c], dvv[c + 1], dvv[c + 2], dvv[c + 3]};
+      }
+    }
+  }
+  float* dqo = (float*)p.dq + (int64_t)inst * p.Lq * HD + h * 16;
+#pragma unroll
+  for (int qi = 0; qi < NQ; ++qi) {
+    if (qi < p.Lq) {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const float r = block_sum<FQ_T>(dq[qi][c], red);
+        if (tid == 0) dqo[(int64_t)qi * HD + c] = r;
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(64) void attn_fewk_fwd_kernel(const grove_small_attn_params p) {
   const int qblocks = (p.Lq + 63) / 64;
   const int qb = blockIdx.x % qblocks;
@@ -627,6 +800,151 @@ extern "C" int grove_cross_entropy(const void* logits, const int32_t* labels, fl
   return GROVE_OK;
 }
 
+// ---- vectorised "few keys" kernels for head dim 16 (the decoder's image -> token cross attention: 1024 queries x 6 keys).
+// A block of 256 threads = 256 queries of one (instance, head); the keys' K / V rows sit in LDS; q / dO rows are read with
+// 16-byte loads. Backward: every thread keeps its dS, P in LDS next to its q, dO row, then 2 x Lk x 16 threads each reduce one
+// (key, column) of dK / dV over the block's queries — ONE atomic per (key, column) per block instead of a cross-lane
+// reduction plus an atomic per wave (the generic kernel above).
+constexpr int FK_T = 256;
+__global__ __launch_bounds__(FK_T) void attn_fewk16_fwd_kernel(const grove_small_attn_params p) {
+  __shared__ float ks[MAXK][16], vs[MAXK][16];
+  const int qblocks = (p.Lq + FK_T - 1) / FK_T;
+  const int qb = blockIdx.x % qblocks, ih = blockIdx.x / qblocks;
+  const int inst = ih / p.heads, h = ih - inst * p.heads;
+  const int tid = threadIdx.x;
+  const bf16_raw* k = (const bf16_raw*)p.k + (int64_t)inst * p.Lk * p.ld_k + h * 16;
+  const bf16_raw* v = (const bf16_raw*)p.v + (int64_t)inst * p.Lk * p.ld_v + h * 16;
+  if (tid < p.Lk * 16) {
+    ks[tid >> 4][tid & 15] = bf2f(k[(int64_t)(tid >> 4) * p.ld_k + (tid & 15)]);
+    vs[tid >> 4][tid & 15] = bf2f(v[(int64_t)(tid >> 4) * p.ld_v + (tid & 15)]);
+  }
+  __syncthreads();
+  const int qi = qb * FK_T + tid;
+  if (qi >= p.Lq) return;
+  float qv[16];
+  load_row16((const bf16_raw*)p.q + ((int64_t)inst * p.Lq + qi) * p.ld_q + h * 16, qv);
+  float sc[MAXK], mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < MAXK; ++j) {
+    sc[j] = -INFINITY;
+    if (j < p.Lk) {
+      float a = 0.f;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) a = fmaf(qv[c], ks[j][c], a);
+      sc[j] = a * 0.25f;
+      mx = fmaxf(mx, sc[j]);
+    }
+  }
+  float l = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXK; ++j) {
+    sc[j] = j < p.Lk ? __expf(sc[j] - mx) : 0.f;
+    l += sc[j];
+  }
+  const float inv = 1.f / l;
+  float o[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) o[c] = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXK; ++j)
+    if (j < p.Lk) {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) o[c] = fmaf(sc[j], vs[j][c], o[c]);
+    }
+  bf16_raw* op = (bf16_raw*)p.o + ((int64_t)inst * p.Lq + qi) * p.ld_o + h * 16;
+  *(u32x4_t*)op = u32x4_t{pack2bf(o[0] * inv, o[1] * inv), pack2bf(o[2] * inv, o[3] * inv), pack2bf(o[4] * inv, o[5] * inv), pack2bf(o[6] * inv, o[7] * inv)};
+  *(u32x4_t*)(op + 8) = u32x4_t{pack2bf(o[8] * inv, o[9] * inv), pack2bf(o[10] * inv, o[11] * inv), pack2bf(o[12] * inv, o[13] * inv), pack2bf(o[14] * inv, o[15] * inv)};
+}
+
+__global__ __launch_bounds__(FK_T) void attn_fewk16_bwd_kernel(const grove_small_attn_params p) {
+  __shared__ float ks[MAXK][16], vs[MAXK][16];
+  __shared__ float qs[FK_T][17], dos[FK_T][17], dss[FK_T][MAXK + 1], pss[FK_T][MAXK + 1];
+  const int qblocks = (p.Lq + FK_T - 1) / FK_T;
+  const int qb = blockIdx.x % qblocks, ih = blockIdx.x / qblocks;
+  const int inst = ih / p.heads, h = ih - inst * p.heads;
+  const int tid = threadIdx.x;
+  const int HD = p.heads * 16;
+  const bf16_raw* k = (const bf16_raw*)p.k + (int64_t)inst * p.Lk * p.ld_k + h * 16;
+  const bf16_raw* v = (const bf16_raw*)p.v + (int64_t)inst * p.Lk * p.ld_v + h * 16;
+  if (tid < p.Lk * 16) {
+    ks[tid >> 4][tid & 15] = bf2f(k[(int64_t)(tid >> 4) * p.ld_k + (tid & 15)]);
+    vs[tid >> 4][tid & 15] = bf2f(v[(int64_t)(tid >> 4) * p.ld_v + (tid & 15)]);
+  }
+  __syncthreads();
+  const int qi = qb * FK_T + tid;
+  const bool active = qi < p.Lq;
+  float qv[16], dov[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) { qv[c] = 0.f; dov[c] = 0.f; }
+  if (active) {
+    load_row16((const bf16_raw*)p.q + ((int64_t)inst * p.Lq + qi) * p.ld_q + h * 16, qv);
+    load_row16((const bf16_raw*)p.d_o + ((int64_t)inst * p.Lq + qi) * p.ld_o + h * 16, dov);
+  }
+  float sc[MAXK], dp[MAXK], mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < MAXK; ++j) {
+    sc[j] = -INFINITY;
+    dp[j] = 0.f;
+    if (j < p.Lk) {
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        a = fmaf(qv[c], ks[j][c], a);
+        b = fmaf(dov[c], vs[j][c], b);
+      }
+      sc[j] = a * 0.25f;
+      dp[j] = b;
+      mx = fmaxf(mx, sc[j]);
+    }
+  }
+  float l = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXK; ++j) {
+    sc[j] = j < p.Lk ? __expf(sc[j] - mx) : 0.f;
+    l += sc[j];
+  }
+  float delta = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXK; ++j) {
+    sc[j] /= l;
+    delta += sc[j] * dp[j];
+  }
+  float dqv[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) dqv[c] = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXK; ++j) {
+    const float ds = (active && j < p.Lk) ? sc[j] * (dp[j] - delta) * 0.25f : 0.f;
+    dss[tid][j] = ds;
+    pss[tid][j] = (active && j < p.Lk) ? sc[j] : 0.f;
+    if (j < p.Lk) {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) dqv[c] = fmaf(ds, ks[j][c], dqv[c]);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 16; ++c) { qs[tid][c] = qv[c]; dos[tid][c] = dov[c]; }
+  if (active) {
+    float* dqo = (float*)p.dq + ((int64_t)inst * p.Lq + qi) * HD + h * 16;
+#pragma unroll
+    for (int c = 0; c < 16; c += 4) *(f32x4_t*)(dqo + c) = f32x4_t{dqv[c], dqv[c + 1], dqv[c + 2], dqv[c + 3]};
+  }
+  __syncthreads();
+  // dK[j][c] = sum_q dS[q][j] q[q][c],  dV[j][c] = sum_q P[q][j] dO[q][c] over this block's queries
+  for (int t = tid; t < 2 * p.Lk * 16; t += FK_T) {
+    const int which = t / (p.Lk * 16), r = t - which * p.Lk * 16;
+    const int j = r >> 4, c = r & 15;
+    float a = 0.f;
+    if (which == 0) {
+      for (int qq = 0; qq < FK_T; ++qq) a = fmaf(dss[qq][j], qs[qq][c], a);
+      atomicAdd((float*)p.dk + ((int64_t)inst * p.Lk + j) * HD + h * 16 + c, a);
+    } else {
+      for (int qq = 0; qq < FK_T; ++qq) a = fmaf(pss[qq][j], dos[qq][c], a);
+      atomicAdd((float*)p.dv + ((int64_t)inst * p.Lk + j) * HD + h * 16 + c, a);
+    }
+  }
+}
+
 static int small_attn_check(const grove_small_attn_params* p, const char* name) {
   GROVE_CHECK(p && p->inst > 0 && p->heads > 0 && p->Lq > 0 && p->Lk > 0, GROVE_E_SHAPE, "%s: bad shape", name);
   GROVE_CHECK(p->d > 0 && p->d <= MAXD, GROVE_E_SHAPE, "%s: head dim %d > %d", name, p->d, MAXD);
@@ -638,9 +956,16 @@ extern "C" int grove_small_attn_fwd(const grove_small_attn_params* p, void* stre
   int rc = small_attn_check(p, "small_attn_fwd");
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
-  if (p->Lk <= MAXK) {
+  const bool vec16 = p->d == 16 && p->ld_q % 8 == 0 && p->ld_k % 8 == 0 && p->ld_v % 8 == 0 && p->ld_o % 8 == 0 &&
+                     (((uintptr_t)p->q | (uintptr_t)p->k | (uintptr_t)p->v | (uintptr_t)p->o) & 15) == 0;
+  if (p->Lk <= MAXK && vec16 && p->Lq >= 64) {
+    hipLaunchKernelGGL(attn_fewk16_fwd_kernel, dim3(p->inst * p->heads * ((p->Lq + FK_T - 1) / FK_T)), dim3(FK_T), 0, s, *p);
+  } else if (p->Lk <= MAXK) {
     const int qblocks = (p->Lq + 63) / 64;
     hipLaunchKernelGGL(attn_fewk_fwd_kernel, dim3(p->inst * p->heads * qblocks), dim3(64), 0, s, *p);
+  } else if (p->d == 16 && p->ld_q % 8 == 0 && p->ld_k % 8 == 0 && p->ld_v % 8 == 0 && (((uintptr_t)p->k | (uintptr_t)p->v) & 15) == 0) {
+    if (p->Lq <= 6) hipLaunchKernelGGL(attn_fewq16_fwd_kernel<6>, dim3(p->inst * p->heads), dim3(FQ_T), 0, s, *p);
+    else hipLaunchKernelGGL(attn_fewq16_fwd_kernel<MAXQ>, dim3(p->inst * p->heads), dim3(FQ_T), 0, s, *p);
   } else {
     hipLaunchKernelGGL(attn_fewq_fwd_kernel, dim3(p->inst * p->heads), dim3(64), 0, s, *p);
   }
@@ -659,8 +984,18 @@ extern "C" int grove_small_attn_bwd(const grove_small_attn_params* p, void* stre
     hipError_t e = hipMemsetAsync(p->dk, 0, bytes, s);
     if (e == hipSuccess) e = hipMemsetAsync(p->dv, 0, bytes, s);
     GROVE_CHECK(e == hipSuccess, GROVE_E_HIP, "small_attn_bwd: memset failed");
-    const int qblocks = (p->Lq + 63) / 64;
-    hipLaunchKernelGGL(attn_fewk_bwd_kernel, dim3(p->inst * p->heads * qblocks), dim3(64), 0, s, *p);
+    const bool vec16 = p->d == 16 && p->ld_q % 8 == 0 && p->ld_k % 8 == 0 && p->ld_v % 8 == 0 && p->ld_o % 8 == 0 &&
+                       (((uintptr_t)p->q | (uintptr_t)p->k | (uintptr_t)p->v | (uintptr_t)p->d_o | (uintptr_t)p->dq) & 15) == 0;
+    if (vec16 && p->Lq >= 64) {
+      hipLaunchKernelGGL(attn_fewk16_bwd_kernel, dim3(p->inst * p->heads * ((p->Lq + FK_T - 1) / FK_T)), dim3(FK_T), 0, s, *p);
+    } else {
+      const int qblocks = (p->Lq + 63) / 64;
+      hipLaunchKernelGGL(attn_fewk_bwd_kernel, dim3(p->inst * p->heads * qblocks), dim3(64), 0, s, *p);
+    }
+  } else if (p->d == 16 && p->ld_q % 8 == 0 && p->ld_k % 8 == 0 && p->ld_v % 8 == 0 && (((uintptr_t)p->k | (uintptr_t)p->v) & 15) == 0 &&
+             (((uintptr_t)p->dk | (uintptr_t)p->dv) & 15) == 0) {
+    if (p->Lq <= 6) hipLaunchKernelGGL(attn_fewq16_bwd_kernel<6>, dim3(p->inst * p->heads), dim3(FQ_T), 0, s, *p);
+    else hipLaunchKernelGGL(attn_fewq16_bwd_kernel<MAXQ>, dim3(p->inst * p->heads), dim3(FQ_T), 0, s, *p);
   } else {
     hipLaunchKernelGGL(attn_fewq_bwd_kernel, dim3(p->inst * p->heads), dim3(64), 0, s, *p);
   }

@@ -373,7 +373,7 @@ def test_cross_entropy(dev):
 
 
 # ----------------------------------------------------------------------------- decoder kernels
-@pytest.mark.parametrize("Lq,Lk,heads,d", [(6, 6, 8, 32), (6, 1024, 8, 16), (1024, 6, 8, 16), (5, 100, 2, 16)])
+@pytest.mark.parametrize("Lq,Lk,heads,d", [(6, 6, 8, 32), (6, 1024, 8, 16), (1024, 6, 8, 16), (5, 100, 2, 16), (8, 300, 4, 16), (3, 1500, 2, 16)])
 def test_small_attn(dev, Lq, Lk, heads, d):
     from grove_amd import ops
     inst = 3
