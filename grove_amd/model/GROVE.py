@@ -441,7 +441,7 @@ class GROVEForCausalLM(torch.nn.Module):
         if R > 0:
             Vv = d.vocab
             ops.wgrad(dlogits, hv.data, self._grad["lm_head.weight"], K=R)
-            Vk = ops.pad_to(Vv, 32)
+            Vk = ops.pad_to(Vv, 64)  # K of the dgrad GEMM: a multiple of 64 keeps it on the BK = 64 kernels
             wT = torch.zeros((H, Vk), dtype=bf, device=self.dev)
             ops.transpose(self._sd["lm_head.weight"], Vv, H, H, wT, Vk, pad_to_cols=Vk)
             dl = dlogits
