@@ -78,3 +78,34 @@ def test_optimizer_step_matches_restated_adamw(dev):
     # the bf16 working copies are the rounded masters
     n, off, k, w = engine.slices[0]
     assert torch.equal(w.reshape(-1), engine.master[off:off + k].to(bf))
+
+
+def test_rccl_bucketed_allreduce_single_rank(dev):
+    """The GPU form of the gradient exchange (RCCL on a side stream, bucketed, compute stream waits) on a one-rank group:
+    the collective is the identity, but every call of the N > 1 path — init with device_id, async all_reduce under the comm
+    stream, event / stream waits — runs against the real RCCL."""
+    import os
+    import socket
+
+    import torch.distributed as dist
+    from grove_amd.train import allreduce_buckets
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        g = torch.arange(1 << 20, dtype=torch.float32, device=dev)
+        ref = g.clone()
+        g.mul_(2.0)  # work queued on the compute stream that the comm stream must wait for
+        allreduce_buckets(g, 300_000, torch.cuda.Stream(device=dev))
+        g.add_(1.0)  # ... and compute that must wait for the collective
+        torch.cuda.synchronize()
+        assert torch.equal(g, ref * 2 + 1)
+        t = torch.tensor([1.0, 2.0], device=dev)
+        dist.all_reduce(t)
+        assert t.tolist() == [1.0, 2.0]
+    finally:
+        dist.destroy_process_group()
