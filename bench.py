@@ -224,6 +224,12 @@ def main():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON: everything else that writes to fd 1 (RCCL prints its version banner there, from
+    # every rank, when the box exports NCCL_DEBUG=VERSION — and flushes it at exit, i.e. AFTER a normal print) goes to stderr
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -305,7 +311,7 @@ def main():
                 res["cpu_baseline"] = cpu_baseline(args)
             except Exception as e:  # the baseline is informational; never lose the measured line
                 res["cpu_baseline"] = {"error": repr(e)}
-        print(json.dumps(res), flush=True)
+        os.write(real_stdout, (json.dumps(res) + "\n").encode())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
