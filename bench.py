@@ -305,7 +305,7 @@ def main():
                 res["fused_vit_llama_forward"] = vit_llama_forward(model, batch, dims)
             except Exception as e:
                 res["fused_vit_llama_forward"] = {"error": repr(e)}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is a rank-0, N = 1 figure (other N: GPU numbers only)
             try:
                 res["box_l1_vs_oracle_tiny"] = round(tiny_box_l1(dev), 6)
                 res["cpu_baseline"] = cpu_baseline(args)
