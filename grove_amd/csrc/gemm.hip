@@ -894,7 +894,7 @@ extern "C" int grove_gemm_bf16(const grove_gemm_params* pp, void* stream) {
     }
   int variant = 128;
   if (g_gemm_tile_m == 192 || (g_gemm_tile_m == 0 && t128 > 300 && c192 <= c128)) variant = 192;
-  const bool narrow = g_gemm_tile_n == 64 || (g_gemm_tile_n == 0 && t128 < 160 && p.N > 64);
+  const bool narrow = g_gemm_tile_n == 64 || (g_gemm_tile_n == 0 && ((t128 < 160 && p.N > 64) || p.N <= 64));  // N <= 64: half of a 128-wide tile would be padding
   g_gemm_last_variant = narrow ? GROVE_GEMM_T128X64 : variant == 192 && g_gemm_glds ? GROVE_GEMM_T192X128 : GROVE_GEMM_T128X128;
   if (narrow) {
     if (g_gemm_glds) return bk64 ? launch<64, true, 2, 4>(p, vec_ok, s) : launch<32, true, 2, 4>(p, vec_ok, s);
