@@ -396,6 +396,11 @@ __device__ __forceinline__ void gemm_epilogue_wide(const grove_gemm_params& p, f
   for (int g = 0; g < 2; ++g) {
     const int n = nw0 + g * 128 + fq * 8;
     if (n >= p.N) continue;
+    // padded-head output (n_group / n_pad): destination column, and whether this chunk closes a group (then the pad
+    // columns behind it are zero-filled by this lane)
+    const int ngrp = p.n_group ? n / p.n_group : 0;
+    const int nd = n + ngrp * p.n_pad;
+    const bool close_group = p.n_group && (n - ngrp * p.n_group + 8 == p.n_group);
     float bv[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bv[e] = 0.f;
@@ -469,10 +474,12 @@ __device__ __forceinline__ void gemm_epilogue_wide(const grove_gemm_params& p, f
         v[4] += bf_lo(rr[i].z); v[5] += bf_hi(rr[i].z); v[6] += bf_lo(rr[i].w); v[7] += bf_hi(rr[i].w);
       }
       if (p.c_dtype == GROVE_BF16) {
-        *(u32x4_t*)((bf16_raw*)p.C + (int64_t)crow[i] * p.ldc + n) =
-            u32x4_t{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+        bf16_raw* c = (bf16_raw*)p.C + (int64_t)crow[i] * p.ldc + nd;
+        *(u32x4_t*)c = u32x4_t{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+        if (close_group)
+          for (int z = 0; z < p.n_pad; z += 8) *(u32x4_t*)(c + 8 + z) = u32x4_t{0u, 0u, 0u, 0u};
       } else {
-        float* c = (float*)p.C + (int64_t)crow[i] * p.ldc + n;
+        float* c = (float*)p.C + (int64_t)crow[i] * p.ldc + nd;
         *(f32x4_t*)c = f32x4_t{v[0], v[1], v[2], v[3]};
         *(f32x4_t*)(c + 4) = f32x4_t{v[4], v[5], v[6], v[7]};
       }
@@ -561,6 +568,10 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
   const int k_per_tap = GATHER ? p.K / p.a_taps : p.K;
   const int kt_per_tap = k_per_tap / P_BK;
   int is_m0 = 0, is_tap = 0;  // GATHER: origin row and tap of the A pointers currently loaded
+  // K map (padded-head A): this lane's logical chunk offset inside a K tile is the same for both of its rows (r and r + 64 share
+  // r & 7 ... the swizzle term (r >> 1) & 7 is the same for r and r + 64), so one correction serves both loads
+  const unsigned a_lc8 = swz<64>(st_r, st_c) * 8;
+  const unsigned k_magic = p.k_group ? ((1u << 24) + p.k_group - 1) / p.k_group : 0;
   // GATHER: my two rows of each A half for tap `tap` of the tile at row m0. The wave's 8 rows per LDS-DMA instruction are 8
   // consecutive m: one 8-dword scalar load, then a per-lane pick. Positions past the end of the index array belong to
   // rows >= M (never stored): the load window is shifted back inside the array and those lanes take any entry.
@@ -609,7 +620,11 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
     char* dst = smem + (stream_t & 1) * P_STAGE + x * P_HALF + wave * (64 * 16);
     int64_t koff0 = (int64_t)is_k * P_BK, koff1 = koff0;
     if (GATHER && (x == 0 || x == 3)) {  // A: the K offset is local to the tap; a zero row stays on the zero page
-      const int64_t ka = (int64_t)(is_k - is_tap * kt_per_tap) * P_BK;
+      int64_t ka = (int64_t)(is_k - is_tap * kt_per_tap) * P_BK;
+      if (p.k_group) {  // padded-head A: my chunk's logical k -> its column (k_magic = ceil(2^24 / k_group): exact for k < 2^16, k % 8 == 0)
+        const unsigned kl = (unsigned)ka + a_lc8;
+        ka = (int64_t)(kl + (unsigned)(((uint64_t)kl * k_magic) >> 24) * p.k_pad) - a_lc8;
+      }
       koff0 = a_zero[x == 3][0] ? 0 : ka;
       koff1 = a_zero[x == 3][1] ? 0 : ka;
     }
@@ -855,6 +870,7 @@ extern "C" int grove_gemm_bf16(const grove_gemm_params* pp, void* stream) {
                        (!p.residual || ((((uintptr_t)p.residual & 15) == 0) && p.ldr % 8 == 0));
   const bool pp_act = p.act == GROVE_ACT_NONE || p.act == GROVE_ACT_GELU || p.act == GROVE_ACT_QUICKGELU || p.act == GROVE_ACT_RELU ||
                       p.act == GROVE_ACT_SWIGLU_PAIR;  // compiled-in epilogues
+  const bool maps = p.n_group || p.k_group;
   const bool p256_ok = g_gemm_glds && bk64 && (!p.a_idx || (long)p.a_taps * p.M >= 8) && bt == 1 && p.split_k <= 1 && !p.accumulate && wide_ok && p.N % 8 == 0 && pp_act;
   // Tile choice by a measured cost model (tools/bench_gemm5.py, microseconds): time = rounds of resident blocks x
   // (K tiles x per-K-tile time + fixed per-tile time). The 128- and 192-row kernels keep 2 blocks per CU (512 slots; a
@@ -879,6 +895,14 @@ extern "C" int grove_gemm_bf16(const grove_gemm_params* pp, void* stream) {
     g_gemm_last_variant = g_gemm_tile_m == 256 ? (p.a_idx ? GROVE_GEMM_PP256_GATHER : GROVE_GEMM_PP256) : (p.a_idx ? GROVE_GEMM_PP192_GATHER : GROVE_GEMM_PP192);
     if (p.a_idx) return g_gemm_tile_m == 256 ? launch_pp<256, true>(p, s) : launch_pp<192, true>(p, s);
     return g_gemm_tile_m == 256 ? launch_pp<256, false>(p, s) : launch_pp<192, false>(p, s);
+  }
+  if (maps) {  // only the pipelined kernel implements the padded-head maps
+    GROVE_CHECK(p256_ok && p.c_dtype == GROVE_BF16 && !p.aux && p.n_group % 8 == 0 && p.n_pad % 8 == 0 && p.k_group % 8 == 0 && p.k_pad % 8 == 0 &&
+                    (!p.k_group || (p.a_idx && p.a_taps == 1 && p.K < 65536)) && (!p.n_group || p.N % p.n_group == 0),
+                GROVE_E_SHAPE, "gemm: n_group/k_group maps need the pipelined kernel (bf16 C, no aux; k map: gathered A with one tap)");
+    g_gemm_last_variant = cp256 <= cp192 ? (p.a_idx ? GROVE_GEMM_PP256_GATHER : GROVE_GEMM_PP256) : (p.a_idx ? GROVE_GEMM_PP192_GATHER : GROVE_GEMM_PP192);
+    if (p.a_idx) return cp256 <= cp192 ? launch_pp<256, true>(p, s) : launch_pp<192, true>(p, s);
+    return cp256 <= cp192 ? launch_pp<256, false>(p, s) : launch_pp<192, false>(p, s);
   }
   if (p.act == GROVE_ACT_SWIGLU_PAIR) {  // only the pipelined kernel's epilogue implements it
     GROVE_CHECK(p256_ok && p.N % 16 == 0 && p.c_dtype == GROVE_BF16 && !p.residual && p.ldc % 4 == 0 && (p.ld_aux % 4 == 0), GROVE_E_SHAPE,

@@ -71,10 +71,18 @@ class SamEncoder:
                   "bproj": sd[p + "attn.proj.bias"], "w1": sd[p + "mlp.lin1.weight"], "b1": sd[p + "mlp.lin1.bias"],
                   "w2": sd[p + "mlp.lin2.weight"], "b2": sd[p + "mlp.lin2.bias"],
                   "window": 0 if i in d.sam_global else d.sam_window, "size": size}
+            # window blocks: the head dim padding (80 -> 96) exists only in the activations the attention kernels read; the four
+            # projections around them use the COMPACT weights with the pipelined GEMM's padded-head column maps (n_map / k_map),
+            # i.e. they neither multiply by the zero rows / columns nor read them
+            Bk["maps"] = (size != d.sam_grid) and hp != hd and hd % 8 == 0 and (nh * hd) % 64 == 0 and C % 64 == 0
+            if Bk["maps"]:
+                Bk["wqkv_c"] = sd[p + "attn.qkv.weight"].to(bf).contiguous()
+                Bk["bqkv_c"] = sd[p + "attn.qkv.bias"].to(bf).contiguous()
+                Bk["wproj_c"] = sd[p + "attn.proj.weight"].to(bf).contiguous()
             Bk["Rcat"], Bk["RcatT"], Bk["khp"], Bk["rel_ld"] = _rcat_tables(size, sd[p + "attn.rel_pos_h"], sd[p + "attn.rel_pos_w"],
                                                                              hd, hp, hd ** -0.5)
             if train and i >= self.first_bwd_block:
-                for k in ("wqkv", "wproj", "w1", "w2"):
+                for k in ("wqkv", "wproj", "w1", "w2") + (("wqkv_c", "wproj_c") if Bk["maps"] else ()):
                     Bk[k + "_t"] = ops.transpose2d(Bk[k])
             self.blocks.append(Bk)
         self.adapters = []
@@ -150,7 +158,10 @@ class SamEncoder:
             rows_w = F * nwin * ws * ws
             nb, L, qhw = F * nwin, ws * ws, (ws, ws)
             pad_rows, pad_src = self._pad[F]
-            qkv = ops.linear(h, Bk["wqkv"], Bk["bqkv"], c_idx=tok2win, out_rows=rows_w)
+            if Bk["maps"]:
+                qkv = ops.linear(h, Bk["wqkv_c"], Bk["bqkv_c"], c_idx=tok2win, out_rows=rows_w, out_cols=3 * nh * hp, n_map=(hd, hp - hd))
+            else:
+                qkv = ops.linear(h, Bk["wqkv"], Bk["bqkv"], c_idx=tok2win, out_rows=rows_w)
             ops.copy_rows(Bk["bqkv"].view(1, -1), qkv, pad_rows.numel(), qkv.shape[1], idx_src=pad_src, idx_dst=pad_rows)
         else:
             nb, L, qhw = F, g * g, (g, g)
@@ -165,7 +176,10 @@ class SamEncoder:
         o, actx = attention_fwd(qkv, nb, L, nh, hp, 0, nh * hp, 2 * nh * hp, hd ** -0.5, rel=rel, rel_hw=(Bk["khp"], qhw[1]), save=save)
         del rel
         if ws > 0:  # un-partition = gather the real tokens' rows of the windowed attention output (padding rows are dropped)
-            x1 = ops.linear(o, Bk["wproj"], Bk["bproj"], residual=x, a_idx=tok2win, a_taps=1, M=x.shape[0])
+            if Bk["maps"]:
+                x1 = ops.linear(o, Bk["wproj_c"], Bk["bproj"], residual=x, a_idx=tok2win, a_taps=1, M=x.shape[0], k_map=(hd, hp - hd))
+            else:
+                x1 = ops.linear(o, Bk["wproj"], Bk["bproj"], residual=x, a_idx=tok2win, a_taps=1, M=x.shape[0])
         else:
             x1 = ops.linear(o, Bk["wproj"], Bk["bproj"], residual=x)
         h2, mean2, rstd2 = ops.layernorm(x1, Bk["ln2"][0], Bk["ln2"][1], 1e-6, save_stats=save)
@@ -255,7 +269,10 @@ class SamEncoder:
             # x1 = x + unpartition(proj(attn(qkv(partition(ln1(x))))))
             if ws > 0:  # real tokens only, scattered into the windowed layout; padding rows carry no gradient
                 pad_rows, pad_src = self._pad[F]
-                do = ops.linear(dx, Bk["wproj_t"], c_idx=tok2win, out_rows=win2tok.shape[0])
+                if Bk["maps"]:
+                    do = ops.linear(dx, Bk["wproj_c_t"], c_idx=tok2win, out_rows=win2tok.shape[0], out_cols=nh * hp, n_map=(hd, hp - hd))
+                else:
+                    do = ops.linear(dx, Bk["wproj_t"], c_idx=tok2win, out_rows=win2tok.shape[0])
                 ops.copy_rows(self._zero_row[:, :do.shape[1]], do, pad_rows.numel(), do.shape[1], idx_src=pad_src, idx_dst=pad_rows)
             else:
                 do = ops.linear(dx, Bk["wproj_t"])
@@ -268,7 +285,10 @@ class SamEncoder:
             ops.gemm_raw(drel, Bk["RcatT"], dqkv, c["nb"] * nh, hp, rel_ld, L * rel_ld, rel_ld, hp, c_idx=hrow, residual=dqkv, ldr=hp,
                          batch=(L, 1), sA=(rel_ld, 0), sB=(hp * rel_ld, 0), sC=(ldd, 0), sR=(ldd, 0))
             if ws > 0:  # only the real tokens' rows of d qkv feed norm1
-                dh = ops.linear(dqkv, Bk["wqkv_t"], a_idx=tok2win, a_taps=1, M=dx.shape[0])
+                if Bk["maps"]:
+                    dh = ops.linear(dqkv, Bk["wqkv_c_t"], a_idx=tok2win, a_taps=1, M=dx.shape[0], k_map=(hd, hp - hd))
+                else:
+                    dh = ops.linear(dqkv, Bk["wqkv_t"], a_idx=tok2win, a_taps=1, M=dx.shape[0])
             else:
                 dh = ops.linear(dqkv, Bk["wqkv_t"])
             del dqkv, do, drel

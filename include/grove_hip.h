@@ -90,6 +90,12 @@ typedef struct grove_gemm_params {
   int32_t split_k;    /* 0 = auto (accumulating f32 GEMMs only), 1 = off, >1 = K range split over blockIdx.z,
                          partials combined with fp32 atomics into the pre-initialised C */
   int32_t ld_aux;     /* row stride of aux; 0 = ldc */
+  /* Padded-head layouts (SAM: head dim 80 stored as 96) without multiplying by the padding — pipelined kernel only:
+   *   n_group / n_pad: logical output column n is stored at n + (n / n_group) * n_pad and the n_pad columns after every
+   *                    group are written as zeros (N, bias and B are the compact sizes);
+   *   k_group / k_pad: logical reduction index k of A is read from column k + (k / k_group) * k_pad (K and B compact;
+   *                    needs a_idx: the gathered-A instance). Groups and pads are multiples of 8; 0 = off. */
+  int32_t n_group, n_pad, k_group, k_pad;
 } grove_gemm_params;
 int grove_gemm_bf16(const grove_gemm_params* p, void* stream);
 /* Which kernel the last grove_gemm_bf16 call launched (measurement aid: bench.py prices each kernel on its own launches). */

@@ -749,3 +749,39 @@ def test_gemm_swiglu_pair_epilogue(dev, M, I, K, save):
     xf, wf = x.float().cpu(), wgu.float().cpu()
     g, u = xf @ wf[:I].t(), xf @ wf[I:].t()
     close(a, torch.nn.functional.silu(g) * u, 2 ** -6, "swiglu pair vs fp32")
+
+
+def test_gemm_padded_head_maps(dev):
+    """n_group/n_pad (compact N written into a padded-head layout, pad columns zeroed) and k_group/k_pad (padded-head A read as
+    compact K) of the pipelined kernel, against the same GEMMs on zero-padded weights (SAM: head dim 80 stored as 96)."""
+    from grove_amd import ops
+    heads, hd, hp, C, M, Mw = 8, 80, 96, 256, 3000, 4100  # 8 x 80 = 640: the compact K must stay a multiple of 64
+    g = torch.Generator().manual_seed(5)
+    tok2win = torch.randperm(Mw, generator=g)[:M].to(torch.int32).to(dev)
+    x = rnd(M, C, seed=1).to(dev)
+    w_c = rnd(heads * hd, C, seed=2, scale=0.1).to(dev)          # compact [480, C]
+    b_c = rnd(heads * hd, seed=3).to(dev)
+    w_p = torch.zeros(heads, hp, C, dtype=bf16, device=dev)
+    w_p[:, :hd] = w_c.view(heads, hd, C)
+    b_p = torch.zeros(heads, hp, dtype=bf16, device=dev)
+    b_p[:, :hd] = b_c.view(heads, hd)
+    # N map + row scatter: compact weights, padded output with garbage pre-filled (pad columns must come out zero)
+    ref = ops.linear(x, w_p.view(heads * hp, C), b_p.view(-1), c_idx=tok2win, out=torch.zeros(Mw, heads * hp, dtype=bf16, device=dev))
+    out = torch.full((Mw, heads * hp), 7.0, dtype=bf16, device=dev)
+    ops.linear(x, w_c, b_c, c_idx=tok2win, out=out, n_map=(hd, hp - hd))
+    rows = tok2win.long()
+    assert torch.equal(out[rows], ref[rows])
+    # K map + row gather: padded-head A, compact K weights
+    a_p = torch.zeros(Mw, heads, hp, dtype=bf16, device=dev)
+    a_p[:, :, :hd] = rnd(Mw, heads, hd, seed=4).to(dev)
+    a_p[:, :, hd:] = 3.0                                         # pad columns are never read
+    w2_c = rnd(C, heads * hd, seed=6, scale=0.1).to(dev)
+    w2_p = torch.zeros(C, heads, hp, dtype=bf16, device=dev)
+    w2_p[:, :, :hd] = w2_c.view(C, heads, hd)
+    a_ref = a_p.clone()
+    a_ref[:, :, hd:] = 0
+    ref2 = ops.linear(a_ref.view(Mw, heads * hp), w2_p.view(C, heads * hp), a_idx=tok2win, a_taps=1, M=M)
+    out2 = ops.linear(a_p.view(Mw, heads * hp), w2_c, a_idx=tok2win, a_taps=1, M=M, k_map=(hd, hp - hd))
+    close(out2, ref2, 2 ** -8, "k map vs padded GEMM")  # (K = 640 vs 768: same products, the zero columns dropped)
+    want = a_ref.view(Mw, heads * hp)[rows].float().cpu() @ w2_p.view(C, heads * hp).float().cpu().t()
+    close(out2, want, 2 ** -7, "k map vs fp32")
