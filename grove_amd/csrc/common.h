@@ -73,7 +73,7 @@ __device__ __forceinline__ float block_max(float v, float* scratch) {
 // erff polynomial ladder — the GELU epilogue is ~20 % of a K=1280 GEMM tile otherwise.
 __device__ __forceinline__ float fast_erf(float x) {
   const float ax = fabsf(x);
-  const float t = __frcp_rn(1.f + 0.3275911f * ax);
+  const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * ax);  // v_rcp_f32 itself (1 ulp); __frcp_rn expands to an IEEE division
   const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
   const float r = 1.f - poly * __expf(-ax * ax);
   return copysignf(r, x);
@@ -81,7 +81,7 @@ __device__ __forceinline__ float fast_erf(float x) {
 
 // logistic function with the hardware reciprocal (v_rcp_f32, 1 ulp) instead of an IEEE division (~10 instructions): every
 // sigmoid-shaped activation of the path goes through it, so fused and unfused forms stay bit-identical to each other.
-__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.f + __expf(-x)); }
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 
 __device__ __forceinline__ float act_apply(int act, float x) {
   switch (act) {

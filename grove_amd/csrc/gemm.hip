@@ -387,101 +387,260 @@ constexpr int P_STAGE = 4 * P_HALF;              // A_lo | B_lo | B_hi | A_hi (s
 // is 16-byte aligned with row strides that keep it so and N % 8 == 0 (no partial column groups).
 // ACT is a compile-time activation (GROVE_ACT_*; -1 = "plain": alpha == 1, no activation, no scale): the persistent
 // kernel has no co-resident block to hide epilogue VALU work behind, so the activation must be straight-line code.
+// The epilogue of an INTERIOR tile with plain addressing (bf16 C, no c_idx / r_idx / n_group): no masks, no per-row index
+// arithmetic. With one wave per SIMD running (the other group waits at a barrier) the epilogue is bound by its own VALU
+// instruction count — s_memtime stamps: ~9000 clocks per group with per-row 64-bit multiplies and validity tests, of which
+// the 16 stores take under 2000 — so: one 64-bit row pointer per A half, uniform (scalar) row steps, and every residual
+// load issued before a store it would otherwise queue behind (vmcnt retires in order):
+//   loads(h0) compute(h0) loads(h1) stores(h0) compute(h1) stores(h1)
+template <int MIH, int BMH, int ACT>
+__device__ __forceinline__ void gemm_epilogue_fast(const grove_gemm_params& p, f32x4_t (&acc)[2 * MIH][4], const int mw0, const int nw0,
+                                                   const int fr, const int fq, const float scale) {
+  constexpr bool PLAIN = ACT < 0;
+  constexpr bool PAIR = ACT == GROVE_ACT_SWIGLU_PAIR;
+  const int n0 = nw0 + fq * 8;  // column group 0; group 1 is 128 columns on
+  const int64_t row0 = mw0 + fr;
+  float bv[2][8];
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[g][e] = 0.f;
+  if (p.bias) {
+    const u32x4_t b0 = *(const u32x4_t*)((const bf16_raw*)p.bias + n0), b1 = *(const u32x4_t*)((const bf16_raw*)p.bias + n0 + 128);
+    const float t0[8] = {bf_lo(b0.x), bf_hi(b0.x), bf_lo(b0.y), bf_hi(b0.y), bf_lo(b0.z), bf_hi(b0.z), bf_lo(b0.w), bf_hi(b0.w)};
+    const float t1[8] = {bf_lo(b1.x), bf_hi(b1.x), bf_lo(b1.y), bf_hi(b1.y), bf_lo(b1.z), bf_hi(b1.z), bf_lo(b1.w), bf_hi(b1.w)};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      bv[0][e] = t0[e];
+      bv[1][e] = t1[e];
+    }
+  }
+  const int64_t ld_aux = p.ld_aux ? p.ld_aux : p.ldc;
+  u32x4_t rr[MIH][2], outp[MIH][2];
+  auto load_res = [&](const int h) {
+    const bf16_raw* rp = (const bf16_raw*)p.residual + (row0 + h * BMH) * p.ldr + n0;
+#pragma unroll
+    for (int i = 0; i < MIH; ++i) {
+      rr[i][0] = *(const u32x4_t*)(rp + (int64_t)(i * 16) * p.ldr);
+      rr[i][1] = *(const u32x4_t*)(rp + (int64_t)(i * 16) * p.ldr + 128);
+    }
+  };
+  auto compute = [&](const int h) {
+    bf16_raw* ap = p.aux ? (bf16_raw*)p.aux + (row0 + h * BMH) * ld_aux + (PAIR ? (n0 >> 3) * 4 : n0) : nullptr;
+#pragma unroll
+    for (int i = 0; i < MIH; ++i)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const f32x4_t a0 = acc[h * MIH + i][2 * g], a1 = acc[h * MIH + i][2 * g + 1];
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (PLAIN) {
+            v[e] = a0[e] + bv[g][e];
+            v[4 + e] = a1[e] + bv[g][4 + e];
+          } else {
+            v[e] = a0[e] * p.alpha + bv[g][e];
+            v[4 + e] = a1[e] * p.alpha + bv[g][4 + e];
+          }
+        }
+        if constexpr (PAIR) {  // see gemm_epilogue_wide
+          const unsigned g01 = pack2bf(v[0], v[1]), g23 = pack2bf(v[2], v[3]), u01 = pack2bf(v[4], v[5]), u23 = pack2bf(v[6], v[7]);
+          if (ap) {
+            bf16_raw* ax = ap + (int64_t)(i * 16) * ld_aux + g * 64;
+            *(u32x2_t*)ax = u32x2_t{g01, g23};
+            *(u32x2_t*)(ax + (p.N >> 1)) = u32x2_t{u01, u23};
+          }
+          const float gg[4] = {bf_lo(g01), bf_hi(g01), bf_lo(g23), bf_hi(g23)};
+          const float uu[4] = {bf_lo(u01), bf_hi(u01), bf_lo(u23), bf_hi(u23)};
+          float o[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = gg[e] * fast_sigmoid(gg[e]) * uu[e];
+          outp[i][g] = u32x4_t{pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), 0u, 0u};
+        } else {
+          if (ap)
+            *(u32x4_t*)(ap + (int64_t)(i * 16) * ld_aux + g * 128) =
+                u32x4_t{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+          if (!PLAIN) {
+            if (ACT != GROVE_ACT_NONE) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = act_apply(ACT, v[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= scale;
+          }
+          if (p.residual) {
+            const u32x4_t q = rr[i][g];
+            v[0] += bf_lo(q.x); v[1] += bf_hi(q.x); v[2] += bf_lo(q.y); v[3] += bf_hi(q.y);
+            v[4] += bf_lo(q.z); v[5] += bf_hi(q.z); v[6] += bf_lo(q.w); v[7] += bf_hi(q.w);
+          }
+          outp[i][g] = u32x4_t{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+        }
+      }
+  };
+  auto store = [&](const int h) {
+    bf16_raw* cp = (bf16_raw*)p.C + (row0 + h * BMH) * p.ldc + (PAIR ? (n0 >> 3) * 4 : n0);
+#pragma unroll
+    for (int i = 0; i < MIH; ++i)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        if constexpr (PAIR) *(u32x2_t*)(cp + (int64_t)(i * 16) * p.ldc + g * 64) = u32x2_t{outp[i][g].x, outp[i][g].y};
+        else *(u32x4_t*)(cp + (int64_t)(i * 16) * p.ldc + g * 128) = outp[i][g];
+      }
+  };
+  if (p.residual) load_res(0);
+  compute(0);
+  if (p.residual) load_res(1);
+  store(0);
+  compute(1);
+  store(1);
+}
+
+// Three passes, so that no vector load is ever pending while stores are issued (hipcc guards a load's first use with
+// s_waitcnt vmcnt(0) whenever control flow makes the count ambiguous; with stores in the queue that wait is a store
+// round trip per row — measured 9100 clocks per epilogue, against ~2000 for the stores themselves):
+//   rows:   destination / residual rows of my 2 * MIH row fragments (c_idx / r_idx loads back to back);
+//   values: per column group, bias + all residual rows in flight together, then the arithmetic IN PLACE in the accumulators
+//           (aux, which keeps the pre-activation value, is stored here);
+//   stores: conversions and stores only.
 template <int MIH, int BMH, int ACT>
 __device__ __forceinline__ void gemm_epilogue_wide(const grove_gemm_params& p, f32x4_t (&acc)[2 * MIH][4], const int mw0, const int nw0,
                                                    const int fr, const int fq, const float scale) {
   constexpr bool PLAIN = ACT < 0;
+  constexpr bool PAIR = ACT == GROVE_ACT_SWIGLU_PAIR;
   const bf16_raw* __restrict__ bias = (const bf16_raw*)p.bias;
+  const bool f32_out = p.c_dtype != GROVE_BF16;
 #pragma unroll
-  for (int g = 0; g < 2; ++g) {
-    const int n = nw0 + g * 128 + fq * 8;
-    if (n >= p.N) continue;
-    // padded-head output (n_group / n_pad): destination column, and whether this chunk closes a group (then the pad
-    // columns behind it are zero-filled by this lane)
-    const int ngrp = p.n_group ? n / p.n_group : 0;
-    const int nd = n + ngrp * p.n_pad;
-    const bool close_group = p.n_group && (n - ngrp * p.n_group + 8 == p.n_group);
-    float bv[8];
+  for (int h = 0; h < 2; ++h) {  // the two A halves in turn: MIH row fragments each (register budget)
+    int crow[MIH], rrow[MIH];
+    {
+      int mc[MIH];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bv[e] = 0.f;
-    if (bias) {
-      const u32x4_t bb = *(const u32x4_t*)(bias + n);
-      bv[0] = bf_lo(bb.x); bv[1] = bf_hi(bb.x); bv[2] = bf_lo(bb.y); bv[3] = bf_hi(bb.y);
-      bv[4] = bf_lo(bb.z); bv[5] = bf_hi(bb.z); bv[6] = bf_lo(bb.w); bv[7] = bf_hi(bb.w);
+      for (int i = 0; i < MIH; ++i) {
+        crow[i] = mw0 + h * BMH + i * 16 + fr;
+        mc[i] = min(crow[i], p.M - 1);
+      }
+      if (p.c_idx) {
+#pragma unroll
+        for (int i = 0; i < MIH; ++i) crow[i] = p.c_idx[mc[i]];
+      }
+#pragma unroll
+      for (int i = 0; i < MIH; ++i) {
+        if (mw0 + h * BMH + i * 16 + fr >= p.M) crow[i] = -1;
+        rrow[i] = crow[i];
+      }
+      if (p.r_idx) {
+        int ri[MIH];
+#pragma unroll
+        for (int i = 0; i < MIH; ++i) ri[i] = p.r_idx[mc[i]];
+#pragma unroll
+        for (int i = 0; i < MIH; ++i)
+          if (crow[i] >= 0) rrow[i] = ri[i];
+      }
     }
-    // row bookkeeping first, then ALL residual loads of this column group in flight at once (the operand fragments'
-    // registers are free here), then the arithmetic and the stores
-    int crow[2 * MIH], rrow[2 * MIH];
+    u32x4_t outp[MIH][2];  // bf16 C: the finished rows, packed (SWIGLU_PAIR: .x .y only)
 #pragma unroll
-    for (int i = 0; i < 2 * MIH; ++i) {
-      const int m = mw0 + (i / MIH) * BMH + (i % MIH) * 16 + fr;
-      crow[i] = m < p.M ? m : -1;
-      if (p.c_idx && crow[i] >= 0) crow[i] = p.c_idx[m];
-      rrow[i] = crow[i];
-      if (p.r_idx && crow[i] >= 0) rrow[i] = p.r_idx[m];
-    }
-    u32x4_t rr[2 * MIH];
-    if (p.residual) {
+    for (int g = 0; g < 2; ++g) {
+      const int n = nw0 + g * 128 + fq * 8;
+      const bool n_ok = n < p.N;
+      const int nc8 = min(n, p.N - 8);
+      const int nd = n + (p.n_group ? n / p.n_group : 0) * p.n_pad;  // padded-head output (n_group / n_pad): destination column
+      u32x4_t bb = u32x4_t{0u, 0u, 0u, 0u};
+      if (bias) bb = *(const u32x4_t*)(bias + nc8);
+      u32x4_t rr[MIH];
+      if (p.residual) {
 #pragma unroll
-      for (int i = 0; i < 2 * MIH; ++i)
-        rr[i] = *(const u32x4_t*)((const bf16_raw*)p.residual + (int64_t)(rrow[i] >= 0 ? rrow[i] : 0) * p.ldr + n);
-    }
+        for (int i = 0; i < MIH; ++i) rr[i] = *(const u32x4_t*)((const bf16_raw*)p.residual + (int64_t)max(rrow[i], 0) * p.ldr + nc8);
+      }
+      const float bv[8] = {bf_lo(bb.x), bf_hi(bb.x), bf_lo(bb.y), bf_hi(bb.y), bf_lo(bb.z), bf_hi(bb.z), bf_lo(bb.w), bf_hi(bb.w)};
 #pragma unroll
-    for (int i = 0; i < 2 * MIH; ++i) {
-      if (crow[i] < 0) continue;
-      float v[8];
+      for (int i = 0; i < MIH; ++i) {
+        const f32x4_t a0 = acc[h * MIH + i][2 * g], a1 = acc[h * MIH + i][2 * g + 1];
+        float v[8];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (PLAIN) {
-          v[e] = acc[i][2 * g][e] + bv[e];
-          v[4 + e] = acc[i][2 * g + 1][e] + bv[4 + e];
+        for (int e = 0; e < 4; ++e) {
+          if (PLAIN) {
+            v[e] = a0[e] + bv[e];
+            v[4 + e] = a1[e] + bv[4 + e];
+          } else {
+            v[e] = a0[e] * p.alpha + bv[e];
+            v[4 + e] = a1[e] * p.alpha + bv[4 + e];
+          }
+        }
+        const bool ok = n_ok && crow[i] >= 0;
+        if constexpr (PAIR) {
+          // v[0..3] = gate, v[4..7] = up of columns (n / 8) * 4 .. + 3 (B rows interleaved by the caller). Rounded to bf16 first:
+          // the same values the unfused path stores and reads back, so the product is bit-identical to grove_swiglu_fwd's.
+          const unsigned g01 = pack2bf(v[0], v[1]), g23 = pack2bf(v[2], v[3]), u01 = pack2bf(v[4], v[5]), u23 = pack2bf(v[6], v[7]);
+          if (p.aux && ok) {
+            bf16_raw* ax = (bf16_raw*)p.aux + (int64_t)crow[i] * (p.ld_aux ? p.ld_aux : p.ldc) + (n >> 3) * 4;
+            *(u32x2_t*)ax = u32x2_t{g01, g23};
+            *(u32x2_t*)(ax + (p.N >> 1)) = u32x2_t{u01, u23};
+          }
+          const float gg[4] = {bf_lo(g01), bf_hi(g01), bf_lo(g23), bf_hi(g23)};
+          const float uu[4] = {bf_lo(u01), bf_hi(u01), bf_lo(u23), bf_hi(u23)};
+          float o[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = gg[e] * fast_sigmoid(gg[e]) * uu[e];
+          outp[i][g] = u32x4_t{pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), 0u, 0u};
+          continue;
+        }
+        if (p.aux && ok)
+          *(u32x4_t*)((bf16_raw*)p.aux + (int64_t)crow[i] * (p.ld_aux ? p.ld_aux : p.ldc) + n) =
+              u32x4_t{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+        if (!PLAIN) {
+          if (ACT != GROVE_ACT_NONE && !PAIR) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = act_apply(ACT, v[e]);
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= scale;
+        }
+        if (p.residual) {
+          const bool has_r = rrow[i] >= 0;  // a row without a residual row (r_idx < 0) adds nothing
+          const u32x4_t q = rr[i];
+          const float rv[8] = {bf_lo(q.x), bf_hi(q.x), bf_lo(q.y), bf_hi(q.y), bf_lo(q.z), bf_hi(q.z), bf_lo(q.w), bf_hi(q.w)};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = has_r ? v[e] + rv[e] : v[e];
+        }
+        if (f32_out) {  // fp32 C (rare on this path): stored row by row
+          float* c = (float*)p.C + (int64_t)crow[i] * p.ldc + nd;
+          if (ok) {
+            *(f32x4_t*)c = f32x4_t{v[0], v[1], v[2], v[3]};
+            *(f32x4_t*)(c + 4) = f32x4_t{v[4], v[5], v[6], v[7]};
+          }
         } else {
-          v[e] = acc[i][2 * g][e] * p.alpha + bv[e];
-          v[4 + e] = acc[i][2 * g + 1][e] * p.alpha + bv[4 + e];
+          outp[i][g] = u32x4_t{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
         }
       }
-      if constexpr (ACT == GROVE_ACT_SWIGLU_PAIR) {
-        // v[0..3] = gate, v[4..7] = up of columns (n / 8) * 4 .. + 3 (B rows interleaved by the caller). Rounded to bf16 first:
-        // the same values the unfused path stores and reads back, so the product is bit-identical to grove_swiglu_fwd's.
-        const unsigned g01 = pack2bf(v[0], v[1]), g23 = pack2bf(v[2], v[3]), u01 = pack2bf(v[4], v[5]), u23 = pack2bf(v[6], v[7]);
-        const int half = p.N >> 1, nc = (n >> 3) * 4;
-        if (p.aux) {
-          bf16_raw* ax = (bf16_raw*)p.aux + (int64_t)crow[i] * (p.ld_aux ? p.ld_aux : p.ldc) + nc;
-          *(u32x2_t*)ax = u32x2_t{g01, g23};
-          *(u32x2_t*)(ax + half) = u32x2_t{u01, u23};
-        }
-        const float gg[4] = {bf_lo(g01), bf_hi(g01), bf_lo(g23), bf_hi(g23)};
-        const float uu[4] = {bf_lo(u01), bf_hi(u01), bf_lo(u23), bf_hi(u23)};
-        float o[4];
+    }
+    if (f32_out) continue;
+    // stores only
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = gg[e] * fast_sigmoid(gg[e]) * uu[e];
-        *(u32x2_t*)((bf16_raw*)p.C + (int64_t)crow[i] * p.ldc + nc) = u32x2_t{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
-        continue;
-      }
-      if (p.aux)
-        *(u32x4_t*)((bf16_raw*)p.aux + (int64_t)crow[i] * (p.ld_aux ? p.ld_aux : p.ldc) + n) =
-            u32x4_t{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
-      if (!PLAIN) {
-        if (ACT != GROVE_ACT_NONE && ACT != GROVE_ACT_SWIGLU_PAIR) {
+    for (int g = 0; g < 2; ++g) {
+      const int n = nw0 + g * 128 + fq * 8;
+      const bool n_ok = n < p.N;
+      const int nd = PAIR ? (n >> 3) * 4 : n + (p.n_group ? n / p.n_group : 0) * p.n_pad;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = act_apply(ACT, v[e]);
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= scale;
-      }
-      if (p.residual && rrow[i] >= 0) {
-        v[0] += bf_lo(rr[i].x); v[1] += bf_hi(rr[i].x); v[2] += bf_lo(rr[i].y); v[3] += bf_hi(rr[i].y);
-        v[4] += bf_lo(rr[i].z); v[5] += bf_hi(rr[i].z); v[6] += bf_lo(rr[i].w); v[7] += bf_hi(rr[i].w);
-      }
-      if (p.c_dtype == GROVE_BF16) {
+      for (int i = 0; i < MIH; ++i) {
         bf16_raw* c = (bf16_raw*)p.C + (int64_t)crow[i] * p.ldc + nd;
-        *(u32x4_t*)c = u32x4_t{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
-        if (close_group)
-          for (int z = 0; z < p.n_pad; z += 8) *(u32x4_t*)(c + 8 + z) = u32x4_t{0u, 0u, 0u, 0u};
-      } else {
-        float* c = (float*)p.C + (int64_t)crow[i] * p.ldc + nd;
-        *(f32x4_t*)c = f32x4_t{v[0], v[1], v[2], v[3]};
-        *(f32x4_t*)(c + 4) = f32x4_t{v[4], v[5], v[6], v[7]};
+        if (n_ok && crow[i] >= 0) {
+          if constexpr (PAIR) *(u32x2_t*)c = u32x2_t{outp[i][g].x, outp[i][g].y};
+          else *(u32x4_t*)c = outp[i][g];
+        }
+      }
+    }
+    if (p.n_group) {  // chunks that close a head group zero-fill the pad columns behind it (bf16 C only)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const int n = nw0 + g * 128 + fq * 8;
+        const int ngrp = n / p.n_group;
+        if (n >= p.N || n - ngrp * p.n_group + 8 != p.n_group) continue;
+#pragma unroll
+        for (int i = 0; i < MIH; ++i) {
+          if (crow[i] < 0) continue;
+          bf16_raw* c = (bf16_raw*)p.C + (int64_t)crow[i] * p.ldc + n + ngrp * p.n_pad + 8;
+          for (int z = 0; z < p.n_pad; z += 8) *(u32x4_t*)(c + z) = u32x4_t{0u, 0u, 0u, 0u};
+        }
       }
     }
   }
@@ -526,8 +685,10 @@ __device__ __forceinline__ i32x8_t sload8(const int* p) {
 
 // GATHER: A rows are looked up per (tap, m) in p.a_idx (implicit-GEMM Conv3d: K = taps x C_in; window (un)partition: one tap),
 // -1 = a zero row.
-template <int BM, bool GATHER>
-__global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_params p, const int tiles_m, const int tiles_n) {
+// ACT: the epilogue compiled in (-1 = plain: act NONE, alpha 1, no scale) — one per kernel: with all of them in one kernel the
+// register allocator spills inside the K loop.
+template <int BM, bool GATHER, int ACT>
+__global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_params p, const int tiles_m, const int tiles_n, const int stagger) {
   constexpr int BMH = BM / 2;    // rows of an A half-tile: 128 or 96
   constexpr int WRH = BMH / 2;   // ... of which one wave group owns 64 or 48
   constexpr int MIH = WRH / 16;  // row fragments per half per wave: 4 or 3
@@ -548,6 +709,14 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
   const int nk = p.K / P_BK;
   const int NT = my_tiles * nk;  // K tiles of my stream
   const int NH = 4 * NT;         // half-tiles of my stream
+  // Start stagger. Blocks that start together finish their tiles together, and 256 simultaneous epilogues ask for 32 MB at
+  // once: the chip takes ~6.4 TB/s of stores, so each block's 128 KB takes ~5 us instead of the ~1.4 us one CU needs when the
+  // others are in their K loops (tools/micro/store_bw.hip). Eight start groups per XCD, `stagger` x 1024 clocks apart, keep
+  // the epilogues of a multi-round launch out of phase for its whole duration.
+  if (stagger > 0) {
+    const int grp = (blockIdx.x >> 3) & 7;
+    for (int i = 0; i < grp * stagger; ++i) __builtin_amdgcn_s_sleep(16);
+  }
   auto tile_origin = [&](int L, int& m0, int& n0) {
     constexpr int GM = 8;
     const int per_band = GM * tiles_n;
@@ -710,7 +879,6 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();  // the stagger
 
-  int c_L = wgid, c_k = 0;  // output tile / K tile being computed
   auto k_tile = [&](auto steady, int T) {
     constexpr bool STEADY = decltype(steady)::value;
     const char* st = smem + (T & 1) * P_STAGE;
@@ -735,47 +903,46 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
     PP_MEM_END(STEADY, q + 3, 1, 2, true)
     PP_MMA(MIH, 0, b0)
     __builtin_amdgcn_s_barrier();
-    if (++c_k == nk) {  // tile done: epilogue (no barriers inside), then on to my next tile whose operands are already landing
-      int m0, n0;
-      tile_origin(c_L, m0, n0);
-      const int mw0 = m0 + wr * WRH, nw0 = n0 + wc * 32;
-      if (p.act == GROVE_ACT_NONE) {
-        if (p.alpha == 1.f && !p.scale_ptr) gemm_epilogue_wide<MIH, BMH, -1>(p, acc, mw0, nw0, fr, fq, 1.f);
-        else gemm_epilogue_wide<MIH, BMH, GROVE_ACT_NONE>(p, acc, mw0, nw0, fr, fq, scale);
-      } else if (p.act == GROVE_ACT_GELU) {
-        gemm_epilogue_wide<MIH, BMH, GROVE_ACT_GELU>(p, acc, mw0, nw0, fr, fq, scale);
-      } else if (p.act == GROVE_ACT_RELU) {
-        gemm_epilogue_wide<MIH, BMH, GROVE_ACT_RELU>(p, acc, mw0, nw0, fr, fq, scale);
-      } else if (p.act == GROVE_ACT_SWIGLU_PAIR) {
-        gemm_epilogue_wide<MIH, BMH, GROVE_ACT_SWIGLU_PAIR>(p, acc, mw0, nw0, fr, fq, scale);
-      } else {
-        gemm_epilogue_wide<MIH, BMH, GROVE_ACT_QUICKGELU>(p, acc, mw0, nw0, fr, fq, scale);
-      }
-#pragma unroll
-      for (int i = 0; i < 2 * MIH; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      c_k = 0;
-      c_L += G;
-    }
   };
+  const bool fast_addr = p.c_dtype == GROVE_BF16 && !p.c_idx && !p.r_idx && !p.n_group;  // gemm_epilogue_fast's case
+  // my output tiles in turn: their K tiles (STEADY while the stream still has a half-tile to issue six phases ahead, i.e. all
+  // but the stream's last two), then the epilogue (no barriers inside) — the next tile's operands are already landing
   int T = 0;
-  for (; T + 2 < NT; ++T) k_tile(std::true_type{}, T);
-  for (; T < NT; ++T) k_tile(std::false_type{}, T);
+  for (int c_L = wgid; c_L < tiles; c_L += G) {
+    const int ns = min(max(NT - 2 - T, 0), nk);
+    int k = 0;
+    for (; k < ns; ++k, ++T) k_tile(std::true_type{}, T);
+    for (; k < nk; ++k, ++T) k_tile(std::false_type{}, T);
+    int m0, n0;
+    tile_origin(c_L, m0, n0);
+    const int mw0 = m0 + wr * WRH, nw0 = n0 + wc * 32;
+    const bool interior = fast_addr && m0 + BM <= p.M && n0 + P_BN <= p.N;
+    if (interior) gemm_epilogue_fast<MIH, BMH, ACT>(p, acc, mw0, nw0, fr, fq, ACT < 0 ? 1.f : scale);
+    else gemm_epilogue_wide<MIH, BMH, ACT>(p, acc, mw0, nw0, fr, fq, ACT < 0 ? 1.f : scale);
+#pragma unroll
+    for (int i = 0; i < 2 * MIH; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
   if (wr == 0) __builtin_amdgcn_s_barrier();
 #undef PP_MMA
 #undef PP_MEM_END
 }
 
 static int g_num_cus = 0;
+static int g_gemm_stagger = -1;  // -1 = auto
+extern "C" int grove_gemm_set_stagger(int units) {
+  g_gemm_stagger = units;
+  return GROVE_OK;
+}
 
-template <int BM, bool GATHER>
-int launch_pp(const grove_gemm_params& p, hipStream_t s) {
+template <int BM, bool GATHER, int ACT>
+int launch_pp_act(const grove_gemm_params& p, hipStream_t s) {
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + P_BN - 1) / P_BN;
   const size_t lds = 2 * (size_t)P_STAGE;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<BM, GATHER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<BM, GATHER, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   if (g_num_cus == 0) {
@@ -786,9 +953,31 @@ int launch_pp(const grove_gemm_params& p, hipStream_t s) {
   }
   const int tiles = tiles_m * tiles_n;
   const int grid = tiles < g_num_cus ? tiles : g_num_cus;
-  hipLaunchKernelGGL((gemm_nt_pp_kernel<BM, GATHER>), dim3(grid, 1, 1), dim3(P_NT), lds, s, p, tiles_m, tiles_n);
+  const int rounds = (tiles + grid - 1) / grid;
+  const int stagger = g_gemm_stagger >= 0 ? g_gemm_stagger : 0;
+  (void)rounds;
+  hipLaunchKernelGGL((gemm_nt_pp_kernel<BM, GATHER, ACT>), dim3(grid, 1, 1), dim3(P_NT), lds, s, p, tiles_m, tiles_n, stagger);
   GROVE_LAUNCH_CHECK();
   return GROVE_OK;
+}
+// the gathered instances carry the epilogues their callers use (plain, scaled, ReLU: window (un)partition, Conv3d adapters)
+inline bool pp_act_ok(const grove_gemm_params& p) {
+  if (p.a_idx) return p.act == GROVE_ACT_NONE || p.act == GROVE_ACT_RELU;
+  return p.act == GROVE_ACT_NONE || p.act == GROVE_ACT_GELU || p.act == GROVE_ACT_QUICKGELU || p.act == GROVE_ACT_RELU || p.act == GROVE_ACT_SWIGLU_PAIR;
+}
+template <int BM, bool GATHER>
+int launch_pp(const grove_gemm_params& p, hipStream_t s) {
+  if (p.act == GROVE_ACT_NONE) {
+    if (p.alpha == 1.f && !p.scale_ptr) return launch_pp_act<BM, GATHER, -1>(p, s);
+    return launch_pp_act<BM, GATHER, GROVE_ACT_NONE>(p, s);
+  }
+  if (p.act == GROVE_ACT_RELU) return launch_pp_act<BM, GATHER, GROVE_ACT_RELU>(p, s);
+  if constexpr (!GATHER) {
+    if (p.act == GROVE_ACT_GELU) return launch_pp_act<BM, false, GROVE_ACT_GELU>(p, s);
+    if (p.act == GROVE_ACT_QUICKGELU) return launch_pp_act<BM, false, GROVE_ACT_QUICKGELU>(p, s);
+    if (p.act == GROVE_ACT_SWIGLU_PAIR) return launch_pp_act<BM, false, GROVE_ACT_SWIGLU_PAIR>(p, s);
+  }
+  GROVE_CHECK(false, GROVE_E_SHAPE, "gemm: no pipelined instance for act %d%s", p.act, GATHER ? " with gathered A" : "");
 }
 
 // fraction of the 256 CUs' block slots that do useful work when `tiles` equal blocks are spread over them
@@ -868,8 +1057,7 @@ extern "C" int grove_gemm_bf16(const grove_gemm_params* pp, void* stream) {
   const bool wide_ok = (((uintptr_t)p.C & 15) == 0) && (p.ldc % (p.c_dtype == GROVE_BF16 ? 8 : 4) == 0) &&
                        (!p.aux || ((uintptr_t)p.aux & 15) == 0) && (!p.bias || ((uintptr_t)p.bias & 15) == 0) &&
                        (!p.residual || ((((uintptr_t)p.residual & 15) == 0) && p.ldr % 8 == 0));
-  const bool pp_act = p.act == GROVE_ACT_NONE || p.act == GROVE_ACT_GELU || p.act == GROVE_ACT_QUICKGELU || p.act == GROVE_ACT_RELU ||
-                      p.act == GROVE_ACT_SWIGLU_PAIR;  // compiled-in epilogues
+  const bool pp_act = pp_act_ok(p);  // compiled-in epilogues
   const bool maps = p.n_group || p.k_group;
   const bool p256_ok = g_gemm_glds && bk64 && (!p.a_idx || (long)p.a_taps * p.M >= 8) && bt == 1 && p.split_k <= 1 && !p.accumulate && wide_ok && p.N % 8 == 0 && pp_act;
   // Tile choice by a measured cost model (tools/bench_gemm5.py, microseconds): time = rounds of resident blocks x
