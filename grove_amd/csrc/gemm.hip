@@ -913,6 +913,11 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
     int k = 0;
     for (; k < ns; ++k, ++T) k_tile(std::true_type{}, T);
     for (; k < nk; ++k, ++T) k_tile(std::false_type{}, T);
+    // Both groups run their epilogues in the same barrier interval: the leading group waits one barrier here (the lagging
+    // group is in its last MFMA segment), the lagging group waits one after its epilogue, which restores the one-barrier lag.
+    // An epilogue is bound by the issue latency of its own VALU / store stream, so two waves per SIMD take little longer
+    // than one, where the groups one after the other took twice as long. No LDS access and no staging in the interval.
+    if (wr == 0) __builtin_amdgcn_s_barrier();
     int m0, n0;
     tile_origin(c_L, m0, n0);
     const int mw0 = m0 + wr * WRH, nw0 = n0 + wc * 32;
@@ -923,6 +928,7 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
     for (int i = 0; i < 2 * MIH; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (wr == 1) __builtin_amdgcn_s_barrier();
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();
 #undef PP_MMA
