@@ -685,10 +685,16 @@ __device__ __forceinline__ i32x8_t sload8(const int* p) {
 
 // GATHER: A rows are looked up per (tap, m) in p.a_idx (implicit-GEMM Conv3d: K = taps x C_in; window (un)partition: one tap),
 // -1 = a zero row.
+// reciprocals for the tile -> origin map (see tile_origin)
+struct pp_tile_map {
+  unsigned magic_band, magic_tail;  // floor(2^32 / d) + 1 for d = 8 * tiles_n and d = tail
+  int full_bands, tail;             // tiles_m / 8, tiles_m % 8
+};
+
 // ACT: the epilogue compiled in (-1 = plain: act NONE, alpha 1, no scale) — one per kernel: with all of them in one kernel the
 // register allocator spills inside the K loop.
 template <int BM, bool GATHER, int ACT>
-__global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_params p, const int tiles_m, const int tiles_n, const int stagger) {
+__global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_params p, const int tiles_m, const int tiles_n, const pp_tile_map tm) {
   constexpr int BMH = BM / 2;    // rows of an A half-tile: 128 or 96
   constexpr int WRH = BMH / 2;   // ... of which one wave group owns 64 or 48
   constexpr int MIH = WRH / 16;  // row fragments per half per wave: 4 or 3
@@ -709,23 +715,23 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
   const int nk = p.K / P_BK;
   const int NT = my_tiles * nk;  // K tiles of my stream
   const int NH = 4 * NT;         // half-tiles of my stream
-  // Start stagger. Blocks that start together finish their tiles together, and 256 simultaneous epilogues ask for 32 MB at
-  // once: the chip takes ~6.4 TB/s of stores, so each block's 128 KB takes ~5 us instead of the ~1.4 us one CU needs when the
-  // others are in their K loops (tools/micro/store_bw.hip). Eight start groups per XCD, `stagger` x 1024 clocks apart, keep
-  // the epilogues of a multi-round launch out of phase for its whole duration.
-  if (stagger > 0) {
-    const int grp = (blockIdx.x >> 3) & 7;
-    for (int i = 0; i < grp * stagger; ++i) __builtin_amdgcn_s_sleep(16);
-  }
+  // tile L -> origin: bands of GM = 8 tile rows, column-major inside a band (the last band may be shorter). Divisions by
+  // multiply-high with host-made reciprocals (exact: L * divisor < 2^32, checked by the launcher) — the compiler's integer
+  // division is ~400 clocks of dependent scalar code, and this runs inside a K tile's staging segment once per output tile.
   auto tile_origin = [&](int L, int& m0, int& n0) {
-    constexpr int GM = 8;
-    const int per_band = GM * tiles_n;
-    const int band = L / per_band;
-    const int first_m = band * GM;
-    const int gm = min(tiles_m - first_m, GM);
+    const int per_band = 8 * tiles_n;
+    const int band = (int)__umulhi((unsigned)L, tm.magic_band);
     const int in_band = L - band * per_band;
-    m0 = (first_m + in_band % gm) * BM;
-    n0 = (in_band / gm) * P_BN;
+    int r, c;
+    if (band == tm.full_bands) {  // the short last band: tm.tail rows
+      c = (int)__umulhi((unsigned)in_band, tm.magic_tail);
+      r = in_band - c * tm.tail;
+    } else {
+      c = in_band >> 3;
+      r = in_band & 7;
+    }
+    m0 = (band * 8 + r) * BM;
+    n0 = c * P_BN;
   };
 
   // staging: regions of a stage in staging order 0 = A_lo, 1 = B_lo, 2 = B_hi, 3 = A_hi. A half-tile region is 128 rows x 8
@@ -936,11 +942,6 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
 }
 
 static int g_num_cus = 0;
-static int g_gemm_stagger = -1;  // -1 = auto
-extern "C" int grove_gemm_set_stagger(int units) {
-  g_gemm_stagger = units;
-  return GROVE_OK;
-}
 
 template <int BM, bool GATHER, int ACT>
 int launch_pp_act(const grove_gemm_params& p, hipStream_t s) {
@@ -959,10 +960,13 @@ int launch_pp_act(const grove_gemm_params& p, hipStream_t s) {
   }
   const int tiles = tiles_m * tiles_n;
   const int grid = tiles < g_num_cus ? tiles : g_num_cus;
-  const int rounds = (tiles + grid - 1) / grid;
-  const int stagger = g_gemm_stagger >= 0 ? g_gemm_stagger : 0;
-  (void)rounds;
-  hipLaunchKernelGGL((gemm_nt_pp_kernel<BM, GATHER, ACT>), dim3(grid, 1, 1), dim3(P_NT), lds, s, p, tiles_m, tiles_n, stagger);
+  GROVE_CHECK((long)tiles * 8 * tiles_n < (1L << 31), GROVE_E_SHAPE, "gemm: %d x %d tiles overflow the pipelined kernel's tile map", tiles_m, tiles_n);
+  pp_tile_map tm;
+  tm.magic_band = (unsigned)((1ull << 32) / (unsigned)(8 * tiles_n)) + 1u;
+  tm.full_bands = tiles_m / 8;
+  tm.tail = tiles_m % 8;
+  tm.magic_tail = tm.tail ? (unsigned)((1ull << 32) / (unsigned)tm.tail) + 1u : 0u;
+  hipLaunchKernelGGL((gemm_nt_pp_kernel<BM, GATHER, ACT>), dim3(grid, 1, 1), dim3(P_NT), lds, s, p, tiles_m, tiles_n, tm);
   GROVE_LAUNCH_CHECK();
   return GROVE_OK;
 }

@@ -115,9 +115,6 @@ int grove_gemm_set_staging(int use_lds_dma);
 int grove_gemm_set_tile_n(int tile_n);
 /* macro-tile M: 0 = auto, 128 or 192 = forced */
 int grove_gemm_set_tile_m(int tile_m);
-/* start stagger of the persistent pipelined kernels, in units of 1024 clocks between the 8 start groups of an XCD:
- * -1 = auto (2 for launches of two or more tile rounds, else 0), >= 0 forced (A/B measurements) */
-int grove_gemm_set_stagger(int units);
 /* K tile: 0 = auto (64 when K % 64 == 0), 32 = forced (A/B measurements) */
 int grove_gemm_set_bk(int bk);
 
