@@ -119,6 +119,39 @@ __device__ __forceinline__ float act_grad(int act, float x) {
   }
 }
 
+// act(x) and d act(x) / dx together: the erf GELU's exp(-x^2 / 2) and the sigmoids are computed once (a GEMM epilogue that
+// stores the derivative for the backward pass — grove_gemm_params.aux_grad — pays two or three extra VALU ops, not a second
+// transcendental chain). Same values as act_apply / act_grad up to the rounding of the shared terms.
+__device__ __forceinline__ void act_apply_grad(int act, float x, float& y, float& g) {
+  switch (act) {
+    case GROVE_ACT_GELU: {
+      const float z = x * 0.70710678118654752440f, az = fabsf(z);
+      const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * az);
+      const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+      const float e = __expf(-az * az);  // = exp(-x^2 / 2)
+      const float cdf = 0.5f * (1.f + copysignf(1.f - poly * e, z));
+      y = x * cdf;
+      g = cdf + x * (0.3989422804014327f * e);
+      return;
+    }
+    case GROVE_ACT_QUICKGELU: {
+      const float s = fast_sigmoid(1.702f * x);
+      y = x * s;
+      g = s + 1.702f * x * s * (1.f - s);
+      return;
+    }
+    case GROVE_ACT_SILU: {
+      const float s = fast_sigmoid(x);
+      y = x * s;
+      g = s + x * s * (1.f - s);
+      return;
+    }
+    default:
+      y = act_apply(act, x);
+      g = act_grad(act, x);
+  }
+}
+
 // error plumbing (host)
 void grove_set_error(const char* fmt, ...);
 #define GROVE_CHECK(cond, code, ...)         \

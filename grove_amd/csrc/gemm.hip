@@ -106,12 +106,15 @@ __device__ __forceinline__ void gemm_epilogue(const grove_gemm_params& p, const 
       }
       if (p.aux) {
         bf16_raw* aux = (bf16_raw*)p.aux + c_boff + (int64_t)crow * p.ldc + n;
+        float av[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) av[e] = (MI <= 4 && p.aux_grad) ? act_grad(p.act, v[e]) : v[e];  // (no sharing with act(v) here; not in the 192-row variant: registers)
         if (full) {
-          *(u32x2_t*)aux = u32x2_t{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+          *(u32x2_t*)aux = u32x2_t{pack2bf(av[0], av[1]), pack2bf(av[2], av[3])};
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            if (n + e < p.N) aux[e] = f2bf(v[e]);
+            if (n + e < p.N) aux[e] = f2bf(av[e]);
         }
       }
       if (p.act != GROVE_ACT_NONE) {
@@ -122,14 +125,17 @@ __device__ __forceinline__ void gemm_epilogue(const grove_gemm_params& p, const 
       for (int e = 0; e < 4; ++e) v[e] *= scale;
       if (p.residual && rrow >= 0) {
         const bf16_raw* res = (const bf16_raw*)p.residual + r_boff + (int64_t)rrow * p.ldr + n;
+        float rv[4] = {0.f, 0.f, 0.f, 0.f};
         if (full) {
           const u32x2_t rr = *(const u32x2_t*)res;
-          v[0] += bf_lo(rr.x); v[1] += bf_hi(rr.x); v[2] += bf_lo(rr.y); v[3] += bf_hi(rr.y);
+          rv[0] = bf_lo(rr.x); rv[1] = bf_hi(rr.x); rv[2] = bf_lo(rr.y); rv[3] = bf_hi(rr.y);
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            if (n + e < p.N) v[e] += bf2f(res[e]);
+            if (n + e < p.N) rv[e] = bf2f(res[e]);
         }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (MI <= 4 && p.residual_mul) ? v[e] * rv[e] : v[e] + rv[e];
       }
       if (p.c_dtype == GROVE_BF16) {
         bf16_raw* c = (bf16_raw*)p.C + c_boff + (int64_t)crow * p.ldc + n;
@@ -457,21 +463,30 @@ __device__ __forceinline__ void gemm_epilogue_fast(const grove_gemm_params& p, f
           for (int e = 0; e < 4; ++e) o[e] = gg[e] * fast_sigmoid(gg[e]) * uu[e];
           outp[i][g] = u32x4_t{pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), 0u, 0u};
         } else {
-          if (ap)
+          if (ap && p.aux_grad) {  // aux = act'(v): computed together with act(v)
+            float av[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) act_apply_grad(ACT < 0 ? GROVE_ACT_NONE : ACT, v[e], v[e], av[e]);
             *(u32x4_t*)(ap + (int64_t)(i * 16) * ld_aux + g * 128) =
-                u32x4_t{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
-          if (!PLAIN) {
-            if (ACT != GROVE_ACT_NONE) {
+                u32x4_t{pack2bf(av[0], av[1]), pack2bf(av[2], av[3]), pack2bf(av[4], av[5]), pack2bf(av[6], av[7])};
+          } else {
+            if (ap)
+              *(u32x4_t*)(ap + (int64_t)(i * 16) * ld_aux + g * 128) =
+                  u32x4_t{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+            if (!PLAIN && ACT != GROVE_ACT_NONE) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] = act_apply(ACT, v[e]);
             }
+          }
+          if (!PLAIN) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] *= scale;
           }
           if (p.residual) {
             const u32x4_t q = rr[i][g];
-            v[0] += bf_lo(q.x); v[1] += bf_hi(q.x); v[2] += bf_lo(q.y); v[3] += bf_hi(q.y);
-            v[4] += bf_lo(q.z); v[5] += bf_hi(q.z); v[6] += bf_lo(q.w); v[7] += bf_hi(q.w);
+            const float rv[8] = {bf_lo(q.x), bf_hi(q.x), bf_lo(q.y), bf_hi(q.y), bf_lo(q.z), bf_hi(q.z), bf_lo(q.w), bf_hi(q.w)};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = p.residual_mul ? v[e] * rv[e] : v[e] + rv[e];
           }
           outp[i][g] = u32x4_t{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
         }
@@ -584,14 +599,23 @@ __device__ __forceinline__ void gemm_epilogue_wide(const grove_gemm_params& p, f
           outp[i][g] = u32x4_t{pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), 0u, 0u};
           continue;
         }
-        if (p.aux && ok)
-          *(u32x4_t*)((bf16_raw*)p.aux + (int64_t)crow[i] * (p.ld_aux ? p.ld_aux : p.ldc) + n) =
-              u32x4_t{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
-        if (!PLAIN) {
-          if (ACT != GROVE_ACT_NONE && !PAIR) {
+        if (p.aux && p.aux_grad) {  // aux = act'(v): computed together with act(v)
+          float av[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) act_apply_grad(ACT < 0 ? GROVE_ACT_NONE : ACT, v[e], v[e], av[e]);
+          if (ok)
+            *(u32x4_t*)((bf16_raw*)p.aux + (int64_t)crow[i] * (p.ld_aux ? p.ld_aux : p.ldc) + n) =
+                u32x4_t{pack2bf(av[0], av[1]), pack2bf(av[2], av[3]), pack2bf(av[4], av[5]), pack2bf(av[6], av[7])};
+        } else {
+          if (p.aux && ok)
+            *(u32x4_t*)((bf16_raw*)p.aux + (int64_t)crow[i] * (p.ld_aux ? p.ld_aux : p.ldc) + n) =
+                u32x4_t{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+          if (!PLAIN && ACT != GROVE_ACT_NONE && !PAIR) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = act_apply(ACT, v[e]);
           }
+        }
+        if (!PLAIN) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] *= scale;
         }
@@ -600,7 +624,7 @@ __device__ __forceinline__ void gemm_epilogue_wide(const grove_gemm_params& p, f
           const u32x4_t q = rr[i];
           const float rv[8] = {bf_lo(q.x), bf_hi(q.x), bf_lo(q.y), bf_hi(q.y), bf_lo(q.z), bf_hi(q.z), bf_lo(q.w), bf_hi(q.w)};
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = has_r ? v[e] + rv[e] : v[e];
+          for (int e = 0; e < 8; ++e) v[e] = has_r ? (p.residual_mul ? v[e] * rv[e] : v[e] + rv[e]) : v[e];
         }
         if (f32_out) {  // fp32 C (rare on this path): stored row by row
           float* c = (float*)p.C + (int64_t)crow[i] * p.ldc + nd;
@@ -1116,6 +1140,7 @@ extern "C" int grove_gemm_bf16(const grove_gemm_params* pp, void* stream) {
     }
   int variant = 128;
   if (g_gemm_tile_m == 192 || (g_gemm_tile_m == 0 && t128 > 300 && c192 <= c128)) variant = 192;
+  if (p.aux_grad || p.residual_mul) variant = 128;  // the 192-row variant's epilogue does not carry them
   const bool narrow = g_gemm_tile_n == 64 || (g_gemm_tile_n == 0 && ((t128 < 160 && p.N > 64) || p.N <= 64));  // N <= 64: half of a 128-wide tile would be padding
   g_gemm_last_variant = narrow ? GROVE_GEMM_T128X64 : variant == 192 && g_gemm_glds ? GROVE_GEMM_T192X128 : GROVE_GEMM_T128X128;
   if (narrow) {

@@ -184,7 +184,9 @@ class SamEncoder:
             x1 = ops.linear(o, Bk["wproj"], Bk["bproj"], residual=x)
         h2, mean2, rstd2 = ops.layernorm(x1, Bk["ln2"][0], Bk["ln2"][1], 1e-6, save_stats=save)
         pre = torch.empty((x.shape[0], 4 * C), dtype=torch.bfloat16, device=self.dev) if save else None
-        f = ops.linear(h2, Bk["w1"], Bk["b1"], act=ops.ACT_GELU, aux=pre)
+        # backward needs only gelu'(lin1(.)) (the block's weights are frozen: no weight gradient reads the pre-activation), so the
+        # GEMM stores the derivative and the backward's lin2 dgrad multiplies by it in its epilogue — no elementwise pass
+        f = ops.linear(h2, Bk["w1"], Bk["b1"], act=ops.ACT_GELU, aux=pre, aux_grad=True)
         x2 = ops.linear(f, Bk["w2"], Bk["b2"], residual=x1)
         if save:
             ctx = dict(x=x, mean=mean, rstd=rstd, qkv=qkv, actx=actx, x1=x1, mean2=mean2, rstd2=rstd2, pre=pre, nb=nb, L=L, qhw=qhw)
@@ -260,8 +262,7 @@ class SamEncoder:
             Bk, c = self.blocks[i], saved["blocks"][i]
             ws = Bk["window"]
             # x2 = x1 + lin2(gelu(lin1(ln2(x1))))
-            df = ops.linear(dx, Bk["w2_t"])
-            ops.act_bwd(c["pre"], df, ops.ACT_GELU, out=df)
+            df = ops.linear(dx, Bk["w2_t"], residual=c["pre"], residual_mul=True)  # (dx @ W2) * gelu'(pre-activation)
             dh2 = ops.linear(df, Bk["w1_t"])
             del df
             ops.layernorm_bwd(c["x1"], Bk["ln2"][0], dh2, c["mean2"], c["rstd2"], dx=dx, accumulate=True)   # dx = d x1

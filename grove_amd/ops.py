@@ -34,7 +34,8 @@ def pad_to(n, m):
 
 def gemm_raw(A, B, Cout, M, N, K, lda, ldb, ldc, *, bias=None, residual=None, ldr=0, aux=None, scale_ptr=None,
              scale_tanh=False, a_idx=None, a_taps=1, c_idx=None, r_idx=None, batch=(1, 1), sA=(0, 0), sB=(0, 0),
-             sC=(0, 0), sR=(0, 0), act=ACT_NONE, accumulate=False, alpha=1.0, split_k=0, ld_aux=0, n_map=(0, 0), k_map=(0, 0)):
+             sC=(0, 0), sR=(0, 0), act=ACT_NONE, accumulate=False, alpha=1.0, split_k=0, ld_aux=0, n_map=(0, 0), k_map=(0, 0),
+             aux_grad=False, residual_mul=False):
     """Direct call of grove_gemm_bf16; A/B/Cout are tensors whose storage the pointers refer to."""
     _chk_dev(A, B, Cout)
     p = _lib.GemmParams()
@@ -51,6 +52,8 @@ def gemm_raw(A, B, Cout, M, N, K, lda, ldb, ldc, *, bias=None, residual=None, ld
     p.accumulate, p.scale_tanh, p.alpha = int(accumulate), int(scale_tanh), float(alpha)
     p.split_k = split_k
     p.ld_aux = ld_aux
+    p.aux_grad = int(aux_grad)
+    p.residual_mul = int(residual_mul)
     p.n_group, p.n_pad = n_map
     p.k_group, p.k_pad = k_map
     _lib.check(_lib.lib().grove_gemm_bf16(C.byref(p), _stream()), "grove_gemm_bf16")
@@ -59,7 +62,7 @@ def gemm_raw(A, B, Cout, M, N, K, lda, ldb, ldc, *, bias=None, residual=None, ld
 
 def linear(x, w, bias=None, *, act=ACT_NONE, residual=None, out=None, out_dtype=bf16, aux=None, alpha=1.0,
            scale_ptr=None, scale_tanh=False, a_idx=None, a_taps=1, c_idx=None, r_idx=None, M=None, out_rows=None,
-           accumulate=False, ld_aux=0, n_map=(0, 0), k_map=(0, 0), out_cols=None):
+           accumulate=False, ld_aux=0, n_map=(0, 0), k_map=(0, 0), out_cols=None, aux_grad=False, residual_mul=False):
     """y = epilogue(x @ w.T): x [*, K] (row stride lda), w [N, K] (nn.Linear layout)."""
     K = w.shape[1]
     N = w.shape[0]
@@ -76,7 +79,8 @@ def linear(x, w, bias=None, *, act=ACT_NONE, residual=None, out=None, out_dtype=
     ldr = residual.stride(0) if residual is not None else 0
     gemm_raw(x2, w, out, M, N, K, x2.stride(0), w.stride(0), out.stride(0), bias=bias, residual=residual, ldr=ldr,
              aux=aux, scale_ptr=scale_ptr, scale_tanh=scale_tanh, a_idx=a_idx, a_taps=a_taps, c_idx=c_idx, r_idx=r_idx,
-             act=act, accumulate=accumulate, alpha=alpha, ld_aux=ld_aux, n_map=n_map, k_map=k_map)
+             act=act, accumulate=accumulate, alpha=alpha, ld_aux=ld_aux, n_map=n_map, k_map=k_map,
+             aux_grad=aux_grad, residual_mul=residual_mul)
     return out
 
 

@@ -54,9 +54,9 @@ int grove_sizeof(const char* name);
  * GEMM:  C[m, n] = epilogue( alpha * sum_k A[row_a(m,k), k] * B[n, k] )
  *   A: bf16 [*, lda] row-major (activations), B: bf16 [N, ldb] row-major (nn.Linear weight
  *   layout, i.e. "NT" GEMM), fp32 accumulate on v_mfma_f32_16x16x32_bf16.
- *   epilogue(v):  v += bias[n];  aux[m,n] = v (optional pre-activation copy for backward);
+ *   epilogue(v):  v += bias[n];  aux[m,n] = v (optional pre-activation copy for backward; act'(v) if aux_grad);
  *                 v = act(v);  v *= scale (scale = *scale_ptr, tanh'd if scale_tanh);
- *                 v += residual[row_r(m), n];  (C += v if accumulate)  store as bf16 / f32.
+ *                 v += residual[row_r(m), n] (v *= ... if residual_mul);  (C += v if accumulate)  store as bf16 / f32.
  *   Gather/scatter row maps (int32, -1 = zero row on A / skipped row on C):
  *     a_idx[tap*M + m] with tap = k / (K / a_taps)  -> implicit-GEMM convolution and window
  *     partition without materialising im2col; c_idx[m], r_idx[m] for scatter / broadcast.
@@ -96,6 +96,11 @@ typedef struct grove_gemm_params {
    *   k_group / k_pad: logical reduction index k of A is read from column k + (k / k_group) * k_pad (K and B compact;
    *                    needs a_idx: the gathered-A instance). Groups and pads are multiples of 8; 0 = off. */
   int32_t n_group, n_pad, k_group, k_pad;
+  /* Activation backward folded into the two GEMMs either side of it (replaces autograd's GeluBackward / the elementwise
+   * dY * act'(x) pass between an MLP's two dgrad GEMMs — image_encoder.py:43 MLPBlock):
+   *   aux_grad:     aux receives act'(v), the activation's derivative at the pre-activation, instead of v itself;
+   *   residual_mul: the residual operand multiplies the result (v *= residual[row_r(m), n]) instead of being added. */
+  int32_t aux_grad, residual_mul;
 } grove_gemm_params;
 int grove_gemm_bf16(const grove_gemm_params* p, void* stream);
 /* Which kernel the last grove_gemm_bf16 call launched (measurement aid: bench.py prices each kernel on its own launches). */

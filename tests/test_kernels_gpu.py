@@ -87,6 +87,32 @@ def test_gemm_epilogue(dev, act):
     close(aux, pre, 6e-3, "aux pre-activation")
 
 
+@pytest.mark.parametrize("M,N,K", [(200, 320, 192), (4096, 1280, 1024)])  # the simple and the pipelined kernel
+@pytest.mark.parametrize("act", [2, 3])
+def test_gemm_fused_activation_backward(dev, act, M, N, K):
+    """MLP backward without the elementwise pass: the forward GEMM stores act'(pre-activation) as aux (aux_grad), the
+    dgrad GEMM of the next layer multiplies by it (residual_mul) — together dX = (dY @ W2) * act'(x) as autograd computes it."""
+    from grove_amd import ops
+    a, b = rnd(M, K, seed=3), rnd(N, K, seed=4, scale=0.05)
+    bias = rnd(N, seed=5)
+    pre = (a.float() @ b.float().t() + bias.float()).requires_grad_(True)
+    y = act_ref(pre, act)
+    dy = rnd(M, N, seed=7)
+    y.backward(dy.float())
+    grad = pre.grad / dy.float()  # act'(pre)
+    grad = torch.where(dy.float() == 0, torch.zeros_like(grad), grad)
+    aux = torch.empty(M, N, dtype=bf16, device=dev)
+    out = ops.linear(a.to(dev), b.to(dev), bias.to(dev), act=act, aux=aux, aux_grad=True)
+    close(out, y, 8e-3, "activation out")
+    mask = dy.float() != 0
+    assert ((aux.float().cpu() - grad).abs()[mask].max().item()) <= 8e-3 * 1.2, "aux = act'(pre)"
+    # second half: C = (dZ @ W) * aux
+    dz, w2 = rnd(M, K, seed=8), rnd(N, K, seed=9, scale=0.05)
+    ref = (dz.float() @ w2.float().t()) * aux.float().cpu()
+    got = ops.linear(dz.to(dev), w2.to(dev), residual=aux, residual_mul=True)
+    close(got, ref, 8e-3, "dgrad * act'")
+
+
 def test_gemm_accumulate_and_alpha(dev):
     from grove_amd import ops
     M, N, K = 96, 160, 64
