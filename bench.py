@@ -54,8 +54,14 @@ def instrumented_gemm_pass(engine, batch):
     from grove_amd import _lib, ops
     orig = ops.gemm_raw
     recs = []
-    names = {1: "gemm_nt_kernel<128x128>", 2: "gemm_nt_kernel<192x128>", 3: "gemm_nt_kernel<128x64>", 4: "gemm_nt_pp_kernel<256, false>",
-             5: "gemm_nt_pp_kernel<192, false>", 6: "gemm_nt_pp_kernel<256, true>", 7: "gemm_nt_pp_kernel<192, true>"}
+    names = {1: "gemm_nt_kernel<128x128>", 2: "gemm_nt_kernel<192x128>", 3: "gemm_nt_kernel<128x64>"}
+    pp = {4: "256, false", 5: "192, false", 6: "256, true", 7: "192, true"}  # + the epilogue: the instance name rocprofv3 prints
+
+    def kernel_name():
+        v = _lib.lib().grove_gemm_last_variant()
+        if v in pp:
+            return f"gemm_nt_pp_kernel<{pp[v]}, {_lib.lib().grove_gemm_last_epilogue()}>"
+        return names.get(v, "?")
 
     def timed(A, B, C, M, N, K, *a, **k):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -64,7 +70,7 @@ def instrumented_gemm_pass(engine, batch):
         e1.record()
         b = k.get("batch", (1, 1))
         recs.append((e0, e1, 2.0 * M * N * K * b[0] * b[1], (M, N, K, b[0] * b[1], k.get("a_taps", 1)),
-                     names.get(_lib.lib().grove_gemm_last_variant(), "?")))
+                     kernel_name()))
         return r
     ops.gemm_raw = timed
     try:

@@ -966,6 +966,7 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
 }
 
 static int g_num_cus = 0;
+static int g_gemm_last_epilogue = 0;  // ACT template argument of the last pipelined launch (see grove_gemm_last_epilogue)
 
 template <int BM, bool GATHER, int ACT>
 int launch_pp_act(const grove_gemm_params& p, hipStream_t s) {
@@ -985,6 +986,7 @@ int launch_pp_act(const grove_gemm_params& p, hipStream_t s) {
   const int tiles = tiles_m * tiles_n;
   const int grid = tiles < g_num_cus ? tiles : g_num_cus;
   GROVE_CHECK((long)tiles * 8 * tiles_n < (1L << 31), GROVE_E_SHAPE, "gemm: %d x %d tiles overflow the pipelined kernel's tile map", tiles_m, tiles_n);
+  g_gemm_last_epilogue = ACT;
   pp_tile_map tm;
   tm.magic_band = (unsigned)((1ull << 32) / (unsigned)(8 * tiles_n)) + 1u;
   tm.full_bands = tiles_m / 8;
@@ -1051,6 +1053,7 @@ extern "C" int grove_gemm_set_staging(int use_lds_dma) {
 }
 
 extern "C" int grove_gemm_last_variant(void) { return g_gemm_last_variant; }
+extern "C" int grove_gemm_last_epilogue(void) { return g_gemm_last_epilogue; }
 
 extern "C" int grove_gemm_bf16(const grove_gemm_params* pp, void* stream) {
   GROVE_CHECK(pp != nullptr, GROVE_E_SHAPE, "gemm: null params");

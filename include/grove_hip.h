@@ -114,6 +114,9 @@ enum grove_gemm_variant {
   GROVE_GEMM_PP192_GATHER = 7  /* gemm_nt_pp_kernel<192, true> */
 };
 int grove_gemm_last_variant(void);
+/* The epilogue compiled into the pipelined kernel of the last call — its third template argument, as profilers print it:
+ * -1 = plain (act NONE, alpha 1, no scale), else the enum grove_act value. Meaningless after a non-pipelined launch. */
+int grove_gemm_last_epilogue(void);
 /* A/B staging variant: 1 = LDS-DMA (global_load_lds, default), 0 = register staged */
 int grove_gemm_set_staging(int use_lds_dma);
 /* macro-tile N: 0 = auto (by wave quantisation), 64 or 128 = forced (for A/B measurements) */
