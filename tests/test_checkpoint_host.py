@@ -1,0 +1,84 @@
+"""Reference-checkpoint import / export (grove_amd/checkpoint.py): host logic on the CPU.
+
+The position-table resizing is checked against outputs of the reference's own functions (tests/golden/posembed_resize_seed5.npz,
+made by oracle/refgen/make_posembed_golden.py); the readers against files written here in each format the reference's
+scripts produce (flat .bin, DeepSpeed-style {"module": ...}, LoRA-prefixed keys, HF sharded directory, safetensors)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from grove_amd import checkpoint as ck
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "posembed_resize_seed5.npz")
+
+
+@pytest.mark.parametrize("tag", ["sam", "small", "up"])
+def test_position_table_resize_matches_reference(tag):
+    z = np.load(GOLD)
+    gs, target, patch, c, hd = (int(v) for v in z[tag + "_cfg"])
+    out = ck.resize_abs_pos_embedding(torch.from_numpy(z[tag + "_pos_in"]), target, patch)
+    assert tuple(out.shape) == (1, target // patch, target // patch, c)
+    assert torch.equal(out, torch.from_numpy(z[tag + "_pos_out"]))  # the same torch op sequence: bit-exact
+    oh, ow = ck.resize_rel_pos_embedding(torch.from_numpy(z[tag + "_relh_in"]), torch.from_numpy(z[tag + "_relw_in"]), target, patch)
+    assert torch.equal(oh, torch.from_numpy(z[tag + "_relh_out"])) and torch.equal(ow, torch.from_numpy(z[tag + "_relw_out"]))
+
+
+def _toy_sd(seed=0):
+    g = torch.Generator().manual_seed(seed)
+    p = "model.grounding_encoder.image_encoder."
+    return {"model.layers.0.mlp.up_proj.weight": torch.randn(6, 4, generator=g), "lm_head.weight": torch.randn(5, 4, generator=g),
+            p + "pos_embed": torch.randn(1, 8, 8, 4, generator=g), p + "blocks.1.attn.rel_pos_h": torch.randn(15, 2, generator=g),
+            p + "blocks.1.attn.rel_pos_w": torch.randn(15, 2, generator=g), p + "blocks.0.attn.rel_pos_h": torch.randn(5, 2, generator=g)}
+
+
+def _same(a, b):
+    assert set(a) == set(b)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+
+
+def test_read_flat_bin_deepspeed_and_lora_prefix(tmp_path):
+    sd = _toy_sd()
+    torch.save(sd, tmp_path / "pytorch_model.bin")
+    _same(ck.read_state_dict(str(tmp_path / "pytorch_model.bin")), sd)
+    torch.save({"module": {"module." + k: v for k, v in sd.items()}, "global_step": 3}, tmp_path / "mp_rank_00_model_states.pt")
+    _same(ck.read_state_dict(str(tmp_path / "mp_rank_00_model_states.pt")), sd)
+    torch.save({"base_model.model." + k: v for k, v in sd.items()}, tmp_path / "lora.bin")  # infer_iground.py:530-535
+    _same(ck.read_state_dict(str(tmp_path / "lora.bin")), sd)
+    with pytest.raises(ValueError):
+        torch.save({"a": 1}, tmp_path / "bad.bin")
+        ck.read_state_dict(str(tmp_path / "bad.bin"))
+
+
+def test_read_hf_sharded_directory_and_safetensors(tmp_path):
+    from safetensors.torch import save_file
+    sd = _toy_sd(1)
+    keys = sorted(sd)
+    d1 = tmp_path / "bin_shards"
+    d1.mkdir()
+    shards = {"pytorch_model-00001-of-00002.bin": keys[:3], "pytorch_model-00002-of-00002.bin": keys[3:]}
+    for f, ks in shards.items():
+        torch.save({k: sd[k] for k in ks}, d1 / f)
+    json.dump({"metadata": {}, "weight_map": {k: f for f, ks in shards.items() for k in ks}}, open(d1 / "pytorch_model.bin.index.json", "w"))
+    _same(ck.read_state_dict(str(d1)), sd)
+    d2 = tmp_path / "st"
+    d2.mkdir()
+    save_file({k: v.contiguous() for k, v in sd.items()}, str(d2 / "model.safetensors"))
+    _same(ck.read_state_dict(str(d2)), sd)
+    with pytest.raises(FileNotFoundError):
+        (tmp_path / "empty").mkdir()
+        ck.read_state_dict(str(tmp_path / "empty"))
+
+
+def test_interpolate_only_what_does_not_fit():
+    sd = _toy_sd(2)
+    before = {k: v.clone() for k, v in sd.items()}
+    p = "model.grounding_encoder.image_encoder."
+    changed = ck.interpolate_positional_embeddings(sd, img_size=64, patch_size=16, global_blocks=(1,))  # grid 8 -> 4
+    assert set(changed) == {p + "pos_embed", p + "blocks.1.attn.rel_pos_h", p + "blocks.1.attn.rel_pos_w"}
+    assert tuple(sd[p + "pos_embed"].shape) == (1, 4, 4, 4) and tuple(sd[p + "blocks.1.attn.rel_pos_h"].shape) == (7, 2)
+    assert torch.equal(sd[p + "blocks.0.attn.rel_pos_h"], before[p + "blocks.0.attn.rel_pos_h"])  # a window block: untouched
+    assert ck.interpolate_positional_embeddings(sd, img_size=64, patch_size=16, global_blocks=(1,)) == []  # idempotent

@@ -109,3 +109,53 @@ def test_rccl_bucketed_allreduce_single_rank(dev):
         assert t.tolist() == [1.0, 2.0]
     finally:
         dist.destroy_process_group()
+
+
+def test_consolidated_checkpoint_export_import(dev, tmp_path):
+    """the trained model leaves as the flat fp32 `pytorch_model.bin` the reference's inference scripts read
+    (zero_to_fp32's output: reference key names, canonical Conv3d layout, trainable weights from the fp32 master copy) and
+    comes back through load_grove_weights — including a pre-trained-style SAM whose position tables are at twice the grid."""
+    from grove_amd import checkpoint as ck
+    from grove_amd.model.GROVE import trainable_names
+    from grove_amd.synthetic import param_shapes, synthetic_state_dict
+    T, args, d, engine = _engine(dev)
+    batch = _batch(d, dev, 3)
+    T.train(itertools.repeat(batch), engine, 0, args, log=lambda *_: None)
+    model = engine.module
+    path = str(tmp_path / "pytorch_model.bin")
+    sd = ck.save_grove_weights(model, path, engine=engine)
+    shapes = param_shapes(d)
+    assert set(sd) == set(shapes) and all(tuple(sd[k].shape) == tuple(shapes[k]) and sd[k].dtype == torch.float32 for k in sd)
+    # trainable tensors are the master copy (more bits than the bf16 working weights), and round to exactly those weights
+    name = next(n for n in trainable_names(d) if n.endswith("conv3d.weight"))
+    assert torch.equal(sd[name].to(bf), model.state_dict()[name].cpu())
+    assert (sd[name] != sd[name].to(bf).float()).any()
+    frozen = "model.layers.0.mlp.up_proj.weight"
+    assert torch.equal(sd[frozen], model.state_dict()[frozen].float().cpu())
+    # import into a model that starts from different weights: same validation loss as the exporter
+    want = T.validate_model_performance(itertools.repeat(batch), engine, 1, args)
+    other = T.initialize_model(args, d, state_dict={k: v * 0.5 for k, v in synthetic_state_dict(d).items()}, device=dev)
+    rep = ck.load_grove_weights(other, path)
+    assert rep.missing_keys == [] and rep.unexpected_keys == [] and rep.resized == []
+    got = T.validate_model_performance(itertools.repeat(batch), T.GroveEngine(other, args, total_steps=1000), 1, args)
+    assert abs(got["loss"] - want["loss"]) < 1e-3 * max(1.0, abs(want["loss"]))
+    # a checkpoint saved for twice the SAM grid is resized on the way in (train.py:561-576), wrapper prefixes are dropped
+    p = "model.grounding_encoder.image_encoder."
+    big = dict(sd)
+    g = d.sam_grid
+    big[p + "pos_embed"] = torch.randn(1, 2 * g, 2 * g, d.sam_dim)
+    for i in d.sam_global:
+        for ax in ("h", "w"):
+            k = p + f"blocks.{i}.attn.rel_pos_{ax}"
+            big[k] = torch.randn(4 * g - 1, sd[k].shape[1])
+    torch.save({"base_model.model." + k: v for k, v in big.items()}, str(tmp_path / "pretrained.bin"))
+    rep = ck.load_grove_weights(other, str(tmp_path / "pretrained.bin"))
+    assert len(rep.resized) == 1 + 2 * len(d.sam_global) and rep.missing_keys == []
+    ref = ck.resize_abs_pos_embedding(big[p + "pos_embed"], d.sam_image, d.sam_patch)
+    assert torch.equal(other.state_dict()[p + "pos_embed"].cpu(), ref.to(bf))
+    # a tensor of the wrong shape is an error, not a silent skip
+    bad = dict(sd)
+    bad[frozen] = torch.zeros(3, 3)
+    torch.save(bad, str(tmp_path / "bad.bin"))
+    with pytest.raises(RuntimeError):
+        ck.load_grove_weights(other, str(tmp_path / "bad.bin"))
