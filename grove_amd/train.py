@@ -82,26 +82,42 @@ class WarmupDecayLR:
         return [self.last]
 
 
-def allreduce_buckets(flat, bucket_elems, comm_stream=None):
+def allreduce_buckets(flat, bucket_elems, comm_stream=None, comm_buf=None):
     """SUM all-reduce of one flat gradient buffer in buckets of `bucket_elems` elements. On GPU the
     collectives are issued on `comm_stream` (RCCL over xGMI) after the producing stream's work, and the
-    compute stream waits for them; on CPU (gloo, used by the tests) the same bucketing runs inline."""
+    compute stream waits for them; on CPU (gloo, used by the tests) the same bucketing runs inline.
+    `comm_buf` (bf16, same length): exchange in bf16 — DeepSpeed's `communication_data_type` default when bf16 is enabled
+    (the reference's config sets none, train.py:466-478), half the xGMI bytes of the fp32 buffer: the gradients are rounded
+    into comm_buf, summed there, and widened back into `flat`."""
     n = flat.numel()
+    wire = flat
+    if comm_buf is not None:
+        assert comm_buf.numel() == n and comm_buf.dtype == torch.bfloat16
+        if flat.is_cuda:
+            ops.to_bf16(flat, out=comm_buf)
+        else:
+            comm_buf.copy_(flat)  # host tensors exist only in the gloo tests
+        wire = comm_buf
     if comm_stream is None:
-        handles = [dist.all_reduce(flat[s0:s0 + bucket_elems], op=dist.ReduceOp.SUM, async_op=True)
+        handles = [dist.all_reduce(wire[s0:s0 + bucket_elems], op=dist.ReduceOp.SUM, async_op=True)
                    for s0 in range(0, n, bucket_elems)]
         for h in handles:
             h.wait()
-        return
-    ev = torch.cuda.Event()
-    ev.record()
-    with torch.cuda.stream(comm_stream):
-        comm_stream.wait_event(ev)
-        handles = [dist.all_reduce(flat[s0:s0 + bucket_elems], op=dist.ReduceOp.SUM, async_op=True)
-                   for s0 in range(0, n, bucket_elems)]
-        for h in handles:
-            h.wait()
-    torch.cuda.current_stream().wait_stream(comm_stream)
+    else:
+        ev = torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(comm_stream):
+            comm_stream.wait_event(ev)
+            handles = [dist.all_reduce(wire[s0:s0 + bucket_elems], op=dist.ReduceOp.SUM, async_op=True)
+                       for s0 in range(0, n, bucket_elems)]
+            for h in handles:
+                h.wait()
+        torch.cuda.current_stream().wait_stream(comm_stream)
+    if comm_buf is not None:
+        if flat.is_cuda:
+            ops.to_f32(comm_buf, out=flat)
+        else:
+            flat.copy_(comm_buf)
 
 
 def shard_clips(n_clips, rank, world):
@@ -114,7 +130,7 @@ def shard_clips(n_clips, rank, world):
 class GroveEngine:
     """Replica-per-GPU data-parallel engine with the DeepSpeed-engine surface train.py relies on."""
 
-    def __init__(self, model: GROVEForCausalLM, args, total_steps=None, bucket_bytes=512 << 20):
+    def __init__(self, model: GROVEForCausalLM, args, total_steps=None, bucket_bytes=512 << 20, comm_dtype=torch.bfloat16):
         self.module = model
         self.args = args
         self.dev = model.dev
@@ -140,7 +156,9 @@ class GroveEngine:
         self.global_step = 0
         self.micro = 0
         self.clip = 1.0  # "gradient_clipping": 1.0 (train.py:475)
-        self.bucket_elems = bucket_bytes // 4
+        # gradient exchange dtype: bf16 like DeepSpeed under bf16 (engine.communication_data_type), or torch.float32
+        self.comm_buf = torch.empty(g.numel(), dtype=torch.bfloat16, device=g.device) if self.world > 1 and comm_dtype == torch.bfloat16 else None
+        self.bucket_elems = bucket_bytes // (2 if self.comm_buf is not None else 4)
         self.comm_stream = torch.cuda.Stream(device=self.dev) if self.world > 1 else None
         self.training = True
 
@@ -163,7 +181,7 @@ class GroveEngine:
         self.micro += 1
 
     def _allreduce(self):
-        allreduce_buckets(self.module._flat_grad, self.bucket_elems, self.comm_stream)
+        allreduce_buckets(self.module._flat_grad, self.bucket_elems, self.comm_stream, self.comm_buf)
 
     def step(self):
         a = self.args

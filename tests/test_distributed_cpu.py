@@ -21,6 +21,13 @@ def _worker(rank, world, port, out):
     g = torch.arange(1000, dtype=torch.float32) * (rank + 1)
     allreduce_buckets(g, 96)  # 11 buckets, last one ragged
     ok = torch.equal(g, torch.arange(1000, dtype=torch.float32) * 3)
+    # bf16 wire format (DeepSpeed's default communication dtype under bf16): rounded, summed, widened back in place
+    gen = torch.Generator().manual_seed(7)
+    base = torch.randn(1000, generator=gen)
+    h = base * (rank + 1)
+    allreduce_buckets(h, 96, comm_buf=torch.empty(1000, dtype=torch.bfloat16))
+    want = (base.to(torch.bfloat16) + (base * 2).to(torch.bfloat16)).float()  # what a bf16 sum of the two rounded ranks holds
+    ok = ok and torch.equal(h, want) and (h - base * 3).abs().max().item() <= 3 * base.abs().max().item() * 2 ** -7
     mine = shard_clips(7, rank, world)
     gathered = [None] * world
     dist.all_gather_object(gathered, mine)

@@ -104,6 +104,12 @@ def test_rccl_bucketed_allreduce_single_rank(dev):
         g.add_(1.0)  # ... and compute that must wait for the collective
         torch.cuda.synchronize()
         assert torch.equal(g, ref * 2 + 1)
+        # the bf16 wire format (the engine's default for N > 1): rounded into the comm buffer, reduced there by RCCL, widened back
+        h = torch.randn(1 << 20, device=dev)
+        want = h.to(bf).float()
+        allreduce_buckets(h, 300_000, torch.cuda.Stream(device=dev), torch.empty(1 << 20, dtype=bf, device=dev))
+        torch.cuda.synchronize()
+        assert torch.equal(h, want)
         t = torch.tensor([1.0, 2.0], device=dev)
         dist.all_reduce(t)
         assert t.tolist() == [1.0, 2.0]
