@@ -67,6 +67,7 @@ class GROVEForCausalLM(torch.nn.Module):
         self._sd = {}
         self._grad = {}
         self._flat_grad = None
+        self._plan_stream = None
         self._alloc_params(state_dict)
         self._build_engines()
         self._ctx = None
@@ -265,6 +266,62 @@ class GROVEForCausalLM(torch.nn.Module):
                 new_lists.append([lst[b][g * 8:(g + 1) * 8] for b in range(B) for g in range(G)])
         return gi, si, rep(input_ids), rep(labels), rep(attention_masks), new_lists, 8, G
 
+    def _host_plan(self, ids, labs, amask, boxes_l, vis_l, B, Tseq, inference):
+        """Host-side bookkeeping of one forward, from the inputs alone (runs under a side stream, see model_forward):
+        the splice plan (llava_with_region_arch.py:84-440), the labelled rows of the shifted CE (llava_llama.py:111-125), the
+        [DET] rows and the (sequence, frame, det) instance order (GROVE.py:200-205, 248-268), and the ground truth per instance
+        (GROVE.py:339-360). Everything the device needs is uploaded here; `device_tensors` lists those uploads."""
+        hp = SimpleNamespace()
+        feat_row = list(range(B))  # image_features[cur_image_idx] (llava_with_region_arch.py:156): row b
+        hp.plan = plan = self._splice_plan(ids, None if inference else labs, None if inference else amask, feat_row)
+        S = plan.S
+        det_rows, hp.counts = self._det_rows(ids.cpu(), S)
+        hp.det_rows = det_rows.to(self.dev)
+        dev_t = [hp.det_rows] + [t for t in (plan.tok, plan.kv_len, plan.vis_dst, plan.vis_src) if t is not None]
+        # instance order = (sequence b, frame t, det k)  (repeat_interleave + boolean gather, GROVE.py:254-257)
+        inst_det, inst_frame, base = [], [], 0
+        for b in range(B):
+            for t in range(Tseq):
+                inst_det += list(range(base, base + hp.counts[b]))
+                inst_frame += [b * Tseq + t] * hp.counts[b]
+            base += hp.counts[b]
+        hp.N = N = len(inst_det)
+        hp.inst_det_t = hp.inst_frame_t = None
+        if int(det_rows.numel()):
+            hp.inst_det_t = torch.tensor(inst_det, dtype=torch.int32).to(self.dev)
+            hp.inst_frame_t = torch.tensor(inst_frame, dtype=torch.int32).to(self.dev)
+            dev_t += [hp.inst_det_t, hp.inst_frame_t]
+        if not inference:
+            lab = plan.labels
+            valid = (lab[:, 1:] != IGNORE_INDEX)
+            bi, ti = valid.nonzero(as_tuple=True)
+            hp.rows = (bi * S + ti).to(torch.int32).to(self.dev)
+            hp.tgt = lab[bi, ti + 1].to(torch.int32).to(self.dev)
+            # the per-frame GT tensors come to the host in TWO transfers
+            v_all = torch.cat([vis_l[b][t].reshape(-1).float() for b in range(B) for t in range(Tseq)]).cpu()
+            gb_rows = [boxes_l[b][t].reshape(-1, 4).shape[0] for b in range(B) for t in range(Tseq)]
+            gb_all = torch.cat([boxes_l[b][t].reshape(-1, 4).float() for b in range(B) for t in range(Tseq)]).cpu()
+            gt = torch.zeros((max(N, 1), 4), dtype=torch.float32)
+            vis = torch.zeros((max(N, 1),), dtype=torch.float32)
+            n_gt = off = v_off = gb_off = 0
+            for b in range(B):
+                for t in range(Tseq):
+                    nv, ng = vis_l[b][t].numel(), gb_rows[b * Tseq + t]
+                    v, gb = v_all[v_off:v_off + nv], gb_all[gb_off:gb_off + ng]
+                    v_off, gb_off = v_off + nv, gb_off + ng
+                    assert gb.shape[0] == int(v.sum()), "Number of ground truth bboxes and objectness labels do not match"
+                    n = hp.counts[b]
+                    vis[off:off + n] = v
+                    if gb.shape[0]:
+                        gt[off:off + n][v.bool()] = gb
+                    n_gt += gb.shape[0]
+                    off += n
+            hp.n_gt = n_gt
+            hp.gt, hp.vis = gt.to(self.dev), vis.to(self.dev)
+            dev_t += [hp.rows, hp.tgt, hp.gt, hp.vis]
+        hp.device_tensors = dev_t
+        return hp
+
     def model_forward(self, global_enc_images, grounding_enc_images, bboxes_region=None, input_ids=None, labels=None,
                       attention_masks=None, offset=None, bboxes_list=None, temp_objectness_labels_list=None,
                       original_size_list=None, inference=False, **kwargs):
@@ -279,27 +336,35 @@ class GROVEForCausalLM(torch.nn.Module):
         B = ids.shape[0]
         train = (not inference) and self._train_mode
         tp = Tape(enabled=train)
-        # 1. grounding encoder (GROVE.py:162)
+        # 1. grounding encoder (GROVE.py:162): queued first, it keeps the GPU busy for the host work below
+        main = torch.cuda.current_stream()
+        if self._plan_stream is None:
+            self._plan_stream = torch.cuda.Stream(device=self.dev)
+        side = self._plan_stream
+        side.wait_stream(main)  # the inputs are complete where the main stream stands now (before this step's kernels)
         emb_rows, sam_ctx = self.sam.forward(simg.to(bf), save=train)
         F = emb_rows.shape[0]
         emb_rows2 = emb_rows.view(F * d.sam_grid ** 2, -1)
+        # 0. everything the host derives from the INPUTS — splice plan, labelled rows, [DET] rows / instances, ground truth —
+        # on a side stream while the encoder runs. Each read-back (.cpu()) and each upload from pageable memory is a stream
+        # sync; on the main stream, in the middle of the step, they left the GPU idle 6-9 ms per step (rocprofv3 kernel trace,
+        # tools/step_gaps.py); the reference does 2 * B * T of them per step for the ground truth alone (GROVE.py:352-353).
+        with torch.cuda.stream(side):
+            hp = self._host_plan(ids, labs, amask, boxes_l, vis_l, B, Tseq, inference)
+        main.wait_stream(side)
+        for t_ in hp.device_tensors:
+            t_.record_stream(main)
+        plan, S, det_rows, counts = hp.plan, hp.plan.S, hp.det_rows, hp.counts
         # 2-3. global encoder + projector, splice, LLaMA (GROVE.py:170-176; llava_llama.py:88-109)
         feats, _ = self.encode_images(gimg, tape=tp)
-        feat_row = list(range(B))  # image_features[cur_image_idx] (llava_with_region_arch.py:156): row b
-        plan = self._splice_plan(ids, None if inference else labs, None if inference else amask, feat_row)
         x = self._embed(plan, feats.data)
         hidden, llama_ctx = self.llama.forward(x, plan.B, plan.S, kv_len=plan.kv_len, save=train)
-        S = plan.S
         H = d.hidden
         out = {}
         ce_state = None
         if not inference:
             # 4. lm_head + shifted CE on the labelled rows only (llava_llama.py:111-125)
-            lab = plan.labels
-            valid = (lab[:, 1:] != IGNORE_INDEX)
-            bi, ti = valid.nonzero(as_tuple=True)
-            rows = (bi * S + ti).to(torch.int32).to(self.dev)
-            tgt = lab[bi, ti + 1].to(torch.int32).to(self.dev)
+            rows, tgt = hp.rows, hp.tgt
             R = int(rows.numel())
             hrows = torch.empty((max(R, 1), H), dtype=bf, device=self.dev)
             ops.copy_rows(hidden, hrows, R, H, idx_src=rows)
@@ -316,8 +381,6 @@ class GROVEForCausalLM(torch.nn.Module):
             ce_loss = loss_sum[0] * (self.ce_loss_weight / max(R, 1))
             ce_state = (hv, dlogits, rows, R)
         # 5. [DET] rows -> text_hidden_fcs -> per-frame instances (GROVE.py:248-268)
-        det_rows, counts = self._det_rows(ids.cpu(), S)
-        det_rows = det_rows.to(self.dev)
         n_det = int(det_rows.numel())
         pred_boxes, pred_logits = [], []
         if n_det == 0:
@@ -331,17 +394,7 @@ class GROVEForCausalLM(torch.nn.Module):
             dv = Var(drows)
             h1 = tp.linear(dv, self.P("model.text_hidden_fcs.0.0.weight"), self.P("model.text_hidden_fcs.0.0.bias"), act=ops.ACT_RELU)
             te = tp.linear(h1, self.P("model.text_hidden_fcs.0.2.weight"), self.P("model.text_hidden_fcs.0.2.bias"))
-            # instance order = (sequence b, frame t, det k)  (repeat_interleave + boolean gather, GROVE.py:254-257)
-            inst_det, inst_frame = [], []
-            base = 0
-            for b in range(B):
-                for t in range(Tseq):
-                    inst_det += list(range(base, base + counts[b]))
-                    inst_frame += [b * Tseq + t] * counts[b]
-                base += counts[b]
-            inst_det_t = torch.tensor(inst_det, dtype=torch.int32, device=self.dev)
-            inst_frame_t = torch.tensor(inst_frame, dtype=torch.int32, device=self.dev)
-            N = len(inst_det)
+            inst_det_t, inst_frame_t, N = hp.inst_det_t, hp.inst_frame_t, hp.N
             text = torch.empty((N, d.out_dim), dtype=bf, device=self.dev)
             ops.copy_rows(te.data, text, N, d.out_dim, idx_src=inst_det_t)
             text_var = Var(text)
@@ -377,26 +430,12 @@ class GROVEForCausalLM(torch.nn.Module):
             return {"pred_bboxes": pred_boxes, "logits_temp_objectness": pred_logits if self.config.use_temp_objectness else None,
                     "flat_boxes": flat_box, "flat_logits": flat_obj, "hidden": hidden.view(B, S, H),
                     "image_embeddings": emb_rows}
-        # 7. losses (GROVE.py:339-381) in fp32 on device
-        gt = torch.zeros((max(N, 1), 4), dtype=torch.float32)
-        vis = torch.zeros((max(N, 1),), dtype=torch.float32)
-        n_gt = 0
-        off = 0
-        for b in range(B):
-            for t in range(Tseq):
-                v = vis_l[b][t].float().cpu()
-                gb = boxes_l[b][t].float().cpu()
-                assert gb.shape[0] == int(v.sum()), "Number of ground truth bboxes and objectness labels do not match"
-                n = counts[b]
-                vis[off:off + n] = v
-                if gb.shape[0]:
-                    gt[off:off + n][v.bool()] = gb
-                n_gt += gb.shape[0]
-                off += n
+        # 7. losses (GROVE.py:339-381) in fp32 on device (ground truth laid out per instance by _host_plan)
+        n_gt = hp.n_gt
         wb = self.giou_loss_weight / (n_gt + 1e-8)
         wo = self.temp_objectness_loss_weight / (N + 1e-8)
         if N > 0:
-            sums, dbox, dobj = ops.box_losses(box, obj if self.config.use_temp_objectness else None, gt.to(self.dev), vis.to(self.dev),
+            sums, dbox, dobj = ops.box_losses(box, obj if self.config.use_temp_objectness else None, hp.gt, hp.vis,
                                               wb, wo, want_grad=train)
         else:
             sums, dbox, dobj = torch.zeros(3, device=self.dev), None, None
