@@ -7,7 +7,9 @@ fine-tune, T=16, per-GPU batch=2, bf16"), config[3] for N>1.
 
 One JSON line on rank 0. `value` = total frames/s over all ranks with inputs resident in HBM; `roofline`
 prices the dominant kernel (the persistent pipelined bf16 MFMA GEMM) from HIP-event timings of its own launches in one
-extra, untimed, instrumented step (the other GEMM kernels are summarised beside it); `cpu_baseline` times the CPU oracle (a port, oracle/grove_oracle.py) on a bounded
+extra, untimed, instrumented step with the two towers serialised (in the timed steps the SAM tower runs on a second stream beside
+CLIP -> LLaMA, so two kernels share the CUs and a launch's wall time is not the kernel's own; `--serial_towers` runs everything that
+way and is the command the committed rocprofv3 summaries come from; the other GEMM kernels are summarised beside it); `cpu_baseline` times the CPU oracle (a port, oracle/grove_oracle.py) on a bounded
 sample of the same workload on the host cores. Synthetic data and random-init weights of the real
 architecture (no checkpoints offline).
 """
@@ -73,6 +75,8 @@ def instrumented_gemm_pass(engine, batch):
                      kernel_name()))
         return r
     ops.gemm_raw = timed
+    overlap = engine.module.tower_overlap
+    engine.module.tower_overlap = False  # a kernel is priced on its own: with the SAM tower on a second stream two kernels share the CUs
     try:
         out = engine(**batch)
         engine.backward(out["loss"])
@@ -80,6 +84,7 @@ def instrumented_gemm_pass(engine, batch):
         torch.cuda.synchronize()
     finally:
         ops.gemm_raw = orig
+        engine.module.tower_overlap = overlap
     per_kernel = {}
     for e0, e1, f, key, var in recs:
         n, fl, t = per_kernel.get(var, (0, 0.0, 0.0))
@@ -228,6 +233,8 @@ def main():
     ap.add_argument("--text_len", type=int, default=128)
     ap.add_argument("--dims", default="full", choices=["full", "tiny"])
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--serial_towers", action="store_true",
+                    help="run the SAM tower on the main stream as well (no kernel overlap): how profiles/*_kernel_stats are collected")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line, the JSON: everything else that writes to fd 1 (RCCL prints its version banner there, from
@@ -249,6 +256,7 @@ def main():
     dims = FULL if args.dims == "full" else TINY
 
     model, engine = build(dims, dev, args)
+    model.tower_overlap = not args.serial_towers
     batch = make_batch(dims, dev, args, rank)
 
     def step():
@@ -297,7 +305,8 @@ def main():
                                    f"({args.batch * args.frames // 8} independent 8-frame windows), LLaVA-1.5-7B + CLIP ViT-L/14-336 + "
                                    f"SAM ViT-H@512 + box decoder, text L={args.text_len}, fwd+bwd+AdamW, shipped freeze policy",
                        "dims": args.dims, "global_batch_clips": world * args.batch, "frames_per_clip": args.frames,
-                       "parallelism": f"dp{world}", "frames_per_sec_per_gpu": round(frames / dt / world, 3), "last_loss": round(loss, 4)},
+                       "parallelism": f"dp{world}", "frames_per_sec_per_gpu": round(frames / dt / world, 3), "last_loss": round(loss, 4),
+                       "towers": "serial" if args.serial_towers else "SAM tower on a second stream beside CLIP->LLaMA (roofline: one extra step with the towers serialised)"},
             "roofline": {"bound": "mfma", "achieved": round(flops / secs / 1e12, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(flops / secs / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                          "kernel": dom + " (grove_gemm_bf16)", "launches_per_step": n_launch,

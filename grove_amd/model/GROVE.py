@@ -68,6 +68,8 @@ class GROVEForCausalLM(torch.nn.Module):
         self._grad = {}
         self._flat_grad = None
         self._plan_stream = None
+        self._sam_stream = None
+        self.tower_overlap = True  # SAM tower on its own stream beside CLIP -> LLaMA (forward and backward)
         self._alloc_params(state_dict)
         self._build_engines()
         self._ctx = None
@@ -342,7 +344,17 @@ class GROVEForCausalLM(torch.nn.Module):
             self._plan_stream = torch.cuda.Stream(device=self.dev)
         side = self._plan_stream
         side.wait_stream(main)  # the inputs are complete where the main stream stands now (before this step's kernels)
-        emb_rows, sam_ctx = self.sam.forward(simg.to(bf), save=train)
+        # The grounding tower shares nothing with the CLIP -> LLaMA tower until the decoder, so it runs on its own stream: the
+        # two kernel sequences interleave on the CUs and fill each other's partial rounds and tails (same-box A/B: -5 ms per
+        # step for the forward alone). `tower_overlap = False` serialises them (clean per-kernel timings).
+        if self.tower_overlap:
+            if self._sam_stream is None:
+                self._sam_stream = torch.cuda.Stream(device=self.dev)
+            self._sam_stream.wait_stream(main)
+            with torch.cuda.stream(self._sam_stream):
+                emb_rows, sam_ctx = self.sam.forward(simg.to(bf), save=train)
+        else:
+            emb_rows, sam_ctx = self.sam.forward(simg.to(bf), save=train)
         F = emb_rows.shape[0]
         emb_rows2 = emb_rows.view(F * d.sam_grid ** 2, -1)
         # 0. everything the host derives from the INPUTS — splice plan, labelled rows, [DET] rows / instances, ground truth —
@@ -359,6 +371,9 @@ class GROVEForCausalLM(torch.nn.Module):
         feats, _ = self.encode_images(gimg, tape=tp)
         x = self._embed(plan, feats.data)
         hidden, llama_ctx = self.llama.forward(x, plan.B, plan.S, kv_len=plan.kv_len, save=train)
+        if self.tower_overlap:
+            main.wait_stream(self._sam_stream)
+            emb_rows.record_stream(main)  # allocated under the SAM stream, read by the decoder on this one
         H = d.hidden
         out = {}
         ce_state = None
@@ -475,6 +490,14 @@ class GROVEForCausalLM(torch.nn.Module):
             dte = torch.zeros((n_det, d.out_dim), dtype=torch.float32, device=self.dev)
             ops.scatter_add_f32(c.dec_state["text"].grad, dte, inst_det_t, c.N, d.out_dim)
             te.grad = ops.to_bf16(dte)
+        # SAM (adapters' weight gradients, dgrad through blocks 31..8): needs d_emb only, so it runs on the SAM stream beside
+        # the lm_head / LLaMA / projector backward below (disjoint slices of the flat gradient buffer)
+        main = torch.cuda.current_stream()
+        if self.tower_overlap and self._sam_stream is not None:
+            self._sam_stream.wait_stream(main)
+            with torch.cuda.stream(self._sam_stream):
+                d_emb.record_stream(self._sam_stream)
+                self.sam.backward(c.sam_ctx, ops.to_bf16(d_emb))
         # lm_head: wgrad + dgrad on the labelled rows
         hv, dlogits, rows, R = c.ce_state
         if R > 0:
@@ -510,8 +533,10 @@ class GROVEForCausalLM(torch.nn.Module):
             c.feats.grad = dfe
         ops.scatter_add_f32(dx, self._grad["model.embed_tokens.weight"], plan.tok, plan.B * plan.S, H)
         c.tp.backward()  # mm_projector
-        # SAM adapters
-        self.sam.backward(c.sam_ctx, ops.to_bf16(d_emb))
+        if self.tower_overlap and self._sam_stream is not None:
+            main.wait_stream(self._sam_stream)
+        else:
+            self.sam.backward(c.sam_ctx, ops.to_bf16(d_emb))
         self._ctx = None
 
     # ------------------------------------------------------------------ generation (GROVE.py:412-451)
