@@ -747,8 +747,8 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
     const int band = (int)__umulhi((unsigned)L, tm.magic_band);
     const int in_band = L - band * per_band;
     int r, c;
-    if (band == tm.full_bands) {  // the short last band: tm.tail rows
-      c = (int)__umulhi((unsigned)in_band, tm.magic_tail);
+    if (band == tm.full_bands) {  // the short last band: tm.tail rows (tail 1: the reciprocal 2^32 does not fit — no division needed)
+      c = tm.tail == 1 ? in_band : (int)__umulhi((unsigned)in_band, tm.magic_tail);
       r = in_band - c * tm.tail;
     } else {
       c = in_band >> 3;
@@ -991,7 +991,7 @@ int launch_pp_act(const grove_gemm_params& p, hipStream_t s) {
   tm.magic_band = (unsigned)((1ull << 32) / (unsigned)(8 * tiles_n)) + 1u;
   tm.full_bands = tiles_m / 8;
   tm.tail = tiles_m % 8;
-  tm.magic_tail = tm.tail ? (unsigned)((1ull << 32) / (unsigned)tm.tail) + 1u : 0u;
+  tm.magic_tail = tm.tail > 1 ? (unsigned)((1ull << 32) / (unsigned)tm.tail) + 1u : 0u;  // tail 1 is special-cased in the kernel
   hipLaunchKernelGGL((gemm_nt_pp_kernel<BM, GATHER, ACT>), dim3(grid, 1, 1), dim3(P_NT), lds, s, p, tiles_m, tiles_n, tm);
   GROVE_LAUNCH_CHECK();
   return GROVE_OK;

@@ -113,6 +113,31 @@ def test_gemm_fused_activation_backward(dev, act, M, N, K):
     close(got, ref, 8e-3, "dgrad * act'")
 
 
+@pytest.mark.parametrize("tile_m", [256, 193])
+def test_pipelined_tile_map_covers_every_tile(dev, tile_m):
+    """The persistent kernel maps tile index -> origin with multiply-high reciprocals (bands of 8 tile rows, a shorter last
+    band): every count of tile rows modulo 8 — including a last band of ONE row, whose reciprocal 2^32 does not fit in 32 bits —
+    must write every output tile exactly as the simple kernel does. The output starts as NaN so a skipped tile shows."""
+    from grove_amd import _lib, ops
+    L = _lib.lib()
+    bm = 256 if tile_m == 256 else 192
+    K, N = 128, 776  # 4 column tiles, the last one partial
+    b = rnd(N, K, seed=12, scale=0.1).to(dev)
+    try:
+        for tiles_m in list(range(1, 19)) + [33, 73]:
+            M = bm * (tiles_m - 1) + 8
+            a = rnd(M, K, seed=11).to(dev)
+            L.grove_gemm_set_tile_m(128)
+            ref = ops.linear(a, b)
+            L.grove_gemm_set_tile_m(tile_m)
+            out = torch.full((M, N), float("nan"), dtype=bf16, device=dev)
+            ops.linear(a, b, out=out)
+            assert L.grove_gemm_last_variant() in (4, 5), "the pipelined kernel must have run"
+            assert torch.equal(out, ref), f"{tiles_m} tile rows (mod 8 = {tiles_m % 8})"
+    finally:
+        L.grove_gemm_set_tile_m(0)
+
+
 def test_gemm_accumulate_and_alpha(dev):
     from grove_amd import ops
     M, N, K = 96, 160, 64
