@@ -138,6 +138,35 @@ def test_pipelined_tile_map_covers_every_tile(dev, tile_m):
         L.grove_gemm_set_tile_m(0)
 
 
+STEP_SHAPES = [(32768, 5120, 1280), (32768, 1280, 5120), (32768, 3840, 1280), (32768, 1280, 1280), (18464, 4096, 1024),
+               (18464, 1024, 4096), (18464, 3072, 1024), (18464, 1024, 1024), (2812, 22016, 4096), (2812, 4096, 11008),
+               (2812, 12288, 4096), (2812, 4096, 4096), (2304, 4096, 1024)]
+
+
+@pytest.mark.parametrize("M,N,K", STEP_SHAPES)
+def test_step_shapes_dispatch_matches_simple_kernel(dev, M, N, K):
+    """The GEMM shapes of the full-size training step (profiles/*_gemm_shapes.txt), as the cost model dispatches them, bit for bit
+    against the simple two-barrier kernel — the sizes at which tile-count-dependent paths (tile map bands, persistent rounds,
+    edge tiles) actually differ from the small test shapes. Bias + residual epilogue; the output starts as NaN."""
+    from grove_amd import _lib, ops
+    L = _lib.lib()
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    a = (torch.randn(M, K, generator=g) * 0.5).to(bf16).to(dev)
+    b = (torch.randn(N, K, generator=g) * 0.05).to(bf16).to(dev)
+    bias = torch.randn(N, generator=g).to(bf16).to(dev)
+    res = torch.randn(M, N, generator=g).to(bf16).to(dev)
+    try:
+        L.grove_gemm_set_tile_m(128)
+        ref = ops.linear(a, b, bias, residual=res)
+        L.grove_gemm_set_tile_m(0)
+        out = torch.full((M, N), float("nan"), dtype=bf16, device=dev)
+        ops.linear(a, b, bias, residual=res, out=out)
+        assert L.grove_gemm_last_variant() in (4, 5), "these shapes belong to the pipelined kernels"
+        assert torch.equal(out, ref)
+    finally:
+        L.grove_gemm_set_tile_m(0)
+
+
 def test_gemm_accumulate_and_alpha(dev):
     from grove_amd import ops
     M, N, K = 96, 160, 64
