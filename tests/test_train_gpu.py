@@ -165,3 +165,24 @@ def test_consolidated_checkpoint_export_import(dev, tmp_path):
     torch.save(bad, str(tmp_path / "bad.bin"))
     with pytest.raises(RuntimeError):
         ck.load_grove_weights(other, str(tmp_path / "bad.bin"))
+
+
+def test_tower_overlap_changes_nothing_but_time(dev):
+    """The SAM tower on its own stream (forward and backward) and the host planning on a side stream are scheduling only: the
+    losses are bit-identical to the serial order and the gradients agree to accumulation-order noise (split-K atomics)."""
+    T, args, d, engine = _engine(dev)
+    model = engine.module
+    batch = _batch(d, dev, 4)
+    res = {}
+    for overlap in (True, False, True):
+        model.tower_overlap = overlap
+        model.zero_grad()
+        out = engine(**batch)
+        engine.backward(out["loss"])
+        torch.cuda.synchronize()
+        res.setdefault(overlap, []).append(({k: float(v) for k, v in out.items() if k.endswith("loss")}, model._flat_grad.clone()))
+    (l_on, g_on), (l_on2, g_on2) = res[True]
+    (l_off, g_off), = res[False]
+    assert l_on == l_off == l_on2, (l_on, l_off)
+    scale = g_off.abs().max().item()
+    assert scale > 0 and (g_on - g_off).abs().max().item() <= 1e-3 * scale and (g_on2 - g_off).abs().max().item() <= 1e-3 * scale
