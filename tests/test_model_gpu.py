@@ -260,3 +260,40 @@ def test_sliding_window_inference_driver(setup, dev):
             assert (bx / 640 - bx_o / 640).abs().mean().item() < 4e-3, f"frame {f} boxes"
             n_box += bx.shape[0]
     assert n_box > 0
+
+
+def test_full_width_towers_match_oracle(dev):
+    """The three towers at the REAL widths (LLaMA 4096 / 11008, CLIP 1024 / 4096, SAM 1280 / 5120, 16 x 80 heads, 14 x 14 windows)
+    with the depths cut to what one pass needs (1 LLaMA layer, 3 CLIP layers + their adapter, 1 windowed + 1 global SAM block, 1 adapter), against
+    the fp32 oracle: the tile counts, persistent rounds, edge tiles and padded-head maps of the full-size GEMM / attention launches
+    only occur at these widths (a tile-map bug that left some 256-row tiles of an 18464-row GEMM unwritten passed every tiny-dims test)."""
+    import dataclasses
+    from grove_amd import GROVEForCausalLM
+    from grove_amd.synthetic import FULL, synthetic_batch, synthetic_state_dict
+    from oracle import grove_oracle as O
+    d = dataclasses.replace(FULL, n_layers=1, clip_layers=3, sam_depth=2, sam_global=(1,), vocab=1024, det_token_idx=1023)
+    sd = synthetic_state_dict(d)
+    sd_r = {k: v.to(bf).float() for k, v in sd.items()}
+    model = GROVEForCausalLM(dims=d, device=dev, state_dict=sd, det_token_idx=d.det_token_idx, num_frames=8, pe_dtype=torch.float32)
+    del sd
+    batch = synthetic_batch(d, B=1, T=8, L=40, n_det=2, seed=5)
+    gi, si = batch.global_enc_images.to(bf), batch.grounding_enc_images.to(bf)
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    with torch.no_grad():
+        feats_o, hs_o = O.encode_images(sd_r, d, gi.float())
+        emb_o = O.sam_image_encoder(sd_r, d, si.float())
+    feats, outs = model(mode="encode_images", images=gi.to(dev))
+    assert rel(outs.hidden_states[-1], hs_o[-1]) < 5e-2, "clip hidden[-2]"
+    assert rel(feats, feats_o) < 5e-2, "projected features"
+    emb = model(mode="get_grounding_encoder_embs", images=si.to(dev))
+    assert rel(emb, emb_o) < 6e-2, "sam embeddings"
+    kw = to_dev(batch, dev)
+    kw["inference"] = True
+    out = model(**kw)
+    kwo = batch.as_kwargs(inference=True)
+    kwo["global_enc_images"], kwo["grounding_enc_images"] = gi.float(), si.float()
+    with torch.no_grad():
+        ref = O.model_forward(sd_r, d, **kwo)
+    assert rel(out["hidden"], ref["hidden"]) < 6e-2, "llama hidden"
+    l1 = (out["flat_boxes"].cpu() - ref["flat_boxes"]).abs().mean().item()
+    assert l1 < 4e-3, f"box L1 {l1}"
