@@ -883,7 +883,7 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
   if (STEADY || (Q) + 6 < NH) {                                                                                           \
     if ((X) == 0) advance_issue();                                                                                        \
     issue(X, T + TOFF);                                                                                                   \
-    if (WAIT) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); /* half-tiles q+3 .. q+6 stay in flight */                 \
+    if (WAIT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + RELAX) : "memory"); /* half-tiles q+3 .. q+6 (and RELAX stores) stay in flight */ \
   } else if (WAIT) {                                                                                                      \
     wait_vm_loads(2 * max(NH - 3 - (Q), 0)); /* the stream's tail: half-tiles q+3 .. NH-1 */                              \
   }                                                                                                                       \
@@ -909,8 +909,14 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();  // the stagger
 
-  auto k_tile = [&](auto steady, int T) {
+  // RELAX: the first K tile after an epilogue that left exactly RELAX stores per wave in the queue (the interior-tile epilogue
+  // without aux: 4 * MIH, every lane, no branches). vmcnt retires in issue order, so for these four phases the stores sit
+  // between the half-tiles already issued and the ones issued now: allowing 8 + RELAX operations in flight retires the same
+  // loads as vmcnt(8) does elsewhere and lets the stores drain behind the MFMAs instead of stalling the first phase (~1500
+  // clocks per output tile). From the next K tile on, vmcnt(8) covers only loads issued after the stores.
+  auto k_tile = [&](auto steady, auto relax_stores, int T) {
     constexpr bool STEADY = decltype(steady)::value;
+    constexpr int RELAX = decltype(relax_stores)::value;
     const char* st = smem + (T & 1) * P_STAGE;
     const int q = 4 * T;
     // ph1
@@ -938,11 +944,17 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
   // my output tiles in turn: their K tiles (STEADY while the stream still has a half-tile to issue six phases ahead, i.e. all
   // but the stream's last two), then the epilogue (no barriers inside) — the next tile's operands are already landing
   int T = 0;
+  bool relax = false;
   for (int c_L = wgid; c_L < tiles; c_L += G) {
     const int ns = min(max(NT - 2 - T, 0), nk);
     int k = 0;
-    for (; k < ns; ++k, ++T) k_tile(std::true_type{}, T);
-    for (; k < nk; ++k, ++T) k_tile(std::false_type{}, T);
+    using no_relax = std::integral_constant<int, 0>;
+    if (relax && ns > 0) {
+      k_tile(std::true_type{}, std::integral_constant<int, 4 * MIH>{}, T);
+      ++k, ++T;
+    }
+    for (; k < ns; ++k, ++T) k_tile(std::true_type{}, no_relax{}, T);
+    for (; k < nk; ++k, ++T) k_tile(std::false_type{}, no_relax{}, T);
     // Both groups run their epilogues in the same barrier interval: the leading group waits one barrier here (the lagging
     // group is in its last MFMA segment), the lagging group waits one after its epilogue, which restores the one-barrier lag.
     // An epilogue is bound by the issue latency of its own VALU / store stream, so two waves per SIMD take little longer
@@ -954,6 +966,7 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
     const bool interior = fast_addr && m0 + BM <= p.M && n0 + P_BN <= p.N;
     if (interior) gemm_epilogue_fast<MIH, BMH, ACT>(p, acc, mw0, nw0, fr, fq, ACT < 0 ? 1.f : scale);
     else gemm_epilogue_wide<MIH, BMH, ACT>(p, acc, mw0, nw0, fr, fq, ACT < 0 ? 1.f : scale);
+    relax = interior && !p.aux;  // exactly 4 * MIH stores per wave were issued
 #pragma unroll
     for (int i = 0; i < 2 * MIH; ++i)
 #pragma unroll
