@@ -169,7 +169,7 @@ def test_consolidated_checkpoint_export_import(dev, tmp_path):
 
 def test_tower_overlap_changes_nothing_but_time(dev):
     """The SAM tower on its own stream (forward and backward) and the host planning on a side stream are scheduling only: the
-    losses are bit-identical to the serial order and the gradients agree to accumulation-order noise (split-K atomics)."""
+    losses and the gradients agree with the serial order to accumulation-order noise (the CE sum and split-K use fp32 atomics)."""
     T, args, d, engine = _engine(dev)
     model = engine.module
     batch = _batch(d, dev, 4)
@@ -183,6 +183,7 @@ def test_tower_overlap_changes_nothing_but_time(dev):
         res.setdefault(overlap, []).append(({k: float(v) for k, v in out.items() if k.endswith("loss")}, model._flat_grad.clone()))
     (l_on, g_on), (l_on2, g_on2) = res[True]
     (l_off, g_off), = res[False]
-    assert l_on == l_off == l_on2, (l_on, l_off)
+    for k in l_off:
+        assert abs(l_on[k] - l_off[k]) <= 1e-5 * max(1.0, abs(l_off[k])) and abs(l_on2[k] - l_off[k]) <= 1e-5 * max(1.0, abs(l_off[k])), (k, l_on, l_off)
     scale = g_off.abs().max().item()
     assert scale > 0 and (g_on - g_off).abs().max().item() <= 1e-3 * scale and (g_on2 - g_off).abs().max().item() <= 1e-3 * scale
