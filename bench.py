@@ -246,9 +246,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal of the N > 1 path on a one-GPU box: GROVE_BENCH_BACKEND=gloo GROVE_BENCH_ONE_GPU=1 runs every rank on cuda:0 and
+    # moves the collectives through the host (RCCL refuses two ranks on one device); never set by the driver
+    if os.environ.get("GROVE_BENCH_ONE_GPU"):
+        local = 0
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        backend = os.environ.get("GROVE_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
