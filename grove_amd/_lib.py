@@ -146,7 +146,7 @@ SYMBOLS = [
     "grove_swiglu_fwd", "grove_swiglu_bwd", "grove_act_bwd", "grove_add_bf16", "grove_add_bcast_rows",
     "grove_copy_rows", "grove_dot_bf16", "grove_axpy_f32", "grove_scatter_add_f32", "grove_colsum_f32", "grove_cast_f32_to_bf16", "grove_cast_bf16_to_f32",
     "grove_im2col_patch", "grove_clip_pool", "grove_cross_entropy", "grove_small_attn_fwd", "grove_small_attn_bwd",
-    "grove_box_head_fwd", "grove_box_head_bwd", "grove_box_losses", "grove_adamw_step", "grove_sumsq_f32",
+    "grove_box_head_fwd", "grove_box_head_bwd", "grove_box_losses", "grove_adamw_step", "grove_adamw_step_multi", "grove_sumsq_f32",
 ]
 
 _lib = None

@@ -758,6 +758,43 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, 
   }
 }
 
+// The same update over ALL trainable tensors in one launch: the fp32 state is one flat buffer (segment s occupies
+// [seg_off[s], seg_off[s] + seg_len[s]), starts 16-byte aligned), only the bf16 model weights live in separate tensors.
+// A block takes 1024 consecutive flat elements; the few elements of an alignment gap between two segments hold zeros in every
+// state buffer and stay zero. Element-wise identical arithmetic to adamw_kernel.
+__global__ __launch_bounds__(256) void adamw_multi_kernel(float* __restrict__ master, const float* __restrict__ grad, float* __restrict__ m,
+                                                          float* __restrict__ v, const int64_t* __restrict__ seg_off,
+                                                          const int64_t* __restrict__ seg_len, bf16_raw* const* __restrict__ model, int nseg,
+                                                          int64_t total, float lr, float b1, float b2, float eps, float wd, float gs, float bc1,
+                                                          float bc2) {
+  for (int64_t c0 = (int64_t)blockIdx.x * 1024; c0 < total; c0 += (int64_t)gridDim.x * 1024) {
+    // segment of the chunk's first element: last s with seg_off[s] <= c0 (uniform per block, scalar loads)
+    int lo = 0, hi = nseg - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (seg_off[mid] <= c0) lo = mid; else hi = mid - 1;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t i = c0 + j * 256 + threadIdx.x;
+      if (i >= total) break;
+      int sg = lo;
+      while (sg + 1 < nseg && seg_off[sg + 1] <= i) ++sg;
+      const float g = grad[i] * gs;
+      float w = master[i];
+      const float mi = b1 * m[i] + (1.f - b1) * g;
+      const float vi = b2 * v[i] + (1.f - b2) * g * g;
+      m[i] = mi;
+      v[i] = vi;
+      w -= lr * wd * w;
+      w -= lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
+      master[i] = w;
+      const int64_t k = i - seg_off[sg];
+      if (k < seg_len[sg] && model[sg]) model[sg][k] = f2bf(w);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n) {
   __shared__ float scratch[4];
   float s = 0.f;
@@ -1034,6 +1071,19 @@ extern "C" int grove_adamw_step(float* master, void* model_bf16, const float* gr
   const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
   hipLaunchKernelGGL(adamw_kernel, cap_grid(n), dim3(256), 0, (hipStream_t)stream, master, (bf16_raw*)model_bf16, grad, m, v, n, lr, beta1, beta2, eps,
                      weight_decay, grad_scale, bc1, bc2);
+  GROVE_LAUNCH_CHECK();
+  return GROVE_OK;
+}
+
+extern "C" int grove_adamw_step_multi(float* master, const float* grad, float* m, float* v, const int64_t* seg_off, const int64_t* seg_len,
+                                      void* const* model_bf16, int32_t nseg, int64_t total, float lr, float beta1, float beta2, float eps,
+                                      float weight_decay, float grad_scale, int32_t step, void* stream) {
+  GROVE_CHECK(nseg > 0 && total > 0 && step >= 1 && seg_off && seg_len && model_bf16, GROVE_E_SHAPE, "adamw_multi: bad args");
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  int64_t g = (total + 1023) / 1024;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, master, grad, m, v, seg_off, seg_len,
+                     (bf16_raw* const*)model_bf16, nseg, total, lr, beta1, beta2, eps, weight_decay, grad_scale, bc1, bc2);
   GROVE_LAUNCH_CHECK();
   return GROVE_OK;
 }

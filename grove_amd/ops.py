@@ -520,6 +520,14 @@ def adamw_step(master, model_bf16, grad, m, v, lr, beta1, beta2, eps, weight_dec
                                            C.c_float(weight_decay), C.c_float(grad_scale), int(step), _stream()), "grove_adamw_step")
 
 
+def adamw_step_multi(master, grad, m, v, seg_off, seg_len, model_ptrs, lr, beta1, beta2, eps, weight_decay, grad_scale, step):
+    """One launch over every trainable tensor: seg_off / seg_len int64 and model_ptrs int64 (data_ptr of each bf16 tensor) device tensors."""
+    _lib.check(_lib.lib().grove_adamw_step_multi(_p(master), _p(grad), _p(m), _p(v), _p(seg_off), _p(seg_len), _p(model_ptrs),
+                                                 int(seg_off.numel()), C.c_int64(master.numel()), C.c_float(lr), C.c_float(beta1),
+                                                 C.c_float(beta2), C.c_float(eps), C.c_float(weight_decay), C.c_float(grad_scale),
+                                                 int(step), _stream()), "grove_adamw_step_multi")
+
+
 def sumsq(x, out=None):
     if out is None:
         out = torch.zeros(1, dtype=torch.float32, device=x.device)

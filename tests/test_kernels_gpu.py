@@ -865,3 +865,38 @@ def test_gemm_padded_head_maps(dev):
     close(out2, ref2, 2 ** -8, "k map vs padded GEMM")  # (K = 640 vs 768: same products, the zero columns dropped)
     want = a_ref.view(Mw, heads * hp)[rows].float().cpu() @ w2_p.view(C, heads * hp).float().cpu().t()
     close(out2, want, 2 ** -7, "k map vs fp32")
+
+
+def test_adamw_multi_tensor_equals_per_tensor(dev):
+    """The one-launch optimizer step over a flat state buffer with separate bf16 tensors (ragged sizes, 16-byte aligned
+    starts with gaps, one tensor without a working copy) is bit-identical to per-tensor grove_adamw_step calls."""
+    from grove_amd import ops
+    sizes = [5, 1024, 3000, 1, 77777, 4096]
+    offs, off = [], 0
+    for k in sizes:
+        offs.append(off)
+        off += (k + 3) // 4 * 4
+    total = off
+    g = torch.Generator().manual_seed(21)
+    state = {n: torch.zeros(total) for n in ("master", "grad", "m", "v")}
+    for o, k in zip(offs, sizes):
+        state["master"][o:o + k] = torch.randn(k, generator=g)
+        state["grad"][o:o + k] = torch.randn(k, generator=g) * 0.1
+        state["m"][o:o + k] = torch.randn(k, generator=g) * 0.01
+        state["v"][o:o + k] = torch.rand(k, generator=g) * 0.01
+    hp = dict(lr=3e-4, beta1=0.9, beta2=0.95, eps=1e-8, weight_decay=0.01, grad_scale=0.37, step=7)
+    a = {n: t.clone().to(dev) for n, t in state.items()}
+    b = {n: t.clone().to(dev) for n, t in state.items()}
+    wa = [torch.zeros(k, dtype=bf16, device=dev) for k in sizes]
+    wb = [torch.zeros(k, dtype=bf16, device=dev) for k in sizes]
+    for i, (o, k) in enumerate(zip(offs, sizes)):
+        ops.adamw_step(a["master"][o:o + k], wa[i] if i != 3 else None, a["grad"][o:o + k], a["m"][o:o + k], a["v"][o:o + k], **hp)
+    seg_off = torch.tensor(offs, dtype=torch.int64, device=dev)
+    seg_len = torch.tensor(sizes, dtype=torch.int64, device=dev)
+    ptrs = torch.tensor([w.data_ptr() if i != 3 else 0 for i, w in enumerate(wb)], dtype=torch.int64, device=dev)
+    ops.adamw_step_multi(b["master"], b["grad"], b["m"], b["v"], seg_off, seg_len, ptrs, **hp)
+    for n in ("master", "m", "v"):
+        assert torch.equal(a[n], b[n]), n
+    for i in range(len(sizes)):
+        assert torch.equal(wa[i], wb[i]), i
+    assert (wb[3] == 0).all()
