@@ -338,39 +338,46 @@ class GROVEForCausalLM(torch.nn.Module):
         B = ids.shape[0]
         train = (not inference) and self._train_mode
         tp = Tape(enabled=train)
-        # 1. grounding encoder (GROVE.py:162): queued first, it keeps the GPU busy for the host work below
+        # Queue order (the host queues ~1900 launches per step at ~30 us each, so WHEN a tower is queued decides when it can start):
+        #   CLIP tower (main stream; needs only the images) -> host planning (side stream; its read-backs wait for the previous
+        #   step, by which time the GPU already has the CLIP tower to run) -> splice + LLaMA (main) -> SAM tower (its own stream).
+        # CLIP -> LLaMA is the longer chain, so it goes first and the SAM tower fills in beside it: both finish together and
+        # overlap for the whole forward (with SAM queued first it finished 40 ms before the LLaMA stack did).
         main = torch.cuda.current_stream()
         if self._plan_stream is None:
             self._plan_stream = torch.cuda.Stream(device=self.dev)
         side = self._plan_stream
-        side.wait_stream(main)  # the inputs are complete where the main stream stands now (before this step's kernels)
-        # The grounding tower shares nothing with the CLIP -> LLaMA tower until the decoder, so it runs on its own stream: the
-        # two kernel sequences interleave on the CUs and fill each other's partial rounds and tails (same-box A/B: -5 ms per
-        # step for the forward alone). `tower_overlap = False` serialises them (clean per-kernel timings).
-        if self.tower_overlap:
-            if self._sam_stream is None:
-                self._sam_stream = torch.cuda.Stream(device=self.dev)
-            self._sam_stream.wait_stream(main)
-            with torch.cuda.stream(self._sam_stream):
-                emb_rows, sam_ctx = self.sam.forward(simg.to(bf), save=train)
-        else:
+        start = torch.cuda.Event()
+        start.record(main)  # the inputs are complete where the main stream stands now (before this step's kernels)
+        side.wait_event(start)
+        if not self.tower_overlap:  # serial order (clean per-kernel timings): grounding encoder first, as the reference (GROVE.py:162)
             emb_rows, sam_ctx = self.sam.forward(simg.to(bf), save=train)
-        F = emb_rows.shape[0]
-        emb_rows2 = emb_rows.view(F * d.sam_grid ** 2, -1)
+        # 2. global encoder + projector (GROVE.py:170-176)
+        feats, _ = self.encode_images(gimg, tape=tp)
         # 0. everything the host derives from the INPUTS — splice plan, labelled rows, [DET] rows / instances, ground truth —
-        # on a side stream while the encoder runs. Each read-back (.cpu()) and each upload from pageable memory is a stream
-        # sync; on the main stream, in the middle of the step, they left the GPU idle 6-9 ms per step (rocprofv3 kernel trace,
-        # tools/step_gaps.py); the reference does 2 * B * T of them per step for the ground truth alone (GROVE.py:352-353).
+        # on a side stream while the GPU runs the CLIP tower. Each read-back (.cpu()) and each upload from pageable memory is a
+        # stream sync; on the main stream, in the middle of the step, they left the GPU idle 6-9 ms per step (rocprofv3 kernel
+        # trace, tools/step_gaps.py); the reference does 2 * B * T of them per step for the ground truth alone (GROVE.py:352-353).
         with torch.cuda.stream(side):
             hp = self._host_plan(ids, labs, amask, boxes_l, vis_l, B, Tseq, inference)
         main.wait_stream(side)
         for t_ in hp.device_tensors:
             t_.record_stream(main)
         plan, S, det_rows, counts = hp.plan, hp.plan.S, hp.det_rows, hp.counts
-        # 2-3. global encoder + projector, splice, LLaMA (GROVE.py:170-176; llava_llama.py:88-109)
-        feats, _ = self.encode_images(gimg, tape=tp)
+        # 3. splice, LLaMA (llava_llama.py:88-109)
         x = self._embed(plan, feats.data)
         hidden, llama_ctx = self.llama.forward(x, plan.B, plan.S, kv_len=plan.kv_len, save=train)
+        # 1. grounding encoder (GROVE.py:162). It shares nothing with the CLIP -> LLaMA tower until the decoder, so it runs on its
+        # own stream: the two kernel sequences interleave on the CUs and fill each other's partial rounds and tails
+        # (same-box A/B: -11 ms per step, forward and backward). `tower_overlap = False` serialises them.
+        if self.tower_overlap:
+            if self._sam_stream is None:
+                self._sam_stream = torch.cuda.Stream(device=self.dev)
+            self._sam_stream.wait_event(start)
+            with torch.cuda.stream(self._sam_stream):
+                emb_rows, sam_ctx = self.sam.forward(simg.to(bf), save=train)
+        F = emb_rows.shape[0]
+        emb_rows2 = emb_rows.view(F * d.sam_grid ** 2, -1)
         if self.tower_overlap:
             main.wait_stream(self._sam_stream)
             emb_rows.record_stream(main)  # allocated under the SAM stream, read by the decoder on this one
@@ -490,14 +497,11 @@ class GROVEForCausalLM(torch.nn.Module):
             dte = torch.zeros((n_det, d.out_dim), dtype=torch.float32, device=self.dev)
             ops.scatter_add_f32(c.dec_state["text"].grad, dte, inst_det_t, c.N, d.out_dim)
             te.grad = ops.to_bf16(dte)
-        # SAM (adapters' weight gradients, dgrad through blocks 31..8): needs d_emb only, so it runs on the SAM stream beside
-        # the lm_head / LLaMA / projector backward below (disjoint slices of the flat gradient buffer)
+        # SAM (adapters' weight gradients, dgrad through blocks 31..8) needs d_emb only: it runs on the SAM stream beside the
+        # lm_head / LLaMA / projector backward (disjoint slices of the flat gradient buffer), queued AFTER that longer chain
         main = torch.cuda.current_stream()
-        if self.tower_overlap and self._sam_stream is not None:
-            self._sam_stream.wait_stream(main)
-            with torch.cuda.stream(self._sam_stream):
-                d_emb.record_stream(self._sam_stream)
-                self.sam.backward(c.sam_ctx, ops.to_bf16(d_emb))
+        dec_done = torch.cuda.Event()
+        dec_done.record(main)
         # lm_head: wgrad + dgrad on the labelled rows
         hv, dlogits, rows, R = c.ce_state
         if R > 0:
@@ -534,6 +538,10 @@ class GROVEForCausalLM(torch.nn.Module):
         ops.scatter_add_f32(dx, self._grad["model.embed_tokens.weight"], plan.tok, plan.B * plan.S, H)
         c.tp.backward()  # mm_projector
         if self.tower_overlap and self._sam_stream is not None:
+            self._sam_stream.wait_event(dec_done)
+            with torch.cuda.stream(self._sam_stream):
+                d_emb.record_stream(self._sam_stream)
+                self.sam.backward(c.sam_ctx, ops.to_bf16(d_emb))
             main.wait_stream(self._sam_stream)
         else:
             self.sam.backward(c.sam_ctx, ops.to_bf16(d_emb))
