@@ -4,7 +4,7 @@ import torch
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from grove_amd import ops
 dev = torch.device("cuda:0")
-# the plain-epilogue launches that carry most of the step's GEMM time (profiles/r01_v8_gemm_shapes.txt): 256-row instance, then 192-row
+# the plain-epilogue launches that carry most of the step's GEMM time (profiles/r01_v9_gemm_shapes.txt): 256-row instance, then 192-row
 shapes = [(32768, 1280, 5120), (32768, 5120, 1280), (32768, 3840, 1280), (2812, 11008, 4096), (32768, 1280, 1280),
           (2812, 4096, 22016), (2812, 12288, 4096), (2812, 4096, 11008), (2812, 4096, 4096), (18464, 1024, 4096)]
 for M, N, K in shapes:

@@ -1,5 +1,5 @@
 """GPU idle gaps inside one training step, from a rocprofv3 kernel-trace database (rocpd .db): which kernels the device waits
-before, and when in the step. Steps are delimited by the bursts of adamw_kernel launches.
+before, and when in the step. Steps are delimited by the optimizer launches (adamw_*).
     python tools/step_gaps.py gpurun_out/prof/xyz_results.db [step_index]"""
 import collections
 import sqlite3
@@ -7,7 +7,7 @@ import sys
 
 db = sqlite3.connect(sys.argv[1])
 rows = db.execute("select name, start, end from kernels order by start").fetchall()
-ad = [(s, e) for n, s, e in rows if "adamw_kernel" in n]
+ad = [(s, e) for n, s, e in rows if "adamw" in n]
 bursts, cb = [], [ad[0][0], ad[0][1]]
 for s, e in ad[1:]:
     if s - cb[1] > 20e6:
