@@ -333,7 +333,7 @@ def synthetic_batch(d: GroveDims, B=1, T=8, L=64, n_det=2, seed=0, ragged=False,
         bl, vl = [], []
         for t in range(T):
             v = (det_uniform01(f"{tag}.vis{b}.{t}", (n_det,)) < 0.7).float()
-            if t == 0 and v.sum() == 0:
+            if t == 0 and n_det > 0 and v.sum() == 0:
                 v[0] = 1.0
             k = int(v.sum().item())
             bx = det_uniform01(f"{tag}.box{b}.{t}", (k, 4)) * 0.5 + 0.2

@@ -297,3 +297,49 @@ def test_full_width_towers_match_oracle(dev):
     assert rel(out["hidden"], ref["hidden"]) < 6e-2, "llama hidden"
     l1 = (out["flat_boxes"].cpu() - ref["flat_boxes"]).abs().mean().item()
     assert l1 < 4e-3, f"box L1 {l1}"
+
+
+def test_no_det_tokens_and_invisible_objects(setup, dev):
+    """Edge cases of the grounding head (GROVE.py:248-268, 339-381): a batch whose answers contain no [DET] token (no decoder
+    instances: the loss is the CE term alone and backward still reaches the LLaMA / projector / embedding path), and a batch in
+    which every object is invisible in every frame (no GT boxes: the box terms are 0 / 1e-8-normalised, only objectness trains)."""
+    from grove_amd import GROVEForCausalLM
+    from grove_amd.synthetic import TINY, synthetic_batch, synthetic_state_dict
+    from oracle import grove_oracle as O
+    _, sd_r, d = setup
+    model = GROVEForCausalLM(dims=d, device=dev, state_dict=synthetic_state_dict(d), det_token_idx=d.det_token_idx, num_frames=8,
+                             pe_dtype=torch.float32, train=True)
+    # (a) no [DET] at all
+    batch = synthetic_batch(d, B=2, T=8, L=40, n_det=0, seed=11)
+    out = model(**to_dev(batch, dev))
+    kwo = batch.as_kwargs()
+    kwo["global_enc_images"], kwo["grounding_enc_images"] = kwo["global_enc_images"].to(bf).float(), kwo["grounding_enc_images"].to(bf).float()
+    with torch.no_grad():
+        ref = O.model_forward(sd_r, d, **kwo)
+    assert abs(float(out["ce_loss"]) - float(ref["ce_loss"])) <= 2e-2 * max(1.0, abs(float(ref["ce_loss"])))
+    for k in ("giou_loss", "l1_loss", "temp_objectness_loss"):
+        assert float(out[k]) == 0.0 and float(ref[k]) == 0.0, k
+    model.zero_grad()
+    model.backward(out["loss"])
+    g = model._flat_grad
+    assert torch.isfinite(g).all() and float(g.abs().max()) > 0
+    assert float(model._grad["model.grounding_encoder.mask_decoder.bbox_prediction_head.0.weight"].abs().max()) == 0.0
+    assert float(model._grad["lm_head.weight"].abs().max()) > 0
+    # (b) [DET] tokens present but nothing visible in any frame
+    batch = synthetic_batch(d, B=2, T=8, L=48, n_det=2, seed=12)
+    kw = to_dev(batch, dev)
+    kwo = batch.as_kwargs()
+    for lst in (kw, kwo):
+        lst["temp_objectness_labels_list"] = [[torch.zeros_like(v) for v in per] for per in lst["temp_objectness_labels_list"]]
+        lst["bboxes_list"] = [[bx[:0] for bx in per] for per in lst["bboxes_list"]]
+    kwo["global_enc_images"], kwo["grounding_enc_images"] = kwo["global_enc_images"].to(bf).float(), kwo["grounding_enc_images"].to(bf).float()
+    out = model(**kw)
+    with torch.no_grad():
+        ref = O.model_forward(sd_r, d, **kwo)
+    for k in ("ce_loss", "giou_loss", "l1_loss", "temp_objectness_loss", "loss"):
+        a, b = float(out[k]), float(ref[k])
+        assert abs(a - b) <= 2e-2 * max(1.0, abs(b)), f"{k}: {a} vs {b}"
+    assert float(out["giou_loss"]) == 0.0 and float(out["l1_loss"]) == 0.0
+    model.zero_grad()
+    model.backward(out["loss"])
+    assert torch.isfinite(model._flat_grad).all()
