@@ -223,6 +223,48 @@ def tiny_box_l1(dev):
     return float((out["flat_boxes"].cpu() - ref["flat_boxes"]).abs().mean())
 
 
+def tiny_train_parity(dev):
+    """SURVEY.md section 8(d)'s accuracy figures for the training configuration, on the tiny-dims case the parity tests use:
+    objectness-logit error, relative error of the loss terms and the cosine of the whole trainable gradient against torch
+    autograd through the fp32 CPU oracle (same bf16-rounded weights and inputs)."""
+    from grove_amd import GROVEForCausalLM
+    from grove_amd.model.GROVE import trainable_names
+    from grove_amd.synthetic import TINY, synthetic_batch, synthetic_state_dict
+    from oracle import grove_oracle as O
+    bf = torch.bfloat16
+    d = TINY
+    sd = synthetic_state_dict(d)
+    names = trainable_names(d)
+    model = GROVEForCausalLM(dims=d, device=dev, state_dict=sd, det_token_idx=d.det_token_idx, num_frames=8, pe_dtype=torch.float32, train=True)
+    batch = synthetic_batch(d, B=2, T=8, L=48, n_det=2, seed=1, ragged=True)
+    kw = batch.as_kwargs()
+    kd = dict(kw)
+    for k in ("global_enc_images", "grounding_enc_images"):
+        kd[k] = kw[k].to(dev).to(bf)
+        kw[k] = kw[k].to(bf).float()
+    for k in ("input_ids", "labels", "attention_masks", "offset"):
+        kd[k] = kw[k].to(dev)
+    model.zero_grad()
+    out = model(**kd)
+    model.backward(out["loss"])
+    sdg = {k: v.to(bf).float().requires_grad_(k in names) for k, v in sd.items()}
+    ref = O.model_forward(sdg, d, **kw)
+    ref["loss"].backward()
+    gs, rs = [], []
+    for n in names:
+        g, r = model._grad[n].detach().float().cpu(), sdg[n].grad
+        if n.endswith("conv3d.weight"):
+            g = g.view(r.shape[0], 3, 3, 3, r.shape[1]).permute(0, 4, 1, 2, 3)
+        gs.append(g.reshape(-1))
+        rs.append(r.reshape(-1))
+    g, r = torch.cat(gs), torch.cat(rs)
+    terms = ("ce_loss", "giou_loss", "l1_loss", "temp_objectness_loss")
+    return {"loss_rel_err_max": round(max(abs(float(out[k]) - float(ref[k])) / max(abs(float(ref[k])), 1e-12) for k in terms), 5),
+            "objectness_logit_abs_err": round(float((out["flat_logits"].detach().cpu() - ref["flat_logits"].detach()).abs().max()), 5),
+            "grad_cosine": round(float(torch.nn.functional.cosine_similarity(g, r, dim=0)), 5),
+            "grad_norm_ratio": round(float(g.norm() / r.norm()), 4), "trainable_elements": int(g.numel())}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -331,6 +373,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is a rank-0, N = 1 figure (other N: GPU numbers only)
             try:
                 res["box_l1_vs_oracle_tiny"] = round(tiny_box_l1(dev), 6)
+                res["train_parity_vs_oracle_tiny"] = tiny_train_parity(dev)
                 res["cpu_baseline"] = cpu_baseline(args)
             except Exception as e:  # the baseline is informational; never lose the measured line
                 res["cpu_baseline"] = {"error": repr(e)}
