@@ -265,6 +265,22 @@ def tiny_train_parity(dev):
             "grad_norm_ratio": round(float(g.norm() / r.norm()), 4), "trainable_elements": int(g.numel())}
 
 
+def self_launch(n, argv):
+    """`python bench.py --gpus N` without a launcher around it: start N ranks (one per GPU) with torch.distributed.run as a CHILD
+    process and pass its single JSON line through. This parent never touches the GPU (no HIP call, no torch.cuda query), so
+    nothing is re-exec'ed from a GPU-initialised process; the child's exit code becomes ours."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -278,6 +294,8 @@ def main():
     ap.add_argument("--serial_towers", action="store_true",
                     help="run the SAM tower on the main stream as well (no kernel overlap): how profiles/*_kernel_stats are collected")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
 
     # stdout carries exactly ONE line, the JSON: everything else that writes to fd 1 (RCCL prints its version banner there, from
     # every rank, when the box exports NCCL_DEBUG=VERSION — and flushes it at exit, i.e. AFTER a normal print) goes to stderr
@@ -355,7 +373,9 @@ def main():
                                    f"({args.batch * args.frames // 8} independent 8-frame windows), LLaVA-1.5-7B + CLIP ViT-L/14-336 + "
                                    f"SAM ViT-H@512 + box decoder, text L={args.text_len}, fwd+bwd+AdamW, shipped freeze policy",
                        "dims": args.dims, "global_batch_clips": world * args.batch, "frames_per_clip": args.frames,
-                       "parallelism": f"dp{world}", "frames_per_sec_per_gpu": round(frames / dt / world, 3), "last_loss": round(loss, 4),
+                       "parallelism": f"dp{world}", "ranks": world,
+                       "collective_backend": (dist.get_backend() if world > 1 else None),
+                       "frames_per_sec_per_gpu": round(frames / dt / world, 3), "last_loss": round(loss, 4),
                        "towers": "serial" if args.serial_towers else "SAM tower on a second stream beside CLIP->LLaMA (roofline: one extra step with the towers serialised)"},
             "roofline": {"bound": "mfma", "achieved": round(flops / secs / 1e12, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(flops / secs / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": traffic,

@@ -106,11 +106,35 @@ def interpolate_positional_embeddings(sd, img_size, patch_size, global_blocks, p
     return changed
 
 
-def load_grove_weights(model, path, strict=False):
+def dims_from_checkpoint(path, sd=None, base=None):
+    """Architecture dimensions of a checkpoint: the HuggingFace `config.json` beside it when there is one (LlamaConfig names:
+    hidden_size, num_hidden_layers, num_attention_heads, intermediate_size, rms_norm_eps, rope_theta — what
+    `from_pretrained` reads at train.py:207-218), the vocabulary size from `model.embed_tokens.weight` itself (the reference
+    resizes it after adding its special tokens, train.py:330), everything else the real GROVE geometry."""
+    from dataclasses import replace
+    from .synthetic import GroveDims
+    d = base if base is not None else GroveDims()
+    cfg_path = os.path.join(path if os.path.isdir(path) else os.path.dirname(os.path.abspath(path)), "config.json")
+    upd = {}
+    if os.path.exists(cfg_path):
+        with open(cfg_path) as fh:
+            cfg = json.load(fh)
+        for ours, theirs in (("hidden", "hidden_size"), ("n_layers", "num_hidden_layers"), ("n_heads", "num_attention_heads"),
+                             ("mlp", "intermediate_size"), ("rms_eps", "rms_norm_eps"), ("rope_theta", "rope_theta"),
+                             ("vocab", "vocab_size"), ("bos_token_id", "bos_token_id"), ("eos_token_id", "eos_token_id"),
+                             ("pad_token_id", "pad_token_id")):
+            if cfg.get(theirs) is not None:
+                upd[ours] = cfg[theirs]
+    if sd is not None and "model.embed_tokens.weight" in sd:
+        upd["vocab"] = int(sd["model.embed_tokens.weight"].shape[0])
+    return replace(d, **upd)
+
+
+def load_grove_weights(model, path, strict=False, sd=None):
     """infer_iground.py:526-535 / train.py:621-624: read `path`, fit SAM's position tables to the model's image size, and
     `load_state_dict` (non-strict by default, as the reference). Shape mismatches raise — a silently skipped tensor would
     leave synthetic weights in place. Returns the load report (missing_keys, unexpected_keys) plus `resized`."""
-    sd = read_state_dict(path)
+    sd = read_state_dict(path) if sd is None else sd
     d = model.dims
     resized = interpolate_positional_embeddings(sd, d.sam_image, d.sam_patch, d.sam_global)
     want = model.state_dict()

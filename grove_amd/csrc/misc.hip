@@ -766,7 +766,12 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(float* __restrict__ ma
                                                           float* __restrict__ v, const int64_t* __restrict__ seg_off,
                                                           const int64_t* __restrict__ seg_len, bf16_raw* const* __restrict__ model, int nseg,
                                                           int64_t total, float lr, float b1, float b2, float eps, float wd, float gs, float bc1,
-                                                          float bc2) {
+                                                          float bc2, const float* __restrict__ sumsq, float clip, float* __restrict__ norm_out) {
+  if (sumsq) {  // global-norm clipping from a DEVICE scalar (no host round trip): norm of the scaled gradient, DeepSpeed's clip_coef
+    const float norm = sqrtf(*sumsq) * gs;
+    if (clip > 0.f && norm > clip) gs *= clip / (norm + 1e-6f);
+    if (norm_out && blockIdx.x == 0 && threadIdx.x == 0) *norm_out = norm;
+  }
   for (int64_t c0 = (int64_t)blockIdx.x * 1024; c0 < total; c0 += (int64_t)gridDim.x * 1024) {
     // segment of the chunk's first element: last s with seg_off[s] <= c0 (uniform per block, scalar loads)
     int lo = 0, hi = nseg - 1;
@@ -1077,13 +1082,15 @@ extern "C" int grove_adamw_step(float* master, void* model_bf16, const float* gr
 
 extern "C" int grove_adamw_step_multi(float* master, const float* grad, float* m, float* v, const int64_t* seg_off, const int64_t* seg_len,
                                       void* const* model_bf16, int32_t nseg, int64_t total, float lr, float beta1, float beta2, float eps,
-                                      float weight_decay, float grad_scale, int32_t step, void* stream) {
+                                      float weight_decay, float grad_scale, int32_t step, const float* sumsq, float clip, float* norm_out,
+                                      void* stream) {
   GROVE_CHECK(nseg > 0 && total > 0 && step >= 1 && seg_off && seg_len && model_bf16, GROVE_E_SHAPE, "adamw_multi: bad args");
   const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
   int64_t g = (total + 1023) / 1024;
   if (g > 4096) g = 4096;
   hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, master, grad, m, v, seg_off, seg_len,
-                     (bf16_raw* const*)model_bf16, nseg, total, lr, beta1, beta2, eps, weight_decay, grad_scale, bc1, bc2);
+                     (bf16_raw* const*)model_bf16, nseg, total, lr, beta1, beta2, eps, weight_decay, grad_scale, bc1, bc2, sumsq, clip,
+                     norm_out);
   GROVE_LAUNCH_CHECK();
   return GROVE_OK;
 }

@@ -41,6 +41,36 @@ def trainable_names(d: GroveDims):
     return names
 
 
+class KVCache:
+    """`past_key_values` of the cached LM step: per layer one bf16 [B, capacity, 2*hidden] tensor holding the rotated keys |
+    values of positions 0..length-1 (zero beyond: the decode kernel reads whole tiles and masks by position). Falsy while
+    empty, like the `past_key_values` test in prepare_inputs_for_generation (llava_llama.py:158-159)."""
+
+    def __init__(self, layers, length=0):
+        self.layers, self.length = layers, length
+
+    @property
+    def capacity(self):
+        return self.layers[0].shape[1] if self.layers else 0
+
+    def __len__(self):
+        return len(self.layers) if self.length > 0 else 0
+
+    def get_seq_length(self, layer_idx=0):
+        return self.length
+
+    def reserve(self, n):
+        """Room for n positions (grows by reallocation; a captured decode graph keeps the old buffers, so generate() sizes
+        the cache for its whole run up front)."""
+        if n <= self.capacity:
+            return
+        cap = max(n, self.capacity + 256)
+        for i, t in enumerate(self.layers):
+            g = torch.zeros((t.shape[0], cap, t.shape[2]), dtype=t.dtype, device=t.device)
+            g[:, :self.length].copy_(t[:, :self.length])
+            self.layers[i] = g
+
+
 class GROVEForCausalLM(torch.nn.Module):
     def __init__(self, config=None, dims: GroveDims = None, device="cuda", state_dict=None, train=False, **kwargs):
         super().__init__()
@@ -63,6 +93,11 @@ class GROVEForCausalLM(torch.nn.Module):
         self.dev = torch.device(device)
         if self.dev.type != "cuda":
             raise RuntimeError("grove_amd runs on MI355X only: there is no CPU path (use oracle/ for a CPU check)")
+        if self.dev.index is None:
+            self.dev = torch.device("cuda", torch.cuda.current_device())
+        # one process per GPU: the C-ABI launches go to the calling thread's current HIP device / torch's current stream there
+        # (DeepSpeed's initialize() did this for the reference, train.py:480-486); ops refuses tensors of any other device
+        torch.cuda.set_device(self.dev)
         self._train_mode = train
         self._sd = {}
         self._grad = {}
@@ -73,6 +108,22 @@ class GROVEForCausalLM(torch.nn.Module):
         self._alloc_params(state_dict)
         self._build_engines()
         self._ctx = None
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, *model_args, dims=None, device="cuda", train=False, torch_dtype=None,
+                        low_cpu_mem_usage=None, **kwargs):
+        """`GROVEForCausalLM.from_pretrained(path, torch_dtype=bf16, low_cpu_mem_usage=True, **model_args)` (train.py:207-218,
+        infer_iground.py:511-528): read a HuggingFace directory / consolidated `pytorch_model.bin` / DeepSpeed module file with
+        the reference's key names, take the LLaMA geometry from its `config.json` (vocabulary from the embedding table itself),
+        fit SAM's position tables to the 512-pixel geometry (train.py:503-576) and load non-strictly. bf16 only."""
+        from ..checkpoint import dims_from_checkpoint, load_grove_weights, read_state_dict
+        if torch_dtype not in (None, torch.bfloat16):
+            raise ValueError("grove_amd computes in bf16 (precision 'bf16', train.py:58): torch_dtype must be torch.bfloat16")
+        sd = read_state_dict(pretrained_model_name_or_path)
+        d = dims_from_checkpoint(pretrained_model_name_or_path, sd, base=dims)
+        model = cls(*model_args, dims=d, device=device, train=train, **kwargs)
+        model.load_report = load_grove_weights(model, pretrained_model_name_or_path, sd=sd)
+        return model
 
     # ------------------------------------------------------------------ parameters / state dict
     def _alloc_params(self, state_dict):
@@ -140,8 +191,8 @@ class GROVEForCausalLM(torch.nn.Module):
 
     # ------------------------------------------------------------------ modes (GROVE.py:138-154)
     def forward(self, **kwargs):
-        if "past_key_values" in kwargs:
-            raise NotImplementedError("cached single-step LM forward is reached through evaluate()/generate() in grove_amd")
+        if "past_key_values" in kwargs:  # GROVE.py:138-140 -> LlavaLlamaForCausalLM.forward (one LM step of generate())
+            return self.lm_forward(**kwargs)
         mode = kwargs.get("mode")
         if mode == "encode_images":
             return self.encode_images(kwargs["images"])
@@ -343,7 +394,7 @@ class GROVEForCausalLM(torch.nn.Module):
         #   step, by which time the GPU already has the CLIP tower to run) -> splice + LLaMA (main) -> SAM tower (its own stream).
         # CLIP -> LLaMA is the longer chain, so it goes first and the SAM tower fills in beside it: both finish together and
         # overlap for the whole forward (with SAM queued first it finished 40 ms before the LLaMA stack did).
-        main = torch.cuda.current_stream()
+        main = torch.cuda.current_stream(self.dev)
         if self._plan_stream is None:
             self._plan_stream = torch.cuda.Stream(device=self.dev)
         side = self._plan_stream
@@ -499,7 +550,7 @@ class GROVEForCausalLM(torch.nn.Module):
             te.grad = ops.to_bf16(dte)
         # SAM (adapters' weight gradients, dgrad through blocks 31..8) needs d_emb only: it runs on the SAM stream beside the
         # lm_head / LLaMA / projector backward (disjoint slices of the flat gradient buffer), queued AFTER that longer chain
-        main = torch.cuda.current_stream()
+        main = torch.cuda.current_stream(self.dev)
         dec_done = torch.cuda.Event()
         dec_done.record(main)
         # lm_head: wgrad + dgrad on the labelled rows
@@ -547,84 +598,172 @@ class GROVEForCausalLM(torch.nn.Module):
             self.sam.backward(c.sam_ctx, ops.to_bf16(d_emb))
         self._ctx = None
 
-    # ------------------------------------------------------------------ generation (GROVE.py:412-451)
+    # ------------------------------------------------------------------ generation (GROVE.py:412-451, llava_llama.py:57-180)
+    def new_kv_cache(self, B, S_max):
+        """An empty `past_key_values` with room for S_max positions."""
+        return KVCache(self.llama.new_kv_cache(B, S_max), 0)
+
     @torch.no_grad()
-    def generate_greedy(self, image_features, input_ids, max_new_tokens, token_embeddings=None, eos_token_id=None, pad_token_id=None,
-                        use_cache=True, use_graph=True):
-        """HF greedy decoding (num_beams=1, do_sample=False; GROVE.py:418-422) restated: rows finish at eos and are padded with
-        pad; returns (sequences incl. -200, hidden of every fed position [B, L+575+new-1, H]).
-        use_cache=True (the reference's setting): one prefill over the spliced prompt fills the per-layer KV cache, then every
-        step feeds ONE token per sequence through the weight-streaming GEMV path (llava_llama.py:144-180). use_cache=False
-        recomputes the whole sequence every step (kept as the second implementation for the tests). The generate callers
-        feed un-padded equal-length prompts (quirk Q9), which is what the cached path assumes."""
+    def lm_forward(self, input_ids=None, attention_mask=None, past_key_values=None, inputs_embeds=None, labels=None, use_cache=None,
+                   output_attentions=None, output_hidden_states=None, images=None, image_features=None, image_forward_outs=None,
+                   images_dtype=None, token_embeddings=None, bboxes=None, return_dict=None, last_logits_only=False, **_):
+        """`LlavaLlamaForCausalLM.forward` as generation drives it (llava_llama.py:57-141; reached through
+        `forward(past_key_values=...)`, GROVE.py:138-140). Two cases, as in `prepare_inputs_for_generation` (:144-180):
+          * `past_key_values` empty / None: the prompt step — splice `image_features[b]` at the -200 slot
+            (llava_with_region_arch.py:84-440), run the stack over the whole [B, L+575] sequence and, with `use_cache`, leave the
+            rotated keys | values of every layer in the returned cache;
+          * `past_key_values` holding t > 0 positions: ONE new token per sequence (the last column of `input_ids`) at position t
+            through the weight-streaming GEMV path, appended to the cache in place.
+        Returns `.logits` ([B, S, V] bf16 for the prompt step — only the last position with `last_logits_only` —, [B, 1, V] fp32
+        for a cached step), `.hidden_states` = the final-norm hidden tensor (what the reference returns outside training mode,
+        llava_llama.py:130-133) and `.past_key_values`. Un-padded equal-length prompts only (quirk Q9: the reference's
+        attention mask is wrong for anything else), so `attention_mask` is not read."""
+        if labels is not None or inputs_embeds is not None or output_attentions:
+            raise NotImplementedError("lm_forward serves generation only: the training CE runs inside model_forward; "
+                                      "inputs_embeds / attentions are not produced on this path")
+        assert bboxes is None or len(bboxes) == 0, "the region encoder is dead on GROVE's path (SURVEY.md section 2 row 10)"
         d = self.dims
+        H = d.hidden
+        B = input_ids.shape[0]
+        lm_head = self._sd["lm_head.weight"]
+        embed = token_embeddings if token_embeddings is not None else self._sd["model.embed_tokens.weight"]
+        cache = past_key_values if isinstance(past_key_values, KVCache) else None
+        if past_key_values is not None and cache is None and len(past_key_values):
+            raise TypeError("past_key_values must be the KVCache a previous lm_forward / generate returned")
+        if cache is not None and cache.length > 0:
+            if B > 8:
+                raise NotImplementedError("cached decode serves 1-8 sequences per step (the GEMV path)")
+            t = cache.length
+            cache.reserve(t + 1)
+            nxt = input_ids[:, -1].to(self.dev).to(torch.int32)
+            xt = torch.empty((B, H), dtype=bf, device=self.dev)
+            ops.copy_rows(embed, xt, B, H, idx_src=nxt)
+            hidden, logits = self.llama.decode_step(xt, t, cache.layers, lm_head)
+            cache.length = t + 1
+            return SimpleNamespace(loss=None, logits=logits.view(B, 1, -1), past_key_values=cache, hidden_states=hidden.view(B, 1, H),
+                                   attentions=None)
+        if image_features is None and images is not None:
+            image_features, image_forward_outs = self.encode_images(images)
+        plan = self._splice_plan(input_ids, None, None, list(range(B)))
+        feats = image_features.reshape(-1, image_features.shape[-1]) if image_features is not None else None
+        x = self._embed(plan, feats, token_embeddings)
+        S = plan.S
+        if use_cache:
+            if cache is None:
+                cache = self.new_kv_cache(B, S + 64)
+            cache.reserve(S)
+        else:
+            cache = None
+        h0, _ = self.llama.forward(x, B, S, kv_cache=cache.layers if cache is not None else None)
+        if cache is not None:
+            cache.length = S
+        if last_logits_only:
+            last = torch.empty((B, H), dtype=bf, device=self.dev)
+            ops.copy_rows(h0, last, B, H, idx_src=(torch.arange(B, dtype=torch.int32, device=self.dev) * S + S - 1))
+            logits = (ops.gemv(last, lm_head, out_dtype=torch.float32) if B <= 8
+                      else ops.linear(last, lm_head, out_dtype=torch.float32)).view(B, 1, -1)
+        else:
+            logits = ops.linear(h0, lm_head).view(B, S, -1)
+        return SimpleNamespace(loss=None, logits=logits, past_key_values=cache, hidden_states=h0.view(B, S, H), attentions=None)
+
+    @torch.no_grad()
+    def generate(self, images=None, input_ids=None, bboxes=None, image_features=None, image_forward_outs=None, images_dtype=None,
+                 token_embeddings=None, max_new_tokens=32, num_beams=1, output_hidden_states=False, return_dict_in_generate=False,
+                 do_sample=False, use_cache=True, synced_gpus=False, eos_token_id=None, pad_token_id=None, use_graph=True, **kwargs):
+        """HF `GenerationMixin.generate` in the one configuration GROVE ever uses (GROVE.py:418-422; infer_iground.py:192):
+        greedy (`num_beams=1, do_sample=False`), `use_cache=True`, extra kwargs threaded to every LM step as
+        `prepare_inputs_for_generation` does (llava_llama.py:144-180). Rows finish at `eos_token_id` and are padded with
+        `pad_token_id` afterwards; the loop stops when every row is finished or after `max_new_tokens`; the last generated
+        token is never fed back. With `return_dict_in_generate` the result carries `.sequences` [B, L+new] (still containing
+        -200) and, with `output_hidden_states`, `.hidden_states` = one tensor per LM step ([B, L+575, H] for the prompt step,
+        [B, 1, H] after), which `evaluate` concatenates on dim 1 (GROVE.py:423-426); otherwise the sequences alone.
+        Steps after the first replay ONE captured HIP graph of the cached step (`use_graph`); each of them is exactly
+        `forward(past_key_values=cache, input_ids=ids[:, -1:], ...)`. `use_cache=False` recomputes the whole sequence per step
+        (second implementation for the tests); its hidden_states are split the same way so that the concatenation is unchanged."""
+        if num_beams != 1 or do_sample:
+            raise NotImplementedError("only greedy decoding (num_beams=1, do_sample=False) exists on GROVE's path (GROVE.py:418-422)")
+        d = self.dims
+        H = d.hidden
         eos = d.eos_token_id if eos_token_id is None else eos_token_id
         pad = d.pad_token_id if pad_token_id is None else pad_token_id
+        if image_features is None and images is not None:
+            image_features, image_forward_outs = self.encode_images(images)
         ids = input_ids.clone()
         B = ids.shape[0]
         finished = torch.zeros(B, dtype=torch.bool, device=ids.device)
-        feats = image_features.reshape(-1, image_features.shape[-1])
         lm_head = self._sd["lm_head.weight"]
         embed = token_embeddings if token_embeddings is not None else self._sd["model.embed_tokens.weight"]
 
-        def pick(last):
-            logits = ops.gemv(last, lm_head, out_dtype=torch.float32) if B <= 8 else ops.linear(last, lm_head, out_dtype=torch.float32)
-            nxt = logits.argmax(-1).to(ids.device)  # argmax over one [B, V] row block (index selection, not arithmetic)
+        def pick(logits):
+            nxt = logits.reshape(B, -1).argmax(-1).to(ids.device)  # argmax over one [B, V] row block (index selection, not arithmetic)
             return torch.where(finished, torch.full_like(nxt, pad), nxt)
 
+        def result(seqs, hiddens, cache):
+            if not return_dict_in_generate:
+                return seqs
+            return SimpleNamespace(sequences=seqs, hidden_states=tuple(hiddens) if output_hidden_states else None,
+                                   past_key_values=cache, scores=None, attentions=None)
+
         if not use_cache or B > 8:
-            hidden, S = None, 0
+            hidden, S, S0 = None, 0, None
             for _ in range(max_new_tokens):
-                plan = self._splice_plan(ids, None, None, list(range(B)))
-                x = self._embed(plan, feats, token_embeddings)
-                hidden, _ = self.llama.forward(x, plan.B, plan.S)
-                S = plan.S
-                last = torch.empty((B, d.hidden), dtype=bf, device=self.dev)
-                ops.copy_rows(hidden, last, B, d.hidden, idx_src=(torch.arange(B, dtype=torch.int32, device=self.dev) * S + S - 1))
-                nxt = pick(last)
+                out = self.lm_forward(input_ids=ids, image_features=image_features, token_embeddings=token_embeddings,
+                                      use_cache=False, last_logits_only=True)
+                hidden = out.hidden_states
+                S = hidden.shape[1]
+                S0 = S if S0 is None else S0
+                nxt = pick(out.logits)
                 ids = torch.cat([ids, nxt[:, None]], 1)
                 finished = finished | (nxt == eos)
                 if bool(finished.all()):
                     break
-            return ids, hidden.view(B, S, d.hidden)
+            return result(ids, [hidden[:, :S0]] + [hidden[:, j:j + 1] for j in range(S0, S)], None)
 
-        plan = self._splice_plan(ids, None, None, list(range(B)))
-        S0 = plan.S
-        cache = self.llama.new_kv_cache(B, S0 + max_new_tokens)
-        x = self._embed(plan, feats, token_embeddings)
-        h0, _ = self.llama.forward(x, B, S0, kv_cache=cache)
-        hiddens = [h0.view(B, S0, d.hidden)]
-        last = torch.empty((B, d.hidden), dtype=bf, device=self.dev)
-        ops.copy_rows(h0, last, B, d.hidden, idx_src=(torch.arange(B, dtype=torch.int32, device=self.dev) * S0 + S0 - 1))
+        out = self.lm_forward(input_ids=ids, image_features=image_features, token_embeddings=token_embeddings, use_cache=True,
+                              past_key_values=self.new_kv_cache(B, ids.shape[1] + 575 + max_new_tokens), last_logits_only=True)
+        cache = out.past_key_values
+        hiddens = [out.hidden_states]
+        logits = out.logits
         step_fn = None
-        logits = None
         for step in range(max_new_tokens):
-            if logits is None:
-                nxt = pick(last)
-            else:
-                nxt = logits.argmax(-1).to(ids.device)
-                nxt = torch.where(finished, torch.full_like(nxt, pad), nxt)
+            nxt = pick(logits)
             ids = torch.cat([ids, nxt[:, None]], 1)
             finished = finished | (nxt == eos)
             if bool(finished.all()) or step == max_new_tokens - 1:
                 break  # the last generated token is never fed back (quirk Q3)
-            xt = torch.empty((B, d.hidden), dtype=bf, device=self.dev)
-            ops.copy_rows(embed, xt, B, d.hidden, idx_src=nxt.to(self.dev).to(torch.int32))
             if use_graph:
+                xt = torch.empty((B, H), dtype=bf, device=self.dev)
+                ops.copy_rows(embed, xt, B, H, idx_src=nxt.to(self.dev).to(torch.int32))
                 if step_fn is None:
-                    step_fn = self.llama.decode_graph(B, cache, lm_head)
-                last, logits = step_fn(xt, S0 + step)
+                    step_fn = self.llama.decode_graph(B, cache.layers, xt, cache.length, lm_head)
+                last, logits = step_fn(xt, cache.length)
+                cache.length += 1
+                hiddens.append(last.view(B, 1, H).clone())
             else:
-                last, logits = self.llama.decode_step(xt, S0 + step, cache, lm_head)
-            hiddens.append(last.view(B, 1, d.hidden).clone())
-        return ids, torch.cat(hiddens, 1)
+                out = self.forward(past_key_values=cache, input_ids=ids[:, -1:], image_features=image_features,
+                                   token_embeddings=token_embeddings, use_cache=True)
+                logits = out.logits
+                hiddens.append(out.hidden_states)
+        return result(ids, hiddens, cache)
+
+    def generate_greedy(self, image_features, input_ids, max_new_tokens, token_embeddings=None, eos_token_id=None, pad_token_id=None,
+                        use_cache=True, use_graph=True):
+        """(sequences, hidden of every fed position [B, L+575+new-1, H]) — `generate` with the per-step hidden states concatenated."""
+        out = self.generate(input_ids=input_ids, image_features=image_features, token_embeddings=token_embeddings,
+                            max_new_tokens=max_new_tokens, eos_token_id=eos_token_id, pad_token_id=pad_token_id, use_cache=use_cache,
+                            use_graph=use_graph, output_hidden_states=True, return_dict_in_generate=True)
+        return out.sequences, torch.cat(out.hidden_states, 1)
 
     @torch.no_grad()
     def evaluate(self, image_features, image_forward_outs, images_dtype, image_embeddings, input_ids, orig_sizes,
                  max_tokens_new=32, bboxes=None, token_embeddings=None, dense_pe=None, device=None, use_cache=True):
         d = self.dims
-        ids, hidden = self.generate_greedy(image_features, input_ids, max_tokens_new, token_embeddings, use_cache=use_cache)
-        hidden = hidden.contiguous()
+        generation_outputs = self.generate(
+            images=None, input_ids=input_ids, bboxes=bboxes, image_features=image_features, image_forward_outs=image_forward_outs,
+            images_dtype=images_dtype, token_embeddings=token_embeddings, max_new_tokens=max_tokens_new, num_beams=1,
+            output_hidden_states=True, return_dict_in_generate=True, do_sample=False, use_cache=use_cache, synced_gpus=False)
+        ids = generation_outputs.sequences
+        hidden = torch.cat(generation_outputs.hidden_states, dim=1).contiguous()  # GROVE.py:423-426
         B, S, H = hidden.shape
         det_rows, counts = self._det_rows(ids.cpu(), S, trailing_pad=False)
         Tseq = self.config.num_frames

@@ -94,17 +94,22 @@ class LlamaStack:
         pos = torch.full((x.shape[0],), t, dtype=torch.int32, device=self.dev)
         return self._decode_body(x, pos, kv_cache, lm_head)
 
-    def decode_graph(self, B, kv_cache, lm_head=None):
+    def decode_graph(self, B, kv_cache, x0, t0, lm_head=None):
         """Capture one cached step in a HIP graph (a step is ~420 launches of a few microseconds each: launch-bound from
-        Python) and return step(x, t) -> (hidden, logits) that replays it."""
+        Python) and return step(x, t) -> (hidden, logits) that replays it.
+        The warm-up before the capture is a REAL launch sequence on the live cache (first-call attribute setup of every kernel):
+        it runs with the first step's own input (x0 at position t0), so the K|V row it appends is exactly the row the first
+        replay rewrites — it must never run with a dummy input / position, which would overwrite a prefilled row (position 0 is
+        the BOS attention sink)."""
         dev, H = self.dev, self.d.hidden
-        x_in = torch.zeros((B, H), dtype=torch.bfloat16, device=dev)
-        pos = torch.zeros(B, dtype=torch.int32, device=dev)
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):  # warm-up outside the capture: first-call attribute setup of every kernel
+        x_in = torch.empty((B, H), dtype=torch.bfloat16, device=dev)
+        x_in.copy_(x0)
+        pos = torch.full((B,), int(t0), dtype=torch.int32, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
             self._decode_body(x_in, pos, kv_cache, lm_head)
-        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.current_stream(dev).wait_stream(side)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             out, logits = self._decode_body(x_in, pos, kv_cache, lm_head)

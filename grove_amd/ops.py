@@ -14,12 +14,27 @@ from ._lib import (ACT_GELU, ACT_NONE, ACT_QUICKGELU, ACT_RELU, ACT_SIGMOID, ACT
 bf16 = torch.bfloat16
 
 
+_last_dev = [-1]  # device index of the last tensor whose pointer was taken (every launch takes its pointers before its stream)
+
+
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """The HIP stream of the launch = torch's current stream on the CURRENT device. Kernels are launched on the calling thread's
+    current HIP device, so the tensors must live there: one process per GPU calls torch.cuda.set_device(local_rank) once
+    (GROVEForCausalLM / GroveEngine do it); a launch whose tensors sit on another device is refused instead of faulting."""
+    s = torch.cuda.current_stream()
+    if _last_dev[0] == -2:
+        raise RuntimeError("grove_amd ops need device tensors (no CPU fallback exists)")
+    if _last_dev[0] != s.device_index and _last_dev[0] >= 0:
+        raise RuntimeError(f"grove_amd: tensors on cuda:{_last_dev[0]} but the current device is cuda:{s.device_index}; "
+                           "call torch.cuda.set_device(local_rank) in every rank before using the model")
+    return C.c_void_p(s.cuda_stream)
 
 
 def _p(t):
-    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    if t is None:
+        return C.c_void_p(0)
+    _last_dev[0] = t.device.index if t.is_cuda else -2
+    return C.c_void_p(t.data_ptr())
 
 
 def _chk_dev(*ts):
@@ -520,12 +535,14 @@ def adamw_step(master, model_bf16, grad, m, v, lr, beta1, beta2, eps, weight_dec
                                            C.c_float(weight_decay), C.c_float(grad_scale), int(step), _stream()), "grove_adamw_step")
 
 
-def adamw_step_multi(master, grad, m, v, seg_off, seg_len, model_ptrs, lr, beta1, beta2, eps, weight_decay, grad_scale, step):
-    """One launch over every trainable tensor: seg_off / seg_len int64 and model_ptrs int64 (data_ptr of each bf16 tensor) device tensors."""
+def adamw_step_multi(master, grad, m, v, seg_off, seg_len, model_ptrs, lr, beta1, beta2, eps, weight_decay, grad_scale, step,
+                     sumsq=None, clip=0.0, norm_out=None):
+    """One launch over every trainable tensor: seg_off / seg_len int64 and model_ptrs int64 (data_ptr of each bf16 tensor) device tensors.
+    sumsq (device fp32 scalar = sum of squares of grad): clip the global norm of grad * grad_scale at `clip` inside the kernel."""
     _lib.check(_lib.lib().grove_adamw_step_multi(_p(master), _p(grad), _p(m), _p(v), _p(seg_off), _p(seg_len), _p(model_ptrs),
                                                  int(seg_off.numel()), C.c_int64(master.numel()), C.c_float(lr), C.c_float(beta1),
                                                  C.c_float(beta2), C.c_float(eps), C.c_float(weight_decay), C.c_float(grad_scale),
-                                                 int(step), _stream()), "grove_adamw_step_multi")
+                                                 int(step), _p(sumsq), C.c_float(clip), _p(norm_out), _stream()), "grove_adamw_step_multi")
 
 
 def sumsq(x, out=None):

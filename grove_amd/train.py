@@ -45,6 +45,17 @@ def parse_args(argv=None):
     p.add_argument("--print_freq", default=1, type=int)
     p.add_argument("--local_rank", default=int(os.environ.get("LOCAL_RANK", 0)), type=int)
     p.add_argument("--log_dir", default="./output", type=str)
+    p.add_argument("--exp_name", default="grove", type=str)
+    p.add_argument("--start_epoch", default=0, type=int)
+    p.add_argument("--eval_only", action="store_true", default=False)
+    p.add_argument("--auto_resume", action="store_true", default=False)
+    p.add_argument("--resume", default="", type=str)
+    p.add_argument("--grove_weights", default="", type=str, help="consolidated pytorch_model.bin / HF directory to start from")
+    p.add_argument("--val_batches", default=2, type=int, help="validation batches per epoch (synthetic loader)")
+    # synthetic-data stand-ins for the dataset arguments (datasets / tokenizer are out of scope)
+    p.add_argument("--dims", default="full", choices=["full", "tiny"], help="architecture size when no checkpoint gives it")
+    p.add_argument("--text_len", default=128, type=int)
+    p.add_argument("--n_det", default=3, type=int)
     return p.parse_args(argv)
 
 
@@ -69,6 +80,13 @@ class WarmupDecayLR:
     def __init__(self, lr, total_steps, warmup_steps=100):
         self.lr, self.total, self.warm = lr, max(total_steps, 1), warmup_steps
         self.last = 0.0
+
+    def for_update(self, k):
+        """Learning rate of the k-th optimizer update (k = 1, 2, ...) under DeepSpeed's calling order: the scheduler is built with
+        last_batch_iteration = -1, which writes warmup_min_lr (0, train.py:472) into the optimizer — the value update 1 uses —
+        and the engine steps the scheduler AFTER every optimizer update (iteration 0 after update 1, gamma(0) = 0 for update 2,
+        gamma(1) for update 3, ...). So update k runs with gamma(k - 2): the first two updates have lr = 0."""
+        return self.get(max(k - 2, 0))
 
     def get(self, step):
         if step < self.warm:
@@ -134,6 +152,7 @@ class GroveEngine:
         self.module = model
         self.args = args
         self.dev = model.dev
+        torch.cuda.set_device(self.dev)  # what deepspeed.initialize() did for the reference: this rank's launches go to ITS GPU
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.names = model.trainable
@@ -160,11 +179,24 @@ class GroveEngine:
         self.global_step = 0
         self.micro = 0
         self.clip = 1.0  # "gradient_clipping": 1.0 (train.py:475)
+        self._sumsq = torch.zeros(1, dtype=torch.float32, device=g.device)
+        self._norm = torch.zeros(1, dtype=torch.float32, device=g.device)
         # gradient exchange dtype: bf16 like DeepSpeed under bf16 (engine.communication_data_type), or torch.float32
         self.comm_buf = torch.empty(g.numel(), dtype=torch.bfloat16, device=g.device) if self.world > 1 and comm_dtype == torch.bfloat16 else None
         self.bucket_elems = bucket_bytes // (2 if self.comm_buf is not None else 4)
         self.comm_stream = torch.cuda.Stream(device=self.dev) if self.world > 1 else None
         self.training = True
+        self.broadcast_parameters()
+
+    def broadcast_parameters(self):
+        """Replicas start from rank 0's values (DeepSpeed broadcasts the module's parameters at initialize() and after a
+        checkpoint load): the fp32 master copy and the bf16 trainable tensors; frozen tensors come from the same checkpoint /
+        initialiser on every rank and are not sent."""
+        if self.world <= 1:
+            return
+        dist.broadcast(self.master, src=0)
+        for _, _, _, w in self.slices:
+            dist.broadcast(w, src=0)
 
     # ---- DeepSpeed-engine surface
     def __call__(self, **batch):
@@ -196,40 +228,59 @@ class GroveEngine:
             self._allreduce()
         g = self.module._flat_grad
         scale = 1.0 / (self.world * a.grad_accumulation_steps)
-        # global-norm clipping at 1.0: clip factor folded into the AdamW grad_scale (one host sync per step)
-        norm = math.sqrt(float(ops.sumsq(g)[0])) * scale
-        if norm > self.clip:
-            scale *= self.clip / (norm + 1e-6)
+        # global-norm clipping at 1.0: the sum of squares stays on the device and the AdamW kernel derives the clip factor from it
+        # (no host read-back in the step: the host keeps queueing the next step's launches while this one runs)
+        self._sumsq.zero_()
+        ops.sumsq(g, out=self._sumsq)
         self.global_step += 1
-        lr = self.scheduler.get(self.global_step)
+        lr = self.scheduler.for_update(self.global_step)
         # one multi-tensor launch (DeepSpeed's FusedAdam does the same): 112 per-tensor launches left 0.9 ms of gaps per step
         ops.adamw_step_multi(self.master, g, self.m, self.v, self._seg_off, self._seg_len, self._seg_ptr, lr, a.beta1, a.beta2, 1e-8,
-                             a.wd, scale, self.global_step)
+                             a.wd, scale, self.global_step, sumsq=self._sumsq, clip=self.clip, norm_out=self._norm)
         self.module.sam.refresh_adapter_scalars()
-        self.last_grad_norm = norm
 
-    def save_checkpoint(self, save_dir, tag=None):
+    @property
+    def last_grad_norm(self):
+        """Pre-clip global gradient norm of the last step (a device scalar; reading it synchronises)."""
+        return float(self._norm[0])
+
+    def save_checkpoint(self, save_dir, tag=None, consolidated=True):
+        """Engine state for resume (`<tag>.pt` + `latest`, like DeepSpeed's tag directory) AND, beside it, the consolidated fp32
+        `pytorch_model.bin` under the reference's key names — what `zero_to_fp32.py ./ pytorch_model.bin` makes out of a DeepSpeed
+        checkpoint (infer_eval_iground.sh:11-15), so the reference's inference scripts read this directory without that step."""
         if self.rank == 0:
             os.makedirs(save_dir, exist_ok=True)
             tag = tag or f"global_step{self.global_step}"
             torch.save({"module": {k: v.cpu() for k, v in self.module.state_dict().items()}, "master": self.master.cpu(),
-                        "exp_avg": self.m.cpu(), "exp_avg_sq": self.v.cpu(), "global_step": self.global_step},
+                        "exp_avg": self.m.cpu(), "exp_avg_sq": self.v.cpu(), "global_step": self.global_step,
+                        "trainable": list(self.names), "world": self.world},
                        os.path.join(save_dir, tag + ".pt"))
+            if consolidated:
+                from .checkpoint import save_grove_weights
+                save_grove_weights(self.module, os.path.join(save_dir, "pytorch_model.bin"), engine=self)
             with open(os.path.join(save_dir, "latest"), "w") as f:
                 f.write(tag)
         if dist.is_initialized():
             dist.barrier()
 
     def load_checkpoint(self, load_dir):
+        """Resume: every rank reads the file (one node, page cache), validates it against THIS engine's layout, and the replicas
+        are re-synchronised from rank 0 afterwards."""
         with open(os.path.join(load_dir, "latest")) as f:
             tag = f.readlines()[0].strip()
-        ck = torch.load(os.path.join(load_dir, tag + ".pt"), map_location="cpu")
+        ck = torch.load(os.path.join(load_dir, tag + ".pt"), map_location="cpu", weights_only=True)
+        if ck["master"].numel() != self.master.numel() or list(ck.get("trainable", self.names)) != list(self.names):
+            raise RuntimeError(f"{load_dir}/{tag}.pt was written for another trainable set / architecture "
+                               f"({ck['master'].numel()} vs {self.master.numel()} optimizer elements)")
         self.module.load_state_dict(ck["module"])
         self.master.copy_(ck["master"])
         self.m.copy_(ck["exp_avg"])
         self.v.copy_(ck["exp_avg_sq"])
-        self.global_step = ck["global_step"]
-        return load_dir, {}
+        self.global_step = int(ck["global_step"])
+        self.broadcast_parameters()
+        if dist.is_initialized():
+            dist.barrier()
+        return load_dir, {"global_step": self.global_step}
 
 
 class AverageMeter:
@@ -289,13 +340,23 @@ def validate_model_performance(val_iter, engine: GroveEngine, n_batches, args):
     meters = {k: AverageMeter(k) for k in ("loss", "ce_loss", "giou_loss", "l1_loss", "temp_objectness_loss")}
     engine.eval()
     was = engine.module._train_mode
-    for _ in range(n_batches):
-        out = engine.module(**next(val_iter))
-        for k, m in meters.items():
-            if k in out:
-                m.update(float(out[k]), 1)
-    engine.module._ctx = None
-    engine.module._train_mode = was
+    engine.module._train_mode = False  # loss only: no tape, no saved activations, no dlogits
+    try:
+        for _ in range(n_batches):
+            out = engine.module(**next(val_iter))
+            for k, m in meters.items():
+                if k in out:
+                    m.update(float(out[k]), 1)
+    finally:
+        engine.module._ctx = None
+        engine.module._train_mode = was
+    if engine.world > 1:  # the reference all-reduces every meter (utils/utils.py:72); here all of them in ONE collective
+        t = torch.tensor([x for m in meters.values() for x in (m.sum, m.count)], dtype=torch.float32, device=engine.dev)
+        dist.all_reduce(t)
+        t = t.tolist()
+        for i, m in enumerate(meters.values()):
+            m.sum, m.count = t[2 * i], t[2 * i + 1]
+            m.avg = m.sum / max(m.count, 1e-5)
     return {k: m.avg for k, m in meters.items()}
 
 
@@ -304,3 +365,97 @@ def save_checkpoint(engine: GroveEngine, args, epoch, metric_name, metric_value,
     if is_best:
         save_dir = os.path.join(args.log_dir, "ckpt_model_best")
         engine.save_checkpoint(save_dir)
+
+
+def synthetic_loader(dims, args, device, rank, world, seed0=0):
+    """Stand-in for the DataLoader over HowToGround / iGround with a DistributedSampler (train.py:440-463): an endless iterator of
+    collate dicts (dataset/dataset.py:64-70) whose clip indices are sharded over the ranks like `shard_clips`. Datasets, video
+    decoding and the tokenizer are out of scope; the content is synthetic, the shapes are the real ones."""
+    from .synthetic import synthetic_batch
+    step = 0
+    while True:
+        clip0 = (step * world + rank) * args.batch_size
+        b = synthetic_batch(dims, B=args.batch_size, T=args.num_frames, L=args.text_len, n_det=args.n_det, seed=seed0 + clip0,
+                            device=device, dtype=torch.bfloat16)
+        yield b.as_kwargs(inference=False)
+        step += 1
+
+
+def resume_training_from_checkpoint(engine, args, log=print):
+    """train.py:489-500: --auto_resume picks `<log_dir>/ckpt_model_last_epoch` / `ckpt_model_best` when present, --resume names a
+    directory; the epoch to continue from is derived from the restored step count."""
+    path = args.resume
+    if not path and args.auto_resume:
+        for name in ("ckpt_model_last_epoch", "ckpt_model_best"):
+            cand = os.path.join(args.log_dir, name)
+            if os.path.exists(os.path.join(cand, "latest")):
+                path = cand
+                break
+    if path:
+        engine.load_checkpoint(path)
+        args.start_epoch = engine.global_step // max(args.steps_per_epoch, 1)
+        log(f"Resume training from {path}, start from epoch {args.start_epoch}")
+
+
+def main(args, dims=None, log=print):
+    """train.py:609-680 for the hot path: model -> (optional fine-tune weights) -> engine -> resume -> epochs of
+    train() + loss validation + keep-the-best checkpointing, one process per GPU (launch with
+    `python -m torch.distributed.run --nproc-per-node N -m grove_amd.train ...`, or one plain process for N = 1)."""
+    from .synthetic import FULL, TINY, synthetic_state_dict
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    device = torch.device("cuda", args.local_rank)
+    torch.cuda.set_device(device)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = os.environ.get("GROVE_BACKEND", "nccl")  # "nccl" IS RCCL on ROCm; gloo only for one-GPU rehearsals
+        dist.init_process_group(backend, **({"device_id": device} if backend == "nccl" else {}))
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    if dims is None:
+        dims = FULL if args.dims == "full" else TINY
+    if args.grove_weights:
+        log(f"Fine-tuning using GROVE weights from {args.grove_weights}.")
+        from .checkpoint import dims_from_checkpoint, read_state_dict
+        sd = read_state_dict(args.grove_weights)
+        dims = dims_from_checkpoint(args.grove_weights, sd, base=dims)
+        model = initialize_model(args, dims, state_dict=None, device=device)
+        from .checkpoint import load_grove_weights
+        load_grove_weights(model, args.grove_weights, sd=sd)
+        del sd
+    else:
+        sd = synthetic_state_dict(dims, device=device, dtype=torch.bfloat16)  # no checkpoints offline: deterministic random init
+        model = initialize_model(args, dims, state_dict=sd, device=device)
+        del sd
+    prepare_model_for_training(model)
+    engine = GroveEngine(model, args)
+    resume_training_from_checkpoint(engine, args, log)
+    train_iter = synthetic_loader(dims, args, device, rank, world, seed0=0)
+    val_iter = synthetic_loader(dims, args, device, rank, world, seed0=10 ** 6)
+    if args.eval_only:
+        val = validate_model_performance(val_iter, engine, args.val_batches, args)
+        if rank == 0:
+            log(f"Validation: {val}")
+        return val
+    best_val_loss = float("inf")
+    val = None
+    for epoch in range(args.start_epoch, args.epochs):
+        train_iter = train(train_iter, engine, epoch, args, log)
+        if dist.is_initialized():
+            dist.barrier()
+        val = validate_model_performance(val_iter, engine, args.val_batches, args)
+        cur = val["loss"]
+        is_best = cur < best_val_loss
+        best_val_loss = min(cur, best_val_loss)
+        if rank == 0:
+            log(f"Epoch: {epoch}, Current Validation Loss: {cur:.4f}, Best Validation Loss: {best_val_loss:}")
+        save_checkpoint(engine, args, epoch, "loss", f"{cur:.4f}", is_best)
+    return {"best_val_loss": best_val_loss, "last_val": val, "global_step": engine.global_step}
+
+
+if __name__ == "__main__":
+    import sys
+    _args = parse_args(sys.argv[1:])
+    _args.local_rank = int(os.environ.get("LOCAL_RANK", _args.local_rank))
+    torch.manual_seed(42)
+    main(_args)
+    if dist.is_initialized():
+        dist.destroy_process_group()

@@ -495,10 +495,14 @@ int grove_adamw_step(float* master, void* model_bf16, const float* grad, float* 
 /* The same step over all trainable tensors in ONE launch (DeepSpeed's multi-tensor FusedAdam, train.py:466-475): the fp32
  * state (master / grad / m / v) is one flat buffer of `total` elements in which tensor s occupies
  * [seg_off[s], seg_off[s] + seg_len[s]) (16-byte aligned starts, zero-filled gaps); model_bf16[s] is that tensor's bf16
- * working copy (NULL = none). seg_off / seg_len / model_bf16 are DEVICE arrays of nseg entries, seg_off ascending. */
+ * working copy (NULL = none). seg_off / seg_len / model_bf16 are DEVICE arrays of nseg entries, seg_off ascending.
+ * Global-norm clipping ("gradient_clipping": 1.0, train.py:475) without a host round trip: sumsq (device, NULL = off) holds the
+ * sum of squares of `grad` (grove_sumsq_f32); the kernel scales by grad_scale * min(1, clip / (sqrt(sumsq) * grad_scale + 1e-6))
+ * and writes the pre-clip norm sqrt(sumsq) * grad_scale to norm_out (device, may be NULL). */
 int grove_adamw_step_multi(float* master, const float* grad, float* m, float* v, const int64_t* seg_off, const int64_t* seg_len,
                            void* const* model_bf16, int32_t nseg, int64_t total, float lr, float beta1, float beta2, float eps,
-                           float weight_decay, float grad_scale, int32_t step, void* stream);
+                           float weight_decay, float grad_scale, int32_t step, const float* sumsq, float clip, float* norm_out,
+                           void* stream);
 /* sum of squares of a flat f32 buffer into out[0] (+=), for grad clipping */
 int grove_sumsq_f32(const float* x, float* out, int64_t n, void* stream);
 

@@ -482,8 +482,9 @@ def loss_components(ce_loss, boxes, logits, gt_boxes, gt_vis, w_ce=1.0, w_box=1.
 
 
 def model_forward(sd, d, global_enc_images, grounding_enc_images, input_ids, labels, attention_masks, bboxes_list=None,
-                  temp_objectness_labels_list=None, original_size_list=None, inference=False, **_):
-    """GROVEForCausalLM.model_forward GROVE.py:156-198 (training: losses; inference: boxes + logits)."""
+                  temp_objectness_labels_list=None, original_size_list=None, inference=False, pe_dtype=torch.float32, **_):
+    """GROVEForCausalLM.model_forward GROVE.py:156-198 (training: losses; inference: boxes + logits).
+    pe_dtype: dtype the dense positional encoding is evaluated in (bf16 reproduces the reference under model.to(bf16), Q10)."""
     image_embeddings = sam_image_encoder(sd, d, grounding_enc_images)
     mask = det_token_mask(d, input_ids)
     feats, _ = encode_images(sd, d, global_enc_images)
@@ -496,7 +497,7 @@ def model_forward(sd, d, global_enc_images, grounding_enc_images, input_ids, lab
         hidden = llama_forward(sd, d, embeds, new_mask)
         ce, _ = lm_loss(sd, hidden, new_labels)
     emb = pred_embeddings(sd, d, hidden, mask)
-    pe = dense_pe(sd, d)
+    pe = dense_pe(sd, d, dtype=pe_dtype).float()
     boxes, logits, flat_box, flat_obj = decode_boxes(sd, d, emb, image_embeddings, original_size_list, pe, inference)
     if inference:
         return {"pred_bboxes": boxes, "logits_temp_objectness": logits, "flat_boxes": flat_box, "flat_logits": flat_obj,

@@ -63,7 +63,52 @@ def reference_greedy(model, d, feats, fouts, dtype, ids, max_new):
     return ids, hidden
 
 
+CLIP_ALPHA = 0.1
+
+
+def clip_alpha_state_dict(sd, d, alpha=CLIP_ALPHA):
+    """The synthetic weights with every CLIP adapter's alpha set to `alpha` (the reference initialises them to 0,
+    modeling_clip.py:596, which makes the adapters an identity; a non-zero value exercises the 16x36 reshape, the Conv3d and
+    the tanh(alpha)*relu(.)+x epilogue of modeling_clip.py:599-611, 705-707)."""
+    sd2 = dict(sd)
+    for j in range(d.clip_layers // 3):
+        k = f"model.vision_tower.vision_tower.vision_model.encoder.adapters.{j}.alpha"
+        sd2[k] = torch.full_like(sd[k], alpha)
+    return sd2
+
+
+def case_clip_adapter_alpha(model, sd, d):
+    sd2 = clip_alpha_state_dict(sd, d)
+    model.load_state_dict(sd2, strict=False)
+    model.eval()
+    batch = synthetic_batch(d, B=2, T=8, L=24, n_det=1, seed=6)
+    with torch.no_grad():
+        feats, fouts = model(mode="encode_images", images=batch.global_enc_images)
+        hs = fouts.hidden_states
+    gold = {"alpha": np.array(CLIP_ALPHA), "image_features": npf(feats[:, ::TOK_STRIDE]), "clip_hidden_m2": npf(hs[-2][:, ::TOK_STRIDE]),
+            "clip_hidden_1": npf(hs[1][:, ::TOK_STRIDE]), "clip_hidden_4": npf(hs[4][:, ::TOK_STRIDE]), "tok_stride": np.array(TOK_STRIDE)}
+    np.savez_compressed(os.path.join(OUT, "tiny_clip_adapter_alpha_seed6.npz"), **gold)
+    with torch.no_grad():
+        of, ohs = O.encode_images(sd2, d, batch.global_enc_images)
+        of0, _ = O.encode_images(sd, d, batch.global_enc_images)
+    print("case E (CLIP adapters, alpha = 0.1):")
+    worst = report("image_features", of, feats)
+    worst = max(worst, report("clip hidden[-2]", ohs[-1], hs[-2]))
+    worst = max(worst, report("clip hidden[1]", ohs[1], hs[1]))
+    worst = max(worst, report("clip hidden[4]", ohs[4], hs[4]))
+    moved = (of - of0).abs().max().item()
+    print(f"  adapters change the projected features by up to {moved:.3e} (must be far above the parity tolerance)")
+    assert moved > 1e-2
+    model.load_state_dict(sd, strict=False)
+    return worst
+
+
 def main():
+    if "--only-clip-alpha" in sys.argv:
+        model, sd = R.build_reference_model(TINY)
+        w = case_clip_adapter_alpha(model, sd, TINY)
+        assert w < 2e-3, "oracle does not reproduce the reference"
+        return
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     d = TINY
@@ -208,6 +253,9 @@ def main():
     print("case D (literal T=16):")
     worst = max(worst, report("objectness logits", flat_list(o["logits_temp_objectness"]), flat_list(res["logits_temp_objectness"])))
     model.config.num_frames = 8
+
+    # ------------------------------------------------------------------ case E: CLIP adapters switched on (alpha != 0)
+    worst = max(worst, case_clip_adapter_alpha(model, sd, d))
     print(f"worst normalised oracle-vs-reference error: {worst:.3e}")
     assert worst < 2e-3, "oracle does not reproduce the reference"
     sizes = {f: os.path.getsize(os.path.join(OUT, f)) for f in sorted(os.listdir(OUT)) if f.endswith(".npz")}

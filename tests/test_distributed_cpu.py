@@ -56,3 +56,7 @@ def test_warmup_decay_lr():
     s = WarmupDecayLR(3e-4, 1000, 100)
     assert s.get(0) == 0.0 and abs(s.get(50) - 1.5e-4) < 1e-12 and abs(s.get(100) - 3e-4) < 1e-12
     assert abs(s.get(550) - 1.5e-4) < 1e-12 and s.get(1000) == 0.0
+    # DeepSpeed's calling order (scheduler stepped after the optimizer, starting from warmup_min_lr): updates 1 and 2 run at 0,
+    # update k at gamma(k - 2)
+    assert s.for_update(1) == 0.0 and s.for_update(2) == 0.0 and abs(s.for_update(3) - 3e-6) < 1e-15
+    assert abs(s.for_update(102) - 3e-4) < 1e-12

@@ -77,12 +77,14 @@ def test_inference_matches_oracle_and_golden(setup, dev):
         ref = O.model_forward(sd, d, **kwo)
     assert rel(out["hidden"], ref["hidden"]) < 4e-2, "llama hidden"
     l1 = (out["flat_boxes"].cpu() - ref["flat_boxes"]).abs().mean().item()
-    assert l1 < 2e-3, f"box L1 {l1}"
+    assert l1 < 1e-3, f"box L1 {l1}"  # north_star: boxes within 1e-3 L1 (measured 9.6e-4)
     dl = (out["flat_logits"].cpu() - ref["flat_logits"]).abs().max().item()
     assert dl < 5e-2, f"objectness logit err {dl}"
     # golden vectors of the reference itself (fp32 weights): same bounds + bf16 weight rounding
     g = np.load(os.path.join(G, "tiny_infer_B2_T8_seed2.npz"))
     l1g = np.abs(out["flat_boxes"].cpu().numpy() - g["flat_boxes_normalised"]).mean()
+    # (the golden comes from the reference's fp32 WEIGHTS; the kernels and the oracle above see them rounded to bf16, which alone
+    # moves the boxes by ~2e-3: this bound checks the fixture, the 1e-3 bound above checks the arithmetic)
     assert l1g < 4e-3, f"box L1 vs reference golden {l1g}"
     # structure of the returned lists (GROVE.py:297-331)
     assert len(out["pred_bboxes"]) == 2 and len(out["pred_bboxes"][0]) == 8
@@ -197,7 +199,7 @@ def test_greedy_evaluate_matches_golden(setup, dev):
         emb_o = O.sam_image_encoder(sd, d, si.float())
         _, boxes_o, logits_o, _, _ = O.evaluate(sd, d, feats_o, emb_o, forced[:, :-1], batch.original_size_list, max_tokens_new=1)
     assert (_flat(logits) - _flat(logits_o)).abs().max().item() < 5e-2
-    assert (_flat(boxes) / 640 - _flat(boxes_o) / 640).abs().mean().item() < 2e-3
+    assert (_flat(boxes) / 640 - _flat(boxes_o) / 640).abs().mean().item() < 1e-3
 
 
 def test_literal_T16_row_indexing(dev):
@@ -296,7 +298,7 @@ def test_full_width_towers_match_oracle(dev):
         ref = O.model_forward(sd_r, d, **kwo)
     assert rel(out["hidden"], ref["hidden"]) < 2e-2, "llama hidden"  # 0.8e-2
     l1 = (out["flat_boxes"].cpu() - ref["flat_boxes"]).abs().mean().item()
-    assert l1 < 2e-3, f"box L1 {l1}"  # 8.3e-4
+    assert l1 < 1e-3, f"box L1 {l1}"  # north_star: boxes within 1e-3 L1 (measured 8.3e-4)
 
 
 def test_no_det_tokens_and_invisible_objects(setup, dev):

@@ -94,3 +94,27 @@ def test_literal_T16_row_indexing(sd):
     with torch.no_grad():
         out = O.model_forward(sd, d16, **batch.as_kwargs(inference=True))
     near(flat(out["logits_temp_objectness"]), g["flat_logits"], what="literal T=16 logits")
+
+
+def clip_alpha_state_dict(sd, alpha):
+    """Synthetic weights with every CLIP adapter switched on (alpha != 0): same rule as oracle/refgen/make_goldens.py."""
+    sd2 = dict(sd)
+    for j in range(TINY.clip_layers // 3):
+        k = f"model.vision_tower.vision_tower.vision_model.encoder.adapters.{j}.alpha"
+        sd2[k] = torch.full_like(sd[k], alpha)
+    return sd2
+
+
+def test_clip_adapter_alpha_nonzero(sd):
+    """a4: SpatioTemporalConvAdapter of the CLIP tower with alpha != 0 (16x36 reshape, Conv3d, tanh(alpha)*relu+x;
+    modeling_clip.py:591-611, 705-707) against the reference's own output."""
+    g = np.load(os.path.join(G, "tiny_clip_adapter_alpha_seed6.npz"))
+    ts = int(g["tok_stride"])
+    sd2 = clip_alpha_state_dict(sd, float(g["alpha"]))
+    batch = synthetic_batch(TINY, B=2, T=8, L=24, n_det=1, seed=6)
+    with torch.no_grad():
+        feats, hs = O.encode_images(sd2, TINY, batch.global_enc_images)
+    near(feats[:, ::ts], g["image_features"], what="image_features")
+    near(hs[-1][:, ::ts], g["clip_hidden_m2"], what="clip hidden[-2]")
+    near(hs[1][:, ::ts], g["clip_hidden_1"], what="clip hidden[1]")
+    near(hs[4][:, ::ts], g["clip_hidden_4"], what="clip hidden[4]")

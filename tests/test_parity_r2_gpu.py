@@ -1,0 +1,327 @@
+"""Round-2 parity cases (VERDICT r1 "next round" 1 and 6), HIP path through the C-ABI vs the CPU oracle / the reference's goldens:
+
+  * config 3's clip fold: a T=16, B=2 training batch (= 4 eight-frame windows with repeated text) against the oracle run on the
+    4 equivalent T=8 window samples — five loss terms and every trainable gradient;
+  * the CLIP tower's SpatioTemporalConvAdapter with alpha != 0 (modeling_clip.py:591-611, 705-707): tiny dims against the
+    reference's own golden, real widths against the oracle;
+  * the product default pe_dtype=bf16 (quirk Q10, prompt_encoder.py:198-229) against the oracle's bf16 op sequence;
+  * the `.generate()` / `forward(past_key_values=...)` / `from_pretrained` surface (GROVE.py:138-140, 418-426; llava_llama.py:144-180).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+bf = torch.bfloat16
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-6)).item()
+
+
+def to_dev(batch, dev):
+    kw = batch.as_kwargs()
+    for k in ("global_enc_images", "grounding_enc_images"):
+        kw[k] = kw[k].to(dev).to(bf)
+    for k in ("input_ids", "labels", "attention_masks", "offset"):
+        kw[k] = kw[k].to(dev)
+    return kw
+
+
+def window_batch_kwargs(batch, G_):
+    """The T = 8*G batch as the B*G independent 8-frame window samples the reference's sliding-window inference would feed
+    (infer_iground.py:245-259): window (b, g) = frames 8g..8g+7 of clip b with clip b's text — built here with plain slicing,
+    independently of GROVEForCausalLM._windows."""
+    kw = batch.as_kwargs()
+    B = batch.input_ids.shape[0]
+
+    def frames(x):
+        return torch.cat([x[b:b + 1, :, 8 * g:8 * g + 8] for b in range(B) for g in range(G_)], 0)
+    out = dict(kw)
+    out["global_enc_images"] = frames(kw["global_enc_images"].to(bf).float())
+    out["grounding_enc_images"] = frames(kw["grounding_enc_images"].to(bf).float())
+    for k in ("input_ids", "labels", "attention_masks"):
+        out[k] = torch.cat([kw[k][b:b + 1] for b in range(B) for _ in range(G_)], 0)
+    out["bboxes_list"] = [kw["bboxes_list"][b][8 * g:8 * g + 8] for b in range(B) for g in range(G_)]
+    out["temp_objectness_labels_list"] = [kw["temp_objectness_labels_list"][b][8 * g:8 * g + 8] for b in range(B) for g in range(G_)]
+    out["original_size_list"] = [kw["original_size_list"][b] for b in range(B) for _ in range(G_)]
+    out["offset"] = torch.arange(B * G_ + 1)
+    return out
+
+
+def test_T16_B2_training_matches_oracle_on_windows(dev):
+    """BASELINE config 3 (T=16, per-GPU batch 2) at tiny dims: losses + all trainable gradients."""
+    from grove_amd import GROVEForCausalLM
+    from grove_amd.model.GROVE import trainable_names
+    from grove_amd.synthetic import TINY, synthetic_batch, synthetic_state_dict
+    from oracle import grove_oracle as O
+    d = TINY
+    sd = synthetic_state_dict(d)
+    names = trainable_names(d)
+    model = GROVEForCausalLM(dims=d, device=dev, state_dict=sd, det_token_idx=d.det_token_idx, num_frames=8,
+                             pe_dtype=torch.float32, train=True)
+    batch = synthetic_batch(d, B=2, T=16, L=48, n_det=2, seed=7, ragged=True)
+    kw = to_dev(batch, dev)
+    model.zero_grad()
+    out = model(**kw)
+    model.backward(out["loss"])
+    # per-clip list structure of the outputs: T entries per clip, window-major inside (GROVE.py:297-331 regrouped)
+    assert out["flat_boxes"].shape[0] == 2 * 16 * 2
+    sdg = {k: v.to(bf).float().requires_grad_(k in names) for k, v in sd.items()}
+    ref = O.model_forward(sdg, d, **window_batch_kwargs(batch, 2))
+    ref["loss"].backward()
+    for k in ("ce_loss", "giou_loss", "l1_loss", "temp_objectness_loss", "loss"):
+        a, b = float(out[k]), float(ref[k])
+        assert abs(a - b) <= 2e-2 * max(1.0, abs(b)), f"{k}: {a} vs {b}"
+    l1 = (out["flat_boxes"].cpu() - ref["flat_boxes"].detach()).abs().mean().item()
+    assert l1 < 1e-3, f"box L1 {l1}"
+    bad = []
+    for n in names:
+        g = model._grad[n].detach().float().cpu()
+        r = sdg[n].grad
+        if n.endswith("conv3d.weight"):
+            Co, Ci = r.shape[0], r.shape[1]
+            g = g.view(Co, 3, 3, 3, Ci).permute(0, 4, 1, 2, 3)
+        g = g.reshape(r.shape)
+        if r.norm() < 1e-6:
+            assert g.norm() < 1e-3, (n, float(g.norm()))
+            continue
+        cos = torch.nn.functional.cosine_similarity(g.flatten(), r.flatten(), dim=0).item()
+        scale = (g.norm() / r.norm().clamp_min(1e-12)).item()
+        lo, hi = (0.85, 1.15) if r.numel() == 1 else (0.9, 1.1)
+        if not (cos > 0.98 and lo < scale < hi):
+            bad.append((n, round(cos, 4), round(scale, 4), float(r.norm())))
+    assert not bad, f"{len(bad)}/{len(names)} gradients off: {bad[:12]}"
+    # inference on the same T=16 batch returns B lists of T frames
+    kw["inference"] = True
+    inf = model(**kw)
+    assert len(inf["pred_bboxes"]) == 2 and all(len(x) == 16 for x in inf["pred_bboxes"])
+
+
+def _alpha_sd(sd, d, alpha):
+    sd2 = dict(sd)
+    for j in range(d.clip_layers // 3):
+        k = f"model.vision_tower.vision_tower.vision_model.encoder.adapters.{j}.alpha"
+        sd2[k] = torch.full_like(sd[k], alpha)
+    return sd2
+
+
+def test_clip_adapter_alpha_nonzero_tiny_vs_reference_golden(dev):
+    from grove_amd import GROVEForCausalLM
+    from grove_amd.synthetic import TINY, synthetic_batch, synthetic_state_dict
+    from oracle import grove_oracle as O
+    d = TINY
+    g = np.load(os.path.join(G, "tiny_clip_adapter_alpha_seed6.npz"))
+    ts = int(g["tok_stride"])
+    sd = _alpha_sd(synthetic_state_dict(d), d, float(g["alpha"]))
+    model = GROVEForCausalLM(dims=d, device=dev, state_dict=sd, det_token_idx=d.det_token_idx, num_frames=8)
+    assert all(A["active"] for A in model.clip.adapters), "the adapter branch must run"
+    batch = synthetic_batch(d, B=2, T=8, L=24, n_det=1, seed=6)
+    gi = batch.global_enc_images.to(bf)
+    feats, outs = model(mode="encode_images", images=gi.to(dev))
+    sd_r = {k: v.to(bf).float() for k, v in sd.items()}
+    with torch.no_grad():
+        feats_o, hs_o = O.encode_images(sd_r, d, gi.float())
+        feats_0, _ = O.encode_images(_alpha_sd(sd_r, d, 0.0), d, gi.float())
+    assert rel(feats_0, feats_o) > 5e-2, "the adapters must move the features far beyond the tolerance"
+    assert rel(outs.hidden_states[-1], hs_o[-1]) < 3e-2, "clip hidden[-2] vs oracle"
+    assert rel(feats, feats_o) < 3e-2, "projected features vs oracle"
+    # the reference's own output (fp32 weights; bf16 weight rounding on top)
+    assert rel(feats[:, ::ts], torch.from_numpy(g["image_features"])) < 4e-2, "projected features vs reference golden"
+    assert rel(outs.hidden_states[-1][:, ::ts], torch.from_numpy(g["clip_hidden_m2"])) < 4e-2, "clip hidden[-2] vs reference golden"
+
+
+def test_clip_adapter_alpha_nonzero_full_width(dev):
+    """Real CLIP width (1024 channels, 27 x 1024 implicit-GEMM K, 16 x 36 grid), 5 layers run = adapters after layers 0 and 3."""
+    import dataclasses
+    from grove_amd.model.clip import ClipTower
+    from grove_amd.synthetic import FULL, synthetic_batch, synthetic_state_dict
+    from oracle import grove_oracle as O
+    from grove_amd.synthetic import param_shapes
+    d = dataclasses.replace(FULL, clip_layers=6)  # the tower runs clip_layers - 1 = 5 layers (hidden_states[-2]); 6 // 3 = 2 adapters
+    names = {n for n in param_shapes(d) if "vision_tower" in n}
+    sd = _alpha_sd(synthetic_state_dict(d, names=names), d, 0.1)
+    k1 = "model.vision_tower.vision_tower.vision_model.encoder.adapters.1.alpha"
+    sd[k1] = torch.full_like(sd[k1], -0.2)
+    sd_dev = {k: v.to(dev).to(bf) for k, v in sd.items()}
+    tower = ClipTower(sd_dev, d, dev)
+    assert tower.adapters[0]["active"] and tower.adapters[1]["active"]
+    batch = synthetic_batch(d, B=1, T=8, L=24, n_det=1, seed=8)
+    gi = batch.global_enc_images.to(bf)
+    pooled, hs = tower.forward(gi.to(dev))
+    sd_r = {k: v.to(bf).float() for k, v in sd.items()}
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    with torch.no_grad():
+        pooled_o, hs_o = O.clip_vision_tower(sd_r, d, gi.float())
+    assert rel(hs, hs_o[-1]) < 2e-2, "clip hidden[-2]"
+    assert rel(pooled, pooled_o) < 2e-2, "pooled features"
+
+
+def test_dense_pe_bf16_default(dev):
+    """Quirk Q10: the product default computes the dense positional encoding with the reference's op sequence in bf16
+    (model.to(bf16) casts the Gaussian matrix, prompt_encoder.py:198-229)."""
+    from grove_amd import GROVEForCausalLM
+    from grove_amd.synthetic import TINY, synthetic_batch, synthetic_state_dict
+    from oracle import grove_oracle as O
+    d = TINY
+    sd = synthetic_state_dict(d)
+    sd_r = {k: v.to(bf).float() for k, v in sd.items()}
+    model = GROVEForCausalLM(dims=d, device=dev, state_dict=sd, det_token_idx=d.det_token_idx, num_frames=8)  # pe_dtype default
+    assert model.pe_dtype == torch.bfloat16
+    pe = model(mode="get_dense_pe")
+    pe_o = O.dense_pe(sd_r, d, dtype=torch.bfloat16)
+    assert pe.dtype == torch.bfloat16 and tuple(pe.shape) == tuple(pe_o.shape)
+    # same op sequence in the same dtype: sin/cos of identical bf16 arguments -> at most one bf16 ulp of libm difference
+    assert (pe.float().cpu() - pe_o.float()).abs().max().item() <= 2 ** -7
+    assert (pe.float().cpu() - O.dense_pe(sd_r, d).float()).abs().max().item() > 1e-2, "bf16 PE differs visibly from the fp32 PE"
+    # the boxes decoded against the bf16 PE match the oracle decoding against ITS bf16 PE
+    batch = synthetic_batch(d, B=2, T=8, L=40, n_det=3, seed=2)
+    kw = to_dev(batch, dev)
+    kw["inference"] = True
+    out = model(**kw)
+    kwo = batch.as_kwargs(inference=True)
+    kwo["global_enc_images"] = kwo["global_enc_images"].to(bf).float()
+    kwo["grounding_enc_images"] = kwo["grounding_enc_images"].to(bf).float()
+    with torch.no_grad():
+        ref = O.model_forward(sd_r, d, pe_dtype=torch.bfloat16, **kwo)
+    l1 = (out["flat_boxes"].cpu() - ref["flat_boxes"]).abs().mean().item()
+    assert l1 < 1e-3, f"box L1 with the bf16 PE {l1}"
+
+
+# ---------------------------------------------------------------------------------------------- generate surface (row g)
+@pytest.fixture(scope="module")
+def gen_setup(dev):
+    from grove_amd import GROVEForCausalLM
+    from grove_amd.synthetic import TINY, synthetic_batch, synthetic_state_dict
+    sd = synthetic_state_dict(TINY)
+    model = GROVEForCausalLM(dims=TINY, device=dev, state_dict=sd, det_token_idx=TINY.det_token_idx, num_frames=8,
+                             pe_dtype=torch.float32)
+    g = np.load(os.path.join(G, "tiny_evaluate_B2_T8_seed3.npz"))
+    batch = synthetic_batch(TINY, B=2, T=8, L=24, n_det=1, seed=3)
+    prompt = batch.input_ids[:, :int(g["prompt_len"])].clone().to(dev)
+    feats, outs = model(mode="encode_images", images=batch.global_enc_images.to(bf).to(dev))
+    return model, TINY, g, prompt, feats, outs
+
+
+def test_generate_returns_reference_ids_and_per_step_hidden_states(gen_setup):
+    """`.generate(...)` with exactly the kwargs evaluate passes (GROVE.py:418-422): `.sequences` = the reference's greedy ids
+    (golden, still containing -200), `.hidden_states` = one tensor per LM step, [B, L+575, H] then [B, 1, H] (GROVE.py:423-426)."""
+    model, d, g, prompt, feats, outs = gen_setup
+    out = model.generate(images=None, input_ids=prompt, bboxes=None, image_features=feats, image_forward_outs=outs, images_dtype=bf,
+                         token_embeddings=None, max_new_tokens=12, num_beams=1, output_hidden_states=True,
+                         return_dict_in_generate=True, do_sample=False, use_cache=True, synced_gpus=False)
+    assert (out.sequences.cpu().numpy() == g["greedy_ids"]).all()
+    assert (out.sequences == -200).sum().item() == prompt.shape[0]
+    n_new = out.sequences.shape[1] - prompt.shape[1]
+    hs = out.hidden_states
+    assert isinstance(hs, tuple) and len(hs) == n_new
+    assert tuple(hs[0].shape) == (2, prompt.shape[1] + 575, d.hidden)
+    assert all(tuple(h.shape) == (2, 1, d.hidden) for h in hs[1:])
+    assert torch.cat(hs, 1).shape[1] == out.sequences.shape[1] + 575 - 1
+    # plain call returns the ids alone; sampling / beams do not exist on this path
+    assert torch.equal(model.generate(input_ids=prompt, image_features=feats, max_new_tokens=12), out.sequences)
+    with pytest.raises(NotImplementedError):
+        model.generate(input_ids=prompt, image_features=feats, max_new_tokens=2, num_beams=4)
+
+
+def test_forward_past_key_values_is_one_cached_lm_step(gen_setup):
+    """The HF greedy loop written out over forward(past_key_values=...) (what GenerationMixin does with
+    prepare_inputs_for_generation, llava_llama.py:144-180) gives the same ids and hidden states as generate(), whose steps replay
+    one HIP graph; and neither clobbers the prefilled cache (the graph warm-up used to zero position 0)."""
+    model, d, g, prompt, feats, outs = gen_setup
+    gen = model.generate(input_ids=prompt, image_features=feats, max_new_tokens=12, output_hidden_states=True,
+                         return_dict_in_generate=True, use_cache=True)
+    ids = prompt.clone()
+    past, hiddens = None, []
+    finished = torch.zeros(ids.shape[0], dtype=torch.bool, device=ids.device)
+    prefill_rows = None
+    for step in range(12):
+        step_ids = ids[:, -1:] if past else ids  # prepare_inputs_for_generation: `if past_key_values: input_ids = input_ids[:, -1:]`
+        out = model(input_ids=step_ids, past_key_values=past, image_features=feats, image_forward_outs=outs, images_dtype=bf,
+                    use_cache=True, output_hidden_states=True, return_dict=True)
+        past = out.past_key_values
+        if step == 0:
+            assert tuple(out.logits.shape) == (2, prompt.shape[1] + 575, d.vocab) or out.logits.shape[-1] >= d.vocab
+            S0 = out.hidden_states.shape[1]
+            prefill_rows = [layer[:, :S0].clone() for layer in past.layers]
+            assert past.get_seq_length() == S0
+        hiddens.append(out.hidden_states)
+        nxt = out.logits[:, -1, :d.vocab].float().argmax(-1)
+        nxt = torch.where(finished, torch.full_like(nxt, d.pad_token_id), nxt)
+        ids = torch.cat([ids, nxt[:, None]], 1)
+        finished |= nxt == d.eos_token_id
+        if bool(finished.all()):
+            break
+    assert (ids.cpu().numpy() == g["greedy_ids"]).all()
+    assert torch.equal(ids, gen.sequences)
+    hid_loop, hid_gen = torch.cat(hiddens, 1), torch.cat(gen.hidden_states, 1)
+    assert hid_loop.shape == hid_gen.shape
+    assert rel(hid_gen, hid_loop) < 1e-3, "graph-replayed steps vs eager cached steps"
+    # the prompt's keys | values are untouched by the decode steps, eager or graph (position 0 = BOS, the attention sink)
+    for li, rows in enumerate(prefill_rows):
+        assert torch.equal(past.layers[li][:, :S0], rows), f"eager steps changed prefilled rows of layer {li}"
+        assert torch.equal(gen.past_key_values.layers[li][:, :S0], rows), f"graph warm-up / replay changed prefilled rows of layer {li}"
+        assert float(rows[:, 0].float().abs().max()) > 0
+    # and the appended rows agree between the two
+    n = past.get_seq_length()
+    assert n == gen.past_key_values.get_seq_length()
+    for li in range(len(prefill_rows)):
+        assert rel(gen.past_key_values.layers[li][:, S0:n], past.layers[li][:, S0:n]) < 1e-3
+
+
+def test_evaluate_goes_through_generate(gen_setup, dev, monkeypatch):
+    from grove_amd.synthetic import synthetic_batch
+    model, d, g, prompt, feats, outs = gen_setup
+    batch = synthetic_batch(d, B=2, T=8, L=24, n_det=1, seed=3)
+    emb = model(mode="get_grounding_encoder_embs", images=batch.grounding_enc_images.to(bf).to(dev))
+    calls = []
+    orig = model.generate
+
+    def spy(**kw):
+        calls.append(kw)
+        return orig(**kw)
+    monkeypatch.setattr(model, "generate", spy)
+    ids, boxes, logits = model(mode="evaluate", image_features=feats, image_forward_outs=outs, images_dtype=bf, image_embeddings=emb,
+                               input_ids=prompt, original_size_list=batch.original_size_list, max_tokens_new=12, bboxes=None,
+                               token_embeddings=None, dense_pe=None, device=dev)
+    assert len(calls) == 1
+    kw = calls[0]
+    assert kw["num_beams"] == 1 and kw["do_sample"] is False and kw["use_cache"] is True and kw["output_hidden_states"] and \
+        kw["return_dict_in_generate"] and kw["max_new_tokens"] == 12
+    assert (ids.cpu().numpy() == g["greedy_ids"]).all()
+
+
+def test_from_pretrained_directory(dev, tmp_path):
+    """train.py:207-218 / infer_iground.py:511-528: HF-style directory (config.json + pytorch_model.bin with the reference's key
+    names, extra dead keys, a `module.` prefix) -> model with the checkpoint's geometry and weights."""
+    import dataclasses
+    from grove_amd import GROVEForCausalLM
+    from grove_amd.synthetic import TINY, synthetic_batch, synthetic_state_dict
+    d = dataclasses.replace(TINY, vocab=328)
+    sd = synthetic_state_dict(d)
+    ck = {"module." + k: v for k, v in sd.items()}
+    ck["module.model.region_encoder.dead.weight"] = torch.zeros(3)
+    torch.save(ck, tmp_path / "pytorch_model.bin")
+    (tmp_path / "config.json").write_text(json.dumps({
+        "hidden_size": d.hidden, "num_hidden_layers": d.n_layers, "num_attention_heads": d.n_heads, "intermediate_size": d.mlp,
+        "rms_norm_eps": d.rms_eps, "rope_theta": d.rope_theta, "vocab_size": 320, "bos_token_id": 1, "eos_token_id": 2, "pad_token_id": 0}))
+    base = dataclasses.replace(TINY, hidden=0, n_layers=0, n_heads=1, mlp=0)  # LLaMA geometry must come from config.json
+    model = GROVEForCausalLM.from_pretrained(str(tmp_path), torch_dtype=torch.bfloat16, low_cpu_mem_usage=True, dims=base, device=dev,
+                                             det_token_idx=d.det_token_idx, num_frames=8, pe_dtype=torch.float32)
+    assert model.dims.hidden == d.hidden and model.dims.n_layers == d.n_layers and model.dims.vocab == 328
+    assert model.load_report.unexpected_keys == ["model.region_encoder.dead.weight"] and not model.load_report.missing_keys
+    ref = GROVEForCausalLM(dims=d, device=dev, state_dict=sd, det_token_idx=d.det_token_idx, num_frames=8, pe_dtype=torch.float32)
+    for k, v in ref.state_dict().items():
+        assert torch.equal(model.state_dict()[k], v), k
+    batch = synthetic_batch(d, B=1, T=8, L=24, n_det=1, seed=3)
+    kw = to_dev(batch, dev)
+    kw["inference"] = True
+    a, b = model(**kw), ref(**kw)
+    assert torch.equal(a["flat_boxes"], b["flat_boxes"])
+    with pytest.raises(ValueError):
+        GROVEForCausalLM.from_pretrained(str(tmp_path), torch_dtype=torch.float16, dims=base, device=dev, det_token_idx=1)

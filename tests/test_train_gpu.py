@@ -32,6 +32,7 @@ def _batch(d, dev, seed):
 
 def test_train_validate_checkpoint(dev, tmp_path):
     T, args, d, engine = _engine(dev)
+    engine.scheduler.warm = 2  # (DeepSpeed's order gives updates 1 and 2 lr = 0; ramp over two steps so that 3 and 4 move the weights)
     args.log_dir = str(tmp_path)
     batch = _batch(d, dev, 1)
     logs = []
@@ -46,6 +47,9 @@ def test_train_validate_checkpoint(dev, tmp_path):
     T2, args2, _, fresh = _engine(dev)
     fresh.load_checkpoint(str(tmp_path / "ckpt_model_best"))
     assert fresh.global_step == 4
+    # the directory also holds what zero_to_fp32.py would have produced (infer_eval_iground.sh:13): the reference's loader reads it
+    cons = torch.load(str(tmp_path / "ckpt_model_best" / "pytorch_model.bin"), map_location="cpu", weights_only=True)
+    assert set(cons) == set(engine.module.state_dict()) and all(v.dtype == torch.float32 for v in cons.values())
     assert torch.equal(fresh.master, engine.master) and torch.equal(fresh.m, engine.m) and torch.equal(fresh.v, engine.v)
     resumed = T.validate_model_performance(itertools.repeat(batch), fresh, 1, args)
     assert abs(resumed["loss"] - after["loss"]) < 1e-3 * max(1.0, abs(after["loss"]))
@@ -55,6 +59,7 @@ def test_optimizer_step_matches_restated_adamw(dev):
     """One engine step = global-norm clip (1.0) + AdamW (betas 0.9/0.95, eps 1e-8, wd 0, bias-corrected, lr from WarmupDecayLR) on
     fp32 master weights, checked parameter by parameter on the gradients the engine itself produced."""
     T, args, d, engine = _engine(dev, lr=3e-4)
+    engine.scheduler.warm = 0  # no warm-up: update 1 runs at the full rate (under the shipped warm-up its lr is 0, see for_update)
     batch = _batch(d, dev, 2)
     out = engine(**batch)
     engine.backward(out["loss"])
@@ -63,7 +68,8 @@ def test_optimizer_step_matches_restated_adamw(dev):
     engine.step()
     norm = float(g.double().pow(2).sum().sqrt())
     scale = 1.0 if norm <= 1.0 else 1.0 / (norm + 1e-6)
-    lr = engine.scheduler.get(1)
+    lr = engine.scheduler.for_update(1)
+    assert lr == 3e-4
     gs = g.double() * scale
     m = (1 - args.beta1) * gs
     v = (1 - args.beta2) * gs * gs
@@ -187,3 +193,47 @@ def test_tower_overlap_changes_nothing_but_time(dev):
         assert abs(l_on[k] - l_off[k]) <= 1e-5 * max(1.0, abs(l_off[k])) and abs(l_on2[k] - l_off[k]) <= 1e-5 * max(1.0, abs(l_off[k])), (k, l_on, l_off)
     scale = g_off.abs().max().item()
     assert scale > 0 and (g_on - g_off).abs().max().item() <= 1e-3 * scale and (g_on2 - g_off).abs().max().item() <= 1e-3 * scale
+
+
+def test_train_main_entry_point(dev, tmp_path):
+    """train.py:609-680 / :929-937: `main(args)` = model -> engine -> epochs of train() + loss validation + keep-the-best
+    checkpoint, on the synthetic loader; then --auto_resume continues from the saved step and --eval_only validates."""
+    from grove_amd import train as T
+    argv = ["--dims", "tiny", "--epochs", "2", "--steps_per_epoch", "3", "--batch_size", "1", "--text_len", "40", "--n_det", "2",
+            "--val_batches", "1", "--lr", "1e-3", "--log_dir", str(tmp_path), "--print_freq", "1"]
+    args = T.parse_args(argv)
+    logs = []
+    res = T.main(args, log=logs.append)
+    assert res["global_step"] == 6 and math.isfinite(res["best_val_loss"])
+    assert any(s.startswith("Epoch: [0][1/3]") for s in logs) and any("Current Validation Loss" in s for s in logs)
+    best = tmp_path / "ckpt_model_best"
+    assert (best / "latest").exists() and (best / "pytorch_model.bin").exists()
+    args2 = T.parse_args(argv + ["--auto_resume", "--eval_only"])
+    logs2 = []
+    val = T.main(args2, log=logs2.append)
+    assert any("Resume training from" in s for s in logs2) and math.isfinite(val["loss"])
+    # fine-tune start from the consolidated file the run wrote (train.py:621-624)
+    args3 = T.parse_args(argv[:-4] + ["--log_dir", str(tmp_path / "ft"), "--grove_weights", str(best), "--epochs", "1"])
+    res3 = T.main(args3, log=lambda *_: None)
+    assert res3["global_step"] == 3
+
+
+def test_bench_self_launches_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it (the shape of the driver's command) spawns its own two ranks before
+    touching the GPU and prints ONE JSON line with n_gpus = 2. On this one-GPU box both ranks share cuda:0 and the collectives go
+    through gloo (RCCL refuses two ranks on one device); on an N-GPU node the same path runs RCCL."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GROVE_BENCH_BACKEND="gloo", GROVE_BENCH_ONE_GPU="1")
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dims", "tiny", "--steps", "2", "--warmup", "1",
+                        "--frames", "8", "--text_len", "48", "--no_cpu_baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["config"]["ranks"] == 2 and res["config"]["collective_backend"] == "gloo"
+    assert res["value"] > 0 and res["steps"] == 2 and res["scaling"] == "weak"
