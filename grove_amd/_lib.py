@@ -36,7 +36,7 @@ class TransposeParams(C.Structure):
 class NormParams(C.Structure):
     _fields_ = [("x", c_vp), ("weight", c_vp), ("bias", c_vp), ("y", c_vp), ("mean", c_vp), ("rstd", c_vp),
                 ("out_idx", c_vp), ("rows", c_i32), ("C", c_i32), ("ld_x", c_i32), ("ld_y", c_i32),
-                ("y_dtype", c_i32), ("eps", c_f32)]
+                ("y_dtype", c_i32), ("eps", c_f32), ("res", c_vp), ("res_bf16", c_vp), ("ld_res", c_i32)]
 
 
 class NormBwdParams(C.Structure):

@@ -32,15 +32,45 @@ __device__ __forceinline__ void store_chunk_bf16(bf16_raw* y, const float* o) {
   *(u32x4_t*)y = u32x4_t{pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
 }
 
-template <bool RMS, int MAXCH>
+// RES: the fp32 residual-stream form. The row that is normalised is v = res[row] (+ x[row], the bf16 output of the branch
+// that just finished); v is written back to res (fp32: the stream is never rounded to bf16 between blocks — at 24-32 layers
+// that rounding, not the MFMA arithmetic, was most of the distance to the fp32 oracle) and, optionally, its bf16 rounding to
+// res_bf16 (what a backward pass or a consumer that needs the stream as a GEMM operand reads). y == NULL: stream update only.
+template <bool RMS, int MAXCH, bool RES>
 __global__ __launch_bounds__(256) void norm_fwd_kernel(const grove_norm_params p) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= p.rows) return;
-  const bf16_raw* x = (const bf16_raw*)p.x + (int64_t)row * p.ld_x;
   RowRegs<MAXCH> r;
-  load_row(x, p.C, lane, r);
   const int nch = p.C >> 3;
+  if constexpr (RES) {
+    float* res = p.res + (int64_t)row * p.ld_res;
+    if (p.x) {
+      load_row((const bf16_raw*)p.x + (int64_t)row * p.ld_x, p.C, lane, r);
+    } else {
+#pragma unroll
+      for (int i = 0; i < MAXCH; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r.v[i][e] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+      const int ch = lane + i * 64;
+      if (ch < nch) {
+        const f32x4_t a = *(const f32x4_t*)(res + ch * 8), b = *(const f32x4_t*)(res + ch * 8 + 4);
+        r.v[i][0] += a[0]; r.v[i][1] += a[1]; r.v[i][2] += a[2]; r.v[i][3] += a[3];
+        r.v[i][4] += b[0]; r.v[i][5] += b[1]; r.v[i][6] += b[2]; r.v[i][7] += b[3];
+        if (p.x) {
+          *(f32x4_t*)(res + ch * 8) = f32x4_t{r.v[i][0], r.v[i][1], r.v[i][2], r.v[i][3]};
+          *(f32x4_t*)(res + ch * 8 + 4) = f32x4_t{r.v[i][4], r.v[i][5], r.v[i][6], r.v[i][7]};
+        }
+        if (p.res_bf16) store_chunk_bf16((bf16_raw*)p.res_bf16 + (int64_t)row * p.C + ch * 8, r.v[i]);
+      }
+    }
+    if (!p.y) return;
+  } else {
+    load_row((const bf16_raw*)p.x + (int64_t)row * p.ld_x, p.C, lane, r);
+  }
   float mean = 0.f;
   if constexpr (!RMS) {
     float s = 0.f;
@@ -233,19 +263,27 @@ int check_fwd(const grove_norm_params* p, const char* name) {
   GROVE_CHECK(p->ld_x % 8 == 0 && p->ld_y % 8 == 0, GROVE_E_ALIGN, "%s: ld_x/ld_y must be multiples of 8", name);
   GROVE_CHECK(((uintptr_t)p->x & 15) == 0 && ((uintptr_t)p->y & 15) == 0 && ((uintptr_t)p->weight & 15) == 0, GROVE_E_ALIGN,
               "%s: pointers must be 16-byte aligned", name);
+  GROVE_CHECK(p->res || (p->x && p->y && p->weight), GROVE_E_SHAPE, "%s: x, y and weight required", name);
+  GROVE_CHECK(!p->res || (p->ld_res % 8 == 0 && ((uintptr_t)p->res & 15) == 0 && ((uintptr_t)p->res_bf16 & 15) == 0 && (!p->y || p->weight)),
+              GROVE_E_ALIGN, "%s: residual stream must be 16-byte aligned with ld_res %% 8 == 0 (and y needs weight)", name);
   return GROVE_OK;
 }
 
 }  // namespace
 
-#define NORM_FWD_DISPATCH(RMS)                                                                              \
+#define NORM_FWD_DISPATCH_R(RMS, RES)                                                                      \
   do {                                                                                                     \
     dim3 g_((p->rows + 3) / 4), b_(256);                                                                   \
     hipStream_t s_ = (hipStream_t)stream;                                                                  \
-    if (p->C <= 512) hipLaunchKernelGGL((norm_fwd_kernel<RMS, 1>), g_, b_, 0, s_, *p);                     \
-    else if (p->C <= 1024) hipLaunchKernelGGL((norm_fwd_kernel<RMS, 2>), g_, b_, 0, s_, *p);               \
-    else if (p->C <= 2048) hipLaunchKernelGGL((norm_fwd_kernel<RMS, 4>), g_, b_, 0, s_, *p);               \
-    else hipLaunchKernelGGL((norm_fwd_kernel<RMS, 8>), g_, b_, 0, s_, *p);                                 \
+    if (p->C <= 512) hipLaunchKernelGGL((norm_fwd_kernel<RMS, 1, RES>), g_, b_, 0, s_, *p);                \
+    else if (p->C <= 1024) hipLaunchKernelGGL((norm_fwd_kernel<RMS, 2, RES>), g_, b_, 0, s_, *p);          \
+    else if (p->C <= 2048) hipLaunchKernelGGL((norm_fwd_kernel<RMS, 4, RES>), g_, b_, 0, s_, *p);          \
+    else hipLaunchKernelGGL((norm_fwd_kernel<RMS, 8, RES>), g_, b_, 0, s_, *p);                            \
+  } while (0)
+#define NORM_FWD_DISPATCH(RMS)                 \
+  do {                                         \
+    if (p->res) NORM_FWD_DISPATCH_R(RMS, true); \
+    else NORM_FWD_DISPATCH_R(RMS, false);      \
   } while (0)
 
 extern "C" int grove_layernorm_fwd(const grove_norm_params* p, void* stream) {

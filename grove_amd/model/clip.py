@@ -84,28 +84,40 @@ class ClipTower:
         del x0
         if taps is not None and 0 in taps:
             taps[0] = x.clone()
+        # The residual stream lives in FP32 (`res`); a branch output `t` (bf16, from the GEMM) is added to it inside the LayerNorm
+        # kernel that follows (residual-stream form of grove_layernorm_fwd): 46 residual adds without a bf16 rounding in between.
+        res = ops.to_f32(x)
+        t = None
         nl = len(self.layers) if upto is None else upto
+        h = torch.empty_like(x)
         for i in range(nl):
             L = self.layers[i]
-            h, _, _ = ops.layernorm(x, L["ln1"][0], L["ln1"][1], d.clip_eps)
+            ops.layernorm(t, L["ln1"][0], L["ln1"][1], d.clip_eps, out=h, res=res)
             qkv = ops.linear(h, L["wqkv"], L["bqkv"])
             o, _ = attention_fwd(qkv, F, n + 1, H, hd, 0, C, 2 * C, hd ** -0.5)
             del qkv
-            ops.linear(o, L["wo"], L["bo"], residual=x, out=x)
-            ops.layernorm(x, L["ln2"][0], L["ln2"][1], d.clip_eps, out=h)
+            t = ops.linear(o, L["wo"], L["bo"])
+            ops.layernorm(t, L["ln2"][0], L["ln2"][1], d.clip_eps, out=h, res=res)
             f = ops.linear(h, L["w1"], L["b1"], act=ops.ACT_QUICKGELU)
-            ops.linear(f, L["w2"], L["b2"], residual=x, out=x)
-            del f, h, o
+            t = ops.linear(f, L["w2"], L["b2"])
+            del f, o
             if i % 3 == 0:
                 A = self.adapters[i // 3]
                 if A["active"]:  # tanh(0) * relu(conv) + x == x exactly, so alpha == 0 skips the conv
-                    y = torch.empty_like(x)
+                    # the Conv3d reads the stream itself (as the implicit GEMM's gathered A rows): materialise its bf16 rounding, then
+                    # the adapter's own contribution tanh(alpha) * relu(conv + b) becomes the next pending branch output (CLS rows: 0)
+                    ops.stream_add(res, t, res_bf16=x)
+                    t = torch.zeros_like(x)
                     ops.linear(x, A["w"], A["b"], act=ops.ACT_RELU, scale_ptr=A["alpha"], scale_tanh=True, a_idx=conv_idx,
-                               a_taps=27, M=F * n, c_idx=patch_rows, residual=x, out=y)
-                    ops.copy_rows(x, y, F, C, idx_src=cls_dst, idx_dst=cls_dst)
-                    x = y
+                               a_taps=27, M=F * n, c_idx=patch_rows, out=t)
             if taps is not None and (i + 1) in taps:
+                ops.stream_add(res, t, res_bf16=x)
+                t = None
                 taps[i + 1] = x.clone()
+        if t is not None:
+            ops.stream_add(res, t, res_bf16=x)
+        else:
+            ops.stream_add(res, None, res_bf16=x)
         return x
 
     def forward(self, images, taps=None):

@@ -35,34 +35,42 @@ class LlamaStack:
         self.norm = sd["model.norm.weight"]
 
     def forward(self, x, B, S, kv_len=None, save=False, kv_cache=None):
-        """x: bf16 [B*S, H] input embeddings (consumed / overwritten). kv_len: int32 [B] valid lengths or None.
+        """x: bf16 [B*S, H] input embeddings. kv_len: int32 [B] valid lengths or None.
         kv_cache: optional list (one per layer) of bf16 [B, S_max, 2H] tensors that receive the rotated keys | values of
-        positions 0..S-1 (the prefill of a cached decode). Returns (final-norm hidden [B*S, H], ctx)."""
+        positions 0..S-1 (the prefill of a cached decode). Returns (final-norm hidden [B*S, H], ctx).
+        The residual stream is held in FP32 (`res`): each branch output (o_proj, down_proj; bf16 from the GEMM) is added to it
+        inside the RMSNorm kernel that follows (grove_rmsnorm_fwd, residual-stream form), so the stream is never rounded to bf16
+        between the 64 residual adds — that rounding was most of the stack's distance to the fp32 oracle at full depth. For the
+        backward the same kernel leaves the bf16 rounding of the stream at every norm input (what HF would have stored)."""
         d = self.d
         H, nh, hd, I = d.hidden, d.n_heads, d.head_dim, d.mlp
         pos = torch.arange(S, dtype=torch.int32, device=self.dev).repeat(B)
         saved = []
+        res = ops.to_f32(x)
+        t = None  # branch output not yet added to the stream
         for li, L in enumerate(self.layers):
-            h = ops.rmsnorm(x, L["ln1"], d.rms_eps)
+            xb = torch.empty_like(x) if save else None
+            h = ops.rmsnorm(t, L["ln1"], d.rms_eps, res=res, res_bf16=xb)
             qkv = ops.linear(h, L["wqkv"])
             ops.rope_(qkv, pos, 0, 2 * nh, hd, d.rope_theta)
             if kv_cache is not None:
                 kv_cache[li][:, :S].copy_(qkv.view(B, S, 3 * H)[:, :, H:])
             o, actx = attention_fwd(qkv, B, S, nh, hd, 0, H, 2 * H, hd ** -0.5, causal=True, kv_len=kv_len, save=save)
-            x1 = ops.linear(o, L["wo"], residual=x)
-            h2 = ops.rmsnorm(x1, L["ln2"], d.rms_eps)
+            t = ops.linear(o, L["wo"])
+            x1b = torch.empty_like(x) if save else None
+            h2 = ops.rmsnorm(t, L["ln2"], d.rms_eps, res=res, res_bf16=x1b)
             if "wgu_sw" in L and h2.shape[0] >= 1024:  # (the fused epilogue lives in the pipelined kernel: big GEMMs only)
                 gu = torch.empty((h2.shape[0], 2 * I), dtype=torch.bfloat16, device=self.dev) if save else None
                 a = ops.linear(h2, L["wgu_sw"], act=ops.ACT_SWIGLU_PAIR, aux=gu, ld_aux=2 * I)
             else:
                 gu = ops.linear(h2, L["wgu"])
                 a = ops.swiglu(gu, I)
-            x2 = ops.linear(a, L["wd"], residual=x1)
+            t = ops.linear(a, L["wd"])
             if save:
-                saved.append((x, qkv, actx, x1, gu))
-            x = x2
-        out = ops.rmsnorm(x, self.norm, d.rms_eps)
-        ctx = (saved, x, pos, B, S) if save else None
+                saved.append((xb, qkv, actx, x1b, gu))
+        xl = torch.empty_like(x) if save else None
+        out = ops.rmsnorm(t, self.norm, d.rms_eps, res=res, res_bf16=xl)
+        ctx = (saved, xl, pos, B, S) if save else None
         return out, ctx
 
     def new_kv_cache(self, B, S_max):

@@ -143,14 +143,20 @@ class SamEncoder:
         return self._idx[key]
 
     # ------------------------------------------------------------------ forward
-    def _attn_block(self, Bk, x, F, idx, save):
+    def _attn_block(self, Bk, res, t, F, idx, save):
+        """One encoder block on the FP32 residual stream `res` (image_encoder.py:243-259). `t` is the previous branch output
+        (bf16) that has not been added to the stream yet: norm1's kernel adds it (residual-stream form of grove_layernorm_fwd), the
+        attention branch's output is added inside norm2's kernel, and the MLP branch's output is returned as the new pending `t`.
+        With `save`, the norms also leave the bf16 rounding of their inputs (x, x1) for the backward."""
         d = self.d
         C, nh, hp, hd = d.sam_dim, d.sam_heads, self.hp, self.hd
         tok2win, win2tok, _, _, _, nwin = idx
         g = d.sam_grid
         ws = Bk["window"]
         ctx = {}
-        h, mean, rstd = ops.layernorm(x, Bk["ln1"][0], Bk["ln1"][1], 1e-6, save_stats=save)
+        rows = res.shape[0]
+        x = torch.empty((rows, C), dtype=torch.bfloat16, device=self.dev) if save else None
+        h, mean, rstd = ops.layernorm(t, Bk["ln1"][0], Bk["ln1"][1], 1e-6, save_stats=save, res=res, res_bf16=x)
         if ws > 0:
             # Window partition (image_encoder.py:329-353) pads AFTER norm1 with zero tokens, whose q|k|v is the bias alone:
             # the GEMM runs over the real tokens only and scatters its rows into the windowed layout (c_idx); the padding
@@ -177,25 +183,31 @@ class SamEncoder:
         del rel
         if ws > 0:  # un-partition = gather the real tokens' rows of the windowed attention output (padding rows are dropped)
             if Bk["maps"]:
-                x1 = ops.linear(o, Bk["wproj_c"], Bk["bproj"], residual=x, a_idx=tok2win, a_taps=1, M=x.shape[0], k_map=(hd, hp - hd))
+                t1 = ops.linear(o, Bk["wproj_c"], Bk["bproj"], a_idx=tok2win, a_taps=1, M=rows, k_map=(hd, hp - hd))
             else:
-                x1 = ops.linear(o, Bk["wproj"], Bk["bproj"], residual=x, a_idx=tok2win, a_taps=1, M=x.shape[0])
+                t1 = ops.linear(o, Bk["wproj"], Bk["bproj"], a_idx=tok2win, a_taps=1, M=rows)
         else:
-            x1 = ops.linear(o, Bk["wproj"], Bk["bproj"], residual=x)
-        h2, mean2, rstd2 = ops.layernorm(x1, Bk["ln2"][0], Bk["ln2"][1], 1e-6, save_stats=save)
-        pre = torch.empty((x.shape[0], 4 * C), dtype=torch.bfloat16, device=self.dev) if save else None
+            t1 = ops.linear(o, Bk["wproj"], Bk["bproj"])
+        x1 = torch.empty((rows, C), dtype=torch.bfloat16, device=self.dev) if save else None
+        h2, mean2, rstd2 = ops.layernorm(t1, Bk["ln2"][0], Bk["ln2"][1], 1e-6, save_stats=save, res=res, res_bf16=x1)
+        pre = torch.empty((rows, 4 * C), dtype=torch.bfloat16, device=self.dev) if save else None
         # backward needs only gelu'(lin1(.)) (the block's weights are frozen: no weight gradient reads the pre-activation), so the
         # GEMM stores the derivative and the backward's lin2 dgrad multiplies by it in its epilogue — no elementwise pass
         f = ops.linear(h2, Bk["w1"], Bk["b1"], act=ops.ACT_GELU, aux=pre, aux_grad=True)
-        x2 = ops.linear(f, Bk["w2"], Bk["b2"], residual=x1)
+        t2 = ops.linear(f, Bk["w2"], Bk["b2"])
         if save:
             ctx = dict(x=x, mean=mean, rstd=rstd, qkv=qkv, actx=actx, x1=x1, mean2=mean2, rstd2=rstd2, pre=pre, nb=nb, L=L, qhw=qhw)
-        return x2, ctx
+        return t2, ctx
 
-    def _adapter(self, A, x, conv_idx, save):
+    def _adapter(self, A, res, t, conv_idx, save):
+        """tanh(alpha) * relu(Conv3d(x) + b) + x (image_encoder.py:48-59) on the FP32 stream: the Conv3d reads the stream itself
+        (gathered rows of the implicit GEMM), so its bf16 rounding x = bf16(res + t) is materialised; the adapter's own
+        contribution becomes the next pending branch output (its `+ x` is the stream)."""
+        x = torch.empty((res.shape[0], res.shape[1]), dtype=torch.bfloat16, device=self.dev)
+        ops.stream_add(res, t, res_bf16=x)
         pre = torch.empty_like(x) if save else None
         y = ops.linear(x, A["w"], A["b"], act=ops.ACT_RELU, scale_ptr=A["alpha_f32"], scale_tanh=True, a_idx=conv_idx, a_taps=27,
-                       M=x.shape[0], residual=x, aux=pre)
+                       M=x.shape[0], aux=pre)
         return y, (x, pre)
 
     def forward(self, images, save=False, upto=None):
@@ -215,16 +227,20 @@ class SamEncoder:
         del col
         saved = {"blocks": {}, "adapters": {}, "F": F}
         nblocks = d.sam_depth if upto is None else upto
+        res = ops.to_f32(x)  # the residual stream, FP32 from here to the neck (see _attn_block)
+        t = None
         for i in range(nblocks):
             keep = save and i >= self.first_bwd_block
-            x, ctx = self._attn_block(self.blocks[i], x, F, idx, keep)
+            t, ctx = self._attn_block(self.blocks[i], res, t, F, idx, keep)
             if keep:
                 saved["blocks"][i] = ctx
             if i in d.sam_global:
                 j = d.sam_global.index(i)
-                x, actx = self._adapter(self.adapters[j], x, conv_idx, save)
+                t, actx = self._adapter(self.adapters[j], res, t, conv_idx, save)
                 if save:
                     saved["adapters"][j] = actx
+        ops.stream_add(res, t, res_bf16=x)  # the neck's 1x1 conv reads the stream as a GEMM operand
+        del res, t
         if upto is not None:
             return x, None
         n0 = ops.linear(x, self.neck_w0)

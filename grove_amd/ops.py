@@ -140,37 +140,63 @@ def transpose2d(x, pad_cols_to=None):
     return transpose(x, R, Cc, x.stride(0), out, ld_out, pad_to_cols=ld_out)
 
 
-def _norm_fwd(fn, name, x, weight, bias, eps, out, out_idx, save_stats, out_dtype, out_rows):
-    _chk_dev(x, weight)
-    rows, Cc = x.shape
+def _norm_fwd(fn, name, x, weight, bias, eps, out, out_idx, save_stats, out_dtype, out_rows, res=None, res_bf16=None, want_y=True):
+    """res (fp32 [rows, C], updated in place): the residual-stream form — normalises res + x (x may be None), see grove_hip.h."""
+    if res is not None:
+        rows, Cc = res.shape
+        assert res.dtype == torch.float32 and res.stride(1) == 1
+        assert x is None or (x.shape == res.shape and x.dtype == bf16)
+        assert res_bf16 is None or (res_bf16.is_contiguous() and res_bf16.shape == res.shape and res_bf16.dtype == bf16)
+        dev_t = res
+    else:
+        rows, Cc = x.shape
+        dev_t = x
+    _chk_dev(dev_t, weight)
+    x_dev = dev_t.device
+    if not want_y:
+        p = _lib.NormParams()
+        p.x, p.res, p.res_bf16 = _p(x), _p(res), _p(res_bf16)
+        p.rows, p.C, p.ld_x, p.ld_res, p.eps = rows, Cc, (x.stride(0) if x is not None else 0), res.stride(0), eps
+        _lib.check(fn(C.byref(p), _stream()), name)
+        return None, None, None
     if out is None:
         orows = out_rows if out_rows is not None else rows
         if out_idx is not None:
-            out = torch.zeros((orows, Cc), dtype=out_dtype, device=x.device)
+            out = torch.zeros((orows, Cc), dtype=out_dtype, device=x_dev)
         else:
-            out = torch.empty((orows, Cc), dtype=out_dtype, device=x.device)
+            out = torch.empty((orows, Cc), dtype=out_dtype, device=x_dev)
     mean = rstd = None
     if save_stats:
-        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
-        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        mean = torch.empty(rows, dtype=torch.float32, device=x_dev)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x_dev)
     p = _lib.NormParams()
     p.x, p.weight, p.bias, p.y = _p(x), _p(weight), _p(bias), _p(out)
     p.mean, p.rstd, p.out_idx = _p(mean), _p(rstd), _p(out_idx)
-    p.rows, p.C, p.ld_x, p.ld_y = rows, Cc, x.stride(0), out.stride(0)
+    p.res, p.res_bf16 = _p(res), _p(res_bf16)
+    p.rows, p.C, p.ld_x, p.ld_y = rows, Cc, (x.stride(0) if x is not None else 0), out.stride(0)
+    p.ld_res = res.stride(0) if res is not None else 0
     p.y_dtype = F32 if out.dtype == torch.float32 else BF16
     p.eps = eps
     _lib.check(fn(C.byref(p), _stream()), name)
     return out, mean, rstd
 
 
-def layernorm(x, weight, bias, eps, *, out=None, out_idx=None, save_stats=False, out_dtype=bf16, out_rows=None):
+def layernorm(x, weight, bias, eps, *, out=None, out_idx=None, save_stats=False, out_dtype=bf16, out_rows=None, res=None,
+              res_bf16=None):
     return _norm_fwd(_lib.lib().grove_layernorm_fwd, "grove_layernorm_fwd", x, weight, bias, eps, out, out_idx,
-                     save_stats, out_dtype, out_rows)
+                     save_stats, out_dtype, out_rows, res=res, res_bf16=res_bf16)
 
 
-def rmsnorm(x, weight, eps, *, out=None):
+def rmsnorm(x, weight, eps, *, out=None, res=None, res_bf16=None):
     return _norm_fwd(_lib.lib().grove_rmsnorm_fwd, "grove_rmsnorm_fwd", x, weight, None, eps, out, None, False, bf16,
-                     None)[0]
+                     None, res=res, res_bf16=res_bf16)[0]
+
+
+def stream_add(res, x, res_bf16=None):
+    """res (fp32 residual stream) += x (bf16 branch output); optionally the bf16 rounding of the updated stream. No norm."""
+    _norm_fwd(_lib.lib().grove_layernorm_fwd, "grove_layernorm_fwd", x, None, None, 0.0, None, None, False, bf16, None,
+              res=res, res_bf16=res_bf16, want_y=False)
+    return res_bf16
 
 
 def _norm_bwd(fn, name, x, weight, dy, mean, rstd, eps, dx, dweight, dbias, in_idx, accumulate):

@@ -174,6 +174,12 @@ int grove_transpose_bf16(const grove_transpose_params* p, void* stream);
  *   out_idx (optional) scatters row r of the input to row out_idx[r] of y (SAM window partition,
  *   image_encoder.py:329-352; rows never written keep their caller-provided zero padding).
  * rmsnorm: HF LlamaRMSNorm (fp32 normalise, cast, times weight).
+ * Residual-stream form (res != NULL): the pre-norm residual connections of the three towers
+ *   (`hidden_states = residual + hidden_states` then the next block's norm: HF LlamaDecoderLayer; modeling_clip.py:386-396;
+ *   image_encoder.py:256-258) fused into the norm that follows them, with the stream itself held in FP32:
+ *   v = res[row] + x[row] (x = the branch output, bf16, or NULL = no update); res[row] = v; res_bf16[row] = bf16(v)
+ *   (optional: [rows, C] contiguous, the copy a backward pass / a GEMM that consumes the stream reads); y = norm(v)
+ *   (y == NULL: stream update only). The reference rounds the stream to bf16 after every block; here it is not rounded.
  * ------------------------------------------------------------------------------------------ */
 typedef struct grove_norm_params {
   const void* x;
@@ -186,6 +192,9 @@ typedef struct grove_norm_params {
   int32_t rows, C, ld_x, ld_y;
   int32_t y_dtype;
   float eps;
+  float* res;      /* f32 [rows, ld_res] residual stream, updated in place, or NULL (plain norm of x) */
+  void* res_bf16;  /* bf16 [rows, C] rounded copy of the updated stream, or NULL */
+  int32_t ld_res;
 } grove_norm_params;
 int grove_layernorm_fwd(const grove_norm_params* p, void* stream);
 int grove_rmsnorm_fwd(const grove_norm_params* p, void* stream);

@@ -290,6 +290,46 @@ def test_rmsnorm_fwd_bwd(dev, C):
     close(dx, xr.grad, 1e-2, "rms dx")
 
 
+@pytest.mark.parametrize("C,rms", [(128, True), (4096, True), (1280, False), (256, False)])
+def test_norm_residual_stream_form(dev, C, rms):
+    """res (fp32) += x (bf16 branch output) fused into the norm that follows; the stream is never rounded: after 40 adds it equals
+    the fp32 sum exactly (to fp32 rounding), its bf16 copy is the rounding of that sum, and y is the norm of the fp32 row."""
+    from grove_amd import ops
+    rows = 23
+    w, b = rnd(C, seed=40), rnd(C, seed=41)
+    res0 = rnd(rows, C, seed=42).float()
+    res = res0.clone().to(dev)
+    ref = res0.clone()
+    norm = (lambda v: v * torch.rsqrt(v.pow(2).mean(-1, keepdim=True) + 1e-5) * w.float()) if rms else \
+        (lambda v: F.layer_norm(v, (C,), w.float(), b.float(), 1e-5))
+    # first norm of a stack: no pending branch output
+    y0 = ops.rmsnorm(None, w.to(dev), 1e-5, res=res) if rms else ops.layernorm(None, w.to(dev), b.to(dev), 1e-5, res=res)[0]
+    close(y0, norm(ref), 8e-3, "norm of the untouched stream")
+    assert torch.equal(res.cpu(), res0)
+    for step in range(40):
+        t = (rnd(rows, C, seed=100 + step).float() * 0.05).to(torch.bfloat16)
+        ref = ref + t.float()
+        xb = torch.empty((rows, C), dtype=torch.bfloat16, device=dev)
+        if rms:
+            y = ops.rmsnorm(t.to(dev), w.to(dev), 1e-5, res=res, res_bf16=xb)
+        else:
+            y, mean, rstd = ops.layernorm(t.to(dev), w.to(dev), b.to(dev), 1e-5, res=res, res_bf16=xb, save_stats=True)
+    assert (res.cpu() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+    assert torch.equal(xb.cpu(), res.cpu().to(torch.bfloat16))
+    close(y, norm(ref), 8e-3, "norm of the fp32 stream")
+    if not rms:
+        close(mean, ref.mean(-1), 1e-4, "saved mean")
+    # stream update without a norm (the consumer needs the stream as a bf16 GEMM operand)
+    t = (rnd(rows, C, seed=99).float() * 0.05).to(torch.bfloat16)
+    xb2 = torch.empty_like(xb)
+    ops.stream_add(res, t.to(dev), res_bf16=xb2)
+    ref = ref + t.float()
+    assert (res.cpu() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+    assert torch.equal(xb2.cpu(), res.cpu().to(torch.bfloat16))
+    ops.stream_add(res, None, res_bf16=xb)  # copy only
+    assert torch.equal(xb, xb2)
+
+
 # ----------------------------------------------------------------------------- softmax family
 @pytest.mark.parametrize("Lq,Lk,causal", [(6, 6, False), (577, 577, False), (50, 50, True), (1, 700, True), (196, 196, False)])
 def test_softmax_fwd_bwd(dev, Lq, Lk, causal):
