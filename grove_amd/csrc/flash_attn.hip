@@ -733,11 +733,26 @@ size_t lds_fwd(const grove_flash_attn_params* p) { return 2 * Cfg<HS>::TILEB + (
 
 }  // namespace
 
+// win_attn.hip: the LDS-resident kernels for SAM's 14 x 14 windows
+bool grove_win_attn_applicable(const grove_flash_attn_params* p);
+int grove_win_attn_fwd_launch(const grove_flash_attn_params* p, hipStream_t s);
+int grove_win_attn_bwd_launch(const grove_flash_attn_params* p, hipStream_t s);
+static int g_win_attn = 1;  // 0 = always the general kernels (A/B arm: grove_flash_attn_set_window_kernels)
+extern "C" int grove_flash_attn_set_window_kernels(int32_t on) {
+  g_win_attn = on != 0;
+  return GROVE_OK;
+}
+
 extern "C" int grove_flash_attn_fwd(const grove_flash_attn_params* p, void* stream) {
   int rc = check(p, "flash_attn_fwd");
   if (rc) return rc;
   GROVE_CHECK(p->o, GROVE_E_SHAPE, "flash_attn_fwd: o required");
   hipStream_t s = (hipStream_t)stream;
+  if (g_win_attn && grove_win_attn_applicable(p)) {
+    grove_win_attn_fwd_launch(p, s);
+    GROVE_LAUNCH_CHECK();
+    return GROVE_OK;
+  }
   dim3 grid((p->Lq + 127) / 128, p->H, p->B);
 #define FWD_L(HS, NRK)                                                                                     \
   {                                                                                                        \
@@ -762,6 +777,12 @@ extern "C" int grove_flash_attn_bwd(const grove_flash_attn_params* p, void* stre
   GROVE_CHECK(p->o && p->d_o && p->lse && p->delta && p->dq && p->dk && p->dv, GROVE_E_SHAPE, "flash_attn_bwd: o, d_o, lse, delta, dq, dk, dv required");
   GROVE_CHECK(!p->drel || p->rel, GROVE_E_SHAPE, "flash_attn_bwd: drel needs rel");
   hipStream_t s = (hipStream_t)stream;
+  if (g_win_attn && grove_win_attn_applicable(p) && p->ld_do % 8 == 0 && p->ld_dq % 4 == 0 && p->ld_dk % 4 == 0 && p->ld_dv % 4 == 0 &&
+      ((uintptr_t)p->d_o & 15) == 0 && ((uintptr_t)p->o & 15) == 0) {
+    grove_win_attn_bwd_launch(p, s);  // one kernel: delta, dK / dV, then dQ / d rel (win_attn.hip)
+    GROVE_LAUNCH_CHECK();
+    return GROVE_OK;
+  }
   const int64_t nrows = (int64_t)p->B * p->H * p->Lq;
   hipLaunchKernelGGL(flash_delta_kernel, dim3((unsigned)((nrows + 15) / 16)), dim3(NTHR), 0, s, *p);
   const int nrel = p->rel ? p->rel_ld : 0;

@@ -1,0 +1,690 @@
+// SAM window attention for gfx950: the 14 x 14 windows of ImageEncoderViT's non-global blocks
+// (image_encoder.py:301-326 Attention with add_decomposed_rel_pos :420-458; window_partition :329-353).
+//
+// One (window, head) problem is tiny and fixed: L = 196 tokens, head dim 80 (stored with a row stride of 96), bias from
+// 14 + 14 relative-position bins. The general flash kernels (flash_attn.hip) ran it at 6-8 % of the MFMA peak: 128-query
+// blocks (196 = 128 + 68), 64-key tiles staged global -> registers -> LDS behind two __syncthreads each, the head dim padded
+// to 96 in every product. Here the WHOLE problem lives in LDS:
+//   * K and V of the (window, head) are copied ONCE by LDS-DMA (global_load_lds_dwordx4, no register staging) into dense
+//     [208][80] bf16 images, 160-byte rows. That stride needs no padding and no swizzle: ds_read_b128 row fragments (rows fr,
+//     16-byte chunk g) and ds_read_b64_tr_b16 transposed fragments (8 consecutive rows x 32 bytes per 32-lane half) both hit
+//     64 distinct banks (row * 160 mod 256 walks the 8 multiples of 32; the b128 lane groups pair chunk c of 8 rows with
+//     chunk c + 1 of the other 8);
+//   * one barrier per block; after it every wave owns PAIRS of 16-query tiles (a K / V / indicator fragment read from LDS feeds
+//     two MFMAs) and computes the full score row block S^T[208 keys][32 queries] in registers — no online softmax, no rescale;
+//   * the head dim is 80 = 32 + 32 + 16: two v_mfma_f32_16x16x32_bf16 and one v_mfma_f32_16x16x16_bf16 per score tile, five
+//     16-wide output tiles in P V — nothing is multiplied by the padding;
+//   * the rel-pos bias is one more MFMA per score tile against a 0 / 1 indicator image E[key][bin] (flash_attn.hip's scheme;
+//     here E is built once per block, 64-byte rows with a chunk XOR that makes its b128 reads conflict-free);
+//   * the softmax denominator comes off the matrix cores too: P^T times an all-ones operand (one MFMA per 32 keys) instead of
+//     52 VALU adds per lane — the VALU, not the MFMA pipe, is what this kernel saturates first.
+// 76 KB of LDS per block -> two blocks per CU: one block's DMA prologue hides under the other's MFMAs.
+#include "common.h"
+
+namespace {
+
+constexpr int WNT = 13;                 // 16-row tiles of queries / keys: 192 < L <= 208
+constexpr int WROWB = 160;              // LDS row stride of the K / V images (80 bf16, dense)
+constexpr int WNCH = WNT * 16 * 10;     // 16-byte chunks per image (2080)
+constexpr int WINSTR = (WNCH + 63) / 64;  // wave-level LDS-DMA instructions per image (33; the last one runs with 32 lanes)
+constexpr int WIMGB = WNCH * 16;        // bytes per image (33,280)
+constexpr int WEB = WNT * 16 * 64;      // indicator image E[208][32 bins] bf16
+constexpr int WTHR = 256;
+
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+
+__device__ __forceinline__ float wexp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+__device__ __forceinline__ f32x4_t mfma32(bf16x8_t a, bf16x8_t b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+// The 16-deep steps (head dim 64..79; the 13th key / query tile) run as a 16x16x32 MFMA whose operands carry four zeros per lane:
+// lane group g then contributes k-slots 8g .. 8g+3 = its four real products, the same sum as v_mfma_f32_16x16x16_bf16. The native
+// 16-deep instruction inside an accumulation chain of 32-deep ones gave wrong tiles here (hipcc 7.2 schedules a dependent MFMA
+// of a DIFFERENT shape too close behind its producer: only same-shape back-to-back accumulation is forwarded by the hardware);
+// one shape throughout costs 8 cycles per such step and needs no hazard padding.
+__device__ __forceinline__ f32x4_t mfma16(s16x4_t a, s16x4_t b, f32x4_t c) {
+  const s16x8_t a8 = s16x8_t{a[0], a[1], a[2], a[3], 0, 0, 0, 0}, b8 = s16x8_t{b[0], b[1], b[2], b[3], 0, 0, 0, 0};
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a8), __builtin_bit_cast(bf16x8_t, b8), c, 0, 0, 0);
+}
+#define KEEP_ALIVE4(a, b, c, d)
+#define KEEP_ALIVE3(a, b, c)
+
+// rows 0 .. 207 (clamped to L - 1) x 10 chunks of one head's [*, 80] slice -> dense LDS image; every lane copies 16 bytes per
+// instruction, the wave's 64 chunks land contiguously (LDS-DMA destinations are lane-linear)
+__device__ __forceinline__ void dma_image(char* img, const bf16_raw* __restrict__ src, int ld, int L, int wave, int lane) {
+#pragma unroll
+  for (int j = 0; j < (WINSTR + 3) / 4; ++j) {
+    const int i = wave + 4 * j;
+    if (i < WINSTR) {
+      const int c = i * 64 + lane;
+      const int row = (c * 6554) >> 16;  // c / 10 (exact for c < 16384)
+      const int col = c - row * 10;
+      const int gr = min(row, L - 1);
+      if (c < WNCH)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (int64_t)gr * ld + col * 8),
+                                         (__attribute__((address_space(3))) void*)(img + i * 1024), 16, 0, 0);
+    }
+  }
+}
+
+// chunk position of E[key][8-bin chunk ch]: ch ^ m[(key >> 2) & 3], m = {0, 2, 3, 1}
+__device__ __forceinline__ int e_swz(int key) { return (0x78 >> (((key >> 2) & 3) * 2)) & 3; }
+
+__device__ __forceinline__ bf16x8_t e_chunk(unsigned kb, int bin0, int KH) {
+  const int kh = kb & 0xff, kwb = KH + (kb >> 8);
+  s16x8_t e;
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) e[jj] = ((bin0 + jj) == kh || (bin0 + jj) == kwb) ? (short)0x3F80 : (short)0;
+  return __builtin_bit_cast(bf16x8_t, e);
+}
+
+__device__ __forceinline__ void build_e(char* Es, int L, int kw, int KH, int tid) {
+  for (int c = tid; c < WNT * 16 * 4; c += WTHR) {
+    const int key = c >> 2, ch = c & 3;
+    const unsigned kb = key < L ? (unsigned)((key / kw) | ((key % kw) << 8)) : 0xFFFFu;
+    *(bf16x8_t*)(Es + key * 64 + ((ch ^ e_swz(key)) << 4)) = e_chunk(kb, ch * 8, KH);
+  }
+}
+
+__device__ __forceinline__ bf16x8_t wscale(bf16x8_t f, float sc) {
+  const u32x4_t u = __builtin_bit_cast(u32x4_t, f);
+  const u32x4_t o = u32x4_t{pack2bf(bf_lo(u.x) * sc, bf_hi(u.x) * sc), pack2bf(bf_lo(u.y) * sc, bf_hi(u.y) * sc),
+                            pack2bf(bf_lo(u.z) * sc, bf_hi(u.z) * sc), pack2bf(bf_lo(u.w) * sc, bf_hi(u.w) * sc)};
+  return __builtin_bit_cast(bf16x8_t, o);
+}
+__device__ __forceinline__ s16x4_t wscale4(u32x2_t u, float sc) {
+  const u32x2_t o = u32x2_t{pack2bf(bf_lo(u.x) * sc, bf_hi(u.x) * sc), pack2bf(bf_lo(u.y) * sc, bf_hi(u.y) * sc)};
+  return __builtin_bit_cast(s16x4_t, o);
+}
+
+__device__ __forceinline__ bf16x8_t wpack(const f32x4_t a, const f32x4_t b) {
+  const u32x4_t u = u32x4_t{pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(b[0], b[1]), pack2bf(b[2], b[3])};
+  return __builtin_bit_cast(bf16x8_t, u);
+}
+__device__ __forceinline__ s16x4_t wpack4(const f32x4_t a) {
+  const u32x2_t u = u32x2_t{pack2bf(a[0], a[1]), pack2bf(a[2], a[3])};
+  return __builtin_bit_cast(s16x4_t, u);
+}
+
+__device__ __forceinline__ float gmax4(float v) {
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
+// transposed fragments of a row-major [rows][80] image: {rows r0+4g..+3 | rows r0+16+4g..+3} of column c0 + fr (32-deep k-step),
+// or the first half alone (16-deep k-step)
+__device__ __forceinline__ s16x4_t tr4(const char* img, int r0, int c0, int lane) {
+  const int fr = lane & 15, g = lane >> 4;
+  const char* a = img + (r0 + 4 * g + (fr >> 2)) * WROWB + (c0 + 4 * (fr & 3)) * 2;
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(a));
+}
+__device__ __forceinline__ bf16x8_t tr8(const char* img, int r0, int c0, int lane) {
+  const s16x4_t lo = tr4(img, r0, c0, lane), hi = tr4(img, r0 + 16, c0, lane);
+  const s16x8_t v = s16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
+struct QPair {          // B operands of one pair of 16-query tiles, pre-scaled into the exp2 domain
+  bf16x8_t f[2][2];     // head-dim k-steps 0..31, 32..63
+  s16x4_t t[2];         // head dim 64..79 (16-deep step)
+  bf16x8_t rel[2];      // rel'[q][32 bins]
+};
+
+__device__ __forceinline__ void load_qpair(QPair& q, const bf16_raw* __restrict__ Q, int ld_q, const bf16_raw* __restrict__ REL, int q0,
+                                           int L, float sc, int fr, int g) {
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int qi = min(q0 + mi * 16 + fr, L - 1);
+    const bf16_raw* row = Q + (int64_t)qi * ld_q;
+    q.f[mi][0] = wscale(*(const bf16x8_t*)(row + g * 8), sc);
+    q.f[mi][1] = wscale(*(const bf16x8_t*)(row + 32 + g * 8), sc);
+    q.t[mi] = wscale4(*(const u32x2_t*)(row + 64 + g * 4), sc);
+    q.rel[mi] = wscale(*(const bf16x8_t*)(REL + (int64_t)qi * 32 + g * 8), sc);
+  }
+}
+
+// ================================================================================ forward
+__device__ __forceinline__ void fwd_pair(const QPair& q, const char* Ks, const char* Vs, const char* Es, int q0, int L, int lane,
+                                         bf16_raw* __restrict__ O, int ld_o, float* __restrict__ LSE) {
+  const int fr = lane & 15, g = lane >> 4;
+  const int esw = e_swz(fr);
+  f32x4_t S[2][WNT];
+#pragma unroll
+  for (int nt = 0; nt < WNT; ++nt) {
+    const char* krow = Ks + (nt * 16 + fr) * WROWB;
+    const bf16x8_t k0 = *(const bf16x8_t*)(krow + g * 16);
+    const bf16x8_t k1 = *(const bf16x8_t*)(krow + 64 + g * 16);
+    const s16x4_t kt = *(const s16x4_t*)(krow + 128 + g * 8);
+    const bf16x8_t ef = *(const bf16x8_t*)(Es + (nt * 16 + fr) * 64 + ((g ^ esw) << 4));
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      f32x4_t a = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      a = mfma32(k0, q.f[mi][0], a);
+      a = mfma32(k1, q.f[mi][1], a);
+      a = mfma16(kt, q.t[mi], a);
+      S[mi][nt] = mfma32(ef, q.rel[mi], a);
+    }
+    KEEP_ALIVE4(k0, k1, kt, ef);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // keys >= L exist only in the last tile: rows 4g + r of it
+  const int kvalid = L - (WNT - 1) * 16 - 4 * g;
+  float mrow[2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (r >= kvalid) S[mi][WNT - 1][r] = -INFINITY;
+    float mx = fmaxf(fmaxf(S[mi][0][0], S[mi][0][1]), fmaxf(S[mi][0][2], S[mi][0][3]));
+#pragma unroll
+    for (int nt = 1; nt < WNT; ++nt) mx = fmaxf(mx, fmaxf(fmaxf(S[mi][nt][0], S[mi][nt][1]), fmaxf(S[mi][nt][2], S[mi][nt][3])));
+    mrow[mi] = gmax4(mx);
+#pragma unroll
+    for (int nt = 0; nt < WNT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) S[mi][nt][r] = wexp2(S[mi][nt][r] - mrow[mi]);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  f32x4_t Oa[2][5], Ls[2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    Ls[mi] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dt = 0; dt < 5; ++dt) Oa[mi][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+  const s16x8_t ones8s = s16x8_t{0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+  const bf16x8_t ones8 = __builtin_bit_cast(bf16x8_t, ones8s);
+  const s16x4_t ones4 = s16x4_t{0x3F80, 0x3F80, 0x3F80, 0x3F80};
+#pragma unroll
+  for (int s2 = 0; s2 < WNT / 2; ++s2) {
+    const bf16x8_t p0 = wpack(S[0][2 * s2], S[0][2 * s2 + 1]), p1 = wpack(S[1][2 * s2], S[1][2 * s2 + 1]);
+#pragma unroll
+    for (int dt = 0; dt < 5; ++dt) {
+      const bf16x8_t vf = tr8(Vs, s2 * 32, dt * 16, lane);
+      Oa[0][dt] = mfma32(vf, p0, Oa[0][dt]);
+      Oa[1][dt] = mfma32(vf, p1, Oa[1][dt]);
+    }
+    Ls[0] = mfma32(ones8, p0, Ls[0]);
+    Ls[1] = mfma32(ones8, p1, Ls[1]);
+  }
+  {
+    const s16x4_t p0 = wpack4(S[0][WNT - 1]), p1 = wpack4(S[1][WNT - 1]);
+#pragma unroll
+    for (int dt = 0; dt < 5; ++dt) {
+      const s16x4_t vt = tr4(Vs, (WNT - 1) * 16, dt * 16, lane);
+      Oa[0][dt] = mfma16(vt, p0, Oa[0][dt]);
+      Oa[1][dt] = mfma16(vt, p1, Oa[1][dt]);
+    }
+    Ls[0] = mfma16(ones4, p0, Ls[0]);
+    Ls[1] = mfma16(ones4, p1, Ls[1]);
+  }
+  // lane holds O^T[d = dt*16 + 4g + r][q = fr]; every row of Ls is the softmax denominator of query fr
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int qi = q0 + mi * 16 + fr;
+    if (qi >= L) continue;
+    const float l = Ls[mi][0];
+    const float inv = __builtin_amdgcn_rcpf(l);
+    bf16_raw* orow = O + (int64_t)qi * ld_o;
+#pragma unroll
+    for (int dt = 0; dt < 5; ++dt) {
+      const f32x4_t o = Oa[mi][dt] * inv;
+      *(u32x2_t*)(orow + dt * 16 + g * 4) = u32x2_t{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+    }
+    *(u32x2_t*)(orow + 80 + g * 4) = u32x2_t{0u, 0u};  // the 16 pad columns of the 96-wide head slot
+    if (LSE && g == 0) LSE[qi] = (mrow[mi] + log2f(l)) * 0.6931471805599453f;
+  }
+}
+
+__global__ __launch_bounds__(WTHR, 2) void win_attn_fwd_kernel(const grove_flash_attn_params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ks = smem;
+  char* Vs = smem + WIMGB;
+  char* Es = smem + 2 * WIMGB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
+  const int L = p.Lq;
+  const bf16_raw* Q = (const bf16_raw*)p.q + (int64_t)b * p.sq + h * p.hs;
+  const bf16_raw* K = (const bf16_raw*)p.k + (int64_t)b * p.sk + h * p.hs;
+  const bf16_raw* V = (const bf16_raw*)p.v + (int64_t)b * p.sv + h * p.hs;
+  const bf16_raw* REL = (const bf16_raw*)p.rel + (int64_t)(b * p.H + h) * L * 32;
+  bf16_raw* O = (bf16_raw*)p.o + (int64_t)b * p.so + h * p.hs;
+  float* LSE = p.lse ? p.lse + (int64_t)(b * p.H + h) * L : nullptr;
+  const float sc = p.alpha * 1.4426950408889634f;
+  dma_image(Ks, K, p.ld_k, L, wave, lane);
+  dma_image(Vs, V, p.ld_v, L, wave, lane);
+  build_e(Es, L, p.rel_kw, p.rel_kh, tid);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+#pragma nounroll
+  for (int q0 = wave * 32; q0 < L; q0 += 128) {
+    QPair q;
+    load_qpair(q, Q, p.ld_q, REL, q0, L, sc, fr, g);
+    fwd_pair(q, Ks, Vs, Es, q0, L, lane, O, p.ld_o, LSE);
+  }
+}
+
+
+// ================================================================================ backward
+// One kernel, two phases over the same 80 KB of LDS (two blocks per CU):
+//   A (waves own KEY tiles, lane = key): Q, dO and rel' of the (window, head) are in LDS, the wave's K / V fragments in
+//     registers; S[q][key] and dP[q][key] per 32 queries, P = exp2(S - lse), dS = P (dP - delta) alpha, and the two products that
+//     sum over queries, dV^T += dO^T P and dK^T += Q^T dS, take P / dS straight from the accumulators (flash_attn.hip's
+//     accumulator-as-operand chaining) with dO^T / Q^T as transposed LDS reads;
+//   B (waves own QUERY tile pairs, lane = query): K, V and the indicator image E replace Q, dO, rel' in LDS (second LDS-DMA; the
+//     bytes come back from L2), Q / dO / rel' fragments in registers; S^T, dP^T per 32 keys, dQ^T += K^T dS^T and
+//     d rel'^T += E^T dS^T.
+// delta = rowsum(dO o O) is computed in the prologue (O straight from global, dO from its LDS image): no separate launch.
+// HBM sees every operand once (q, k, v, dO, O, rel', lse in; dq, dk, dv, d rel' out).
+__device__ __forceinline__ bf16x8_t ld_rows(const char* img, int row, int byte_off) { return *(const bf16x8_t*)(img + row * WROWB + byte_off); }
+
+__device__ __forceinline__ s16x4_t tr4e(const char* Es, int r0, int c0, int lane) {  // transposed read of the swizzled 64-byte-row image
+  const int fr = lane & 15, g = lane >> 4;
+  const int row = r0 + 4 * g + (fr >> 2);
+  const int cb = (c0 + 4 * (fr & 3)) * 2;
+  const char* a = Es + row * 64 + ((((cb >> 4) ^ e_swz(row)) << 4) | (cb & 15));
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(a));
+}
+__device__ __forceinline__ bf16x8_t tr8e(const char* Es, int r0, int c0, int lane) {
+  const s16x4_t lo = tr4e(Es, r0, c0, lane), hi = tr4e(Es, r0 + 16, c0, lane);
+  const s16x8_t v = s16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
+struct KVFrag {      // B operands of one 16-key tile (phase A): K pre-scaled into the exp2 domain, V, the indicator columns
+  bf16x8_t k[2];
+  s16x4_t kt;
+  bf16x8_t v[2];
+  s16x4_t vt;
+  bf16x8_t e;
+};
+
+__device__ __forceinline__ void store_t(bf16_raw* __restrict__ dst, int ld, int row, const f32x4_t (&acc)[5], int g) {
+  bf16_raw* r = dst + (int64_t)row * ld;
+#pragma unroll
+  for (int dt = 0; dt < 5; ++dt) *(u32x2_t*)(r + dt * 16 + g * 4) = u32x2_t{pack2bf(acc[dt][0], acc[dt][1]), pack2bf(acc[dt][2], acc[dt][3])};
+  *(u32x2_t*)(r + 80 + g * 4) = u32x2_t{0u, 0u};
+}
+
+// phase A for up to two key tiles kt0, kt0 + 4 of this wave
+__device__ __forceinline__ void bwd_keys(int kt0, int ntile, const bf16_raw* __restrict__ K, int ld_k, const bf16_raw* __restrict__ V, int ld_v,
+                                         const char* Qs, const char* dOs, const char* Rs, const float* lse_s, const float* del_s, int L, float sc,
+                                         float alpha, int kw, int KH, int lane, bf16_raw* __restrict__ DK, int ld_dk, bf16_raw* __restrict__ DV,
+                                         int ld_dv) {
+  const int fr = lane & 15, g = lane >> 4;
+  const int esw = e_swz(fr);
+  KVFrag kv[2];
+#pragma unroll
+  for (int nj = 0; nj < 2; ++nj) {
+    const int key = (kt0 + 4 * nj) * 16 + fr;
+    const int kc = min(key, L - 1);
+    const bf16_raw* kr = K + (int64_t)kc * ld_k;
+    const bf16_raw* vr = V + (int64_t)kc * ld_v;
+    kv[nj].k[0] = wscale(*(const bf16x8_t*)(kr + g * 8), sc);
+    kv[nj].k[1] = wscale(*(const bf16x8_t*)(kr + 32 + g * 8), sc);
+    kv[nj].kt = wscale4(*(const u32x2_t*)(kr + 64 + g * 4), sc);
+    kv[nj].v[0] = *(const bf16x8_t*)(vr + g * 8);
+    kv[nj].v[1] = *(const bf16x8_t*)(vr + 32 + g * 8);
+    kv[nj].vt = __builtin_bit_cast(s16x4_t, *(const u32x2_t*)(vr + 64 + g * 4));
+    const unsigned kb = key < L ? (unsigned)((key / kw) | ((key % kw) << 8)) : 0xFFFFu;
+    kv[nj].e = e_chunk(kb, g * 8, KH);
+  }
+  f32x4_t dk[2][5], dv[2][5];
+#pragma unroll
+  for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+    for (int dt = 0; dt < 5; ++dt) { dk[nj][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dv[nj][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+  const f32x4_t z4 = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma nounroll
+  for (int qs = 0; qs < WNT / 2; ++qs) {  // 32 queries per step
+    f32x4_t sacc[2][2], pacc[2][2];
+#pragma unroll
+    for (int qi_ = 0; qi_ < 2; ++qi_) {
+      const int row = (2 * qs + qi_) * 16 + fr;
+      const bf16x8_t qa0 = ld_rows(Qs, row, g * 16), qa1 = ld_rows(Qs, row, 64 + g * 16);
+      const s16x4_t qat = *(const s16x4_t*)(Qs + row * WROWB + 128 + g * 8);
+      const bf16x8_t da0 = ld_rows(dOs, row, g * 16), da1 = ld_rows(dOs, row, 64 + g * 16);
+      const s16x4_t dat = *(const s16x4_t*)(dOs + row * WROWB + 128 + g * 8);
+      const bf16x8_t ra = *(const bf16x8_t*)(Rs + row * 64 + ((g ^ esw) << 4));
+#pragma unroll
+      for (int nj = 0; nj < 2; ++nj) {
+        if (nj < ntile) {
+          f32x4_t a = mfma32(qa0, kv[nj].k[0], z4);
+          a = mfma32(qa1, kv[nj].k[1], a);
+          a = mfma16(qat, kv[nj].kt, a);
+          sacc[qi_][nj] = mfma32(ra, kv[nj].e, a);
+          f32x4_t c = mfma32(da0, kv[nj].v[0], z4);
+          c = mfma32(da1, kv[nj].v[1], c);
+          pacc[qi_][nj] = mfma16(dat, kv[nj].vt, c);
+        }
+      }
+      KEEP_ALIVE4(qa0, qa1, qat, ra);
+      KEEP_ALIVE3(da0, da1, dat);
+    }
+    f32x4_t lse4[2], del4[2];
+#pragma unroll
+    for (int qi_ = 0; qi_ < 2; ++qi_) {
+      lse4[qi_] = *(const f32x4_t*)(lse_s + (2 * qs + qi_) * 16 + g * 4);
+      del4[qi_] = *(const f32x4_t*)(del_s + (2 * qs + qi_) * 16 + g * 4);
+    }
+    bf16x8_t pfr[2], dsfr[2];
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj) {
+      if (nj < ntile) {
+        f32x4_t pp[2], dd[2];
+#pragma unroll
+        for (int qi_ = 0; qi_ < 2; ++qi_)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pr = wexp2(sacc[qi_][nj][r] - lse4[qi_][r]);
+            pp[qi_][r] = pr;
+            dd[qi_][r] = pr * (pacc[qi_][nj][r] - del4[qi_][r]) * alpha;
+          }
+        pfr[nj] = wpack(pp[0], pp[1]);
+        dsfr[nj] = wpack(dd[0], dd[1]);
+      }
+    }
+#pragma unroll
+    for (int dt = 0; dt < 5; ++dt) {
+      const bf16x8_t dob = tr8(dOs, qs * 32, dt * 16, lane);
+      const bf16x8_t qb = tr8(Qs, qs * 32, dt * 16, lane);
+#pragma unroll
+      for (int nj = 0; nj < 2; ++nj) {
+        if (nj < ntile) {
+          dv[nj][dt] = mfma32(dob, pfr[nj], dv[nj][dt]);
+          dk[nj][dt] = mfma32(qb, dsfr[nj], dk[nj][dt]);
+        }
+      }
+    }
+  }
+  {  // the 13th query tile (rows >= L carry no probability)
+    const int row = (WNT - 1) * 16 + fr;
+    const bf16x8_t qa0 = ld_rows(Qs, row, g * 16), qa1 = ld_rows(Qs, row, 64 + g * 16);
+    const s16x4_t qat = *(const s16x4_t*)(Qs + row * WROWB + 128 + g * 8);
+    const bf16x8_t da0 = ld_rows(dOs, row, g * 16), da1 = ld_rows(dOs, row, 64 + g * 16);
+    const s16x4_t dat = *(const s16x4_t*)(dOs + row * WROWB + 128 + g * 8);
+    const bf16x8_t ra = *(const bf16x8_t*)(Rs + row * 64 + ((g ^ esw) << 4));
+    const f32x4_t lse4 = *(const f32x4_t*)(lse_s + (WNT - 1) * 16 + g * 4), del4 = *(const f32x4_t*)(del_s + (WNT - 1) * 16 + g * 4);
+    const int qvalid = L - (WNT - 1) * 16 - 4 * g;
+    s16x4_t p4[2], d4[2];
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj) {
+      if (nj < ntile) {
+        f32x4_t a = mfma32(qa0, kv[nj].k[0], z4);
+        a = mfma32(qa1, kv[nj].k[1], a);
+        a = mfma16(qat, kv[nj].kt, a);
+        a = mfma32(ra, kv[nj].e, a);
+        f32x4_t c = mfma32(da0, kv[nj].v[0], z4);
+        c = mfma32(da1, kv[nj].v[1], c);
+        c = mfma16(dat, kv[nj].vt, c);
+        f32x4_t pp, dd;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pr = r < qvalid ? wexp2(a[r] - lse4[r]) : 0.f;
+          pp[r] = pr;
+          dd[r] = pr * (c[r] - del4[r]) * alpha;
+        }
+        p4[nj] = wpack4(pp);
+        d4[nj] = wpack4(dd);
+      }
+    }
+    KEEP_ALIVE4(qa0, qa1, qat, ra);
+    KEEP_ALIVE3(da0, da1, dat);
+#pragma unroll
+    for (int dt = 0; dt < 5; ++dt) {
+      const s16x4_t dob = tr4(dOs, (WNT - 1) * 16, dt * 16, lane);
+      const s16x4_t qb = tr4(Qs, (WNT - 1) * 16, dt * 16, lane);
+#pragma unroll
+      for (int nj = 0; nj < 2; ++nj) {
+        if (nj < ntile) {
+          dv[nj][dt] = mfma16(dob, p4[nj], dv[nj][dt]);
+          dk[nj][dt] = mfma16(qb, d4[nj], dk[nj][dt]);
+        }
+      }
+    }
+  }
+  // lane holds dK^T / dV^T[d = dt*16 + 4g + r][key = fr]
+#pragma unroll
+  for (int nj = 0; nj < 2; ++nj) {
+    const int key = (kt0 + 4 * nj) * 16 + fr;
+    if (nj < ntile && key < L) {
+      store_t(DK, ld_dk, key, dk[nj], g);
+      store_t(DV, ld_dv, key, dv[nj], g);
+    }
+  }
+}
+
+struct QDPair {         // B operands of one pair of 16-query tiles (phase B)
+  QPair q;              // Q and rel', pre-scaled into the exp2 domain
+  bf16x8_t d[2][2];     // dO
+  s16x4_t dt[2];
+  float lse2[2], del[2];
+};
+
+__device__ __forceinline__ void bwd_queries(const QDPair& x, const char* Ks, const char* Vs, const char* Es, int q0, int L, float alpha, int lane,
+                                            bf16_raw* __restrict__ DQ, int ld_dq, bf16_raw* __restrict__ DR) {
+  const int fr = lane & 15, g = lane >> 4;
+  const int esw = e_swz(fr);
+  const f32x4_t z4 = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  f32x4_t dq[2][5], drl[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    drl[mi][0] = z4;
+    drl[mi][1] = z4;
+#pragma unroll
+    for (int dt = 0; dt < 5; ++dt) dq[mi][dt] = z4;
+  }
+#pragma nounroll
+  for (int s2 = 0; s2 < WNT / 2; ++s2) {  // 32 keys per step
+    f32x4_t s[2][2], dp[2][2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int row = (2 * s2 + ni) * 16 + fr;
+      const bf16x8_t k0 = ld_rows(Ks, row, g * 16), k1 = ld_rows(Ks, row, 64 + g * 16);
+      const s16x4_t kt = *(const s16x4_t*)(Ks + row * WROWB + 128 + g * 8);
+      const bf16x8_t v0 = ld_rows(Vs, row, g * 16), v1 = ld_rows(Vs, row, 64 + g * 16);
+      const s16x4_t vt = *(const s16x4_t*)(Vs + row * WROWB + 128 + g * 8);
+      const bf16x8_t ef = *(const bf16x8_t*)(Es + row * 64 + ((g ^ esw) << 4));
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        f32x4_t a = mfma32(k0, x.q.f[mi][0], z4);
+        a = mfma32(k1, x.q.f[mi][1], a);
+        a = mfma16(kt, x.q.t[mi], a);
+        s[mi][ni] = mfma32(ef, x.q.rel[mi], a);
+        f32x4_t c = mfma32(v0, x.d[mi][0], z4);
+        c = mfma32(v1, x.d[mi][1], c);
+        dp[mi][ni] = mfma16(vt, x.dt[mi], c);
+      }
+      KEEP_ALIVE4(k0, k1, kt, ef);
+      KEEP_ALIVE3(v0, v1, vt);
+    }
+    bf16x8_t dsf[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pr = wexp2(s[mi][ni][r] - x.lse2[mi]);
+          s[mi][ni][r] = pr * (dp[mi][ni][r] - x.del[mi]) * alpha;
+        }
+      dsf[mi] = wpack(s[mi][0], s[mi][1]);
+    }
+#pragma unroll
+    for (int dt = 0; dt < 5; ++dt) {
+      const bf16x8_t ktr = tr8(Ks, s2 * 32, dt * 16, lane);
+      dq[0][dt] = mfma32(ktr, dsf[0], dq[0][dt]);
+      dq[1][dt] = mfma32(ktr, dsf[1], dq[1][dt]);
+    }
+#pragma unroll
+    for (int bt = 0; bt < 2; ++bt) {
+      const bf16x8_t et = tr8e(Es, s2 * 32, bt * 16, lane);
+      drl[0][bt] = mfma32(et, dsf[0], drl[0][bt]);
+      drl[1][bt] = mfma32(et, dsf[1], drl[1][bt]);
+    }
+  }
+  {  // the 13th key tile (keys >= L carry no probability)
+    const int row = (WNT - 1) * 16 + fr;
+    const bf16x8_t k0 = ld_rows(Ks, row, g * 16), k1 = ld_rows(Ks, row, 64 + g * 16);
+    const s16x4_t kt = *(const s16x4_t*)(Ks + row * WROWB + 128 + g * 8);
+    const bf16x8_t v0 = ld_rows(Vs, row, g * 16), v1 = ld_rows(Vs, row, 64 + g * 16);
+    const s16x4_t vt = *(const s16x4_t*)(Vs + row * WROWB + 128 + g * 8);
+    const bf16x8_t ef = *(const bf16x8_t*)(Es + row * 64 + ((g ^ esw) << 4));
+    const int kvalid = L - (WNT - 1) * 16 - 4 * g;
+    s16x4_t d4[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      f32x4_t a = mfma32(k0, x.q.f[mi][0], z4);
+      a = mfma32(k1, x.q.f[mi][1], a);
+      a = mfma16(kt, x.q.t[mi], a);
+      a = mfma32(ef, x.q.rel[mi], a);
+      f32x4_t c = mfma32(v0, x.d[mi][0], z4);
+      c = mfma32(v1, x.d[mi][1], c);
+      c = mfma16(vt, x.dt[mi], c);
+      f32x4_t dd;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pr = r < kvalid ? wexp2(a[r] - x.lse2[mi]) : 0.f;
+        dd[r] = pr * (c[r] - x.del[mi]) * alpha;
+      }
+      d4[mi] = wpack4(dd);
+    }
+    KEEP_ALIVE4(k0, k1, kt, ef);
+    KEEP_ALIVE3(v0, v1, vt);
+#pragma unroll
+    for (int dt = 0; dt < 5; ++dt) {
+      const s16x4_t ktr = tr4(Ks, (WNT - 1) * 16, dt * 16, lane);
+      dq[0][dt] = mfma16(ktr, d4[0], dq[0][dt]);
+      dq[1][dt] = mfma16(ktr, d4[1], dq[1][dt]);
+    }
+#pragma unroll
+    for (int bt = 0; bt < 2; ++bt) {
+      const s16x4_t et = tr4e(Es, (WNT - 1) * 16, bt * 16, lane);
+      drl[0][bt] = mfma16(et, d4[0], drl[0][bt]);
+      drl[1][bt] = mfma16(et, d4[1], drl[1][bt]);
+    }
+  }
+  // lane holds dQ^T[d][q = fr] and d rel'^T[bin = bt*16 + 4g + r][q = fr]
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int qi = q0 + mi * 16 + fr;
+    if (qi >= L) continue;
+    store_t(DQ, ld_dq, qi, dq[mi], g);
+    if (DR) {
+      bf16_raw* r = DR + (int64_t)qi * 32;
+#pragma unroll
+      for (int bt = 0; bt < 2; ++bt)
+        *(u32x2_t*)(r + bt * 16 + g * 4) = u32x2_t{pack2bf(drl[mi][bt][0], drl[mi][bt][1]), pack2bf(drl[mi][bt][2], drl[mi][bt][3])};
+    }
+  }
+}
+
+__global__ __launch_bounds__(WTHR, 2) void win_attn_bwd_kernel(const grove_flash_attn_params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Xs = smem;                  // Q, then K
+  char* Ys = smem + WIMGB;          // dO, then V
+  char* Rs = smem + 2 * WIMGB;      // rel' (pre-scaled), then the indicator image E
+  float* lse_s = (float*)(Rs + WEB);
+  float* del_s = lse_s + WNT * 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
+  const int L = p.Lq;
+  const int64_t bh = (int64_t)(b * p.H + h) * L;
+  const bf16_raw* Q = (const bf16_raw*)p.q + (int64_t)b * p.sq + h * p.hs;
+  const bf16_raw* K = (const bf16_raw*)p.k + (int64_t)b * p.sk + h * p.hs;
+  const bf16_raw* V = (const bf16_raw*)p.v + (int64_t)b * p.sv + h * p.hs;
+  const bf16_raw* dO = (const bf16_raw*)p.d_o + (int64_t)b * p.sdo + h * p.hs;
+  const bf16_raw* Og = (const bf16_raw*)p.o + (int64_t)b * p.so + h * p.hs;
+  const bf16_raw* REL = (const bf16_raw*)p.rel + bh * 32;
+  const float sc = p.alpha * 1.4426950408889634f;
+  // ---- prologue: Q, dO -> LDS (DMA); rel' (scaled) -> LDS; lse; delta
+  dma_image(Xs, Q, p.ld_q, L, wave, lane);
+  dma_image(Ys, dO, p.ld_do, L, wave, lane);
+  for (int c = tid; c < WNT * 16 * 4; c += WTHR) {
+    const int row = c >> 2, ch = c & 3;
+    u32x4_t v = u32x4_t{0u, 0u, 0u, 0u};
+    if (row < L) v = *(const u32x4_t*)(REL + (int64_t)row * 32 + ch * 8);
+    *(bf16x8_t*)(Rs + row * 64 + ((ch ^ e_swz(row)) << 4)) = wscale(__builtin_bit_cast(bf16x8_t, v), sc);
+  }
+  u32x4_t orow[10];
+  const int myrow = min(tid, L - 1);
+  if (tid < WNT * 16) {
+#pragma unroll
+    for (int c = 0; c < 10; ++c) orow[c] = *(const u32x4_t*)(Og + (int64_t)myrow * p.ld_o + c * 8);
+    lse_s[tid] = p.lse[bh + myrow] * 1.4426950408889634f;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid < WNT * 16) {
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < 10; ++c) {
+      const u32x4_t d = *(const u32x4_t*)(Ys + tid * WROWB + c * 16);
+      const u32x4_t o = orow[c];
+      acc += bf_lo(o.x) * bf_lo(d.x) + bf_hi(o.x) * bf_hi(d.x) + bf_lo(o.y) * bf_lo(d.y) + bf_hi(o.y) * bf_hi(d.y) +
+             bf_lo(o.z) * bf_lo(d.z) + bf_hi(o.z) * bf_hi(d.z) + bf_lo(o.w) * bf_lo(d.w) + bf_hi(o.w) * bf_hi(d.w);
+    }
+    del_s[tid] = acc;
+  }
+  __syncthreads();
+  // ---- phase A: dK, dV of this wave's key tiles {w, w+4} and {w+8, w+12}
+  bf16_raw* DK = (bf16_raw*)p.dk + (int64_t)b * p.sdk + h * p.hs;
+  bf16_raw* DV = (bf16_raw*)p.dv + (int64_t)b * p.sdv + h * p.hs;
+#pragma nounroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int kt0 = wave + 8 * pass;
+    const int ntile = (kt0 + 4 < WNT) ? 2 : 1;
+    bwd_keys(kt0, ntile, K, p.ld_k, V, p.ld_v, Xs, Ys, Rs, lse_s, del_s, L, sc, p.alpha, p.rel_kw, p.rel_kh, lane, DK, p.ld_dk, DV, p.ld_dv);
+  }
+  __syncthreads();
+  // ---- phase B: K, V, E replace Q, dO, rel' in LDS; dQ and d rel' of this wave's query-tile pairs
+  dma_image(Xs, K, p.ld_k, L, wave, lane);
+  dma_image(Ys, V, p.ld_v, L, wave, lane);
+  build_e(Rs, L, p.rel_kw, p.rel_kh, tid);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  bf16_raw* DQ = (bf16_raw*)p.dq + (int64_t)b * p.sdq + h * p.hs;
+  bf16_raw* DR = p.drel ? (bf16_raw*)p.drel + bh * 32 : nullptr;
+#pragma nounroll
+  for (int q0 = wave * 32; q0 < L; q0 += 128) {
+    QDPair x;
+    load_qpair(x.q, Q, p.ld_q, REL, q0, L, sc, fr, g);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int qi = min(q0 + mi * 16 + fr, L - 1);
+      const bf16_raw* row = dO + (int64_t)qi * p.ld_do;
+      x.d[mi][0] = *(const bf16x8_t*)(row + g * 8);
+      x.d[mi][1] = *(const bf16x8_t*)(row + 32 + g * 8);
+      x.dt[mi] = __builtin_bit_cast(s16x4_t, *(const u32x2_t*)(row + 64 + g * 4));
+      x.lse2[mi] = lse_s[qi];
+      x.del[mi] = del_s[qi];
+    }
+    bwd_queries(x, Xs, Ys, Rs, q0, L, p.alpha, lane, DQ, p.ld_dq, DR);
+  }
+}
+
+}  // namespace
+
+// Does this problem fit the window kernels? (192 < L <= 208 tokens, head dim 80 in a 96-wide slot, 32 rel bins, no masks)
+bool grove_win_attn_applicable(const grove_flash_attn_params* p) {
+  return p->hs == 96 && p->hs_valid == 80 && p->Lq == p->Lk && p->Lk > (WNT - 1) * 16 && p->Lk <= WNT * 16 && p->rel && p->rel_ld == 32 &&
+         !p->causal && !p->kv_len && p->ld_q % 8 == 0 && p->ld_k % 8 == 0 && p->ld_v % 8 == 0 && p->ld_o % 8 == 0;
+}
+
+int grove_win_attn_bwd_launch(const grove_flash_attn_params* p, hipStream_t s) {
+  const size_t lds = 2 * WIMGB + WEB + 2 * WNT * 16 * sizeof(float);
+  hipFuncSetAttribute((const void*)win_attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(win_attn_bwd_kernel, dim3((unsigned)(p->B * p->H)), dim3(WTHR), lds, s, *p);
+  return 0;
+}
+
+int grove_win_attn_fwd_launch(const grove_flash_attn_params* p, hipStream_t s) {
+  const size_t lds = 2 * WIMGB + WEB;
+  hipFuncSetAttribute((const void*)win_attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(win_attn_fwd_kernel, dim3((unsigned)(p->B * p->H)), dim3(WTHR), lds, s, *p);
+  return 0;
+}

@@ -179,7 +179,7 @@ class SamEncoder:
         rel = torch.empty((nb * nh, L, rel_ld), dtype=torch.bfloat16, device=self.dev)
         ops.gemm_raw(qkv, Bk["Rcat"], rel, nb * nh, rel_ld, hp, hp, hp, L * rel_ld, a_idx=hrow, batch=(L, 1),
                      sA=(ld, 0), sB=(rel_ld * hp, 0), sC=(rel_ld, 0))
-        o, actx = attention_fwd(qkv, nb, L, nh, hp, 0, nh * hp, 2 * nh * hp, hd ** -0.5, rel=rel, rel_hw=(Bk["khp"], qhw[1]), save=save)
+        o, actx = attention_fwd(qkv, nb, L, nh, hp, 0, nh * hp, 2 * nh * hp, hd ** -0.5, rel=rel, rel_hw=(Bk["khp"], qhw[1]), save=save, hs_valid=hd)
         del rel
         if ws > 0:  # un-partition = gather the real tokens' rows of the windowed attention output (padding rows are dropped)
             if Bk["maps"]:

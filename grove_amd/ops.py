@@ -251,7 +251,7 @@ def softmax_bwd(dprobs, probs, Lk, scale, *, drel=None, rel_hw=(0, 0), out=None)
 
 
 def flash_attn(qkv, B, L, H, hs, q_off, k_off, v_off, alpha, *, causal=False, kv_len=None, rel=None, rel_hw=(0, 0), out=None,
-               want_lse=False):
+               want_lse=False, hs_valid=0):
     """Fused attention over a fused qkv activation [B*L, ld]; returns (out [B*L, H*hs], lse or None)."""
     dev = qkv.device
     ld = qkv.stride(0)
@@ -268,6 +268,7 @@ def flash_attn(qkv, B, L, H, hs, q_off, k_off, v_off, alpha, *, causal=False, kv
     p.ld_o = out.stride(0)
     p.causal, p.rel_kh, p.rel_kw, p.alpha = int(causal), rel_hw[0], rel_hw[1], alpha
     p.rel_ld = rel.shape[-1] if rel is not None else 0
+    p.hs_valid = hs_valid
     _lib.check(_lib.lib().grove_flash_attn_fwd(C.byref(p), _stream()), "grove_flash_attn_fwd")
     return out, lse
 
@@ -331,7 +332,7 @@ def flash_attn_kv(q, k, v, B, H, Lq, Lk, hs, alpha, *, sq, sk, sv, ld_q, ld_k, l
     return out
 
 def flash_attn_bwd(qkv, out, d_out, lse, dqkv, B, L, H, hs, q_off, k_off, v_off, alpha, *, causal=False, kv_len=None, rel=None,
-                   rel_hw=(0, 0), want_drel=False):
+                   rel_hw=(0, 0), want_drel=False, hs_valid=0):
     dev = qkv.device
     ld, ldd = qkv.stride(0), dqkv.stride(0)
     delta = torch.empty((B * H, L), dtype=torch.float32, device=dev)
@@ -349,6 +350,7 @@ def flash_attn_bwd(qkv, out, d_out, lse, dqkv, B, L, H, hs, q_off, k_off, v_off,
     p.ld_dq = p.ld_dk = p.ld_dv = ldd
     p.causal, p.rel_kh, p.rel_kw, p.alpha = int(causal), rel_hw[0], rel_hw[1], alpha
     p.rel_ld = rel.shape[-1] if rel is not None else 0
+    p.hs_valid = hs_valid
     _lib.check(_lib.lib().grove_flash_attn_bwd(C.byref(p), _stream()), "grove_flash_attn_bwd")
     return drel
 

@@ -277,9 +277,14 @@ typedef struct grove_flash_attn_params {
   int32_t ld_q, ld_k, ld_v, ld_o, ld_do, ld_dq, ld_dk, ld_dv;
   int32_t causal, rel_kh, rel_kw, rel_ld; /* key j -> bins j / rel_kw and rel_kh + j % rel_kw */
   float alpha;
+  int32_t hs_valid; /* real head dim inside the hs-wide slot (0 = hs). SAM: 80 in 96 — with Lq == Lk in (192, 208] and 32 rel bins
+                       (the 14 x 14 windows of image_encoder.py:329-353) the LDS-resident window kernels run (win_attn.hip): nothing
+                       is multiplied by the padding, and the pad columns of o / dq / dk / dv are written as zeros */
 } grove_flash_attn_params;
 int grove_flash_attn_fwd(const grove_flash_attn_params* p, void* stream);
 int grove_flash_attn_bwd(const grove_flash_attn_params* p, void* stream);
+/* 1 (default): problems that fit them run on the window kernels; 0: always the general kernels (A/B arm of tests and tools) */
+int grove_flash_attn_set_window_kernels(int32_t on);
 
 /* Decomposed relative-position terms of SAM attention (image_encoder.py:420-458):
  * rel[b*heads + h, q, 0:kh]     = sum_c qv[q, h, c] * Rh[qh(q), :, c]

@@ -604,6 +604,9 @@ def test_gemm_split_k_atomics(dev):
     (1, 2, 1024, 96, 80, False, False, (32, 32)),
     (2, 4, 50, 32, 16, False, False, (5, 10)),
     (1, 2, 703, 128, 128, True, False, None),
+    (5, 16, 196, 96, 80, False, False, (14, 14)),   # SAM window problem, many (window, head) pairs: the LDS-resident window kernels
+    (2, 3, 208, 96, 80, False, False, (13, 16)),    # every key / query tile full
+    (2, 2, 195, 96, 80, False, False, (13, 15)),    # three valid rows in the last tile
 ])
 def test_flash_attention_fwd_bwd(dev, B, H, L, hs, hd, causal, use_len, rel_hw):
     """Fused attention (fwd, dQ/dK/dV, d rel) against torch autograd in fp32 on the same bf16 inputs.
@@ -651,13 +654,26 @@ def test_flash_attention_fwd_bwd(dev, B, H, L, hs, hd, causal, use_len, rel_hw):
     rel_d = relp.to(dev) if relp is not None else None
     rel_arg = (khp, kw) if relp is not None else (0, 0)
     kvl = kv_len.to(dev) if kv_len is not None else None
+    hv = hd if hd < hs else 0
     out, lse = ops.flash_attn(dev_qkv, B, L, H, hs, 0, H * hs, 2 * H * hs, alpha, causal=causal, kv_len=kvl, rel=rel_d,
-                              rel_hw=rel_arg, want_lse=True)
+                              rel_hw=rel_arg, want_lse=True, hs_valid=hv)
     close(out, o_ref, 1e-2, "flash fwd")
     close(lse, lse_ref, 2e-3, "lse")
+    if hv == 80 and 192 < L <= 208 and rel_arg[0] + 16 == 32:
+        # this problem ran on the window kernels (win_attn.hip): same result from the general kernels, pad columns exact zeros
+        from grove_amd import _lib
+        _lib.lib().grove_flash_attn_set_window_kernels(0)
+        try:
+            out_g, lse_g = ops.flash_attn(dev_qkv, B, L, H, hs, 0, H * hs, 2 * H * hs, alpha, rel=rel_d, rel_hw=rel_arg, want_lse=True,
+                                          hs_valid=hv)
+        finally:
+            _lib.lib().grove_flash_attn_set_window_kernels(1)
+        close(out, out_g.float().cpu(), 1e-2, "window kernel vs general kernel")
+        close(lse, lse_g.float().cpu(), 2e-3, "window kernel lse vs general kernel")
+        assert float(out.view(B * L, H, hs)[..., hd:].float().abs().max()) == 0.0
     dqkv = torch.full_like(dev_qkv, float("nan"))
     drel = ops.flash_attn_bwd(dev_qkv, out, do.to(dev), lse, dqkv, B, L, H, hs, 0, H * hs, 2 * H * hs, alpha, causal=causal,
-                              kv_len=kvl, rel=rel_d, rel_hw=rel_arg, want_drel=relp is not None)
+                              kv_len=kvl, rel=rel_d, rel_hw=rel_arg, want_drel=relp is not None, hs_valid=hv)
     gref = t.grad.reshape(B * L, 3 * H * hs)
     for name, c0 in (("dq", 0), ("dk", H * hs), ("dv", 2 * H * hs)):
         close(dqkv[:, c0:c0 + H * hs], gref[:, c0:c0 + H * hs], 2e-2, name)
