@@ -126,6 +126,15 @@ __device__ __forceinline__ bf16x8_t tr8(const char* img, int r0, int c0, int lan
   return __builtin_bit_cast(bf16x8_t, v);
 }
 
+// Workgroups are dealt to the 8 XCDs round-robin (block i -> XCD i % 8). The heads of one window share cache lines (a head's row
+// is 160 of 192 bytes, so every other 128-byte line holds two heads): problem = (window, head) with the head fastest, and
+// consecutive problems go to the SAME XCD so that its L2 sees each line once (bijective for any grid size).
+__device__ __forceinline__ int problem_of_block(int bid, int n) {
+  const int per = n >> 3, rem = n & 7;   // XCD x owns per (+1 if x < rem) consecutive problems
+  const int x = bid & 7, s = bid >> 3;
+  return x * per + min(x, rem) + s;
+}
+
 struct QPair {          // B operands of one pair of 16-query tiles, pre-scaled into the exp2 domain
   bf16x8_t f[2][2];     // head-dim k-steps 0..31, 32..63
   s16x4_t t[2];         // head dim 64..79 (16-deep step)
@@ -245,7 +254,8 @@ __global__ __launch_bounds__(WTHR, 2) void win_attn_fwd_kernel(const grove_flash
   char* Es = smem + 2 * WIMGB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, g = lane >> 4;
-  const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
+  const int pidx = problem_of_block(blockIdx.x, gridDim.x);
+  const int b = pidx / p.H, h = pidx - b * p.H;
   const int L = p.Lq;
   const bf16_raw* Q = (const bf16_raw*)p.q + (int64_t)b * p.sq + h * p.hs;
   const bf16_raw* K = (const bf16_raw*)p.k + (int64_t)b * p.sk + h * p.hs;
@@ -257,13 +267,17 @@ __global__ __launch_bounds__(WTHR, 2) void win_attn_fwd_kernel(const grove_flash
   dma_image(Ks, K, p.ld_k, L, wave, lane);
   dma_image(Vs, V, p.ld_v, L, wave, lane);
   build_e(Es, L, p.rel_kw, p.rel_kh, tid);
+  QPair q;
+  load_qpair(q, Q, p.ld_q, REL, wave * 32, L, sc, fr, g);  // in flight together with the DMA
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 #pragma nounroll
   for (int q0 = wave * 32; q0 < L; q0 += 128) {
-    QPair q;
-    load_qpair(q, Q, p.ld_q, REL, q0, L, sc, fr, g);
+    QPair qn;
+    const bool more = q0 + 128 < L;
+    if (more) load_qpair(qn, Q, p.ld_q, REL, q0 + 128, L, sc, fr, g);  // lands under this pair's MFMAs
     fwd_pair(q, Ks, Vs, Es, q0, L, lane, O, p.ld_o, LSE);
+    if (more) q = qn;
   }
 }
 
@@ -309,16 +323,13 @@ __device__ __forceinline__ void store_t(bf16_raw* __restrict__ dst, int ld, int 
   *(u32x2_t*)(r + 80 + g * 4) = u32x2_t{0u, 0u};
 }
 
-// phase A for up to two key tiles kt0, kt0 + 4 of this wave
-__device__ __forceinline__ void bwd_keys(int kt0, int ntile, const bf16_raw* __restrict__ K, int ld_k, const bf16_raw* __restrict__ V, int ld_v,
-                                         const char* Qs, const char* dOs, const char* Rs, const float* lse_s, const float* del_s, int L, float sc,
-                                         float alpha, int kw, int KH, int lane, bf16_raw* __restrict__ DK, int ld_dk, bf16_raw* __restrict__ DV,
-                                         int ld_dv) {
+// phase A for NTILE (1 or 2) key tiles kt0, kt0 + 4 of this wave
+template <int NTILE>
+__device__ __forceinline__ void load_kv(KVFrag (&kv)[NTILE], int kt0, const bf16_raw* __restrict__ K, int ld_k, const bf16_raw* __restrict__ V,
+                                        int ld_v, int L, float sc, int kw, int KH, int lane) {
   const int fr = lane & 15, g = lane >> 4;
-  const int esw = e_swz(fr);
-  KVFrag kv[2];
 #pragma unroll
-  for (int nj = 0; nj < 2; ++nj) {
+  for (int nj = 0; nj < NTILE; ++nj) {
     const int key = (kt0 + 4 * nj) * 16 + fr;
     const int kc = min(key, L - 1);
     const bf16_raw* kr = K + (int64_t)kc * ld_k;
@@ -332,15 +343,24 @@ __device__ __forceinline__ void bwd_keys(int kt0, int ntile, const bf16_raw* __r
     const unsigned kb = key < L ? (unsigned)((key / kw) | ((key % kw) << 8)) : 0xFFFFu;
     kv[nj].e = e_chunk(kb, g * 8, KH);
   }
-  f32x4_t dk[2][5], dv[2][5];
+}
+
+template <int NTILE>
+__device__ __forceinline__ void bwd_keys(const KVFrag (&kv)[NTILE], int kt0,
+                                         const char* Qs, const char* dOs, const char* Rs, const float* lse_s, const float* del_s, int L,
+                                         float alpha, int lane, bf16_raw* __restrict__ DK, int ld_dk, bf16_raw* __restrict__ DV, int ld_dv) {
+  const int fr = lane & 15, g = lane >> 4;
+  const int esw = e_swz(fr);
+  constexpr int ntile = NTILE;
+  f32x4_t dk[NTILE][5], dv[NTILE][5];
 #pragma unroll
-  for (int nj = 0; nj < 2; ++nj)
+  for (int nj = 0; nj < NTILE; ++nj)
 #pragma unroll
     for (int dt = 0; dt < 5; ++dt) { dk[nj][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dv[nj][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
   const f32x4_t z4 = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma nounroll
   for (int qs = 0; qs < WNT / 2; ++qs) {  // 32 queries per step
-    f32x4_t sacc[2][2], pacc[2][2];
+    f32x4_t sacc[2][NTILE], pacc[2][NTILE];
 #pragma unroll
     for (int qi_ = 0; qi_ < 2; ++qi_) {
       const int row = (2 * qs + qi_) * 16 + fr;
@@ -350,7 +370,7 @@ __device__ __forceinline__ void bwd_keys(int kt0, int ntile, const bf16_raw* __r
       const s16x4_t dat = *(const s16x4_t*)(dOs + row * WROWB + 128 + g * 8);
       const bf16x8_t ra = *(const bf16x8_t*)(Rs + row * 64 + ((g ^ esw) << 4));
 #pragma unroll
-      for (int nj = 0; nj < 2; ++nj) {
+      for (int nj = 0; nj < NTILE; ++nj) {
         if (nj < ntile) {
           f32x4_t a = mfma32(qa0, kv[nj].k[0], z4);
           a = mfma32(qa1, kv[nj].k[1], a);
@@ -370,9 +390,9 @@ __device__ __forceinline__ void bwd_keys(int kt0, int ntile, const bf16_raw* __r
       lse4[qi_] = *(const f32x4_t*)(lse_s + (2 * qs + qi_) * 16 + g * 4);
       del4[qi_] = *(const f32x4_t*)(del_s + (2 * qs + qi_) * 16 + g * 4);
     }
-    bf16x8_t pfr[2], dsfr[2];
+    bf16x8_t pfr[NTILE], dsfr[NTILE];
 #pragma unroll
-    for (int nj = 0; nj < 2; ++nj) {
+    for (int nj = 0; nj < NTILE; ++nj) {
       if (nj < ntile) {
         f32x4_t pp[2], dd[2];
 #pragma unroll
@@ -392,7 +412,7 @@ __device__ __forceinline__ void bwd_keys(int kt0, int ntile, const bf16_raw* __r
       const bf16x8_t dob = tr8(dOs, qs * 32, dt * 16, lane);
       const bf16x8_t qb = tr8(Qs, qs * 32, dt * 16, lane);
 #pragma unroll
-      for (int nj = 0; nj < 2; ++nj) {
+      for (int nj = 0; nj < NTILE; ++nj) {
         if (nj < ntile) {
           dv[nj][dt] = mfma32(dob, pfr[nj], dv[nj][dt]);
           dk[nj][dt] = mfma32(qb, dsfr[nj], dk[nj][dt]);
@@ -409,9 +429,9 @@ __device__ __forceinline__ void bwd_keys(int kt0, int ntile, const bf16_raw* __r
     const bf16x8_t ra = *(const bf16x8_t*)(Rs + row * 64 + ((g ^ esw) << 4));
     const f32x4_t lse4 = *(const f32x4_t*)(lse_s + (WNT - 1) * 16 + g * 4), del4 = *(const f32x4_t*)(del_s + (WNT - 1) * 16 + g * 4);
     const int qvalid = L - (WNT - 1) * 16 - 4 * g;
-    s16x4_t p4[2], d4[2];
+    s16x4_t p4[NTILE], d4[NTILE];
 #pragma unroll
-    for (int nj = 0; nj < 2; ++nj) {
+    for (int nj = 0; nj < NTILE; ++nj) {
       if (nj < ntile) {
         f32x4_t a = mfma32(qa0, kv[nj].k[0], z4);
         a = mfma32(qa1, kv[nj].k[1], a);
@@ -438,7 +458,7 @@ __device__ __forceinline__ void bwd_keys(int kt0, int ntile, const bf16_raw* __r
       const s16x4_t dob = tr4(dOs, (WNT - 1) * 16, dt * 16, lane);
       const s16x4_t qb = tr4(Qs, (WNT - 1) * 16, dt * 16, lane);
 #pragma unroll
-      for (int nj = 0; nj < 2; ++nj) {
+      for (int nj = 0; nj < NTILE; ++nj) {
         if (nj < ntile) {
           dv[nj][dt] = mfma16(dob, p4[nj], dv[nj][dt]);
           dk[nj][dt] = mfma16(qb, d4[nj], dk[nj][dt]);
@@ -448,7 +468,7 @@ __device__ __forceinline__ void bwd_keys(int kt0, int ntile, const bf16_raw* __r
   }
   // lane holds dK^T / dV^T[d = dt*16 + 4g + r][key = fr]
 #pragma unroll
-  for (int nj = 0; nj < 2; ++nj) {
+  for (int nj = 0; nj < NTILE; ++nj) {
     const int key = (kt0 + 4 * nj) * 16 + fr;
     if (nj < ntile && key < L) {
       store_t(DK, ld_dk, key, dk[nj], g);
@@ -591,7 +611,8 @@ __global__ __launch_bounds__(WTHR, 2) void win_attn_bwd_kernel(const grove_flash
   float* del_s = lse_s + WNT * 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, g = lane >> 4;
-  const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
+  const int pidx = problem_of_block(blockIdx.x, gridDim.x);
+  const int b = pidx / p.H, h = pidx - b * p.H;
   const int L = p.Lq;
   const int64_t bh = (int64_t)(b * p.H + h) * L;
   const bf16_raw* Q = (const bf16_raw*)p.q + (int64_t)b * p.sq + h * p.hs;
@@ -617,6 +638,8 @@ __global__ __launch_bounds__(WTHR, 2) void win_attn_bwd_kernel(const grove_flash
     for (int c = 0; c < 10; ++c) orow[c] = *(const u32x4_t*)(Og + (int64_t)myrow * p.ld_o + c * 8);
     lse_s[tid] = p.lse[bh + myrow] * 1.4426950408889634f;
   }
+  KVFrag kv0[2];
+  load_kv<2>(kv0, wave, K, p.ld_k, V, p.ld_v, L, sc, p.rel_kw, p.rel_kh, lane);  // pass 0's fragments: in flight with the DMA
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid < WNT * 16) {
@@ -634,24 +657,24 @@ __global__ __launch_bounds__(WTHR, 2) void win_attn_bwd_kernel(const grove_flash
   // ---- phase A: dK, dV of this wave's key tiles {w, w+4} and {w+8, w+12}
   bf16_raw* DK = (bf16_raw*)p.dk + (int64_t)b * p.sdk + h * p.hs;
   bf16_raw* DV = (bf16_raw*)p.dv + (int64_t)b * p.sdv + h * p.hs;
-#pragma nounroll
-  for (int pass = 0; pass < 2; ++pass) {
-    const int kt0 = wave + 8 * pass;
-    const int ntile = (kt0 + 4 < WNT) ? 2 : 1;
-    bwd_keys(kt0, ntile, K, p.ld_k, V, p.ld_v, Xs, Ys, Rs, lse_s, del_s, L, sc, p.alpha, p.rel_kw, p.rel_kh, lane, DK, p.ld_dk, DV, p.ld_dv);
+  bwd_keys<2>(kv0, wave, Xs, Ys, Rs, lse_s, del_s, L, p.alpha, lane, DK, p.ld_dk, DV, p.ld_dv);
+  if (wave == 0) {  // key tiles {8, 12}
+    KVFrag kv1[2];
+    load_kv<2>(kv1, 8, K, p.ld_k, V, p.ld_v, L, sc, p.rel_kw, p.rel_kh, lane);
+    bwd_keys<2>(kv1, 8, Xs, Ys, Rs, lse_s, del_s, L, p.alpha, lane, DK, p.ld_dk, DV, p.ld_dv);
+  } else {          // key tile 8 + wave
+    KVFrag kv1[1];
+    load_kv<1>(kv1, 8 + wave, K, p.ld_k, V, p.ld_v, L, sc, p.rel_kw, p.rel_kh, lane);
+    bwd_keys<1>(kv1, 8 + wave, Xs, Ys, Rs, lse_s, del_s, L, p.alpha, lane, DK, p.ld_dk, DV, p.ld_dv);
   }
   __syncthreads();
   // ---- phase B: K, V, E replace Q, dO, rel' in LDS; dQ and d rel' of this wave's query-tile pairs
   dma_image(Xs, K, p.ld_k, L, wave, lane);
   dma_image(Ys, V, p.ld_v, L, wave, lane);
   build_e(Rs, L, p.rel_kw, p.rel_kh, tid);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
   bf16_raw* DQ = (bf16_raw*)p.dq + (int64_t)b * p.sdq + h * p.hs;
   bf16_raw* DR = p.drel ? (bf16_raw*)p.drel + bh * 32 : nullptr;
-#pragma nounroll
-  for (int q0 = wave * 32; q0 < L; q0 += 128) {
-    QDPair x;
+  auto load_x = [&](QDPair& x, int q0) {
     load_qpair(x.q, Q, p.ld_q, REL, q0, L, sc, fr, g);
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
@@ -660,10 +683,18 @@ __global__ __launch_bounds__(WTHR, 2) void win_attn_bwd_kernel(const grove_flash
       x.d[mi][0] = *(const bf16x8_t*)(row + g * 8);
       x.d[mi][1] = *(const bf16x8_t*)(row + 32 + g * 8);
       x.dt[mi] = __builtin_bit_cast(s16x4_t, *(const u32x2_t*)(row + 64 + g * 4));
-      x.lse2[mi] = lse_s[qi];
+      x.lse2[mi] = lse_s[qi];   // (lse_s / del_s are not overwritten by phase B's images)
       x.del[mi] = del_s[qi];
     }
+  };
+  QDPair x;
+  load_x(x, wave * 32);  // in flight with the DMA
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+#pragma nounroll
+  for (int q0 = wave * 32; q0 < L; q0 += 128) {
     bwd_queries(x, Xs, Ys, Rs, q0, L, p.alpha, lane, DQ, p.ld_dq, DR);
+    if (q0 + 128 < L) load_x(x, q0 + 128);
   }
 }
 

@@ -5,7 +5,7 @@ sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(_
 from grove_amd import ops
 dev = torch.device("cuda:0")
 bf = torch.bfloat16
-cases = [("sam window", 288, 16, 196, 96, 80, False, (14, 14)), ("sam global", 32, 16, 1024, 96, 80, False, (32, 32)),
+cases = [("sam window", 288, 16, 196, 96, 80, False, (14, 14)), ("sam win gen", 288, 16, 196, 96, 80, False, (14, 14)), ("sam global", 32, 16, 1024, 96, 80, False, (32, 32)),
          ("llama", 4, 32, 703, 128, 128, True, None), ("clip", 32, 16, 577, 64, 64, False, None)]
 for name, B, H, L, hs, hd, causal, rel_hw in cases:
     qkv = torch.zeros(B * L, 3 * H * hs, device=dev)
@@ -19,11 +19,14 @@ for name, B, H, L, hs, hd, causal, rel_hw in cases:
         arg = (khp, rel_hw[1])
     alpha = hd ** -0.5
     dq = torch.empty_like(qkv)
+    hv = hd if hd < hs else 0
+    from grove_amd import _lib
+    _lib.lib().grove_flash_attn_set_window_kernels(0 if name == "sam win gen" else 1)  # "gen": the general kernels on the window shape
     def fwd():
-        return ops.flash_attn(qkv, B, L, H, hs, 0, H * hs, 2 * H * hs, alpha, causal=causal, rel=rel, rel_hw=arg, want_lse=True)
+        return ops.flash_attn(qkv, B, L, H, hs, 0, H * hs, 2 * H * hs, alpha, causal=causal, rel=rel, rel_hw=arg, want_lse=True, hs_valid=hv)
     out, lse = fwd()
     def bwd():
-        ops.flash_attn_bwd(qkv, out, do, lse, dq, B, L, H, hs, 0, H * hs, 2 * H * hs, alpha, causal=causal, rel=rel, rel_hw=arg, want_drel=rel is not None)
+        ops.flash_attn_bwd(qkv, out, do, lse, dq, B, L, H, hs, 0, H * hs, 2 * H * hs, alpha, causal=causal, rel=rel, rel_hw=arg, want_drel=rel is not None, hs_valid=hv)
     res = []
     for fn, mult in ((fwd, 4), (bwd, 10)):
         fn(); torch.cuda.synchronize()

@@ -12,8 +12,12 @@ qkv = qkv.to(bf)
 do = torch.randn(B * L, H * hs, device=dev).to(bf)
 rel = torch.randn(B * H, L, 32, device=dev).to(bf)
 dq = torch.empty_like(qkv)
-for _ in range(3):
-    out, lse = ops.flash_attn(qkv, B, L, H, hs, 0, H * hs, 2 * H * hs, hd ** -0.5, rel=rel, rel_hw=(16, 14), want_lse=True)
-    ops.flash_attn_bwd(qkv, out, do, lse, dq, B, L, H, hs, 0, H * hs, 2 * H * hs, hd ** -0.5, rel=rel, rel_hw=(16, 14), want_drel=True)
+from grove_amd import _lib
+for window_kernels in (0, 1):  # 0: the general flash kernels on the window shape (round 1), 1: the LDS-resident window kernels
+    _lib.lib().grove_flash_attn_set_window_kernels(window_kernels)
+    for _ in range(3):
+        out, lse = ops.flash_attn(qkv, B, L, H, hs, 0, H * hs, 2 * H * hs, hd ** -0.5, rel=rel, rel_hw=(16, 14), want_lse=True, hs_valid=hd)
+        ops.flash_attn_bwd(qkv, out, do, lse, dq, B, L, H, hs, 0, H * hs, 2 * H * hs, hd ** -0.5, rel=rel, rel_hw=(16, 14), want_drel=True,
+                           hs_valid=hd)
 torch.cuda.synchronize()
 print("done")
