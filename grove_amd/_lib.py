@@ -77,7 +77,7 @@ class RowsParams(C.Structure):
 class SmallAttnParams(C.Structure):
     _fields_ = [("q", c_vp), ("k", c_vp), ("v", c_vp), ("o", c_vp), ("d_o", c_vp), ("dq", c_vp), ("dk", c_vp), ("dv", c_vp),
                 ("inst", c_i32), ("heads", c_i32), ("d", c_i32), ("Lq", c_i32), ("Lk", c_i32),
-                ("ld_q", c_i32), ("ld_k", c_i32), ("ld_v", c_i32), ("ld_o", c_i32)]
+                ("ld_q", c_i32), ("ld_k", c_i32), ("ld_v", c_i32), ("ld_o", c_i32), ("q_f32", c_i32), ("kv_f32", c_i32), ("o_f32", c_i32)]
 
 
 class BoxHeadParams(C.Structure):
@@ -129,6 +129,11 @@ class NormalizeParams(C.Structure):
                 ("top", c_i32), ("left", c_i32), ("out_dtype", c_i32), ("rescale", c_f32), ("mean", c_f32 * 3), ("std", c_f32 * 3)]
 
 
+class GemmF32Params(C.Structure):
+    _fields_ = [("A", c_vp), ("W", c_vp), ("bias", c_vp), ("residual", c_vp), ("C", c_vp), ("C_bf16", c_vp),
+                ("M", c_i32), ("N", c_i32), ("K", c_i32), ("lda", c_i32), ("ldw", c_i32), ("ldc", c_i32), ("ldr", c_i32), ("act", c_i32)]
+
+
 STRUCTS = {
     "grove_gemm_params": GemmParams, "grove_transpose_params": TransposeParams, "grove_norm_params": NormParams,
     "grove_norm_bwd_params": NormBwdParams, "grove_softmax_params": SoftmaxParams,
@@ -136,7 +141,7 @@ STRUCTS = {
     "grove_rows_params": RowsParams, "grove_small_attn_params": SmallAttnParams, "grove_box_head_params": BoxHeadParams,
     "grove_box_head_bwd_params": BoxHeadBwdParams, "grove_flash_attn_params": FlashAttnParams,
     "grove_gemm_tn_params": GemmTnParams, "grove_gemv_params": GemvParams, "grove_decode_attn_params": DecodeAttnParams, "grove_resample_params": ResampleParams,
-    "grove_normalize_params": NormalizeParams,
+    "grove_normalize_params": NormalizeParams, "grove_gemm_f32_params": GemmF32Params,
 }
 
 # every symbol include/grove_hip.h declares (tests/test_abi.py checks the header against this list)
@@ -146,7 +151,7 @@ SYMBOLS = [
     "grove_flash_attn_fwd", "grove_flash_attn_bwd", "grove_flash_attn_set_window_kernels", "grove_softmax_fwd", "grove_softmax_bwd", "grove_relpos_fwd", "grove_relpos_bwd", "grove_rope_inplace",
     "grove_swiglu_fwd", "grove_swiglu_bwd", "grove_act_bwd", "grove_add_bf16", "grove_add_bcast_rows",
     "grove_copy_rows", "grove_dot_bf16", "grove_axpy_f32", "grove_scatter_add_f32", "grove_colsum_f32", "grove_cast_f32_to_bf16", "grove_cast_bf16_to_f32",
-    "grove_im2col_patch", "grove_clip_pool", "grove_cross_entropy", "grove_small_attn_fwd", "grove_small_attn_bwd",
+    "grove_im2col_patch", "grove_clip_pool", "grove_cross_entropy", "grove_small_attn_fwd", "grove_small_attn_bwd", "grove_gemm_f32",
     "grove_box_head_fwd", "grove_box_head_bwd", "grove_box_losses", "grove_adamw_step", "grove_adamw_step_multi", "grove_sumsq_f32",
 ]
 

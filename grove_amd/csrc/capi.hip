@@ -43,6 +43,7 @@ extern "C" int grove_sizeof(const char* name) {
   SZ(grove_decode_attn_params);
   SZ(grove_resample_params);
   SZ(grove_normalize_params);
+  SZ(grove_gemm_f32_params);
 #undef SZ
   return -1;
 }

@@ -88,27 +88,32 @@ __global__ __launch_bounds__(256) void ce_kernel(const bf16_raw* __restrict__ lo
 // "few queries": one wave per (instance, head), loops the <= 8 queries; lanes own keys.
 constexpr int MAXD = 32;
 constexpr int MAXQ = 8;
+// element i of a bf16 or f32 array (the generic kernels serve the fp32 token path of the decoder: q_f32 / kv_f32 / o_f32)
+__device__ __forceinline__ float ldx(const void* base, int64_t i, int f32) { return f32 ? ((const float*)base)[i] : bf2f(((const bf16_raw*)base)[i]); }
+__device__ __forceinline__ void stx(void* base, int64_t i, float v, int f32) {
+  if (f32) ((float*)base)[i] = v;
+  else ((bf16_raw*)base)[i] = f2bf(v);
+}
 
 __global__ __launch_bounds__(64) void attn_fewq_fwd_kernel(const grove_small_attn_params p) {
   const int inst = blockIdx.x / p.heads, h = blockIdx.x - inst * p.heads;
   const int lane = threadIdx.x;
   const int d = p.d;
   const float scale = rsqrtf((float)d);
-  const bf16_raw* q = (const bf16_raw*)p.q + (int64_t)inst * p.Lq * p.ld_q + h * d;
-  const bf16_raw* k = (const bf16_raw*)p.k + (int64_t)inst * p.Lk * p.ld_k + h * d;
-  const bf16_raw* v = (const bf16_raw*)p.v + (int64_t)inst * p.Lk * p.ld_v + h * d;
-  bf16_raw* o = (bf16_raw*)p.o + (int64_t)inst * p.Lq * p.ld_o + h * d;
+  const int qf = p.q_f32, kf = p.kv_f32, of = p.o_f32;
+  const int64_t q0 = (int64_t)inst * p.Lq * p.ld_q + h * d, k0 = (int64_t)inst * p.Lk * p.ld_k + h * d;
+  const int64_t v0 = (int64_t)inst * p.Lk * p.ld_v + h * d, o0 = (int64_t)inst * p.Lq * p.ld_o + h * d;
   for (int qi = 0; qi < p.Lq; ++qi) {
     float qv[MAXD];
 #pragma unroll
-    for (int c = 0; c < MAXD; ++c) qv[c] = c < d ? bf2f(q[(int64_t)qi * p.ld_q + c]) * scale : 0.f;
+    for (int c = 0; c < MAXD; ++c) qv[c] = c < d ? ldx(p.q, q0 + (int64_t)qi * p.ld_q + c, qf) * scale : 0.f;
     // pass 1: max
     float mx = -INFINITY;
     for (int j = lane; j < p.Lk; j += 64) {
       float s = 0.f;
 #pragma unroll
       for (int c = 0; c < MAXD; ++c)
-        if (c < d) s += qv[c] * bf2f(k[(int64_t)j * p.ld_k + c]);
+        if (c < d) s += qv[c] * ldx(p.k, k0 + (int64_t)j * p.ld_k + c, kf);
       mx = fmaxf(mx, s);
     }
     mx = wave_max(mx);
@@ -120,12 +125,12 @@ __global__ __launch_bounds__(64) void attn_fewq_fwd_kernel(const grove_small_att
       float s = 0.f;
 #pragma unroll
       for (int c = 0; c < MAXD; ++c)
-        if (c < d) s += qv[c] * bf2f(k[(int64_t)j * p.ld_k + c]);
+        if (c < d) s += qv[c] * ldx(p.k, k0 + (int64_t)j * p.ld_k + c, kf);
       const float e = __expf(s - mx);
       l += e;
 #pragma unroll
       for (int c = 0; c < MAXD; ++c)
-        if (c < d) acc[c] += e * bf2f(v[(int64_t)j * p.ld_v + c]);
+        if (c < d) acc[c] += e * ldx(p.v, v0 + (int64_t)j * p.ld_v + c, kf);
     }
     l = wave_sum(l);
     const float inv = 1.f / l;
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(64) void attn_fewq_fwd_kernel(const grove_small_att
     for (int c = 0; c < MAXD; ++c) {
       if (c < d) {
         const float r = wave_sum(acc[c]) * inv;
-        if (lane == 0) o[(int64_t)qi * p.ld_o + c] = f2bf(r);
+        if (lane == 0) stx(p.o, o0 + (int64_t)qi * p.ld_o + c, r, of);
       }
     }
   }
@@ -425,12 +430,12 @@ __global__ __launch_bounds__(64) void attn_fewk_fwd_kernel(const grove_small_att
   if (qi >= p.Lq) return;
   const int d = p.d;
   const float scale = rsqrtf((float)d);
-  const bf16_raw* q = (const bf16_raw*)p.q + ((int64_t)inst * p.Lq + qi) * p.ld_q + h * d;
-  const bf16_raw* k = (const bf16_raw*)p.k + (int64_t)inst * p.Lk * p.ld_k + h * d;
-  const bf16_raw* v = (const bf16_raw*)p.v + (int64_t)inst * p.Lk * p.ld_v + h * d;
+  const int qf = p.q_f32, kf = p.kv_f32, of = p.o_f32;
+  const int64_t q0 = ((int64_t)inst * p.Lq + qi) * p.ld_q + h * d, k0 = (int64_t)inst * p.Lk * p.ld_k + h * d;
+  const int64_t v0 = (int64_t)inst * p.Lk * p.ld_v + h * d, o0 = ((int64_t)inst * p.Lq + qi) * p.ld_o + h * d;
   float qv[MAXD];
 #pragma unroll
-  for (int c = 0; c < MAXD; ++c) qv[c] = c < d ? bf2f(q[c]) * scale : 0.f;
+  for (int c = 0; c < MAXD; ++c) qv[c] = c < d ? ldx(p.q, q0 + c, qf) * scale : 0.f;
   float s[MAXK];
   float mx = -INFINITY;
 #pragma unroll
@@ -440,7 +445,7 @@ __global__ __launch_bounds__(64) void attn_fewk_fwd_kernel(const grove_small_att
       float a = 0.f;
 #pragma unroll
       for (int c = 0; c < MAXD; ++c)
-        if (c < d) a += qv[c] * bf2f(k[(int64_t)j * p.ld_k + c]);
+        if (c < d) a += qv[c] * ldx(p.k, k0 + (int64_t)j * p.ld_k + c, kf);
       s[j] = a;
       mx = fmaxf(mx, a);
     }
@@ -452,15 +457,14 @@ __global__ __launch_bounds__(64) void attn_fewk_fwd_kernel(const grove_small_att
     l += s[j];
   }
   const float inv = 1.f / l;
-  bf16_raw* o = (bf16_raw*)p.o + ((int64_t)inst * p.Lq + qi) * p.ld_o + h * d;
 #pragma unroll
   for (int c = 0; c < MAXD; ++c) {
     if (c < d) {
       float a = 0.f;
 #pragma unroll
       for (int j = 0; j < MAXK; ++j)
-        if (j < p.Lk) a += s[j] * bf2f(v[(int64_t)j * p.ld_v + c]);
-      o[c] = f2bf(a * inv);
+        if (j < p.Lk) a += s[j] * ldx(p.v, v0 + (int64_t)j * p.ld_v + c, kf);
+      stx(p.o, o0 + c, a * inv, of);
     }
   }
 }
@@ -987,6 +991,47 @@ __global__ __launch_bounds__(FK_T) void attn_fewk16_bwd_kernel(const grove_small
   }
 }
 
+
+// ---------------------------------------------------------------- exact-fp32 small GEMM (decoder token path, text_hidden_fcs)
+// C[M, N] (f32) = act(A[M, K] (f32) . W[N, K]^T (bf16 weights, exact in f32) + bias) + residual (f32), on v_mfma_f32_16x16x4_f32:
+// products and sums in fp32 — no bf16 rounding of the activations. One wave per 16 x 16 output tile, four column tiles per
+// block; a lane loads 16 bytes of its A row and 8 bytes of its W row per 16-deep K chunk and issues four MFMAs whose k-slot
+// is (lane >> 4) * 4 + j for both operands. For M of a few hundred rows (6 tokens per box instance): the exact unit is 1/16 of
+// the bf16 rate, which is irrelevant at ~1 GFLOP per decoder pass.
+typedef __attribute__((ext_vector_type(4))) float f32x4v;
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const grove_gemm_f32_params p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  const int m0 = blockIdx.y * 16, n0 = (blockIdx.x * 4 + wave) * 16;
+  if (n0 >= p.N) return;
+  const int am = min(m0 + i, p.M - 1), wn = min(n0 + i, p.N - 1);
+  const float* a = p.A + (int64_t)am * p.lda + kq * 4;
+  const bf16_raw* w = (const bf16_raw*)p.W + (int64_t)wn * p.ldw + kq * 4;
+  f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int k0 = 0; k0 < p.K; k0 += 16) {
+    const f32x4_t av = *(const f32x4_t*)(a + k0);
+    const u32x2_t wv = *(const u32x2_t*)(w + k0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bf_lo(wv.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bf_hi(wv.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bf_lo(wv.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bf_hi(wv.y), acc, 0, 0, 0);
+  }
+  // lane holds C[m0 + 4 kq + r][n0 + i]
+  const int n = n0 + i;
+  if (n >= p.N) return;
+  const float b = p.bias ? bf2f(((const bf16_raw*)p.bias)[n]) : 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int m = m0 + 4 * kq + r;
+    if (m >= p.M) continue;
+    float v = act_apply(p.act, acc[r] + b);
+    if (p.residual) v += p.residual[(int64_t)m * p.ldr + n];
+    p.C[(int64_t)m * p.ldc + n] = v;
+    if (p.C_bf16) ((bf16_raw*)p.C_bf16)[(int64_t)m * p.ldc + n] = f2bf(v);
+  }
+}
+
 static int small_attn_check(const grove_small_attn_params* p, const char* name) {
   GROVE_CHECK(p && p->inst > 0 && p->heads > 0 && p->Lq > 0 && p->Lk > 0, GROVE_E_SHAPE, "%s: bad shape", name);
   GROVE_CHECK(p->d > 0 && p->d <= MAXD, GROVE_E_SHAPE, "%s: head dim %d > %d", name, p->d, MAXD);
@@ -994,10 +1039,26 @@ static int small_attn_check(const grove_small_attn_params* p, const char* name) 
   return GROVE_OK;
 }
 
+extern "C" int grove_gemm_f32(const grove_gemm_f32_params* p, void* stream) {
+  GROVE_CHECK(p && p->M > 0 && p->N > 0 && p->K > 0 && p->A && p->W && p->C, GROVE_E_SHAPE, "gemm_f32: bad shape");
+  GROVE_CHECK(p->K % 16 == 0 && p->lda % 4 == 0 && p->ldw % 4 == 0 && ((uintptr_t)p->A & 15) == 0 && ((uintptr_t)p->W & 7) == 0, GROVE_E_ALIGN,
+              "gemm_f32: K must be a multiple of 16, rows 16-byte (A) / 8-byte (W) aligned");
+  dim3 grid((p->N + 63) / 64, (p->M + 15) / 16);
+  hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, *p);
+  GROVE_LAUNCH_CHECK();
+  return GROVE_OK;
+}
+
 extern "C" int grove_small_attn_fwd(const grove_small_attn_params* p, void* stream) {
   int rc = small_attn_check(p, "small_attn_fwd");
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
+  if (p->q_f32 || p->kv_f32 || p->o_f32) {  // the decoder's fp32 token path: the generic kernels read / write either dtype
+    if (p->Lk <= MAXK) hipLaunchKernelGGL(attn_fewk_fwd_kernel, dim3(p->inst * p->heads * ((p->Lq + 63) / 64)), dim3(64), 0, s, *p);
+    else hipLaunchKernelGGL(attn_fewq_fwd_kernel, dim3(p->inst * p->heads), dim3(64), 0, s, *p);
+    GROVE_LAUNCH_CHECK();
+    return GROVE_OK;
+  }
   const bool vec16 = p->d == 16 && p->ld_q % 8 == 0 && p->ld_k % 8 == 0 && p->ld_v % 8 == 0 && p->ld_o % 8 == 0 &&
                      (((uintptr_t)p->q | (uintptr_t)p->k | (uintptr_t)p->v | (uintptr_t)p->o) & 15) == 0;
   if (p->Lk <= MAXK && vec16 && p->Lq >= 64) {
@@ -1019,6 +1080,7 @@ extern "C" int grove_small_attn_bwd(const grove_small_attn_params* p, void* stre
   int rc = small_attn_check(p, "small_attn_bwd");
   if (rc) return rc;
   GROVE_CHECK(p->d_o && p->dq && p->dk && p->dv && p->o, GROVE_E_SHAPE, "small_attn_bwd: d_o/dq/dk/dv/o required");
+  GROVE_CHECK(!(p->q_f32 || p->kv_f32 || p->o_f32), GROVE_E_DTYPE, "small_attn_bwd: bf16 operands only (the fp32 token path is inference-only)");
   hipStream_t s = (hipStream_t)stream;
   if (p->Lk <= MAXK) {
     // dk/dv accumulate with atomics -> zero them first

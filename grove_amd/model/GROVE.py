@@ -462,14 +462,25 @@ class GROVEForCausalLM(torch.nn.Module):
             dec_state = None
             N = 0
         else:
-            drows = torch.empty((n_det, H), dtype=bf, device=self.dev)
-            ops.copy_rows(hidden, drows, n_det, H, idx_src=det_rows)
-            dv = Var(drows)
-            h1 = tp.linear(dv, self.P("model.text_hidden_fcs.0.0.weight"), self.P("model.text_hidden_fcs.0.0.bias"), act=ops.ACT_RELU)
-            te = tp.linear(h1, self.P("model.text_hidden_fcs.0.2.weight"), self.P("model.text_hidden_fcs.0.2.bias"))
             inst_det_t, inst_frame_t, N = hp.inst_det_t, hp.inst_frame_t, hp.N
-            text = torch.empty((N, d.out_dim), dtype=bf, device=self.dev)
-            ops.copy_rows(te.data, text, N, d.out_dim, idx_src=inst_det_t)
+            if train or not self.decoder.precise:
+                drows = torch.empty((n_det, H), dtype=bf, device=self.dev)
+                ops.copy_rows(hidden, drows, n_det, H, idx_src=det_rows)
+                dv = Var(drows)
+                h1 = tp.linear(dv, self.P("model.text_hidden_fcs.0.0.weight"), self.P("model.text_hidden_fcs.0.0.bias"), act=ops.ACT_RELU)
+                te = tp.linear(h1, self.P("model.text_hidden_fcs.0.2.weight"), self.P("model.text_hidden_fcs.0.2.bias"))
+                text = torch.empty((N, d.out_dim), dtype=bf, device=self.dev)
+                ops.copy_rows(te.data, text, N, d.out_dim, idx_src=inst_det_t)
+            else:
+                # no backward to serve: the [DET] rows stay in fp32 from the LLaMA residual stream to the box head — final RMSNorm of
+                # the fp32 stream rows, text_hidden_fcs on the exact-fp32 MFMA GEMM, fp32 token side of the decoder (row gathers are
+                # index selection)
+                dv = te = None
+                srows = self.llama.last_stream.index_select(0, det_rows.long())
+                hn = ops.rmsnorm(None, self._sd["model.norm.weight"], d.rms_eps, res=srows, out_dtype=torch.float32)
+                h1 = ops.linear_f32(hn, self._sd["model.text_hidden_fcs.0.0.weight"], self._sd["model.text_hidden_fcs.0.0.bias"], act=ops.ACT_RELU)
+                te32 = ops.linear_f32(h1, self._sd["model.text_hidden_fcs.0.2.weight"], self._sd["model.text_hidden_fcs.0.2.bias"])
+                text = te32.index_select(0, inst_det_t.long())
             text_var = Var(text)
             box, obj, dec_state = self.decoder.forward(emb_rows2, text_var, inst_frame_t, train=train)
         # 6. split per clip / frame (GROVE.py:297-331)

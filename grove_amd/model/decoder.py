@@ -38,6 +38,7 @@ class BoxDecoder:
         self.d, self.dev = d, device
         self.grads = grads or {}
         self.sd = sd
+        self.precise = True  # inference: token side of the decoder in fp32 (forward_f32); False = the bf16 path everywhere
         g = d.sam_grid
         self.key_pe = dense_pe_rows(sd[PE_ + "pe_layer.positional_encoding_gaussian_matrix"], g, pe_dtype).to(bf).contiguous()
         self.pe_nchw = self.key_pe.float().reshape(g, g, -1).permute(2, 0, 1).unsqueeze(0).to(pe_dtype)
@@ -53,10 +54,84 @@ class BoxDecoder:
         o = tp.small_attn(qp, kp, vp, inst, d.dec_heads, internal // d.dec_heads, Lq, Lk)
         return tp.linear(o, self.P(prefix + "out_proj.weight"), self.P(prefix + "out_proj.bias"), residual=residual)
 
+    # ------------------------------------------------------------------ inference: the token side in fp32
+    def forward_f32(self, image_emb_rows, text, frame_of_instance):
+        """The two-way decoder with its TOKEN side in fp32 (inference): the 6 tokens per instance — their residual / post-norm
+        chain, every projection that reads them (exact-fp32 MFMA GEMM, grove_gemm_f32), the 6-token attentions' q or k / v, and the
+        outputs of the token -> image attentions — carry no bf16 rounding from the [DET] embedding to the box head. The image side
+        (N x 1024 keys: k / v projections, image -> token attention, norm4) stays on the bf16 MFMA kernels: a measured budget of
+        the box error against the fp32 oracle put 6.5e-4 of the 9.3e-4 mean L1 on the token side's bf16 activations and 7e-6 on the
+        whole SAM tower's (tools/box_error_budget.py). text: fp32 or bf16 [N, 256]. Returns (box f32 [N, 4], obj f32 [N])."""
+        d = self.d
+        D, g2, nh = d.dec_dim, d.sam_grid ** 2, d.dec_heads
+        N = text.shape[0]
+        sd = self.sd
+        f32 = torch.float32
+
+        def lin32(x, pre, act=ops.ACT_NONE, residual=None):
+            return ops.linear_f32(x, sd[pre + ".weight"], sd[pre + ".bias"], act=act, residual=residual)
+
+        def ln32(x, pre):
+            return ops.layernorm(None, sd[pre + ".weight"], sd[pre + ".bias"], 1e-5, res=x, out_dtype=f32)[0]
+
+        tokens = torch.empty((N, 6, D), dtype=f32, device=self.dev)  # [iou | 4 mask | text] (mask_decoder.py:166-173): exact widening copies
+        tokens[:, 0] = sd[M_ + "iou_token.weight"][0]
+        tokens[:, 1:5] = sd[M_ + "mask_tokens.weight"]
+        tokens[:, 5] = text
+        tokens = tokens.view(N * 6, D)
+        key_src = (frame_of_instance.to(torch.int64)[:, None] * g2 + torch.arange(g2, device=self.dev)[None]).reshape(-1).to(torch.int32)
+        keys = torch.empty((N * g2, D), dtype=bf, device=self.dev)
+        ops.copy_rows(image_emb_rows, keys, N * g2, D, idx_src=key_src)
+        ops.add_bcast_rows(keys, sd[PE_ + "no_mask_embed.weight"], 1, out=keys)
+        queries = tokens
+        t = M_ + "transformer."
+
+        def token_to_image(pre, queries, keys):
+            q_in = ops.add_f32(queries, tokens)
+            k_img = ops.add_bcast_rows(keys, self.key_pe, g2)
+            qp = lin32(q_in, pre + "q_proj")
+            kp = ops.linear(k_img, sd[pre + "k_proj.weight"], sd[pre + "k_proj.bias"])
+            vp = ops.linear(keys, sd[pre + "v_proj.weight"], sd[pre + "v_proj.bias"])
+            hd = (D // 2) // nh
+            o = ops.small_attn(qp, kp, vp, N, nh, hd, 6, g2, out_dtype=f32)
+            return lin32(o, pre + "out_proj", residual=queries), k_img
+
+        for i in range(d.dec_depth):
+            p = t + f"layers.{i}."
+            sa = p + "self_attn."
+            qk_in = queries if i == 0 else ops.add_f32(queries, tokens)  # skip_first_layer_pe (transformer.py:153-155)
+            qp, kp, vp = lin32(qk_in, sa + "q_proj"), lin32(qk_in, sa + "k_proj"), lin32(queries, sa + "v_proj")
+            o = ops.small_attn(qp, kp, vp, N, nh, D // nh, 6, 6, out_dtype=f32)
+            queries = lin32(o, sa + "out_proj", residual=None if i == 0 else queries)
+            queries = ln32(queries, p + "norm1")
+            queries, k_img = token_to_image(p + "cross_attn_token_to_image.", queries, keys)
+            queries = ln32(queries, p + "norm2")
+            h = lin32(queries, p + "mlp.lin1", act=ops.ACT_RELU)
+            queries = lin32(h, p + "mlp.lin2", residual=queries)
+            queries = ln32(queries, p + "norm3")
+            ia = p + "cross_attn_image_to_token."
+            q_in = ops.add_f32(queries, tokens)
+            qp = ops.linear(k_img, sd[ia + "q_proj.weight"], sd[ia + "q_proj.bias"])
+            kp, vp = lin32(q_in, ia + "k_proj"), lin32(queries, ia + "v_proj")
+            o = ops.small_attn(qp, kp, vp, N, nh, (D // 2) // nh, g2, 6)
+            keys = ops.linear(o, sd[ia + "out_proj.weight"], sd[ia + "out_proj.bias"], residual=keys)
+            keys = ops.layernorm(keys, sd[p + "norm4.weight"], sd[p + "norm4.bias"], 1e-5)[0]
+        queries, _ = token_to_image(t + "final_attn_token_to_image.", queries, keys)
+        q5 = queries.view(N, 6, D)[:, 5].contiguous()
+        hs = ln32(q5, t + "norm_final_attn")
+        hp = M_ + "bbox_prediction_head."
+        box, obj, _ = ops.box_head(hs, sd[hp + "0.weight"], sd[hp + "0.bias"], sd[hp + "2.weight"], sd[hp + "2.bias"],
+                                   sd[M_ + "temporal_objectness_head.weight"], sd[M_ + "temporal_objectness_head.bias"])
+        return box, obj
+
     def forward(self, image_emb_rows, text_embeds, frame_of_instance, train=False):
         """image_emb_rows: bf16 [F*g*g, 256] channels-last SAM embeddings; text_embeds: Var bf16 [N, 256]
-        ([DET] embeddings, one per (frame, DET) instance); frame_of_instance: int32 [N] frame index.
-        Returns (box f32 [N,4], obj f32 [N], state for backward)."""
+        ([DET] embeddings, one per (frame, DET) instance; fp32 allowed when not training); frame_of_instance: int32 [N] frame index.
+        Returns (box f32 [N,4], obj f32 [N], state for backward). Without a backward to serve (train=False) the token side runs
+        in fp32 (forward_f32); the training forward keeps the bf16 tape path whose backward kernels exist."""
+        if not train and self.precise:
+            box, obj = self.forward_f32(image_emb_rows, text_embeds.data, frame_of_instance)
+            return box, obj, None
         d = self.d
         D, g2 = d.dec_dim, d.sam_grid ** 2
         N = text_embeds.data.shape[0]

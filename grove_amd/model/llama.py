@@ -70,6 +70,7 @@ class LlamaStack:
                 saved.append((xb, qkv, actx, x1b, gu))
         xl = torch.empty_like(x) if save else None
         out = ops.rmsnorm(t, self.norm, d.rms_eps, res=res, res_bf16=xl)
+        self.last_stream = res  # fp32 pre-norm stream of this forward: the box path re-normalises its [DET] rows in fp32
         ctx = (saved, xl, pos, B, S) if save else None
         return out, ctx
 

@@ -187,8 +187,8 @@ def layernorm(x, weight, bias, eps, *, out=None, out_idx=None, save_stats=False,
                      save_stats, out_dtype, out_rows, res=res, res_bf16=res_bf16)
 
 
-def rmsnorm(x, weight, eps, *, out=None, res=None, res_bf16=None):
-    return _norm_fwd(_lib.lib().grove_rmsnorm_fwd, "grove_rmsnorm_fwd", x, weight, None, eps, out, None, False, bf16,
+def rmsnorm(x, weight, eps, *, out=None, res=None, res_bf16=None, out_dtype=bf16):
+    return _norm_fwd(_lib.lib().grove_rmsnorm_fwd, "grove_rmsnorm_fwd", x, weight, None, eps, out, None, False, out_dtype,
                      None, res=res, res_bf16=res_bf16)[0]
 
 
@@ -493,13 +493,16 @@ def cross_entropy(logits, labels, V, *, loss_sum=None, dlogits=None, grad_scale=
     return loss_sum
 
 
-def small_attn(q, k, v, inst, heads, d, Lq, Lk, *, out=None):
+def small_attn(q, k, v, inst, heads, d, Lq, Lk, *, out=None, out_dtype=bf16):
+    """q / k,v / out may each be bf16 or fp32 (k and v together): the decoder's fp32 token path mixes them."""
     if out is None:
-        out = torch.empty((inst * Lq, heads * d), dtype=bf16, device=q.device)
+        out = torch.empty((inst * Lq, heads * d), dtype=out_dtype, device=q.device)
+    assert k.dtype == v.dtype
     p = _lib.SmallAttnParams()
     p.q, p.k, p.v, p.o = _p(q), _p(k), _p(v), _p(out)
     p.inst, p.heads, p.d, p.Lq, p.Lk = inst, heads, d, Lq, Lk
     p.ld_q, p.ld_k, p.ld_v, p.ld_o = q.stride(-2), k.stride(-2), v.stride(-2), out.stride(-2)
+    p.q_f32, p.kv_f32, p.o_f32 = int(q.dtype == torch.float32), int(k.dtype == torch.float32), int(out.dtype == torch.float32)
     _lib.check(_lib.lib().grove_small_attn_fwd(C.byref(p), _stream()), "grove_small_attn_fwd")
     return out
 
@@ -517,6 +520,31 @@ def small_attn_bwd(q, k, v, o, d_o, inst, heads, d, Lq, Lk):
     assert d_o.stride(-2) == o.stride(-2)
     _lib.check(_lib.lib().grove_small_attn_bwd(C.byref(p), _stream()), "grove_small_attn_bwd")
     return dq, dk, dv
+
+
+def linear_f32(x, w, bias=None, *, act=ACT_NONE, residual=None, out=None, out_bf16=None):
+    """y (fp32) = act(x (fp32) @ w.T (bf16) + bias) + residual (fp32) with exact fp32 products (grove_gemm_f32)."""
+    _chk_dev(x, w)
+    assert x.dtype == torch.float32 and w.dtype == bf16 and x.stride(1) == 1 and w.stride(1) == 1
+    M, K = x.shape
+    N = w.shape[0]
+    assert w.shape[1] == K
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    p = _lib.GemmF32Params()
+    p.A, p.W, p.bias, p.residual, p.C, p.C_bf16 = _p(x), _p(w), _p(bias), _p(residual), _p(out), _p(out_bf16)
+    p.M, p.N, p.K, p.lda, p.ldw, p.ldc = M, N, K, x.stride(0), w.stride(0), out.stride(0)
+    p.ldr = residual.stride(0) if residual is not None else 0
+    p.act = act
+    assert out_bf16 is None or out_bf16.stride(0) == out.stride(0)
+    _lib.check(_lib.lib().grove_gemm_f32(C.byref(p), _stream()), "grove_gemm_f32")
+    return out
+
+
+def add_f32(a, b):
+    """a + b for fp32 tensors of one shape (new tensor): cast-free copy + grove_axpy_f32."""
+    out = a.clone()
+    return axpy(out.view(-1), b.reshape(-1)).view(a.shape)
 
 
 def box_head(x, W1, b1, W2, b2, Wo, bo):

@@ -462,9 +462,25 @@ typedef struct grove_small_attn_params {
   void* dk;
   void* dv;
   int32_t inst, heads, d, Lq, Lk, ld_q, ld_k, ld_v, ld_o;
+  int32_t q_f32, kv_f32, o_f32; /* forward only: q / k,v / o are f32 arrays (the decoder's fp32 token path); leading dims in elements */
 } grove_small_attn_params;
 int grove_small_attn_fwd(const grove_small_attn_params* p, void* stream);
 int grove_small_attn_bwd(const grove_small_attn_params* p, void* stream);
+
+/* Exact-fp32 small GEMM on v_mfma_f32_16x16x4_f32: C f32 [M, N] = act(A f32 [M, K] . W bf16 [N, K]^T + bias bf16 [N]) + residual f32.
+ * K % 16 == 0. C_bf16 (optional, same leading dim as C) receives the bf16 rounding. The token side of the two-way decoder
+ * (transformer.py:151-242: 6 tokens per box instance) and text_hidden_fcs on the [DET] rows (GROVE.py:75-79, 248-268) run through
+ * it at inference, so the box path carries no bf16 activation rounding between the LLaMA hidden state and the box head. */
+typedef struct grove_gemm_f32_params {
+  const float* A;
+  const void* W;
+  const void* bias;      /* bf16 [N] or NULL */
+  const float* residual; /* f32 [M, ldr] or NULL */
+  float* C;
+  void* C_bf16;          /* bf16 [M, ldc] or NULL */
+  int32_t M, N, K, lda, ldw, ldc, ldr, act;
+} grove_gemm_f32_params;
+int grove_gemm_f32(const grove_gemm_f32_params* p, void* stream);
 
 /* Box + temporal-objectness heads in fp32 (mask_decoder.py:80-84,198-203): x f32 [N, D];
  * box = sigmoid(W2 relu(W1 x + b1) + b2) [N,4]; obj = Wo x + bo [N]. Weights bf16.
