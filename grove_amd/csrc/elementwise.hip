@@ -68,6 +68,36 @@ __global__ __launch_bounds__(EB) void act_bwd_kernel(const bf16_raw* __restrict_
   }
 }
 
+__global__ __launch_bounds__(EB) void act_fwd_kernel(const bf16_raw* __restrict__ x, bf16_raw* __restrict__ y, int64_t nvec, int act) {
+  for (int64_t t = (int64_t)blockIdx.x * EB + threadIdx.x; t < nvec; t += (int64_t)gridDim.x * EB) {
+    float v[8];
+    unpack8(*(const u32x4_t*)(x + t * 8), v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = act_apply(act, v[e]);
+    *(u32x4_t*)(y + t * 8) = pack8(v);
+  }
+}
+
+// bilinear resize, align_corners = False (torch F.interpolate): fp32 planes [P, h, w] -> [P, H, W]; the source may be a crop
+// (rows < h_use, columns < w_use) of a plane stored with pitch w / plane stride h * w.
+__global__ __launch_bounds__(EB) void resize_bilinear_kernel(const float* __restrict__ src, float* __restrict__ dst, int P, int h, int w, int h_use,
+                                                             int w_use, int H, int W) {
+  const float sy = (float)h_use / (float)H, sx = (float)w_use / (float)W;
+  const int64_t n = (int64_t)P * H * W;
+  for (int64_t t = (int64_t)blockIdx.x * EB + threadIdx.x; t < n; t += (int64_t)gridDim.x * EB) {
+    const int X = (int)(t % W), Y = (int)((t / W) % H), pl = (int)(t / ((int64_t)W * H));
+    float fy = ((float)Y + 0.5f) * sy - 0.5f, fx = ((float)X + 0.5f) * sx - 0.5f;
+    fy = fy < 0.f ? 0.f : fy;
+    fx = fx < 0.f ? 0.f : fx;
+    const int y0 = min((int)fy, h_use - 1), x0 = min((int)fx, w_use - 1);
+    const int y1 = min(y0 + 1, h_use - 1), x1 = min(x0 + 1, w_use - 1);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const float* s = src + (int64_t)pl * h * w;
+    const float v00 = s[(int64_t)y0 * w + x0], v01 = s[(int64_t)y0 * w + x1], v10 = s[(int64_t)y1 * w + x0], v11 = s[(int64_t)y1 * w + x1];
+    dst[t] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+  }
+}
+
 __global__ __launch_bounds__(EB) void add_kernel(const bf16_raw* __restrict__ a, const bf16_raw* __restrict__ b, bf16_raw* __restrict__ y, int64_t nvec) {
   for (int64_t t = (int64_t)blockIdx.x * EB + threadIdx.x; t < nvec; t += (int64_t)gridDim.x * EB) {
     float x[8], z[8];
@@ -262,6 +292,22 @@ extern "C" int grove_act_bwd(const void* pre, const void* dy, void* dx, int64_t 
   GROVE_CHECK(n > 0, GROVE_E_SHAPE, "act_bwd: bad size");
   CHECK_VEC8(n, "act_bwd");
   hipLaunchKernelGGL(act_bwd_kernel, grid_for(n / 8), dim3(EB), 0, (hipStream_t)stream, (const bf16_raw*)pre, (const bf16_raw*)dy, (bf16_raw*)dx, n / 8, act);
+  GROVE_LAUNCH_CHECK();
+  return GROVE_OK;
+}
+extern "C" int grove_act_fwd(const void* x, void* y, int64_t n, int32_t act, void* stream) {
+  GROVE_CHECK(n > 0, GROVE_E_SHAPE, "act_fwd: bad size");
+  CHECK_VEC8(n, "act_fwd");
+  hipLaunchKernelGGL(act_fwd_kernel, grid_for(n / 8), dim3(EB), 0, (hipStream_t)stream, (const bf16_raw*)x, (bf16_raw*)y, n / 8, act);
+  GROVE_LAUNCH_CHECK();
+  return GROVE_OK;
+}
+extern "C" int grove_resize_bilinear_f32(const float* src, float* dst, int32_t planes, int32_t h, int32_t w, int32_t h_use, int32_t w_use, int32_t H,
+                                         int32_t W, void* stream) {
+  GROVE_CHECK(src && dst && planes > 0 && h > 0 && w > 0 && H > 0 && W > 0 && h_use > 0 && h_use <= h && w_use > 0 && w_use <= w, GROVE_E_SHAPE,
+              "resize_bilinear: bad shape");
+  hipLaunchKernelGGL(resize_bilinear_kernel, grid_for((int64_t)planes * H * W), dim3(EB), 0, (hipStream_t)stream, src, dst, planes, h, w, h_use, w_use, H,
+                     W);
   GROVE_LAUNCH_CHECK();
   return GROVE_OK;
 }

@@ -17,7 +17,7 @@ from types import SimpleNamespace
 import torch
 
 from .. import ops
-from ..synthetic import GroveDims, IGNORE_INDEX, IMAGE_TOKEN_INDEX, param_shapes
+from ..synthetic import GroveDims, IGNORE_INDEX, IMAGE_TOKEN_INDEX, is_mask_branch, param_shapes
 from .clip import ClipTower
 from .decoder import BoxDecoder, M_ as DEC_PREFIX
 from .llama import LlamaStack
@@ -34,6 +34,8 @@ def trainable_names(d: GroveDims):
     so they never get a gradient and are excluded."""
     names = []
     for n in param_shapes(d):
+        if is_mask_branch(n):  # flagged trainable by --train_mask_decoder, but no gradient reaches them on the box ("query") path
+            continue
         if n in ("model.embed_tokens.weight", "lm_head.weight") or n.startswith("model.mm_projector.") \
                 or n.startswith("model.text_hidden_fcs.") or n.startswith(DEC_PREFIX) \
                 or n.startswith(SAM_PREFIX + "adapters."):
@@ -219,6 +221,29 @@ class GROVEForCausalLM(torch.nn.Module):
         if tape is not None:
             return y, hs
         return y.data.view(G, 576, -1), SimpleNamespace(hidden_states=(hs,))
+
+    @torch.no_grad()
+    def predict_masks(self, image_embeddings, text_embeds, frame_of_instance, input_size=None, original_size=None, multimask_output=False):
+        """The SAM mask output north_star names (dormant in the reference: its MaskDecoder is built with decoding_type "query",
+        GROVE.py:39-51): `mask_decoder(image_embeddings, dense_pe, sparse=text_embeds, dense=no_mask, multimask_output, reps)` with
+        the mask branch (mask_decoder.py:206-227) + `postprocess_masks` (sam.py:137-172). image_embeddings: channels-last rows
+        [F, g*g, 256] (as model_forward(inference=True) returns) or NCHW [F, 256, g, g]; text_embeds [N, 256] = the [DET] embeddings
+        (text_hidden_fcs output); frame_of_instance int32 [N]. Returns dict(low_res_masks [N, C, 4g, 4g], iou_predictions [N, C],
+        boxes, objectness, and masks [N, C, H, W] logits when the sizes are given; binarise with > 0)."""
+        d = self.dims
+        g2 = d.sam_grid ** 2
+        emb = image_embeddings
+        if emb.dim() == 4:  # NCHW -> channels-last rows
+            F = emb.shape[0]
+            rows = torch.empty((F, g2, d.sam_out), dtype=bf, device=self.dev)
+            ops.transpose(emb.contiguous(), d.sam_out, g2, g2, rows, d.sam_out, batch=(F, 1), s_in=(d.sam_out * g2, 0), s_out=(g2 * d.sam_out, 0))
+            emb = rows
+        box, obj, low, iou = self.decoder.forward_f32(emb.reshape(-1, d.sam_out), text_embeds, frame_of_instance.to(self.dev).to(torch.int32),
+                                                      want_masks=True, multimask_output=multimask_output)
+        out = {"low_res_masks": low, "iou_predictions": iou, "boxes": box, "objectness": obj}
+        if input_size is not None and original_size is not None:
+            out["masks"] = self.decoder.postprocess_masks(low, input_size, original_size)
+        return out
 
     def get_grounding_encoder_embs(self, images):
         """GROVE.py:134-136 -> [B*T, 256, g, g] (NCHW like the reference; internally channels-last)."""

@@ -55,13 +55,14 @@ class BoxDecoder:
         return tp.linear(o, self.P(prefix + "out_proj.weight"), self.P(prefix + "out_proj.bias"), residual=residual)
 
     # ------------------------------------------------------------------ inference: the token side in fp32
-    def forward_f32(self, image_emb_rows, text, frame_of_instance):
+    def forward_f32(self, image_emb_rows, text, frame_of_instance, want_masks=False, multimask_output=False):
         """The two-way decoder with its TOKEN side in fp32 (inference): the 6 tokens per instance — their residual / post-norm
         chain, every projection that reads them (exact-fp32 MFMA GEMM, grove_gemm_f32), the 6-token attentions' q or k / v, and the
         outputs of the token -> image attentions — carry no bf16 rounding from the [DET] embedding to the box head. The image side
         (N x 1024 keys: k / v projections, image -> token attention, norm4) stays on the bf16 MFMA kernels: a measured budget of
         the box error against the fp32 oracle put 6.5e-4 of the 9.3e-4 mean L1 on the token side's bf16 activations and 7e-6 on the
-        whole SAM tower's (tools/box_error_budget.py). text: fp32 or bf16 [N, 256]. Returns (box f32 [N, 4], obj f32 [N])."""
+        whole SAM tower's (tools/box_error_budget.py). text: fp32 or bf16 [N, 256]. Returns (box f32 [N, 4], obj f32 [N]) and, with
+        want_masks, the mask branch's (low-res mask logits [N, 1 or 3, 4g, 4g], iou predictions [N, 1 or 3]) as well."""
         d = self.d
         D, g2, nh = d.dec_dim, d.sam_grid ** 2, d.dec_heads
         N = text.shape[0]
@@ -117,12 +118,68 @@ class BoxDecoder:
             keys = ops.linear(o, sd[ia + "out_proj.weight"], sd[ia + "out_proj.bias"], residual=keys)
             keys = ops.layernorm(keys, sd[p + "norm4.weight"], sd[p + "norm4.bias"], 1e-5)[0]
         queries, _ = token_to_image(t + "final_attn_token_to_image.", queries, keys)
-        q5 = queries.view(N, 6, D)[:, 5].contiguous()
-        hs = ln32(q5, t + "norm_final_attn")
+        if want_masks:
+            hs_all = ln32(queries, t + "norm_final_attn").view(N, 6, D)  # hs of all six tokens (transformer.py:99-106)
+            hs = hs_all[:, 5].contiguous()
+        else:
+            hs_all = None
+            hs = ln32(queries.view(N, 6, D)[:, 5].contiguous(), t + "norm_final_attn")
         hp = M_ + "bbox_prediction_head."
         box, obj, _ = ops.box_head(hs, sd[hp + "0.weight"], sd[hp + "0.bias"], sd[hp + "2.weight"], sd[hp + "2.bias"],
                                    sd[M_ + "temporal_objectness_head.weight"], sd[M_ + "temporal_objectness_head.bias"])
-        return box, obj
+        if not want_masks:
+            return box, obj
+        low, iou = self._mask_branch(hs_all, keys, N)
+        sl = slice(1, None) if multimask_output else slice(0, 1)
+        return box, obj, low[:, sl], iou[:, sl]
+
+    def _mask_branch(self, hs_all, keys, N):
+        """MaskDecoder.predict_masks, mask branch (mask_decoder.py:206-227; dormant under GROVE's decoding_type "query" — SURVEY.md
+        section 8(f) 3). hs_all fp32 [N, 6, D] = the decoder's output tokens, keys bf16 [N*g*g, D] = its output image tokens
+        (channels-last: `src.transpose(1, 2).view(b, c, h, w)` is a view of these rows).
+          output_upscaling: a ConvTranspose2d with kernel 2 / stride 2 writes every input pixel to its own 2 x 2 output block, so it IS
+          a linear layer per pixel with the 4 sub-pixels stacked on the output channels — two MFMA GEMMs (256 -> 4 x 64, then per
+          sub-pixel 64 -> 4 x 32, GELU in its epilogue) around a LayerNorm2d over 64 channels (a row LayerNorm in this layout) and
+          a GELU; the 16 sub-pixels are un-shuffled into image order once, at the very end, on the tiny mask tensor.
+          hyper-network MLPs + IoU head: fp32 (grove_gemm_f32) on the token side; masks = up . hyper_in^T as one batched GEMM.
+        Returns (mask logits fp32 [N, 4, 4g, 4g], iou fp32 [N, 4])."""
+        d, sd = self.d, self.sd
+        D, g, g2 = d.dec_dim, d.sam_grid, d.sam_grid ** 2
+        C1, C2 = D // 4, D // 8
+        if not hasattr(self, "_up"):
+            w1 = sd[M_ + "output_upscaling.0.weight"]  # [Ci, Co, 2, 2] -> [(dy dx co), ci]
+            w2 = sd[M_ + "output_upscaling.3.weight"]
+            self._up = dict(w1=w1.permute(2, 3, 1, 0).reshape(4 * C1, D).contiguous(), b1=sd[M_ + "output_upscaling.0.bias"].repeat(4).contiguous(),
+                            w2=w2.permute(2, 3, 1, 0).reshape(4 * C2, C1).contiguous(), b2=sd[M_ + "output_upscaling.3.bias"].repeat(4).contiguous())
+        U = self._up
+        x = ops.linear(keys, U["w1"], U["b1"])                                            # [N*g2, 4*C1]: pixel-major, sub-pixel, channel
+        x = x.view(N * g2 * 4, C1)
+        x, _, _ = ops.layernorm(x, sd[M_ + "output_upscaling.1.weight"], sd[M_ + "output_upscaling.1.bias"], 1e-6)
+        ops.act_fwd(x, ops.ACT_GELU, out=x)
+        up = ops.linear(x, U["w2"], U["b2"], act=ops.ACT_GELU)                            # [N*g2*4, 4*C2]
+        f32 = torch.float32
+
+        def mlp3(pre, v):
+            v = ops.linear_f32(v, sd[pre + "layers.0.weight"], sd[pre + "layers.0.bias"], act=ops.ACT_RELU)
+            v = ops.linear_f32(v, sd[pre + "layers.1.weight"], sd[pre + "layers.1.bias"], act=ops.ACT_RELU)
+            return ops.linear_f32(v, sd[pre + "layers.2.weight"], sd[pre + "layers.2.bias"])
+        hyper = torch.zeros((N, 64, C2), dtype=bf, device=self.dev)  # rows 0..3 = the four mask tokens' hyper vectors (B operand, zero padded)
+        for i in range(4):
+            hyper[:, i] = mlp3(M_ + f"output_hypernetworks_mlps.{i}.", hs_all[:, 1 + i].contiguous())
+        iou = mlp3(M_ + "iou_prediction_head.", hs_all[:, 0].contiguous())
+        P = g2 * 16                                                                       # output pixels per instance
+        m = torch.empty((N, P, 8), dtype=f32, device=self.dev)
+        ops.gemm_raw(up, hyper, m, P, 8, C2, C2, C2, 8, batch=(N, 1), sA=(P * C2, 0), sB=(64 * C2, 0), sC=(P * 8, 0))
+        # rows of `m` run (y, x, dy, dx, dy2, dx2): image row 4y + 2dy + dy2, column 4x + 2dx + dx2 (index plumbing on the result)
+        masks = m[:, :, :4].reshape(N, g, g, 2, 2, 2, 2, 4).permute(0, 7, 1, 3, 5, 2, 4, 6).reshape(N, 4, 4 * g, 4 * g).contiguous()
+        return masks, iou
+
+    def postprocess_masks(self, masks, input_size, original_size):
+        """Sam.postprocess_masks (sam.py:137-172): bilinear to the encoder's square input, crop the padding, bilinear to the original
+        frame — the crop folds into the second resize's source window. masks fp32 [N, C, h, w] -> [N, C, H, W] logits."""
+        S = self.d.sam_image
+        m = ops.resize_bilinear(masks.contiguous(), S, S)
+        return ops.resize_bilinear(m, int(original_size[0]), int(original_size[1]), crop=(int(input_size[0]), int(input_size[1])))
 
     def forward(self, image_emb_rows, text_embeds, frame_of_instance, train=False):
         """image_emb_rows: bf16 [F*g*g, 256] channels-last SAM embeddings; text_embeds: Var bf16 [N, 256]

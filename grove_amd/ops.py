@@ -406,6 +406,24 @@ def act_bwd(pre, dy, act, out=None):
     return out
 
 
+def act_fwd(x, act, out=None):
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.check(_lib.lib().grove_act_fwd(_p(x), _p(out), C.c_int64(x.numel()), act, _stream()), "grove_act_fwd")
+    return out
+
+
+def resize_bilinear(src, H, W, crop=None):
+    """fp32 [..., h, w] -> [..., H, W], bilinear with align_corners=False; crop=(h_use, w_use) samples only that corner of the source."""
+    assert src.dtype == torch.float32 and src.is_contiguous()
+    h, w = src.shape[-2], src.shape[-1]
+    hu, wu = crop if crop is not None else (h, w)
+    planes = src.numel() // (h * w)
+    out = torch.empty(src.shape[:-2] + (H, W), dtype=torch.float32, device=src.device)
+    _lib.check(_lib.lib().grove_resize_bilinear_f32(_p(src), _p(out), planes, h, w, hu, wu, H, W, _stream()), "grove_resize_bilinear_f32")
+    return out
+
+
 def add(a, b, out=None):
     if out is None:
         out = torch.empty_like(a)

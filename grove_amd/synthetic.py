@@ -231,7 +231,29 @@ def param_shapes(d: GroveDims, with_region_encoder: bool = False):
     P[m + "bbox_prediction_head.2.bias"] = (4,)
     P[m + "temporal_objectness_head.weight"] = (1, D)
     P[m + "temporal_objectness_head.bias"] = (1,)
+    # mask branch (mask_decoder.py:56-78, 206-227): dormant under GROVE's decoding_type "query", present in every checkpoint
+    P[m + "output_upscaling.0.weight"] = (D, D // 4, 2, 2)
+    P[m + "output_upscaling.0.bias"] = (D // 4,)
+    P[m + "output_upscaling.1.weight"] = (D // 4,)
+    P[m + "output_upscaling.1.bias"] = (D // 4,)
+    P[m + "output_upscaling.3.weight"] = (D // 4, D // 8, 2, 2)
+    P[m + "output_upscaling.3.bias"] = (D // 8,)
+    for i in range(4):
+        for j, (o, k) in enumerate(((D, D), (D, D), (D // 8, D))):
+            P[m + f"output_hypernetworks_mlps.{i}.layers.{j}.weight"] = (o, k)
+            P[m + f"output_hypernetworks_mlps.{i}.layers.{j}.bias"] = (o,)
+    for j, (o, k) in enumerate(((256, D), (256, 256), (4, 256))):
+        P[m + f"iou_prediction_head.layers.{j}.weight"] = (o, k)
+        P[m + f"iou_prediction_head.layers.{j}.bias"] = (o,)
     return P
+
+
+MASK_BRANCH = ("output_upscaling.", "output_hypernetworks_mlps.", "iou_prediction_head.")
+
+
+def is_mask_branch(name: str) -> bool:
+    """Parameters only the (dormant) mask branch of the SAM decoder reads: no gradient reaches them on GROVE's box path."""
+    return any(k in name for k in MASK_BRANCH)
 
 
 def init_spec(name: str, shape, d: GroveDims):
@@ -243,6 +265,8 @@ def init_spec(name: str, shape, d: GroveDims):
         return (0.0, 0.0) if "vision_tower" in name else (0.1, 0.0)
     if "norm" in name and leaf == "weight" and len(shape) == 1:
         return (1.0, 0.05)
+    if "output_upscaling.1." in name:  # LayerNorm2d
+        return ((1.0, 0.05) if leaf == "weight" else (0.0, 0.02))
     if "neck.1." in name or "neck.3." in name:
         return ((1.0, 0.05) if leaf == "weight" else (0.0, 0.02))
     if name.endswith("temporal_objectness_head.bias"):

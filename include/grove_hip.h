@@ -399,6 +399,12 @@ int grove_swiglu_fwd(const void* gu, void* y, int32_t rows, int32_t I, void* str
 int grove_swiglu_bwd(const void* gu, const void* dy, void* dgu, int32_t rows, int32_t I, void* stream);
 /* dx = dy * act'(pre) (in place allowed) */
 int grove_act_bwd(const void* pre, const void* dy, void* dx, int64_t n, int32_t act, void* stream);
+/* y = act(x) (bf16, in place allowed): the GELU between LayerNorm2d and the second ConvTranspose2d of output_upscaling (mask_decoder.py:58-67) */
+int grove_act_fwd(const void* x, void* y, int64_t n, int32_t act, void* stream);
+/* Bilinear resize with align_corners = False of fp32 planes [planes, h, w] -> [planes, H, W]; only rows < h_use and columns < w_use of
+ * every source plane are sampled (the padding crop of Sam.postprocess_masks, sam.py:137-172: interpolate, crop, interpolate). */
+int grove_resize_bilinear_f32(const float* src, float* dst, int32_t planes, int32_t h, int32_t w, int32_t h_use, int32_t w_use, int32_t H,
+                              int32_t W, void* stream);
 /* y = a + b (bf16), n elements; b may be NULL (copy) */
 int grove_add_bf16(const void* a, const void* b, void* y, int64_t n, void* stream);
 /* y[r, :] = a[r, :] + b[r % period, :]   (keys + key_pe, transformer.py:168-170) */

@@ -384,6 +384,49 @@ def mask_decoder_query(sd, d, image_embeddings, image_pe, text_embeds, reps):
     return box, obj
 
 
+def _mlp3(sd, prefix, x):
+    """mask_decoder.py MLP.forward :247-252 with three layers (ReLU between)."""
+    x = F.relu(_lin(sd, prefix + "layers.0", x))
+    x = F.relu(_lin(sd, prefix + "layers.1", x))
+    return _lin(sd, prefix + "layers.2", x)
+
+
+def mask_decoder_masks(sd, d, image_embeddings, image_pe, text_embeds, reps, multimask_output=False):
+    """MaskDecoder.forward :87-153 / predict_masks :155-227 with the MASK branch (decoding_type != "query"; dormant in GROVE,
+    SURVEY.md section 8(f) 3): the same token / image transformer, then output_upscaling (ConvTranspose2d 256->64 k2 s2,
+    LayerNorm2d eps 1e-6, GELU, ConvTranspose2d 64->32 k2 s2, GELU) on the image side, one 3-layer hyper-network MLP per mask
+    token, masks = hyper_in @ upscaled, and the IoU head on the iou token. Returns (low-res mask logits [N, 1 or 3, 4g, 4g],
+    iou predictions [N, 1 or 3])."""
+    N = text_embeds.shape[0]
+    out_tok = torch.cat([sd[M + "iou_token.weight"], sd[M + "mask_tokens.weight"]], 0)
+    tokens = torch.cat([out_tok.unsqueeze(0).expand(N, -1, -1), text_embeds], 1)
+    idx = torch.repeat_interleave(torch.arange(image_embeddings.shape[0]), torch.tensor(reps))
+    g = d.sam_grid
+    dense = sd[PE + "no_mask_embed.weight"].reshape(1, -1, 1, 1).expand(N, -1, g, g)
+    src = image_embeddings[idx] + dense
+    pos = image_pe.repeat_interleave(N, 0)
+    hs, keys = two_way_transformer(sd, d, src, pos, tokens)
+    iou_token_out, mask_tokens_out = hs[:, 0, :], hs[:, 1:5, :]
+    x = keys.transpose(1, 2).reshape(N, -1, g, g)
+    x = F.conv_transpose2d(x, sd[M + "output_upscaling.0.weight"], sd[M + "output_upscaling.0.bias"], stride=2)
+    x = F.gelu(_ln2d(x, sd[M + "output_upscaling.1.weight"], sd[M + "output_upscaling.1.bias"]))
+    up = F.gelu(F.conv_transpose2d(x, sd[M + "output_upscaling.3.weight"], sd[M + "output_upscaling.3.bias"], stride=2))
+    hyper_in = torch.stack([_mlp3(sd, M + f"output_hypernetworks_mlps.{i}.", mask_tokens_out[:, i, :]) for i in range(4)], 1)
+    b, c, h, w = up.shape
+    masks = (hyper_in @ up.reshape(b, c, h * w)).reshape(b, 4, h, w)
+    iou = _mlp3(sd, M + "iou_prediction_head.", iou_token_out)
+    sl = slice(1, None) if multimask_output else slice(0, 1)
+    return masks[:, sl], iou[:, sl]
+
+
+def postprocess_masks(masks, img_size, input_size, original_size):
+    """Sam.postprocess_masks sam.py:137-172: bilinear (align_corners=False) to the encoder's square input, crop the padding away,
+    bilinear to the original frame size. masks [N, C, h, w] -> [N, C, H_orig, W_orig] (logits; binarise with > 0)."""
+    m = F.interpolate(masks.float(), (img_size, img_size), mode="bilinear", align_corners=False)
+    m = m[..., : input_size[0], : input_size[1]]
+    return F.interpolate(m, original_size, mode="bilinear", align_corners=False)
+
+
 # --------------------------------------------------------------------------------------------
 # GROVE glue (model/GROVE.py)
 # --------------------------------------------------------------------------------------------

@@ -103,7 +103,63 @@ def case_clip_adapter_alpha(model, sd, d):
     return worst
 
 
+def case_mask_branch(model, sd, d):
+    """SAM mask branch (dormant under GROVE's decoding_type "query"): run the reference's own MaskDecoder with the mask branch
+    switched on and Sam.postprocess_masks, on the instances of the inference case (seed 2)."""
+    model.eval()
+    batch = synthetic_batch(d, B=2, T=8, L=40, n_det=3, seed=2)
+    ge = model.get_model().grounding_encoder
+    dec = ge.mask_decoder
+    with torch.no_grad():
+        emb = model(mode="get_grounding_encoder_embs", images=batch.grounding_enc_images)
+        pe = model(mode="get_dense_pe")
+        lo = super(type(model), model).forward(images=batch.global_enc_images, input_ids=batch.input_ids, output_hidden_states=True)
+        dmask = model._create_det_token_mask(batch.input_ids)
+        _, pemb = model._process_hidden_states([lo.hidden_states], dmask, None)
+        # exactly what _generate_and_postprocess_masks feeds the decoder (GROVE.py:270-296), with the mask branch selected
+        reps = [p.shape[0] for p in pemb]
+        text = torch.cat(pemb, 0).unsqueeze(1)
+        sparse, dense = ge.prompt_encoder(points=None, boxes=None, masks=None, text_embeds=text)
+        dec.decoding_type = "mask"
+        try:
+            low, iou = dec(image_embeddings=emb, image_pe=pe, sparse_prompt_embeddings=sparse.to(text.dtype),
+                           dense_prompt_embeddings=dense, multimask_output=False, reps=reps)
+            low3, iou3 = dec(image_embeddings=emb, image_pe=pe, sparse_prompt_embeddings=sparse.to(text.dtype),
+                             dense_prompt_embeddings=dense, multimask_output=True, reps=reps)
+        finally:
+            dec.decoding_type = "query"
+        band = int(d.sam_image * 360 / 640)  # SAM letter-box of a 640 x 360 frame (synthetic_batch): input_size (H, W)
+        full = ge.postprocess_masks(low, (band, d.sam_image), (360, 640))
+    gold = {"low_res_masks_first4": npf(low[:4]), "low_res_masks_sub": npf(low[:, :, ::PIX_STRIDE, ::PIX_STRIDE]), "iou_pred": npf(iou),
+            "low_res_masks_multi_sub": npf(low3[:, :, ::2 * PIX_STRIDE, ::2 * PIX_STRIDE]), "iou_pred_multi": npf(iou3),
+            "masks_sub": npf(full[:, :, ::2 * PIX_STRIDE, ::2 * PIX_STRIDE]),
+            "mask_area": npf((full > 0).float().sum((1, 2, 3))), "input_size": np.array([band, d.sam_image]),
+            "original_size": np.array([360, 640]), "pix_stride": np.array(PIX_STRIDE), "reps": np.array(reps)}
+    np.savez_compressed(os.path.join(OUT, "tiny_mask_branch_seed2.npz"), **gold)
+    with torch.no_grad():
+        o_emb = O.sam_image_encoder(sd, d, batch.grounding_enc_images)
+        of, _ = O.encode_images(sd, d, batch.global_enc_images)
+        hid = O.llama_forward(sd, d, O.splice(sd, batch.input_ids, None, None, of)[0], None)
+        embl = O.pred_embeddings(sd, d, hid, O.det_token_mask(d, batch.input_ids))
+        otext = torch.cat(embl, 0).unsqueeze(1)
+        olow, oiou = O.mask_decoder_masks(sd, d, o_emb, O.dense_pe(sd, d), otext, [e.shape[0] for e in embl])
+        olow3, oiou3 = O.mask_decoder_masks(sd, d, o_emb, O.dense_pe(sd, d), otext, [e.shape[0] for e in embl], multimask_output=True)
+        ofull = O.postprocess_masks(olow, d.sam_image, (band, d.sam_image), (360, 640))
+    print("case F (SAM mask branch):")
+    scale = low.abs().max().item()
+    worst = report("low-res mask logits", olow, low) / scale
+    worst = max(worst, report("multimask logits", olow3, low3) / scale)
+    worst = max(worst, report("iou predictions", oiou, iou), report("iou (multi)", oiou3, iou3))
+    worst = max(worst, report("post-processed masks", ofull, full) / scale)
+    return worst
+
+
 def main():
+    if "--only-mask-branch" in sys.argv:
+        model, sd = R.build_reference_model(TINY)
+        w = case_mask_branch(model, sd, TINY)
+        assert w < 2e-3, "oracle does not reproduce the reference"
+        return
     if "--only-clip-alpha" in sys.argv:
         model, sd = R.build_reference_model(TINY)
         w = case_clip_adapter_alpha(model, sd, TINY)
@@ -256,6 +312,9 @@ def main():
 
     # ------------------------------------------------------------------ case E: CLIP adapters switched on (alpha != 0)
     worst = max(worst, case_clip_adapter_alpha(model, sd, d))
+
+    # ------------------------------------------------------------------ case F: the SAM mask branch
+    worst = max(worst, case_mask_branch(model, sd, d))
     print(f"worst normalised oracle-vs-reference error: {worst:.3e}")
     assert worst < 2e-3, "oracle does not reproduce the reference"
     sizes = {f: os.path.getsize(os.path.join(OUT, f)) for f in sorted(os.listdir(OUT)) if f.endswith(".npz")}

@@ -113,7 +113,6 @@ def hot_path_names_check(d: GroveDims):
     param_shapes() — guards the state-dict compatibility surface."""
     model, sd = build_reference_model(d)
     ours = set(param_shapes(d))
-    dead = ("region_encoder.", "output_upscaling", "output_hypernetworks_mlps", "iou_prediction_head",
-            "point_embeddings", "not_a_point_embed", "mask_downscaling")
+    dead = ("region_encoder.", "point_embeddings", "not_a_point_embed", "mask_downscaling")
     theirs = [k for k in model.state_dict() if not any(s in k for s in dead)]
     return sorted(set(theirs) - ours), sorted(ours - set(theirs))

@@ -118,3 +118,29 @@ def test_clip_adapter_alpha_nonzero(sd):
     near(hs[-1][:, ::ts], g["clip_hidden_m2"], what="clip hidden[-2]")
     near(hs[1][:, ::ts], g["clip_hidden_1"], what="clip hidden[1]")
     near(hs[4][:, ::ts], g["clip_hidden_4"], what="clip hidden[4]")
+
+
+def test_mask_branch(sd):
+    """(f)3: the SAM mask branch (mask_decoder.py:206-227) and Sam.postprocess_masks (sam.py:137-172) against the reference's own
+    MaskDecoder run with the mask branch selected, on the [DET] instances of the inference case."""
+    g = np.load(os.path.join(G, "tiny_mask_branch_seed2.npz"))
+    ps = int(g["pix_stride"])
+    d = TINY
+    batch = synthetic_batch(d, B=2, T=8, L=40, n_det=3, seed=2)
+    with torch.no_grad():
+        emb = O.sam_image_encoder(sd, d, batch.grounding_enc_images)
+        feats, _ = O.encode_images(sd, d, batch.global_enc_images)
+        hid = O.llama_forward(sd, d, O.splice(sd, batch.input_ids, None, None, feats)[0], None)
+        embl = O.pred_embeddings(sd, d, hid, O.det_token_mask(d, batch.input_ids))
+        text, reps = torch.cat(embl, 0).unsqueeze(1), [e.shape[0] for e in embl]
+        assert reps == g["reps"].tolist()
+        low, iou = O.mask_decoder_masks(sd, d, emb, O.dense_pe(sd, d), text, reps)
+        low3, iou3 = O.mask_decoder_masks(sd, d, emb, O.dense_pe(sd, d), text, reps, multimask_output=True)
+        full = O.postprocess_masks(low, d.sam_image, tuple(g["input_size"].tolist()), tuple(g["original_size"].tolist()))
+    near(low[:4], g["low_res_masks_first4"], what="low-res masks")
+    near(low[:, :, ::ps, ::ps], g["low_res_masks_sub"], what="low-res masks (all instances)")
+    near(iou, g["iou_pred"], what="iou")
+    near(low3[:, :, ::2 * ps, ::2 * ps], g["low_res_masks_multi_sub"], what="multimask")
+    near(iou3, g["iou_pred_multi"], what="iou multimask")
+    near(full[:, :, ::2 * ps, ::2 * ps], g["masks_sub"], what="post-processed masks")
+    near((full > 0).float().sum((1, 2, 3)), g["mask_area"], 1e-3, "mask areas")

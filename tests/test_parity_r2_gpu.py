@@ -331,3 +331,63 @@ def test_from_pretrained_directory(dev, tmp_path):
     assert torch.equal(a["flat_boxes"], b["flat_boxes"])
     with pytest.raises(ValueError):
         GROVEForCausalLM.from_pretrained(str(tmp_path), torch_dtype=torch.float16, dims=base, device=dev, det_token_idx=1)
+
+
+# ---------------------------------------------------------------------------------------------- SAM mask branch ((f) 3)
+def test_mask_branch_matches_oracle_and_reference_golden(dev):
+    """predict_masks = the decoder's mask branch (output_upscaling as two GEMMs around a row LayerNorm, hyper-network MLPs and IoU head
+    in fp32, masks = up . hyper^T) + postprocess_masks (two bilinear resizes with the padding crop), against the oracle on the
+    HIP towers' own outputs and against the reference's MaskDecoder (golden, fp32 weights)."""
+    from grove_amd import GROVEForCausalLM
+    from grove_amd.synthetic import TINY, synthetic_batch, synthetic_state_dict
+    from oracle import grove_oracle as O
+    d = TINY
+    g = np.load(os.path.join(G, "tiny_mask_branch_seed2.npz"))
+    ps = int(g["pix_stride"])
+    sd = synthetic_state_dict(d)
+    sd_r = {k: v.to(bf).float() for k, v in sd.items()}
+    model = GROVEForCausalLM(dims=d, device=dev, state_dict=sd, det_token_idx=d.det_token_idx, num_frames=8, pe_dtype=torch.float32)
+    batch = synthetic_batch(d, B=2, T=8, L=40, n_det=3, seed=2)
+    kw = to_dev(batch, dev)
+    kw["inference"] = True
+    out = model(**kw)
+    # the [DET] embeddings and instance order of this batch, from the oracle on the same rounded weights (the branch under test
+    # starts at the decoder; its inputs are the HIP SAM embeddings and these embeddings)
+    gi, si = batch.global_enc_images.to(bf).float(), batch.grounding_enc_images.to(bf).float()
+    with torch.no_grad():
+        emb_o = O.sam_image_encoder(sd_r, d, si)
+        feats_o, _ = O.encode_images(sd_r, d, gi)
+        hid = O.llama_forward(sd_r, d, O.splice(sd_r, batch.input_ids, None, None, feats_o)[0], None)
+        embl = O.pred_embeddings(sd_r, d, hid, O.det_token_mask(d, batch.input_ids))
+        text_o, reps = torch.cat(embl, 0), [e.shape[0] for e in embl]
+        pe = O.dense_pe(sd_r, d)
+        low_o, iou_o = O.mask_decoder_masks(sd_r, d, emb_o, pe, text_o.unsqueeze(1), reps)
+        low3_o, iou3_o = O.mask_decoder_masks(sd_r, d, emb_o, pe, text_o.unsqueeze(1), reps, multimask_output=True)
+        insz, orsz = tuple(g["input_size"].tolist()), tuple(g["original_size"].tolist())
+        full_o = O.postprocess_masks(low_o, d.sam_image, insz, orsz)
+    inst_frame = torch.repeat_interleave(torch.arange(len(reps)), torch.tensor(reps)).to(torch.int32)
+    res = model.predict_masks(out["image_embeddings"], text_o.to(dev), inst_frame, input_size=insz, original_size=orsz)
+    scale = low_o.abs().max().item()
+    assert tuple(res["low_res_masks"].shape) == tuple(low_o.shape) and tuple(res["masks"].shape) == tuple(full_o.shape)
+    assert (res["low_res_masks"].cpu() - low_o).abs().max().item() < 2e-2 * scale, "low-res mask logits vs oracle"
+    assert (res["iou_predictions"].cpu() - iou_o).abs().max().item() < 2e-2
+    assert (res["masks"].cpu() - full_o).abs().max().item() < 2e-2 * scale, "post-processed masks vs oracle"
+    # binary masks: the pixels that disagree are the ones whose logit is within the tolerance of 0
+    dis = ((res["masks"].cpu() > 0) != (full_o > 0))
+    assert dis.float().mean().item() < 5e-3 and (full_o[dis].abs() < 2e-2 * scale).all()
+    res3 = model.predict_masks(out["image_embeddings"], text_o.to(dev), inst_frame, multimask_output=True)
+    assert tuple(res3["low_res_masks"].shape) == tuple(low3_o.shape)
+    assert (res3["low_res_masks"].cpu() - low3_o).abs().max().item() < 2e-2 * low3_o.abs().max().item()
+    assert (res3["iou_predictions"].cpu() - iou3_o).abs().max().item() < 2e-2
+    # boxes of the same call = the box path's
+    assert (res["boxes"].cpu() - out["flat_boxes"].cpu()).abs().max().item() < 2e-3
+    # the reference's own output (fp32 weights; bf16 weight rounding on top)
+    assert (res["low_res_masks"].cpu()[:, :, ::ps, ::ps] - torch.from_numpy(g["low_res_masks_sub"])).abs().max().item() < 6e-2 * scale
+    area = (res["masks"].cpu() > 0).float().sum((1, 2, 3))
+    ref_area = torch.from_numpy(g["mask_area"])
+    assert ((area - ref_area).abs() <= 0.05 * ref_area.clamp_min(200.0)).all(), (area, ref_area)
+    # the bilinear kernel alone against torch (exact arithmetic order differs: fp32 rounding only)
+    x = torch.randn(3, 2, 17, 23)
+    y = model.decoder.postprocess_masks(x.to(dev), (40, 50), (37, 91)).cpu()
+    y_ref = O.postprocess_masks(x, d.sam_image, (40, 50), (37, 91))
+    assert (y - y_ref).abs().max().item() < 1e-5
