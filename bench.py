@@ -38,7 +38,8 @@ def build(dims, dev, args):
     model = T.initialize_model(targs, dims, state_dict=sd, device=dev)
     del sd
     torch.cuda.empty_cache()
-    engine = T.GroveEngine(model, targs, total_steps=100000)
+    engine = T.GroveEngine(model, targs, total_steps=100000, exchange=getattr(args, "exchange", "allreduce"),
+                           overlap=not getattr(args, "no_comm_overlap", False))
     return model, engine
 
 
@@ -291,6 +292,10 @@ def main():
     ap.add_argument("--text_len", type=int, default=128)
     ap.add_argument("--dims", default="full", choices=["full", "tiny"])
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--exchange", default="allreduce", choices=["allreduce", "rs_ag"],
+                    help="N > 1: one all-reduce per gradient bucket, or reduce-scatter + all-gather per bucket")
+    ap.add_argument("--no_comm_overlap", action="store_true",
+                    help="N > 1: exchange all gradients after the backward instead of group by group from inside it (exposed-communication A/B)")
     ap.add_argument("--serial_towers", action="store_true",
                     help="run the SAM tower on the main stream as well (no kernel overlap): how profiles/*_kernel_stats are collected")
     args = ap.parse_args()
@@ -374,6 +379,8 @@ def main():
                                    f"SAM ViT-H@512 + box decoder, text L={args.text_len}, fwd+bwd+AdamW, shipped freeze policy",
                        "dims": args.dims, "global_batch_clips": world * args.batch, "frames_per_clip": args.frames,
                        "parallelism": f"dp{world}", "ranks": world,
+                       "gradient_exchange": (None if world == 1 else f"{args.exchange}, bf16 wire, " +
+                                             ("after the backward" if args.no_comm_overlap else "overlapped with the backward (per parameter group)")),
                        "collective_backend": (dist.get_backend() if world > 1 else None),
                        "frames_per_sec_per_gpu": round(frames / dt / world, 3), "last_loss": round(loss, 4),
                        "towers": "serial" if args.serial_towers else "SAM tower on a second stream beside CLIP->LLaMA (roofline: one extra step with the towers serialised)"},

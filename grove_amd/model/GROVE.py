@@ -584,6 +584,7 @@ class GROVEForCausalLM(torch.nn.Module):
             dte = torch.zeros((n_det, d.out_dim), dtype=torch.float32, device=self.dev)
             ops.scatter_add_f32(c.dec_state["text"].grad, dte, inst_det_t, c.N, d.out_dim)
             te.grad = ops.to_bf16(dte)
+        self._grads_final([DEC_PREFIX])  # box decoder + heads: first group to finish
         # SAM (adapters' weight gradients, dgrad through blocks 31..8) needs d_emb only: it runs on the SAM stream beside the
         # lm_head / LLaMA / projector backward (disjoint slices of the flat gradient buffer), queued AFTER that longer chain
         main = torch.cuda.current_stream(self.dev)
@@ -603,6 +604,7 @@ class GROVEForCausalLM(torch.nn.Module):
                 dl[:, :dlogits.shape[1]].copy_(dlogits)  # column re-pad of a tiny [R, V] matrix (plumbing)
             dh = ops.linear(dl, wT)
             ops.copy_rows(dh, d_hidden, R, H, idx_dst=rows, accumulate=True)
+        self._grads_final(["lm_head."])
         # text_hidden_fcs (tape) -> d hidden at the DET rows;  projector closures run later with feats.grad set
         c.tp_fns = c.tp.fns
         if c.det is not None:
@@ -613,6 +615,7 @@ class GROVEForCausalLM(torch.nn.Module):
             for fn in reversed(fns):
                 fn()
             ops.copy_rows(dv.grad, d_hidden, n_det, H, idx_dst=det_rows, accumulate=True)
+        self._grads_final(["model.text_hidden_fcs."])
         # LLaMA (dgrad only)
         dx = self.llama.backward(c.llama_ctx, d_hidden)
         # splice backward: visual rows -> projector; text rows -> embed_tokens
@@ -624,14 +627,18 @@ class GROVEForCausalLM(torch.nn.Module):
             c.feats.grad = dfe
         ops.scatter_add_f32(dx, self._grad["model.embed_tokens.weight"], plan.tok, plan.B * plan.S, H)
         c.tp.backward()  # mm_projector
+        self._grads_final(["model.embed_tokens.", "model.mm_projector."])
+
+        def adapter_done(j, stream):  # the SAM tower's own stream finishes adapter j's weight / bias / alpha gradients
+            self._grads_final([SAM_PREFIX + f"adapters.{j}."], stream)
         if self.tower_overlap and self._sam_stream is not None:
             self._sam_stream.wait_event(dec_done)
             with torch.cuda.stream(self._sam_stream):
                 d_emb.record_stream(self._sam_stream)
-                self.sam.backward(c.sam_ctx, ops.to_bf16(d_emb))
+                self.sam.backward(c.sam_ctx, ops.to_bf16(d_emb), on_adapter_done=lambda j: adapter_done(j, self._sam_stream))
             main.wait_stream(self._sam_stream)
         else:
-            self.sam.backward(c.sam_ctx, ops.to_bf16(d_emb))
+            self.sam.backward(c.sam_ctx, ops.to_bf16(d_emb), on_adapter_done=lambda j: adapter_done(j, None))
         self._ctx = None
 
     # ------------------------------------------------------------------ generation (GROVE.py:412-451, llava_llama.py:57-180)

@@ -255,7 +255,7 @@ class SamEncoder:
     def _wgrad(self, name, dy, x_rows_T, K_pad):
         raise NotImplementedError
 
-    def backward(self, saved, d_out):
+    def backward(self, saved, d_out, on_adapter_done=None):
         """d_out: bf16 [F*g*g, 256] gradient of the channels-last embeddings. Accumulates adapter
         gradients into self.grads (f32) and returns nothing (the image carries no gradient)."""
         d = self.d
@@ -273,6 +273,8 @@ class SamEncoder:
             if i in d.sam_global:
                 j = d.sam_global.index(i)
                 dx = self._adapter_bwd(self.adapters[j], saved["adapters"][j], dx, conv_idx, need_dx=(i >= self.first_bwd_block))
+                if on_adapter_done is not None:
+                    on_adapter_done(j)  # adapter j's gradients are final: the gradient exchange may start on them
             if i < self.first_bwd_block:
                 break
             Bk, c = self.blocks[i], saved["blocks"][i]

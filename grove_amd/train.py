@@ -138,6 +138,98 @@ def allreduce_buckets(flat, bucket_elems, comm_stream=None, comm_buf=None):
             flat.copy_(comm_buf)
 
 
+class GradExchange:
+    """Gradient exchange of the flat fp32 gradient buffer, overlapped with the backward.
+
+    The trainable parameters lie in the flat buffer in GROUPS whose gradients complete at different points of the backward
+    (reverse-autograd order: box decoder -> lm_head -> text_hidden_fcs -> SAM adapters 3..0 on the SAM stream -> embed_tokens +
+    mm_projector at the very end). `ready(lo, hi, stream)` is called by the model as soon as a group's slice [lo, hi) is final:
+    the slice is rounded into the bf16 wire buffer (DeepSpeed's communication dtype under bf16; fp32 optional) and exchanged on the
+    communication stream in buckets, while the rest of the backward keeps the CUs busy. `finish()` (engine.step) makes the compute
+    stream wait for the collectives and widens the wire buffer back into the fp32 buffer the optimizer reads.
+      mode "allreduce": one SUM all-reduce per bucket.
+      mode "rs_ag":     reduce-scatter + all-gather per bucket (the two halves of a ring all-reduce as separate RCCL calls: the form
+                        a sharded optimizer update slots between; here the full replica updates everything, so the result is the same).
+    On CPU tensors (gloo: the tests) the same code runs inline without streams."""
+
+    def __init__(self, flat, world, bucket_elems, comm_dtype=torch.bfloat16, mode="allreduce", comm_stream=None):
+        assert mode in ("allreduce", "rs_ag")
+        self.flat, self.world, self.mode = flat, world, mode
+        self.wire = torch.empty(flat.numel(), dtype=comm_dtype, device=flat.device) if comm_dtype != torch.float32 else None
+        # buckets are multiples of the world size so that reduce-scatter shards are equal
+        self.bucket = max(world, bucket_elems // world * world)
+        self.stream = comm_stream
+        self.pending = []     # [lo, hi) ranges already handed to the communication stream this step
+        self.handles = []
+
+    def _exchange(self, buf):
+        n = buf.numel()
+        for s0 in range(0, n, self.bucket):
+            b = buf[s0:s0 + self.bucket]
+            if self.mode == "rs_ag" and b.numel() % self.world == 0:
+                k = b.numel() // self.world
+                r = dist.get_rank()
+                shard = b[r * k:(r + 1) * k]  # in place: RCCL reduces into / gathers from the rank's own slice of the bucket
+                if b.is_cuda:  # stream-ordered on the communication stream
+                    self.handles.append(dist.reduce_scatter_tensor(shard, b, op=dist.ReduceOp.SUM, async_op=True))
+                    self.handles.append(dist.all_gather_into_tensor(b, shard, async_op=True))
+                else:          # gloo (tests): no in-place aliasing, no ordering between queued operations
+                    tmp = torch.empty_like(shard)
+                    dist.reduce_scatter_tensor(tmp, b.clone(), op=dist.ReduceOp.SUM)
+                    dist.all_gather_into_tensor(b, tmp)
+            else:  # ragged tail of a group (not a multiple of the world size): plain all-reduce
+                self.handles.append(dist.all_reduce(b, op=dist.ReduceOp.SUM, async_op=True))
+
+    def ready(self, lo, hi, producer_stream=None):
+        """Gradients of flat[lo:hi] are final once `producer_stream` reaches this point: start their exchange."""
+        if hi <= lo:
+            return
+        src = self.flat[lo:hi]
+        if not self.flat.is_cuda:
+            buf = src
+            if self.wire is not None:
+                self.wire[lo:hi].copy_(src)
+                buf = self.wire[lo:hi]
+            self._exchange(buf)
+            self.pending.append((lo, hi))
+            return
+        ev = torch.cuda.Event()
+        ev.record(producer_stream if producer_stream is not None else torch.cuda.current_stream(self.flat.device))
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ev)
+            buf = src
+            if self.wire is not None:
+                buf = self.wire[lo:hi]
+                ops.to_bf16(src, out=buf)
+            self._exchange(buf)
+        self.pending.append((lo, hi))
+
+    def finish(self):
+        """Everything not handed over by ready() is exchanged now; then wait and widen. Returns the exchanged ranges."""
+        covered = sorted(self.pending)
+        pos, gaps = 0, []
+        for lo, hi in covered:
+            if lo > pos:
+                gaps.append((pos, lo))
+            pos = max(pos, hi)
+        if pos < self.flat.numel():
+            gaps.append((pos, self.flat.numel()))
+        for lo, hi in gaps:
+            self.ready(lo, hi)
+        for h in self.handles:
+            h.wait()
+        self.handles = []
+        if self.flat.is_cuda:
+            torch.cuda.current_stream(self.flat.device).wait_stream(self.stream)
+        if self.wire is not None:
+            if self.flat.is_cuda:
+                ops.to_f32(self.wire, out=self.flat)
+            else:
+                self.flat.copy_(self.wire)
+        done, self.pending = self.pending, []
+        return done
+
+
 def shard_clips(n_clips, rank, world):
     """DistributedSampler partition of train.py:453 (no shuffle, padded by wrap-around): clip indices of `rank`."""
     per = (n_clips + world - 1) // world
@@ -148,7 +240,8 @@ def shard_clips(n_clips, rank, world):
 class GroveEngine:
     """Replica-per-GPU data-parallel engine with the DeepSpeed-engine surface train.py relies on."""
 
-    def __init__(self, model: GROVEForCausalLM, args, total_steps=None, bucket_bytes=512 << 20, comm_dtype=torch.bfloat16):
+    def __init__(self, model: GROVEForCausalLM, args, total_steps=None, bucket_bytes=128 << 20, comm_dtype=torch.bfloat16,
+                 exchange="allreduce", overlap=True):
         self.module = model
         self.args = args
         self.dev = model.dev
@@ -181,10 +274,14 @@ class GroveEngine:
         self.clip = 1.0  # "gradient_clipping": 1.0 (train.py:475)
         self._sumsq = torch.zeros(1, dtype=torch.float32, device=g.device)
         self._norm = torch.zeros(1, dtype=torch.float32, device=g.device)
-        # gradient exchange dtype: bf16 like DeepSpeed under bf16 (engine.communication_data_type), or torch.float32
-        self.comm_buf = torch.empty(g.numel(), dtype=torch.bfloat16, device=g.device) if self.world > 1 and comm_dtype == torch.bfloat16 else None
-        self.bucket_elems = bucket_bytes // (2 if self.comm_buf is not None else 4)
+        # gradient exchange: bf16 on the wire like DeepSpeed under bf16 (engine.communication_data_type) or torch.float32; bucketed,
+        # launched from inside the backward as each parameter group's gradients complete (GradExchange)
         self.comm_stream = torch.cuda.Stream(device=self.dev) if self.world > 1 else None
+        self.exchange = None
+        if self.world > 1:
+            self.exchange = GradExchange(g, self.world, bucket_bytes // (2 if comm_dtype == torch.bfloat16 else 4), comm_dtype, exchange,
+                                         self.comm_stream)
+        self.overlap = overlap
         self.training = True
         self.broadcast_parameters()
 
@@ -213,11 +310,17 @@ class GroveEngine:
         return self
 
     def backward(self, loss):
-        self.module.backward(loss)
+        last_micro = self.micro + 1 >= self.args.grad_accumulation_steps
+        # on the micro-step that completes the accumulation the model reports every finished gradient group to the exchange
+        self.module._grad_ready_cb = self.exchange.ready if (self.exchange is not None and self.overlap and last_micro) else None
+        try:
+            self.module.backward(loss)
+        finally:
+            self.module._grad_ready_cb = None
         self.micro += 1
 
     def _allreduce(self):
-        allreduce_buckets(self.module._flat_grad, self.bucket_elems, self.comm_stream, self.comm_buf)
+        self.exchanged_ranges = self.exchange.finish()
 
     def step(self):
         a = self.args

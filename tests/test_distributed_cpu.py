@@ -28,6 +28,22 @@ def _worker(rank, world, port, out):
     allreduce_buckets(h, 96, comm_buf=torch.empty(1000, dtype=torch.bfloat16))
     want = (base.to(torch.bfloat16) + (base * 2).to(torch.bfloat16)).float()  # what a bf16 sum of the two rounded ranks holds
     ok = ok and torch.equal(h, want) and (h - base * 3).abs().max().item() <= 3 * base.abs().max().item() * 2 ** -7
+    # the overlapped exchange: groups handed over out of order as the backward finishes them, the rest at finish(); both modes
+    from grove_amd.train import GradExchange
+    for mode in ("allreduce", "rs_ag"):
+        for wire in (torch.bfloat16, torch.float32):
+            base = torch.randn(1003, generator=torch.Generator().manual_seed(11))
+            flat = base * (rank + 1)
+            ex = GradExchange(flat, world, 96, comm_dtype=wire, mode=mode)
+            ex.ready(800, 1003)   # "decoder": ragged tail (1003 is odd: falls back to all-reduce for the last bucket)
+            ex.ready(200, 500)    # "lm_head"
+            done = ex.finish()    # everything else
+            assert sorted(done) == [(0, 200), (200, 500), (500, 800), (800, 1003)], done
+            if wire == torch.float32:
+                ok = ok and torch.allclose(flat, base * 3, rtol=1e-6, atol=0)
+            else:
+                want = (base.to(torch.bfloat16).float() + (base * 2).to(torch.bfloat16).float())
+                ok = ok and (flat - want).abs().max().item() <= want.abs().max().item() * 2 ** -7
     mine = shard_clips(7, rank, world)
     gathered = [None] * world
     dist.all_gather_object(gathered, mine)

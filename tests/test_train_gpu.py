@@ -237,3 +237,12 @@ def test_bench_self_launches_ranks(tmp_path):
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["config"]["ranks"] == 2 and res["config"]["collective_backend"] == "gloo"
     assert res["value"] > 0 and res["steps"] == 2 and res["scaling"] == "weak"
+    # the exchange variants reach the same loss: group-by-group from inside the backward (default), after the backward, and the
+    # reduce-scatter + all-gather form
+    losses = [res["config"]["last_loss"]]
+    for extra in (["--no_comm_overlap"], ["--exchange", "rs_ag"]):
+        q = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dims", "tiny", "--steps", "2", "--warmup", "1",
+                            "--frames", "8", "--text_len", "48", "--no_cpu_baseline"] + extra, env=env, capture_output=True, text=True, timeout=900)
+        assert q.returncode == 0, q.stderr[-2000:]
+        losses.append(json.loads([ln for ln in q.stdout.splitlines() if ln.strip()][0])["config"]["last_loss"])
+    assert max(losses) - min(losses) <= 2e-3 * max(1.0, abs(losses[0])), losses
