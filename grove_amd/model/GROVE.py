@@ -110,6 +110,19 @@ class GROVEForCausalLM(torch.nn.Module):
         self._alloc_params(state_dict)
         self._build_engines()
         self._ctx = None
+        self._grad_ready_cb = None  # set by GroveEngine: called with (lo, hi, stream) when flat-gradient slice [lo, hi) is final
+
+    def _grads_final(self, prefixes, stream=None):
+        """Tell the gradient exchange that every trainable tensor whose name starts with one of `prefixes` has its final gradient
+        (a prefix's tensors are contiguous in the flat buffer: trainable_names keeps groups together)."""
+        if self._grad_ready_cb is None:
+            return
+        for pre in prefixes:  # one contiguous range per prefix
+            names = [n for n in self.trainable if n.startswith(pre)]
+            if names:
+                lo = min(self._grad_off[n] for n in names)
+                hi = max(self._grad_off[n] + (self._sd[n].numel() + 3) // 4 * 4 for n in names)
+                self._grad_ready_cb(lo, hi, stream)
 
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path, *model_args, dims=None, device="cuda", train=False, torch_dtype=None,
