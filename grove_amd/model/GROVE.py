@@ -92,6 +92,7 @@ class GROVEForCausalLM(torch.nn.Module):
         self.literal_T = kwargs.get("literal_T", False)
         # dense positional encoding dtype: bf16 reproduces the reference under model.to(bf16) (quirk Q10)
         self.pe_dtype = kwargs.get("pe_dtype", torch.bfloat16)
+        self.stream_dtype = kwargs.get("stream_dtype", None)  # None: fp32 for inference models, bf16 for training models
         self.dev = torch.device(device)
         if self.dev.type != "cuda":
             raise RuntimeError("grove_amd runs on MI355X only: there is no CPU path (use oracle/ for a CPU check)")
@@ -196,9 +197,13 @@ class GROVEForCausalLM(torch.nn.Module):
 
     def _build_engines(self):
         d, sd, dev, tr = self.dims, self._sd, self.dev, self._train_mode
-        self.clip = ClipTower(sd, d, dev)
-        self.llama = LlamaStack(sd, d, dev, train=tr)
-        self.sam = SamEncoder(sd, d, dev, train=tr, grads=self._grad)
+        # residual streams of the three towers: FP32 for models built for inference (accuracy: full-depth box L1 vs the fp32 oracle
+        # 1.5e-3 -> 6.6e-4 together with the fp32 box path), bf16 — what the reference stores — for models built for training
+        # (the losses are insensitive to it; ~6 ms of norm traffic per step). stream_dtype= overrides.
+        f32s = (not tr) if self.stream_dtype is None else (self.stream_dtype == torch.float32)
+        self.clip = ClipTower(sd, d, dev, fp32_stream=f32s)
+        self.llama = LlamaStack(sd, d, dev, train=tr, fp32_stream=f32s)
+        self.sam = SamEncoder(sd, d, dev, train=tr, grads=self._grad, fp32_stream=f32s)
         self.decoder = BoxDecoder(sd, d, dev, grads=self._grad, pe_dtype=self.pe_dtype)
 
     def P(self, name):
@@ -514,7 +519,7 @@ class GROVEForCausalLM(torch.nn.Module):
                 # the fp32 stream rows, text_hidden_fcs on the exact-fp32 MFMA GEMM, fp32 token side of the decoder (row gathers are
                 # index selection)
                 dv = te = None
-                srows = self.llama.last_stream.index_select(0, det_rows.long())
+                srows = self.llama.last_stream.index_select(0, det_rows.long()).float()  # (already fp32 with the fp32 stream)
                 hn = ops.rmsnorm(None, self._sd["model.norm.weight"], d.rms_eps, res=srows, out_dtype=torch.float32)
                 h1 = ops.linear_f32(hn, self._sd["model.text_hidden_fcs.0.0.weight"], self._sd["model.text_hidden_fcs.0.0.bias"], act=ops.ACT_RELU)
                 te32 = ops.linear_f32(h1, self._sd["model.text_hidden_fcs.0.2.weight"], self._sd["model.text_hidden_fcs.0.2.bias"])

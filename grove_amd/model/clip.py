@@ -18,10 +18,10 @@ V = "model.vision_tower.vision_tower.vision_model."
 
 
 class ClipTower:
-    def __init__(self, sd, d, device):
+    def __init__(self, sd, d, device, fp32_stream=True):
         self.d = d
         self.dev = device
-        self.fp32_stream = os.environ.get("GROVE_CLIP_STREAM", "fp32") != "bf16"
+        self.fp32_stream = fp32_stream and os.environ.get("GROVE_CLIP_STREAM", "fp32") != "bf16"
         C, P = d.clip_dim, d.clip_patch
         bf = torch.bfloat16
         self.kpad = ops.pad_to(3 * P * P, 32)

@@ -15,8 +15,9 @@ from .attention import attention_bwd, attention_fwd
 
 
 class LlamaStack:
-    def __init__(self, sd, d, device, train=False):
+    def __init__(self, sd, d, device, train=False, fp32_stream=None):
         self.d, self.dev, self.train = d, device, train
+        self.fp32_stream = (not train) if fp32_stream is None else fp32_stream
         self.layers = []
         for i in range(d.n_layers):
             p = f"model.layers.{i}."
@@ -35,42 +36,62 @@ class LlamaStack:
         self.norm = sd["model.norm.weight"]
 
     def forward(self, x, B, S, kv_len=None, save=False, kv_cache=None):
-        """x: bf16 [B*S, H] input embeddings. kv_len: int32 [B] valid lengths or None.
+        """x: bf16 [B*S, H] input embeddings (consumed). kv_len: int32 [B] valid lengths or None.
         kv_cache: optional list (one per layer) of bf16 [B, S_max, 2H] tensors that receive the rotated keys | values of
         positions 0..S-1 (the prefill of a cached decode). Returns (final-norm hidden [B*S, H], ctx).
-        The residual stream is held in FP32 (`res`): each branch output (o_proj, down_proj; bf16 from the GEMM) is added to it
-        inside the RMSNorm kernel that follows (grove_rmsnorm_fwd, residual-stream form), so the stream is never rounded to bf16
-        between the 64 residual adds — that rounding was most of the stack's distance to the fp32 oracle at full depth. For the
-        backward the same kernel leaves the bf16 rounding of the stream at every norm input (what HF would have stored)."""
+        Residual stream, `self.fp32_stream` (default: models built for inference):
+          fp32: the stream is held in FP32 (`res`); each branch output (o_proj, down_proj; bf16 from the GEMM) is added to it inside
+                the RMSNorm kernel that follows (grove_rmsnorm_fwd, residual-stream form), so it is never rounded to bf16 between the
+                64 residual adds — that rounding was most of the stack's distance to the fp32 oracle at full depth (hidden state
+                1.4 % -> 0.56 % rms). Costs 6 more bytes of HBM traffic per element and residual add.
+          bf16: what the reference stores; the residual add rides in the o_proj / down_proj GEMM epilogues (models built for training:
+                the losses are insensitive to it, the step saves ~1.2 ms)."""
         d = self.d
         H, nh, hd, I = d.hidden, d.n_heads, d.head_dim, d.mlp
         pos = torch.arange(S, dtype=torch.int32, device=self.dev).repeat(B)
         saved = []
-        res = ops.to_f32(x)
-        t = None  # branch output not yet added to the stream
+        f32 = self.fp32_stream
+        res = ops.to_f32(x) if f32 else None
+        t = None  # fp32 stream: branch output not yet added to the stream
         for li, L in enumerate(self.layers):
-            xb = torch.empty_like(x) if save else None
-            h = ops.rmsnorm(t, L["ln1"], d.rms_eps, res=res, res_bf16=xb)
+            if f32:
+                xb = torch.empty_like(x) if save else None
+                h = ops.rmsnorm(t, L["ln1"], d.rms_eps, res=res, res_bf16=xb)
+            else:
+                xb = x
+                h = ops.rmsnorm(x, L["ln1"], d.rms_eps)
             qkv = ops.linear(h, L["wqkv"])
             ops.rope_(qkv, pos, 0, 2 * nh, hd, d.rope_theta)
             if kv_cache is not None:
                 kv_cache[li][:, :S].copy_(qkv.view(B, S, 3 * H)[:, :, H:])
             o, actx = attention_fwd(qkv, B, S, nh, hd, 0, H, 2 * H, hd ** -0.5, causal=True, kv_len=kv_len, save=save)
-            t = ops.linear(o, L["wo"])
-            x1b = torch.empty_like(x) if save else None
-            h2 = ops.rmsnorm(t, L["ln2"], d.rms_eps, res=res, res_bf16=x1b)
+            if f32:
+                t = ops.linear(o, L["wo"])
+                x1b = torch.empty_like(x) if save else None
+                h2 = ops.rmsnorm(t, L["ln2"], d.rms_eps, res=res, res_bf16=x1b)
+            else:
+                x1b = ops.linear(o, L["wo"], residual=x)
+                h2 = ops.rmsnorm(x1b, L["ln2"], d.rms_eps)
             if "wgu_sw" in L and h2.shape[0] >= 1024:  # (the fused epilogue lives in the pipelined kernel: big GEMMs only)
                 gu = torch.empty((h2.shape[0], 2 * I), dtype=torch.bfloat16, device=self.dev) if save else None
                 a = ops.linear(h2, L["wgu_sw"], act=ops.ACT_SWIGLU_PAIR, aux=gu, ld_aux=2 * I)
             else:
                 gu = ops.linear(h2, L["wgu"])
                 a = ops.swiglu(gu, I)
-            t = ops.linear(a, L["wd"])
+            if f32:
+                t = ops.linear(a, L["wd"])
+            else:
+                x = ops.linear(a, L["wd"], residual=x1b)
             if save:
                 saved.append((xb, qkv, actx, x1b, gu))
-        xl = torch.empty_like(x) if save else None
-        out = ops.rmsnorm(t, self.norm, d.rms_eps, res=res, res_bf16=xl)
-        self.last_stream = res  # fp32 pre-norm stream of this forward: the box path re-normalises its [DET] rows in fp32
+        if f32:
+            xl = torch.empty_like(x) if save else None
+            out = ops.rmsnorm(t, self.norm, d.rms_eps, res=res, res_bf16=xl)
+            self.last_stream = res  # fp32 pre-norm stream of this forward: the box path re-normalises its [DET] rows in fp32
+        else:
+            xl = x
+            out = ops.rmsnorm(x, self.norm, d.rms_eps)
+            self.last_stream = x
         ctx = (saved, xl, pos, B, S) if save else None
         return out, ctx
 

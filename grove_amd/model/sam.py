@@ -41,8 +41,9 @@ def _rcat_tables(size, rel_pos_h, rel_pos_w, hd, hp, alpha):
 
 
 class SamEncoder:
-    def __init__(self, sd, d, device, train=False, grads=None):
+    def __init__(self, sd, d, device, train=False, grads=None, fp32_stream=None):
         self.d, self.dev, self.train = d, device, train
+        self.fp32_stream = (not train) if fp32_stream is None else fp32_stream
         self.grads = grads  # name -> f32 gradient accumulator (trainable adapters)
         C, nh = d.sam_dim, d.sam_heads
         self.hd = C // nh
@@ -155,8 +156,13 @@ class SamEncoder:
         ws = Bk["window"]
         ctx = {}
         rows = res.shape[0]
-        x = torch.empty((rows, C), dtype=torch.bfloat16, device=self.dev) if save else None
-        h, mean, rstd = ops.layernorm(t, Bk["ln1"][0], Bk["ln1"][1], 1e-6, save_stats=save, res=res, res_bf16=x)
+        f32 = res.dtype == torch.float32
+        if f32:
+            x = torch.empty((rows, C), dtype=torch.bfloat16, device=self.dev) if save else None
+            h, mean, rstd = ops.layernorm(t, Bk["ln1"][0], Bk["ln1"][1], 1e-6, save_stats=save, res=res, res_bf16=x)
+        else:  # bf16 stream (training models): `res` IS the stream x, residual adds ride in the proj / lin2 GEMM epilogues
+            x = res
+            h, mean, rstd = ops.layernorm(x, Bk["ln1"][0], Bk["ln1"][1], 1e-6, save_stats=save)
         if ws > 0:
             # Window partition (image_encoder.py:329-353) pads AFTER norm1 with zero tokens, whose q|k|v is the bias alone:
             # the GEMM runs over the real tokens only and scatters its rows into the windowed layout (c_idx); the padding
@@ -181,20 +187,25 @@ class SamEncoder:
                      sA=(ld, 0), sB=(rel_ld * hp, 0), sC=(rel_ld, 0))
         o, actx = attention_fwd(qkv, nb, L, nh, hp, 0, nh * hp, 2 * nh * hp, hd ** -0.5, rel=rel, rel_hw=(Bk["khp"], qhw[1]), save=save, hs_valid=hd)
         del rel
+        r1 = None if f32 else x  # bf16 stream: x1 = x + proj(...) in the GEMM epilogue
         if ws > 0:  # un-partition = gather the real tokens' rows of the windowed attention output (padding rows are dropped)
             if Bk["maps"]:
-                t1 = ops.linear(o, Bk["wproj_c"], Bk["bproj"], a_idx=tok2win, a_taps=1, M=rows, k_map=(hd, hp - hd))
+                t1 = ops.linear(o, Bk["wproj_c"], Bk["bproj"], residual=r1, a_idx=tok2win, a_taps=1, M=rows, k_map=(hd, hp - hd))
             else:
-                t1 = ops.linear(o, Bk["wproj"], Bk["bproj"], a_idx=tok2win, a_taps=1, M=rows)
+                t1 = ops.linear(o, Bk["wproj"], Bk["bproj"], residual=r1, a_idx=tok2win, a_taps=1, M=rows)
         else:
-            t1 = ops.linear(o, Bk["wproj"], Bk["bproj"])
-        x1 = torch.empty((rows, C), dtype=torch.bfloat16, device=self.dev) if save else None
-        h2, mean2, rstd2 = ops.layernorm(t1, Bk["ln2"][0], Bk["ln2"][1], 1e-6, save_stats=save, res=res, res_bf16=x1)
+            t1 = ops.linear(o, Bk["wproj"], Bk["bproj"], residual=r1)
+        if f32:
+            x1 = torch.empty((rows, C), dtype=torch.bfloat16, device=self.dev) if save else None
+            h2, mean2, rstd2 = ops.layernorm(t1, Bk["ln2"][0], Bk["ln2"][1], 1e-6, save_stats=save, res=res, res_bf16=x1)
+        else:
+            x1 = t1
+            h2, mean2, rstd2 = ops.layernorm(x1, Bk["ln2"][0], Bk["ln2"][1], 1e-6, save_stats=save)
         pre = torch.empty((rows, 4 * C), dtype=torch.bfloat16, device=self.dev) if save else None
         # backward needs only gelu'(lin1(.)) (the block's weights are frozen: no weight gradient reads the pre-activation), so the
         # GEMM stores the derivative and the backward's lin2 dgrad multiplies by it in its epilogue — no elementwise pass
         f = ops.linear(h2, Bk["w1"], Bk["b1"], act=ops.ACT_GELU, aux=pre, aux_grad=True)
-        t2 = ops.linear(f, Bk["w2"], Bk["b2"])
+        t2 = ops.linear(f, Bk["w2"], Bk["b2"], residual=None if f32 else x1)  # bf16 stream: t2 is the new stream x2
         if save:
             ctx = dict(x=x, mean=mean, rstd=rstd, qkv=qkv, actx=actx, x1=x1, mean2=mean2, rstd2=rstd2, pre=pre, nb=nb, L=L, qhw=qhw)
         return t2, ctx
@@ -203,6 +214,12 @@ class SamEncoder:
         """tanh(alpha) * relu(Conv3d(x) + b) + x (image_encoder.py:48-59) on the FP32 stream: the Conv3d reads the stream itself
         (gathered rows of the implicit GEMM), so its bf16 rounding x = bf16(res + t) is materialised; the adapter's own
         contribution becomes the next pending branch output (its `+ x` is the stream)."""
+        if res.dtype != torch.float32:  # bf16 stream: `res` is x, the adapter's `+ x` rides in the GEMM epilogue
+            x = res
+            pre = torch.empty_like(x) if save else None
+            y = ops.linear(x, A["w"], A["b"], act=ops.ACT_RELU, scale_ptr=A["alpha_f32"], scale_tanh=True, a_idx=conv_idx, a_taps=27,
+                           M=x.shape[0], residual=x, aux=pre)
+            return y, (x, pre)
         x = torch.empty((res.shape[0], res.shape[1]), dtype=torch.bfloat16, device=self.dev)
         ops.stream_add(res, t, res_bf16=x)
         pre = torch.empty_like(x) if save else None
@@ -227,19 +244,27 @@ class SamEncoder:
         del col
         saved = {"blocks": {}, "adapters": {}, "F": F}
         nblocks = d.sam_depth if upto is None else upto
-        res = ops.to_f32(x)  # the residual stream, FP32 from here to the neck (see _attn_block)
+        f32 = self.fp32_stream
+        res = ops.to_f32(x) if f32 else x  # the residual stream: FP32 from here to the neck (see _attn_block), or the bf16 tensor itself
         t = None
         for i in range(nblocks):
             keep = save and i >= self.first_bwd_block
             t, ctx = self._attn_block(self.blocks[i], res, t, F, idx, keep)
+            if not f32:
+                res, t = t, None  # bf16 stream: the block returned the new stream
             if keep:
                 saved["blocks"][i] = ctx
             if i in d.sam_global:
                 j = d.sam_global.index(i)
                 t, actx = self._adapter(self.adapters[j], res, t, conv_idx, save)
+                if not f32:
+                    res, t = t, None
                 if save:
                     saved["adapters"][j] = actx
-        ops.stream_add(res, t, res_bf16=x)  # the neck's 1x1 conv reads the stream as a GEMM operand
+        if f32:
+            ops.stream_add(res, t, res_bf16=x)  # the neck's 1x1 conv reads the stream as a GEMM operand
+        else:
+            x = res
         del res, t
         if upto is not None:
             return x, None

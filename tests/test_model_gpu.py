@@ -373,7 +373,10 @@ def test_full_width_backward_matches_oracle_autograd(dev):
     # d alpha of an adapter is ONE dot product, sum(dy * relu(conv)), over ~10^7 terms of both signs: a random walk whose value
     # (adapter 0: 6.5e-4) is of the order of its step norm sqrt(sum (dy * relu)^2) (7.9e-4). The incoming dy carries the bf16
     # decoder backward's error (8 % in norm, not independent per element), so the sum is only determined to about one step norm —
-    # in the reference's own bf16 run just as well. The oracle's step norm is the bound each alpha gradient is held to.
+    # in the reference's own bf16 run just as well. Each alpha gradient is held to 2.5 step norms of the oracle (a 2.5-sigma bound
+    # on the walk): which realisation of the noise one gets depends on the kernels in the chain — with round 1's attention
+    # backward the two sums landed within 1 step norm, with the window kernels (same per-element accuracy of dq / dk / dv / d rel:
+    # 0.36-0.39 % rms against fp64 autograd for both, tools/debug_win_bwd.py) within 1.6.
     term_norm = []
     orig_adapter = O.conv_adapter
 
@@ -405,7 +408,7 @@ def test_full_width_backward_matches_oracle_autograd(dev):
         if n.endswith("alpha") and "image_encoder.adapters." in n:
             j = int(n.split("adapters.")[1].split(".")[0])
             noise = term_norm[j][0]
-            if abs(float(g) - float(r)) > 0.15 * abs(float(r)) + noise:
+            if abs(float(g) - float(r)) > 0.15 * abs(float(r)) + 2.5 * noise:
                 bad.append((n, float(g), float(r), noise))
             continue
         cos = torch.nn.functional.cosine_similarity(g.flatten(), r.flatten(), dim=0).item()
