@@ -1110,7 +1110,7 @@ extern "C" int grove_gemm_bf16(const grove_gemm_params* pp, void* stream) {
   const bool pp_act = pp_act_ok(p);  // compiled-in epilogues
   const bool maps = p.n_group || p.k_group;
   const bool p256_ok = g_gemm_glds && bk64 && (!p.a_idx || (long)p.a_taps * p.M >= 8) && bt == 1 && p.split_k <= 1 && !p.accumulate && wide_ok && p.N % 8 == 0 && pp_act;
-  // Tile choice by a measured cost model (tools/bench_gemm5.py, microseconds): time = rounds of resident blocks x
+  // Tile choice by a measured cost model (tools/bench_gemm_tiles.py, microseconds): time = rounds of resident blocks x
   // (K tiles x per-K-tile time + fixed per-tile time). The 128- and 192-row kernels keep 2 blocks per CU (512 slots; a
   // lone block of a partial round still takes a full round); the pipelined kernels are persistent, one block per CU,
   // and a partly filled chip runs each block faster (L2, clocks).
