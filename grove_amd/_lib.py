@@ -134,6 +134,11 @@ class GemmF32Params(C.Structure):
                 ("M", c_i32), ("N", c_i32), ("K", c_i32), ("lda", c_i32), ("ldw", c_i32), ("ldc", c_i32), ("ldr", c_i32), ("act", c_i32)]
 
 
+class GemmFp8Params(C.Structure):
+    _fields_ = [("A", c_vp), ("B", c_vp), ("C", c_vp), ("scale_a", c_vp), ("scale_b", c_vp), ("bias", c_vp), ("residual", c_vp),
+                ("M", c_i32), ("N", c_i32), ("K", c_i32), ("lda", c_i32), ("ldb", c_i32), ("ldc", c_i32), ("ldr", c_i32), ("act", c_i32)]
+
+
 STRUCTS = {
     "grove_gemm_params": GemmParams, "grove_transpose_params": TransposeParams, "grove_norm_params": NormParams,
     "grove_norm_bwd_params": NormBwdParams, "grove_softmax_params": SoftmaxParams,
@@ -141,7 +146,7 @@ STRUCTS = {
     "grove_rows_params": RowsParams, "grove_small_attn_params": SmallAttnParams, "grove_box_head_params": BoxHeadParams,
     "grove_box_head_bwd_params": BoxHeadBwdParams, "grove_flash_attn_params": FlashAttnParams,
     "grove_gemm_tn_params": GemmTnParams, "grove_gemv_params": GemvParams, "grove_decode_attn_params": DecodeAttnParams, "grove_resample_params": ResampleParams,
-    "grove_normalize_params": NormalizeParams, "grove_gemm_f32_params": GemmF32Params,
+    "grove_normalize_params": NormalizeParams, "grove_gemm_f32_params": GemmF32Params, "grove_gemm_fp8_params": GemmFp8Params,
 }
 
 # every symbol include/grove_hip.h declares (tests/test_abi.py checks the header against this list)
@@ -151,7 +156,7 @@ SYMBOLS = [
     "grove_flash_attn_fwd", "grove_flash_attn_bwd", "grove_flash_attn_set_window_kernels", "grove_softmax_fwd", "grove_softmax_bwd", "grove_relpos_fwd", "grove_relpos_bwd", "grove_rope_inplace",
     "grove_swiglu_fwd", "grove_swiglu_bwd", "grove_act_bwd", "grove_act_fwd", "grove_resize_bilinear_f32", "grove_add_bf16", "grove_add_bcast_rows",
     "grove_copy_rows", "grove_dot_bf16", "grove_axpy_f32", "grove_scatter_add_f32", "grove_colsum_f32", "grove_cast_f32_to_bf16", "grove_cast_bf16_to_f32",
-    "grove_im2col_patch", "grove_clip_pool", "grove_cross_entropy", "grove_small_attn_fwd", "grove_small_attn_bwd", "grove_gemm_f32",
+    "grove_im2col_patch", "grove_clip_pool", "grove_cross_entropy", "grove_small_attn_fwd", "grove_small_attn_bwd", "grove_gemm_f32", "grove_gemm_fp8", "grove_quant_fp8_rows",
     "grove_box_head_fwd", "grove_box_head_bwd", "grove_box_losses", "grove_adamw_step", "grove_adamw_step_multi", "grove_sumsq_f32",
 ]
 

@@ -44,6 +44,7 @@ extern "C" int grove_sizeof(const char* name) {
   SZ(grove_resample_params);
   SZ(grove_normalize_params);
   SZ(grove_gemm_f32_params);
+  SZ(grove_gemm_fp8_params);
 #undef SZ
   return -1;
 }

@@ -1,0 +1,166 @@
+// FP8 (OCP e4m3fn) GEMM on the block-scaled MFMA of gfx950, for the frozen linear layers of the CLIP tower and the LLaMA stack at
+// inference (BASELINE config 5: "fp8 MFMA ViT+LLaMA path"):
+//     C[M, N] (bf16) = act( (Aq[M, K] . Bq[N, K]^T) * sa[m] * sb[n] + bias[n] ) + residual[m, n]
+// Aq / Bq hold e4m3 codes; sa (per activation row) and sb (per weight row = output channel) are fp32 de-quantisation scales
+// (amax / 448), applied in the epilogue. The product runs on v_mfma_scale_f32_16x16x128_f8f6f4 — the K = 128 form that reaches the
+// fp8 rate (2x bf16 per clock; the un-scaled K = 32 fp8 MFMA only runs at the bf16 rate) — with unit E8M0 block scales: per-row /
+// per-channel scaling in fp32 is finer than a power-of-two per 32 elements and needs no scale operand traffic.
+// Structure: 128 x 128 output tile per workgroup of 4 waves (2 x 2, 64 x 64 each = 16 accumulator tiles), K tiles of 128 bytes,
+// A / B tiles double-buffered in LDS by LDS-DMA (global_load_lds_dwordx4) with the 16-byte chunk of a row XOR-swizzled by (row & 7)
+// on the SOURCE address, one counted vmcnt + two barriers per K tile, two workgroups per CU. Operand map (checked on hardware with
+// exact integer data, tests/test_kernels_gpu.py): lane l holds row l & 15, bytes k = 32 (l >> 4) .. + 31 of the 128-deep step.
+#include "common.h"
+
+namespace {
+
+constexpr int F8_BM = 128, F8_BN = 128, F8_BK = 128;  // BK in bytes = fp8 elements
+constexpr int F8_NT = 256;
+constexpr int F8_TILE = F8_BM * F8_BK;                // 16 KB per operand tile
+
+typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+
+__device__ __forceinline__ void f8_stage(char* lds_tile, const unsigned char* __restrict__ src, int ld, int row0, int rows_valid, int k0, int wave,
+                                         int lane) {
+  // tile = 1024 chunks of 16 bytes: chunk d -> (row = d >> 3, position = d & 7) holds source chunk position ^ (row & 7)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int d = (wave * 4 + i) * 64 + lane;
+    const int row = d >> 3, pos = d & 7;
+    const int gr = min(row0 + row, rows_valid - 1);
+    const unsigned char* g = src + (int64_t)gr * ld + k0 + ((pos ^ (row & 7)) << 4);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)(lds_tile + (wave * 4 + i) * 1024), 16, 0, 0);
+  }
+}
+
+__device__ __forceinline__ i32x8_t f8_frag(const char* tile, int row, int kg) {
+  const int sw = row & 7;
+  const u32x4_t lo = *(const u32x4_t*)(tile + row * F8_BK + (((2 * kg) ^ sw) << 4));
+  const u32x4_t hi = *(const u32x4_t*)(tile + row * F8_BK + (((2 * kg + 1) ^ sw) << 4));
+  return i32x8_t{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+}
+
+__global__ __launch_bounds__(F8_NT, 2) void gemm_fp8_kernel(const grove_gemm_fp8_params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, kg = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  // XCD-aware tile order: consecutive tiles of one XCD share the B column block
+  const int tiles_m = (p.M + F8_BM - 1) / F8_BM;
+  const int n_tiles = gridDim.x;
+  const int per = n_tiles >> 3, rem = n_tiles & 7;
+  const int x = blockIdx.x & 7, s = blockIdx.x >> 3;
+  const int tile = x * per + min(x, rem) + s;
+  const int tm = tile % tiles_m, tn = tile / tiles_m;
+  const int m0 = tm * F8_BM, n0 = tn * F8_BN;
+  const unsigned char* A = (const unsigned char*)p.A;
+  const unsigned char* B = (const unsigned char*)p.B;
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int nk = p.K / F8_BK;
+  f8_stage(smem, A, p.lda, m0, p.M, 0, wave, lane);
+  f8_stage(smem + F8_TILE, B, p.ldb, n0, p.N, 0, wave, lane);
+  const int one = 127;  // E8M0 2^0
+  for (int kt = 0; kt < nk; ++kt) {
+    char* cur = smem + (kt & 1) * 2 * F8_TILE;
+    if (kt + 1 < nk) {
+      char* nxt = smem + ((kt + 1) & 1) * 2 * F8_TILE;
+      f8_stage(nxt, A, p.lda, m0, p.M, (kt + 1) * F8_BK, wave, lane);
+      f8_stage(nxt + F8_TILE, B, p.ldb, n0, p.N, (kt + 1) * F8_BK, wave, lane);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // this tile's 8 loads have landed; the next tile's stay in flight
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    i32x8_t bf[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) bf[ni] = f8_frag(cur + F8_TILE, wn * 64 + ni * 16 + fr, kg);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const i32x8_t af = f8_frag(cur, wm * 64 + mi * 16 + fr, kg);
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+        acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af, bf[ni], acc[mi][ni], 0, 0, 0, one, 0, one);
+    }
+    __syncthreads();  // everyone is done with `cur` before the next iteration's DMA overwrites it
+  }
+  // epilogue: lane holds C[m = 4 kg + r][n = fr] of every 16 x 16 tile
+  const float* sa = p.scale_a;
+  const float* sb = p.scale_b;
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    const int n = n0 + wn * 64 + ni * 16 + fr;
+    if (n >= p.N) continue;
+    const float sbn = sb[n];
+    const float bn = p.bias ? bf2f(((const bf16_raw*)p.bias)[n]) : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm * 64 + mi * 16 + 4 * kg + r;
+        if (m >= p.M) continue;
+        float v = act_apply(p.act, acc[mi][ni][r] * (sa[m] * sbn) + bn);
+        if (p.residual) v += bf2f(((const bf16_raw*)p.residual)[(int64_t)m * p.ldr + n]);
+        ((bf16_raw*)p.C)[(int64_t)m * p.ldc + n] = f2bf(v);
+      }
+    }
+  }
+}
+
+// bf16 rows -> e4m3 codes + one fp32 scale per row (amax / 448; a zero row gets scale 1). One wave per row.
+__global__ __launch_bounds__(256) void quant_fp8_rows_kernel(const bf16_raw* __restrict__ x, unsigned char* __restrict__ q, float* __restrict__ scale,
+                                                             int rows, int K, int ld_x, int ld_q) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const bf16_raw* xr = x + (int64_t)row * ld_x;
+  float amax = 0.f;
+  for (int c = lane * 8; c < K; c += 512) {
+    const u32x4_t u = *(const u32x4_t*)(xr + c);
+    amax = fmaxf(amax, fmaxf(fmaxf(fabsf(bf_lo(u.x)), fabsf(bf_hi(u.x))), fmaxf(fabsf(bf_lo(u.y)), fabsf(bf_hi(u.y)))));
+    amax = fmaxf(amax, fmaxf(fmaxf(fabsf(bf_lo(u.z)), fabsf(bf_hi(u.z))), fmaxf(fabsf(bf_lo(u.w)), fabsf(bf_hi(u.w)))));
+  }
+  amax = wave_max(amax);
+  const float sc = amax > 0.f ? amax * (1.f / 448.f) : 1.f;
+  const float inv = 1.f / sc;
+  if (lane == 0) scale[row] = sc;
+  unsigned char* qr = q + (int64_t)row * ld_q;
+  for (int c = lane * 8; c < K; c += 512) {
+    const u32x4_t u = *(const u32x4_t*)(xr + c);
+    auto cl = [inv](float v) { return fminf(fmaxf(v * inv, -448.f), 448.f); };  // e4m3fn has no infinity: keep the row maximum at 448
+    int w0 = 0, w1 = 0;
+    w0 = __builtin_amdgcn_cvt_pk_fp8_f32(cl(bf_lo(u.x)), cl(bf_hi(u.x)), w0, false);
+    w0 = __builtin_amdgcn_cvt_pk_fp8_f32(cl(bf_lo(u.y)), cl(bf_hi(u.y)), w0, true);
+    w1 = __builtin_amdgcn_cvt_pk_fp8_f32(cl(bf_lo(u.z)), cl(bf_hi(u.z)), w1, false);
+    w1 = __builtin_amdgcn_cvt_pk_fp8_f32(cl(bf_lo(u.w)), cl(bf_hi(u.w)), w1, true);
+    *(u32x2_t*)(qr + c) = u32x2_t{(unsigned)w0, (unsigned)w1};
+  }
+}
+
+}  // namespace
+
+extern "C" int grove_gemm_fp8(const grove_gemm_fp8_params* p, void* stream) {
+  GROVE_CHECK(p && p->M > 0 && p->N > 0 && p->K > 0 && p->A && p->B && p->C && p->scale_a && p->scale_b, GROVE_E_SHAPE, "gemm_fp8: bad arguments");
+  GROVE_CHECK(p->K % F8_BK == 0, GROVE_E_SHAPE, "gemm_fp8: K=%d must be a multiple of %d", p->K, F8_BK);
+  GROVE_CHECK(p->lda % 16 == 0 && p->ldb % 16 == 0 && ((uintptr_t)p->A & 15) == 0 && ((uintptr_t)p->B & 15) == 0, GROVE_E_ALIGN,
+              "gemm_fp8: operand rows must be 16-byte aligned");
+  const int tiles = ((p->M + F8_BM - 1) / F8_BM) * ((p->N + F8_BN - 1) / F8_BN);
+  const size_t lds = 4 * F8_TILE;
+  hipFuncSetAttribute((const void*)gemm_fp8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(gemm_fp8_kernel, dim3(tiles), dim3(F8_NT), lds, (hipStream_t)stream, *p);
+  GROVE_LAUNCH_CHECK();
+  return GROVE_OK;
+}
+
+extern "C" int grove_quant_fp8_rows(const void* x, void* q, float* scale, int32_t rows, int32_t K, int32_t ld_x, int32_t ld_q, void* stream) {
+  GROVE_CHECK(x && q && scale && rows > 0 && K > 0, GROVE_E_SHAPE, "quant_fp8_rows: bad arguments");
+  GROVE_CHECK(K % 8 == 0 && ld_x % 8 == 0 && ld_q % 8 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)q & 7) == 0, GROVE_E_ALIGN,
+              "quant_fp8_rows: K and the leading dims must be multiples of 8");
+  hipLaunchKernelGGL(quant_fp8_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_raw*)x, (unsigned char*)q, scale, rows, K,
+                     ld_x, ld_q);
+  GROVE_LAUNCH_CHECK();
+  return GROVE_OK;
+}

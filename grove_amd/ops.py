@@ -559,6 +559,37 @@ def linear_f32(x, w, bias=None, *, act=ACT_NONE, residual=None, out=None, out_bf
     return out
 
 
+def quant_fp8_rows(x):
+    """bf16 [rows, K] -> (e4m3 codes uint8 [rows, K], fp32 scale [rows]): per-row amax / 448 scaling (grove_quant_fp8_rows)."""
+    _chk_dev(x)
+    rows, K = x.shape
+    assert x.dtype == bf16 and x.stride(1) == 1
+    q = torch.empty((rows, K), dtype=torch.uint8, device=x.device)
+    sc = torch.empty(rows, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().grove_quant_fp8_rows(_p(x), _p(q), _p(sc), rows, K, x.stride(0), q.stride(0), _stream()), "grove_quant_fp8_rows")
+    return q, sc
+
+
+def linear_fp8(x, wq, w_scale, bias=None, *, act=ACT_NONE, residual=None, out=None, xq=None):
+    """y (bf16) = act(x @ w.T + bias) + residual with both operands in fp8: wq / w_scale = quant_fp8_rows(w) (made once), the bf16
+    activation x is quantised per row on the fly (or pass xq = (codes, scales) to reuse a quantisation)."""
+    if xq is None:
+        xq = quant_fp8_rows(x)
+    aq, a_scale = xq
+    M, K = aq.shape
+    N = wq.shape[0]
+    assert wq.shape[1] == K and wq.dtype == torch.uint8
+    if out is None:
+        out = torch.empty((M, N), dtype=bf16, device=aq.device)
+    p = _lib.GemmFp8Params()
+    p.A, p.B, p.C, p.scale_a, p.scale_b, p.bias, p.residual = _p(aq), _p(wq), _p(out), _p(a_scale), _p(w_scale), _p(bias), _p(residual)
+    p.M, p.N, p.K, p.lda, p.ldb, p.ldc = M, N, K, aq.stride(0), wq.stride(0), out.stride(0)
+    p.ldr = residual.stride(0) if residual is not None else 0
+    p.act = act
+    _lib.check(_lib.lib().grove_gemm_fp8(C.byref(p), _stream()), "grove_gemm_fp8")
+    return out
+
+
 def add_f32(a, b):
     """a + b for fp32 tensors of one shape (new tensor): cast-free copy + grove_axpy_f32."""
     out = a.clone()

@@ -488,6 +488,23 @@ typedef struct grove_gemm_f32_params {
 } grove_gemm_f32_params;
 int grove_gemm_f32(const grove_gemm_f32_params* p, void* stream);
 
+/* FP8 (OCP e4m3fn) GEMM for the frozen linear layers at inference (BASELINE config 5):
+ * C bf16 [M, N] = act((A . B^T) * scale_a[m] * scale_b[n] + bias[n]) + residual[m, n]; A [M, lda], B [N, ldb]: e4m3 codes (bytes),
+ * K % 128 == 0, rows 16-byte aligned; scale_a f32 [M] / scale_b f32 [N]: de-quantisation scales (amax / 448 per row, as
+ * grove_quant_fp8_rows produces them). Runs on v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales. Replaces nn.Linear in
+ * CLIPAttention / CLIPMLP (modeling_clip.py:257-348) and HF LlamaAttention / LlamaMLP for an fp8-quantised checkpoint. */
+typedef struct grove_gemm_fp8_params {
+  const void* A; const void* B;
+  void* C;                 /* bf16 [M, ldc] */
+  const float* scale_a; const float* scale_b;
+  const void* bias;        /* bf16 [N] or NULL */
+  const void* residual;    /* bf16 [M, ldr] or NULL */
+  int32_t M, N, K, lda, ldb, ldc, ldr, act;
+} grove_gemm_fp8_params;
+int grove_gemm_fp8(const grove_gemm_fp8_params* p, void* stream);
+/* x bf16 [rows, ld_x] -> q e4m3 [rows, ld_q] with one scale per row: scale = amax / 448 (1 for a zero row), q = x / scale */
+int grove_quant_fp8_rows(const void* x, void* q, float* scale, int32_t rows, int32_t K, int32_t ld_x, int32_t ld_q, void* stream);
+
 /* Box + temporal-objectness heads in fp32 (mask_decoder.py:80-84,198-203): x f32 [N, D];
  * box = sigmoid(W2 relu(W1 x + b1) + b2) [N,4]; obj = Wo x + bo [N]. Weights bf16.
  * hidden (f32 [N, D]) is saved for backward. */

@@ -956,3 +956,56 @@ def test_adamw_multi_tensor_equals_per_tensor(dev):
     for i in range(len(sizes)):
         assert torch.equal(wa[i], wb[i]), i
     assert (wb[3] == 0).all()
+
+
+# ----------------------------------------------------------------------------- fp8 path (config 5)
+def _e4m3(x):
+    """torch's OCP e4m3fn rounding of an fp32 tensor, back in fp32 (the CPU model of grove_quant_fp8_rows's cast)."""
+    return x.clamp(-448, 448).to(torch.float8_e4m3fn).float()
+
+
+def test_fp8_gemm_operand_map_exact_integers(dev):
+    """Small integers are exact in e4m3, unit scales: the MFMA operand map of gemm_fp8.hip (row = lane & 15, k = 32 (lane >> 4) + j),
+    the XOR-swizzled LDS image and the tile order must reproduce the integer product EXACTLY; B is asymmetric."""
+    from grove_amd import ops
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 200, 264, 384
+    a = torch.randint(-2, 3, (M, K), generator=g).float() * (torch.rand(M, K, generator=g) < 0.2).float()
+    b = torch.randint(-3, 4, (N, K), generator=g).float() * (torch.rand(N, K, generator=g) < 0.3).float()
+    b[:, 0] += (torch.arange(N) % 5 == 0).float()
+    aq = a.to(torch.float8_e4m3fn).view(torch.uint8).to(dev)
+    bq = b.to(torch.float8_e4m3fn).view(torch.uint8).to(dev)
+    one_m, one_n = torch.ones(M, device=dev), torch.ones(N, device=dev)
+    y = ops.linear_fp8(None, bq, one_n, xq=(aq, one_m))
+    ref = a @ b.t()
+    assert ref.abs().max() < 256  # exact in bf16
+    assert torch.equal(y.float().cpu(), ref), (y.float().cpu() - ref).abs().max()
+
+
+@pytest.mark.parametrize("M,N,K,act", [(333, 520, 1024, 0), (2812, 4096, 4096, 0), (1000, 1024, 512, 1)])
+def test_fp8_linear_quantised(dev, M, N, K, act):
+    """quant_fp8_rows (per-row amax / 448, e4m3) + the fp8 GEMM with bias / activation / residual, against the same quantisation
+    modelled with torch's float8_e4m3fn casts (tight), and against the unquantised product (the fp8 error itself: a few percent)."""
+    from grove_amd import ops
+    x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05)
+    bias, res = rnd(N, seed=3), rnd(M, N, seed=4)
+    xq, xs = ops.quant_fp8_rows(x.to(dev))
+    wq, ws = ops.quant_fp8_rows(w.to(dev))
+    xs_ref = x.float().abs().amax(1) / 448
+    assert torch.allclose(xs.cpu(), xs_ref, rtol=1e-6)
+    x_model = _e4m3(x.float() / xs_ref[:, None])
+    same = (xq.cpu().view(torch.float8_e4m3fn).float() == x_model).float().mean().item()
+    assert same > 0.999, same  # (ties of the device's division vs torch's can differ in the last bit on a handful of elements)
+    ws_ref = w.float().abs().amax(1) / 448
+    w_model = _e4m3(w.float() / ws_ref[:, None])
+    a = {0: ops.ACT_NONE, 1: ops.ACT_GELU}[act]
+    y = ops.linear_fp8(x.to(dev), wq, ws, bias.to(dev), act=a, residual=res.to(dev))
+    pre = (x_model @ w_model.t()) * xs_ref[:, None] * ws_ref[None, :] + bias.float()
+    ref = (torch.nn.functional.gelu(pre) if act else pre) + res.float()
+    rms = ((y.float().cpu() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+    assert rms < 6e-3, f"fp8 gemm vs its own quantisation model: rms {rms}"  # bf16 output rounding + last-bit ties of the device division (measured 3.0-3.4e-3)
+    close(y, ref, 2e-2, "fp8 gemm vs its own quantisation model")
+    full = x.float() @ w.float().t() + bias.float()
+    full = (torch.nn.functional.gelu(full) if act else full) + res.float()
+    err = ((y.float().cpu() - full).pow(2).mean().sqrt() / full.pow(2).mean().sqrt()).item()
+    assert err < 6e-2, f"fp8 quantisation error {err}"
