@@ -282,6 +282,74 @@ def self_launch(n, argv):
     return subprocess.run(cmd, env=env).returncode
 
 
+def infer_bench(args, dev, dims):
+    """BASELINE config 5 as an explicit mode (`--mode infer`; never the default line): clip inference with the SAM mask decoder at
+    T = 32 — CLIP + LLaMA linear layers on the fp8 MFMA GEMM with `--dtype fp8` (bf16 otherwise), SAM tower, box decoder AND the mask
+    branch (low-res masks -> postprocess to the original frame size) for every ([DET], frame) instance. One step = one batch of
+    `--batch` clips x `--frames` frames (= frames / 8 independent windows each) through model_forward(inference=True) + predict_masks."""
+    from grove_amd import GROVEForCausalLM, ops
+    from grove_amd.synthetic import synthetic_batch, synthetic_state_dict
+    bf = torch.bfloat16
+    sd = synthetic_state_dict(dims, device=dev, dtype=bf)
+    model = GROVEForCausalLM(dims=dims, device=dev, state_dict=sd, det_token_idx=dims.det_token_idx, num_frames=8, gemm_dtype=args.dtype)
+    del sd
+    torch.cuda.empty_cache()
+    b = synthetic_batch(dims, B=args.batch, T=args.frames, L=args.text_len, n_det=3, seed=7, device=dev, dtype=bf)
+    kw = b.as_kwargs(inference=True)
+    band = int(dims.sam_image * 360 / 640)
+    rec = []
+    orig_fp8, orig_lin = ops.linear_fp8, ops.gemm_raw
+
+    def step(instrument=False):
+        out = model(**kw)
+        n_inst = out["flat_boxes"].shape[0]
+        frames = args.batch * args.frames
+        per = n_inst // frames
+        inst_frame = torch.arange(frames, dtype=torch.int32, device=dev).repeat_interleave(per)
+        text = model._last_text if hasattr(model, "_last_text") else None
+        res = model.predict_masks(out["image_embeddings"], text, inst_frame, input_size=(band, dims.sam_image), original_size=(360, 640))
+        return out, res
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out, res = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # dominant kernel of the mode: event-timed launches of the ViT / LLaMA linear layers in one extra pass
+    def timed_fp8(x, wq, ws, *a, **k):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = orig_fp8(x, wq, ws, *a, **k)
+        e1.record()
+        M = (k["xq"][0] if k.get("xq") is not None else x).shape[0]
+        rec.append((e0, e1, 2.0 * M * wq.shape[0] * wq.shape[1]))
+        return r
+    if args.dtype == "fp8":
+        ops.linear_fp8 = timed_fp8
+        try:
+            step()
+            torch.cuda.synchronize()
+        finally:
+            ops.linear_fp8 = orig_fp8
+    frames = args.batch * args.frames * args.steps
+    line = {"metric": "frames/sec (clip inference fwd + SAM masks)", "value": round(frames / dt, 3), "unit": "frames/s", "n_gpus": 1, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"GROVE inference + SAM mask decoder: {args.batch} clips x T={args.frames} frames ({args.batch * args.frames // 8} windows), "
+                                   f"LLaVA-1.5-7B + CLIP ViT-L/14-336 ({args.dtype} linear layers) + SAM ViT-H@512 (bf16) + box / mask decoder, text L={args.text_len}",
+                       "dims": args.dims, "instances": int(out["flat_boxes"].shape[0]), "mask_shape": list(res["masks"].shape)}}
+    if rec:
+        fl = sum(f for _, _, f in rec)
+        secs = sum(e0.elapsed_time(e1) for e0, e1, _ in rec) * 1e-3
+        line["roofline"] = {"bound": "mfma", "achieved": round(fl / secs / 1e12, 2), "peak": 5000.0, "unit": "TFLOP/s", "frac": round(fl / secs / 1e12 / 5000.0, 4),
+                            "traffic": None, "kernel": "gemm_fp8_kernel (grove_gemm_fp8; launch + its activation quantisation)", "launches_per_step": len(rec),
+                            "flops_per_step": fl}
+    return line
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -292,6 +360,9 @@ def main():
     ap.add_argument("--text_len", type=int, default=128)
     ap.add_argument("--dims", default="full", choices=["full", "tiny"])
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--mode", default="train", choices=["train", "infer"],
+                    help="train (default, the headline line: BASELINE config 3) or infer (config 5: inference + SAM masks, use --frames 32 --dtype fp8)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"], help="--mode infer: linear layers of the CLIP tower and the LLaMA stack")
     ap.add_argument("--exchange", default="allreduce", choices=["allreduce", "rs_ag"],
                     help="N > 1: one all-reduce per gradient bucket, or reduce-scatter + all-gather per bucket")
     ap.add_argument("--no_comm_overlap", action="store_true",
@@ -328,6 +399,10 @@ def main():
     from grove_amd.synthetic import FULL, TINY
     dims = FULL if args.dims == "full" else TINY
 
+    if args.mode == "infer":
+        assert world == 1, "--mode infer is a one-GPU line"
+        os.write(real_stdout, (json.dumps(infer_bench(args, dev, dims)) + "\n").encode())
+        return
     model, engine = build(dims, dev, args)
     model.tower_overlap = not args.serial_towers
     batch = make_batch(dims, dev, args, rank)

@@ -93,6 +93,8 @@ class GROVEForCausalLM(torch.nn.Module):
         # dense positional encoding dtype: bf16 reproduces the reference under model.to(bf16) (quirk Q10)
         self.pe_dtype = kwargs.get("pe_dtype", torch.bfloat16)
         self.stream_dtype = kwargs.get("stream_dtype", None)  # None: fp32 for inference models, bf16 for training models
+        # "bf16" (default) or "fp8": the linear layers of the CLIP tower and the LLaMA stack on the e4m3 MFMA GEMM (config 5; inference)
+        self.gemm_dtype = kwargs.get("gemm_dtype", "bf16")
         self.dev = torch.device(device)
         if self.dev.type != "cuda":
             raise RuntimeError("grove_amd runs on MI355X only: there is no CPU path (use oracle/ for a CPU check)")
@@ -201,8 +203,11 @@ class GROVEForCausalLM(torch.nn.Module):
         # 1.5e-3 -> 6.6e-4 together with the fp32 box path), bf16 — what the reference stores — for models built for training
         # (the losses are insensitive to it; ~6 ms of norm traffic per step). stream_dtype= overrides.
         f32s = (not tr) if self.stream_dtype is None else (self.stream_dtype == torch.float32)
-        self.clip = ClipTower(sd, d, dev, fp32_stream=f32s)
-        self.llama = LlamaStack(sd, d, dev, train=tr, fp32_stream=f32s)
+        fp8 = self.gemm_dtype == "fp8"
+        if fp8 and tr:
+            raise ValueError("gemm_dtype='fp8' is an inference configuration (BASELINE config 5): build the model with train=False")
+        self.clip = ClipTower(sd, d, dev, fp32_stream=f32s, fp8=fp8)
+        self.llama = LlamaStack(sd, d, dev, train=tr, fp32_stream=f32s, fp8=fp8)
         self.sam = SamEncoder(sd, d, dev, train=tr, grads=self._grad, fp32_stream=f32s)
         self.decoder = BoxDecoder(sd, d, dev, grads=self._grad, pe_dtype=self.pe_dtype)
 
@@ -524,6 +529,7 @@ class GROVEForCausalLM(torch.nn.Module):
                 h1 = ops.linear_f32(hn, self._sd["model.text_hidden_fcs.0.0.weight"], self._sd["model.text_hidden_fcs.0.0.bias"], act=ops.ACT_RELU)
                 te32 = ops.linear_f32(h1, self._sd["model.text_hidden_fcs.0.2.weight"], self._sd["model.text_hidden_fcs.0.2.bias"])
                 text = te32.index_select(0, inst_det_t.long())
+                self._last_text = text  # the ([DET], frame) embeddings of this forward: predict_masks(...) takes them as prompts
             text_var = Var(text)
             box, obj, dec_state = self.decoder.forward(emb_rows2, text_var, inst_frame_t, train=train)
         # 6. split per clip / frame (GROVE.py:297-331)

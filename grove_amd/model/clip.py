@@ -18,7 +18,7 @@ V = "model.vision_tower.vision_tower.vision_model."
 
 
 class ClipTower:
-    def __init__(self, sd, d, device, fp32_stream=True):
+    def __init__(self, sd, d, device, fp32_stream=True, fp8=False):
         self.d = d
         self.dev = device
         self.fp32_stream = fp32_stream and os.environ.get("GROVE_CLIP_STREAM", "fp32") != "bf16"
@@ -44,6 +44,10 @@ class ClipTower:
                 "w1": sd[p + "mlp.fc1.weight"], "b1": sd[p + "mlp.fc1.bias"],
                 "w2": sd[p + "mlp.fc2.weight"], "b2": sd[p + "mlp.fc2.bias"],
             }
+            if fp8:  # e4m3 copies of the four projections (per-output-channel scales); K must fit the fp8 GEMM's 128-byte K tile
+                for k in ("wqkv", "wo", "w1", "w2"):
+                    if L[k].shape[1] % 128 == 0:
+                        L[k + "_q"] = ops.quant_fp8_rows(L[k].contiguous())
             self.layers.append(L)
         self.adapters = []
         for j in range(d.clip_layers // 3):
@@ -68,6 +72,12 @@ class ClipTower:
             conv = conv3d_gather_index(F // 8, 8, 16, n // 16, frame_rows=n + 1, row_offset=1).to(self.dev)
             self._idx[F] = (patch_rows, pos_rows, cls_dst, cls_src, conv)
         return self._idx[F]
+
+    @staticmethod
+    def _lin(L, k, x, bias, act=ops.ACT_NONE, residual=None, out=None):
+        if (k + "_q") in L:
+            return ops.linear_fp8(x, L[k + "_q"][0], L[k + "_q"][1], bias, act=act, residual=residual, out=out)
+        return ops.linear(x, L[k], bias, act=act, residual=residual, out=out)
 
     def hidden_states(self, images, upto=None, taps=None):
         """images bf16 [B, 3, T, H, W] -> hidden state after `upto` layers ([F*577, C]).
@@ -98,13 +108,13 @@ class ClipTower:
         for i in range(nl):
             L = self.layers[i]
             ops.layernorm(t, L["ln1"][0], L["ln1"][1], d.clip_eps, out=h, res=res)
-            qkv = ops.linear(h, L["wqkv"], L["bqkv"])
+            qkv = self._lin(L, "wqkv", h, L["bqkv"])
             o, _ = attention_fwd(qkv, F, n + 1, H, hd, 0, C, 2 * C, hd ** -0.5)
             del qkv
-            t = ops.linear(o, L["wo"], L["bo"])
+            t = self._lin(L, "wo", o, L["bo"])
             ops.layernorm(t, L["ln2"][0], L["ln2"][1], d.clip_eps, out=h, res=res)
-            f = ops.linear(h, L["w1"], L["b1"], act=ops.ACT_QUICKGELU)
-            t = ops.linear(f, L["w2"], L["b2"])
+            f = self._lin(L, "w1", h, L["b1"], act=ops.ACT_QUICKGELU)
+            t = self._lin(L, "w2", f, L["b2"])
             del f, o
             if i % 3 == 0:
                 A = self.adapters[i // 3]
@@ -137,13 +147,13 @@ class ClipTower:
         for i in range(nl):
             L = self.layers[i]
             h, _, _ = ops.layernorm(x, L["ln1"][0], L["ln1"][1], d.clip_eps)
-            qkv = ops.linear(h, L["wqkv"], L["bqkv"])
+            qkv = self._lin(L, "wqkv", h, L["bqkv"])
             o, _ = attention_fwd(qkv, F, n + 1, H, hd, 0, C, 2 * C, hd ** -0.5)
             del qkv
-            ops.linear(o, L["wo"], L["bo"], residual=x, out=x)
+            self._lin(L, "wo", o, L["bo"], residual=x, out=x)
             ops.layernorm(x, L["ln2"][0], L["ln2"][1], d.clip_eps, out=h)
-            f = ops.linear(h, L["w1"], L["b1"], act=ops.ACT_QUICKGELU)
-            ops.linear(f, L["w2"], L["b2"], residual=x, out=x)
+            f = self._lin(L, "w1", h, L["b1"], act=ops.ACT_QUICKGELU)
+            self._lin(L, "w2", f, L["b2"], residual=x, out=x)
             del f, h, o
             if i % 3 == 0:
                 A = self.adapters[i // 3]

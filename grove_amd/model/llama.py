@@ -15,9 +15,13 @@ from .attention import attention_bwd, attention_fwd
 
 
 class LlamaStack:
-    def __init__(self, sd, d, device, train=False, fp32_stream=None):
+    def __init__(self, sd, d, device, train=False, fp32_stream=None, fp8=False):
         self.d, self.dev, self.train = d, device, train
         self.fp32_stream = (not train) if fp32_stream is None else fp32_stream
+        # fp8 (BASELINE config 5): the four projections of every layer run on the e4m3 block-scaled MFMA GEMM (grove_gemm_fp8) with
+        # per-output-channel weight scales made here and per-row activation scales made on the fly; inference only (no fp8 dgrad)
+        assert not (fp8 and train), "the fp8 path is inference-only"
+        self.fp8 = fp8
         self.layers = []
         for i in range(d.n_layers):
             p = f"model.layers.{i}."
@@ -32,8 +36,18 @@ class LlamaStack:
             if train:
                 for k in ("wqkv", "wo", "wgu", "wd"):
                     L[k + "_t"] = ops.transpose2d(L[k])
+            if fp8:
+                for k in ("wqkv", "wo", "wgu", "wd"):
+                    if L[k].shape[1] % 128 == 0:
+                        L[k + "_q"] = ops.quant_fp8_rows(L[k])
             self.layers.append(L)
         self.norm = sd["model.norm.weight"]
+
+    def _lin(self, L, k, x, residual=None):
+        """x @ L[k].T (+ residual): the fp8 GEMM when this stack is quantised (and K fits its 128-byte K tile), else the bf16 one."""
+        if (k + "_q") in L:
+            return ops.linear_fp8(x, L[k + "_q"][0], L[k + "_q"][1], residual=residual)
+        return ops.linear(x, L[k], residual=residual)
 
     def forward(self, x, B, S, kv_len=None, save=False, kv_cache=None):
         """x: bf16 [B*S, H] input embeddings (consumed). kv_len: int32 [B] valid lengths or None.
@@ -60,28 +74,31 @@ class LlamaStack:
             else:
                 xb = x
                 h = ops.rmsnorm(x, L["ln1"], d.rms_eps)
-            qkv = ops.linear(h, L["wqkv"])
+            qkv = self._lin(L, "wqkv", h)
             ops.rope_(qkv, pos, 0, 2 * nh, hd, d.rope_theta)
             if kv_cache is not None:
                 kv_cache[li][:, :S].copy_(qkv.view(B, S, 3 * H)[:, :, H:])
             o, actx = attention_fwd(qkv, B, S, nh, hd, 0, H, 2 * H, hd ** -0.5, causal=True, kv_len=kv_len, save=save)
             if f32:
-                t = ops.linear(o, L["wo"])
+                t = self._lin(L, "wo", o)
                 x1b = torch.empty_like(x) if save else None
                 h2 = ops.rmsnorm(t, L["ln2"], d.rms_eps, res=res, res_bf16=x1b)
             else:
-                x1b = ops.linear(o, L["wo"], residual=x)
+                x1b = self._lin(L, "wo", o, residual=x)
                 h2 = ops.rmsnorm(x1b, L["ln2"], d.rms_eps)
-            if "wgu_sw" in L and h2.shape[0] >= 1024:  # (the fused epilogue lives in the pipelined kernel: big GEMMs only)
+            if "wgu_q" in L:
+                gu = self._lin(L, "wgu", h2)
+                a = ops.swiglu(gu, I)
+            elif "wgu_sw" in L and h2.shape[0] >= 1024:  # (the fused epilogue lives in the pipelined kernel: big GEMMs only)
                 gu = torch.empty((h2.shape[0], 2 * I), dtype=torch.bfloat16, device=self.dev) if save else None
                 a = ops.linear(h2, L["wgu_sw"], act=ops.ACT_SWIGLU_PAIR, aux=gu, ld_aux=2 * I)
             else:
                 gu = ops.linear(h2, L["wgu"])
                 a = ops.swiglu(gu, I)
             if f32:
-                t = ops.linear(a, L["wd"])
+                t = self._lin(L, "wd", a)
             else:
-                x = ops.linear(a, L["wd"], residual=x1b)
+                x = self._lin(L, "wd", a, residual=x1b)
             if save:
                 saved.append((xb, qkv, actx, x1b, gu))
         if f32:

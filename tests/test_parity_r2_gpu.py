@@ -391,3 +391,44 @@ def test_mask_branch_matches_oracle_and_reference_golden(dev):
     y = model.decoder.postprocess_masks(x.to(dev), (40, 50), (37, 91)).cpu()
     y_ref = O.postprocess_masks(x, d.sam_image, (40, 50), (37, 91))
     assert (y - y_ref).abs().max().item() < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------- fp8 ViT + LLaMA path (config 5)
+def test_fp8_vit_llama_path_vs_oracle_and_bf16(dev):
+    """gemm_dtype="fp8": every linear layer of the CLIP tower and the LLaMA stack on the e4m3 MFMA GEMM (per-output-channel weight
+    scales, per-row activation scales), everything else unchanged. fp8 carries 3 mantissa bits, so the bounds are the quantisation's,
+    not bf16's: tower outputs within 8 % of the fp32 oracle (bf16: < 1 %), boxes within 1e-2 L1 (bf16: < 1e-3), same box counts
+    as the bf16 model except where an objectness logit sits within the fp8 error of the threshold."""
+    import dataclasses
+    from grove_amd import GROVEForCausalLM
+    from grove_amd.synthetic import TINY, synthetic_batch, synthetic_state_dict
+    from oracle import grove_oracle as O
+    d = dataclasses.replace(TINY, clip_dim=128, clip_heads=2, clip_mlp=256)  # every GEMM K a multiple of the fp8 kernel's 128
+    sd = synthetic_state_dict(d)
+    sd_r = {k: v.to(bf).float() for k, v in sd.items()}
+    m8 = GROVEForCausalLM(dims=d, device=dev, state_dict=sd, det_token_idx=d.det_token_idx, num_frames=8, pe_dtype=torch.float32, gemm_dtype="fp8")
+    m16 = GROVEForCausalLM(dims=d, device=dev, state_dict=sd, det_token_idx=d.det_token_idx, num_frames=8, pe_dtype=torch.float32)
+    assert all("wqkv_q" in L and "wd_q" in L for L in m8.llama.layers) and all("w1_q" in L for L in m8.clip.layers)
+    with pytest.raises(ValueError):
+        GROVEForCausalLM(dims=d, device=dev, state_dict=sd, det_token_idx=d.det_token_idx, train=True, gemm_dtype="fp8")
+    batch = synthetic_batch(d, B=2, T=8, L=40, n_det=3, seed=2)
+    kw = to_dev(batch, dev)
+    kw["inference"] = True
+    o8, o16 = m8(**kw), m16(**kw)
+    kwo = batch.as_kwargs(inference=True)
+    kwo["global_enc_images"], kwo["grounding_enc_images"] = kwo["global_enc_images"].to(bf).float(), kwo["grounding_enc_images"].to(bf).float()
+    with torch.no_grad():
+        ref = O.model_forward(sd_r, d, **kwo)
+        feats_o, _ = O.encode_images(sd_r, d, kwo["global_enc_images"])
+    feats8, _ = m8(mode="encode_images", images=kw["global_enc_images"])
+
+    def rms(a, b):
+        a, b = a.detach().float().cpu(), b.detach().float().cpu()
+        return ((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt()).item()
+    e_feat, e_hid = rms(feats8, feats_o), rms(o8["hidden"], ref["hidden"])
+    l1_8 = (o8["flat_boxes"].cpu() - ref["flat_boxes"]).abs().mean().item()
+    l1_16 = (o16["flat_boxes"].cpu() - ref["flat_boxes"]).abs().mean().item()
+    print(f"fp8: projected features rms {e_feat:.3e}, llama hidden rms {e_hid:.3e}, box L1 {l1_8:.3e} (bf16 model {l1_16:.3e})")
+    assert 1e-3 < e_feat < 8e-2 and 1e-3 < e_hid < 8e-2, (e_feat, e_hid)   # really quantised, and within the fp8 budget
+    assert l1_16 < 1e-3 and l1_8 < 1e-2, (l1_16, l1_8)
+    assert (o8["flat_logits"].cpu() - ref["flat_logits"]).abs().max().item() < 0.25
