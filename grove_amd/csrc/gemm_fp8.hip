@@ -5,23 +5,25 @@
 // (amax / 448), applied in the epilogue. The product runs on v_mfma_scale_f32_16x16x128_f8f6f4 — the K = 128 form that reaches the
 // fp8 rate (2x bf16 per clock; the un-scaled K = 32 fp8 MFMA only runs at the bf16 rate) — with unit E8M0 block scales: per-row /
 // per-channel scaling in fp32 is finer than a power-of-two per 32 elements and needs no scale operand traffic.
-// Structure: 128 x 128 output tile per workgroup of 4 waves (2 x 2, 64 x 64 each = 16 accumulator tiles), K tiles of 128 bytes,
-// A / B tiles double-buffered in LDS by LDS-DMA (global_load_lds_dwordx4) with the 16-byte chunk of a row XOR-swizzled by (row & 7)
-// on the SOURCE address, one counted vmcnt + two barriers per K tile, two workgroups per CU. Operand map (checked on hardware with
+// Structure: 256 x 256 output tile per workgroup of 8 waves (2 x 4, 128 x 64 each = 32 accumulator tiles; at the fp8 rate a 128 x 128
+// tile would need ~40 TB/s of L2 -> LDS traffic, four times what the chip delivers: the tile, not the MFMA, sets the ceiling), K
+// tiles of 128 bytes, A / B tiles double-buffered in LDS (128 KB) by LDS-DMA (global_load_lds_dwordx4) with the 16-byte chunk of a
+// row XOR-swizzled by (row & 7) on the SOURCE address, one counted vmcnt + two barriers per K tile, one workgroup per CU. The
+// products are formed transposed (B fragment as the MFMA's A operand) so that a lane owns four consecutive output columns. Operand map (checked on hardware with
 // exact integer data, tests/test_kernels_gpu.py): lane l holds row l & 15, bytes k = 32 (l >> 4) .. + 31 of the 128-deep step.
 #include "common.h"
 
 namespace {
 
-constexpr int F8_BM = 128, F8_BN = 128, F8_BK = 128;  // BK in bytes = fp8 elements
-constexpr int F8_NT = 256;
-constexpr int F8_TILE = F8_BM * F8_BK;                // 16 KB per operand tile
+constexpr int F8_BM = 256, F8_BN = 256, F8_BK = 128;  // BK in bytes = fp8 elements
+constexpr int F8_NT = 512;
+constexpr int F8_TILE = F8_BM * F8_BK;                // 32 KB per operand tile
 
 typedef __attribute__((ext_vector_type(8))) int i32x8_t;
 
 __device__ __forceinline__ void f8_stage(char* lds_tile, const unsigned char* __restrict__ src, int ld, int row0, int rows_valid, int k0, int wave,
                                          int lane) {
-  // tile = 1024 chunks of 16 bytes: chunk d -> (row = d >> 3, position = d & 7) holds source chunk position ^ (row & 7)
+  // tile = 2048 chunks of 16 bytes (8 waves x 4 instructions x 64 lanes): chunk d -> (row = d >> 3, position = d & 7) holds source chunk position ^ (row & 7)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int d = (wave * 4 + i) * 64 + lane;
@@ -40,11 +42,11 @@ __device__ __forceinline__ i32x8_t f8_frag(const char* tile, int row, int kg) {
   return i32x8_t{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
 }
 
-__global__ __launch_bounds__(F8_NT, 2) void gemm_fp8_kernel(const grove_gemm_fp8_params p) {
+__global__ __launch_bounds__(F8_NT, 1) void gemm_fp8_kernel(const grove_gemm_fp8_params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, kg = lane >> 4;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave >> 2, wn = wave & 3;  // 2 x 4 waves: 128 rows x 64 columns each
   // XCD-aware tile order: consecutive tiles of one XCD share the B column block
   const int tiles_m = (p.M + F8_BM - 1) / F8_BM;
   const int n_tiles = gridDim.x;
@@ -55,9 +57,9 @@ __global__ __launch_bounds__(F8_NT, 2) void gemm_fp8_kernel(const grove_gemm_fp8
   const int m0 = tm * F8_BM, n0 = tn * F8_BN;
   const unsigned char* A = (const unsigned char*)p.A;
   const unsigned char* B = (const unsigned char*)p.B;
-  f32x4_t acc[4][4];
+  f32x4_t acc[8][4];
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
+  for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   const int nk = p.K / F8_BK;
@@ -79,32 +81,49 @@ __global__ __launch_bounds__(F8_NT, 2) void gemm_fp8_kernel(const grove_gemm_fp8
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) bf[ni] = f8_frag(cur + F8_TILE, wn * 64 + ni * 16 + fr, kg);
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-      const i32x8_t af = f8_frag(cur, wm * 64 + mi * 16 + fr, kg);
+    for (int mi = 0; mi < 8; ++mi) {
+      const i32x8_t af = f8_frag(cur, wm * 128 + mi * 16 + fr, kg);
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
-        acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af, bf[ni], acc[mi][ni], 0, 0, 0, one, 0, one);
+      for (int ni = 0; ni < 4; ++ni)  // transposed product: D[row = n][col = m]
+        acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bf[ni], af, acc[mi][ni], 0, 0, 0, one, 0, one);
     }
     __syncthreads();  // everyone is done with `cur` before the next iteration's DMA overwrites it
   }
-  // epilogue: lane holds C[m = 4 kg + r][n = fr] of every 16 x 16 tile
+  // epilogue: lane holds C[m = fr][n = 4 kg + r] of every 16 x 16 tile: four consecutive columns -> 8-byte accesses
   const float* sa = p.scale_a;
   const float* sb = p.scale_b;
+  const bool vec = (p.N % 4 == 0) && (p.ldc % 4 == 0) && (!p.residual || p.ldr % 4 == 0) && (((uintptr_t)p.C | (uintptr_t)p.residual | (uintptr_t)p.bias) & 7) == 0;
 #pragma unroll
-  for (int ni = 0; ni < 4; ++ni) {
-    const int n = n0 + wn * 64 + ni * 16 + fr;
-    if (n >= p.N) continue;
-    const float sbn = sb[n];
-    const float bn = p.bias ? bf2f(((const bf16_raw*)p.bias)[n]) : 0.f;
+  for (int mi = 0; mi < 8; ++mi) {
+    const int m = m0 + wm * 128 + mi * 16 + fr;
+    if (m >= p.M) continue;
+    const float sam = sa[m];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
+    for (int ni = 0; ni < 4; ++ni) {
+      const int n = n0 + wn * 64 + ni * 16 + 4 * kg;
+      if (n >= p.N) continue;
+      float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wm * 64 + mi * 16 + 4 * kg + r;
-        if (m >= p.M) continue;
-        float v = act_apply(p.act, acc[mi][ni][r] * (sa[m] * sbn) + bn);
-        if (p.residual) v += bf2f(((const bf16_raw*)p.residual)[(int64_t)m * p.ldr + n]);
-        ((bf16_raw*)p.C)[(int64_t)m * p.ldc + n] = f2bf(v);
+        const int nn = min(n + r, p.N - 1);
+        const float b = p.bias ? bf2f(((const bf16_raw*)p.bias)[nn]) : 0.f;
+        v[r] = act_apply(p.act, acc[mi][ni][r] * (sam * sb[nn]) + b);
+      }
+      bf16_raw* c = (bf16_raw*)p.C + (int64_t)m * p.ldc + n;
+      if (vec) {
+        if (p.residual) {
+          const u32x2_t rr = *(const u32x2_t*)((const bf16_raw*)p.residual + (int64_t)m * p.ldr + n);
+          v[0] += bf_lo(rr.x); v[1] += bf_hi(rr.x); v[2] += bf_lo(rr.y); v[3] += bf_hi(rr.y);
+        }
+        *(u32x2_t*)c = u32x2_t{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (n + r >= p.N) break;
+          float o = v[r];
+          if (p.residual) o += bf2f(((const bf16_raw*)p.residual)[(int64_t)m * p.ldr + n + r]);
+          c[r] = f2bf(o);
+        }
       }
     }
   }
