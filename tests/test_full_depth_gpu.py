@@ -23,11 +23,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 class LazyRoundedWeights(dict):
     """{name: fp32 tensor of the bf16-rounded synthetic weight}, generated on access (the oracle only indexes / .get()s)."""
 
-    def __init__(self, d):
+    def __init__(self, d, gen_device="cpu"):
         super().__init__()
         from grove_amd.synthetic import param_shapes
         self.d, self.shapes = d, param_shapes(d)
         self._last = (None, None)
+        self.gen_device = gen_device  # the name-keyed generator is bit-identical on CPU and GPU; the GPU makes 7.6e9 values in seconds
 
     def __contains__(self, k):
         return k in self.shapes
@@ -38,7 +39,7 @@ class LazyRoundedWeights(dict):
             return self._last[1]
         shape = self.shapes[k]
         mean, std = init_spec(k, shape, self.d)
-        t = det_tensor(k, shape, std=std, mean=mean).to(bf).float()
+        t = det_tensor(k, shape, std=std, mean=mean, device=self.gen_device).to(bf).float().cpu()
         self._last = (k, t)
         return t
 
@@ -92,7 +93,7 @@ def test_full_depth_inference_vs_fp32_oracle(dev, which):
     torch.cuda.synchronize()
     t_gpu = time.time() - t0
 
-    sd = LazyRoundedWeights(d)
+    sd = LazyRoundedWeights(d, gen_device=dev)
     torch.set_num_threads(min(os.cpu_count() or 1, 64))
     gi, si = kw["global_enc_images"].to(bf).float(), kw["grounding_enc_images"].to(bf).float()
     t0 = time.time()

@@ -30,7 +30,7 @@ def main():
     for k in ("input_ids", "labels", "attention_masks", "offset"):
         kd[k] = kw[k].to(dev)
     out = model(**kd)
-    sd = LazyRoundedWeights(d)
+    sd = LazyRoundedWeights(d, gen_device=dev)
     torch.set_num_threads(min(os.cpu_count() or 1, 64))
     gi, si = kw["global_enc_images"].to(bf).float(), kw["grounding_enc_images"].to(bf).float()
     with torch.no_grad():
