@@ -114,6 +114,17 @@ class GROVEForCausalLM(torch.nn.Module):
         self._build_engines()
         self._ctx = None
         self._grad_ready_cb = None  # set by GroveEngine: called with (lo, hi, stream) when flat-gradient slice [lo, hi) is final
+        self._weights_event = None  # set by GroveEngine.step: recorded behind the optimizer update on its own stream
+
+    def set_weights_event(self, ev):
+        self._weights_event = ev
+
+    def wait_weights(self, stream=None):
+        """Make `stream` (default: the current one) wait for the optimizer update that may still be writing the trainable tensors
+        (GroveEngine.step runs it on its own stream so that it hides under the next forward's frozen layers). Every first read of a
+        trainable tensor in a forward, and every export of the weights, goes through here; a completed event costs nothing."""
+        if self._weights_event is not None:
+            (stream if stream is not None else torch.cuda.current_stream(self.dev)).wait_event(self._weights_event)
 
     def _grads_final(self, prefixes, stream=None):
         """Tell the gradient exchange that every trainable tensor whose name starts with one of `prefixes` has its final gradient
@@ -178,6 +189,7 @@ class GROVEForCausalLM(torch.nn.Module):
             self.trainable = names
 
     def state_dict(self, *a, **k):
+        self.wait_weights()
         return dict(self._sd)
 
     def load_state_dict(self, sd, strict=False, **k):
@@ -185,6 +197,7 @@ class GROVEForCausalLM(torch.nn.Module):
         unexpected = [n for n in sd if n not in self._sd]
         if strict and (missing or unexpected):
             raise RuntimeError(f"missing {missing[:3]} unexpected {unexpected[:3]}")
+        self.wait_weights()
         for n, v in sd.items():
             if n in self._sd:
                 self._sd[n].copy_(v.to(self.dev))
@@ -235,7 +248,8 @@ class GROVEForCausalLM(torch.nn.Module):
 
     def encode_images(self, images, tape=None):
         """llava_with_region_arch.py:79-82 -> (image_features [B*T/8, 576, hidden], hidden_states[-2])."""
-        pooled, hs = self.clip.forward(images.to(bf))
+        pooled, hs = self.clip.forward(images.to(bf))  # frozen tower: may run beside a pending optimizer update
+        self.wait_weights()                             # the projector is trainable
         G = pooled.shape[0]
         tp = tape if tape is not None else Tape(enabled=False)
         x = Var(pooled.view(G * 576, -1), needs_grad=False)
@@ -255,6 +269,7 @@ class GROVEForCausalLM(torch.nn.Module):
         boxes, objectness, and masks [N, C, H, W] logits when the sizes are given; binarise with > 0)."""
         d = self.dims
         g2 = d.sam_grid ** 2
+        self.wait_weights()
         emb = image_embeddings
         if emb.dim() == 4:  # NCHW -> channels-last rows
             F = emb.shape[0]
@@ -270,7 +285,7 @@ class GROVEForCausalLM(torch.nn.Module):
 
     def get_grounding_encoder_embs(self, images):
         """GROVE.py:134-136 -> [B*T, 256, g, g] (NCHW like the reference; internally channels-last)."""
-        rows, _ = self.sam.forward(images.to(bf))
+        rows, _ = self.sam.forward(images.to(bf), before_adapters=self.wait_weights)
         F, g = rows.shape[0], self.dims.sam_grid
         out = torch.empty((F, rows.shape[2], g * g), dtype=bf, device=self.dev)
         ops.transpose(rows, g * g, rows.shape[2], rows.shape[2], out, g * g, batch=(F, 1), s_in=(g * g * rows.shape[2], 0),
@@ -450,7 +465,7 @@ class GROVEForCausalLM(torch.nn.Module):
         start.record(main)  # the inputs are complete where the main stream stands now (before this step's kernels)
         side.wait_event(start)
         if not self.tower_overlap:  # serial order (clean per-kernel timings): grounding encoder first, as the reference (GROVE.py:162)
-            emb_rows, sam_ctx = self.sam.forward(simg.to(bf), save=train)
+            emb_rows, sam_ctx = self.sam.forward(simg.to(bf), save=train, before_adapters=self.wait_weights)
         # 2. global encoder + projector (GROVE.py:170-176)
         feats, _ = self.encode_images(gimg, tape=tp)
         # 0. everything the host derives from the INPUTS — splice plan, labelled rows, [DET] rows / instances, ground truth —
@@ -464,6 +479,7 @@ class GROVEForCausalLM(torch.nn.Module):
             t_.record_stream(main)
         plan, S, det_rows, counts = hp.plan, hp.plan.S, hp.det_rows, hp.counts
         # 3. splice, LLaMA (llava_llama.py:88-109)
+        self.wait_weights()
         x = self._embed(plan, feats.data)
         hidden, llama_ctx = self.llama.forward(x, plan.B, plan.S, kv_len=plan.kv_len, save=train)
         # 1. grounding encoder (GROVE.py:162). It shares nothing with the CLIP -> LLaMA tower until the decoder, so it runs on its
@@ -474,7 +490,7 @@ class GROVEForCausalLM(torch.nn.Module):
                 self._sam_stream = torch.cuda.Stream(device=self.dev)
             self._sam_stream.wait_event(start)
             with torch.cuda.stream(self._sam_stream):
-                emb_rows, sam_ctx = self.sam.forward(simg.to(bf), save=train)
+                emb_rows, sam_ctx = self.sam.forward(simg.to(bf), save=train, before_adapters=self.wait_weights)
         F = emb_rows.shape[0]
         emb_rows2 = emb_rows.view(F * d.sam_grid ** 2, -1)
         if self.tower_overlap:
@@ -685,6 +701,7 @@ class GROVEForCausalLM(torch.nn.Module):
         for a cached step), `.hidden_states` = the final-norm hidden tensor (what the reference returns outside training mode,
         llava_llama.py:130-133) and `.past_key_values`. Un-padded equal-length prompts only (quirk Q9: the reference's
         attention mask is wrong for anything else), so `attention_mask` is not read."""
+        self.wait_weights()
         if labels is not None or inputs_embeds is not None or output_attentions:
             raise NotImplementedError("lm_forward serves generation only: the training CE runs inside model_forward; "
                                       "inputs_embeds / attentions are not produced on this path")

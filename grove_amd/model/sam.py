@@ -227,7 +227,7 @@ class SamEncoder:
                        M=x.shape[0], aux=pre)
         return y, (x, pre)
 
-    def forward(self, images, save=False, upto=None):
+    def forward(self, images, save=False, upto=None, before_adapters=None):
         """images bf16 [B, 3, T, 512, 512] -> channels-last embeddings [F, g*g, 256] (the reference returns
         NCHW [F,256,g,g]; the boundary transposes on request). save=True keeps what backward needs."""
         d = self.d
@@ -256,6 +256,9 @@ class SamEncoder:
                 saved["blocks"][i] = ctx
             if i in d.sam_global:
                 j = d.sam_global.index(i)
+                if before_adapters is not None:  # first read of a trainable tensor on this stream (blocks are frozen): see wait_weights
+                    before_adapters()
+                    before_adapters = None
                 t, actx = self._adapter(self.adapters[j], res, t, conv_idx, save)
                 if not f32:
                     res, t = t, None

@@ -66,6 +66,7 @@ def test_optimizer_step_matches_restated_adamw(dev):
     g = engine.module._flat_grad.clone()
     w0 = engine.master.clone()
     engine.step()
+    torch.cuda.synchronize()  # the update runs on the engine's optimizer stream (it overlaps the next forward's frozen layers)
     norm = float(g.double().pow(2).sum().sqrt())
     scale = 1.0 if norm <= 1.0 else 1.0 / (norm + 1e-6)
     lr = engine.scheduler.for_update(1)
@@ -246,3 +247,27 @@ def test_bench_self_launches_ranks(tmp_path):
         assert q.returncode == 0, q.stderr[-2000:]
         losses.append(json.loads([ln for ln in q.stdout.splitlines() if ln.strip()][0])["config"]["last_loss"])
     assert max(losses) - min(losses) <= 2e-3 * max(1.0, abs(losses[0])), losses
+
+
+def test_optimizer_stream_overlap_is_race_free(dev):
+    """The update runs on its own stream and the next forward waits for it only where it first reads a trainable tensor. Three steps
+    with the overlap must give bit-identical weights and losses to three steps with the compute stream waiting inside step()."""
+    res = {}
+    for overlap in (True, False, True):
+        T, args, d, engine = _engine(dev)
+        engine.scheduler.warm = 0
+        engine.overlap_optimizer = overlap
+        losses = []
+        for s in range(3):
+            out = engine(**_batch(d, dev, 10 + s))
+            losses.append(out["loss"])
+            engine.backward(out["loss"])
+            engine.step()
+        torch.cuda.synchronize()
+        res.setdefault(overlap, []).append((torch.stack(losses).cpu(), engine.master.clone().cpu()))
+    (l_a, w_a), (l_c, w_c) = res[True]
+    (l_b, w_b), = res[False]
+    # (split-K / CE sums use fp32 atomics: run-to-run noise of the same configuration is the yardstick)
+    noise = max((w_a - w_c).abs().max().item(), 1e-7)
+    assert (w_a - w_b).abs().max().item() <= 4 * noise + 1e-6, ((w_a - w_b).abs().max().item(), noise)
+    assert (l_a - l_b).abs().max().item() <= 1e-4 * l_b.abs().max().item() + 4 * (l_a - l_c).abs().max().item()
