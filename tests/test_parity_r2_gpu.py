@@ -432,3 +432,34 @@ def test_fp8_vit_llama_path_vs_oracle_and_bf16(dev):
     assert 1e-3 < e_feat < 0.12 and 1e-3 < e_hid < 0.15, (e_feat, e_hid)   # really quantised, and within the fp8 budget
     assert l1_16 < 1e-3 and l1_8 < 2e-2, (l1_16, l1_8)
     assert (o8["flat_logits"].cpu() - ref["flat_logits"]).abs().max().item() < 0.5
+
+
+def test_T32_inference_windows_and_masks(dev):
+    """Config 5's clip shape at tiny dims: T = 32 = four 8-frame windows per clip (same text), inference forward against the oracle on
+    the four window samples, then masks for every ([DET], frame) instance of the clip."""
+    from grove_amd import GROVEForCausalLM
+    from grove_amd.synthetic import TINY, synthetic_batch, synthetic_state_dict
+    from oracle import grove_oracle as O
+    d = TINY
+    sd = synthetic_state_dict(d)
+    sd_r = {k: v.to(bf).float() for k, v in sd.items()}
+    model = GROVEForCausalLM(dims=d, device=dev, state_dict=sd, det_token_idx=d.det_token_idx, num_frames=8, pe_dtype=torch.float32)
+    batch = synthetic_batch(d, B=1, T=32, L=40, n_det=2, seed=9)
+    kw = to_dev(batch, dev)
+    kw["inference"] = True
+    out = model(**kw)
+    assert len(out["pred_bboxes"]) == 1 and len(out["pred_bboxes"][0]) == 32
+    kwo = window_batch_kwargs(batch, 4)
+    kwo["inference"] = True
+    with torch.no_grad():
+        ref = O.model_forward(sd_r, d, **kwo)
+    l1 = (out["flat_boxes"].cpu() - ref["flat_boxes"]).abs().mean().item()
+    assert l1 < 1e-3, f"box L1 {l1}"
+    assert (out["flat_logits"].cpu() - ref["flat_logits"]).abs().max().item() < 5e-2
+    n = out["flat_boxes"].shape[0]
+    assert n == 32 * 2
+    inst_frame = torch.arange(32, dtype=torch.int32).repeat_interleave(2)
+    band = int(d.sam_image * 360 / 640)
+    res = model.predict_masks(out["image_embeddings"], model._last_text, inst_frame, input_size=(band, d.sam_image), original_size=(360, 640))
+    assert tuple(res["masks"].shape) == (n, 1, 360, 640) and torch.isfinite(res["masks"]).all()
+    assert (res["boxes"].cpu() - out["flat_boxes"].cpu()).abs().max().item() < 1e-5
