@@ -126,7 +126,7 @@ class GROVEForCausalLM(torch.nn.Module):
         if self._weights_event is not None:
             (stream if stream is not None else torch.cuda.current_stream(self.dev)).wait_event(self._weights_event)
 
-    def _grads_final(self, prefixes, stream=None):
+    def _grads_final(self, prefixes, stream=None, event=None):
         """Tell the gradient exchange that every trainable tensor whose name starts with one of `prefixes` has its final gradient
         (a prefix's tensors are contiguous in the flat buffer: trainable_names keeps groups together)."""
         if self._grad_ready_cb is None:
@@ -136,7 +136,7 @@ class GROVEForCausalLM(torch.nn.Module):
             if names:
                 lo = min(self._grad_off[n] for n in names)
                 hi = max(self._grad_off[n] + (self._sd[n].numel() + 3) // 4 * 4 for n in names)
-                self._grad_ready_cb(lo, hi, stream)
+                self._grad_ready_cb(lo, hi, stream, event)
 
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path, *model_args, dims=None, device="cuda", train=False, torch_dtype=None,
@@ -667,7 +667,13 @@ class GROVEForCausalLM(torch.nn.Module):
             c.feats.grad = dfe
         ops.scatter_add_f32(dx, self._grad["model.embed_tokens.weight"], plan.tok, plan.B * plan.S, H)
         c.tp.backward()  # mm_projector
-        self._grads_final(["model.embed_tokens.", "model.mm_projector."])
+        # embed_tokens + projector are final HERE on the main stream, but their exchange is queued behind the SAM adapters' (below):
+        # the communication stream is FIFO, and the adapters finish on the SAM stream while the LLaMA dgrad above is still running —
+        # handed over first, this last group would hold them back until the end of the LLaMA sweep
+        main_grads_done = None
+        if self._grad_ready_cb is not None:
+            main_grads_done = torch.cuda.Event()
+            main_grads_done.record(main)
 
         def adapter_done(j, stream):  # the SAM tower's own stream finishes adapter j's weight / bias / alpha gradients
             self._grads_final([SAM_PREFIX + f"adapters.{j}."], stream)
@@ -676,9 +682,11 @@ class GROVEForCausalLM(torch.nn.Module):
             with torch.cuda.stream(self._sam_stream):
                 d_emb.record_stream(self._sam_stream)
                 self.sam.backward(c.sam_ctx, ops.to_bf16(d_emb), on_adapter_done=lambda j: adapter_done(j, self._sam_stream))
+            self._grads_final(["model.embed_tokens.", "model.mm_projector."], event=main_grads_done)
             main.wait_stream(self._sam_stream)
         else:
             self.sam.backward(c.sam_ctx, ops.to_bf16(d_emb), on_adapter_done=lambda j: adapter_done(j, None))
+            self._grads_final(["model.embed_tokens.", "model.mm_projector."], event=main_grads_done)
         self._ctx = None
 
     # ------------------------------------------------------------------ generation (GROVE.py:412-451, llava_llama.py:57-180)

@@ -180,8 +180,9 @@ class GradExchange:
             else:  # ragged tail of a group (not a multiple of the world size): plain all-reduce
                 self.handles.append(dist.all_reduce(b, op=dist.ReduceOp.SUM, async_op=True))
 
-    def ready(self, lo, hi, producer_stream=None):
-        """Gradients of flat[lo:hi] are final once `producer_stream` reaches this point: start their exchange."""
+    def ready(self, lo, hi, producer_stream=None, event=None):
+        """Gradients of flat[lo:hi] are final once `producer_stream` reaches this point (or once `event`, recorded earlier by the
+        caller, has passed): start their exchange. Collectives are issued in call order — identical on every rank."""
         if hi <= lo:
             return
         src = self.flat[lo:hi]
@@ -193,8 +194,10 @@ class GradExchange:
             self._exchange(buf)
             self.pending.append((lo, hi))
             return
-        ev = torch.cuda.Event()
-        ev.record(producer_stream if producer_stream is not None else torch.cuda.current_stream(self.flat.device))
+        ev = event
+        if ev is None:
+            ev = torch.cuda.Event()
+            ev.record(producer_stream if producer_stream is not None else torch.cuda.current_stream(self.flat.device))
         with torch.cuda.stream(self.stream):
             self.stream.wait_event(ev)
             buf = src
