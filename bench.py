@@ -139,6 +139,30 @@ def vit_llama_forward(model, batch, dims, reps=5):
             "frac_of_bf16_peak": round(flops / ms / 1e9 / PEAK_BF16_TFLOPS, 4), "windows": B, "S": S}
 
 
+def decode_rate(model, dims, dev):
+    """Cached greedy decode on the bench's own model (config 2's inner loop): ms per generated token at B = 1 after a 615-position
+    prefill, and the fraction of the HBM peak the weight stream reaches (13.2 GB of bf16 weights are read once per token)."""
+    from grove_amd.synthetic import synthetic_batch
+    b = synthetic_batch(dims, B=1, T=8, L=64, n_det=1, seed=5, device=dev, dtype=torch.bfloat16)
+    with torch.no_grad():
+        feats, _ = model.encode_images(b.global_enc_images)
+        prompt = b.input_ids[:, :40].contiguous()
+
+        def run(n):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            model.generate(input_ids=prompt, image_features=feats, max_new_tokens=n, eos_token_id=-1)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0
+        run(3)
+        t9, t33 = run(9), run(33)
+    per_tok = (t33 - t9) / 24
+    wbytes = 2.0 * (dims.n_layers * (4 * dims.hidden * dims.hidden + 3 * dims.hidden * dims.mlp) + dims.vocab * dims.hidden)
+    return {"ms_per_token": round(per_tok * 1e3, 3), "tokens_per_s": round(1.0 / per_tok, 1), "batch": 1, "prefill_positions": 575 + 40,
+            "roofline": {"bound": "hbm", "achieved": round(wbytes / per_tok / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(wbytes / per_tok / 8e12, 3), "weight_bytes_per_token": wbytes}}
+
+
 def cpu_baseline(args):
     """Oracle (CPU port) on a bounded sample of the same workload: one 8-frame window at FULL dimensions, one
     layer of each tower forward (+ backward where the step has one), scaled by the layer counts of the step."""
@@ -474,6 +498,11 @@ def main():
                 res["fused_vit_llama_forward"] = vit_llama_forward(model, batch, dims)
             except Exception as e:
                 res["fused_vit_llama_forward"] = {"error": repr(e)}
+            if world == 1:
+                try:
+                    res["greedy_decode"] = decode_rate(model, dims, dev)
+                except Exception as e:
+                    res["greedy_decode"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is a rank-0, N = 1 figure (other N: GPU numbers only)
             try:
                 res["box_l1_vs_oracle_tiny"] = round(tiny_box_l1(dev), 6)
