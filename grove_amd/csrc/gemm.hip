@@ -17,6 +17,11 @@
 #include <type_traits>
 
 #include "common.h"
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
 
 namespace {
 
@@ -707,18 +712,38 @@ __device__ __forceinline__ i32x8_t sload8(const int* p) {
   return v;
 }
 
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4_t sload4(const void* p) {  // 4 consecutive int32, same reasoning (p is wave-uniform by construction)
+  i32x4_t v;
+  const uint64_t a = (uint64_t)p;
+  const uint64_t u = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a) |
+                     ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32)) << 32);
+  asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"((const void*)u) : "memory");
+  return v;
+}
+
 // GATHER: A rows are looked up per (tap, m) in p.a_idx (implicit-GEMM Conv3d: K = taps x C_in; window (un)partition: one tap),
 // -1 = a zero row.
-// reciprocals for the tile -> origin map (see tile_origin)
-struct pp_tile_map {
-  unsigned magic_band, magic_tail;  // floor(2^32 / d) + 1 for d = 8 * tiles_n and d = tail
-  int full_bands, tail;             // tiles_m / 8, tiles_m % 8
+// THE WORK LIST. The host writes, once per shape, what every block does (pp_table below); the kernel only walks its column:
+//   row 0        header  {NT = K tiles of the block's stream, number of segments, 0, 0}
+//   row 1 + i    segment {m0, n0, k0 | k1 << 16, part}: K tiles [k0, k1) of the output tile at (m0, n0)
+// one 16-byte scalar load per segment, no index arithmetic (and none of its scalar registers) in the kernel.
+//   part 0       a whole tile (k0 = 0, k1 = nk): accumulate, epilogue. The data-parallel rounds: tile L = wgid + i * G, band-major.
+//   part 1 + s   STREAM-K: a K range of a tile of the last, partial round; the raw fp32 accumulators go to workspace slot s
+//                and gemm_pp_fixup_kernel (next launch on the stream) sums a tile's slots in K order and runs the epilogue.
+// Stream-K tail (plan_stream_k): tiles = rounds * G + tail with tail <= G / 2 — the tiles of the partial round are cut into 2..4
+// equal K ranges, one block each, so that (nearly) every CU works through the last round instead of `tail` CUs for a whole
+// tile. The order of the sum is fixed by the list, so results are deterministic.
+struct pp_work {
+  const i32x4_t* table;
+  float* ws;  // slots of 8 waves x 32 accumulators x 64 lanes x 16 B (lane-linear: the fix-up's same wave reads them with the same map)
 };
+constexpr size_t P_SLOT = (size_t)8 * 32 * 64 * 16;
 
 // ACT: the epilogue compiled in (-1 = plain: act NONE, alpha 1, no scale) — one per kernel: with all of them in one kernel the
 // register allocator spills inside the K loop.
 template <int BM, bool GATHER, int ACT>
-__global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_params p, const int tiles_m, const int tiles_n, const pp_tile_map tm) {
+__global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_params p, const pp_work work) {
   constexpr int BMH = BM / 2;    // rows of an A half-tile: 128 or 96
   constexpr int WRH = BMH / 2;   // ... of which one wave group owns 64 or 48
   constexpr int MIH = WRH / 16;  // row fragments per half per wave: 4 or 3
@@ -730,33 +755,16 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
   const bf16_raw* __restrict__ A = (const bf16_raw*)p.A;
   const bf16_raw* __restrict__ B = (const bf16_raw*)p.B;
 
-  // my tiles: L = wgid + k * G; blocks of one XCD (blockIdx % 8) take neighbouring tiles of every round
+  // my column of the work list: blocks of one XCD (blockIdx % 8) take neighbouring tiles of every round
   const int G = gridDim.x;
   const int xcd = blockIdx.x & 7, q8 = G >> 3, r8 = G & 7;
   const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
-  const int tiles = tiles_m * tiles_n;
-  const int my_tiles = (tiles - wgid + G - 1) / G;
-  const int nk = p.K / P_BK;
-  const int NT = my_tiles * nk;  // K tiles of my stream
-  const int NH = 4 * NT;         // half-tiles of my stream
-  // tile L -> origin: bands of GM = 8 tile rows, column-major inside a band (the last band may be shorter). Divisions by
-  // multiply-high with host-made reciprocals (exact: L * divisor < 2^32, checked by the launcher) — the compiler's integer
-  // division is ~400 clocks of dependent scalar code, and this runs inside a K tile's staging segment once per output tile.
-  auto tile_origin = [&](int L, int& m0, int& n0) {
-    const int per_band = 8 * tiles_n;
-    const int band = (int)__umulhi((unsigned)L, tm.magic_band);
-    const int in_band = L - band * per_band;
-    int r, c;
-    if (band == tm.full_bands) {  // the short last band: tm.tail rows (tail 1: the reciprocal 2^32 does not fit — no division needed)
-      c = tm.tail == 1 ? in_band : (int)__umulhi((unsigned)in_band, tm.magic_tail);
-      r = in_band - c * tm.tail;
-    } else {
-      c = in_band >> 3;
-      r = in_band & 7;
-    }
-    m0 = (band * 8 + r) * BM;
-    n0 = c * P_BN;
-  };
+  const i32x4_t* my_work = work.table + wgid;
+  const i32x4_t head = sload4(my_work);
+  const int NT = head[0];    // K tiles of my stream
+  const int nseg = head[1];  // segments of my stream
+  const int NH = 4 * NT;     // half-tiles of my stream
+  if (NT == 0) return;       // (a block past the end of a stream-K tail)
 
   // staging: regions of a stage in staging order 0 = A_lo, 1 = B_lo, 2 = B_hi, 3 = A_hi. A half-tile region is 128 rows x 8
   // chunks = 2 LDS-DMA instructions per thread. (BM = 192 uses 96 rows of an A region; every wave still issues both
@@ -795,10 +803,8 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
     is_m0 = m0;
     is_tap = tap;
   };
-  auto set_src = [&](int L) {
-    int m0, n0;
-    tile_origin(L, m0, n0);
-    if constexpr (GATHER) set_src_a(m0, 0);
+  auto set_src = [&](int m0, int n0, int k0) {
+    if constexpr (GATHER) set_src_a(m0, k0 ? __builtin_amdgcn_readfirstlane(k0 / kt_per_tap) : 0);  // (a stream-K part starts inside the K range)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int r = st_r + 64 * i;
@@ -814,7 +820,12 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
       src[2][i] = B + (int64_t)min(n0 + 128 + pn, p.N - 1) * p.ldb + c;
     }
   };
-  int is_L = wgid, is_k = 0;  // output tile and K tile of the half-tile being issued
+  int is_seg = 0, is_k, is_kend;  // segment and K tile of the half-tile being issued
+  {
+    const i32x4_t e = sload4(my_work + G);
+    is_k = e[2] & 0xffff, is_kend = (unsigned)e[2] >> 16;
+    set_src(e[0], e[1], is_k);
+  }
   auto issue = [&](int x, int stream_t) {
     char* dst = smem + (stream_t & 1) * P_STAGE + x * P_HALF + wave * (64 * 16);
     int64_t koff0 = (int64_t)is_k * P_BK, koff1 = koff0;
@@ -833,10 +844,11 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
                                      (__attribute__((address_space(3))) void*)(dst + P_NT * 16), 16, 0, 0);
   };
   auto advance_issue = [&]() {  // before the A_lo of every K tile but the first
-    if (++is_k == nk) {
-      is_k = 0;
-      is_L += G;
-      set_src(is_L);
+    if (++is_k == is_kend) {
+      ++is_seg;
+      const i32x4_t e = sload4(my_work + (is_seg + 1) * G);
+      is_k = e[2] & 0xffff, is_kend = (unsigned)e[2] >> 16;
+      set_src(e[0], e[1], is_k);
     } else if (GATHER && is_k == (is_tap + 1) * kt_per_tap) {
       set_src_a(is_m0, is_tap + 1);  // next tap of the same tile: new A rows
     }
@@ -899,7 +911,6 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
   }
   asm volatile("" ::"v"(scale));
   // prologue: half-tiles 0..5 of my stream, the first two landed before anyone reads
-  set_src(is_L);
   issue(0, 0); issue(1, 0); issue(2, 0); issue(3, 0);
   if (NT > 1) {
     advance_issue();
@@ -945,8 +956,10 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
   // but the stream's last two), then the epilogue (no barriers inside) — the next tile's operands are already landing
   int T = 0;
   bool relax = false;
-  for (int c_L = wgid; c_L < tiles; c_L += G) {
-    const int ns = min(max(NT - 2 - T, 0), nk);
+  for (int sg = 0; sg < nseg; ++sg) {
+    const i32x4_t e = sload4(my_work + (sg + 1) * G);
+    const int m0 = e[0], n0 = e[1], nks = (int)((unsigned)e[2] >> 16) - (e[2] & 0xffff), part = e[3];
+    const int ns = min(max(NT - 2 - T, 0), nks);
     int k = 0;
     using no_relax = std::integral_constant<int, 0>;
     if (relax && ns > 0) {
@@ -954,19 +967,34 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
       ++k, ++T;
     }
     for (; k < ns; ++k, ++T) k_tile(std::true_type{}, no_relax{}, T);
-    for (; k < nk; ++k, ++T) k_tile(std::false_type{}, no_relax{}, T);
+    for (; k < nks; ++k, ++T) k_tile(std::false_type{}, no_relax{}, T);
     // Both groups run their epilogues in the same barrier interval: the leading group waits one barrier here (the lagging
     // group is in its last MFMA segment), the lagging group waits one after its epilogue, which restores the one-barrier lag.
     // An epilogue is bound by the issue latency of its own VALU / store stream, so two waves per SIMD take little longer
     // than one, where the groups one after the other took twice as long. No LDS access and no staging in the interval.
     if (wr == 0) __builtin_amdgcn_s_barrier();
-    int m0, n0;
-    tile_origin(c_L, m0, n0);
-    const int mw0 = m0 + wr * WRH, nw0 = n0 + wc * 32;
-    const bool interior = fast_addr && m0 + BM <= p.M && n0 + P_BN <= p.N;
-    if (interior) gemm_epilogue_fast<MIH, BMH, ACT>(p, acc, mw0, nw0, fr, fq, ACT < 0 ? 1.f : scale);
-    else gemm_epilogue_wide<MIH, BMH, ACT>(p, acc, mw0, nw0, fr, fq, ACT < 0 ? 1.f : scale);
-    relax = interior && !p.aux;  // exactly 4 * MIH stores per wave were issued
+    if (__builtin_expect(part != 0, 0)) {
+      // stream-K part: raw accumulators to my slot — wave-uniform base + lane offset + immediate, one address register for all
+      // the stores; the empty asm pins that arithmetic here (hoisted out of the segment loop it would hold registers across
+      // the K loops, and so would this branch without the "unlikely"). The stores are not counted for RELAX: the next K tile's
+      // vmcnt(8) simply waits for them too.
+      char* wb = (char*)work.ws + ((size_t)(part - 1) * 8 + wave) * 32768;
+      int lo = lane * 16;
+      asm volatile("" : "+s"(wb), "+v"(lo));
+#pragma unroll
+      for (int i = 0; i < 2 * MIH; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *(f32x4_t*)(wb + (i * 4 + j) * 1024 + lo) = acc[i][j];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      relax = false;
+    } else {
+      const int mw0 = m0 + wr * WRH, nw0 = n0 + wc * 32;
+      const bool interior = fast_addr && m0 + BM <= p.M && n0 + P_BN <= p.N;
+      if (interior) gemm_epilogue_fast<MIH, BMH, ACT>(p, acc, mw0, nw0, fr, fq, ACT < 0 ? 1.f : scale);
+      else gemm_epilogue_wide<MIH, BMH, ACT>(p, acc, mw0, nw0, fr, fq, ACT < 0 ? 1.f : scale);
+      relax = interior && !p.aux;  // exactly 4 * MIH stores per wave were issued
+    }
 #pragma unroll
     for (int i = 0; i < 2 * MIH; ++i)
 #pragma unroll
@@ -978,8 +1006,170 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
 #undef PP_MEM_END
 }
 
+// Stream-K fix-up: split tile {m0, n0, first slot, parts}; wave w sums what wave w of the parts left and runs the same epilogue
+// the main kernel would have run (same accumulator map, same functions). The waves are independent: FIX_WAVES per block,
+// 8 / FIX_WAVES blocks per tile, so that the few split tiles still spread over the whole chip.
+constexpr int FIX_WAVES = 2;
+template <int BM, int ACT>
+__global__ __launch_bounds__(64 * FIX_WAVES) void gemm_pp_fixup_kernel(const grove_gemm_params p, const i32x4_t* __restrict__ list, const float* __restrict__ ws) {
+  constexpr int BMH = BM / 2, WRH = BMH / 2, MIH = WRH / 16;
+  constexpr int BPT = 8 / FIX_WAVES;  // blocks per tile
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x % BPT) * FIX_WAVES + (tid >> 6));
+  const int wr = wave >> 2, wc = wave & 3;
+  const int fr = lane & 15, fq = lane >> 4;
+  const i32x4_t e = list[blockIdx.x / BPT];
+  const int m0 = e[0], n0 = e[1], s0 = e[2], np = e[3];
+  float scale = 1.f;
+  if (p.scale_ptr) {
+    scale = *p.scale_ptr;
+    if (p.scale_tanh) scale = tanhf(scale);
+  }
+  f32x4_t acc[2 * MIH][4];
+  {
+    const char* wb = (const char*)ws + ((size_t)s0 * 8 + wave) * 32768 + lane * 16;
+#pragma unroll
+    for (int i = 0; i < 2 * MIH; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = *(const f32x4_t*)(wb + (i * 4 + j) * 1024);
+  }
+  for (int q = 1; q < np; ++q) {
+    const char* wb = (const char*)ws + ((size_t)(s0 + q) * 8 + wave) * 32768 + lane * 16;
+#pragma unroll
+    for (int i = 0; i < 2 * MIH; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] += *(const f32x4_t*)(wb + (i * 4 + j) * 1024);
+  }
+  const bool fast_addr = p.c_dtype == GROVE_BF16 && !p.c_idx && !p.r_idx && !p.n_group;
+  const int mw0 = m0 + wr * WRH, nw0 = n0 + wc * 32;
+  const bool interior = fast_addr && m0 + BM <= p.M && n0 + P_BN <= p.N;
+  if (interior) gemm_epilogue_fast<MIH, BMH, ACT>(p, acc, mw0, nw0, fr, fq, ACT < 0 ? 1.f : scale);
+  else gemm_epilogue_wide<MIH, BMH, ACT>(p, acc, mw0, nw0, fr, fq, ACT < 0 ? 1.f : scale);
+}
+
 static int g_num_cus = 0;
 static int g_gemm_last_epilogue = 0;  // ACT template argument of the last pipelined launch (see grove_gemm_last_epilogue)
+static int g_gemm_stream_k = 1;       // plan_stream_k mode (grove_gemm_set_stream_k)
+static int g_gemm_last_stream_k = 0;  // S of the last pipelined launch
+
+inline int num_cus() {
+  if (g_num_cus == 0) {
+    int dev = 0, n = 0;
+    hipGetDevice(&dev);
+    hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    g_num_cus = n > 0 ? n : 256;
+  }
+  return g_num_cus;
+}
+
+// Stream-K plan for `tiles` output tiles of nk K tiles on G blocks: after the whole rounds, a partial round of `tail` tiles
+// is cut into s = G / tail (2..4) K ranges of S = ceil(nk / s) K tiles, one block each. S = 0: whole tiles only. kt_units: the
+// length of the launch in K tiles either way; a split costs the raw 256 KB stores of the parts, the fix-up launch that reads
+// them back and some of the L2 sharing between neighbouring tiles: SK_FIXED K tiles' worth (~30 us, measured).
+// (Equal parts, not one evenly dealt stream: blocks that share an operand panel stay in the same K phase, so the panel is
+// fetched into L2 once — dealt out unevenly, 240 tiles on 256 CUs ran 1.5x SLOWER than whole tiles.)
+constexpr int SK_FIXED = 20;
+struct sk_plan { int S, parts, rounds, tail; double kt_units; };
+inline sk_plan plan_stream_k(long tiles, int nk, int G, int mode) {  // mode: 0 = never, 1 = where it pays, 2 = wherever it applies (tests)
+  sk_plan pl;
+  pl.rounds = (int)(tiles / G), pl.tail = (int)(tiles % G), pl.S = 0, pl.parts = 1;
+  pl.kt_units = (double)((tiles + G - 1) / G) * nk;
+  if (!mode || pl.tail == 0 || pl.rounds == 0) return pl;
+  const int s = std::min(G / pl.tail, 4);
+  if (s < 2) return pl;
+  const int S = (nk + s - 1) / s;
+  const double t = (double)pl.rounds * nk + S + SK_FIXED;
+  if (S >= 2 && (mode == 2 || t < 0.97 * pl.kt_units)) pl.S = S, pl.parts = (nk + S - 1) / S, pl.kt_units = t;
+  return pl;
+}
+
+// The work list of a shape (see pp_work) and the fix-up's list of split tiles, built once and kept on the device.
+struct pp_table_key {
+  int dev, bm, tiles_m, tiles_n, nk, G, S;
+  bool operator<(const pp_table_key& o) const {
+    return std::tie(dev, bm, tiles_m, tiles_n, nk, G, S) < std::tie(o.dev, o.bm, o.tiles_m, o.tiles_n, o.nk, o.G, o.S);
+  }
+};
+struct pp_table_dev { i32x4_t* table; i32x4_t* fixups; int n_fixups, n_slots; };
+static std::map<pp_table_key, pp_table_dev> g_pp_tables;
+static std::mutex g_pp_mutex;
+
+inline bool stream_capturing(hipStream_t s) {
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  return hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
+}
+
+inline const pp_table_dev* pp_table(const pp_table_key& key, const sk_plan& pl, hipStream_t s) {
+  std::lock_guard<std::mutex> lk(g_pp_mutex);
+  auto it = g_pp_tables.find(key);
+  if (it != g_pp_tables.end()) return &it->second;
+  if (stream_capturing(s)) return nullptr;  // no allocation inside a capture: run the shape once before capturing
+  const int G = key.G, nk = key.nk, bm = key.bm, S = key.S;
+  const int tiles = key.tiles_m * key.tiles_n;
+  // tile L -> origin: bands of 8 tile rows, column-major inside a band (the last band may be shorter)
+  auto origin = [&](int L, int& m0, int& n0) {
+    const int per_band = 8 * key.tiles_n, band = L / per_band, in_band = L - band * per_band;
+    const int rows = std::min(8, key.tiles_m - band * 8);
+    m0 = (band * 8 + in_band % rows) * bm;
+    n0 = (in_band / rows) * P_BN;
+  };
+  const int n_dp_max = S ? pl.rounds : (tiles + G - 1) / G;
+  const int rows = 1 + n_dp_max + 1;
+  std::vector<i32x4_t> t((size_t)rows * G, i32x4_t{0, 0, 0, 0});
+  std::vector<i32x4_t> fix;
+  for (int w = 0; w < G; ++w) {
+    int n = 0, NT = 0;
+    auto push = [&](int L, int k0, int k1, int part) {
+      int m0, n0;
+      origin(L, m0, n0);
+      t[(size_t)(1 + n) * G + w] = i32x4_t{m0, n0, k0 | (k1 << 16), part};
+      ++n, NT += k1 - k0;
+    };
+    const int n_dp = S ? pl.rounds : (tiles - w + G - 1) / G;
+    for (int i = 0; i < n_dp; ++i) push(w + i * G, 0, nk, 0);
+    if (S && w < pl.tail * pl.parts) {  // part-major: neighbouring blocks hold the same K range of neighbouring tiles
+      const int j = w / pl.tail, a = w % pl.tail;
+      push(pl.rounds * G + a, j * S, std::min(nk, (j + 1) * S), 1 + a * pl.parts + j);  // slot: a tile's parts in K order
+    }
+    t[w] = i32x4_t{NT, n, 0, 0};
+  }
+  if (S)
+    for (int a = 0; a < pl.tail; ++a) {
+      int m0, n0;
+      origin(pl.rounds * G + a, m0, n0);
+      fix.push_back(i32x4_t{m0, n0, a * pl.parts, pl.parts});
+    }
+  pp_table_dev d{nullptr, nullptr, (int)fix.size(), S ? pl.tail * pl.parts : 0};
+  bool ok = hipMalloc((void**)&d.table, t.size() * sizeof(i32x4_t)) == hipSuccess &&
+            hipMemcpy(d.table, t.data(), t.size() * sizeof(i32x4_t), hipMemcpyHostToDevice) == hipSuccess;
+  if (ok && !fix.empty())
+    ok = hipMalloc((void**)&d.fixups, fix.size() * sizeof(i32x4_t)) == hipSuccess &&
+         hipMemcpy(d.fixups, fix.data(), fix.size() * sizeof(i32x4_t), hipMemcpyHostToDevice) == hipSuccess;
+  if (!ok) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return &(g_pp_tables[key] = d);
+}
+
+// workspace of the stream-K parts: one per (device, stream) — launches on one stream are ordered, launches on two streams may
+// overlap. G slots: a block holds at most one part.
+struct sk_workspace { int dev; hipStream_t stream; float* ws; };
+static sk_workspace g_sk_ws[16];
+static int g_sk_ws_n = 0;
+inline float* stream_k_workspace(hipStream_t s, int dev, int G) {
+  std::lock_guard<std::mutex> lk(g_pp_mutex);
+  for (int i = 0; i < g_sk_ws_n; ++i)
+    if (g_sk_ws[i].dev == dev && g_sk_ws[i].stream == s) return g_sk_ws[i].ws;
+  if (g_sk_ws_n == 16 || stream_capturing(s)) return nullptr;
+  sk_workspace w{dev, s, nullptr};
+  if (hipMalloc((void**)&w.ws, P_SLOT * G) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  g_sk_ws[g_sk_ws_n++] = w;
+  return w.ws;
+}
 
 template <int BM, bool GATHER, int ACT>
 int launch_pp_act(const grove_gemm_params& p, hipStream_t s) {
@@ -990,23 +1180,27 @@ int launch_pp_act(const grove_gemm_params& p, hipStream_t s) {
     hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<BM, GATHER, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  if (g_num_cus == 0) {
-    int dev = 0, n = 0;
-    hipGetDevice(&dev);
-    hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    g_num_cus = n > 0 ? n : 256;
-  }
-  const int tiles = tiles_m * tiles_n;
-  const int grid = tiles < g_num_cus ? tiles : g_num_cus;
-  GROVE_CHECK((long)tiles * 8 * tiles_n < (1L << 31), GROVE_E_SHAPE, "gemm: %d x %d tiles overflow the pipelined kernel's tile map", tiles_m, tiles_n);
+  const int G = num_cus(), nk = p.K / P_BK;
+  const long tiles = (long)tiles_m * tiles_n;
+  GROVE_CHECK(tiles < (1L << 24) && nk < 65536, GROVE_E_SHAPE, "gemm: %d x %d tiles x %d K tiles overflow the pipelined kernel's work list", tiles_m, tiles_n, nk);
   g_gemm_last_epilogue = ACT;
-  pp_tile_map tm;
-  tm.magic_band = (unsigned)((1ull << 32) / (unsigned)(8 * tiles_n)) + 1u;
-  tm.full_bands = tiles_m / 8;
-  tm.tail = tiles_m % 8;
-  tm.magic_tail = tm.tail > 1 ? (unsigned)((1ull << 32) / (unsigned)tm.tail) + 1u : 0u;  // tail 1 is special-cased in the kernel
-  hipLaunchKernelGGL((gemm_nt_pp_kernel<BM, GATHER, ACT>), dim3(grid, 1, 1), dim3(P_NT), lds, s, p, tiles_m, tiles_n, tm);
+  int dev = 0;
+  hipGetDevice(&dev);
+  pp_work work{nullptr, nullptr};
+  sk_plan pl = plan_stream_k(tiles, nk, G, g_gemm_stream_k);
+  if (pl.S && !(work.ws = stream_k_workspace(s, dev, G))) pl = plan_stream_k(tiles, nk, G, 0);
+  const int grid = pl.S ? G : (int)(tiles < G ? tiles : G);  // (the list is laid out for this grid: its row stride and wgid map)
+  const pp_table_dev* td = pp_table(pp_table_key{dev, BM, tiles_m, tiles_n, nk, grid, pl.S}, pl, s);
+  GROVE_CHECK(td != nullptr, GROVE_E_HIP, "gemm: no work list for %d x %d tiles (first use of a shape inside a stream capture, or out of memory)", tiles_m, tiles_n);
+  GROVE_CHECK(td->n_slots <= G, GROVE_E_WORKSPACE, "gemm: %d stream-K parts for %d slots", td->n_slots, G);
+  work.table = td->table;
+  g_gemm_last_stream_k = pl.S;
+  hipLaunchKernelGGL((gemm_nt_pp_kernel<BM, GATHER, ACT>), dim3(grid, 1, 1), dim3(P_NT), lds, s, p, work);
   GROVE_LAUNCH_CHECK();
+  if (td->n_fixups) {
+    hipLaunchKernelGGL((gemm_pp_fixup_kernel<BM, ACT>), dim3(td->n_fixups * (8 / FIX_WAVES), 1, 1), dim3(64 * FIX_WAVES), 0, s, p, (const i32x4_t*)td->fixups, (const float*)work.ws);
+    GROVE_LAUNCH_CHECK();
+  }
   return GROVE_OK;
 }
 // the gathered instances carry the epilogues their callers use (plain, scaled, ReLU: window (un)partition, Conv3d adapters)
@@ -1065,6 +1259,11 @@ extern "C" int grove_gemm_set_staging(int use_lds_dma) {
   return GROVE_OK;
 }
 
+extern "C" int grove_gemm_set_stream_k(int mode) {
+  g_gemm_stream_k = mode < 0 ? 0 : mode > 2 ? 2 : mode;
+  return GROVE_OK;
+}
+extern "C" int grove_gemm_last_stream_k(void) { return g_gemm_last_stream_k; }
 extern "C" int grove_gemm_last_variant(void) { return g_gemm_last_variant; }
 extern "C" int grove_gemm_last_epilogue(void) { return g_gemm_last_epilogue; }
 
@@ -1123,6 +1322,8 @@ extern "C" int grove_gemm_bf16(const grove_gemm_params* pp, void* stream) {
   const long tp256 = (long)((p.M + 255) / 256) * tn256, tp192 = (long)((p.M + 191) / 192) * tn256;
   auto pp_cost = [&](long tiles, double kt, double fixed) {
     const double r = rounds(tiles, 256);
+    const sk_plan pl = plan_stream_k(tiles, p.K / 64, 256, bk64 ? g_gemm_stream_k : 0);
+    if (pl.S) return pl.kt_units * kt + r * fixed;  // the tail is dealt out by K tiles: every CU busy for the same time
     const double fill = (double)tiles / (r * 256.0);
     return r * (nk64 * kt * (0.6 + 0.4 * fill) + fixed);
   };

@@ -117,6 +117,13 @@ int grove_gemm_last_variant(void);
 /* The epilogue compiled into the pipelined kernel of the last call — its third template argument, as profilers print it:
  * -1 = plain (act NONE, alpha 1, no scale), else the enum grove_act value. Meaningless after a non-pipelined launch. */
 int grove_gemm_last_epilogue(void);
+/* Stream-K tail of the pipelined kernels. When the output tiles do not fill a last round of the persistent grid (at most half
+ * of the CUs would work), that round's tiles are cut into 2..4 equal K ranges, one block each; the raw fp32 parts go through a
+ * per-stream workspace and a fix-up launch sums them in K order and runs the epilogue (deterministic). mode 1 (default) =
+ * where the cost model says it pays, 0 = never (whole tiles only), 2 = wherever it applies (tests).
+ * grove_gemm_last_stream_k: K tiles per part of the last pipelined launch, 0 = it ran whole tiles only. */
+int grove_gemm_set_stream_k(int mode);
+int grove_gemm_last_stream_k(void);
 /* A/B staging variant: 1 = LDS-DMA (global_load_lds, default), 0 = register staged */
 int grove_gemm_set_staging(int use_lds_dma);
 /* macro-tile N: 0 = auto (by wave quantisation), 64 or 128 = forced (for A/B measurements) */

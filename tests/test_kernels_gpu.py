@@ -162,9 +162,117 @@ def test_step_shapes_dispatch_matches_simple_kernel(dev, M, N, K):
         out = torch.full((M, N), float("nan"), dtype=bf16, device=dev)
         ops.linear(a, b, bias, residual=res, out=out)
         assert L.grove_gemm_last_variant() in (4, 5), "these shapes belong to the pipelined kernels"
+        if L.grove_gemm_last_stream_k():  # a split K sum rounds differently: bit-exact with whole tiles, within bf16 rounding as dispatched
+            close(out, ref, 2 ** -7, "stream-K dispatch")
+            L.grove_gemm_set_stream_k(0)
+            out = torch.full((M, N), float("nan"), dtype=bf16, device=dev)
+            ops.linear(a, b, bias, residual=res, out=out)
         assert torch.equal(out, ref)
     finally:
         L.grove_gemm_set_tile_m(0)
+        L.grove_gemm_set_stream_k(1)
+
+
+@pytest.mark.parametrize("tile_m,M", [(256, 20200), (193, 15350)])
+def test_gemm_stream_k_tail(dev, tile_m, M):
+    """Stream-K tail of the pipelined kernels (one whole round + 60 / 64 tiles cut into four K ranges): every epilogue family
+    through the fix-up launch — plain bias + residual, GELU with aux and a tanh'd scale, the SwiGLU pair, scattered fp32 rows
+    (c_idx / r_idx), padded-head output columns (n_map) — against the same launch with whole tiles (bf16 rounding of a
+    different fp32 sum order) and against fp32. The outputs start as NaN: a tile nobody finished shows."""
+    from grove_amd import _lib, ops
+    L = _lib.lib()
+    N, K = 1000, 2560
+    g = torch.Generator().manual_seed(M)
+    a = (torch.randn(M, K, generator=g) * 0.5).to(bf16).to(dev)
+    b = (torch.randn(N, K, generator=g) * 0.05).to(bf16).to(dev)
+    bias = torch.randn(N, generator=g).to(bf16).to(dev)
+    res = torch.randn(M, N, generator=g).to(bf16).to(dev)
+    perm = torch.randperm(M, generator=g).to(torch.int32).to(dev)
+    sc = torch.tensor([0.7]).to(dev)
+    rows = slice(M - 1500, M)  # the last rows: tiles of the split round
+
+    def run(**kw):
+        outs = []
+        for mode in (0, 1):
+            L.grove_gemm_set_stream_k(mode)
+            kw2 = dict(kw)
+            if "aux" in kw2:
+                kw2["aux"] = torch.full_like(kw2["aux"], float("nan"))
+            if "out" in kw2:
+                kw2["out"] = torch.full_like(kw2["out"], float("nan"))
+            w = kw2.pop("w", b)
+            o = ops.linear(a, w, kw2.pop("bias", bias), **kw2)
+            assert L.grove_gemm_last_variant() == (4 if tile_m == 256 else 5)
+            assert (L.grove_gemm_last_stream_k() > 0) == (mode == 1), "the split must engage exactly when it is on"
+            outs.append((o, kw2.get("aux")))
+        return outs
+
+    try:
+        L.grove_gemm_set_tile_m(tile_m)
+        pre = a[rows].float() @ b.float().t() + bias.float()
+        # plain
+        (o0, _), (o1, _) = run(residual=res)
+        close(o1, o0, 2 ** -7, "plain: split vs whole")
+        close(o1[rows], pre + res[rows].float(), 2 ** -7, "plain vs fp32")
+        # GELU, aux = pre-activation, tanh'd scale
+        (o0, x0), (o1, x1) = run(act=ops.ACT_GELU, aux=torch.empty(M, N, dtype=bf16, device=dev), scale_ptr=sc, scale_tanh=True)
+        close(o1, o0, 2 ** -7, "gelu: split vs whole")
+        close(x1, x0, 2 ** -7, "gelu aux: split vs whole")
+        close(o1[rows], torch.nn.functional.gelu(pre) * torch.tanh(sc.float()), 2 ** -6, "gelu vs fp32")
+        # SwiGLU pair: gate / up rows interleaved in groups of four
+        Np = 1024
+        wg, wu = (torch.randn(Np // 2, K, generator=g) * 0.05).to(bf16), (torch.randn(Np // 2, K, generator=g) * 0.05).to(bf16)
+        wp = torch.stack([wg.view(-1, 4, K), wu.view(-1, 4, K)], 1).reshape(Np, K).to(dev)
+        (o0, _), (o1, _) = run(w=wp, bias=None, act=ops.ACT_SWIGLU_PAIR)
+        close(o1, o0, 2 ** -7, "swiglu pair: split vs whole")
+        gate, up = a[rows].float() @ wg.float().t().to(dev), a[rows].float() @ wu.float().t().to(dev)
+        close(o1[rows], torch.nn.functional.silu(gate) * up, 2 ** -6, "swiglu pair vs fp32")
+        # scattered fp32 rows: the wide epilogue
+        (o0, _), (o1, _) = run(out=torch.empty(M, N, dtype=torch.float32, device=dev), c_idx=perm, r_idx=perm, residual=res)
+        close(o1, o0, 1e-5, "scattered fp32: split vs whole")
+        full = torch.zeros(M, N, device=dev)
+        full[perm[rows].long()] = pre + res[perm[rows].long()].float()
+        close(o1[perm[rows].long()], full[perm[rows].long()], 1e-4, "scattered fp32 vs fp32")
+        # padded-head output columns: groups of 40 columns padded by 8
+        (o0, _), (o1, _) = run(n_map=(40, 8), out=torch.empty(M, N // 40 * 48, dtype=bf16, device=dev))
+        close(o1, o0, 2 ** -7, "n_map: split vs whole")
+        close(o1.view(M, -1, 48)[rows, :, :40].reshape(-1, N), pre, 2 ** -7, "n_map vs fp32")
+        assert (o1.view(M, -1, 48)[:, :, 40:] == 0).all(), "n_map pad columns"
+    finally:
+        L.grove_gemm_set_tile_m(0)
+        L.grove_gemm_set_stream_k(1)
+
+
+def test_gemm_stream_k_gathered_taps(dev):
+    """The gathered-A instances under the stream-K tail: a K range that starts inside the tap list (27-tap Conv3d rows, -1 = zero
+    row; 2 K tiles per tap, parts of 14 K tiles) with the ReLU + residual + tanh'd scale epilogue the adapters use."""
+    from grove_amd import _lib, ops
+    from grove_amd.model.indexing import conv3d_gather_index
+    L = _lib.lib()
+    G, T, H, W, Ci, Co = 2, 8, 32, 40, 128, 1024
+    M = G * T * H * W  # 20480 rows: 80 x 4 tiles of 256 = one round + 64
+    x, w, bias = rnd(M, Ci, seed=21).to(dev), rnd(Co, 27 * Ci, seed=22, scale=0.03).to(dev), rnd(Co, seed=23).to(dev)
+    res = rnd(M, Co, seed=24).to(dev)
+    idx = conv3d_gather_index(G, T, H, W).to(dev)
+    kw = dict(act=ops.ACT_RELU, residual=res, scale_ptr=torch.tensor([0.3]).to(dev), scale_tanh=True, a_idx=idx, a_taps=27, M=M)
+    try:
+        for tile_m, variant in ((256, 6), (193, 7)):
+            L.grove_gemm_set_tile_m(tile_m)
+            outs = []
+            for mode in (0, 2):  # (2: the 192-row tiling leaves 108 x 4 = 432 tiles = 1 round + 176: no split there)
+                L.grove_gemm_set_stream_k(mode)
+                outs.append(ops.linear(x, w, bias, **kw))
+                assert L.grove_gemm_last_variant() == variant
+                if tile_m == 256:
+                    assert (L.grove_gemm_last_stream_k() > 0) == (mode == 2)
+            close(outs[1], outs[0], 2 ** -7, f"gathered taps, tile {tile_m}: split vs whole")
+        L.grove_gemm_set_tile_m(128)
+        L.grove_gemm_set_stream_k(1)
+        ref = ops.linear(x, w, bias, **kw)
+        close(outs[1], ref, 2 ** -7, "gathered taps vs the two-barrier kernel")
+    finally:
+        L.grove_gemm_set_tile_m(0)
+        L.grove_gemm_set_stream_k(1)
 
 
 def test_gemm_accumulate_and_alpha(dev):
