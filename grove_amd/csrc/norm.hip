@@ -257,6 +257,97 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const grove_norm_bwd_para
   }
 }
 
+// The backward of a FROZEN norm (no dweight): one row per wave, a pure stream. The row operands stay PACKED (bf16 pairs as
+// loaded) and are unpacked where they are used, twice: 3 x 4 x MAXCH registers instead of 3 x 8 x MAXCH floats. The float
+// form needed 276 registers at C = 4096 — one wave per SIMD, so the 2812 rows of a LLaMA norm went through the chip in three
+// latency-bound rounds (50 us for 69 MB). The arithmetic and its order are those of norm_bwd_kernel.
+template <bool RMS, int MAXCH>
+__global__ __launch_bounds__(256) void norm_bwd_stream_kernel(const grove_norm_bwd_params p) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= p.rows) return;
+  const int nch = p.C >> 3;
+  int drow = row;
+  if (p.in_idx) drow = p.in_idx[row];  // (in flight beside the x / weight loads; only the dy loads wait for it)
+  const bf16_raw* xr = (const bf16_raw*)p.x + (int64_t)row * p.ld_x;
+  const bf16_raw* wr = (const bf16_raw*)p.weight;
+  const u32x4_t zero = u32x4_t{0u, 0u, 0u, 0u};
+  u32x4_t xp[MAXCH], gp[MAXCH], wp[MAXCH];
+#pragma unroll
+  for (int i = 0; i < MAXCH; ++i) {
+    const int ch = lane + i * 64;
+    xp[i] = ch < nch ? *(const u32x4_t*)(xr + ch * 8) : zero;
+    wp[i] = ch < nch ? *(const u32x4_t*)(wr + ch * 8) : zero;
+  }
+  float mean = 0.f, rstd = 0.f;
+  if constexpr (!RMS) {
+    mean = p.mean[row];
+    rstd = p.rstd[row];
+  }
+  const bf16_raw* dyr = (const bf16_raw*)p.dy + (int64_t)max(drow, 0) * p.ld_dy;
+#pragma unroll
+  for (int i = 0; i < MAXCH; ++i) {
+    const int ch = lane + i * 64;
+    gp[i] = (ch < nch && drow >= 0) ? *(const u32x4_t*)(dyr + ch * 8) : zero;
+  }
+  auto elem = [](const u32x4_t& u, int e) {
+    const unsigned w = e < 2 ? u.x : e < 4 ? u.y : e < 6 ? u.z : u.w;
+    return (e & 1) ? bf_hi(w) : bf_lo(w);
+  };
+  if constexpr (RMS) {
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float x = elem(xp[i], e);
+        ss += x * x;
+      }
+    rstd = rsqrtf(wave_sum(ss) / (float)p.C + p.eps);
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) asm volatile("" : "+v"(xp[i]));
+  }
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXCH; ++i) {
+    if (lane + i * 64 < nch) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xh = (elem(xp[i], e) - mean) * rstd;
+        const float g = elem(gp[i], e) * elem(wp[i], e);
+        s1 += g;
+        s2 += g * xh;
+      }
+    }
+  }
+  s2 = wave_sum(s2) / (float)p.C;
+  if constexpr (RMS) s1 = 0.f;
+  else s1 = wave_sum(s1) / (float)p.C;
+  // (opaque to the optimizer from here on: otherwise it keeps the unpacked xh / g of the first pass alive for the second)
+#pragma unroll
+  for (int i = 0; i < MAXCH; ++i) asm volatile("" : "+v"(xp[i]), "+v"(gp[i]), "+v"(wp[i]));
+  bf16_raw* dx = (bf16_raw*)p.dx + (int64_t)row * p.ld_dx;
+#pragma unroll
+  for (int i = 0; i < MAXCH; ++i) {
+    const int ch = lane + i * 64;
+    if (ch < nch) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xh = (elem(xp[i], e) - mean) * rstd;
+        const float g = elem(gp[i], e) * elem(wp[i], e);
+        o[e] = rstd * (g - s1 - xh * s2);
+      }
+      if (p.accumulate) {
+        const u32x4_t u = *(const u32x4_t*)(dx + ch * 8);
+        o[0] += bf_lo(u.x); o[1] += bf_hi(u.x); o[2] += bf_lo(u.y); o[3] += bf_hi(u.y);
+        o[4] += bf_lo(u.z); o[5] += bf_hi(u.z); o[6] += bf_lo(u.w); o[7] += bf_hi(u.w);
+      }
+      store_chunk_bf16(dx + ch * 8, o);
+    }
+  }
+}
+
 int check_fwd(const grove_norm_params* p, const char* name) {
   GROVE_CHECK(p && p->rows > 0 && p->C > 0, GROVE_E_SHAPE, "%s: bad shape", name);
   GROVE_CHECK(p->C % 8 == 0 && p->C <= MAXCH_ALL * 512, GROVE_E_SHAPE, "%s: C=%d must be a multiple of 8 and <= %d", name, p->C, MAXCH_ALL * 512);
@@ -320,7 +411,17 @@ static int norm_bwd_launch(const grove_norm_bwd_params* p, bool rms, void* strea
     else if (p->C <= 1024) NB(RMS, 2, DW); \
     else NB(RMS, 4, DW);              \
   } while (0)
-  if (p->C > 2048) {
+#define NBS(RMS, NCH) hipLaunchKernelGGL((norm_bwd_stream_kernel<RMS, NCH>), grid, dim3(256), 0, s_, *p)
+#define NBS_C(RMS)                     \
+  do {                                 \
+    if (p->C <= 512) NBS(RMS, 1);      \
+    else if (p->C <= 1024) NBS(RMS, 2); \
+    else if (p->C <= 2048) NBS(RMS, 4); \
+    else NBS(RMS, 8);                  \
+  } while (0)
+  if (!dw) {
+    if (rms) NBS_C(true); else NBS_C(false);
+  } else if (p->C > 2048) {
     if (rms) NB(true, 8, false); else NB(false, 8, false);
   } else if (rms) {
     if (dw) NB_C(true, true); else NB_C(true, false);
