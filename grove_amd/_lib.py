@@ -64,6 +64,11 @@ class RelposParams(C.Structure):
                 ("hd", c_i32), ("hd_stride", c_i32), ("ld_q", c_i32)]
 
 
+
+class RelBiasParams(C.Structure):
+    _fields_ = [("q", c_vp), ("table", c_vp), ("rel", c_vp), ("dq", c_vp),
+                ("nb", c_i32), ("nh", c_i32), ("L", c_i32), ("hp", c_i32), ("hd", c_i32), ("rel_ld", c_i32), ("ld_q", c_i32), ("ld_dq", c_i32)]
+
 class RopeParams(C.Structure):
     _fields_ = [("x", c_vp), ("pos", c_vp), ("rows", c_i32), ("ld", c_i32), ("col0", c_i32), ("nheads", c_i32),
                 ("hd", c_i32), ("inverse", c_i32), ("theta", c_f32)]
@@ -142,7 +147,7 @@ class GemmFp8Params(C.Structure):
 STRUCTS = {
     "grove_gemm_params": GemmParams, "grove_transpose_params": TransposeParams, "grove_norm_params": NormParams,
     "grove_norm_bwd_params": NormBwdParams, "grove_softmax_params": SoftmaxParams,
-    "grove_softmax_bwd_params": SoftmaxBwdParams, "grove_relpos_params": RelposParams, "grove_rope_params": RopeParams,
+    "grove_softmax_bwd_params": SoftmaxBwdParams, "grove_relpos_params": RelposParams, "grove_rel_bias_params": RelBiasParams, "grove_rope_params": RopeParams,
     "grove_rows_params": RowsParams, "grove_small_attn_params": SmallAttnParams, "grove_box_head_params": BoxHeadParams,
     "grove_box_head_bwd_params": BoxHeadBwdParams, "grove_flash_attn_params": FlashAttnParams,
     "grove_gemm_tn_params": GemmTnParams, "grove_gemv_params": GemvParams, "grove_decode_attn_params": DecodeAttnParams, "grove_resample_params": ResampleParams,
@@ -153,7 +158,7 @@ STRUCTS = {
 SYMBOLS = [
     "grove_version", "grove_last_error", "grove_sizeof", "grove_gemm_bf16", "grove_gemm_last_variant", "grove_gemm_last_epilogue", "grove_gemm_set_staging", "grove_gemm_set_stream_k", "grove_gemm_last_stream_k", "grove_gemm_set_tile_n", "grove_gemm_set_tile_m", "grove_gemm_set_bk", "grove_gemm_tn_bf16", "grove_gemm_tn_set_pipelined", "grove_gemv_bf16", "grove_decode_attn", "grove_resample_u8", "grove_normalize_pack",
     "grove_transpose_bf16", "grove_layernorm_fwd", "grove_rmsnorm_fwd", "grove_layernorm_bwd", "grove_rmsnorm_bwd",
-    "grove_flash_attn_fwd", "grove_flash_attn_bwd", "grove_flash_attn_set_window_kernels", "grove_softmax_fwd", "grove_softmax_bwd", "grove_relpos_fwd", "grove_relpos_bwd", "grove_rope_inplace",
+    "grove_flash_attn_fwd", "grove_flash_attn_bwd", "grove_flash_attn_set_window_kernels", "grove_softmax_fwd", "grove_softmax_bwd", "grove_relpos_fwd", "grove_relpos_bwd", "grove_rel_bias_fwd", "grove_rel_bias_bwd", "grove_rope_inplace",
     "grove_swiglu_fwd", "grove_swiglu_bwd", "grove_act_bwd", "grove_act_fwd", "grove_resize_bilinear_f32", "grove_add_bf16", "grove_add_bcast_rows",
     "grove_copy_rows", "grove_dot_bf16", "grove_axpy_f32", "grove_scatter_add_f32", "grove_colsum_f32", "grove_cast_f32_to_bf16", "grove_cast_bf16_to_f32",
     "grove_im2col_patch", "grove_clip_pool", "grove_cross_entropy", "grove_small_attn_fwd", "grove_small_attn_bwd", "grove_gemm_f32", "grove_gemm_fp8", "grove_quant_fp8_rows",

@@ -32,6 +32,7 @@ extern "C" int grove_sizeof(const char* name) {
   SZ(grove_softmax_params);
   SZ(grove_softmax_bwd_params);
   SZ(grove_relpos_params);
+  SZ(grove_rel_bias_params);
   SZ(grove_rope_params);
   SZ(grove_rows_params);
   SZ(grove_small_attn_params);

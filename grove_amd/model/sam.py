@@ -182,9 +182,12 @@ class SamEncoder:
         ld = qkv.stride(0)
         rel_ld = Bk["rel_ld"]
         hrow = self._head_rows(nb, L)
-        rel = torch.empty((nb * nh, L, rel_ld), dtype=torch.bfloat16, device=self.dev)
-        ops.gemm_raw(qkv, Bk["Rcat"], rel, nb * nh, rel_ld, hp, hp, hp, L * rel_ld, a_idx=hrow, batch=(L, 1),
-                     sA=(ld, 0), sB=(rel_ld * hp, 0), sC=(rel_ld, 0))
+        if ops.rel_bias_applicable(nh, hp, rel_ld):
+            rel = ops.rel_bias_fwd(qkv, Bk["Rcat"], nb, nh, L, hp, hd)
+        else:
+            rel = torch.empty((nb * nh, L, rel_ld), dtype=torch.bfloat16, device=self.dev)
+            ops.gemm_raw(qkv, Bk["Rcat"], rel, nb * nh, rel_ld, hp, hp, hp, L * rel_ld, a_idx=hrow, batch=(L, 1),
+                         sA=(ld, 0), sB=(rel_ld * hp, 0), sC=(rel_ld, 0))
         o, actx = attention_fwd(qkv, nb, L, nh, hp, 0, nh * hp, 2 * nh * hp, hd ** -0.5, rel=rel, rel_hw=(Bk["khp"], qhw[1]), save=save, hs_valid=hd)
         del rel
         r1 = None if f32 else x  # bf16 stream: x1 = x + proj(...) in the GEMM epilogue
@@ -328,9 +331,12 @@ class SamEncoder:
             drel = attention_bwd(c["actx"], qkv, do, dqkv, want_drel=True)
             # dq[(b q), h, :] += d rel'[(b h), q, :] . R_cat[q]  (one GEMM batched over q, accumulating in place)
             L, rel_ld, ldd = c["L"], Bk["rel_ld"], dqkv.stride(0)
-            hrow = self._head_rows(c["nb"], L)
-            ops.gemm_raw(drel, Bk["RcatT"], dqkv, c["nb"] * nh, hp, rel_ld, L * rel_ld, rel_ld, hp, c_idx=hrow, residual=dqkv, ldr=hp,
-                         batch=(L, 1), sA=(rel_ld, 0), sB=(hp * rel_ld, 0), sC=(ldd, 0), sR=(ldd, 0))
+            if ops.rel_bias_applicable(nh, hp, rel_ld):
+                ops.rel_bias_bwd(drel, Bk["RcatT"], dqkv, c["nb"], nh, L, hp, self.hd)
+            else:
+                hrow = self._head_rows(c["nb"], L)
+                ops.gemm_raw(drel, Bk["RcatT"], dqkv, c["nb"] * nh, hp, rel_ld, L * rel_ld, rel_ld, hp, c_idx=hrow, residual=dqkv, ldr=hp,
+                             batch=(L, 1), sA=(rel_ld, 0), sB=(hp * rel_ld, 0), sC=(ldd, 0), sR=(ldd, 0))
             if ws > 0:  # only the real tokens' rows of d qkv feed norm1
                 if Bk["maps"]:
                     dh = ops.linear(dqkv, Bk["wqkv_c_t"], a_idx=tok2win, a_taps=1, M=dx.shape[0], k_map=(hd, hp - hd))

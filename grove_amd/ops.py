@@ -5,6 +5,7 @@ hand-written gfx950 kernels in grove_amd/csrc. Nothing in this module falls back
 Tensors are bf16 unless stated; every function launches on torch's current stream.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -353,6 +354,40 @@ def flash_attn_bwd(qkv, out, d_out, lse, dqkv, B, L, H, hs, q_off, k_off, v_off,
     p.hs_valid = hs_valid
     _lib.check(_lib.lib().grove_flash_attn_bwd(C.byref(p), _stream()), "grove_flash_attn_bwd")
     return drel
+
+
+def rel_bias_applicable(nh, hp, rel_ld):
+    """Shapes the matrix-core rel-pos streams take (grove_rel_bias_*); others go through the batched GEMM."""
+    if os.environ.get("GROVE_REL_BIAS_STREAMS", "1") == "0":  # A/B arm of whole-program runs: the batched GEMMs
+        return False
+    return nh <= 16 and hp % 32 == 0 and hp <= 128 and rel_ld in (32, 64)
+
+
+def rel_bias_fwd(q, rcat, nb, nh, L, hp, hd, *, out=None):
+    """rel'[(b h), q, :] = q[(b q), h, :] . rcat[q]^T: q bf16 [nb*L, ld] with head h at column h*hp, rcat bf16 [L, rel_ld, hp]."""
+    _chk_dev(q, rcat)
+    rel_ld = rcat.shape[1]
+    assert rcat.shape == (L, rel_ld, hp) and rcat.is_contiguous() and q.stride(1) == 1
+    if out is None:
+        out = torch.empty((nb * nh, L, rel_ld), dtype=bf16, device=q.device)
+    p = _lib.RelBiasParams()
+    p.q, p.table, p.rel, p.dq = _p(q), _p(rcat), _p(out), None
+    p.nb, p.nh, p.L, p.hp, p.hd, p.rel_ld, p.ld_q, p.ld_dq = nb, nh, L, hp, hd, rel_ld, q.stride(0), 0
+    _lib.check(_lib.lib().grove_rel_bias_fwd(C.byref(p), _stream()), "grove_rel_bias_fwd")
+    return out
+
+
+def rel_bias_bwd(drel, rcat_t, dq, nb, nh, L, hp, hd):
+    """dq[(b q), h, :] += d rel'[(b h), q, :] . rcat[q] in place: rcat_t bf16 [L, hp, rel_ld], dq bf16 [nb*L, ld]."""
+    _chk_dev(drel, rcat_t, dq)
+    rel_ld = rcat_t.shape[2]
+    assert rcat_t.shape == (L, hp, rel_ld) and rcat_t.is_contiguous() and drel.is_contiguous() and dq.stride(1) == 1
+    assert drel.shape == (nb * nh, L, rel_ld)
+    p = _lib.RelBiasParams()
+    p.q, p.table, p.rel, p.dq = None, _p(rcat_t), _p(drel), _p(dq)
+    p.nb, p.nh, p.L, p.hp, p.hd, p.rel_ld, p.ld_q, p.ld_dq = nb, nh, L, hp, hd, rel_ld, 0, dq.stride(0)
+    _lib.check(_lib.lib().grove_rel_bias_bwd(C.byref(p), _stream()), "grove_rel_bias_bwd")
+    return dq
 
 
 def relpos(q, Rh, Rw, batch, heads, qhw, khw, hd, hd_stride, ld_q, *, rel=None, dq=None, backward=False):

@@ -309,6 +309,22 @@ typedef struct grove_relpos_params {
 int grove_relpos_fwd(const grove_relpos_params* p, void* stream);
 int grove_relpos_bwd(const grove_relpos_params* p, void* stream);
 
+/* The same terms in the form the fused attention kernels consume, as two streams on the matrix cores (rel_bias.hip):
+ *   fwd  rel[(b*nh + h), q, bin] = sum_d q[(b*L + q), h*hp + d] * table[q][bin][d]        table = Rcat  bf16 [L, rel_ld, hp]
+ *   bwd  dq[(b*L + q), h*hp + d] += sum_bin rel[(b*nh + h), q, bin] * table[q][d][bin]    table = RcatT bf16 [L, hp, rel_ld]
+ * bins = [rel_h | rel_w] padded to rel_ld (32 or 64), tables pre-divided by the softmax scale and zero in the pad bins and in
+ * the pad dims hd..hp-1 (sam.py:_rcat_tables). q / dq: bf16 rows, head h at column h*hp (hp % 32 == 0, <= 128), nh <= 16.
+ * Replaces the two GEMMs batched over the L query positions (4608 x 32 x 96 per position at SAM-H window size). */
+typedef struct grove_rel_bias_params {
+  const void* q;     /* fwd: bf16 [nb*L, ld_q] */
+  const void* table; /* fwd: Rcat; bwd: RcatT */
+  void* rel;         /* bf16 [nb*nh, L, rel_ld]: fwd out; bwd: d rel in */
+  void* dq;          /* bwd: bf16 [nb*L, ld_dq], accumulated in place */
+  int32_t nb, nh, L, hp, hd, rel_ld, ld_q, ld_dq;
+} grove_rel_bias_params;
+int grove_rel_bias_fwd(const grove_rel_bias_params* p, void* stream);
+int grove_rel_bias_bwd(const grove_rel_bias_params* p, void* stream);
+
 /* Rotary embedding, HF rotate_half convention, applied in place to q and k heads inside a fused
  * qkv activation: x: bf16 [rows, ld]; row r has position pos[r]; heads at columns
  * col0 + h*hd for h < nheads. inverse=1 applies the transpose rotation (backward).

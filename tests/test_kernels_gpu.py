@@ -1117,3 +1117,47 @@ def test_fp8_linear_quantised(dev, M, N, K, act):
     full = (torch.nn.functional.gelu(full) if act else full) + res.float()
     err = ((y.float().cpu() - full).pow(2).mean().sqrt() / full.pow(2).mean().sqrt()).item()
     assert err < 6e-2, f"fp8 quantisation error {err}"
+
+
+@pytest.mark.parametrize("nb,nh,size,hd,hp", [(18, 16, 14, 80, 96), (3, 16, 32, 80, 96), (5, 4, 6, 32, 32), (7, 12, 14, 64, 64)])
+def test_rel_bias_streams(dev, nb, nh, size, hd, hp):
+    """The matrix-core rel-pos streams (grove_rel_bias_fwd / _bwd) against fp32 and against the GEMM batched over the query
+    positions they replace: SAM-H window (14 x 14, hd 80 padded to 96, 32 bins) and global (32 x 32, 64 bins) shapes, fewer
+    than 16 heads, window counts that are not a multiple of the per-wave chunk. The backward accumulates into dq in place and
+    must leave the pad dims hd..hp-1 and the k | v columns of the fused buffer untouched."""
+    from grove_amd import ops
+    from grove_amd.model.sam import _rcat_tables
+    L = size * size
+    g = torch.Generator().manual_seed(nb * 1000 + size)
+    rel_h = (torch.randn(2 * size - 1, hd, generator=g) * 0.5).to(bf16).to(dev)
+    rel_w = (torch.randn(2 * size - 1, hd, generator=g) * 0.5).to(bf16).to(dev)
+    rcat, rcat_t, khp, rel_ld = _rcat_tables(size, rel_h, rel_w, hd, hp, hd ** -0.5)
+    assert ops.rel_bias_applicable(nh, hp, rel_ld)
+    ld = 3 * nh * hp
+    qkv = (torch.randn(nb * L, ld, generator=g) * 0.5).to(bf16).to(dev)
+    qkv.view(nb * L, 3 * nh, hp)[:, :, hd:] = 0  # pad dims: zero, as the qkv GEMM writes them
+    hrow = (torch.arange(nb, dtype=torch.int32)[:, None] * (L * (ld // hp)) + torch.arange(nh, dtype=torch.int32)[None, :]).reshape(-1).to(dev)
+    # forward
+    rel = ops.rel_bias_fwd(qkv, rcat, nb, nh, L, hp, hd)
+    ref_g = torch.empty((nb * nh, L, rel_ld), dtype=bf16, device=dev)
+    ops.gemm_raw(qkv, rcat, ref_g, nb * nh, rel_ld, hp, hp, hp, L * rel_ld, a_idx=hrow, batch=(L, 1), sA=(ld, 0), sB=(rel_ld * hp, 0), sC=(rel_ld, 0))
+    q4 = qkv.view(nb, L, 3 * nh, hp)[:, :, :nh].float()                      # [nb, L, nh, hp]
+    ref = torch.einsum("bqhd,qnd->bhqn", q4, rcat.float()).reshape(nb * nh, L, rel_ld)
+    close(rel, ref, 2 ** -7, "rel' vs fp32")
+    assert (rel.float() - ref_g.float()).abs().max().item() <= 2 ** -7 * ref.abs().max().item(), "rel' vs the batched GEMM"
+    # backward
+    drel = (torch.randn(nb * nh, L, rel_ld, generator=g) * 0.3).to(bf16).to(dev)
+    dq0 = (torch.randn(nb * L, ld, generator=g) * 0.5).to(bf16).to(dev)
+    dq = dq0.clone()
+    ops.rel_bias_bwd(drel, rcat_t, dq, nb, nh, L, hp, hd)
+    dq_g = dq0.clone()
+    ops.gemm_raw(drel, rcat_t, dq_g, nb * nh, hp, rel_ld, L * rel_ld, rel_ld, hp, c_idx=hrow, residual=dq_g, ldr=hp,
+                 batch=(L, 1), sA=(rel_ld, 0), sB=(hp * rel_ld, 0), sC=(ld, 0), sR=(ld, 0))
+    add = torch.einsum("bhqn,qdn->bqhd", drel.float().view(nb, nh, L, rel_ld), rcat_t.float())  # [nb, L, nh, hp]
+    want = dq0.float().view(nb, L, 3 * nh, hp).clone()
+    want[:, :, :nh] += add
+    close(dq, want.view(nb * L, ld), 2 ** -7, "dq += d rel' . Rcat vs fp32")
+    assert (dq.float() - dq_g.float()).abs().max().item() <= 2 ** -7 * want.abs().max().item(), "dq vs the batched GEMM"
+    untouched = torch.ones(3 * nh, hp, dtype=torch.bool)
+    untouched[:nh, :hd] = False
+    assert torch.equal(dq.view(nb * L, 3 * nh, hp)[:, untouched.to(dev)], dq0.view(nb * L, 3 * nh, hp)[:, untouched.to(dev)]), "columns outside q[:hd]"
