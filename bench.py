@@ -466,7 +466,7 @@ def main():
     all_n, all_f, all_s = (sum(v[i] for v in per_kernel.values()) for i in range(3))
     traffic = None
     try:  # memory-side bytes per launch from the committed PMC passes (profiles/, collected as the microarch guide prescribes)
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_gemm_traffic.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_gemm_traffic.json")) as fh:
             traffic = json.load(fh)["launch_weighted_mean_bytes"].get(dom[dom.index("<"):dom.index(",")] + ">")
     except Exception:
         pass
