@@ -371,7 +371,7 @@ def infer_bench(args, dev, dims):
         fl = sum(f for _, _, f in rec)
         secs = sum(e0.elapsed_time(e1) for e0, e1, _ in rec) * 1e-3
         line["roofline"] = {"bound": "mfma", "achieved": round(fl / secs / 1e12, 2), "peak": 5000.0, "unit": "TFLOP/s", "frac": round(fl / secs / 1e12 / 5000.0, 4),
-                            "traffic": None, "kernel": "gemm_fp8_kernel (grove_gemm_fp8; launch + its activation quantisation)", "launches_per_step": len(rec),
+                            "traffic": None, "kernel": "gemm_nt_pp_kernel<.., FP8> (grove_gemm_fp8: the e4m3 instances of the pipelined kernel; launch + its activation quantisation)", "launches_per_step": len(rec),
                             "flops_per_step": fl}
     return line
 

@@ -17,6 +17,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include <string.h>
 #include <algorithm>
 #include <map>
 #include <mutex>
@@ -737,12 +738,46 @@ __device__ __forceinline__ i32x4_t sload4(const void* p) {  // 4 consecutive int
 struct pp_work {
   const i32x4_t* table;
   float* ws;  // slots of 8 waves x 32 accumulators x 64 lanes x 16 B (lane-linear: the fix-up's same wave reads them with the same map)
+  const float* row_scale;  // FP8 instances: de-quantisation scales of the activation rows [M] and of the weight rows [N]
+  const float* col_scale;
 };
 constexpr size_t P_SLOT = (size_t)8 * 32 * 64 * 16;
 
+// FP8 instances: the accumulators hold sums of products of e4m3 CODES; times row_scale[m] * col_scale[n] they are the product
+// the epilogue expects (same map as the epilogues: row fragment i of A half h, column group g, 8 consecutive columns).
+template <int MIH, int BMH>
+__device__ __forceinline__ void fp8_scale_acc(const grove_gemm_params& p, const pp_work& work, f32x4_t (&acc)[2 * MIH][4], const int mw0,
+                                              const int nw0, const int fr, const int fq) {
+  float cs[2][8];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const int n = min(nw0 + g * 128 + fq * 8, p.N - 8);  // (N % 8 == 0: a column group is whole or absent)
+    const f32x4_t c0 = *(const f32x4_t*)(work.col_scale + n), c1 = *(const f32x4_t*)(work.col_scale + n + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) cs[g][e] = c0[e], cs[g][4 + e] = c1[e];
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < MIH; ++i) {
+      const float rs = work.row_scale[min(mw0 + h * BMH + i * 16 + fr, p.M - 1)];
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc[h * MIH + i][2 * g][e] *= rs * cs[g][e];
+          acc[h * MIH + i][2 * g + 1][e] *= rs * cs[g][4 + e];
+        }
+    }
+}
+
 // ACT: the epilogue compiled in (-1 = plain: act NONE, alpha 1, no scale) — one per kernel: with all of them in one kernel the
 // register allocator spills inside the K loop.
-template <int BM, bool GATHER, int ACT>
+// FP8: A and B hold e4m3 codes; the kernel moves the same bytes (the host passes K, lda, ldb in 2-byte units: a 128-byte LDS row is
+// 128 codes instead of 64 bf16) and a phase's MFMAs are v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales — one per
+// (row fragment, column fragment) on the SAME two 16-byte reads per operand that feed the two bf16 k-steps: a lane's 32 bytes are
+// chunks fq and fq + 4 of the row for A and B alike, and which k a byte is does not matter as long as both operands agree.
+template <int BM, bool GATHER, int ACT, bool FP8 = false>
 __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_params p, const pp_work work) {
   constexpr int BMH = BM / 2;    // rows of an A half-tile: 128 or 96
   constexpr int WRH = BMH / 2;   // ... of which one wave group owns 64 or 48
@@ -881,11 +916,21 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
       bb[j][1] = *(const bf16x8_t*)(st + x * P_HALF + b_off + j * 16 * P_ROWB + kc1);
     }
   };
+  auto cat8 = [](const bf16x8_t lo, const bf16x8_t hi) __attribute__((always_inline)) {
+    const u32x4_t a = __builtin_bit_cast(u32x4_t, lo), b = __builtin_bit_cast(u32x4_t, hi);
+    return i32x8_t{(int)a.x, (int)a.y, (int)a.z, (int)a.w, (int)b.x, (int)b.y, (int)b.z, (int)b.w};
+  };
 #define PP_MMA(IO, JO, BB)                                                                                                \
   __builtin_amdgcn_sched_barrier(0);                                                                                      \
   __builtin_amdgcn_s_setprio(1);                                                                                          \
-  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < MIH; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) \
-      acc[IO + i][JO + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BB[j][ks], af[i][ks], acc[IO + i][JO + j], 0, 0, 0);   \
+  if constexpr (FP8) {                                                                                                    \
+    _Pragma("unroll") for (int i = 0; i < MIH; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                         \
+        acc[IO + i][JO + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(cat8(BB[j][0], BB[j][1]), cat8(af[i][0], af[i][1]), \
+                                                                               acc[IO + i][JO + j], 0, 0, 0, 127, 0, 127); \
+  } else {                                                                                                                \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < MIH; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) \
+        acc[IO + i][JO + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BB[j][ks], af[i][ks], acc[IO + i][JO + j], 0, 0, 0); \
+  }                                                                                                                       \
   __builtin_amdgcn_s_setprio(0);                                                                                          \
   __builtin_amdgcn_sched_barrier(0);
   // end of a phase's memory segment: stage half-tile q + 6, retire what phase q + 1 reads, meet the other group.
@@ -991,9 +1036,10 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
     } else {
       const int mw0 = m0 + wr * WRH, nw0 = n0 + wc * 32;
       const bool interior = fast_addr && m0 + BM <= p.M && n0 + P_BN <= p.N;
+      if constexpr (FP8) fp8_scale_acc<MIH, BMH>(p, work, acc, mw0, nw0, fr, fq);
       if (interior) gemm_epilogue_fast<MIH, BMH, ACT>(p, acc, mw0, nw0, fr, fq, ACT < 0 ? 1.f : scale);
       else gemm_epilogue_wide<MIH, BMH, ACT>(p, acc, mw0, nw0, fr, fq, ACT < 0 ? 1.f : scale);
-      relax = interior && !p.aux;  // exactly 4 * MIH stores per wave were issued
+      relax = interior && !p.aux && !FP8;  // exactly 4 * MIH stores per wave were issued (FP8: the scale loads sit in the queue too)
     }
 #pragma unroll
     for (int i = 0; i < 2 * MIH; ++i)
@@ -1010,8 +1056,9 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
 // the main kernel would have run (same accumulator map, same functions). The waves are independent: FIX_WAVES per block,
 // 8 / FIX_WAVES blocks per tile, so that the few split tiles still spread over the whole chip.
 constexpr int FIX_WAVES = 2;
-template <int BM, int ACT>
-__global__ __launch_bounds__(64 * FIX_WAVES) void gemm_pp_fixup_kernel(const grove_gemm_params p, const i32x4_t* __restrict__ list, const float* __restrict__ ws) {
+template <int BM, int ACT, bool FP8 = false>
+__global__ __launch_bounds__(64 * FIX_WAVES) void gemm_pp_fixup_kernel(const grove_gemm_params p, const i32x4_t* __restrict__ list, const float* __restrict__ ws,
+                                                                       const pp_work work) {
   constexpr int BMH = BM / 2, WRH = BMH / 2, MIH = WRH / 16;
   constexpr int BPT = 8 / FIX_WAVES;  // blocks per tile
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1043,6 +1090,7 @@ __global__ __launch_bounds__(64 * FIX_WAVES) void gemm_pp_fixup_kernel(const gro
   const bool fast_addr = p.c_dtype == GROVE_BF16 && !p.c_idx && !p.r_idx && !p.n_group;
   const int mw0 = m0 + wr * WRH, nw0 = n0 + wc * 32;
   const bool interior = fast_addr && m0 + BM <= p.M && n0 + P_BN <= p.N;
+  if constexpr (FP8) fp8_scale_acc<MIH, BMH>(p, work, acc, mw0, nw0, fr, fq);
   if (interior) gemm_epilogue_fast<MIH, BMH, ACT>(p, acc, mw0, nw0, fr, fq, ACT < 0 ? 1.f : scale);
   else gemm_epilogue_wide<MIH, BMH, ACT>(p, acc, mw0, nw0, fr, fq, ACT < 0 ? 1.f : scale);
 }
@@ -1171,13 +1219,13 @@ inline float* stream_k_workspace(hipStream_t s, int dev, int G) {
   return w.ws;
 }
 
-template <int BM, bool GATHER, int ACT>
-int launch_pp_act(const grove_gemm_params& p, hipStream_t s) {
+template <int BM, bool GATHER, int ACT, bool FP8 = false>
+int launch_pp_act(const grove_gemm_params& p, hipStream_t s, const float* row_scale = nullptr, const float* col_scale = nullptr) {
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + P_BN - 1) / P_BN;
   const size_t lds = 2 * (size_t)P_STAGE;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<BM, GATHER, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<BM, GATHER, ACT, FP8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   const int G = num_cus(), nk = p.K / P_BK;
@@ -1186,7 +1234,7 @@ int launch_pp_act(const grove_gemm_params& p, hipStream_t s) {
   g_gemm_last_epilogue = ACT;
   int dev = 0;
   hipGetDevice(&dev);
-  pp_work work{nullptr, nullptr};
+  pp_work work{nullptr, nullptr, row_scale, col_scale};
   sk_plan pl = plan_stream_k(tiles, nk, G, g_gemm_stream_k);
   if (pl.S && !(work.ws = stream_k_workspace(s, dev, G))) pl = plan_stream_k(tiles, nk, G, 0);
   const int grid = pl.S ? G : (int)(tiles < G ? tiles : G);  // (the list is laid out for this grid: its row stride and wgid map)
@@ -1195,10 +1243,11 @@ int launch_pp_act(const grove_gemm_params& p, hipStream_t s) {
   GROVE_CHECK(td->n_slots <= G, GROVE_E_WORKSPACE, "gemm: %d stream-K parts for %d slots", td->n_slots, G);
   work.table = td->table;
   g_gemm_last_stream_k = pl.S;
-  hipLaunchKernelGGL((gemm_nt_pp_kernel<BM, GATHER, ACT>), dim3(grid, 1, 1), dim3(P_NT), lds, s, p, work);
+  hipLaunchKernelGGL((gemm_nt_pp_kernel<BM, GATHER, ACT, FP8>), dim3(grid, 1, 1), dim3(P_NT), lds, s, p, work);
   GROVE_LAUNCH_CHECK();
   if (td->n_fixups) {
-    hipLaunchKernelGGL((gemm_pp_fixup_kernel<BM, ACT>), dim3(td->n_fixups * (8 / FIX_WAVES), 1, 1), dim3(64 * FIX_WAVES), 0, s, p, (const i32x4_t*)td->fixups, (const float*)work.ws);
+    hipLaunchKernelGGL((gemm_pp_fixup_kernel<BM, ACT, FP8>), dim3(td->n_fixups * (8 / FIX_WAVES), 1, 1), dim3(64 * FIX_WAVES), 0, s, p, (const i32x4_t*)td->fixups,
+                       (const float*)work.ws, work);
     GROVE_LAUNCH_CHECK();
   }
   return GROVE_OK;
@@ -1257,6 +1306,33 @@ extern "C" int grove_gemm_set_tile_n(int tile_n) {
 extern "C" int grove_gemm_set_staging(int use_lds_dma) {
   g_gemm_glds = use_lds_dma ? 1 : 0;
   return GROVE_OK;
+}
+
+// The e4m3 GEMM (grove_gemm_fp8, gemm_fp8.hip) on the FP8 instances of the pipelined kernel: same staging stream and phase
+// structure, twice the math per byte. Returns 1 when the problem does not fit them (the caller falls back to its own kernel).
+int grove_gemm_fp8_pipelined(const grove_gemm_fp8_params* q, hipStream_t s) {
+  const bool al = ((((uintptr_t)q->C | (uintptr_t)q->bias | (uintptr_t)q->residual | (uintptr_t)q->scale_b) & 15) == 0) && q->ldc % 8 == 0 &&
+                  (!q->residual || q->ldr % 8 == 0);
+  if (!al || q->N % 8 != 0 || q->K % 128 != 0 || q->lda % 16 != 0 || q->ldb % 16 != 0) return 1;
+  if (q->act != GROVE_ACT_NONE && q->act != GROVE_ACT_QUICKGELU) return 1;
+  grove_gemm_params p;
+  memset(&p, 0, sizeof(p));
+  p.A = q->A, p.B = q->B, p.C = q->C, p.bias = q->bias, p.residual = q->residual;
+  p.M = q->M, p.N = q->N, p.K = q->K / 2, p.lda = q->lda / 2, p.ldb = q->ldb / 2, p.ldc = q->ldc, p.ldr = q->residual ? q->ldr : 0;
+  p.act = q->act, p.alpha = 1.f, p.c_dtype = GROVE_BF16, p.batch1 = p.batch2 = 1, p.a_taps = 1;
+  // 256- or 192-row tiles by the cost model of the bf16 instances (same bytes per K tile, same phase lengths)
+  const int G = num_cus(), nk = q->K / 128;
+  const long tn = (q->N + 255) / 256;
+  auto cost = [&](long tiles, double kt, double fixed) {
+    const sk_plan pl = plan_stream_k(tiles, nk, G, g_gemm_stream_k);
+    const double r = (double)((tiles + G - 1) / G);
+    if (pl.S) return pl.kt_units * kt + r * fixed;
+    return r * (nk * kt * (0.6 + 0.4 * (double)tiles / (r * G)) + fixed);
+  };
+  const bool big = cost((long)((q->M + 255) / 256) * tn, 1.5, 6.0) <= cost((long)((q->M + 191) / 192) * tn, 1.17, 4.8);
+  if (q->act == GROVE_ACT_NONE) return big ? launch_pp_act<256, false, -1, true>(p, s, q->scale_a, q->scale_b) : launch_pp_act<192, false, -1, true>(p, s, q->scale_a, q->scale_b);
+  return big ? launch_pp_act<256, false, GROVE_ACT_QUICKGELU, true>(p, s, q->scale_a, q->scale_b)
+             : launch_pp_act<192, false, GROVE_ACT_QUICKGELU, true>(p, s, q->scale_a, q->scale_b);
 }
 
 extern "C" int grove_gemm_set_stream_k(int mode) {

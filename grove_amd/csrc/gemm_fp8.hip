@@ -166,11 +166,22 @@ __global__ __launch_bounds__(256) void quant_fp8_rows_kernel(const bf16_raw* __r
 
 }  // namespace
 
+int grove_gemm_fp8_pipelined(const grove_gemm_fp8_params* q, hipStream_t s);  // gemm.hip
+static int g_fp8_pipelined = 1;  // 0 = always the two-barrier kernel of this file (A/B arm: grove_gemm_fp8_set_pipelined)
+extern "C" int grove_gemm_fp8_set_pipelined(int on) {
+  g_fp8_pipelined = on ? 1 : 0;
+  return GROVE_OK;
+}
+
 extern "C" int grove_gemm_fp8(const grove_gemm_fp8_params* p, void* stream) {
   GROVE_CHECK(p && p->M > 0 && p->N > 0 && p->K > 0 && p->A && p->B && p->C && p->scale_a && p->scale_b, GROVE_E_SHAPE, "gemm_fp8: bad arguments");
   GROVE_CHECK(p->K % F8_BK == 0, GROVE_E_SHAPE, "gemm_fp8: K=%d must be a multiple of %d", p->K, F8_BK);
   GROVE_CHECK(p->lda % 16 == 0 && p->ldb % 16 == 0 && ((uintptr_t)p->A & 15) == 0 && ((uintptr_t)p->B & 15) == 0, GROVE_E_ALIGN,
               "gemm_fp8: operand rows must be 16-byte aligned");
+  if (g_fp8_pipelined) {  // the FP8 instances of the persistent pipelined kernel (gemm.hip) when the problem fits them
+    const int rc = grove_gemm_fp8_pipelined(p, (hipStream_t)stream);
+    if (rc <= 0) return rc;
+  }
   const int tiles = ((p->M + F8_BM - 1) / F8_BM) * ((p->N + F8_BN - 1) / F8_BN);
   const size_t lds = 4 * F8_TILE;
   hipFuncSetAttribute((const void*)gemm_fp8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

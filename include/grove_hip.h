@@ -525,6 +525,9 @@ typedef struct grove_gemm_fp8_params {
   int32_t M, N, K, lda, ldb, ldc, ldr, act;
 } grove_gemm_fp8_params;
 int grove_gemm_fp8(const grove_gemm_fp8_params* p, void* stream);
+/* 1 (default): problems that fit them (K % 128 == 0, N % 8 == 0, 16-byte aligned operands, act NONE / QUICKGELU) run on the FP8
+ * instances of the persistent pipelined kernel; 0: always the two-barrier kernel (A/B arm of tests and tools) */
+int grove_gemm_fp8_set_pipelined(int on);
 /* x bf16 [rows, ld_x] -> q e4m3 [rows, ld_q] with one scale per row: scale = amax / 448 (1 for a zero row), q = x / scale */
 int grove_quant_fp8_rows(const void* x, void* q, float* scale, int32_t rows, int32_t K, int32_t ld_x, int32_t ld_q, void* stream);
 

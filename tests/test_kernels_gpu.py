@@ -1084,13 +1084,20 @@ def test_fp8_gemm_operand_map_exact_integers(dev):
     aq = a.to(torch.float8_e4m3fn).view(torch.uint8).to(dev)
     bq = b.to(torch.float8_e4m3fn).view(torch.uint8).to(dev)
     one_m, one_n = torch.ones(M, device=dev), torch.ones(N, device=dev)
-    y = ops.linear_fp8(None, bq, one_n, xq=(aq, one_m))
     ref = a @ b.t()
     assert ref.abs().max() < 256  # exact in bf16
-    assert torch.equal(y.float().cpu(), ref), (y.float().cpu() - ref).abs().max()
+    from grove_amd import _lib
+    try:
+        for pipelined in (1, 0):  # the FP8 instance of the persistent pipelined kernel (gemm.hip), then gemm_fp8.hip's own kernel
+            _lib.lib().grove_gemm_fp8_set_pipelined(pipelined)
+            y = ops.linear_fp8(None, bq, one_n, xq=(aq, one_m))
+            assert torch.equal(y.float().cpu(), ref), (pipelined, (y.float().cpu() - ref).abs().max())
+    finally:
+        _lib.lib().grove_gemm_fp8_set_pipelined(1)
 
 
-@pytest.mark.parametrize("M,N,K,act", [(333, 520, 1024, 0), (2812, 4096, 4096, 0), (1000, 1024, 512, 1)])
+@pytest.mark.parametrize("M,N,K,act", [(333, 520, 1024, 0), (2812, 4096, 4096, 0), (1000, 1024, 512, 1), (1000, 1024, 512, 2), (20200, 1000, 5120, 2),
+                                       (20200, 1000, 5120, 0)])
 def test_fp8_linear_quantised(dev, M, N, K, act):
     """quant_fp8_rows (per-row amax / 448, e4m3) + the fp8 GEMM with bias / activation / residual, against the same quantisation
     modelled with torch's float8_e4m3fn casts (tight), and against the unquantised product (the fp8 error itself: a few percent)."""
@@ -1106,15 +1113,23 @@ def test_fp8_linear_quantised(dev, M, N, K, act):
     assert same > 0.999, same  # (ties of the device's division vs torch's can differ in the last bit on a handful of elements)
     ws_ref = w.float().abs().amax(1) / 448
     w_model = _e4m3(w.float() / ws_ref[:, None])
-    a = {0: ops.ACT_NONE, 1: ops.ACT_GELU}[act]
+    a = {0: ops.ACT_NONE, 1: ops.ACT_GELU, 2: ops.ACT_QUICKGELU}[act]  # (GELU: no pipelined instance -> gemm_fp8.hip's own kernel)
+    fact = {0: lambda v: v, 1: torch.nn.functional.gelu, 2: lambda v: v * torch.sigmoid(1.702 * v)}[act]
     y = ops.linear_fp8(x.to(dev), wq, ws, bias.to(dev), act=a, residual=res.to(dev))
     pre = (x_model @ w_model.t()) * xs_ref[:, None] * ws_ref[None, :] + bias.float()
-    ref = (torch.nn.functional.gelu(pre) if act else pre) + res.float()
+    ref = fact(pre) + res.float()
     rms = ((y.float().cpu() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
     assert rms < 6e-3, f"fp8 gemm vs its own quantisation model: rms {rms}"  # bf16 output rounding + last-bit ties of the device division (measured 3.0-3.4e-3)
     close(y, ref, 2e-2, "fp8 gemm vs its own quantisation model")
-    full = x.float() @ w.float().t() + bias.float()
-    full = (torch.nn.functional.gelu(full) if act else full) + res.float()
+    full = fact(x.float() @ w.float().t() + bias.float()) + res.float()
+    if act != 1:  # both kernels: same products, different fp32 sum order
+        from grove_amd import _lib
+        try:
+            _lib.lib().grove_gemm_fp8_set_pipelined(0)
+            y0 = ops.linear_fp8(x.to(dev), wq, ws, bias.to(dev), act=a, residual=res.to(dev))
+        finally:
+            _lib.lib().grove_gemm_fp8_set_pipelined(1)
+        close(y, y0, 2 ** -7, "pipelined FP8 instance vs the two-barrier fp8 kernel")
     err = ((y.float().cpu() - full).pow(2).mean().sqrt() / full.pow(2).mean().sqrt()).item()
     assert err < 6e-2, f"fp8 quantisation error {err}"
 
