@@ -169,6 +169,21 @@ __device__ __forceinline__ float group_sum4(float v) {
   return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
+
+// Launch order of a CAUSAL problem: the work of a 128-row block grows (query-major kernels) or shrinks (key-major) with its
+// position in the sequence, and 768 blocks of 2..12 key tiles on 512 block slots end with the longest ones running alone. Blocks
+// are dispatched in linear blockIdx order, so the sequence block becomes the SLOWEST index, longest first (LPT order).
+__device__ __forceinline__ void causal_block_order(const bool causal, const bool reverse, int& bx, int& h, int& b) {
+  bx = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  if (!causal) return;
+  const int id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  const int nbh = gridDim.y * gridDim.z;
+  const int qi = id / nbh, bh = id - qi * nbh;
+  bx = reverse ? (int)gridDim.x - 1 - qi : qi;
+  h = bh % (int)gridDim.y;
+  b = bh / (int)gridDim.y;
+}
+
 // ================================================================================ forward
 // min 2 waves per SIMD (<= 256 registers): keeps the MFMA accumulators in arch VGPRs — with the 512-register budget
 // hipcc parks them in AGPRs and pays ~350 v_accvgpr moves per tile around the softmax VALU work.
@@ -181,8 +196,9 @@ __global__ __launch_bounds__(NTHR, 2) void flash_fwd_kernel(const grove_flash_at
   char* Es = smem + 2 * C::TILEB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, g = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int qblk = blockIdx.x * 128;
+  int bx, h, b;
+  causal_block_order(p.causal != 0, true, bx, h, b);
+  const int qblk = bx * 128;
   const int q0 = qblk + wave * 32;
   const bf16_raw* Q = (const bf16_raw*)p.q + (int64_t)b * p.sq + h * HS;
   const bf16_raw* K = (const bf16_raw*)p.k + (int64_t)b * p.sk + h * HS;
@@ -372,8 +388,9 @@ __global__ __launch_bounds__(NTHR, (HS <= 96 ? 2 : 1)) void flash_bwd_dkv_kernel
   constexpr int RELB = 64 * 2 + 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, g = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int kblk = blockIdx.x * 128;
+  int bx, h, b;
+  causal_block_order(p.causal != 0, false, bx, h, b);
+  const int kblk = bx * 128;
   const int k0 = kblk + wave * 32;
   const bf16_raw* Q = (const bf16_raw*)p.q + (int64_t)b * p.sq + h * HS;
   const bf16_raw* K = (const bf16_raw*)p.k + (int64_t)b * p.sk + h * HS;
@@ -563,8 +580,9 @@ __global__ __launch_bounds__(NTHR, 2) void flash_bwd_dq_kernel(const grove_flash
   const int nbt = (REL && p.drel) ? (nrel + 15) >> 4 : 0;  // 16-bin tiles of d rel (<= 2 * NRK)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, g = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int qblk = blockIdx.x * 128;
+  int bx, h, b;
+  causal_block_order(p.causal != 0, true, bx, h, b);
+  const int qblk = bx * 128;
   const int q0 = qblk + wave * 32;
   const bf16_raw* Q = (const bf16_raw*)p.q + (int64_t)b * p.sq + h * HS;
   const bf16_raw* K = (const bf16_raw*)p.k + (int64_t)b * p.sk + h * HS;
