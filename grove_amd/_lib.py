@@ -110,7 +110,7 @@ class FlashAttnParams(C.Structure):
                 ("B", c_i32), ("H", c_i32), ("Lq", c_i32), ("Lk", c_i32), ("hs", c_i32),
                 ("ld_q", c_i32), ("ld_k", c_i32), ("ld_v", c_i32), ("ld_o", c_i32), ("ld_do", c_i32), ("ld_dq", c_i32),
                 ("ld_dk", c_i32), ("ld_dv", c_i32), ("causal", c_i32), ("rel_kh", c_i32), ("rel_kw", c_i32), ("rel_ld", c_i32), ("alpha", c_f32),
-                ("hs_valid", c_i32)]
+                ("hs_valid", c_i32), ("q_valid", c_vp)]
 
 
 class GemvParams(C.Structure):
@@ -158,7 +158,7 @@ STRUCTS = {
 SYMBOLS = [
     "grove_version", "grove_last_error", "grove_sizeof", "grove_gemm_bf16", "grove_gemm_last_variant", "grove_gemm_last_epilogue", "grove_gemm_set_staging", "grove_gemm_set_stream_k", "grove_gemm_last_stream_k", "grove_gemm_set_tile_n", "grove_gemm_set_tile_m", "grove_gemm_set_bk", "grove_gemm_tn_bf16", "grove_gemm_tn_set_pipelined", "grove_gemv_bf16", "grove_decode_attn", "grove_resample_u8", "grove_normalize_pack",
     "grove_transpose_bf16", "grove_layernorm_fwd", "grove_rmsnorm_fwd", "grove_layernorm_bwd", "grove_rmsnorm_bwd",
-    "grove_flash_attn_fwd", "grove_flash_attn_bwd", "grove_flash_attn_set_window_kernels", "grove_softmax_fwd", "grove_softmax_bwd", "grove_relpos_fwd", "grove_relpos_bwd", "grove_rel_bias_fwd", "grove_rel_bias_bwd", "grove_rope_inplace",
+    "grove_flash_attn_fwd", "grove_flash_attn_bwd", "grove_flash_attn_set_window_kernels", "grove_flash_attn_window_kernels_on", "grove_softmax_fwd", "grove_softmax_bwd", "grove_relpos_fwd", "grove_relpos_bwd", "grove_rel_bias_fwd", "grove_rel_bias_bwd", "grove_rope_inplace",
     "grove_swiglu_fwd", "grove_swiglu_bwd", "grove_act_bwd", "grove_act_fwd", "grove_resize_bilinear_f32", "grove_add_bf16", "grove_add_bcast_rows",
     "grove_copy_rows", "grove_dot_bf16", "grove_axpy_f32", "grove_scatter_add_f32", "grove_colsum_f32", "grove_cast_f32_to_bf16", "grove_cast_bf16_to_f32",
     "grove_im2col_patch", "grove_clip_pool", "grove_cross_entropy", "grove_small_attn_fwd", "grove_small_attn_bwd", "grove_gemm_f32", "grove_gemm_fp8", "grove_gemm_fp8_set_pipelined", "grove_quant_fp8_rows",

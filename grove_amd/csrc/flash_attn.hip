@@ -760,6 +760,7 @@ extern "C" int grove_flash_attn_set_window_kernels(int32_t on) {
   g_win_attn = on != 0;
   return GROVE_OK;
 }
+extern "C" int grove_flash_attn_window_kernels_on(void) { return g_win_attn ? 1 : 0; }
 
 extern "C" int grove_flash_attn_fwd(const grove_flash_attn_params* p, void* stream) {
   int rc = check(p, "flash_attn_fwd");

@@ -49,6 +49,33 @@ __device__ __forceinline__ f32x4_t mfma16(s16x4_t a, s16x4_t b, f32x4_t c) {
 #define KEEP_ALIVE4(a, b, c, d)
 #define KEEP_ALIVE3(a, b, c)
 
+// THE QUERIES THAT COUNT. window_partition pads the token grid to whole windows (image_encoder.py:329-353): at 32 x 32 -> 3 x 3
+// windows of 14 x 14, 42 % of the windowed rows are padding. As KEYS they are real (k, v = the bias row) — as QUERIES their outputs
+// are dropped by window_unpartition and carry no gradient, so the kernels work through the valid queries only: window b keeps
+// its top-left vy x vx positions (p.q_valid[b] = {vy, vx}; NULL = all), compact query i is position (i / vx) * kw + i % vx, and
+// the query-indexed loops, LDS images and stores run over nq = vy * vx rows (196, 56 or 16 instead of 196: 59 % of the
+// query tiles per frame). Rows of o / lse / dq / d rel' at padded positions are not written, d_o there is not read.
+struct QList {
+  int nq, vx, kw, mvx;  // mvx = ceil(2^16 / vx): i / vx = (i * mvx) >> 16 for i < 208 (vx <= 14: exact below 334)
+  __device__ __forceinline__ int pos(int i) const {
+    const int r = (i * mvx) >> 16;
+    return r * kw + (i - r * vx);
+  }
+};
+__device__ __forceinline__ QList make_qlist(const grove_flash_attn_params& p, int b) {
+  QList ql;
+  ql.kw = p.rel_kw;
+  int vy = p.Lq / p.rel_kw;
+  ql.vx = p.rel_kw;
+  if (p.q_valid) {
+    vy = p.q_valid[2 * b];
+    ql.vx = p.q_valid[2 * b + 1];
+  }
+  ql.nq = p.q_valid ? vy * ql.vx : p.Lq;
+  ql.mvx = (65536 + ql.vx - 1) / ql.vx;
+  return ql;
+}
+
 // rows 0 .. 207 (clamped to L - 1) x 10 chunks of one head's [*, 80] slice -> dense LDS image; every lane copies 16 bytes per
 // instruction, the wave's 64 chunks land contiguously (LDS-DMA destinations are lane-linear)
 __device__ __forceinline__ void dma_image(char* img, const bf16_raw* __restrict__ src, int ld, int L, int wave, int lane) {
@@ -60,6 +87,22 @@ __device__ __forceinline__ void dma_image(char* img, const bf16_raw* __restrict_
       const int row = (c * 6554) >> 16;  // c / 10 (exact for c < 16384)
       const int col = c - row * 10;
       const int gr = min(row, L - 1);
+      if (c < WNCH)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (int64_t)gr * ld + col * 8),
+                                         (__attribute__((address_space(3))) void*)(img + i * 1024), 16, 0, 0);
+    }
+  }
+}
+// the same for a QUERY-indexed operand: image row i = compact query min(i, nq - 1)
+__device__ __forceinline__ void dma_image_q(char* img, const bf16_raw* __restrict__ src, int ld, const QList& ql, int wave, int lane) {
+#pragma unroll
+  for (int j = 0; j < (WINSTR + 3) / 4; ++j) {
+    const int i = wave + 4 * j;
+    if (i < WINSTR) {
+      const int c = i * 64 + lane;
+      const int row = (c * 6554) >> 16;
+      const int col = c - row * 10;
+      const int gr = ql.pos(min(row, ql.nq - 1));
       if (c < WNCH)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (int64_t)gr * ld + col * 8),
                                          (__attribute__((address_space(3))) void*)(img + i * 1024), 16, 0, 0);
@@ -142,10 +185,10 @@ struct QPair {          // B operands of one pair of 16-query tiles, pre-scaled 
 };
 
 __device__ __forceinline__ void load_qpair(QPair& q, const bf16_raw* __restrict__ Q, int ld_q, const bf16_raw* __restrict__ REL, int q0,
-                                           int L, float sc, int fr, int g) {
+                                           const QList& ql, float sc, int fr, int g) {
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi) {
-    const int qi = min(q0 + mi * 16 + fr, L - 1);
+    const int qi = ql.pos(min(q0 + mi * 16 + fr, ql.nq - 1));
     const bf16_raw* row = Q + (int64_t)qi * ld_q;
     q.f[mi][0] = wscale(*(const bf16x8_t*)(row + g * 8), sc);
     q.f[mi][1] = wscale(*(const bf16x8_t*)(row + 32 + g * 8), sc);
@@ -155,7 +198,7 @@ __device__ __forceinline__ void load_qpair(QPair& q, const bf16_raw* __restrict_
 }
 
 // ================================================================================ forward
-__device__ __forceinline__ void fwd_pair(const QPair& q, const char* Ks, const char* Vs, const char* Es, int q0, int L, int lane,
+__device__ __forceinline__ void fwd_pair(const QPair& q, const char* Ks, const char* Vs, const char* Es, int q0, int L, const QList& ql, int lane,
                                          bf16_raw* __restrict__ O, int ld_o, float* __restrict__ LSE) {
   const int fr = lane & 15, g = lane >> 4;
   const int esw = e_swz(fr);
@@ -232,8 +275,8 @@ __device__ __forceinline__ void fwd_pair(const QPair& q, const char* Ks, const c
   // lane holds O^T[d = dt*16 + 4g + r][q = fr]; every row of Ls is the softmax denominator of query fr
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi) {
-    const int qi = q0 + mi * 16 + fr;
-    if (qi >= L) continue;
+    if (q0 + mi * 16 + fr >= ql.nq) continue;
+    const int qi = ql.pos(q0 + mi * 16 + fr);
     const float l = Ls[mi][0];
     const float inv = __builtin_amdgcn_rcpf(l);
     bf16_raw* orow = O + (int64_t)qi * ld_o;
@@ -267,16 +310,17 @@ __global__ __launch_bounds__(WTHR, 2) void win_attn_fwd_kernel(const grove_flash
   dma_image(Ks, K, p.ld_k, L, wave, lane);
   dma_image(Vs, V, p.ld_v, L, wave, lane);
   build_e(Es, L, p.rel_kw, p.rel_kh, tid);
+  const QList ql = make_qlist(p, b);
   QPair q;
-  load_qpair(q, Q, p.ld_q, REL, wave * 32, L, sc, fr, g);  // in flight together with the DMA
+  load_qpair(q, Q, p.ld_q, REL, wave * 32, ql, sc, fr, g);  // in flight together with the DMA
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 #pragma nounroll
-  for (int q0 = wave * 32; q0 < L; q0 += 128) {
+  for (int q0 = wave * 32; q0 < ql.nq; q0 += 128) {
     QPair qn;
-    const bool more = q0 + 128 < L;
-    if (more) load_qpair(qn, Q, p.ld_q, REL, q0 + 128, L, sc, fr, g);  // lands under this pair's MFMAs
-    fwd_pair(q, Ks, Vs, Es, q0, L, lane, O, p.ld_o, LSE);
+    const bool more = q0 + 128 < ql.nq;
+    if (more) load_qpair(qn, Q, p.ld_q, REL, q0 + 128, ql, sc, fr, g);  // lands under this pair's MFMAs
+    fwd_pair(q, Ks, Vs, Es, q0, L, ql, lane, O, p.ld_o, LSE);
     if (more) q = qn;
   }
 }
@@ -347,7 +391,7 @@ __device__ __forceinline__ void load_kv(KVFrag (&kv)[NTILE], int kt0, const bf16
 
 template <int NTILE>
 __device__ __forceinline__ void bwd_keys(const KVFrag (&kv)[NTILE], int kt0,
-                                         const char* Qs, const char* dOs, const char* Rs, const float* lse_s, const float* del_s, int L,
+                                         const char* Qs, const char* dOs, const char* Rs, const float* lse_s, const float* del_s, int L, int nq,
                                          float alpha, int lane, bf16_raw* __restrict__ DK, int ld_dk, bf16_raw* __restrict__ DV, int ld_dv) {
   const int fr = lane & 15, g = lane >> 4;
   const int esw = e_swz(fr);
@@ -358,8 +402,11 @@ __device__ __forceinline__ void bwd_keys(const KVFrag (&kv)[NTILE], int kt0,
 #pragma unroll
     for (int dt = 0; dt < 5; ++dt) { dk[nj][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dv[nj][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
   const f32x4_t z4 = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  // the images hold the nq valid queries in rows 0 .. nq - 1 (rows beyond: copies of the last one with lse = +inf, i.e. P = 0):
+  // nqt 16-row tiles = nqt / 2 steps of 32 and, if nqt is odd, one 16-deep step
+  const int nqt = (nq + 15) >> 4;
 #pragma nounroll
-  for (int qs = 0; qs < WNT / 2; ++qs) {  // 32 queries per step
+  for (int qs = 0; qs < (nqt >> 1); ++qs) {  // 32 queries per step
     f32x4_t sacc[2][NTILE], pacc[2][NTILE];
 #pragma unroll
     for (int qi_ = 0; qi_ < 2; ++qi_) {
@@ -420,15 +467,16 @@ __device__ __forceinline__ void bwd_keys(const KVFrag (&kv)[NTILE], int kt0,
       }
     }
   }
-  {  // the 13th query tile (rows >= L carry no probability)
-    const int row = (WNT - 1) * 16 + fr;
+  if (nqt & 1) {  // the odd last query tile (rows >= nq carry no probability)
+    const int lt = nqt - 1;
+    const int row = lt * 16 + fr;
     const bf16x8_t qa0 = ld_rows(Qs, row, g * 16), qa1 = ld_rows(Qs, row, 64 + g * 16);
     const s16x4_t qat = *(const s16x4_t*)(Qs + row * WROWB + 128 + g * 8);
     const bf16x8_t da0 = ld_rows(dOs, row, g * 16), da1 = ld_rows(dOs, row, 64 + g * 16);
     const s16x4_t dat = *(const s16x4_t*)(dOs + row * WROWB + 128 + g * 8);
     const bf16x8_t ra = *(const bf16x8_t*)(Rs + row * 64 + ((g ^ esw) << 4));
-    const f32x4_t lse4 = *(const f32x4_t*)(lse_s + (WNT - 1) * 16 + g * 4), del4 = *(const f32x4_t*)(del_s + (WNT - 1) * 16 + g * 4);
-    const int qvalid = L - (WNT - 1) * 16 - 4 * g;
+    const f32x4_t lse4 = *(const f32x4_t*)(lse_s + lt * 16 + g * 4), del4 = *(const f32x4_t*)(del_s + lt * 16 + g * 4);
+    const int qvalid = nq - lt * 16 - 4 * g;
     s16x4_t p4[NTILE], d4[NTILE];
 #pragma unroll
     for (int nj = 0; nj < NTILE; ++nj) {
@@ -455,8 +503,8 @@ __device__ __forceinline__ void bwd_keys(const KVFrag (&kv)[NTILE], int kt0,
     KEEP_ALIVE3(da0, da1, dat);
 #pragma unroll
     for (int dt = 0; dt < 5; ++dt) {
-      const s16x4_t dob = tr4(dOs, (WNT - 1) * 16, dt * 16, lane);
-      const s16x4_t qb = tr4(Qs, (WNT - 1) * 16, dt * 16, lane);
+      const s16x4_t dob = tr4(dOs, lt * 16, dt * 16, lane);
+      const s16x4_t qb = tr4(Qs, lt * 16, dt * 16, lane);
 #pragma unroll
       for (int nj = 0; nj < NTILE; ++nj) {
         if (nj < ntile) {
@@ -484,8 +532,8 @@ struct QDPair {         // B operands of one pair of 16-query tiles (phase B)
   float lse2[2], del[2];
 };
 
-__device__ __forceinline__ void bwd_queries(const QDPair& x, const char* Ks, const char* Vs, const char* Es, int q0, int L, float alpha, int lane,
-                                            bf16_raw* __restrict__ DQ, int ld_dq, bf16_raw* __restrict__ DR) {
+__device__ __forceinline__ void bwd_queries(const QDPair& x, const char* Ks, const char* Vs, const char* Es, int q0, int L, const QList& ql, float alpha,
+                                            int lane, bf16_raw* __restrict__ DQ, int ld_dq, bf16_raw* __restrict__ DR) {
   const int fr = lane & 15, g = lane >> 4;
   const int esw = e_swz(fr);
   const f32x4_t z4 = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -590,8 +638,8 @@ __device__ __forceinline__ void bwd_queries(const QDPair& x, const char* Ks, con
   // lane holds dQ^T[d][q = fr] and d rel'^T[bin = bt*16 + 4g + r][q = fr]
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi) {
-    const int qi = q0 + mi * 16 + fr;
-    if (qi >= L) continue;
+    if (q0 + mi * 16 + fr >= ql.nq) continue;
+    const int qi = ql.pos(q0 + mi * 16 + fr);
     store_t(DQ, ld_dq, qi, dq[mi], g);
     if (DR) {
       bf16_raw* r = DR + (int64_t)qi * 32;
@@ -623,20 +671,21 @@ __global__ __launch_bounds__(WTHR, 2) void win_attn_bwd_kernel(const grove_flash
   const bf16_raw* REL = (const bf16_raw*)p.rel + bh * 32;
   const float sc = p.alpha * 1.4426950408889634f;
   // ---- prologue: Q, dO -> LDS (DMA); rel' (scaled) -> LDS; lse; delta
-  dma_image(Xs, Q, p.ld_q, L, wave, lane);
-  dma_image(Ys, dO, p.ld_do, L, wave, lane);
+  const QList ql = make_qlist(p, b);
+  dma_image_q(Xs, Q, p.ld_q, ql, wave, lane);
+  dma_image_q(Ys, dO, p.ld_do, ql, wave, lane);
   for (int c = tid; c < WNT * 16 * 4; c += WTHR) {
     const int row = c >> 2, ch = c & 3;
     u32x4_t v = u32x4_t{0u, 0u, 0u, 0u};
-    if (row < L) v = *(const u32x4_t*)(REL + (int64_t)row * 32 + ch * 8);
+    if (row < ql.nq) v = *(const u32x4_t*)(REL + (int64_t)ql.pos(row) * 32 + ch * 8);
     *(bf16x8_t*)(Rs + row * 64 + ((ch ^ e_swz(row)) << 4)) = wscale(__builtin_bit_cast(bf16x8_t, v), sc);
   }
   u32x4_t orow[10];
-  const int myrow = min(tid, L - 1);
+  const int myrow = ql.pos(min(tid, ql.nq - 1));
   if (tid < WNT * 16) {
 #pragma unroll
     for (int c = 0; c < 10; ++c) orow[c] = *(const u32x4_t*)(Og + (int64_t)myrow * p.ld_o + c * 8);
-    lse_s[tid] = p.lse[bh + myrow] * 1.4426950408889634f;
+    lse_s[tid] = tid < ql.nq ? p.lse[bh + myrow] * 1.4426950408889634f : INFINITY;  // (+inf: a row past the last query has P = exp2(s - inf) = 0)
   }
   KVFrag kv0[2];
   load_kv<2>(kv0, wave, K, p.ld_k, V, p.ld_v, L, sc, p.rel_kw, p.rel_kh, lane);  // pass 0's fragments: in flight with the DMA
@@ -657,15 +706,15 @@ __global__ __launch_bounds__(WTHR, 2) void win_attn_bwd_kernel(const grove_flash
   // ---- phase A: dK, dV of this wave's key tiles {w, w+4} and {w+8, w+12}
   bf16_raw* DK = (bf16_raw*)p.dk + (int64_t)b * p.sdk + h * p.hs;
   bf16_raw* DV = (bf16_raw*)p.dv + (int64_t)b * p.sdv + h * p.hs;
-  bwd_keys<2>(kv0, wave, Xs, Ys, Rs, lse_s, del_s, L, p.alpha, lane, DK, p.ld_dk, DV, p.ld_dv);
+  bwd_keys<2>(kv0, wave, Xs, Ys, Rs, lse_s, del_s, L, ql.nq, p.alpha, lane, DK, p.ld_dk, DV, p.ld_dv);
   if (wave == 0) {  // key tiles {8, 12}
     KVFrag kv1[2];
     load_kv<2>(kv1, 8, K, p.ld_k, V, p.ld_v, L, sc, p.rel_kw, p.rel_kh, lane);
-    bwd_keys<2>(kv1, 8, Xs, Ys, Rs, lse_s, del_s, L, p.alpha, lane, DK, p.ld_dk, DV, p.ld_dv);
+    bwd_keys<2>(kv1, 8, Xs, Ys, Rs, lse_s, del_s, L, ql.nq, p.alpha, lane, DK, p.ld_dk, DV, p.ld_dv);
   } else {          // key tile 8 + wave
     KVFrag kv1[1];
     load_kv<1>(kv1, 8 + wave, K, p.ld_k, V, p.ld_v, L, sc, p.rel_kw, p.rel_kh, lane);
-    bwd_keys<1>(kv1, 8 + wave, Xs, Ys, Rs, lse_s, del_s, L, p.alpha, lane, DK, p.ld_dk, DV, p.ld_dv);
+    bwd_keys<1>(kv1, 8 + wave, Xs, Ys, Rs, lse_s, del_s, L, ql.nq, p.alpha, lane, DK, p.ld_dk, DV, p.ld_dv);
   }
   __syncthreads();
   // ---- phase B: K, V, E replace Q, dO, rel' in LDS; dQ and d rel' of this wave's query-tile pairs
@@ -675,16 +724,16 @@ __global__ __launch_bounds__(WTHR, 2) void win_attn_bwd_kernel(const grove_flash
   bf16_raw* DQ = (bf16_raw*)p.dq + (int64_t)b * p.sdq + h * p.hs;
   bf16_raw* DR = p.drel ? (bf16_raw*)p.drel + bh * 32 : nullptr;
   auto load_x = [&](QDPair& x, int q0) {
-    load_qpair(x.q, Q, p.ld_q, REL, q0, L, sc, fr, g);
+    load_qpair(x.q, Q, p.ld_q, REL, q0, ql, sc, fr, g);
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
-      const int qi = min(q0 + mi * 16 + fr, L - 1);
-      const bf16_raw* row = dO + (int64_t)qi * p.ld_do;
+      const int qc = min(q0 + mi * 16 + fr, ql.nq - 1);  // compact index: lse_s / del_s; position: the global rows
+      const bf16_raw* row = dO + (int64_t)ql.pos(qc) * p.ld_do;
       x.d[mi][0] = *(const bf16x8_t*)(row + g * 8);
       x.d[mi][1] = *(const bf16x8_t*)(row + 32 + g * 8);
       x.dt[mi] = __builtin_bit_cast(s16x4_t, *(const u32x2_t*)(row + 64 + g * 4));
-      x.lse2[mi] = lse_s[qi];   // (lse_s / del_s are not overwritten by phase B's images)
-      x.del[mi] = del_s[qi];
+      x.lse2[mi] = lse_s[qc];   // (lse_s / del_s are not overwritten by phase B's images)
+      x.del[mi] = del_s[qc];
     }
   };
   QDPair x;
@@ -692,9 +741,9 @@ __global__ __launch_bounds__(WTHR, 2) void win_attn_bwd_kernel(const grove_flash
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 #pragma nounroll
-  for (int q0 = wave * 32; q0 < L; q0 += 128) {
-    bwd_queries(x, Xs, Ys, Rs, q0, L, p.alpha, lane, DQ, p.ld_dq, DR);
-    if (q0 + 128 < L) load_x(x, q0 + 128);
+  for (int q0 = wave * 32; q0 < ql.nq; q0 += 128) {
+    bwd_queries(x, Xs, Ys, Rs, q0, L, ql, p.alpha, lane, DQ, p.ld_dq, DR);
+    if (q0 + 128 < ql.nq) load_x(x, q0 + 128);
   }
 }
 

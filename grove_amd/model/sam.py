@@ -128,8 +128,15 @@ class SamEncoder:
             pos_rows = (torch.arange(F * g * g, dtype=torch.int32) % (g * g))
             pad_rows = (win2tok < 0).nonzero().flatten().to(torch.int32)  # window-layout rows that are padding
             zeros = torch.zeros_like(pad_rows)
+            # the real tokens of a window are its top-left vy x vx positions (the grid is padded at the bottom / right only):
+            # the window kernels skip the other positions as queries (grove_flash_attn_params.q_valid)
+            ws = d.sam_window
+            real = (win2tok >= 0).view(-1, ws, ws)
+            vy, vx = real.any(2).sum(1), real.any(1).sum(1)
+            assert torch.equal(real, (torch.arange(ws)[None, :, None] < vy[:, None, None]) & (torch.arange(ws)[None, None, :] < vx[:, None, None]))
+            q_valid = torch.stack([vy, vx], 1).to(torch.int32).contiguous()
             self._idx[F] = tuple(t.to(self.dev) for t in (tok2win, win2tok, conv, neck, pos_rows)) + (nwin,)
-            self._pad[F] = (pad_rows.to(self.dev), zeros.to(self.dev))
+            self._pad[F] = (pad_rows.to(self.dev), zeros.to(self.dev), q_valid.to(self.dev))
         return self._idx[F]
 
     def _head_rows(self, nb, L):
@@ -169,14 +176,14 @@ class SamEncoder:
             # rows (42 % of the windowed rows at 32x32 -> 3x3 windows of 14) are filled with the bias row.
             rows_w = F * nwin * ws * ws
             nb, L, qhw = F * nwin, ws * ws, (ws, ws)
-            pad_rows, pad_src = self._pad[F]
+            pad_rows, pad_src, q_valid = self._pad[F]
             if Bk["maps"]:
                 qkv = ops.linear(h, Bk["wqkv_c"], Bk["bqkv_c"], c_idx=tok2win, out_rows=rows_w, out_cols=3 * nh * hp, n_map=(hd, hp - hd))
             else:
                 qkv = ops.linear(h, Bk["wqkv"], Bk["bqkv"], c_idx=tok2win, out_rows=rows_w)
             ops.copy_rows(Bk["bqkv"].view(1, -1), qkv, pad_rows.numel(), qkv.shape[1], idx_src=pad_src, idx_dst=pad_rows)
         else:
-            nb, L, qhw = F, g * g, (g, g)
+            nb, L, qhw, q_valid = F, g * g, (g, g), None
             qkv = ops.linear(h, Bk["wqkv"], Bk["bqkv"])
         # rel'[(b h), q, :] = q_vec . R_cat[q]^T as ONE GEMM batched over the L query positions
         ld = qkv.stride(0)
@@ -188,7 +195,10 @@ class SamEncoder:
             rel = torch.empty((nb * nh, L, rel_ld), dtype=torch.bfloat16, device=self.dev)
             ops.gemm_raw(qkv, Bk["Rcat"], rel, nb * nh, rel_ld, hp, hp, hp, L * rel_ld, a_idx=hrow, batch=(L, 1),
                          sA=(ld, 0), sB=(rel_ld * hp, 0), sC=(rel_ld, 0))
-        o, actx = attention_fwd(qkv, nb, L, nh, hp, 0, nh * hp, 2 * nh * hp, hd ** -0.5, rel=rel, rel_hw=(Bk["khp"], qhw[1]), save=save, hs_valid=hd)
+        if q_valid is not None and not ops.window_kernels_take(L, hp, hd, rel_ld):
+            q_valid = None  # (the general kernels process every row)
+        o, actx = attention_fwd(qkv, nb, L, nh, hp, 0, nh * hp, 2 * nh * hp, hd ** -0.5, rel=rel, rel_hw=(Bk["khp"], qhw[1]), save=save, hs_valid=hd,
+                                q_valid=q_valid)
         del rel
         r1 = None if f32 else x  # bf16 stream: x1 = x + proj(...) in the GEMM epilogue
         if ws > 0:  # un-partition = gather the real tokens' rows of the windowed attention output (padding rows are dropped)
@@ -318,12 +328,13 @@ class SamEncoder:
             del dh2
             # x1 = x + unpartition(proj(attn(qkv(partition(ln1(x))))))
             if ws > 0:  # real tokens only, scattered into the windowed layout; padding rows carry no gradient
-                pad_rows, pad_src = self._pad[F]
+                pad_rows, pad_src, _ = self._pad[F]
                 if Bk["maps"]:
                     do = ops.linear(dx, Bk["wproj_c_t"], c_idx=tok2win, out_rows=win2tok.shape[0], out_cols=nh * hp, n_map=(hd, hp - hd))
                 else:
                     do = ops.linear(dx, Bk["wproj_t"], c_idx=tok2win, out_rows=win2tok.shape[0])
-                ops.copy_rows(self._zero_row[:, :do.shape[1]], do, pad_rows.numel(), do.shape[1], idx_src=pad_src, idx_dst=pad_rows)
+                if c["actx"].q_valid is None:  # (the window kernels skip the padded positions as queries and never read these rows)
+                    ops.copy_rows(self._zero_row[:, :do.shape[1]], do, pad_rows.numel(), do.shape[1], idx_src=pad_src, idx_dst=pad_rows)
             else:
                 do = ops.linear(dx, Bk["wproj_t"])
             qkv = c["qkv"]

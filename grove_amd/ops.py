@@ -251,8 +251,13 @@ def softmax_bwd(dprobs, probs, Lk, scale, *, drel=None, rel_hw=(0, 0), out=None)
     return out
 
 
+def window_kernels_take(L, hs, hs_valid, rel_ld):
+    """Will the LDS-resident window kernels (win_attn.hip) run this attention problem? (They honour q_valid; the general ones do not.)"""
+    return bool(_lib.lib().grove_flash_attn_window_kernels_on()) and hs == 96 and hs_valid == 80 and 192 < L <= 208 and rel_ld == 32
+
+
 def flash_attn(qkv, B, L, H, hs, q_off, k_off, v_off, alpha, *, causal=False, kv_len=None, rel=None, rel_hw=(0, 0), out=None,
-               want_lse=False, hs_valid=0):
+               want_lse=False, hs_valid=0, q_valid=None):
     """Fused attention over a fused qkv activation [B*L, ld]; returns (out [B*L, H*hs], lse or None)."""
     dev = qkv.device
     ld = qkv.stride(0)
@@ -270,6 +275,7 @@ def flash_attn(qkv, B, L, H, hs, q_off, k_off, v_off, alpha, *, causal=False, kv
     p.causal, p.rel_kh, p.rel_kw, p.alpha = int(causal), rel_hw[0], rel_hw[1], alpha
     p.rel_ld = rel.shape[-1] if rel is not None else 0
     p.hs_valid = hs_valid
+    p.q_valid = _p(q_valid)
     _lib.check(_lib.lib().grove_flash_attn_fwd(C.byref(p), _stream()), "grove_flash_attn_fwd")
     return out, lse
 
@@ -333,7 +339,7 @@ def flash_attn_kv(q, k, v, B, H, Lq, Lk, hs, alpha, *, sq, sk, sv, ld_q, ld_k, l
     return out
 
 def flash_attn_bwd(qkv, out, d_out, lse, dqkv, B, L, H, hs, q_off, k_off, v_off, alpha, *, causal=False, kv_len=None, rel=None,
-                   rel_hw=(0, 0), want_drel=False, hs_valid=0):
+                   rel_hw=(0, 0), want_drel=False, hs_valid=0, q_valid=None):
     dev = qkv.device
     ld, ldd = qkv.stride(0), dqkv.stride(0)
     delta = torch.empty((B * H, L), dtype=torch.float32, device=dev)
@@ -352,6 +358,7 @@ def flash_attn_bwd(qkv, out, d_out, lse, dqkv, B, L, H, hs, q_off, k_off, v_off,
     p.causal, p.rel_kh, p.rel_kw, p.alpha = int(causal), rel_hw[0], rel_hw[1], alpha
     p.rel_ld = rel.shape[-1] if rel is not None else 0
     p.hs_valid = hs_valid
+    p.q_valid = _p(q_valid)
     _lib.check(_lib.lib().grove_flash_attn_bwd(C.byref(p), _stream()), "grove_flash_attn_bwd")
     return drel
 

@@ -287,11 +287,17 @@ typedef struct grove_flash_attn_params {
   int32_t hs_valid; /* real head dim inside the hs-wide slot (0 = hs). SAM: 80 in 96 — with Lq == Lk in (192, 208] and 32 rel bins
                        (the 14 x 14 windows of image_encoder.py:329-353) the LDS-resident window kernels run (win_attn.hip): nothing
                        is multiplied by the padding, and the pad columns of o / dq / dk / dv are written as zeros */
+  const int32_t* q_valid; /* window kernels only: int32 [B][2] = {vy, vx} or NULL. Batch b keeps the top-left vy x vx positions of its
+                       (Lq / rel_kw) x rel_kw window as QUERIES (window_partition's zero padding, image_encoder.py:329-353: real as keys,
+                       dropped as queries): rows of o / lse / dq / drel at the other positions are NOT written and d_o there is NOT read.
+                       The general kernels ignore the field and process every row (the caller then supplies zero d_o rows there);
+                       grove_flash_attn_window_kernels_on() tells which family runs a fitting problem */
 } grove_flash_attn_params;
 int grove_flash_attn_fwd(const grove_flash_attn_params* p, void* stream);
 int grove_flash_attn_bwd(const grove_flash_attn_params* p, void* stream);
 /* 1 (default): problems that fit them run on the window kernels; 0: always the general kernels (A/B arm of tests and tools) */
 int grove_flash_attn_set_window_kernels(int32_t on);
+int grove_flash_attn_window_kernels_on(void);
 
 /* Decomposed relative-position terms of SAM attention (image_encoder.py:420-458):
  * rel[b*heads + h, q, 0:kh]     = sum_c qv[q, h, c] * Rh[qh(q), :, c]

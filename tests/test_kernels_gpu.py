@@ -1176,3 +1176,59 @@ def test_rel_bias_streams(dev, nb, nh, size, hd, hp):
     untouched = torch.ones(3 * nh, hp, dtype=torch.bool)
     untouched[:nh, :hd] = False
     assert torch.equal(dq.view(nb * L, 3 * nh, hp)[:, untouched.to(dev)], dq0.view(nb * L, 3 * nh, hp)[:, untouched.to(dev)]), "columns outside q[:hd]"
+
+
+def test_window_attention_valid_queries(dev):
+    """q_valid of the window kernels: window b keeps its top-left vy x vx positions as queries (window_partition's padding is real as
+    keys, dropped as queries). Against fp32 attention over ALL keys at the valid queries: o / lse forward; dq / d rel' at the valid
+    queries and dk / dv everywhere backward, with NaN in d_o at the padded positions (never read) and NaN-filled outputs (rows at
+    padded positions stay untouched). The window shapes of a 32 x 32 grid: 14 x 14 (full), 4 x 14, 14 x 4, 4 x 4."""
+    from grove_amd import ops
+    B, H, L, hs, hd, ws = 4, 16, 196, 96, 80, 14
+    valid = [(14, 14), (4, 14), (14, 4), (4, 4)]
+    assert ops.window_kernels_take(L, hs, hd, 32)
+    g = torch.Generator().manual_seed(77)
+    alpha = hd ** -0.5
+    qkv = torch.zeros(B * L, 3, H, hs)
+    qkv[..., :hd] = torch.randn(B * L, 3, H, hd, generator=g) * 0.7
+    qkv = qkv.view(B * L, 3 * H * hs).to(bf16)
+    relp = torch.zeros(B * H, L, 32)
+    relp[..., :ws] = torch.randn(B * H, L, ws, generator=g) / alpha
+    relp[..., 16:16 + ws] = torch.randn(B * H, L, ws, generator=g) / alpha
+    relp = relp.to(bf16)
+    do = torch.zeros(B * L, H, hs)
+    do[..., :hd] = torch.randn(B * L, H, hd, generator=g) * 0.5  # (pad dims: zero, as the projection's dgrad writes them)
+    do = do.view(B * L, H * hs).to(bf16)
+    qmask = torch.zeros(B, ws, ws, dtype=torch.bool)
+    for b, (vy, vx) in enumerate(valid):
+        qmask[b, :vy, :vx] = True
+    qmask = qmask.view(B, L)
+    # fp32 reference: every key, gradients only from the valid queries
+    t = qkv.float().view(B, L, 3, H, hs).requires_grad_(True)
+    q, k, v = t[:, :, 0].transpose(1, 2), t[:, :, 1].transpose(1, 2), t[:, :, 2].transpose(1, 2)
+    relr = relp.float().clone().requires_grad_(True)
+    s = q @ k.transpose(-1, -2) * alpha + ((relr[..., :ws, None] + relr[..., None, 16:16 + ws]) * alpha).reshape(B, H, L, L)
+    o_ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B * L, H * hs)
+    do_ref = do.float() * qmask.view(B * L, 1)
+    o_ref.backward(do_ref)
+    lse_ref = torch.logsumexp(s, -1).reshape(B * H, L)
+    qv = torch.tensor(valid, dtype=torch.int32).to(dev)
+    out = torch.full((B * L, H * hs), float("nan"), dtype=bf16, device=dev)
+    out, lse = ops.flash_attn(qkv.to(dev), B, L, H, hs, 0, H * hs, 2 * H * hs, alpha, rel=relp.to(dev), rel_hw=(16, ws), want_lse=True,
+                              hs_valid=hd, q_valid=qv, out=out)
+    rows = qmask.view(-1)
+    close(out[rows.to(dev)], o_ref[rows], 1e-2, "o at the valid queries")
+    assert torch.isnan(out[(~rows).to(dev)].float()).all(), "rows of o at padded positions must not be written"
+    hm = qmask[:, None, :].expand(B, H, L).reshape(B * H, L)
+    close(lse[hm.to(dev)], lse_ref[hm], 2e-3, "lse at the valid queries")
+    do_dev = do.clone()
+    do_dev[~rows] = float("nan")
+    dqkv = torch.full((B * L, 3 * H * hs), float("nan"), dtype=bf16, device=dev)
+    drel = ops.flash_attn_bwd(qkv.to(dev), out, do_dev.to(dev), lse, dqkv, B, L, H, hs, 0, H * hs, 2 * H * hs, alpha, rel=relp.to(dev),
+                              rel_hw=(16, ws), want_drel=True, hs_valid=hd, q_valid=qv)
+    gref = t.grad.reshape(B * L, 3 * H * hs)
+    close(dqkv[rows.to(dev), :H * hs], gref[rows, :H * hs], 2e-2, "dq at the valid queries")
+    close(dqkv[:, H * hs:2 * H * hs], gref[:, H * hs:2 * H * hs], 2e-2, "dk")
+    close(dqkv[:, 2 * H * hs:], gref[:, 2 * H * hs:], 2e-2, "dv")
+    close(drel[hm.to(dev)], relr.grad[hm], 2e-2, "d rel' at the valid queries")
+    assert torch.isnan(dqkv[(~rows).to(dev), :H * hs].float()).all(), "rows of dq at padded positions must not be written"
