@@ -67,7 +67,8 @@ class RelposParams(C.Structure):
 
 class RelBiasParams(C.Structure):
     _fields_ = [("q", c_vp), ("table", c_vp), ("rel", c_vp), ("dq", c_vp),
-                ("nb", c_i32), ("nh", c_i32), ("L", c_i32), ("hp", c_i32), ("hd", c_i32), ("rel_ld", c_i32), ("ld_q", c_i32), ("ld_dq", c_i32)]
+                ("nb", c_i32), ("nh", c_i32), ("L", c_i32), ("hp", c_i32), ("hd", c_i32), ("rel_ld", c_i32), ("ld_q", c_i32), ("ld_dq", c_i32),
+                ("q_valid", c_vp), ("kw", c_i32)]
 
 class RopeParams(C.Structure):
     _fields_ = [("x", c_vp), ("pos", c_vp), ("rows", c_i32), ("ld", c_i32), ("col0", c_i32), ("nheads", c_i32),

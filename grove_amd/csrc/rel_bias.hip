@@ -28,6 +28,18 @@ __device__ __forceinline__ bf16x8_t zero_frag() {
 // 32s + 8g + j and 32s + 8g + 4 + j, so a lane's accumulators of a tile pair are 8 consecutive bins / dims: 16-byte accesses.
 __device__ __forceinline__ int paired_row(int t, int i) { return 32 * (t >> 1) + 8 * (i >> 2) + 4 * (t & 1) + (i & 3); }
 
+
+// Bit u of the result: window w0 + u keeps position q as a QUERY (grove_rel_bias_params.q_valid, the window kernels' rule: the
+// top-left vy x vx positions of the (L / kw) x kw window). Padded positions get no rel' row and no dq contribution: the
+// attention kernels neither read nor write them. NULL: every window. A wave's chunk holds at most 64 windows.
+__device__ __forceinline__ unsigned long long valid_windows(const grove_rel_bias_params& p, int q, int w0, int w1, int lane) {
+  if (!p.q_valid) return ~0ull;
+  const int qy = q / p.kw, qx = q - qy * p.kw;
+  bool ok = false;
+  if (w0 + lane < w1) ok = qy < p.q_valid[2 * (w0 + lane)] && qx < p.q_valid[2 * (w0 + lane) + 1];
+  return __builtin_amdgcn_ballot_w64(ok);
+}
+
 // KS: 32-deep steps along the head dim (hp / 32); NP: pairs of 16-bin tiles (rel_ld / 32)
 template <int KS, int NP>
 __global__ __launch_bounds__(RB_THREADS) void rel_bias_fwd_kernel(const grove_rel_bias_params p, const int win_per_wave) {
@@ -47,13 +59,17 @@ __global__ __launch_bounds__(RB_THREADS) void rel_bias_fwd_kernel(const grove_re
   const bf16_raw* Q = (const bf16_raw*)p.q + (int64_t)q * p.ld_q + hq * p.hp + 8 * g;
   bf16_raw* O = (bf16_raw*)p.rel + ((int64_t)hq * p.L + q) * p.rel_ld + 8 * g;
   const int64_t q_step = (int64_t)p.L * p.ld_q, o_step = (int64_t)p.nh * p.L * p.rel_ld;
+  const unsigned long long live = valid_windows(p, q, w0, w1, lane);
   constexpr int U = 4;  // windows in flight per wave (loads of all U first: the stream is latency-bound otherwise)
   for (int w = w0; w < w1; w += U) {
+    if (((live >> (w - w0)) & ((1ull << U) - 1)) == 0) continue;  // (wave-uniform)
     bf16x8_t qf[U][KS];
 #pragma unroll
-    for (int u = 0; u < U; ++u)
+    for (int u = 0; u < U; ++u) {
+      const bool on = (live >> (w - w0 + u)) & 1;
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) qf[u][ks] = ld_frag(Q + min(w + u, w1 - 1) * q_step + 32 * ks);
+      for (int ks = 0; ks < KS; ++ks) qf[u][ks] = on ? ld_frag(Q + min(w + u, w1 - 1) * q_step + 32 * ks) : zero_frag();
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -64,7 +80,7 @@ __global__ __launch_bounds__(RB_THREADS) void rel_bias_fwd_kernel(const grove_re
           a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rf[2 * s][ks], qf[u][ks], a0, 0, 0, 0);
           a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rf[2 * s + 1][ks], qf[u][ks], a1, 0, 0, 0);
         }
-        if (head_ok && w + u < w1)
+        if (head_ok && w + u < w1 && ((live >> (w - w0 + u)) & 1))
           *(u32x4_t*)(O + (w + u) * o_step + 32 * s) = u32x4_t{pack2bf(a0[0], a0[1]), pack2bf(a0[2], a0[3]), pack2bf(a1[0], a1[1]), pack2bf(a1[2], a1[3])};
       }
   }
@@ -91,14 +107,16 @@ __global__ __launch_bounds__(RB_THREADS) void rel_bias_bwd_kernel(const grove_re
   const bf16_raw* D = (const bf16_raw*)p.rel + ((int64_t)hq * p.L + q) * p.rel_ld + 8 * g;
   bf16_raw* DQ = (bf16_raw*)p.dq + (int64_t)q * p.ld_dq + hq * p.hp;
   const int64_t d_step = (int64_t)p.nh * p.L * p.rel_ld, q_step = (int64_t)p.L * p.ld_dq;
+  const unsigned long long live = valid_windows(p, q, w0, w1, lane);
   constexpr int U = 2;  // windows in flight per wave
   for (int w = w0; w < w1; w += U) {
+    if (((live >> (w - w0)) & ((1ull << U) - 1)) == 0) continue;  // (wave-uniform)
     bf16x8_t df[U][KB];
     u32x4_t old[U][NP];
     u32x2_t old1[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int wu = min(w + u, w1 - 1);
+      const int wu = ((live >> (w - w0 + u)) & 1) ? min(w + u, w1 - 1) : w0 + __builtin_ctzll(live);  // (a dead window reads a live one's rows: finite, L2-hot, never stored)
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) df[u][kb] = ld_frag(D + wu * d_step + 32 * kb);
 #pragma unroll
@@ -107,7 +125,7 @@ __global__ __launch_bounds__(RB_THREADS) void rel_bias_bwd_kernel(const grove_re
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const bool ok = head_ok && w + u < w1;
+      const bool ok = head_ok && w + u < w1 && ((live >> (w - w0 + u)) & 1);
 #pragma unroll
       for (int s = 0; s < NP; ++s) {
         f32x4_t a0 = f32x4_t{0.f, 0.f, 0.f, 0.f}, a1 = a0;
@@ -139,6 +157,7 @@ int check(const grove_rel_bias_params* p, const char* name, bool bwd) {
   GROVE_CHECK(p->hp % 32 == 0 && p->hp <= 128 && (p->rel_ld == 32 || p->rel_ld == 64), GROVE_E_SHAPE,
               "%s: hp=%d must be a multiple of 32 up to 128, rel_ld=%d must be 32 or 64", name, p->hp, p->rel_ld);
   GROVE_CHECK(p->hd > 0 && p->hd <= p->hp, GROVE_E_SHAPE, "%s: hd=%d outside (0, hp]", name, p->hd);
+  GROVE_CHECK(!p->q_valid || (p->kw > 0 && p->L % p->kw == 0), GROVE_E_SHAPE, "%s: q_valid needs kw (window width) dividing L", name);
   GROVE_CHECK(p->table && p->rel && (bwd ? p->dq != nullptr : p->q != nullptr), GROVE_E_SHAPE, "%s: null operand", name);
   GROVE_CHECK((bwd ? p->ld_dq : p->ld_q) % 8 == 0, GROVE_E_ALIGN, "%s: leading dims must be multiples of 8", name);
   GROVE_CHECK((((uintptr_t)p->table | (uintptr_t)p->rel | (uintptr_t)(bwd ? p->dq : p->q)) & 15) == 0, GROVE_E_ALIGN, "%s: operands must be 16-byte aligned", name);
@@ -151,6 +170,7 @@ inline void plan(const grove_rel_bias_params* p, int& win_per_wave, dim3& grid) 
   long per_q = (target_waves + p->L - 1) / p->L;            // waves per position
   win_per_wave = (int)((p->nb + per_q - 1) / per_q);
   if (win_per_wave < 4) win_per_wave = p->nb < 4 ? p->nb : 4;
+  if (win_per_wave > 64) win_per_wave = 64;  // (valid_windows: one ballot bit per window of a wave's chunk)
   const int waves = (p->nb + win_per_wave - 1) / win_per_wave;
   grid = dim3(p->L, (waves + RB_THREADS / 64 - 1) / (RB_THREADS / 64), 1);
 }

@@ -189,14 +189,14 @@ class SamEncoder:
         ld = qkv.stride(0)
         rel_ld = Bk["rel_ld"]
         hrow = self._head_rows(nb, L)
+        if q_valid is not None and not ops.window_kernels_take(L, hp, hd, rel_ld):
+            q_valid = None  # (the general kernels process every row)
         if ops.rel_bias_applicable(nh, hp, rel_ld):
-            rel = ops.rel_bias_fwd(qkv, Bk["Rcat"], nb, nh, L, hp, hd)
+            rel = ops.rel_bias_fwd(qkv, Bk["Rcat"], nb, nh, L, hp, hd, q_valid=q_valid, kw=qhw[1])
         else:
             rel = torch.empty((nb * nh, L, rel_ld), dtype=torch.bfloat16, device=self.dev)
             ops.gemm_raw(qkv, Bk["Rcat"], rel, nb * nh, rel_ld, hp, hp, hp, L * rel_ld, a_idx=hrow, batch=(L, 1),
                          sA=(ld, 0), sB=(rel_ld * hp, 0), sC=(rel_ld, 0))
-        if q_valid is not None and not ops.window_kernels_take(L, hp, hd, rel_ld):
-            q_valid = None  # (the general kernels process every row)
         o, actx = attention_fwd(qkv, nb, L, nh, hp, 0, nh * hp, 2 * nh * hp, hd ** -0.5, rel=rel, rel_hw=(Bk["khp"], qhw[1]), save=save, hs_valid=hd,
                                 q_valid=q_valid)
         del rel
@@ -343,7 +343,7 @@ class SamEncoder:
             # dq[(b q), h, :] += d rel'[(b h), q, :] . R_cat[q]  (one GEMM batched over q, accumulating in place)
             L, rel_ld, ldd = c["L"], Bk["rel_ld"], dqkv.stride(0)
             if ops.rel_bias_applicable(nh, hp, rel_ld):
-                ops.rel_bias_bwd(drel, Bk["RcatT"], dqkv, c["nb"], nh, L, hp, self.hd)
+                ops.rel_bias_bwd(drel, Bk["RcatT"], dqkv, c["nb"], nh, L, hp, self.hd, q_valid=c["actx"].q_valid, kw=Bk["window"])
             else:
                 hrow = self._head_rows(c["nb"], L)
                 ops.gemm_raw(drel, Bk["RcatT"], dqkv, c["nb"] * nh, hp, rel_ld, L * rel_ld, rel_ld, hp, c_idx=hrow, residual=dqkv, ldr=hp,

@@ -370,7 +370,7 @@ def rel_bias_applicable(nh, hp, rel_ld):
     return nh <= 16 and hp % 32 == 0 and hp <= 128 and rel_ld in (32, 64)
 
 
-def rel_bias_fwd(q, rcat, nb, nh, L, hp, hd, *, out=None):
+def rel_bias_fwd(q, rcat, nb, nh, L, hp, hd, *, out=None, q_valid=None, kw=0):
     """rel'[(b h), q, :] = q[(b q), h, :] . rcat[q]^T: q bf16 [nb*L, ld] with head h at column h*hp, rcat bf16 [L, rel_ld, hp]."""
     _chk_dev(q, rcat)
     rel_ld = rcat.shape[1]
@@ -380,11 +380,12 @@ def rel_bias_fwd(q, rcat, nb, nh, L, hp, hd, *, out=None):
     p = _lib.RelBiasParams()
     p.q, p.table, p.rel, p.dq = _p(q), _p(rcat), _p(out), None
     p.nb, p.nh, p.L, p.hp, p.hd, p.rel_ld, p.ld_q, p.ld_dq = nb, nh, L, hp, hd, rel_ld, q.stride(0), 0
+    p.q_valid, p.kw = _p(q_valid), kw
     _lib.check(_lib.lib().grove_rel_bias_fwd(C.byref(p), _stream()), "grove_rel_bias_fwd")
     return out
 
 
-def rel_bias_bwd(drel, rcat_t, dq, nb, nh, L, hp, hd):
+def rel_bias_bwd(drel, rcat_t, dq, nb, nh, L, hp, hd, *, q_valid=None, kw=0):
     """dq[(b q), h, :] += d rel'[(b h), q, :] . rcat[q] in place: rcat_t bf16 [L, hp, rel_ld], dq bf16 [nb*L, ld]."""
     _chk_dev(drel, rcat_t, dq)
     rel_ld = rcat_t.shape[2]
@@ -393,6 +394,7 @@ def rel_bias_bwd(drel, rcat_t, dq, nb, nh, L, hp, hd):
     p = _lib.RelBiasParams()
     p.q, p.table, p.rel, p.dq = None, _p(rcat_t), _p(drel), _p(dq)
     p.nb, p.nh, p.L, p.hp, p.hd, p.rel_ld, p.ld_q, p.ld_dq = nb, nh, L, hp, hd, rel_ld, 0, dq.stride(0)
+    p.q_valid, p.kw = _p(q_valid), kw
     _lib.check(_lib.lib().grove_rel_bias_bwd(C.byref(p), _stream()), "grove_rel_bias_bwd")
     return dq
 

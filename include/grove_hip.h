@@ -327,6 +327,9 @@ typedef struct grove_rel_bias_params {
   void* rel;         /* bf16 [nb*nh, L, rel_ld]: fwd out; bwd: d rel in */
   void* dq;          /* bwd: bf16 [nb*L, ld_dq], accumulated in place */
   int32_t nb, nh, L, hp, hd, rel_ld, ld_q, ld_dq;
+  const int32_t* q_valid; /* int32 [nb][2] = {vy, vx} or NULL: grove_flash_attn_params.q_valid's rule — positions outside the top-left
+                             vy x vx block of window b get no rel row (fwd) and no dq contribution (bwd; their rel rows are not read) */
+  int32_t kw;             /* window width (positions per window row); with q_valid only */
 } grove_rel_bias_params;
 int grove_rel_bias_fwd(const grove_rel_bias_params* p, void* stream);
 int grove_rel_bias_bwd(const grove_rel_bias_params* p, void* stream);

@@ -1232,3 +1232,41 @@ def test_window_attention_valid_queries(dev):
     close(dqkv[:, 2 * H * hs:], gref[:, 2 * H * hs:], 2e-2, "dv")
     close(drel[hm.to(dev)], relr.grad[hm], 2e-2, "d rel' at the valid queries")
     assert torch.isnan(dqkv[(~rows).to(dev), :H * hs].float()).all(), "rows of dq at padded positions must not be written"
+
+
+def test_rel_bias_streams_skip_padded_positions(dev):
+    """q_valid of the rel-pos streams: positions outside a window's top-left vy x vx block get no rel' row (the output starts as NaN
+    and must stay NaN there), their d rel' rows are not read (NaN there) and their dq rows are not touched."""
+    from grove_amd import ops
+    from grove_amd.model.sam import _rcat_tables
+    nb, nh, size, hd, hp = 13, 16, 14, 80, 96
+    L = size * size
+    g = torch.Generator().manual_seed(5)
+    rel_h = (torch.randn(2 * size - 1, hd, generator=g) * 0.5).to(bf16).to(dev)
+    rel_w = (torch.randn(2 * size - 1, hd, generator=g) * 0.5).to(bf16).to(dev)
+    rcat, rcat_t, khp, rel_ld = _rcat_tables(size, rel_h, rel_w, hd, hp, hd ** -0.5)
+    ld = 3 * nh * hp
+    qkv = (torch.randn(nb * L, ld, generator=g) * 0.5).to(bf16)
+    qkv.view(nb * L, 3 * nh, hp)[:, :, hd:] = 0
+    shapes = [(14, 14), (4, 14), (14, 4), (4, 4)]
+    valid = torch.tensor([shapes[b % 4] for b in range(nb)], dtype=torch.int32)
+    mask = (torch.arange(size)[None, :, None] < valid[:, 0, None, None]) & (torch.arange(size)[None, None, :] < valid[:, 1, None, None])
+    mask = mask.view(nb, L)                                        # [nb, L]
+    qkv[~mask.view(-1)] = float("nan")                             # rows at padded positions are never read
+    rel = torch.full((nb * nh, L, rel_ld), float("nan"), dtype=bf16, device=dev)
+    ops.rel_bias_fwd(qkv.to(dev), rcat, nb, nh, L, hp, hd, out=rel, q_valid=valid.to(dev), kw=size)
+    q4 = torch.nan_to_num(qkv.float()).view(nb, L, 3 * nh, hp)[:, :, :nh]
+    ref = torch.einsum("bqhd,qnd->bhqn", q4, rcat.float().cpu())     # [nb, nh, L, rel_ld]
+    hm = mask[:, None, :].expand(nb, nh, L)
+    got = rel.float().cpu().view(nb, nh, L, rel_ld)
+    close(got[hm], ref[hm], 2 ** -7, "rel' at the real positions")
+    assert torch.isnan(got[~hm]).all(), "rel' rows at padded positions must not be written"
+    drel = (torch.randn(nb * nh, L, rel_ld, generator=g) * 0.3).to(bf16)
+    drel.view(nb, nh, L, rel_ld)[~hm] = float("nan")
+    dq0 = (torch.randn(nb * L, ld, generator=g) * 0.5).to(bf16)
+    dq = dq0.clone().to(dev)
+    ops.rel_bias_bwd(drel.to(dev), rcat_t, dq, nb, nh, L, hp, hd, q_valid=valid.to(dev), kw=size)
+    add = torch.einsum("bhqn,qdn->bqhd", torch.nan_to_num(drel.float()).view(nb, nh, L, rel_ld), rcat_t.float().cpu())
+    want = dq0.float().view(nb, L, 3 * nh, hp).clone()
+    want[:, :, :nh] += add * mask[:, :, None, None]
+    close(dq, want.view(nb * L, ld), 2 ** -7, "dq += d rel' . Rcat at the real positions, untouched elsewhere")
