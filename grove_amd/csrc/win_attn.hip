@@ -57,9 +57,14 @@ __device__ __forceinline__ f32x4_t mfma16(s16x4_t a, s16x4_t b, f32x4_t c) {
 // query tiles per frame). Rows of o / lse / dq / d rel' at padded positions are not written, d_o there is not read.
 struct QList {
   int nq, vx, kw, mvx;  // mvx = ceil(2^16 / vx): i / vx = (i * mvx) >> 16 for i < 208 (vx <= 14: exact below 334)
+  int vy, mkw;          // mkw = ceil(2^16 / kw)
   __device__ __forceinline__ int pos(int i) const {
     const int r = (i * mvx) >> 16;
     return r * kw + (i - r * vx);
+  }
+  __device__ __forceinline__ bool real(int position) const {  // is this position of the window a real token?
+    const int r = (position * mkw) >> 16;
+    return r < vy && position - r * kw < vx;
   }
 };
 __device__ __forceinline__ QList make_qlist(const grove_flash_attn_params& p, int b) {
@@ -73,6 +78,8 @@ __device__ __forceinline__ QList make_qlist(const grove_flash_attn_params& p, in
   }
   ql.nq = p.q_valid ? vy * ql.vx : p.Lq;
   ql.mvx = (65536 + ql.vx - 1) / ql.vx;
+  ql.vy = vy;
+  ql.mkw = (65536 + ql.kw - 1) / ql.kw;
   return ql;
 }
 
@@ -90,6 +97,25 @@ __device__ __forceinline__ void dma_image(char* img, const bf16_raw* __restrict_
       if (c < WNCH)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (int64_t)gr * ld + col * 8),
                                          (__attribute__((address_space(3))) void*)(img + i * 1024), 16, 0, 0);
+    }
+  }
+}
+// the same for a KEY-indexed operand whose rows at padded positions are all one row (pad != NULL: k / v of a zero token = the
+// bias): those chunks come from `pad` (L2-resident), and the caller need not have filled the padded rows of src
+__device__ __forceinline__ void dma_image_k(char* img, const bf16_raw* __restrict__ src, int ld, int L, const bf16_raw* __restrict__ pad,
+                                            const QList& ql, int wave, int lane) {
+#pragma unroll
+  for (int j = 0; j < (WINSTR + 3) / 4; ++j) {
+    const int i = wave + 4 * j;
+    if (i < WINSTR) {
+      const int c = i * 64 + lane;
+      const int row = (c * 6554) >> 16;
+      const int col = c - row * 10;
+      const int gr = min(row, L - 1);
+      const bf16_raw* g = (pad && !ql.real(gr)) ? pad + col * 8 : src + (int64_t)gr * ld + col * 8;
+      if (c < WNCH)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(img + i * 1024), 16,
+                                         0, 0);
     }
   }
 }
@@ -307,10 +333,12 @@ __global__ __launch_bounds__(WTHR, 2) void win_attn_fwd_kernel(const grove_flash
   bf16_raw* O = (bf16_raw*)p.o + (int64_t)b * p.so + h * p.hs;
   float* LSE = p.lse ? p.lse + (int64_t)(b * p.H + h) * L : nullptr;
   const float sc = p.alpha * 1.4426950408889634f;
-  dma_image(Ks, K, p.ld_k, L, wave, lane);
-  dma_image(Vs, V, p.ld_v, L, wave, lane);
-  build_e(Es, L, p.rel_kw, p.rel_kh, tid);
   const QList ql = make_qlist(p, b);
+  const bf16_raw* PK = p.pad_k ? (const bf16_raw*)p.pad_k + h * p.hs : nullptr;
+  const bf16_raw* PV = p.pad_v ? (const bf16_raw*)p.pad_v + h * p.hs : nullptr;
+  dma_image_k(Ks, K, p.ld_k, L, PK, ql, wave, lane);
+  dma_image_k(Vs, V, p.ld_v, L, PV, ql, wave, lane);
+  build_e(Es, L, p.rel_kw, p.rel_kh, tid);
   QPair q;
   load_qpair(q, Q, p.ld_q, REL, wave * 32, ql, sc, fr, g);  // in flight together with the DMA
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -370,14 +398,16 @@ __device__ __forceinline__ void store_t(bf16_raw* __restrict__ dst, int ld, int 
 // phase A for NTILE (1 or 2) key tiles kt0, kt0 + 4 of this wave
 template <int NTILE>
 __device__ __forceinline__ void load_kv(KVFrag (&kv)[NTILE], int kt0, const bf16_raw* __restrict__ K, int ld_k, const bf16_raw* __restrict__ V,
-                                        int ld_v, int L, float sc, int kw, int KH, int lane) {
+                                        int ld_v, int L, float sc, int kw, int KH, int lane, const bf16_raw* __restrict__ PK,
+                                        const bf16_raw* __restrict__ PV, const QList& ql) {
   const int fr = lane & 15, g = lane >> 4;
 #pragma unroll
   for (int nj = 0; nj < NTILE; ++nj) {
     const int key = (kt0 + 4 * nj) * 16 + fr;
     const int kc = min(key, L - 1);
-    const bf16_raw* kr = K + (int64_t)kc * ld_k;
-    const bf16_raw* vr = V + (int64_t)kc * ld_v;
+    const bool padded = PK && !ql.real(kc);  // (k / v of a padded position: the bias row)
+    const bf16_raw* kr = padded ? PK : K + (int64_t)kc * ld_k;
+    const bf16_raw* vr = padded ? PV : V + (int64_t)kc * ld_v;
     kv[nj].k[0] = wscale(*(const bf16x8_t*)(kr + g * 8), sc);
     kv[nj].k[1] = wscale(*(const bf16x8_t*)(kr + 32 + g * 8), sc);
     kv[nj].kt = wscale4(*(const u32x2_t*)(kr + 64 + g * 4), sc);
@@ -392,7 +422,8 @@ __device__ __forceinline__ void load_kv(KVFrag (&kv)[NTILE], int kt0, const bf16
 template <int NTILE>
 __device__ __forceinline__ void bwd_keys(const KVFrag (&kv)[NTILE], int kt0,
                                          const char* Qs, const char* dOs, const char* Rs, const float* lse_s, const float* del_s, int L, int nq,
-                                         float alpha, int lane, bf16_raw* __restrict__ DK, int ld_dk, bf16_raw* __restrict__ DV, int ld_dv) {
+                                         float alpha, int lane, bf16_raw* __restrict__ DK, int ld_dk, bf16_raw* __restrict__ DV, int ld_dv,
+                                         const QList& ql, bool drop_padded) {
   const int fr = lane & 15, g = lane >> 4;
   const int esw = e_swz(fr);
   constexpr int ntile = NTILE;
@@ -518,7 +549,7 @@ __device__ __forceinline__ void bwd_keys(const KVFrag (&kv)[NTILE], int kt0,
 #pragma unroll
   for (int nj = 0; nj < NTILE; ++nj) {
     const int key = (kt0 + 4 * nj) * 16 + fr;
-    if (nj < ntile && key < L) {
+    if (nj < ntile && key < L && !(drop_padded && !ql.real(key))) {  // (nobody reads dk / dv of a padded position)
       store_t(DK, ld_dk, key, dk[nj], g);
       store_t(DV, ld_dv, key, dv[nj], g);
     }
@@ -672,6 +703,8 @@ __global__ __launch_bounds__(WTHR, 2) void win_attn_bwd_kernel(const grove_flash
   const float sc = p.alpha * 1.4426950408889634f;
   // ---- prologue: Q, dO -> LDS (DMA); rel' (scaled) -> LDS; lse; delta
   const QList ql = make_qlist(p, b);
+  const bf16_raw* PK = p.pad_k ? (const bf16_raw*)p.pad_k + h * p.hs : nullptr;
+  const bf16_raw* PV = p.pad_v ? (const bf16_raw*)p.pad_v + h * p.hs : nullptr;
   dma_image_q(Xs, Q, p.ld_q, ql, wave, lane);
   dma_image_q(Ys, dO, p.ld_do, ql, wave, lane);
   for (int c = tid; c < WNT * 16 * 4; c += WTHR) {
@@ -688,7 +721,7 @@ __global__ __launch_bounds__(WTHR, 2) void win_attn_bwd_kernel(const grove_flash
     lse_s[tid] = tid < ql.nq ? p.lse[bh + myrow] * 1.4426950408889634f : INFINITY;  // (+inf: a row past the last query has P = exp2(s - inf) = 0)
   }
   KVFrag kv0[2];
-  load_kv<2>(kv0, wave, K, p.ld_k, V, p.ld_v, L, sc, p.rel_kw, p.rel_kh, lane);  // pass 0's fragments: in flight with the DMA
+  load_kv<2>(kv0, wave, K, p.ld_k, V, p.ld_v, L, sc, p.rel_kw, p.rel_kh, lane, PK, PV, ql);  // pass 0's fragments: in flight with the DMA
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid < WNT * 16) {
@@ -706,20 +739,20 @@ __global__ __launch_bounds__(WTHR, 2) void win_attn_bwd_kernel(const grove_flash
   // ---- phase A: dK, dV of this wave's key tiles {w, w+4} and {w+8, w+12}
   bf16_raw* DK = (bf16_raw*)p.dk + (int64_t)b * p.sdk + h * p.hs;
   bf16_raw* DV = (bf16_raw*)p.dv + (int64_t)b * p.sdv + h * p.hs;
-  bwd_keys<2>(kv0, wave, Xs, Ys, Rs, lse_s, del_s, L, ql.nq, p.alpha, lane, DK, p.ld_dk, DV, p.ld_dv);
+  bwd_keys<2>(kv0, wave, Xs, Ys, Rs, lse_s, del_s, L, ql.nq, p.alpha, lane, DK, p.ld_dk, DV, p.ld_dv, ql, PK != nullptr);
   if (wave == 0) {  // key tiles {8, 12}
     KVFrag kv1[2];
-    load_kv<2>(kv1, 8, K, p.ld_k, V, p.ld_v, L, sc, p.rel_kw, p.rel_kh, lane);
-    bwd_keys<2>(kv1, 8, Xs, Ys, Rs, lse_s, del_s, L, ql.nq, p.alpha, lane, DK, p.ld_dk, DV, p.ld_dv);
+    load_kv<2>(kv1, 8, K, p.ld_k, V, p.ld_v, L, sc, p.rel_kw, p.rel_kh, lane, PK, PV, ql);
+    bwd_keys<2>(kv1, 8, Xs, Ys, Rs, lse_s, del_s, L, ql.nq, p.alpha, lane, DK, p.ld_dk, DV, p.ld_dv, ql, PK != nullptr);
   } else {          // key tile 8 + wave
     KVFrag kv1[1];
-    load_kv<1>(kv1, 8 + wave, K, p.ld_k, V, p.ld_v, L, sc, p.rel_kw, p.rel_kh, lane);
-    bwd_keys<1>(kv1, 8 + wave, Xs, Ys, Rs, lse_s, del_s, L, ql.nq, p.alpha, lane, DK, p.ld_dk, DV, p.ld_dv);
+    load_kv<1>(kv1, 8 + wave, K, p.ld_k, V, p.ld_v, L, sc, p.rel_kw, p.rel_kh, lane, PK, PV, ql);
+    bwd_keys<1>(kv1, 8 + wave, Xs, Ys, Rs, lse_s, del_s, L, ql.nq, p.alpha, lane, DK, p.ld_dk, DV, p.ld_dv, ql, PK != nullptr);
   }
   __syncthreads();
   // ---- phase B: K, V, E replace Q, dO, rel' in LDS; dQ and d rel' of this wave's query-tile pairs
-  dma_image(Xs, K, p.ld_k, L, wave, lane);
-  dma_image(Ys, V, p.ld_v, L, wave, lane);
+  dma_image_k(Xs, K, p.ld_k, L, PK, ql, wave, lane);
+  dma_image_k(Ys, V, p.ld_v, L, PV, ql, wave, lane);
   build_e(Rs, L, p.rel_kw, p.rel_kh, tid);
   bf16_raw* DQ = (bf16_raw*)p.dq + (int64_t)b * p.sdq + h * p.hs;
   bf16_raw* DR = p.drel ? (bf16_raw*)p.drel + bh * 32 : nullptr;

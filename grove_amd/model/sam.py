@@ -181,16 +181,19 @@ class SamEncoder:
                 qkv = ops.linear(h, Bk["wqkv_c"], Bk["bqkv_c"], c_idx=tok2win, out_rows=rows_w, out_cols=3 * nh * hp, n_map=(hd, hp - hd))
             else:
                 qkv = ops.linear(h, Bk["wqkv"], Bk["bqkv"], c_idx=tok2win, out_rows=rows_w)
-            ops.copy_rows(Bk["bqkv"].view(1, -1), qkv, pad_rows.numel(), qkv.shape[1], idx_src=pad_src, idx_dst=pad_rows)
+            # padded positions: q | k | v = the bias row. The window kernels take k / v of those positions from that one row and skip them
+            # as queries, so the rows are filled only for the general kernels
+            pad_row = Bk["bqkv"]  # (padded-head layout: a row of qkv)
+            if not ops.window_kernels_take(ws * ws, hp, hd, Bk["rel_ld"]):
+                q_valid = pad_row = None
+                ops.copy_rows(Bk["bqkv"].view(1, -1), qkv, pad_rows.numel(), qkv.shape[1], idx_src=pad_src, idx_dst=pad_rows)
         else:
-            nb, L, qhw, q_valid = F, g * g, (g, g), None
+            nb, L, qhw, q_valid, pad_row = F, g * g, (g, g), None, None
             qkv = ops.linear(h, Bk["wqkv"], Bk["bqkv"])
         # rel'[(b h), q, :] = q_vec . R_cat[q]^T as ONE GEMM batched over the L query positions
         ld = qkv.stride(0)
         rel_ld = Bk["rel_ld"]
         hrow = self._head_rows(nb, L)
-        if q_valid is not None and not ops.window_kernels_take(L, hp, hd, rel_ld):
-            q_valid = None  # (the general kernels process every row)
         if ops.rel_bias_applicable(nh, hp, rel_ld):
             rel = ops.rel_bias_fwd(qkv, Bk["Rcat"], nb, nh, L, hp, hd, q_valid=q_valid, kw=qhw[1])
         else:
@@ -198,7 +201,7 @@ class SamEncoder:
             ops.gemm_raw(qkv, Bk["Rcat"], rel, nb * nh, rel_ld, hp, hp, hp, L * rel_ld, a_idx=hrow, batch=(L, 1),
                          sA=(ld, 0), sB=(rel_ld * hp, 0), sC=(rel_ld, 0))
         o, actx = attention_fwd(qkv, nb, L, nh, hp, 0, nh * hp, 2 * nh * hp, hd ** -0.5, rel=rel, rel_hw=(Bk["khp"], qhw[1]), save=save, hs_valid=hd,
-                                q_valid=q_valid)
+                                q_valid=q_valid, pad_row=pad_row)
         del rel
         r1 = None if f32 else x  # bf16 stream: x1 = x + proj(...) in the GEMM epilogue
         if ws > 0:  # un-partition = gather the real tokens' rows of the windowed attention output (padding rows are dropped)

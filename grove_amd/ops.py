@@ -257,7 +257,7 @@ def window_kernels_take(L, hs, hs_valid, rel_ld):
 
 
 def flash_attn(qkv, B, L, H, hs, q_off, k_off, v_off, alpha, *, causal=False, kv_len=None, rel=None, rel_hw=(0, 0), out=None,
-               want_lse=False, hs_valid=0, q_valid=None):
+               want_lse=False, hs_valid=0, q_valid=None, pad_row=None):
     """Fused attention over a fused qkv activation [B*L, ld]; returns (out [B*L, H*hs], lse or None)."""
     dev = qkv.device
     ld = qkv.stride(0)
@@ -276,6 +276,9 @@ def flash_attn(qkv, B, L, H, hs, q_off, k_off, v_off, alpha, *, causal=False, kv
     p.rel_ld = rel.shape[-1] if rel is not None else 0
     p.hs_valid = hs_valid
     p.q_valid = _p(q_valid)
+    if pad_row is not None:  # the qkv row of a padded position (same column layout as a row of qkv)
+        assert q_valid is not None and pad_row.numel() == qkv.shape[1]
+        p.pad_k, p.pad_v = _p(pad_row.view(-1)[k_off:]), _p(pad_row.view(-1)[v_off:])
     _lib.check(_lib.lib().grove_flash_attn_fwd(C.byref(p), _stream()), "grove_flash_attn_fwd")
     return out, lse
 
@@ -339,7 +342,7 @@ def flash_attn_kv(q, k, v, B, H, Lq, Lk, hs, alpha, *, sq, sk, sv, ld_q, ld_k, l
     return out
 
 def flash_attn_bwd(qkv, out, d_out, lse, dqkv, B, L, H, hs, q_off, k_off, v_off, alpha, *, causal=False, kv_len=None, rel=None,
-                   rel_hw=(0, 0), want_drel=False, hs_valid=0, q_valid=None):
+                   rel_hw=(0, 0), want_drel=False, hs_valid=0, q_valid=None, pad_row=None):
     dev = qkv.device
     ld, ldd = qkv.stride(0), dqkv.stride(0)
     delta = torch.empty((B * H, L), dtype=torch.float32, device=dev)
@@ -359,6 +362,9 @@ def flash_attn_bwd(qkv, out, d_out, lse, dqkv, B, L, H, hs, q_off, k_off, v_off,
     p.rel_ld = rel.shape[-1] if rel is not None else 0
     p.hs_valid = hs_valid
     p.q_valid = _p(q_valid)
+    if pad_row is not None:
+        assert q_valid is not None and pad_row.numel() == qkv.shape[1]
+        p.pad_k, p.pad_v = _p(pad_row.view(-1)[k_off:]), _p(pad_row.view(-1)[v_off:])
     _lib.check(_lib.lib().grove_flash_attn_bwd(C.byref(p), _stream()), "grove_flash_attn_bwd")
     return drel
 

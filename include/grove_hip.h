@@ -292,6 +292,9 @@ typedef struct grove_flash_attn_params {
                        dropped as queries): rows of o / lse / dq / drel at the other positions are NOT written and d_o there is NOT read.
                        The general kernels ignore the field and process every row (the caller then supplies zero d_o rows there);
                        grove_flash_attn_window_kernels_on() tells which family runs a fitting problem */
+  const void* pad_k; const void* pad_v; /* with q_valid, window kernels only: bf16 rows [H*hs] = k / v of a padded position (a zero token's
+                       projection = the bias), or NULL. Given, the k / v rows at padded positions are NOT read (the caller need not
+                       fill them) and dk / dv there are NOT written */
 } grove_flash_attn_params;
 int grove_flash_attn_fwd(const grove_flash_attn_params* p, void* stream);
 int grove_flash_attn_bwd(const grove_flash_attn_params* p, void* stream);

@@ -1232,6 +1232,29 @@ def test_window_attention_valid_queries(dev):
     close(dqkv[:, 2 * H * hs:], gref[:, 2 * H * hs:], 2e-2, "dv")
     close(drel[hm.to(dev)], relr.grad[hm], 2e-2, "d rel' at the valid queries")
     assert torch.isnan(dqkv[(~rows).to(dev), :H * hs].float()).all(), "rows of dq at padded positions must not be written"
+    # pad_row: k / v of the padded positions come from ONE row (the bias); the rows of qkv there are not read (NaN) and dk / dv there
+    # are not written. Reference = the same run with the row copied into every padded position.
+    pad_row = torch.zeros(3, H, hs)
+    pad_row[..., :hd] = torch.randn(3, H, hd, generator=g) * 0.7
+    pad_row = pad_row.view(-1).to(bf16)
+    filled = qkv.clone()
+    filled[~rows] = pad_row
+    o_f, lse_f = ops.flash_attn(filled.to(dev), B, L, H, hs, 0, H * hs, 2 * H * hs, alpha, rel=relp.to(dev), rel_hw=(16, ws), want_lse=True,
+                                hs_valid=hd, q_valid=qv)
+    dq_f = torch.full((B * L, 3 * H * hs), float("nan"), dtype=bf16, device=dev)
+    dr_f = ops.flash_attn_bwd(filled.to(dev), o_f, do_dev.to(dev), lse_f, dq_f, B, L, H, hs, 0, H * hs, 2 * H * hs, alpha, rel=relp.to(dev),
+                              rel_hw=(16, ws), want_drel=True, hs_valid=hd, q_valid=qv)
+    holes = qkv.clone()
+    holes[~rows] = float("nan")
+    o_p, lse_p = ops.flash_attn(holes.to(dev), B, L, H, hs, 0, H * hs, 2 * H * hs, alpha, rel=relp.to(dev), rel_hw=(16, ws), want_lse=True,
+                                hs_valid=hd, q_valid=qv, pad_row=pad_row.to(dev))
+    dq_p = torch.full((B * L, 3 * H * hs), float("nan"), dtype=bf16, device=dev)
+    dr_p = ops.flash_attn_bwd(holes.to(dev), o_p, do_dev.to(dev), lse_p, dq_p, B, L, H, hs, 0, H * hs, 2 * H * hs, alpha, rel=relp.to(dev),
+                              rel_hw=(16, ws), want_drel=True, hs_valid=hd, q_valid=qv, pad_row=pad_row.to(dev))
+    rd = rows.to(dev)
+    assert torch.equal(o_p[rd], o_f[rd]) and torch.equal(lse_p[hm.to(dev)], lse_f[hm.to(dev)]), "forward with the padded keys taken from pad_row"
+    assert torch.equal(dq_p[rd], dq_f[rd]) and torch.equal(dr_p[hm.to(dev)], dr_f[hm.to(dev)]), "backward with the padded keys taken from pad_row"
+    assert torch.isnan(dq_p[~rd].float()).all(), "dq / dk / dv rows at padded positions must not be written"
 
 
 def test_rel_bias_streams_skip_padded_positions(dev):
