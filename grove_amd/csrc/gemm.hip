@@ -1147,11 +1147,8 @@ inline bool stream_capturing(hipStream_t s) {
   return hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
 }
 
-inline const pp_table_dev* pp_table(const pp_table_key& key, const sk_plan& pl, hipStream_t s) {
-  std::lock_guard<std::mutex> lk(g_pp_mutex);
-  auto it = g_pp_tables.find(key);
-  if (it != g_pp_tables.end()) return &it->second;
-  if (stream_capturing(s)) return nullptr;  // no allocation inside a capture: run the shape once before capturing
+// the lists of a shape on the host: `t` = the work list (rows of G entries, see pp_work), `fix` = the split tiles {m0, n0, first slot, parts}
+inline void build_work_list(const pp_table_key& key, const sk_plan& pl, std::vector<i32x4_t>& t, std::vector<i32x4_t>& fix) {
   const int G = key.G, nk = key.nk, bm = key.bm, S = key.S;
   const int tiles = key.tiles_m * key.tiles_n;
   // tile L -> origin: bands of 8 tile rows, column-major inside a band (the last band may be shorter)
@@ -1163,8 +1160,8 @@ inline const pp_table_dev* pp_table(const pp_table_key& key, const sk_plan& pl, 
   };
   const int n_dp_max = S ? pl.rounds : (tiles + G - 1) / G;
   const int rows = 1 + n_dp_max + 1;
-  std::vector<i32x4_t> t((size_t)rows * G, i32x4_t{0, 0, 0, 0});
-  std::vector<i32x4_t> fix;
+  t.assign((size_t)rows * G, i32x4_t{0, 0, 0, 0});
+  fix.clear();
   for (int w = 0; w < G; ++w) {
     int n = 0, NT = 0;
     auto push = [&](int L, int k0, int k1, int part) {
@@ -1187,7 +1184,16 @@ inline const pp_table_dev* pp_table(const pp_table_key& key, const sk_plan& pl, 
       origin(pl.rounds * G + a, m0, n0);
       fix.push_back(i32x4_t{m0, n0, a * pl.parts, pl.parts});
     }
-  pp_table_dev d{nullptr, nullptr, (int)fix.size(), S ? pl.tail * pl.parts : 0};
+}
+
+inline const pp_table_dev* pp_table(const pp_table_key& key, const sk_plan& pl, hipStream_t s) {
+  std::lock_guard<std::mutex> lk(g_pp_mutex);
+  auto it = g_pp_tables.find(key);
+  if (it != g_pp_tables.end()) return &it->second;
+  if (stream_capturing(s)) return nullptr;  // no allocation inside a capture: run the shape once before capturing
+  std::vector<i32x4_t> t, fix;
+  build_work_list(key, pl, t, fix);
+  pp_table_dev d{nullptr, nullptr, (int)fix.size(), key.S ? pl.tail * pl.parts : 0};
   bool ok = hipMalloc((void**)&d.table, t.size() * sizeof(i32x4_t)) == hipSuccess &&
             hipMemcpy(d.table, t.data(), t.size() * sizeof(i32x4_t), hipMemcpyHostToDevice) == hipSuccess;
   if (ok && !fix.empty())
@@ -1333,6 +1339,26 @@ int grove_gemm_fp8_pipelined(const grove_gemm_fp8_params* q, hipStream_t s) {
   if (q->act == GROVE_ACT_NONE) return big ? launch_pp_act<256, false, -1, true>(p, s, q->scale_a, q->scale_b) : launch_pp_act<192, false, -1, true>(p, s, q->scale_a, q->scale_b);
   return big ? launch_pp_act<256, false, GROVE_ACT_QUICKGELU, true>(p, s, q->scale_a, q->scale_b)
              : launch_pp_act<192, false, GROVE_ACT_QUICKGELU, true>(p, s, q->scale_a, q->scale_b);
+}
+
+// Host-only view of the pipelined kernels' work list (no device needed): what `grid` blocks do for tiles_m x tiles_n output tiles of
+// BM x 256 with nk K tiles. list: int32 [rows][grid][4] (row 0 = {K tiles of the block's stream, segments, 0, 0}; row 1 + i = segment
+// {m0, n0, k0 | k1 << 16, part}), fixups: int32 [n][4] = {m0, n0, first slot, parts}. Returns the number of rows (negative: an error or a
+// buffer too small); *n_fixups and *k_tiles_per_part (0 = whole tiles only) describe the stream-K tail. mode as grove_gemm_set_stream_k.
+extern "C" int grove_gemm_work_list(int bm, int tiles_m, int tiles_n, int nk, int num_cus, int mode, int32_t* list, int64_t list_cap,
+                                    int32_t* fixups, int64_t fixups_cap, int* n_fixups, int* k_tiles_per_part) {
+  GROVE_CHECK((bm == 192 || bm == 256) && tiles_m > 0 && tiles_n > 0 && nk > 0 && nk < 65536 && num_cus > 0, GROVE_E_SHAPE, "gemm_work_list: bad arguments");
+  const long tiles = (long)tiles_m * tiles_n;
+  const sk_plan pl = plan_stream_k(tiles, nk, num_cus, mode);
+  const int grid = pl.S ? num_cus : (int)(tiles < num_cus ? tiles : num_cus);
+  std::vector<i32x4_t> t, fix;
+  build_work_list(pp_table_key{0, bm, tiles_m, tiles_n, nk, grid, pl.S}, pl, t, fix);
+  GROVE_CHECK((int64_t)t.size() * 4 <= list_cap && (int64_t)fix.size() * 4 <= fixups_cap, GROVE_E_WORKSPACE, "gemm_work_list: %zu + %zu entries do not fit the buffers", t.size(), fix.size());
+  memcpy(list, t.data(), t.size() * sizeof(i32x4_t));
+  if (!fix.empty()) memcpy(fixups, fix.data(), fix.size() * sizeof(i32x4_t));
+  *n_fixups = (int)fix.size();
+  *k_tiles_per_part = pl.S;
+  return (int)(t.size() / grid);
 }
 
 extern "C" int grove_gemm_set_stream_k(int mode) {

@@ -123,6 +123,13 @@ int grove_gemm_last_epilogue(void);
  * where the cost model says it pays, 0 = never (whole tiles only), 2 = wherever it applies (tests).
  * grove_gemm_last_stream_k: K tiles per part of the last pipelined launch, 0 = it ran whole tiles only. */
 int grove_gemm_set_stream_k(int mode);
+/* Host-only view of the persistent kernels' work list (needs no device): what each of the `grid` = min(tiles, num_cus) (num_cus with a
+ * stream-K tail) blocks does for tiles_m x tiles_n output tiles of bm x 256 (bm = 192 / 256) with nk K tiles of 64.
+ * list: int32 [rows][grid][4] — row 0 = {K tiles of the block's stream, its segments, 0, 0}, row 1 + i = segment {m0, n0, k0 | k1 << 16,
+ * part}: part 0 = whole tile with epilogue, part 1 + s = K range [k0, k1) whose raw fp32 sum goes to workspace slot s.
+ * fixups: int32 [n][4] = split tile {m0, n0, first slot, parts}. Returns rows (< 0: error / buffers too small). */
+int grove_gemm_work_list(int bm, int tiles_m, int tiles_n, int nk, int num_cus, int mode, int32_t* list, int64_t list_cap,
+                         int32_t* fixups, int64_t fixups_cap, int* n_fixups, int* k_tiles_per_part);
 int grove_gemm_last_stream_k(void);
 /* A/B staging variant: 1 = LDS-DMA (global_load_lds, default), 0 = register staged */
 int grove_gemm_set_staging(int use_lds_dma);
