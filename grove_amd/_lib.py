@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libgrove_hip.so")
+LIB_PATH = os.environ.get("GROVE_HIP_LIB") or os.path.join(_HERE, "csrc", "libgrove_hip.so")  # (GROVE_HIP_LIB: another build of the library, for A/B runs)
 
 c_i32, c_i64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 

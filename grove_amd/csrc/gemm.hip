@@ -926,10 +926,10 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
   if constexpr (FP8) {                                                                                                    \
     _Pragma("unroll") for (int i = 0; i < MIH; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                         \
         acc[IO + i][JO + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(cat8(BB[j][0], BB[j][1]), cat8(af[i][0], af[i][1]), \
-                                                                               acc[IO + i][JO + j], 0, 0, 0, 127, 0, 127); \
+                                                                               FIRST ? zero4 : acc[IO + i][JO + j], 0, 0, 0, 127, 0, 127); \
   } else {                                                                                                                \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < MIH; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) \
-        acc[IO + i][JO + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BB[j][ks], af[i][ks], acc[IO + i][JO + j], 0, 0, 0); \
+        acc[IO + i][JO + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BB[j][ks], af[i][ks], (FIRST && ks == 0) ? zero4 : acc[IO + i][JO + j], 0, 0, 0); \
   }                                                                                                                       \
   __builtin_amdgcn_s_setprio(0);                                                                                          \
   __builtin_amdgcn_sched_barrier(0);
@@ -970,9 +970,12 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
   // between the half-tiles already issued and the ones issued now: allowing 8 + RELAX operations in flight retires the same
   // loads as vmcnt(8) does elsewhere and lets the stores drain behind the MFMAs instead of stalling the first phase (~1500
   // clocks per output tile). From the next K tile on, vmcnt(8) covers only loads issued after the stores.
-  auto k_tile = [&](auto steady, auto relax_stores, int T) {
+  // FIRST: a segment's first K tile starts its accumulators from the zero operand of the MFMA (no 128-register clear per tile)
+  auto k_tile = [&](auto steady, auto relax_stores, auto first, int T) {
     constexpr bool STEADY = decltype(steady)::value;
     constexpr int RELAX = decltype(relax_stores)::value;
+    constexpr bool FIRST = decltype(first)::value && !FP8;  // (the FP8 instances keep the explicit clear: with the zero operand hipcc spills 4x more there)
+    const f32x4_t zero4 = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const char* st = smem + (T & 1) * P_STAGE;
     const int q = 4 * T;
     // ph1
@@ -1005,14 +1008,14 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
     const i32x4_t e = sload4(my_work + (sg + 1) * G);
     const int m0 = e[0], n0 = e[1], nks = (int)((unsigned)e[2] >> 16) - (e[2] & 0xffff), part = e[3];
     const int ns = min(max(NT - 2 - T, 0), nks);
-    int k = 0;
+    int k = 1;
     using no_relax = std::integral_constant<int, 0>;
-    if (relax && ns > 0) {
-      k_tile(std::true_type{}, std::integral_constant<int, 4 * MIH>{}, T);
-      ++k, ++T;
-    }
-    for (; k < ns; ++k, ++T) k_tile(std::true_type{}, no_relax{}, T);
-    for (; k < nks; ++k, ++T) k_tile(std::false_type{}, no_relax{}, T);
+    if (relax && ns > 0) k_tile(std::true_type{}, std::integral_constant<int, 4 * MIH>{}, std::true_type{}, T);
+    else if (ns > 0) k_tile(std::true_type{}, no_relax{}, std::true_type{}, T);
+    else k_tile(std::false_type{}, no_relax{}, std::true_type{}, T);
+    ++T;
+    for (; k < ns; ++k, ++T) k_tile(std::true_type{}, no_relax{}, std::false_type{}, T);
+    for (; k < nks; ++k, ++T) k_tile(std::false_type{}, no_relax{}, std::false_type{}, T);
     // Both groups run their epilogues in the same barrier interval: the leading group waits one barrier here (the lagging
     // group is in its last MFMA segment), the lagging group waits one after its epilogue, which restores the one-barrier lag.
     // An epilogue is bound by the issue latency of its own VALU / store stream, so two waves per SIMD take little longer
@@ -1041,10 +1044,12 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
       else gemm_epilogue_wide<MIH, BMH, ACT>(p, acc, mw0, nw0, fr, fq, ACT < 0 ? 1.f : scale);
       relax = interior && !p.aux && !FP8;  // exactly 4 * MIH stores per wave were issued (FP8: the scale loads sit in the queue too)
     }
+    if constexpr (FP8) {
 #pragma unroll
-    for (int i = 0; i < 2 * MIH; ++i)
+      for (int i = 0; i < 2 * MIH; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
     if (wr == 1) __builtin_amdgcn_s_barrier();
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();
