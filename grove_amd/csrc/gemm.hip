@@ -1008,12 +1008,14 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
     const i32x4_t e = sload4(my_work + (sg + 1) * G);
     const int m0 = e[0], n0 = e[1], nks = (int)((unsigned)e[2] >> 16) - (e[2] & 0xffff), part = e[3];
     const int ns = min(max(NT - 2 - T, 0), nks);
-    int k = 1;
+    int k = 0;
     using no_relax = std::integral_constant<int, 0>;
-    if (relax && ns > 0) k_tile(std::true_type{}, std::integral_constant<int, 4 * MIH>{}, std::true_type{}, T);
-    else if (ns > 0) k_tile(std::true_type{}, no_relax{}, std::true_type{}, T);
-    else k_tile(std::false_type{}, no_relax{}, std::true_type{}, T);
-    ++T;
+    if constexpr (!FP8) {  // (the FP8 instances clear explicitly below and never relax: two K-tile bodies instead of five)
+      if (relax && ns > 0) k_tile(std::true_type{}, std::integral_constant<int, 4 * MIH>{}, std::true_type{}, T);
+      else if (ns > 0) k_tile(std::true_type{}, no_relax{}, std::true_type{}, T);
+      else k_tile(std::false_type{}, no_relax{}, std::true_type{}, T);
+      ++k, ++T;
+    }
     for (; k < ns; ++k, ++T) k_tile(std::true_type{}, no_relax{}, std::false_type{}, T);
     for (; k < nks; ++k, ++T) k_tile(std::false_type{}, no_relax{}, std::false_type{}, T);
     // Both groups run their epilogues in the same barrier interval: the leading group waits one barrier here (the lagging
