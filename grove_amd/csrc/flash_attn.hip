@@ -352,6 +352,7 @@ __global__ __launch_bounds__(NTHR, 2) void flash_fwd_kernel(const grove_flash_at
 }
 
 // ================================================================================ delta = rowsum(dO * O)
+template <bool VEC16>  // 16-byte loads when o / d_o rows allow them (the product's layouts do), else 4-byte
 __global__ __launch_bounds__(NTHR) void flash_delta_kernel(const grove_flash_attn_params p) {
   // one 16-lane group per (b, h, q) row
   const int64_t t = (int64_t)blockIdx.x * (NTHR / 16) + (threadIdx.x >> 4);
@@ -364,9 +365,17 @@ __global__ __launch_bounds__(NTHR) void flash_delta_kernel(const grove_flash_att
     const int b = bh / p.H, h = bh - b * p.H;
     const bf16_raw* O = (const bf16_raw*)p.o + (int64_t)b * p.so + (int64_t)qi * p.ld_o + h * p.hs;
     const bf16_raw* dO = (const bf16_raw*)p.d_o + (int64_t)b * p.sdo + (int64_t)qi * p.ld_do + h * p.hs;
-    for (int c = l16 * 2; c < p.hs; c += 32) {
-      const unsigned a = *(const unsigned*)(O + c), d = *(const unsigned*)(dO + c);
-      acc += bf_lo(a) * bf_lo(d) + bf_hi(a) * bf_hi(d);
+    if constexpr (VEC16) {
+      for (int c = l16 * 8; c < p.hs; c += 128) {  // a 128-wide head row is one load per operand for the 16-lane group
+        const u32x4_t a = *(const u32x4_t*)(O + c), d = *(const u32x4_t*)(dO + c);
+        acc += bf_lo(a.x) * bf_lo(d.x) + bf_hi(a.x) * bf_hi(d.x) + bf_lo(a.y) * bf_lo(d.y) + bf_hi(a.y) * bf_hi(d.y) +
+               bf_lo(a.z) * bf_lo(d.z) + bf_hi(a.z) * bf_hi(d.z) + bf_lo(a.w) * bf_lo(d.w) + bf_hi(a.w) * bf_hi(d.w);
+      }
+    } else {
+      for (int c = l16 * 2; c < p.hs; c += 32) {
+        const unsigned a = *(const unsigned*)(O + c), d = *(const unsigned*)(dO + c);
+        acc += bf_lo(a) * bf_lo(d) + bf_hi(a) * bf_hi(d);
+      }
     }
   }
 #pragma unroll
@@ -803,7 +812,9 @@ extern "C" int grove_flash_attn_bwd(const grove_flash_attn_params* p, void* stre
     return GROVE_OK;
   }
   const int64_t nrows = (int64_t)p->B * p->H * p->Lq;
-  hipLaunchKernelGGL(flash_delta_kernel, dim3((unsigned)((nrows + 15) / 16)), dim3(NTHR), 0, s, *p);
+  const bool vec16 = p->ld_o % 8 == 0 && p->ld_do % 8 == 0 && p->so % 8 == 0 && p->sdo % 8 == 0 && (((uintptr_t)p->o | (uintptr_t)p->d_o) & 15) == 0;
+  if (vec16) hipLaunchKernelGGL(flash_delta_kernel<true>, dim3((unsigned)((nrows + 15) / 16)), dim3(NTHR), 0, s, *p);
+  else hipLaunchKernelGGL(flash_delta_kernel<false>, dim3((unsigned)((nrows + 15) / 16)), dim3(NTHR), 0, s, *p);
   const int nrel = p->rel ? p->rel_ld : 0;
   dim3 gk((p->Lk + 127) / 128, p->H, p->B), gq((p->Lq + 127) / 128, p->H, p->B);
 #define BWD_L(HS, NRK)                                                                                     \
