@@ -1123,7 +1123,7 @@ inline int num_cus() {
 // them back and some of the L2 sharing between neighbouring tiles: SK_FIXED K tiles' worth (~30 us, measured).
 // (Equal parts, not one evenly dealt stream: blocks that share an operand panel stay in the same K phase, so the panel is
 // fetched into L2 once — dealt out unevenly, 240 tiles on 256 CUs ran 1.5x SLOWER than whole tiles.)
-constexpr int SK_FIXED = 20;
+constexpr int SK_FIXED = 20;  // ... at 256 parts (128 tiles in halves); the stores and the fix-up scale with the parts, a third of it is launch gaps
 struct sk_plan { int S, parts, rounds, tail; double kt_units; };
 inline sk_plan plan_stream_k(long tiles, int nk, int G, int mode) {  // mode: 0 = never, 1 = where it pays, 2 = wherever it applies (tests)
   sk_plan pl;
@@ -1133,7 +1133,9 @@ inline sk_plan plan_stream_k(long tiles, int nk, int G, int mode) {  // mode: 0 
   const int s = std::min(G / pl.tail, 4);
   if (s < 2) return pl;
   const int S = (nk + s - 1) / s;
-  const double t = (double)pl.rounds * nk + S + SK_FIXED;
+  const double pf = (double)(pl.tail * s) / G;  // part blocks / CUs: 5 K tiles for the extra launch + the stores and read-backs (measured: 20 at pf = 1, ~8 at 0.56)
+  const double fixed = 5.0 + (SK_FIXED - 5.0) * pf * pf;
+  const double t = (double)pl.rounds * nk + S + fixed;
   if (S >= 2 && (mode == 2 || t < 0.97 * pl.kt_units)) pl.S = S, pl.parts = (nk + S - 1) / S, pl.kt_units = t;
   return pl;
 }
@@ -1434,7 +1436,7 @@ extern "C" int grove_gemm_bf16(const grove_gemm_params* pp, void* stream) {
     const sk_plan pl = plan_stream_k(tiles, p.K / 64, 256, bk64 ? g_gemm_stream_k : 0);
     if (pl.S) return pl.kt_units * kt + r * fixed;  // the tail is dealt out by K tiles: every CU busy for the same time
     const double fill = (double)tiles / (r * 256.0);
-    return r * (nk64 * kt * (0.6 + 0.4 * fill) + fixed);
+    return r * (nk64 * kt * (0.7 + 0.3 * fill) + fixed);
   };
   const double cp256 = pp_cost(tp256, 1.5, 3.0 + 3.0 * out_scale);
   const double cp192 = pp_cost(tp192, 1.17, 0.8 * (3.0 + 3.0 * out_scale));

@@ -26,7 +26,9 @@ for M, N, K in shapes:
                 if name == "auto":
                     ref = out.clone()
                 else:
-                    assert (out.float() - ref.float()).abs().max().item() == 0, (name, M, N, K)
+                    # bit-identical unless a stream-K split changed the fp32 sum order of some tiles (then: bf16 rounding)
+                    err = (out.float() - ref.float()).abs().max().item()
+                    assert err <= 2 ** -7 * ref.float().abs().max().item(), (name, M, N, K, err)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(5):
