@@ -407,7 +407,7 @@ constexpr int P_STAGE = 4 * P_HALF;              // A_lo | B_lo | B_hi | A_hi (s
 //   loads(h0) compute(h0) loads(h1) stores(h0) compute(h1) stores(h1)
 template <int MIH, int BMH, int ACT>
 __device__ __forceinline__ void gemm_epilogue_fast(const grove_gemm_params& p, f32x4_t (&acc)[2 * MIH][4], const int mw0, const int nw0,
-                                                   const int fr, const int fq, const float scale, const bool transposed) {
+                                                   const int fr, const int fq, const float scale) {
   constexpr bool PLAIN = ACT < 0;
   constexpr bool PAIR = ACT == GROVE_ACT_SWIGLU_PAIR;
   const int n0 = nw0 + fq * 8;  // column group 0; group 1 is 128 columns on
@@ -498,45 +498,14 @@ __device__ __forceinline__ void gemm_epilogue_fast(const grove_gemm_params& p, f
         }
       }
   };
-  // THE LANE MAP OF THE STORES. In the accumulator map lane l = 16 fq + fr holds row fr: the 4 lanes of a quad are 4 different rows,
-  // and the memory pipeline takes a 16-byte-per-lane store one QUAD per clock when the quad's 64 bytes are contiguous, one LANE per
-  // clock when they are not (tools/micro/store_pattern.hip: the same 128 KB tile leaves an otherwise idle CU in 1.1 us quad-contiguous
-  // and in 3.75 us in the accumulator map — exactly the epilogue's residue per tile that survived every other experiment). So the packed
-  // rows are transposed across the lanes first (ds_bpermute: LDS crossbar, no memory): lane l' = 4 r + c takes row r, chunk c from lane
-  // 16 c + r, and a quad stores 64 contiguous bytes.
-  const int lane_t = fq * 16 + fr;
-  const int r_t = lane_t >> 2, c_t = lane_t & 3;
-  const int src_t = (c_t * 16 + r_t) * 4;
   auto store = [&](const int h) {
-    bf16_raw* cp = (bf16_raw*)p.C + (int64_t)(mw0 + r_t + h * BMH) * p.ldc + (PAIR ? ((nw0 + c_t * 8) >> 3) * 4 : nw0 + c_t * 8);
-    if (!transposed) {  // (the block's last tile: nothing follows that the stores could hide under, the permutes would only add latency)
-      bf16_raw* cd = (bf16_raw*)p.C + (row0 + h * BMH) * p.ldc + (PAIR ? (n0 >> 3) * 4 : n0);
-#pragma unroll
-      for (int i = 0; i < MIH; ++i)
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-          if constexpr (PAIR) *(u32x2_t*)(cd + (int64_t)(i * 16) * p.ldc + g * 64) = u32x2_t{outp[i][g].x, outp[i][g].y};
-          else *(u32x4_t*)(cd + (int64_t)(i * 16) * p.ldc + g * 128) = outp[i][g];
-        }
-      return;
-    }
-    // (inline asm: through the builtin hipcc treats the permute as an LDS access that may alias the LDS-DMA targets and guards the
-    // K loop's first ds_read of every K tile with s_waitcnt vmcnt(0) — the staging queue drained once per K tile, 4-6 % on long K)
+    bf16_raw* cp = (bf16_raw*)p.C + (row0 + h * BMH) * p.ldc + (PAIR ? (n0 >> 3) * 4 : n0);
 #pragma unroll
     for (int i = 0; i < MIH; ++i)
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
-        const u32x4_t o = outp[i][g];
-        unsigned tx, ty, tz = 0u, tw = 0u;
-        asm volatile("ds_bpermute_b32 %0, %1, %2" : "=v"(tx) : "v"(src_t), "v"(o.x));
-        asm volatile("ds_bpermute_b32 %0, %1, %2" : "=v"(ty) : "v"(src_t), "v"(o.y));
-        if constexpr (!PAIR) {
-          asm volatile("ds_bpermute_b32 %0, %1, %2" : "=v"(tz) : "v"(src_t), "v"(o.z));
-          asm volatile("ds_bpermute_b32 %0, %1, %2" : "=v"(tw) : "v"(src_t), "v"(o.w));
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tx), "+v"(ty), "+v"(tz), "+v"(tw));
-        if constexpr (PAIR) *(u32x2_t*)(cp + (int64_t)(i * 16) * p.ldc + g * 64) = u32x2_t{tx, ty};
-        else *(u32x4_t*)(cp + (int64_t)(i * 16) * p.ldc + g * 128) = u32x4_t{tx, ty, tz, tw};
+        if constexpr (PAIR) *(u32x2_t*)(cp + (int64_t)(i * 16) * p.ldc + g * 64) = u32x2_t{outp[i][g].x, outp[i][g].y};
+        else *(u32x4_t*)(cp + (int64_t)(i * 16) * p.ldc + g * 128) = outp[i][g];
       }
   };
   if (p.residual) load_res(0);
@@ -1073,7 +1042,7 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
       const int mw0 = m0 + wr * WRH, nw0 = n0 + wc * 32;
       const bool interior = fast_addr && m0 + BM <= p.M && n0 + P_BN <= p.N;
       if constexpr (FP8) fp8_scale_acc<MIH, BMH>(p, work, acc, mw0, nw0, fr, fq);
-      if (interior) gemm_epilogue_fast<MIH, BMH, ACT>(p, acc, mw0, nw0, fr, fq, ACT < 0 ? 1.f : scale, sg + 1 < nseg);
+      if (interior) gemm_epilogue_fast<MIH, BMH, ACT>(p, acc, mw0, nw0, fr, fq, ACT < 0 ? 1.f : scale);
       else gemm_epilogue_wide<MIH, BMH, ACT>(p, acc, mw0, nw0, fr, fq, ACT < 0 ? 1.f : scale);
       relax = interior && !p.aux && !FP8;  // exactly 4 * MIH stores per wave were issued (FP8: the scale loads sit in the queue too)
     }
@@ -1129,7 +1098,7 @@ __global__ __launch_bounds__(64 * FIX_WAVES) void gemm_pp_fixup_kernel(const gro
   const int mw0 = m0 + wr * WRH, nw0 = n0 + wc * 32;
   const bool interior = fast_addr && m0 + BM <= p.M && n0 + P_BN <= p.N;
   if constexpr (FP8) fp8_scale_acc<MIH, BMH>(p, work, acc, mw0, nw0, fr, fq);
-  if (interior) gemm_epilogue_fast<MIH, BMH, ACT>(p, acc, mw0, nw0, fr, fq, ACT < 0 ? 1.f : scale, false);
+  if (interior) gemm_epilogue_fast<MIH, BMH, ACT>(p, acc, mw0, nw0, fr, fq, ACT < 0 ? 1.f : scale);
   else gemm_epilogue_wide<MIH, BMH, ACT>(p, acc, mw0, nw0, fr, fq, ACT < 0 ? 1.f : scale);
 }
 
