@@ -1253,6 +1253,11 @@ int launch_pp_act(const grove_gemm_params& p, hipStream_t s, const float* row_sc
   sk_plan pl = plan_stream_k(tiles, nk, G, g_gemm_stream_k);
   if (pl.S && !(work.ws = stream_k_workspace(s, dev, G))) pl = plan_stream_k(tiles, nk, G, 0);
   const int grid = pl.S ? G : (int)(tiles < G ? tiles : G);  // (the list is laid out for this grid: its row stride and wgid map)
+  if (pl.S) {  // keep the whole-tile list of the shape at hand too: a later launch inside a stream capture on a stream without a
+               // workspace falls back to it and must not have to allocate
+    const int grid0 = (int)(tiles < G ? tiles : G);
+    (void)pp_table(pp_table_key{dev, BM, tiles_m, tiles_n, nk, grid0, 0}, plan_stream_k(tiles, nk, G, 0), s);
+  }
   const pp_table_dev* td = pp_table(pp_table_key{dev, BM, tiles_m, tiles_n, nk, grid, pl.S}, pl, s);
   GROVE_CHECK(td != nullptr, GROVE_E_HIP, "gemm: no work list for %d x %d tiles (first use of a shape inside a stream capture, or out of memory)", tiles_m, tiles_n);
   GROVE_CHECK(td->n_slots <= G, GROVE_E_WORKSPACE, "gemm: %d stream-K parts for %d slots", td->n_slots, G);

@@ -1293,3 +1293,34 @@ def test_rel_bias_streams_skip_padded_positions(dev):
     want = dq0.float().view(nb, L, 3 * nh, hp).clone()
     want[:, :, :nh] += add * mask[:, :, None, None]
     close(dq, want.view(nb * L, ld), 2 ** -7, "dq += d rel' . Rcat at the real positions, untouched elsewhere")
+
+
+def test_gemm_stream_k_shape_inside_a_stream_capture(dev):
+    """A shape whose eager launches take the stream-K tail, launched inside a HIP-graph capture on a stream that has no stream-K
+    workspace yet: the library must not allocate there — it falls back to whole tiles (the list was built together with the
+    stream-K one) and the replayed graph gives the whole-tile result bit for bit."""
+    from grove_amd import _lib, ops
+    L = _lib.lib()
+    M, N, K = 20200, 1000, 2560
+    g = torch.Generator().manual_seed(3)
+    a = (torch.randn(M, K, generator=g) * 0.5).to(bf16).to(dev)
+    b = (torch.randn(N, K, generator=g) * 0.05).to(bf16).to(dev)
+    try:
+        L.grove_gemm_set_tile_m(256)
+        eager = ops.linear(a, b)                       # warm-up on the current stream: stream-K list + whole-tile list
+        assert L.grove_gemm_last_stream_k() > 0
+        L.grove_gemm_set_stream_k(0)
+        whole = ops.linear(a, b)
+        L.grove_gemm_set_stream_k(1)
+        out = torch.empty_like(whole)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):                  # (captures on a fresh side stream)
+            ops.linear(a, b, out=out)
+        out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, whole) or torch.equal(out, eager)
+        close(out, eager, 2 ** -7, "captured launch vs eager stream-K launch")
+    finally:
+        L.grove_gemm_set_tile_m(0)
+        L.grove_gemm_set_stream_k(1)
