@@ -1178,14 +1178,15 @@ def test_rel_bias_streams(dev, nb, nh, size, hd, hp):
     assert torch.equal(dq.view(nb * L, 3 * nh, hp)[:, untouched.to(dev)], dq0.view(nb * L, 3 * nh, hp)[:, untouched.to(dev)]), "columns outside q[:hd]"
 
 
-def test_window_attention_valid_queries(dev):
+@pytest.mark.parametrize("valid", [[(14, 14), (4, 14), (14, 4), (4, 4)], [(1, 1), (3, 7), (14, 1), (9, 14)]])
+def test_window_attention_valid_queries(dev, valid):
     """q_valid of the window kernels: window b keeps its top-left vy x vx positions as queries (window_partition's padding is real as
     keys, dropped as queries). Against fp32 attention over ALL keys at the valid queries: o / lse forward; dq / d rel' at the valid
     queries and dk / dv everywhere backward, with NaN in d_o at the padded positions (never read) and NaN-filled outputs (rows at
-    padded positions stay untouched). The window shapes of a 32 x 32 grid: 14 x 14 (full), 4 x 14, 14 x 4, 4 x 4."""
+    padded positions stay untouched). The window shapes of a 32 x 32 grid — 14 x 14 (full), 4 x 14, 14 x 4, 4 x 4 — and odd ones (a single
+    query, one column, partial tiles in both query loops)."""
     from grove_amd import ops
     B, H, L, hs, hd, ws = 4, 16, 196, 96, 80, 14
-    valid = [(14, 14), (4, 14), (14, 4), (4, 4)]
     assert ops.window_kernels_take(L, hs, hd, 32)
     g = torch.Generator().manual_seed(77)
     alpha = hd ** -0.5
