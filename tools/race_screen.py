@@ -38,6 +38,7 @@ def screen(name, fn_ref, fn_new):
     bad += fails
 
 
+L.grove_gemm_set_stream_k(0)  # bit-for-bit against the two-barrier kernels needs whole tiles (a split K sum rounds differently); the split is screened below
 for (M, N, K) in [(2812, 4096, 64), (2812, 4096, 128), (2812, 4096, 192), (3000, 520, 1280), (32768, 1280, 256), (2812, 12288, 4096), (8200, 5120, 320)]:
     a = torch.randn(M, K, device=dev).to(bf); b = (torch.randn(N, K, device=dev) * 0.1).to(bf)
     bias = torch.randn(N, device=dev).to(bf); res = torch.randn(M, N, device=dev).to(bf)
@@ -53,6 +54,24 @@ for (M, N, K) in [(2812, 4096, 64), (2812, 4096, 128), (2812, 4096, 192), (3000,
                 o = ops.linear(a, b, **k2)
                 return (o, aux) if aux is not None else o
             screen(f"NT {M}x{N}x{K} tile {tm} {kw_name}", lambda: run(128), lambda: run(tm))
+L.grove_gemm_set_tile_m(0)
+# stream-K tail (parts through the workspace + fix-up launch): deterministic by construction — screened against its own first result,
+# whole-tile result within bf16 rounding
+L.grove_gemm_set_stream_k(1)
+for (M, N, K, tm) in [(32768, 1280, 5120, 256), (2812, 12288, 4096, 256), (20200, 1000, 2560, 256), (15350, 1000, 2560, 193)]:
+    a = torch.randn(M, K, device=dev).to(bf); b = (torch.randn(N, K, device=dev) * 0.1).to(bf)
+    bias = torch.randn(N, device=dev).to(bf); res = torch.randn(M, N, device=dev).to(bf)
+    def sk():
+        L.grove_gemm_set_tile_m(tm)
+        return ops.linear(a, b, bias, residual=res)
+    first = sk()
+    assert L.grove_gemm_last_stream_k() > 0, (M, N, K, tm)
+    L.grove_gemm_set_stream_k(0)
+    whole = sk()
+    L.grove_gemm_set_stream_k(1)
+    assert (first.float() - whole.float()).abs().max().item() <= 2 ** -7 * whole.float().abs().max().item()
+    screen(f"NT {M}x{N}x{K} tile {tm} stream-K (self)", sk, sk)
+L.grove_gemm_set_stream_k(0)
 L.grove_gemm_set_tile_m(0)
 # gathered A (27 taps) and SwiGLU pair
 G, T, H, W, Ci, Co = 2, 8, 16, 16, 128, 512
@@ -86,5 +105,6 @@ r0, r1 = tng(0), tng(1)
 assert (r0 - r1).abs().max().item() <= 2e-6 * r0.abs().max().item(), "TN gathered pipelined vs 128x128 kernel"
 screen("TN gathered conv3d wgrad (self)", lambda: tng(1), lambda: tng(1))
 L.grove_gemm_tn_set_pipelined(-1)
+L.grove_gemm_set_stream_k(1)
 print("TOTAL MISMATCHES", bad)
 sys.exit(1 if bad else 0)
