@@ -776,6 +776,8 @@ extern "C" int grove_flash_attn_fwd(const grove_flash_attn_params* p, void* stre
   if (rc) return rc;
   GROVE_CHECK(p->o, GROVE_E_SHAPE, "flash_attn_fwd: o required");
   hipStream_t s = (hipStream_t)stream;
+  GROVE_CHECK(!p->o_map || (g_win_attn && grove_win_attn_applicable(p) && p->q_valid), GROVE_E_SHAPE,
+              "flash_attn_fwd: o_map (token-order output) is a window-kernel feature and needs q_valid");
   if (g_win_attn && grove_win_attn_applicable(p)) {
     grove_win_attn_fwd_launch(p, s);
     GROVE_LAUNCH_CHECK();
@@ -805,6 +807,8 @@ extern "C" int grove_flash_attn_bwd(const grove_flash_attn_params* p, void* stre
   GROVE_CHECK(p->o && p->d_o && p->lse && p->delta && p->dq && p->dk && p->dv, GROVE_E_SHAPE, "flash_attn_bwd: o, d_o, lse, delta, dq, dk, dv required");
   GROVE_CHECK(!p->drel || p->rel, GROVE_E_SHAPE, "flash_attn_bwd: drel needs rel");
   hipStream_t s = (hipStream_t)stream;
+  GROVE_CHECK(!p->o_map || (g_win_attn && grove_win_attn_applicable(p) && p->q_valid && p->ld_do % 8 == 0), GROVE_E_SHAPE,
+              "flash_attn_bwd: o_map (token-order o / d_o) is a window-kernel feature and needs q_valid");
   if (g_win_attn && grove_win_attn_applicable(p) && p->ld_do % 8 == 0 && p->ld_dq % 4 == 0 && p->ld_dk % 4 == 0 && p->ld_dv % 4 == 0 &&
       ((uintptr_t)p->d_o & 15) == 0 && ((uintptr_t)p->o & 15) == 0) {
     grove_win_attn_bwd_launch(p, s);  // one kernel: delta, dK / dV, then dQ / d rel (win_attn.hip)

@@ -120,7 +120,9 @@ __device__ __forceinline__ void dma_image_k(char* img, const bf16_raw* __restric
   }
 }
 // the same for a QUERY-indexed operand: image row i = compact query min(i, nq - 1)
-__device__ __forceinline__ void dma_image_q(char* img, const bf16_raw* __restrict__ src, int ld, const QList& ql, int wave, int lane) {
+// rowmap (or NULL): position -> row of src (an operand kept in token order: grove_flash_attn_params.o_map)
+__device__ __forceinline__ void dma_image_q(char* img, const bf16_raw* __restrict__ src, int ld, const QList& ql, int wave, int lane,
+                                            const int32_t* __restrict__ rowmap = nullptr) {
 #pragma unroll
   for (int j = 0; j < (WINSTR + 3) / 4; ++j) {
     const int i = wave + 4 * j;
@@ -128,7 +130,8 @@ __device__ __forceinline__ void dma_image_q(char* img, const bf16_raw* __restric
       const int c = i * 64 + lane;
       const int row = (c * 6554) >> 16;
       const int col = c - row * 10;
-      const int gr = ql.pos(min(row, ql.nq - 1));
+      int gr = ql.pos(min(row, ql.nq - 1));
+      if (rowmap) gr = rowmap[gr];
       if (c < WNCH)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (int64_t)gr * ld + col * 8),
                                          (__attribute__((address_space(3))) void*)(img + i * 1024), 16, 0, 0);
@@ -225,7 +228,7 @@ __device__ __forceinline__ void load_qpair(QPair& q, const bf16_raw* __restrict_
 
 // ================================================================================ forward
 __device__ __forceinline__ void fwd_pair(const QPair& q, const char* Ks, const char* Vs, const char* Es, int q0, int L, const QList& ql, int lane,
-                                         bf16_raw* __restrict__ O, int ld_o, float* __restrict__ LSE) {
+                                         bf16_raw* __restrict__ O, int ld_o, float* __restrict__ LSE, const int32_t* __restrict__ omap, bool o_pad) {
   const int fr = lane & 15, g = lane >> 4;
   const int esw = e_swz(fr);
   f32x4_t S[2][WNT];
@@ -305,13 +308,13 @@ __device__ __forceinline__ void fwd_pair(const QPair& q, const char* Ks, const c
     const int qi = ql.pos(q0 + mi * 16 + fr);
     const float l = Ls[mi][0];
     const float inv = __builtin_amdgcn_rcpf(l);
-    bf16_raw* orow = O + (int64_t)qi * ld_o;
+    bf16_raw* orow = O + (int64_t)(omap ? omap[qi] : qi) * ld_o;
 #pragma unroll
     for (int dt = 0; dt < 5; ++dt) {
       const f32x4_t o = Oa[mi][dt] * inv;
       *(u32x2_t*)(orow + dt * 16 + g * 4) = u32x2_t{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
     }
-    *(u32x2_t*)(orow + 80 + g * 4) = u32x2_t{0u, 0u};  // the 16 pad columns of the 96-wide head slot
+    if (o_pad) *(u32x2_t*)(orow + 80 + g * 4) = u32x2_t{0u, 0u};  // the 16 pad columns of a 96-wide head slot
     if (LSE && g == 0) LSE[qi] = (mrow[mi] + log2f(l)) * 0.6931471805599453f;
   }
 }
@@ -330,7 +333,10 @@ __global__ __launch_bounds__(WTHR, 2) void win_attn_fwd_kernel(const grove_flash
   const bf16_raw* K = (const bf16_raw*)p.k + (int64_t)b * p.sk + h * p.hs;
   const bf16_raw* V = (const bf16_raw*)p.v + (int64_t)b * p.sv + h * p.hs;
   const bf16_raw* REL = (const bf16_raw*)p.rel + (int64_t)(b * p.H + h) * L * 32;
-  bf16_raw* O = (bf16_raw*)p.o + (int64_t)b * p.so + h * p.hs;
+  // o in token order (o_map: row of (b, position), head h at column h * o_hs) or in the layout of q
+  const int ohs = p.o_map && p.o_hs ? p.o_hs : p.hs;
+  const int32_t* omap = p.o_map ? p.o_map + (int64_t)b * L : nullptr;
+  bf16_raw* O = (bf16_raw*)p.o + (p.o_map ? (int64_t)0 : (int64_t)b * p.so) + h * ohs;
   float* LSE = p.lse ? p.lse + (int64_t)(b * p.H + h) * L : nullptr;
   const float sc = p.alpha * 1.4426950408889634f;
   const QList ql = make_qlist(p, b);
@@ -348,7 +354,7 @@ __global__ __launch_bounds__(WTHR, 2) void win_attn_fwd_kernel(const grove_flash
     QPair qn;
     const bool more = q0 + 128 < ql.nq;
     if (more) load_qpair(qn, Q, p.ld_q, REL, q0 + 128, ql, sc, fr, g);  // lands under this pair's MFMAs
-    fwd_pair(q, Ks, Vs, Es, q0, L, ql, lane, O, p.ld_o, LSE);
+    fwd_pair(q, Ks, Vs, Es, q0, L, ql, lane, O, p.ld_o, LSE, omap, ohs >= 96);
     if (more) q = qn;
   }
 }
@@ -697,8 +703,10 @@ __global__ __launch_bounds__(WTHR, 2) void win_attn_bwd_kernel(const grove_flash
   const bf16_raw* Q = (const bf16_raw*)p.q + (int64_t)b * p.sq + h * p.hs;
   const bf16_raw* K = (const bf16_raw*)p.k + (int64_t)b * p.sk + h * p.hs;
   const bf16_raw* V = (const bf16_raw*)p.v + (int64_t)b * p.sv + h * p.hs;
-  const bf16_raw* dO = (const bf16_raw*)p.d_o + (int64_t)b * p.sdo + h * p.hs;
-  const bf16_raw* Og = (const bf16_raw*)p.o + (int64_t)b * p.so + h * p.hs;
+  const int ohs = p.o_map && p.o_hs ? p.o_hs : p.hs;
+  const int32_t* omap = p.o_map ? p.o_map + (int64_t)b * L : nullptr;
+  const bf16_raw* dO = (const bf16_raw*)p.d_o + (p.o_map ? (int64_t)0 : (int64_t)b * p.sdo) + h * ohs;
+  const bf16_raw* Og = (const bf16_raw*)p.o + (p.o_map ? (int64_t)0 : (int64_t)b * p.so) + h * ohs;
   const bf16_raw* REL = (const bf16_raw*)p.rel + bh * 32;
   const float sc = p.alpha * 1.4426950408889634f;
   // ---- prologue: Q, dO -> LDS (DMA); rel' (scaled) -> LDS; lse; delta
@@ -706,7 +714,7 @@ __global__ __launch_bounds__(WTHR, 2) void win_attn_bwd_kernel(const grove_flash
   const bf16_raw* PK = p.pad_k ? (const bf16_raw*)p.pad_k + h * p.hs : nullptr;
   const bf16_raw* PV = p.pad_v ? (const bf16_raw*)p.pad_v + h * p.hs : nullptr;
   dma_image_q(Xs, Q, p.ld_q, ql, wave, lane);
-  dma_image_q(Ys, dO, p.ld_do, ql, wave, lane);
+  dma_image_q(Ys, dO, p.ld_do, ql, wave, lane, omap);
   for (int c = tid; c < WNT * 16 * 4; c += WTHR) {
     const int row = c >> 2, ch = c & 3;
     u32x4_t v = u32x4_t{0u, 0u, 0u, 0u};
@@ -716,8 +724,9 @@ __global__ __launch_bounds__(WTHR, 2) void win_attn_bwd_kernel(const grove_flash
   u32x4_t orow[10];
   const int myrow = ql.pos(min(tid, ql.nq - 1));
   if (tid < WNT * 16) {
+    const int64_t orow_i = omap ? omap[myrow] : myrow;
 #pragma unroll
-    for (int c = 0; c < 10; ++c) orow[c] = *(const u32x4_t*)(Og + (int64_t)myrow * p.ld_o + c * 8);
+    for (int c = 0; c < 10; ++c) orow[c] = *(const u32x4_t*)(Og + orow_i * p.ld_o + c * 8);
     lse_s[tid] = tid < ql.nq ? p.lse[bh + myrow] * 1.4426950408889634f : INFINITY;  // (+inf: a row past the last query has P = exp2(s - inf) = 0)
   }
   KVFrag kv0[2];
@@ -761,7 +770,8 @@ __global__ __launch_bounds__(WTHR, 2) void win_attn_bwd_kernel(const grove_flash
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
       const int qc = min(q0 + mi * 16 + fr, ql.nq - 1);  // compact index: lse_s / del_s; position: the global rows
-      const bf16_raw* row = dO + (int64_t)ql.pos(qc) * p.ld_do;
+      const int qp = ql.pos(qc);
+      const bf16_raw* row = dO + (int64_t)(omap ? omap[qp] : qp) * p.ld_do;
       x.d[mi][0] = *(const bf16x8_t*)(row + g * 8);
       x.d[mi][1] = *(const bf16x8_t*)(row + 32 + g * 8);
       x.dt[mi] = __builtin_bit_cast(s16x4_t, *(const u32x2_t*)(row + 64 + g * 4));

@@ -9,6 +9,8 @@ the packed qkv / proj weights so every attention GEMM has K % 32 == 0.
 Backward (shipped freeze policy, train.py:279-280): only the adapters train; gradients flow
 neck -> adapter 3 -> blocks 31..24 -> ... -> adapter 0, i.e. dgrad through blocks first_global+1..depth-1.
 """
+import os
+
 import torch
 
 from .. import ops
@@ -200,11 +202,16 @@ class SamEncoder:
             rel = torch.empty((nb * nh, L, rel_ld), dtype=torch.bfloat16, device=self.dev)
             ops.gemm_raw(qkv, Bk["Rcat"], rel, nb * nh, rel_ld, hp, hp, hp, L * rel_ld, a_idx=hrow, batch=(L, 1),
                          sA=(ld, 0), sB=(rel_ld * hp, 0), sC=(rel_ld, 0))
+        # window kernels + compact weights: the attention output goes straight to TOKEN order with compact heads (o_map = window row ->
+        # token), so window_unpartition + proj is a plain GEMM (and its backward likewise)
+        o_tok = ws > 0 and q_valid is not None and Bk["maps"] and os.environ.get("GROVE_SAM_O_TOKEN", "1") != "0"
         o, actx = attention_fwd(qkv, nb, L, nh, hp, 0, nh * hp, 2 * nh * hp, hd ** -0.5, rel=rel, rel_hw=(Bk["khp"], qhw[1]), save=save, hs_valid=hd,
-                                q_valid=q_valid, pad_row=pad_row)
+                                q_valid=q_valid, pad_row=pad_row, o_map=win2tok if o_tok else None, o_rows=rows)
         del rel
         r1 = None if f32 else x  # bf16 stream: x1 = x + proj(...) in the GEMM epilogue
-        if ws > 0:  # un-partition = gather the real tokens' rows of the windowed attention output (padding rows are dropped)
+        if o_tok:
+            t1 = ops.linear(o, Bk["wproj_c"], Bk["bproj"], residual=r1)
+        elif ws > 0:  # un-partition = gather the real tokens' rows of the windowed attention output (padding rows are dropped)
             if Bk["maps"]:
                 t1 = ops.linear(o, Bk["wproj_c"], Bk["bproj"], residual=r1, a_idx=tok2win, a_taps=1, M=rows, k_map=(hd, hp - hd))
             else:
@@ -332,7 +339,9 @@ class SamEncoder:
             # x1 = x + unpartition(proj(attn(qkv(partition(ln1(x))))))
             if ws > 0:  # real tokens only, scattered into the windowed layout; padding rows carry no gradient
                 pad_rows, pad_src, _ = self._pad[F]
-                if Bk["maps"]:
+                if c["actx"].o_map is not None:  # the attention output lives in token order with compact heads: a plain dgrad
+                    do = ops.linear(dx, Bk["wproj_c_t"])
+                elif Bk["maps"]:
                     do = ops.linear(dx, Bk["wproj_c_t"], c_idx=tok2win, out_rows=win2tok.shape[0], out_cols=nh * hp, n_map=(hd, hp - hd))
                 else:
                     do = ops.linear(dx, Bk["wproj_t"], c_idx=tok2win, out_rows=win2tok.shape[0])

@@ -257,12 +257,13 @@ def window_kernels_take(L, hs, hs_valid, rel_ld):
 
 
 def flash_attn(qkv, B, L, H, hs, q_off, k_off, v_off, alpha, *, causal=False, kv_len=None, rel=None, rel_hw=(0, 0), out=None,
-               want_lse=False, hs_valid=0, q_valid=None, pad_row=None):
-    """Fused attention over a fused qkv activation [B*L, ld]; returns (out [B*L, H*hs], lse or None)."""
+               want_lse=False, hs_valid=0, q_valid=None, pad_row=None, o_map=None, o_rows=0):
+    """Fused attention over a fused qkv activation [B*L, ld]; returns (out [B*L, H*hs], lse or None).
+    o_map (window kernels, with q_valid): out is [o_rows, H*hs_valid] in TOKEN order, row o_map[b*L + i] for position i of batch b."""
     dev = qkv.device
     ld = qkv.stride(0)
     if out is None:
-        out = torch.empty((B * L, H * hs), dtype=bf16, device=dev)
+        out = torch.empty((o_rows, H * hs_valid) if o_map is not None else (B * L, H * hs), dtype=bf16, device=dev)
     lse = torch.empty((B * H, L), dtype=torch.float32, device=dev) if want_lse else None
     p = _lib.FlashAttnParams()
     p.q, p.k, p.v, p.o = _p(qkv[:, q_off:]), _p(qkv[:, k_off:]), _p(qkv[:, v_off:]), _p(out)
@@ -276,6 +277,9 @@ def flash_attn(qkv, B, L, H, hs, q_off, k_off, v_off, alpha, *, causal=False, kv
     p.rel_ld = rel.shape[-1] if rel is not None else 0
     p.hs_valid = hs_valid
     p.q_valid = _p(q_valid)
+    if o_map is not None:
+        assert q_valid is not None and hs_valid and o_map.numel() == B * L
+        p.o_map, p.o_hs = _p(o_map), hs_valid
     if pad_row is not None:  # the qkv row of a padded position (same column layout as a row of qkv)
         assert q_valid is not None and pad_row.numel() == qkv.shape[1]
         p.pad_k, p.pad_v = _p(pad_row.view(-1)[k_off:]), _p(pad_row.view(-1)[v_off:])
@@ -342,7 +346,7 @@ def flash_attn_kv(q, k, v, B, H, Lq, Lk, hs, alpha, *, sq, sk, sv, ld_q, ld_k, l
     return out
 
 def flash_attn_bwd(qkv, out, d_out, lse, dqkv, B, L, H, hs, q_off, k_off, v_off, alpha, *, causal=False, kv_len=None, rel=None,
-                   rel_hw=(0, 0), want_drel=False, hs_valid=0, q_valid=None, pad_row=None):
+                   rel_hw=(0, 0), want_drel=False, hs_valid=0, q_valid=None, pad_row=None, o_map=None):
     dev = qkv.device
     ld, ldd = qkv.stride(0), dqkv.stride(0)
     delta = torch.empty((B * H, L), dtype=torch.float32, device=dev)
@@ -362,6 +366,9 @@ def flash_attn_bwd(qkv, out, d_out, lse, dqkv, B, L, H, hs, q_off, k_off, v_off,
     p.rel_ld = rel.shape[-1] if rel is not None else 0
     p.hs_valid = hs_valid
     p.q_valid = _p(q_valid)
+    if o_map is not None:
+        assert q_valid is not None and hs_valid and o_map.numel() == B * L
+        p.o_map, p.o_hs = _p(o_map), hs_valid
     if pad_row is not None:
         assert q_valid is not None and pad_row.numel() == qkv.shape[1]
         p.pad_k, p.pad_v = _p(pad_row.view(-1)[k_off:]), _p(pad_row.view(-1)[v_off:])

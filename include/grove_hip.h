@@ -299,6 +299,11 @@ typedef struct grove_flash_attn_params {
                        dropped as queries): rows of o / lse / dq / drel at the other positions are NOT written and d_o there is NOT read.
                        The general kernels ignore the field and process every row (the caller then supplies zero d_o rows there);
                        grove_flash_attn_window_kernels_on() tells which family runs a fitting problem */
+  const int32_t* o_map; /* with q_valid, window kernels only: int32 [B * Lq] or NULL. Given, o and d_o are NOT in the layout of q but in
+                       TOKEN order: the row of (batch b, position i) is o_map[b * Lq + i] (valid at every position q_valid keeps), head h at
+                       column h * o_hs (o_hs = 0: hs; SAM: 80 — compact heads), row strides ld_o / ld_do, so / sdo unused. window_unpartition
+                       (image_encoder.py:356-384) and its backward then need no gather: the projection reads / writes plain matrices */
+  int32_t o_hs;
   const void* pad_k; const void* pad_v; /* with q_valid, window kernels only: bf16 rows [H*hs] = k / v of a padded position (a zero token's
                        projection = the bias), or NULL. Given, the k / v rows at padded positions are NOT read (the caller need not
                        fill them) and dk / dv there are NOT written */

@@ -1256,6 +1256,24 @@ def test_window_attention_valid_queries(dev, valid):
     assert torch.equal(o_p[rd], o_f[rd]) and torch.equal(lse_p[hm.to(dev)], lse_f[hm.to(dev)]), "forward with the padded keys taken from pad_row"
     assert torch.equal(dq_p[rd], dq_f[rd]) and torch.equal(dr_p[hm.to(dev)], dr_f[hm.to(dev)]), "backward with the padded keys taken from pad_row"
     assert torch.isnan(dq_p[~rd].float()).all(), "dq / dk / dv rows at padded positions must not be written"
+    # o_map: o and d_o in TOKEN order with compact heads (row o_map[b * L + i], head h at column h * hd) — window_unpartition folded
+    # into the kernels' addressing. Same numbers as the windowed-layout run, at permuted rows.
+    ntok = int(rows.sum())
+    tok_of = torch.full((B * L,), -1, dtype=torch.int32)
+    tok_of[rows] = torch.randperm(ntok, generator=g).to(torch.int32)
+    omap = tok_of.to(dev)
+    o_t = torch.full((ntok, H * hd), float("nan"), dtype=bf16, device=dev)
+    o_t, lse_t = ops.flash_attn(holes.to(dev), B, L, H, hs, 0, H * hs, 2 * H * hs, alpha, rel=relp.to(dev), rel_hw=(16, ws), want_lse=True,
+                                hs_valid=hd, q_valid=qv, pad_row=pad_row.to(dev), o_map=omap, o_rows=ntok, out=o_t)
+    sel = tok_of[rows].long().to(dev)
+    assert torch.equal(o_t[sel].view(ntok, H, hd), o_p[rd].view(ntok, H, hs)[..., :hd]), "token-order o"
+    assert torch.equal(lse_t[hm.to(dev)], lse_p[hm.to(dev)])
+    do_t = torch.zeros(ntok, H * hd, dtype=bf16, device=dev)
+    do_t[sel] = do_dev.to(dev)[rd].view(ntok, H, hs)[..., :hd].reshape(ntok, H * hd)
+    dq_t = torch.full((B * L, 3 * H * hs), float("nan"), dtype=bf16, device=dev)
+    dr_t = ops.flash_attn_bwd(holes.to(dev), o_t, do_t, lse_t, dq_t, B, L, H, hs, 0, H * hs, 2 * H * hs, alpha, rel=relp.to(dev),
+                              rel_hw=(16, ws), want_drel=True, hs_valid=hd, q_valid=qv, pad_row=pad_row.to(dev), o_map=omap)
+    assert torch.equal(dq_t[rd], dq_p[rd]) and torch.equal(dr_t[hm.to(dev)], dr_p[hm.to(dev)]), "backward from token-order o / d_o"
 
 
 def test_rel_bias_streams_skip_padded_positions(dev):
