@@ -167,6 +167,8 @@ __global__ __launch_bounds__(TNT) void gemm_tn_kernel(const grove_gemm_tn_params
 // k per wave instruction) when the tile's A_lo is issued — no vector load inside the loop (see sload8 in gemm.hip).
 // =====================================================================================================
 constexpr int Q_NT = 512, Q_BK = 64;
+int g_tn_split_tail = 1;  // cut the tiles of a partial last round into K ranges: 0 never, 1 gathered launches, 2 every launch (grove_gemm_tn_set_split_tail)
+int g_tn_last_parts = 1;  // K ranges per cut tile in the last pipelined launch
 constexpr int Q_ROWB = 256;                 // bytes per LDS row (128 bf16 columns)
 constexpr int Q_HALF = Q_BK * Q_ROWB;       // 16 KB
 constexpr int Q_STAGE = 4 * Q_HALF;
@@ -213,7 +215,8 @@ __device__ __forceinline__ bf16x8_t tr_join(const TrFrag& f) {
 }
 
 template <bool GATHER>
-__global__ __launch_bounds__(Q_NT) void gemm_tn_pp_kernel(const grove_gemm_tn_params p, const int tiles_m, const int tiles_n) {
+__global__ __launch_bounds__(Q_NT) void gemm_tn_pp_kernel(const grove_gemm_tn_params p, const int tiles_m, const int tiles_n, const int tiles_whole,
+                                                          const int parts) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -224,10 +227,31 @@ __global__ __launch_bounds__(Q_NT) void gemm_tn_pp_kernel(const grove_gemm_tn_pa
   const int G = gridDim.x;
   const int xcd = blockIdx.x & 7, q8 = G >> 3, r8 = G & 7;
   const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+  // Work units, dealt round-robin (unit u = wgid + G r): the first tiles_whole tiles whole, then the tiles of the partial last
+  // round cut into `parts` equal K ranges, part-major (all first parts, then all second parts: the blocks of a round walk the same
+  // K range, as they do in a round of whole tiles). A partial range is added to C with fp32 atomics (launch_tn_pp picks parts).
   const int tiles = tiles_m * tiles_n;
-  const int my_tiles = (tiles - wgid + G - 1) / G;
+  const int tail_tiles = tiles - tiles_whole;
+  const int units = tiles_whole + tail_tiles * parts;
   const int nk = p.K / Q_BK;
-  const int NT = my_tiles * nk, NH = 4 * NT;
+  auto unit_of = [&](int u, int& L, int& ka, int& kb) {
+    if (u < tiles_whole) {
+      L = u; ka = 0; kb = nk;
+    } else {
+      const int v = u - tiles_whole;
+      const int part = (v >= tail_tiles) + (v >= 2 * tail_tiles) + (v >= 3 * tail_tiles);
+      L = tiles_whole + v - part * tail_tiles;
+      ka = part * nk / parts;
+      kb = (part + 1) * nk / parts;
+    }
+  };
+  int NT = 0;
+  for (int u = wgid; u < units; u += G) {
+    int L, ka, kb;
+    unit_of(u, L, ka, kb);
+    NT += kb - ka;
+  }
+  const int NH = 4 * NT;
   const int n_per_tap = p.N / p.b_taps;
 
   // staging: thread -> (row k = 32 i + tid / 16, physical chunk tid % 16) of a half-tile, two instructions per half
@@ -237,8 +261,10 @@ __global__ __launch_bounds__(Q_NT) void gemm_tn_pp_kernel(const grove_gemm_tn_pa
   int colb[2];               // B_lo / B_hi column offsets inside a (gathered) row
   const bf16_raw* pbrow[2];  // GATHER: my two B rows of the K tile being issued (nullptr = zero row)
   const int32_t* bidx = nullptr;
-  int is_L = wgid, is_k = 0;
-  auto set_tile = [&](int L) {  // consecutive tiles share the B panel
+  int is_u = wgid, is_k = 0, is_kb = 0;
+  auto set_tile = [&](int u) {  // consecutive tiles share the B panel
+    int L;
+    unit_of(u, L, is_k, is_kb);
     const int tm = L % tiles_m, tn = L / tiles_m;
     const int m0 = tm * 256, n0 = tn * 256;
     const int tap = n0 / n_per_tap, nb0 = n0 - tap * n_per_tap;
@@ -264,13 +290,16 @@ __global__ __launch_bounds__(Q_NT) void gemm_tn_pp_kernel(const grove_gemm_tn_pa
     pbrow[0] = r0 >= 0 ? B + (int64_t)r0 * p.ldb : nullptr;
     pbrow[1] = r1 >= 0 ? B + (int64_t)r1 * p.ldb : nullptr;
   };
-  auto next_rows_base = [&]() -> const int32_t* {  // index window of the K tile AFTER (is_L, is_k)
+  auto next_rows_base = [&]() -> const int32_t* {  // index window of the K tile AFTER (is_u, is_k)
     int k2 = is_k + 1;
     const int32_t* bb = bidx;
-    if (k2 == nk) {
+    if (k2 == is_kb) {
+      int L2 = 0, kb2;
       k2 = 0;
-      const int L2 = is_L + G;
-      if (L2 < tiles) bb = p.b_idx + (int64_t)(((L2 / tiles_m) * 256) / n_per_tap) * p.K;
+      if (is_u + G < units) {
+        unit_of(is_u + G, L2, k2, kb2);
+        bb = p.b_idx + (int64_t)(((L2 / tiles_m) * 256) / n_per_tap) * p.K;
+      }
     }
     return bb + k2 * Q_BK;
   };
@@ -291,10 +320,9 @@ __global__ __launch_bounds__(Q_NT) void gemm_tn_pp_kernel(const grove_gemm_tn_pa
     }
   };
   auto advance_issue = [&]() {
-    if (++is_k == nk) {
-      is_k = 0;
-      is_L += G;
-      set_tile(is_L);
+    if (++is_k == is_kb) {
+      is_u += G;
+      set_tile(is_u);
     }
     if (GATHER) {
       take_rows();
@@ -349,9 +377,9 @@ __global__ __launch_bounds__(Q_NT) void gemm_tn_pp_kernel(const grove_gemm_tn_pa
   float scale = p.alpha;
   if (p.scale_ptr) scale *= p.scale_tanh ? tanhf(*p.scale_ptr) : *p.scale_ptr;
   asm volatile("" ::"v"(scale));  // fetched and used before the loop (see gemm_nt_pp_kernel)
-  set_tile(is_L);
+  set_tile(is_u);
   if (GATHER) {
-    prefetch_rows(bidx);
+    prefetch_rows(bidx + is_k * Q_BK);
     take_rows();
     prefetch_rows(next_rows_base());
   }
@@ -364,7 +392,8 @@ __global__ __launch_bounds__(Q_NT) void gemm_tn_pp_kernel(const grove_gemm_tn_pa
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();
 
-  int c_L = wgid, c_k = 0;
+  int c_u = wgid, c_L, c_k, c_kb;
+  unit_of(c_u, c_L, c_k, c_kb);
   for (int T = 0; T < NT; ++T) {
     const unsigned st_off = (T & 1) * Q_STAGE;
     const int q = 4 * T;
@@ -385,10 +414,26 @@ __global__ __launch_bounds__(Q_NT) void gemm_tn_pp_kernel(const grove_gemm_tn_pa
     QQ_MEM_END(q + 3, 1, 2, true)
     QQ_MMA(4, 0, b0)
     __builtin_amdgcn_s_barrier();
-    if (++c_k == nk) {
+    if (++c_k == c_kb) {
       // acc[i][j] holds D[n = 4 g + e][m = fr] of A fragment i (m) and B fragment j (n): C += scale * D, 16 bytes per lane
       const int tm = c_L % tiles_m, tn = c_L / tiles_m;
       const int m0 = tm * 256 + wr * 64 + fr, n0 = tn * 256 + wc * 32 + 4 * g;
+      if (__builtin_expect(c_u >= tiles_whole && parts > 1, 0)) {  // one K range of a cut tile
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int n = n0 + (j >> 1) * 128 + (j & 1) * 16;
+          if (n >= p.N) continue;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int m = m0 + (i >> 2) * 128 + (i & 3) * 16;
+            if (m < p.M) {
+              float* c = p.C + (int64_t)m * p.ldc + n;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) unsafeAtomicAdd(c + e, acc[i][j][e] * scale);
+            }
+          }
+        }
+      } else
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int n = n0 + (j >> 1) * 128 + (j & 1) * 16;
@@ -409,8 +454,8 @@ __global__ __launch_bounds__(Q_NT) void gemm_tn_pp_kernel(const grove_gemm_tn_pa
       for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      c_k = 0;
-      c_L += G;
+      c_u += G;
+      if (c_u < units) unit_of(c_u, c_L, c_k, c_kb);
     }
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();
@@ -435,7 +480,23 @@ int launch_tn_pp(const grove_gemm_tn_params& p, hipStream_t s) {
     attr_set = true;
   }
   const int tiles = tiles_m * tiles_n;
-  hipLaunchKernelGGL(gemm_tn_pp_kernel<GATHER>, dim3(tiles < num_cus ? tiles : num_cus), dim3(Q_NT), lds, s, p, tiles_m, tiles_n);
+  const int G = tiles < num_cus ? tiles : num_cus;
+  // The partial last round (675 tiles on 256 CUs: 2 rounds + 163 tiles) is cut into 2-4 K ranges when that shortens it:
+  // ceil(tail * parts / G) rounds of 1 / parts each, e.g. 163 x 3 = 489 units = 2 rounds of a third (0.67 instead of 1).
+  // Measured (tools/bench_gemm_tn.py, (1280, 34560, 32768)): gathered taps 2.90-2.98 -> 2.85 ms; the plain form does not move
+  // (2.73 ms either way: at the board's power limit a launch costs its energy, not its rounds), so by default only gathered
+  // launches are cut and plain ones keep their fixed sum order.
+  int parts = 1, tail = tiles % G;
+  if (tail && (g_tn_split_tail == 2 || (g_tn_split_tail == 1 && GATHER))) {
+    double best = 1.0;
+    for (int s2 = 2; s2 <= 4; ++s2) {
+      if (p.K / Q_BK / s2 < 32) break;
+      const double c = (double)((tail * s2 + G - 1) / G) / s2 + 0.02 * s2;  // + the atomics of a part
+      if (c < best) { best = c; parts = s2; }
+    }
+  }
+  g_tn_last_parts = parts;
+  hipLaunchKernelGGL(gemm_tn_pp_kernel<GATHER>, dim3(G), dim3(Q_NT), lds, s, p, tiles_m, tiles_n, parts > 1 ? tiles - tail : tiles, parts);
   GROVE_LAUNCH_CHECK();
   return GROVE_OK;
 }
@@ -447,6 +508,12 @@ extern "C" int grove_gemm_tn_set_pipelined(int mode) {
   g_tn_pipelined = mode;
   return GROVE_OK;
 }
+
+extern "C" int grove_gemm_tn_set_split_tail(int on) {
+  g_tn_split_tail = on;
+  return GROVE_OK;
+}
+extern "C" int grove_gemm_tn_last_parts(void) { return g_tn_last_parts; }
 
 extern "C" int grove_gemm_tn_bf16(const grove_gemm_tn_params* pp, void* stream) {
   GROVE_CHECK(pp && pp->M > 0 && pp->N > 0 && pp->K > 0, GROVE_E_SHAPE, "gemm_tn: bad shape");

@@ -165,6 +165,12 @@ int grove_gemm_tn_bf16(const grove_gemm_tn_params* p, void* stream);
 /* kernel choice of grove_gemm_tn_bf16: -1 = auto (default), 0 = the 128 x 128 kernel always, 1 = the persistent pipelined
  * 256 x 256 kernel whenever the problem is eligible (K % 64 == 0, no split-K, column tiles inside one tap) */
 int grove_gemm_tn_set_pipelined(int mode);
+/* The pipelined kernel cuts the tiles of a partial last round into 2-4 equal K ranges when that shortens the round (675 tiles on
+ * 256 CUs: 2 rounds + 163 tiles -> 2 + 2/3); a cut tile's ranges are added to C with fp32 atomics, so its sum order is not fixed
+ * (as with split_k > 1). on: 0 = every tile whole, 1 = gathered (b_idx) launches only (default: the plain form does not gain),
+ * 2 = every eligible launch. grove_gemm_tn_last_parts: K ranges per cut tile in the last pipelined launch. */
+int grove_gemm_tn_set_split_tail(int on);
+int grove_gemm_tn_last_parts(void);
 
 /* out[c, r] = in[r, c] for a batch of 2-D bf16 matrices (used for V^T, dY^T, X^T, NCHW<->NHWC).
  * rows beyond `rows` in the output's padded leading dim (ld_out > rows) are zero filled up to

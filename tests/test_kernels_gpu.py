@@ -972,8 +972,28 @@ def test_wgrad_tn_pipelined(dev):
         L.grove_gemm_tn_set_pipelined(1)
         out = ops.wgrad(dz, xx, torch.zeros(Co, 27 * Ci, dtype=torch.float32, device=dev), b_idx=idx, b_taps=27)
         close(out, ref, 2e-6, "pipelined conv3d wgrad vs 128x128 kernel")
+        # a partial last round cut into K ranges (fp32 atomics): 300 tiles on 256 CUs, plain and gathered
+        Kt, M2, N2 = 8192, 1280, 15360
+        dy, x = rnd(Kt, M2, seed=95).to(dev), rnd(Kt, N2, seed=96).to(dev)
+        L.grove_gemm_tn_set_split_tail(0)
+        ref = ops.wgrad(dy, x, torch.ones(M2, N2, dtype=torch.float32, device=dev), alpha=0.5)
+        assert L.grove_gemm_tn_last_parts() == 1
+        L.grove_gemm_tn_set_split_tail(2)
+        out = ops.wgrad(dy, x, torch.ones(M2, N2, dtype=torch.float32, device=dev), alpha=0.5)
+        assert L.grove_gemm_tn_last_parts() > 1, "the tail of 44 tiles is cut"
+        close(out, ref, 2e-6, "cut last round vs whole tiles")
+        G, T, H, W, Ci, Co = 2, 4, 32, 32, 512, 1280
+        xx, dz = rnd(G * T * H * W, Ci, seed=97).to(dev), rnd(G * T * H * W, Co, seed=98).to(dev)
+        idx = conv3d_gather_index(G, T, H, W).to(dev)
+        L.grove_gemm_tn_set_split_tail(0)
+        ref = ops.wgrad(dz, xx, torch.zeros(Co, 27 * Ci, dtype=torch.float32, device=dev), b_idx=idx, b_taps=27)
+        L.grove_gemm_tn_set_split_tail(1)
+        out = ops.wgrad(dz, xx, torch.zeros(Co, 27 * Ci, dtype=torch.float32, device=dev), b_idx=idx, b_taps=27)
+        assert L.grove_gemm_tn_last_parts() > 1
+        close(out, ref, 2e-6, "cut last round, gathered taps")
     finally:
         L.grove_gemm_tn_set_pipelined(-1)
+        L.grove_gemm_tn_set_split_tail(1)
 
 
 @pytest.mark.parametrize("M,I,K,save", [(2812, 1024, 256, True), (1500, 2752, 128, False)])

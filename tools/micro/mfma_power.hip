@@ -1,0 +1,81 @@
+// What does the matrix pipe sustain under the board's power limit, and does the MFMA block shape matter? Register-only loops (no LDS, no
+// memory): 8 waves per CU on every CU, operands = normally distributed bf16 values loaded once, 8 (16x16x32) or 4 (32x32x16) independent
+// accumulators per wave so that the pipe never waits on a dependency. Each variant runs for ~3 s; prints TFLOP/s and the implied clock
+// (TFLOP/s / (256 CUs * 4 SIMDs * 1024 FLOP per clock)).   hipcc --offload-arch=gfx950 -O3 mfma_power.hip -o mfma_power
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <cstring>
+#include <vector>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int SHAPE, int NFRAG>
+__global__ __launch_bounds__(512) void k(const bf16x8* __restrict__ src, float* __restrict__ out, int iters) {
+  bf16x8 a[NFRAG], b[NFRAG];
+  for (int i = 0; i < NFRAG; ++i) {
+    a[i] = src[(threadIdx.x + 512 * i) & 4095];
+    b[i] = src[(threadIdx.x + 512 * i + 2048) & 4095];
+  }
+  float s = 0.f;
+  if (SHAPE == 16) {
+    f32x4 acc[NFRAG][NFRAG];
+    for (int i = 0; i < NFRAG; ++i) for (int j = 0; j < NFRAG; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < NFRAG; ++i)
+#pragma unroll
+        for (int j = 0; j < NFRAG; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    for (int i = 0; i < NFRAG; ++i) for (int j = 0; j < NFRAG; ++j) s += acc[i][j][0] + acc[i][j][3];
+  } else {
+    f32x16 acc[NFRAG][NFRAG];
+    for (int i = 0; i < NFRAG; ++i) for (int j = 0; j < NFRAG; ++j) for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < NFRAG; ++i)
+#pragma unroll
+        for (int j = 0; j < NFRAG; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    for (int i = 0; i < NFRAG; ++i) for (int j = 0; j < NFRAG; ++j) s += acc[i][j][0] + acc[i][j][15];
+  }
+  if (s == 12345.678f) out[0] = s;
+}
+
+int main(int argc, char** argv) {
+  const double secs = argc > 1 ? atof(argv[1]) : 3.0;
+  std::vector<unsigned short> h(4096 * 8);
+  srand(1);
+  for (auto& v : h) {  // ~N(0, 1) as bf16 (sum of 12 uniforms), the statistics of the bench's synthetic activations
+    float x = -6.f;
+    for (int i = 0; i < 12; ++i) x += (float)rand() / RAND_MAX;
+    unsigned u; memcpy(&u, &x, 4);
+    v = (unsigned short)(u >> 16);
+  }
+  bf16x8* src; float* out;
+  hipMalloc(&src, h.size() * 2); hipMalloc(&out, 4);
+  hipMemcpy(src, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int rep = 0; rep < 2; ++rep)
+    for (int shape : {16, 32}) {
+      // flops per wave per iteration: 16x16x32: 4 MFMAs x 16384 (2 x 2 fragments); 32x32x16: 4 x 32768
+      const int iters = 200000;
+      const double fl = (double)iters * 4 * (shape == 16 ? 16384.0 : 32768.0) * 8 * 256;
+      double tot_ms = 0, tot_fl = 0;
+      while (tot_ms < secs * 1e3) {
+        hipEventRecord(e0);
+        if (shape == 16) hipLaunchKernelGGL((k<16, 2>), dim3(256), dim3(512), 0, 0, src, out, iters);
+        else hipLaunchKernelGGL((k<32, 2>), dim3(256), dim3(512), 0, 0, src, out, iters);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        tot_ms += ms; tot_fl += fl;
+      }
+      const double tf = tot_fl / tot_ms / 1e9;
+      printf("mfma %s: %.1f TFLOP/s sustained over %.1f s -> %.0f MHz at 100 %% pipe use\n", shape == 16 ? "16x16x32" : "32x32x16", tf, tot_ms / 1e3,
+             tf * 1e12 / (256.0 * 4 * 1024) / 1e6);
+      fflush(stdout);
+    }
+  return 0;
+}
