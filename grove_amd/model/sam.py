@@ -399,7 +399,11 @@ class SamEncoder:
         if need_dx:
             # dx = dy + conv^T(dz): flipped taps, swapped channels
             if "w_d" not in A or self.train:
-                w5 = A["w"].view(C, 3, 3, 3, C)
-                A["w_d"] = w5.flip(1, 2, 3).permute(4, 1, 2, 3, 0).reshape(C, 27 * C).contiguous()
+                # w_d[ci, 26 - tap, co] = w[co, tap, ci]: 27 C x C transposes in one launch, the output blocks walked backwards
+                # (one pass at HBM speed instead of torch's flip + permute copies: 0.4 ms per adapter per step)
+                wd = A.get("w_d")
+                if wd is None or wd.shape != (C, 27 * C):
+                    wd = A["w_d"] = torch.empty((C, 27 * C), dtype=torch.bfloat16, device=A["w"].device)
+                ops.transpose(A["w"], C, C, 27 * C, wd[:, 26 * C:], 27 * C, batch=(27, 1), s_in=(C, 0), s_out=(-C, 0))
             dx = ops.linear(prod, A["w_d"], a_idx=conv_idx, a_taps=27, M=M, residual=dy, scale_ptr=a, scale_tanh=True)
         return dx

@@ -12,6 +12,27 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// The GEMM phase's 4 A x 2 B fragments in three issue orders: 0 = i outer / j inner (B changes every instruction, both operands every
+// second one), 1 = snake (exactly one operand changes per instruction), 2 = every instruction reads the same two operands.
+template <int ORDER>
+__global__ __launch_bounds__(512) void korder(const bf16x8* __restrict__ src, float* __restrict__ out, int iters) {
+  bf16x8 a[4], b[2];
+  for (int i = 0; i < 4; ++i) a[i] = src[(threadIdx.x + 512 * i) & 4095];
+  for (int i = 0; i < 2; ++i) b[i] = src[(threadIdx.x + 512 * i + 2048) & 4095];
+  f32x4 acc[4][2];
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+#define MM(I, J, AI, BJ) acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[AI], b[BJ], acc[I][J], 0, 0, 0); __builtin_amdgcn_sched_barrier(0);
+  for (int it = 0; it < iters; ++it) {
+    if (ORDER == 0) { MM(0,0,0,0) MM(0,1,0,1) MM(1,0,1,0) MM(1,1,1,1) MM(2,0,2,0) MM(2,1,2,1) MM(3,0,3,0) MM(3,1,3,1) }
+    if (ORDER == 1) { MM(0,0,0,0) MM(0,1,0,1) MM(1,1,1,1) MM(1,0,1,0) MM(2,0,2,0) MM(2,1,2,1) MM(3,1,3,1) MM(3,0,3,0) }
+    if (ORDER == 2) { MM(0,0,0,0) MM(0,1,0,0) MM(1,1,0,0) MM(1,0,0,0) MM(2,0,0,0) MM(2,1,0,0) MM(3,1,0,0) MM(3,0,0,0) }
+  }
+#undef MM
+  float s = 0.f;
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 2; ++j) s += acc[i][j][0] + acc[i][j][3];
+  if (s == 12345.678f) out[0] = s;
+}
+
 template <int SHAPE, int NFRAG>
 __global__ __launch_bounds__(512) void k(const bf16x8* __restrict__ src, float* __restrict__ out, int iters) {
   bf16x8 a[NFRAG], b[NFRAG];
@@ -75,6 +96,25 @@ int main(int argc, char** argv) {
       const double tf = tot_fl / tot_ms / 1e9;
       printf("mfma %s: %.1f TFLOP/s sustained over %.1f s -> %.0f MHz at 100 %% pipe use\n", shape == 16 ? "16x16x32" : "32x32x16", tf, tot_ms / 1e3,
              tf * 1e12 / (256.0 * 4 * 1024) / 1e6);
+      fflush(stdout);
+    }
+  for (int rep = 0; rep < 2; ++rep)
+    for (int order = 0; order < 3; ++order) {
+      const int iters = 100000;
+      const double fl = (double)iters * 8 * 16384.0 * 8 * 256;
+      double tot_ms = 0, tot_fl = 0;
+      while (tot_ms < secs * 1e3) {
+        hipEventRecord(e0);
+        if (order == 0) hipLaunchKernelGGL(korder<0>, dim3(256), dim3(512), 0, 0, src, out, iters);
+        else if (order == 1) hipLaunchKernelGGL(korder<1>, dim3(256), dim3(512), 0, 0, src, out, iters);
+        else hipLaunchKernelGGL(korder<2>, dim3(256), dim3(512), 0, 0, src, out, iters);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        tot_ms += ms; tot_fl += fl;
+      }
+      const double tf = tot_fl / tot_ms / 1e9;
+      printf("16x16x32, 4 A x 2 B fragments, order %d (%s): %.1f TFLOP/s -> %.0f MHz\n", order,
+             order == 0 ? "i outer, j inner" : order == 1 ? "snake" : "same operands", tf, tf * 1e12 / (256.0 * 4 * 1024) / 1e6);
       fflush(stdout);
     }
   return 0;
