@@ -121,8 +121,19 @@ __device__ __forceinline__ void dma_image_k(char* img, const bf16_raw* __restric
 }
 // the same for a QUERY-indexed operand: image row i = compact query min(i, nq - 1)
 // rowmap (or NULL): position -> row of src (an operand kept in token order: grove_flash_attn_params.o_map)
-__device__ __forceinline__ void dma_image_q(char* img, const bf16_raw* __restrict__ src, int ld, const QList& ql, int wave, int lane,
-                                            const int32_t* __restrict__ rowmap = nullptr) {
+// Split in two so that the row indices of a mapped operand can be fetched well before its DMA is issued (image_q_rows first,
+// other work, then dma_image_rows): a DMA whose address hangs on an index load issued right before it pays that load's latency.
+struct ImageRows { int r[(WINSTR + 3) / 4]; };
+__device__ __forceinline__ void image_q_rows(ImageRows& rows, const QList& ql, int wave, int lane, const int32_t* __restrict__ rowmap) {
+#pragma unroll
+  for (int j = 0; j < (WINSTR + 3) / 4; ++j) {
+    const int c = min((wave + 4 * j) * 64 + lane, WNCH - 1);
+    const int row = (c * 6554) >> 16;
+    const int gr = ql.pos(min(row, ql.nq - 1));
+    rows.r[j] = rowmap ? rowmap[gr] : gr;
+  }
+}
+__device__ __forceinline__ void dma_image_rows(char* img, const bf16_raw* __restrict__ src, int ld, const ImageRows& rows, int wave, int lane) {
 #pragma unroll
   for (int j = 0; j < (WINSTR + 3) / 4; ++j) {
     const int i = wave + 4 * j;
@@ -130,13 +141,16 @@ __device__ __forceinline__ void dma_image_q(char* img, const bf16_raw* __restric
       const int c = i * 64 + lane;
       const int row = (c * 6554) >> 16;
       const int col = c - row * 10;
-      int gr = ql.pos(min(row, ql.nq - 1));
-      if (rowmap) gr = rowmap[gr];
       if (c < WNCH)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (int64_t)gr * ld + col * 8),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (int64_t)rows.r[j] * ld + col * 8),
                                          (__attribute__((address_space(3))) void*)(img + i * 1024), 16, 0, 0);
     }
   }
+}
+__device__ __forceinline__ void dma_image_q(char* img, const bf16_raw* __restrict__ src, int ld, const QList& ql, int wave, int lane) {
+  ImageRows rows;
+  image_q_rows(rows, ql, wave, lane, nullptr);
+  dma_image_rows(img, src, ld, rows, wave, lane);
 }
 
 // chunk position of E[key][8-bin chunk ch]: ch ^ m[(key >> 2) & 3], m = {0, 2, 3, 1}
@@ -713,18 +727,22 @@ __global__ __launch_bounds__(WTHR, 2) void win_attn_bwd_kernel(const grove_flash
   const QList ql = make_qlist(p, b);
   const bf16_raw* PK = p.pad_k ? (const bf16_raw*)p.pad_k + h * p.hs : nullptr;
   const bf16_raw* PV = p.pad_v ? (const bf16_raw*)p.pad_v + h * p.hs : nullptr;
+  // token-order d_o / o (o_map): the indices first — the d_o image's rows and this thread's o row — so that they arrive under the
+  // Q image's DMA and the rel' staging instead of in front of the d_o DMA
+  ImageRows do_rows;
+  image_q_rows(do_rows, ql, wave, lane, omap);
+  const int myrow = ql.pos(min(tid, ql.nq - 1));
+  const int64_t orow_i = omap ? omap[myrow] : myrow;
   dma_image_q(Xs, Q, p.ld_q, ql, wave, lane);
-  dma_image_q(Ys, dO, p.ld_do, ql, wave, lane, omap);
   for (int c = tid; c < WNT * 16 * 4; c += WTHR) {
     const int row = c >> 2, ch = c & 3;
     u32x4_t v = u32x4_t{0u, 0u, 0u, 0u};
     if (row < ql.nq) v = *(const u32x4_t*)(REL + (int64_t)ql.pos(row) * 32 + ch * 8);
     *(bf16x8_t*)(Rs + row * 64 + ((ch ^ e_swz(row)) << 4)) = wscale(__builtin_bit_cast(bf16x8_t, v), sc);
   }
+  dma_image_rows(Ys, dO, p.ld_do, do_rows, wave, lane);
   u32x4_t orow[10];
-  const int myrow = ql.pos(min(tid, ql.nq - 1));
   if (tid < WNT * 16) {
-    const int64_t orow_i = omap ? omap[myrow] : myrow;
 #pragma unroll
     for (int c = 0; c < 10; ++c) orow[c] = *(const u32x4_t*)(Og + orow_i * p.ld_o + c * 8);
     lse_s[tid] = tid < ql.nq ? p.lse[bh + myrow] * 1.4426950408889634f : INFINITY;  // (+inf: a row past the last query has P = exp2(s - inf) = 0)
@@ -760,18 +778,25 @@ __global__ __launch_bounds__(WTHR, 2) void win_attn_bwd_kernel(const grove_flash
   }
   __syncthreads();
   // ---- phase B: K, V, E replace Q, dO, rel' in LDS; dQ and d rel' of this wave's query-tile pairs
+  int tok[2];  // d_o rows of this lane's queries in the first pass of the loop below, fetched ahead of the DMA
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int qp = ql.pos(min(wave * 32 + mi * 16 + fr, ql.nq - 1));
+    tok[mi] = omap ? omap[qp] : qp;
+  }
   dma_image_k(Xs, K, p.ld_k, L, PK, ql, wave, lane);
   dma_image_k(Ys, V, p.ld_v, L, PV, ql, wave, lane);
   build_e(Rs, L, p.rel_kw, p.rel_kh, tid);
   bf16_raw* DQ = (bf16_raw*)p.dq + (int64_t)b * p.sdq + h * p.hs;
   bf16_raw* DR = p.drel ? (bf16_raw*)p.drel + bh * 32 : nullptr;
-  auto load_x = [&](QDPair& x, int q0) {
+  auto load_x = [&](QDPair& x, int q0, const int* tk) {
     load_qpair(x.q, Q, p.ld_q, REL, q0, ql, sc, fr, g);
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
       const int qc = min(q0 + mi * 16 + fr, ql.nq - 1);  // compact index: lse_s / del_s; position: the global rows
-      const int qp = ql.pos(qc);
-      const bf16_raw* row = dO + (int64_t)(omap ? omap[qp] : qp) * p.ld_do;
+      int trow = ql.pos(qc);
+      if (tk) trow = tk[mi]; else if (omap) trow = omap[trow];
+      const bf16_raw* row = dO + (int64_t)trow * p.ld_do;
       x.d[mi][0] = *(const bf16x8_t*)(row + g * 8);
       x.d[mi][1] = *(const bf16x8_t*)(row + 32 + g * 8);
       x.dt[mi] = __builtin_bit_cast(s16x4_t, *(const u32x2_t*)(row + 64 + g * 4));
@@ -780,13 +805,13 @@ __global__ __launch_bounds__(WTHR, 2) void win_attn_bwd_kernel(const grove_flash
     }
   };
   QDPair x;
-  load_x(x, wave * 32);  // in flight with the DMA
+  load_x(x, wave * 32, tok);  // in flight with the DMA
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 #pragma nounroll
   for (int q0 = wave * 32; q0 < ql.nq; q0 += 128) {
     bwd_queries(x, Xs, Ys, Rs, q0, L, ql, p.alpha, lane, DQ, p.ld_dq, DR);
-    if (q0 + 128 < ql.nq) load_x(x, q0 + 128);
+    if (q0 + 128 < ql.nq) load_x(x, q0 + 128, nullptr);
   }
 }
 

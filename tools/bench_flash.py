@@ -39,3 +39,46 @@ for name, B, H, L, hs, hd, causal, rel_hw in cases:
         flops = mult * B * H * L * L * hd * (0.5 if causal else 1.0)
         res.append((ms, flops / ms / 1e9))
     print(f"{name:11s} B={B} H={H} L={L} hs={hs}: fwd {res[0][0]:.3f} ms {res[0][1]:6.1f} TF/s | bwd {res[1][0]:.3f} ms {res[1][1]:6.1f} TF/s", flush=True)
+
+# SAM window attention as the step runs it: real tokens only (q_valid, pad_row) and o / d_o in token order with compact heads (o_map)
+_lib.lib().grove_flash_attn_set_window_kernels(1)
+F, H, L, hs, hd, ws, grid = 32, 16, 196, 96, 80, 14, 32
+nw = (grid + ws - 1) // ws
+B = F * nw * nw
+ext = [min(ws, grid - w * ws) for w in range(nw)]
+qv = torch.tensor([[ext[wy], ext[wx]] for _ in range(F) for wy in range(nw) for wx in range(nw)], dtype=torch.int32, device=dev)
+omap = torch.full((B, ws, ws), -1, dtype=torch.int32)
+for f in range(F):
+    for wy in range(nw):
+        for wx in range(nw):
+            ys = torch.arange(ext[wy]) + wy * ws
+            xs = torch.arange(ext[wx]) + wx * ws
+            omap[(f * nw + wy) * nw + wx, :ext[wy], :ext[wx]] = (f * grid * grid + ys[:, None] * grid + xs[None, :]).to(torch.int32)
+omap = omap.reshape(-1).to(dev)
+ntok = F * grid * grid
+qkv = torch.zeros(B * L, 3 * H * hs, device=dev)
+qkv.view(B * L, 3, H, hs)[..., :hd] = torch.randn(B * L, 3, H, hd, device=dev)
+qkv = qkv.to(bf)
+pad_row = qkv[0].clone()
+rel = torch.randn(B * H, L, 32, device=dev).to(bf)
+dq = torch.empty_like(qkv)
+alpha = hd ** -0.5
+for name, tokens in (("win real", False), ("win real tok", True)):
+    kw = dict(o_map=omap, o_rows=ntok) if tokens else {}
+    do = torch.randn(ntok, H * hd, device=dev).to(bf) if tokens else torch.randn(B * L, H * hs, device=dev).to(bf)
+    def fwd():
+        return ops.flash_attn(qkv, B, L, H, hs, 0, H * hs, 2 * H * hs, alpha, rel=rel, rel_hw=(16, ws), want_lse=True, hs_valid=hd, q_valid=qv, pad_row=pad_row, **kw)
+    out, lse = fwd()
+    def bwd():
+        ops.flash_attn_bwd(qkv, out, do, lse, dq, B, L, H, hs, 0, H * hs, 2 * H * hs, alpha, rel=rel, rel_hw=(16, ws), want_drel=True, hs_valid=hd, q_valid=qv,
+                           pad_row=pad_row, **({"o_map": omap} if tokens else {}))
+    res = []
+    for fn in (fwd, bwd):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        res.append(e0.elapsed_time(e1) / 10)
+    print(f"{name:12s} F={F} windows={B} H={H} (q_valid, pad_row{', o_map' if tokens else ''}): fwd {res[0]:.3f} ms | bwd {res[1]:.3f} ms", flush=True)
