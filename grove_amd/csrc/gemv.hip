@@ -160,8 +160,8 @@ extern "C" int grove_gemv_bf16(const grove_gemv_params* pp, void* stream) {
 
 // ----------------------------------------------------------------------------------------------------------------------
 // Fused decode attention: RoPE(q, k) + cache append + one-query attention. One block per (sequence, head).
-// Scores: thread j handles key j (+256 per pass): 16-byte loads of the key row against q in LDS (broadcast reads).
-// Values: 16 lanes cover one value row (16 B each), 16 rows per pass; the 16 partial sums are reduced through LDS.
+// Scores: the hd/8 lanes of a group cover one key row (16 B each, contiguous), 16 rows per pass, 4 passes in flight; the partial
+// dot products are summed across the group's lanes. Values: the same lane map; the 16 partial sums are reduced through LDS.
 // HBM-bound on the cache read (2 * S * H * hd * 2 B per layer per sequence).
 // ----------------------------------------------------------------------------------------------------------------------
 namespace {
@@ -200,21 +200,40 @@ __global__ __launch_bounds__(DA_THREADS) void decode_attn_kernel(const grove_dec
   __syncthreads();  // block-wide visibility of the appended row (same block reads it back below)
   __threadfence_block();
   const int Lk = t + 1;
+  constexpr int CPR = HD / 8;           // 16-byte chunks per row
+  constexpr int G = DA_THREADS / CPR;   // rows per pass (16 for hd 128, 32 for hd 64)
+  const int g = tid / CPR, c = tid - g * CPR;
   float mx = -INFINITY;
-  for (int j = tid; j < Lk; j += DA_THREADS) {
-    const bf16_raw* kr = kc + (int64_t)j * 2 * HH;
-    float s = 0.f;
+  {
+    // the CPR lanes of a group read one key row (contiguous 16-byte pieces), each against its 8 q values; 4 rows in flight per lane
+    float qv[8];
 #pragma unroll
-    for (int c = 0; c < HD / 8; ++c) {
-      const u32x4_t kv = *(const u32x4_t*)(kr + c * 8);
-      s = fmaf(bf_lo(kv.x), q_s[c * 8 + 0], s); s = fmaf(bf_hi(kv.x), q_s[c * 8 + 1], s);
-      s = fmaf(bf_lo(kv.y), q_s[c * 8 + 2], s); s = fmaf(bf_hi(kv.y), q_s[c * 8 + 3], s);
-      s = fmaf(bf_lo(kv.z), q_s[c * 8 + 4], s); s = fmaf(bf_hi(kv.z), q_s[c * 8 + 5], s);
-      s = fmaf(bf_lo(kv.w), q_s[c * 8 + 6], s); s = fmaf(bf_hi(kv.w), q_s[c * 8 + 7], s);
+    for (int e = 0; e < 8; ++e) qv[e] = q_s[c * 8 + e];
+    const bf16_raw* kbase = kc + c * 8;
+    auto dot8 = [&](const u32x4_t kv) {
+      float s = bf_lo(kv.x) * qv[0];
+      s = fmaf(bf_hi(kv.x), qv[1], s);
+      s = fmaf(bf_lo(kv.y), qv[2], s); s = fmaf(bf_hi(kv.y), qv[3], s);
+      s = fmaf(bf_lo(kv.z), qv[4], s); s = fmaf(bf_hi(kv.z), qv[5], s);
+      s = fmaf(bf_lo(kv.w), qv[6], s); s = fmaf(bf_hi(kv.w), qv[7], s);
+      return s;
+    };
+    auto finish = [&](float s, int j) {  // sum over the group's lanes (CPR = 4, 8 or 16 consecutive lanes)
+#pragma unroll
+      for (int off = CPR / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+      s *= p.alpha;
+      if (c == 0) sc[j] = s;
+      mx = fmaxf(mx, s);
+    };
+    int j = g;
+    for (; j + 3 * G < Lk; j += 4 * G) {
+      u32x4_t kv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) kv[u] = *(const u32x4_t*)(kbase + (int64_t)(j + u * G) * 2 * HH);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) finish(dot8(kv[u]), j + u * G);
     }
-    s *= p.alpha;
-    sc[j] = s;
-    mx = fmaxf(mx, s);
+    for (; j < Lk; j += G) finish(dot8(*(const u32x4_t*)(kbase + (int64_t)j * 2 * HH)), j);
   }
   mx = block_max<DA_THREADS>(mx, red);
   float sum = 0.f;
@@ -226,9 +245,6 @@ __global__ __launch_bounds__(DA_THREADS) void decode_attn_kernel(const grove_dec
   sum = block_sum<DA_THREADS>(sum, red);  // (its barriers also publish sc[])
   const float inv = 1.f / sum;
   // o[d] = sum_j p_j v_j[d]: lane group g = tid / (HD/8) takes rows j = g, g + G, ...; chunk c = tid % (HD/8)
-  constexpr int CPR = HD / 8;           // 16-byte chunks per row
-  constexpr int G = DA_THREADS / CPR;   // rows per pass (16 for hd 128, 32 for hd 64)
-  const int g = tid / CPR, c = tid - g * CPR;
   float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   auto pv = [&](float pj, const u32x4_t vv) {
     o[0] = fmaf(pj, bf_lo(vv.x), o[0]); o[1] = fmaf(pj, bf_hi(vv.x), o[1]);
