@@ -636,14 +636,16 @@ class GROVEForCausalLM(torch.nn.Module):
         if R > 0:
             Vv = d.vocab
             ops.wgrad(dlogits, hv.data, self._grad["lm_head.weight"], K=R)
-            Vk = ops.pad_to(Vv, 64)  # K of the dgrad GEMM: a multiple of 64 keeps it on the BK = 64 kernels
-            wT = torch.zeros((H, Vk), dtype=bf, device=self.dev)
-            ops.transpose(self._sd["lm_head.weight"], Vv, H, H, wT, Vk, pad_to_cols=Vk)
-            dl = dlogits
-            if dlogits.shape[1] != Vk:
-                dl = torch.zeros((R, Vk), dtype=bf, device=self.dev)
-                dl[:, :dlogits.shape[1]].copy_(dlogits)  # column re-pad of a tiny [R, V] matrix (plumbing)
-            dh = ops.linear(dl, wT)
+            # dgrad: d h[R, H] = dlogits[R, V] . W[V, H]. W is K-major for this product, so it runs as the TN form on the weight
+            # as stored — (d h)^T[H, R] = W^T . dlogits^T, K = V split over the chip by the kernel's own split-K — instead of an NT
+            # GEMM on a transposed copy of the 262 MB matrix (the copy alone cost more than this whole sequence).
+            Rp = ops.pad_to(R, 8)
+            dlT = torch.empty((Vv, Rp), dtype=bf, device=self.dev)  # (transpose zero-fills the pad columns)
+            ops.transpose(dlogits, R, Vv, dlogits.stride(0), dlT, Rp, pad_to_cols=Rp)
+            dhT = torch.zeros((H, Rp), dtype=torch.float32, device=self.dev)
+            ops.wgrad(self._sd["lm_head.weight"], dlT, dhT, K=Vv)
+            dh = torch.empty((Rp, H), dtype=bf, device=self.dev)
+            ops.transpose(ops.to_bf16(dhT), H, Rp, Rp, dh, H)
             ops.copy_rows(dh, d_hidden, R, H, idx_dst=rows, accumulate=True)
         self._grads_final(["lm_head."])
         # text_hidden_fcs (tape) -> d hidden at the DET rows;  projector closures run later with feats.grad set
