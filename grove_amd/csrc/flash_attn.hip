@@ -446,7 +446,7 @@ __global__ __launch_bounds__(NTHR, (HS <= 96 ? 2 : 1)) void flash_bwd_dkv_kernel
   const float sc = p.alpha * 1.4426950408889634f;
 
   // register prefetch of the next Q / dO tile only where the 256-register budget has room for it
-  constexpr bool PREFETCH = HS <= 64;
+  constexpr bool PREFETCH = HS <= 64 || HS == 128;  // (head dim 128 runs one wave per SIMD: 512 registers)
   TileRegs<PREFETCH ? HS : 32> qreg, doreg;
   if constexpr (PREFETCH) {
     load_tile<HS>(qreg, Q, p.ld_q, qstart, p.Lq, tid);
