@@ -577,7 +577,7 @@ __global__ __launch_bounds__(NTHR, (HS <= 96 ? 2 : 1)) void flash_bwd_dkv_kernel
 // The two 16-query tiles of a wave are processed one after the other per key tile (halves the live S / dP
 // accumulators) so that the kernel fits the 256-register budget that keeps MFMA results in arch VGPRs.
 template <int HS, int NRK>
-__global__ __launch_bounds__(NTHR, 2) void flash_bwd_dq_kernel(const grove_flash_attn_params p) {
+__global__ __launch_bounds__(NTHR, 2) void flash_bwd_dq_kernel(const grove_flash_attn_params p, const int make_delta) {
   using C = Cfg<HS>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;
@@ -619,7 +619,23 @@ __global__ __launch_bounds__(NTHR, 2) void flash_bwd_dq_kernel(const grove_flash
       for (int k2 = 0; k2 < NRK; ++k2) relf[mi][k2] = scale_frag(relfrag(rrow, k2 * 32 + g * 8, nrel), sc);
     }
     lse2[mi] = p.lse[(int64_t)(b * p.H + h) * p.Lq + qi] * 1.4426950408889634f;
-    del[mi] = p.delta[(int64_t)(b * p.H + h) * p.Lq + qi];
+    if (make_delta) {
+      // delta = rowsum(dO * O) of this block's queries, made here (the lane already holds its 8-column pieces of the dO row) and
+      // left in p.delta for the dK / dV kernel, which is launched after this one: no separate pass over o and d_o
+      const bf16_raw* orow = (const bf16_raw*)p.o + (int64_t)b * p.so + h * HS + (int64_t)qi * p.ld_o;
+      float dp = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) {
+        const u32x4_t a = *(const u32x4_t*)(orow + ks * 32 + g * 8), d = __builtin_bit_cast(u32x4_t, dof[mi][ks]);
+        dp += bf_lo(a.x) * bf_lo(d.x) + bf_hi(a.x) * bf_hi(d.x) + bf_lo(a.y) * bf_lo(d.y) + bf_hi(a.y) * bf_hi(d.y) +
+              bf_lo(a.z) * bf_lo(d.z) + bf_hi(a.z) * bf_hi(d.z) + bf_lo(a.w) * bf_lo(d.w) + bf_hi(a.w) * bf_hi(d.w);
+      }
+      dp = group_sum(dp);
+      del[mi] = dp;
+      if (g == 0 && q0 + mi * 16 + fr < p.Lq) p.delta[(int64_t)(b * p.H + h) * p.Lq + qi] = dp;
+    } else {
+      del[mi] = p.delta[(int64_t)(b * p.H + h) * p.Lq + qi];
+    }
 #pragma unroll
     for (int bt = 0; bt < NBT; ++bt) drl[mi][bt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -817,16 +833,17 @@ extern "C" int grove_flash_attn_bwd(const grove_flash_attn_params* p, void* stre
   }
   const int64_t nrows = (int64_t)p->B * p->H * p->Lq;
   const bool vec16 = p->ld_o % 8 == 0 && p->ld_do % 8 == 0 && p->so % 8 == 0 && p->sdo % 8 == 0 && (((uintptr_t)p->o | (uintptr_t)p->d_o) & 15) == 0;
-  if (vec16) hipLaunchKernelGGL(flash_delta_kernel<true>, dim3((unsigned)((nrows + 15) / 16)), dim3(NTHR), 0, s, *p);
-  else hipLaunchKernelGGL(flash_delta_kernel<false>, dim3((unsigned)((nrows + 15) / 16)), dim3(NTHR), 0, s, *p);
+  // delta = rowsum(dO * O): made by the dQ kernel (launched first) when the rows allow 16-byte loads, else by its own pass
+  const int make_delta = vec16 ? 1 : 0;
+  if (!vec16) hipLaunchKernelGGL(flash_delta_kernel<false>, dim3((unsigned)((nrows + 15) / 16)), dim3(NTHR), 0, s, *p);
   const int nrel = p->rel ? p->rel_ld : 0;
   dim3 gk((p->Lk + 127) / 128, p->H, p->B), gq((p->Lq + 127) / 128, p->H, p->B);
 #define BWD_L(HS, NRK)                                                                                     \
   {                                                                                                        \
     hipFuncSetAttribute((const void*)flash_bwd_dkv_kernel<HS, NRK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1); \
     hipFuncSetAttribute((const void*)flash_bwd_dq_kernel<HS, NRK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);  \
+    hipLaunchKernelGGL((flash_bwd_dq_kernel<HS, NRK>), gq, dim3(NTHR), l2, s, *p, make_delta);              \
     hipLaunchKernelGGL((flash_bwd_dkv_kernel<HS, NRK>), gk, dim3(NTHR), l1, s, *p);                         \
-    hipLaunchKernelGGL((flash_bwd_dq_kernel<HS, NRK>), gq, dim3(NTHR), l2, s, *p);                          \
   }
 #define BWD(HS)                                                                                            \
   {                                                                                                        \
