@@ -194,7 +194,8 @@ __global__ __launch_bounds__(NTHR, 2) void flash_fwd_kernel(const grove_flash_at
   char* Ks = smem;
   char* Vs = smem + C::TILEB;
   char* Es = smem + 2 * C::TILEB;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // an SGPR: everything derived from it (key / query ranges, mask tests) is wave-uniform control flow
   const int fr = lane & 15, g = lane >> 4;
   int bx, h, b;
   causal_block_order(p.causal != 0, true, bx, h, b);
@@ -395,7 +396,8 @@ __global__ __launch_bounds__(NTHR, (HS <= 96 ? 2 : 1)) void flash_bwd_dkv_kernel
   float* del_s = lse_s + BKV;                    // [64]
   char* relq = (char*)(del_s + BKV);             // bf16 [64 q][64 bins], row stride RELB (rel / alpha)
   constexpr int RELB = 64 * 2 + 32;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // an SGPR: everything derived from it (key / query ranges, mask tests) is wave-uniform control flow
   const int fr = lane & 15, g = lane >> 4;
   int bx, h, b;
   causal_block_order(p.causal != 0, false, bx, h, b);
@@ -587,7 +589,8 @@ __global__ __launch_bounds__(NTHR, 2) void flash_bwd_dq_kernel(const grove_flash
   const int nrel = REL ? p.rel_ld : 0;
   constexpr int nrk = NRK;
   const int nbt = (REL && p.drel) ? (nrel + 15) >> 4 : 0;  // 16-bin tiles of d rel (<= 2 * NRK)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // an SGPR: everything derived from it (key / query ranges, mask tests) is wave-uniform control flow
   const int fr = lane & 15, g = lane >> 4;
   int bx, h, b;
   causal_block_order(p.causal != 0, true, bx, h, b);
