@@ -643,7 +643,9 @@ class GROVEForCausalLM(torch.nn.Module):
             dlT = torch.empty((Vv, Rp), dtype=bf, device=self.dev)  # (transpose zero-fills the pad columns)
             ops.transpose(dlogits, R, Vv, dlogits.stride(0), dlT, Rp, pad_to_cols=Rp)
             dhT = torch.zeros((H, Rp), dtype=torch.float32, device=self.dev)
-            ops.wgrad(self._sd["lm_head.weight"], dlT, dhT, K=Vv)
+            # (6 K ranges: beyond that the fp32 atomics on the small [H, R] output outweigh the extra blocks — 235 us at the
+            # automatic 12, 168 at 6, tools/bench_general_gemm.py)
+            ops.wgrad(self._sd["lm_head.weight"], dlT, dhT, K=Vv, split_k=6 if Vv >= 4096 else 0)
             dh = torch.empty((Rp, H), dtype=bf, device=self.dev)
             ops.transpose(ops.to_bf16(dhT), H, Rp, Rp, dh, H)
             ops.copy_rows(dh, d_hidden, R, H, idx_dst=rows, accumulate=True)
