@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+FP8_BOX_L1_BOUND = 1.5e-2  # e4m3's own figure on the tiny case (1.03e-2 measured and predicted, tools/fp8_policy_study.py) x 1.5
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak of MI355X (MI355X_MICROARCH.md, chip-level parameters)
 
 
@@ -39,7 +40,7 @@ def build(dims, dev, args):
     del sd
     torch.cuda.empty_cache()
     engine = T.GroveEngine(model, targs, total_steps=100000, exchange=getattr(args, "exchange", "allreduce"),
-                           overlap=not getattr(args, "no_comm_overlap", False))
+                           overlap=not getattr(args, "no_comm_overlap", False), sparse_embed=not getattr(args, "dense_embed", False))
     return model, engine
 
 
@@ -163,14 +164,12 @@ def decode_rate(model, dims, dev):
                          "frac": round(wbytes / per_tok / 8e12, 3), "weight_bytes_per_token": wbytes}}
 
 
-def cpu_baseline(args):
-    """Oracle (CPU port) on a bounded sample of the same workload: one 8-frame window at FULL dimensions, one
-    layer of each tower forward (+ backward where the step has one), scaled by the layer counts of the step."""
+def cpu_layer_samples(args):
+    """Per-layer samples of the oracle at full dims (one layer of each tower, forward and — where the step has one — backward):
+    the backward part of the CPU baseline, and the whole of it in the `--cpu_baseline sampled` fallback."""
     from grove_amd.synthetic import FULL, det_tensor, param_shapes, synthetic_state_dict
     from oracle import grove_oracle as O
     d = FULL
-    cores = min(os.cpu_count() or 1, 64)  # torch CPU kernels stop scaling (and oversubscribe) beyond ~64 threads
-    torch.set_num_threads(cores)
     want = [n for n in param_shapes(d) if any(s in n for s in (
         "vision_model.encoder.layers.1.", "image_encoder.blocks.6.", "image_encoder.blocks.7.", "image_encoder.adapters.0.",
         "model.layers.0."))]
@@ -216,14 +215,66 @@ def cpu_baseline(args):
     n_glob = len(d.sam_global)
     n_bwd = d.sam_depth - (min(d.sam_global) + 1)
     n_bwd_glob = n_glob - 1
-    total = (t_clip * (d.clip_layers - 1)
-             + swf * (d.sam_depth - n_glob) + sgf * n_glob + swb * (n_bwd - n_bwd_glob) + sgb * n_bwd_glob
-             + (saf + sab) * n_glob + (lf + lb) * d.n_layers)
+    fwd = t_clip * (d.clip_layers - 1) + swf * (d.sam_depth - n_glob) + sgf * n_glob + saf * n_glob + lf * d.n_layers
+    bwd = swb * (n_bwd - n_bwd_glob) + sgb * n_bwd_glob + sab * n_glob + lb * d.n_layers
     measured = t_clip + swf + swb + sgf + sgb + saf + sab + lf + lb
-    return {"value": round(8.0 / total, 4), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": (f"oracle fp32 at full dims, one 8-frame window: 1 CLIP layer fwd, 1 windowed + 1 global SAM block fwd+bwd, "
-                       f"1 SAM adapter fwd+bwd, 1 LLaMA layer (S={S}) fwd+dgrad; {measured:.1f} s measured, scaled by layer counts "
-                       f"(stems/projector/decoder/lm_head <2% of FLOPs, not included) to {total:.0f} s per window")}
+    return fwd, bwd, measured, S
+
+
+def cpu_baseline(args, dev=None):
+    """The CPU oracle (a port, oracle/grove_oracle.py) on the host cores, on a bounded sample of the bench workload: ONE of the
+    step's 8-frame windows at FULL dimensions.
+      default (`--cpu_baseline window`): the whole window FORWARD — SAM tower, CLIP tower, projector, splice, LLaMA 32 layers, box
+        decoder — is run and timed end to end (about a minute on 64 threads; weights are regenerated tensor by tensor, their
+        generation time excluded), and the step's backward is added from per-layer fwd+bwd samples scaled by the layer counts;
+      `--cpu_baseline train`: the whole window fwd + bwd through torch autograd, timed (needs ~80 GB of host memory);
+      `--cpu_baseline sampled`: per-layer samples only (the round-1/2 figure; a few seconds)."""
+    from grove_amd.synthetic import FULL, synthetic_batch
+    from oracle import grove_oracle as O
+    d = FULL
+    cores = min(os.cpu_count() or 1, 64)  # torch CPU kernels stop scaling (and oversubscribe) beyond ~64 threads
+    torch.set_num_threads(cores)
+    mode = args.cpu_baseline
+    fwd_s, bwd_s, sampled, S = cpu_layer_samples(args)
+    if mode == "sampled":
+        total = fwd_s + bwd_s
+        return {"value": round(8.0 / total, 4), "unit": "frames/s", "cores": cores, "kind": "port", "measured": False, "seconds_per_window": round(total, 1),
+                "sample": (f"oracle fp32 at full dims, one 8-frame window: 1 CLIP layer fwd, 1 windowed + 1 global SAM block fwd+bwd, "
+                           f"1 SAM adapter fwd+bwd, 1 LLaMA layer (S={S}) fwd+dgrad; {sampled:.1f} s measured, scaled by layer counts "
+                           f"(stems/projector/decoder/lm_head <2% of FLOPs, not included) to {total:.0f} s per window")}
+    from oracle.lazy_weights import LazyRoundedWeights
+    bf = torch.bfloat16
+    batch = synthetic_batch(d, B=1, T=8, L=args.text_len, n_det=3, seed=7)
+    kw = batch.as_kwargs(inference=(mode != "train"))
+    for k in ("global_enc_images", "grounding_enc_images"):
+        kw[k] = kw[k].to(bf).float()
+    if mode == "train":
+        from grove_amd.model.GROVE import trainable_names
+        from grove_amd.synthetic import synthetic_state_dict
+        names = set(trainable_names(d))
+        sd = {k: v.to(bf).float().cpu().requires_grad_(k in names)
+              for k, v in synthetic_state_dict(d, device=dev if dev is not None else "cpu", dtype=torch.float32).items()}
+        t0 = time.perf_counter()
+        out = O.model_forward(sd, d, **kw)
+        t1 = time.perf_counter()
+        out["loss"].backward()
+        t2 = time.perf_counter()
+        total = t2 - t0
+        return {"value": round(8.0 / total, 4), "unit": "frames/s", "cores": cores, "kind": "port", "measured": True, "seconds_per_window": round(total, 1),
+                "sample": (f"oracle fp32 at full dims, ONE whole 8-frame window of the step (B=1, T=8, L={args.text_len}), forward {t1 - t0:.1f} s + "
+                           f"backward through torch autograd {t2 - t1:.1f} s, timed end to end on {cores} threads")}
+    sd = LazyRoundedWeights(d, gen_device=dev if dev is not None else "cpu")
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        O.model_forward(sd, d, **kw)
+    t_fwd = time.perf_counter() - t0 - sd.fetch_seconds
+    total = t_fwd + bwd_s
+    return {"value": round(8.0 / total, 4), "unit": "frames/s", "cores": cores, "kind": "port", "measured": True, "seconds_per_window": round(total, 1),
+            "forward_seconds_measured": round(t_fwd, 1), "forward_frames_per_s": round(8.0 / t_fwd, 4), "backward_seconds_from_layer_samples": round(bwd_s, 1),
+            "sample": (f"oracle fp32 at full dims, ONE whole 8-frame window of the step (B=1, T=8, L={args.text_len}): the full forward (SAM + CLIP + projector "
+                       f"+ LLaMA + box decoder) run and timed end to end = {t_fwd:.1f} s on {cores} threads (weight generation, {sd.fetch_seconds:.1f} s, excluded; "
+                       f"the per-layer samples put it at {fwd_s:.1f} s); the step's backward added from per-layer fwd+bwd samples x layer counts = {bwd_s:.1f} s "
+                       f"(`--cpu_baseline train` times the whole fwd+bwd instead)")}
 
 
 def tiny_box_l1(dev):
@@ -306,7 +357,32 @@ def self_launch(n, argv):
     return subprocess.run(cmd, env=env).returncode
 
 
-def infer_bench(args, dev, dims):
+def infer_box_l1(dev, dtype):
+    """Box L1 of the inference configuration of this mode (bf16 or fp8 linear layers) against the fp32 CPU oracle on the tiny-dims
+    case of tests/test_parity_r2_gpu.py::test_fp8_vit_llama_path_vs_oracle_and_bf16 (every GEMM K a multiple of 128)."""
+    import dataclasses
+    from grove_amd import GROVEForCausalLM
+    from grove_amd.synthetic import TINY, synthetic_batch, synthetic_state_dict
+    from oracle import grove_oracle as O
+    bf = torch.bfloat16
+    d = dataclasses.replace(TINY, clip_dim=128, clip_heads=2, clip_mlp=256)
+    sd = synthetic_state_dict(d)
+    model = GROVEForCausalLM(dims=d, device=dev, state_dict=sd, det_token_idx=d.det_token_idx, num_frames=8, pe_dtype=torch.float32, gemm_dtype=dtype)
+    batch = synthetic_batch(d, B=2, T=8, L=40, n_det=3, seed=2)
+    kw = batch.as_kwargs(inference=True)
+    kd = dict(kw)
+    for k in ("global_enc_images", "grounding_enc_images"):
+        kd[k] = kw[k].to(dev).to(bf)
+        kw[k] = kw[k].to(bf).float()
+    for k in ("input_ids", "labels", "attention_masks", "offset"):
+        kd[k] = kw[k].to(dev)
+    out = model(**kd)
+    with torch.no_grad():
+        ref = O.model_forward({k: v.to(bf).float() for k, v in sd.items()}, d, **kw)
+    return float((out["flat_boxes"].cpu() - ref["flat_boxes"]).abs().mean())
+
+
+def infer_bench(args, dev, dims, world=1, rank=0):
     """BASELINE config 5 as an explicit mode (`--mode infer`; never the default line): clip inference with the SAM mask decoder at
     T = 32 — CLIP + LLaMA linear layers on the fp8 MFMA GEMM with `--dtype fp8` (bf16 otherwise), SAM tower, box decoder AND the mask
     branch (low-res masks -> postprocess to the original frame size) for every ([DET], frame) instance. One step = one batch of
@@ -318,7 +394,10 @@ def infer_bench(args, dev, dims):
     model = GROVEForCausalLM(dims=dims, device=dev, state_dict=sd, det_token_idx=dims.det_token_idx, num_frames=8, gemm_dtype=args.dtype)
     del sd
     torch.cuda.empty_cache()
-    b = synthetic_batch(dims, B=args.batch, T=args.frames, L=args.text_len, n_det=3, seed=7, device=dev, dtype=bf)
+    # N > 1 (config 5 is an 8-GPU job): replicas only — every rank runs its own `--batch` clips (seeded by rank, the
+    # DistributedSampler shard of infer_iground.py:538-551), no data-path collective; one all_gather_object of the per-rank
+    # results at the end of the run, as infer_iground.py:290-293
+    b = synthetic_batch(dims, B=args.batch, T=args.frames, L=args.text_len, n_det=3, seed=7 + 1000 * rank, device=dev, dtype=bf)
     kw = b.as_kwargs(inference=True)
     band = int(dims.sam_image * 360 / 640)
     rec = []
@@ -337,11 +416,29 @@ def infer_bench(args, dev, dims):
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out, res = step()
     torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    gathered = 1
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+        # the job's one collective (after the timed region, like the reference's end-of-run gather): per-clip results to every rank
+        from grove_amd.infer import update_and_sort_video_outputs
+        mine = {f"rank{rank}_clip{c}": {"pred_bboxes": [x.cpu() for x in out["pred_bboxes"][c]],
+                                         "logits_temp_objectness": [x.cpu() for x in out["logits_temp_objectness"][c]]} for c in range(args.batch)}
+        parts = [None] * world
+        dist.all_gather_object(parts, mine)
+        gathered = len(update_and_sort_video_outputs(parts)) // args.batch
     # dominant kernel of the mode: event-timed launches of the ViT / LLaMA linear layers in one extra pass
     def timed_fp8(x, wq, ws, *a, **k):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -360,13 +457,16 @@ def infer_bench(args, dev, dims):
         finally:
             ops.linear_fp8 = orig_fp8
             model.tower_overlap = overlap
-    frames = args.batch * args.frames * args.steps
-    line = {"metric": "frames/sec (clip inference fwd + SAM masks)", "value": round(frames / dt, 3), "unit": "frames/s", "n_gpus": 1, "steps": args.steps,
+    frames = world * args.batch * args.frames * args.steps
+    line = {"metric": "frames/sec (clip inference fwd + SAM masks)", "value": round(frames / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"GROVE inference + SAM mask decoder: {args.batch} clips x T={args.frames} frames ({args.batch * args.frames // 8} windows), "
                                    f"LLaVA-1.5-7B + CLIP ViT-L/14-336 ({args.dtype} linear layers) + SAM ViT-H@512 (bf16) + box / mask decoder, text L={args.text_len}",
-                       "dims": args.dims, "instances": int(out["flat_boxes"].shape[0]), "mask_shape": list(res["masks"].shape)}}
+                       "dims": args.dims, "instances": int(out["flat_boxes"].shape[0]), "mask_shape": list(res["masks"].shape),
+                       "parallelism": f"dp{world} (replicas only: clips sharded over ranks, end-of-run all_gather_object)", "ranks": world,
+                       "ranks_gathered": gathered, "collective_backend": (dist.get_backend() if world > 1 else None),
+                       "frames_per_sec_per_gpu": round(frames / dt / world, 3)}}
     if rec:
         fl = sum(f for _, _, f in rec)
         secs = sum(e0.elapsed_time(e1) for e0, e1, _ in rec) * 1e-3
@@ -386,11 +486,16 @@ def main():
     ap.add_argument("--text_len", type=int, default=128)
     ap.add_argument("--dims", default="full", choices=["full", "tiny"])
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--cpu_baseline", default="window", choices=["window", "train", "sampled"],
+                    help="CPU oracle leg: one whole window forward timed end to end (+ backward from layer samples; default), the whole "
+                         "window fwd+bwd timed (needs ~80 GB host memory), or per-layer samples only")
     ap.add_argument("--mode", default="train", choices=["train", "infer"],
                     help="train (default, the headline line: BASELINE config 3) or infer (config 5: inference + SAM masks, use --frames 32 --dtype fp8)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"], help="--mode infer: linear layers of the CLIP tower and the LLaMA stack")
-    ap.add_argument("--exchange", default="allreduce", choices=["allreduce", "rs_ag"],
-                    help="N > 1: one all-reduce per gradient bucket, or reduce-scatter + all-gather per bucket")
+    ap.add_argument("--exchange", default="allreduce", choices=["allreduce", "rs_ag", "a2a_f32"],
+                    help="N > 1: one all-reduce per gradient bucket, reduce-scatter + all-gather per bucket, or all-to-all + fp32 sum + all-gather")
+    ap.add_argument("--dense_embed", action="store_true",
+                    help="N > 1: exchange embed_tokens' gradient densely (131 M elements) instead of as touched rows (A/B arm)")
     ap.add_argument("--no_comm_overlap", action="store_true",
                     help="N > 1: exchange all gradients after the backward instead of group by group from inside it (exposed-communication A/B)")
     ap.add_argument("--serial_towers", action="store_true",
@@ -426,8 +531,18 @@ def main():
     dims = FULL if args.dims == "full" else TINY
 
     if args.mode == "infer":
-        assert world == 1, "--mode infer is a one-GPU line"
-        os.write(real_stdout, (json.dumps(infer_bench(args, dev, dims)) + "\n").encode())
+        line = infer_bench(args, dev, dims, world, rank)
+        if rank == 0:
+            if not args.no_cpu_baseline and world == 1:
+                try:  # parity figure of THIS mode's arithmetic (fp8: the quantised path's own figure)
+                    line["box_l1_vs_oracle"] = {"value": round(infer_box_l1(dev, args.dtype), 6), "case": "tiny dims (K % 128 == 0), B=2, T=8, vs fp32 CPU oracle",
+                                                "tolerance": 1e-3 if args.dtype == "bf16" else FP8_BOX_L1_BOUND}
+                except Exception as e:
+                    line["box_l1_vs_oracle"] = {"error": repr(e)}
+            os.write(real_stdout, (json.dumps(line) + "\n").encode())
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
         return
     model, engine = build(dims, dev, args)
     model.tower_overlap = not args.serial_towers
@@ -459,6 +574,7 @@ def main():
         dt = float(t[0])
     frames = world * args.batch * args.frames * args.steps
     loss = float(out["loss"])
+    exposed_ms = engine.exposed_comm_ms() if world > 1 else None  # last timed step: what the compute stream waited for the collectives
 
     per_kernel = instrumented_gemm_pass(engine, batch)
     dom = max(per_kernel, key=lambda k: per_kernel[k][2])  # the kernel that takes most of the step
@@ -481,7 +597,9 @@ def main():
                        "dims": args.dims, "global_batch_clips": world * args.batch, "frames_per_clip": args.frames,
                        "parallelism": f"dp{world}", "ranks": world,
                        "gradient_exchange": (None if world == 1 else f"{args.exchange}, bf16 wire, " +
-                                             ("after the backward" if args.no_comm_overlap else "overlapped with the backward (per parameter group)")),
+                                             ("after the backward" if args.no_comm_overlap else "overlapped with the backward (per parameter group)") +
+                                             (", embed_tokens dense" if args.dense_embed else ", embed_tokens as touched rows (all-gather of ids + rows, fp32 sum)")),
+                       "exposed_comm_ms": (None if exposed_ms is None else round(exposed_ms, 3)),
                        "collective_backend": (dist.get_backend() if world > 1 else None),
                        "frames_per_sec_per_gpu": round(frames / dt / world, 3), "last_loss": round(loss, 4),
                        "towers": "serial" if args.serial_towers else "SAM tower on a second stream beside CLIP->LLaMA (roofline: one extra step with the towers serialised)"},
@@ -507,7 +625,7 @@ def main():
             try:
                 res["box_l1_vs_oracle_tiny"] = round(tiny_box_l1(dev), 6)
                 res["train_parity_vs_oracle_tiny"] = tiny_train_parity(dev)
-                res["cpu_baseline"] = cpu_baseline(args)
+                res["cpu_baseline"] = cpu_baseline(args, dev)
             except Exception as e:  # the baseline is informational; never lose the measured line
                 res["cpu_baseline"] = {"error": repr(e)}
         os.write(real_stdout, (json.dumps(res) + "\n").encode())

@@ -130,10 +130,62 @@ def dims_from_checkpoint(path, sd=None, base=None):
     return replace(d, **upd)
 
 
-def load_grove_weights(model, path, strict=False, sd=None):
+def constructor_init(name, shape):
+    """The value a parameter has in the reference when NO checkpoint provides it: PyTorch's constructor defaults, which is what
+    `initialize_custom_layers_in_model` (train.py:160-191) and GROVEForCausalLM.__init__ (GROVE.py:75-79) leave in the custom layers
+    of a model started from a base LLaVA checkpoint — nn.Linear / nn.Conv3d: weight and bias U(-1/sqrt(fan_in), 1/sqrt(fan_in))
+    (kaiming_uniform with a = sqrt(5)); adapter `alpha` zeros (image_encoder.py:45); LayerNorm 1 / 0; nn.Embedding N(0, 1).
+    Deterministic in (name, element index) so that every rank builds the same tensor."""
+    import math
+    from .synthetic import det_uniform01
+    leaf = name.rsplit(".", 1)[-1]
+    if leaf == "alpha":
+        return torch.zeros(shape)
+    if "norm" in name and len(shape) == 1:
+        return torch.ones(shape) if leaf == "weight" else torch.zeros(shape)
+    if name.endswith(("iou_token.weight", "mask_tokens.weight", "no_mask_embed.weight", "embed_tokens.weight")):
+        u1, u2 = det_uniform01(name + "#1", shape), det_uniform01(name + "#2", shape)
+        return torch.sqrt(-2.0 * torch.log(u1.clamp_min(1e-7))) * torch.cos(2.0 * math.pi * u2)  # Box-Muller: N(0, 1)
+    if leaf == "bias":
+        return ("bias", name[: -len("bias")] + "weight")  # bound comes from the fan-in of the `weight` beside it
+    fan_in = 1
+    for s_ in shape[1:]:
+        fan_in *= int(s_)
+    bound = 1.0 / math.sqrt(max(fan_in, 1))
+    return (det_uniform01(name, shape) * 2.0 - 1.0) * bound
+
+
+def init_missing_trainable(model, missing):
+    """{name: tensor} for the TRAINABLE parameters a checkpoint does not provide (they used to stay all-zero — a dead
+    ReLU MLP for `text_hidden_fcs` / the box head, silently). Frozen ones are left to the caller to report."""
+    import math
+    from .model.GROVE import trainable_names
+    from .synthetic import det_uniform01, param_shapes
+    shapes = param_shapes(model.dims)
+    train = set(trainable_names(model.dims))
+    out = {}
+    for n in missing:
+        if n not in train:
+            continue
+        v = constructor_init(n, shapes[n])
+        if isinstance(v, tuple):  # bias: U(-1/sqrt(fan_in of its weight), +)
+            wshape = shapes.get(v[1])
+            fan_in = 1
+            for s_ in (wshape[1:] if wshape is not None else shapes[n]):
+                fan_in *= int(s_)
+            v = (det_uniform01(n, shapes[n]) * 2.0 - 1.0) / math.sqrt(max(fan_in, 1))
+        out[n] = v
+    return out
+
+
+def load_grove_weights(model, path, strict=False, sd=None, log=None):
     """infer_iground.py:526-535 / train.py:621-624: read `path`, fit SAM's position tables to the model's image size, and
     `load_state_dict` (non-strict by default, as the reference). Shape mismatches raise — a silently skipped tensor would
-    leave synthetic weights in place. Returns the load report (missing_keys, unexpected_keys) plus `resized`."""
+    leave synthetic weights in place. Keys the checkpoint lacks: trainable ones (a base LLaVA checkpoint has no `text_hidden_fcs`,
+    SAM adapters or box heads, train.py:207-218) get the reference's constructor initialisation (`constructor_init`), as the
+    reference's own modules would hold; frozen ones stay zero and are reported with a warning. Returns the load report
+    (missing_keys, unexpected_keys) plus `resized`, `initialised`, `missing_frozen`."""
+    import warnings
     sd = read_state_dict(path) if sd is None else sd
     d = model.dims
     resized = interpolate_positional_embeddings(sd, d.sam_image, d.sam_patch, d.sam_global)
@@ -141,8 +193,22 @@ def load_grove_weights(model, path, strict=False, sd=None):
     bad = [(k, tuple(v.shape), tuple(want[k].shape)) for k, v in sd.items() if k in want and tuple(v.shape) != tuple(want[k].shape)]
     if bad:
         raise RuntimeError(f"{path}: {len(bad)} tensors do not fit the model, e.g. {bad[:3]}")
+    missing = [n for n in want if n not in sd]
+    init = init_missing_trainable(model, missing)
+    if init:
+        sd = dict(sd)
+        sd.update(init)
     rep = model.load_state_dict(sd, strict=strict)
+    rep.missing_keys = missing
     rep.resized = resized
+    rep.initialised = sorted(init)
+    rep.missing_frozen = [n for n in missing if n not in init]
+    say = log if log is not None else (lambda m: warnings.warn(m, stacklevel=2))
+    if rep.initialised:
+        say(f"{path}: {len(rep.initialised)} trainable tensors absent from the checkpoint were given the reference's constructor "
+            f"initialisation (e.g. {rep.initialised[:3]})")
+    if rep.missing_frozen:
+        say(f"{path}: {len(rep.missing_frozen)} FROZEN tensors are absent from the checkpoint and stay zero (e.g. {rep.missing_frozen[:3]})")
     return rep
 
 

@@ -171,6 +171,18 @@ __global__ __launch_bounds__(EB) void scatter_add_kernel(const bf16_raw* __restr
   }
 }
 
+// the same with fp32 source rows (the fp32-wire form of the sparse embedding-row gradient exchange)
+__global__ __launch_bounds__(EB) void scatter_add_f32src_kernel(const float* __restrict__ src, float* __restrict__ dst, const int32_t* __restrict__ idx,
+                                                                int rows, int C, int ld_src, int ld_dst) {
+  const int64_t n = (int64_t)rows * C;
+  for (int64_t t = (int64_t)blockIdx.x * EB + threadIdx.x; t < n; t += (int64_t)gridDim.x * EB) {
+    const int r = (int)(t / C), c = (int)(t - (int64_t)r * C);
+    const int d = idx ? idx[r] : r;
+    if (d < 0) continue;
+    atomicAdd(dst + (int64_t)d * ld_dst + c, src[(int64_t)r * ld_src + c]);
+  }
+}
+
 // column sums: block (64 column-pairs x 4 row lanes); each thread sums 2 adjacent columns over a
 // row slice, LDS-combine the 4 row lanes, one atomic per column per block.
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16_raw* __restrict__ x, float* __restrict__ out, int rows, int C, int ld, int rows_per_block) {
@@ -348,6 +360,13 @@ extern "C" int grove_scatter_add_f32(const void* src, float* dst, const int32_t*
   GROVE_CHECK(rows > 0 && C > 0 && C % 2 == 0 && ld_src % 2 == 0, GROVE_E_SHAPE, "scatter_add: bad shape");
   hipLaunchKernelGGL(scatter_add_kernel, grid_for((int64_t)rows * (C / 2)), dim3(EB), 0, (hipStream_t)stream, (const bf16_raw*)src, dst, idx, rows, C,
                      ld_src, ld_dst);
+  GROVE_LAUNCH_CHECK();
+  return GROVE_OK;
+}
+extern "C" int grove_scatter_add_rows_f32(const float* src, float* dst, const int32_t* idx, int32_t rows, int32_t C, int32_t ld_src, int32_t ld_dst,
+                                          void* stream) {
+  GROVE_CHECK(rows > 0 && C > 0, GROVE_E_SHAPE, "scatter_add_rows_f32: bad shape");
+  hipLaunchKernelGGL(scatter_add_f32src_kernel, grid_for((int64_t)rows * C), dim3(EB), 0, (hipStream_t)stream, src, dst, idx, rows, C, ld_src, ld_dst);
   GROVE_LAUNCH_CHECK();
   return GROVE_OK;
 }

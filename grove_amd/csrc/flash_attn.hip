@@ -797,6 +797,9 @@ extern "C" int grove_flash_attn_fwd(const grove_flash_attn_params* p, void* stre
   hipStream_t s = (hipStream_t)stream;
   GROVE_CHECK(!p->o_map || (g_win_attn && grove_win_attn_applicable(p) && p->q_valid), GROVE_E_SHAPE,
               "flash_attn_fwd: o_map (token-order output) is a window-kernel feature and needs q_valid");
+  // q_valid / pad_k / pad_v exist only in the window kernels: the general ones below would read the (uninitialised) pad rows instead
+  GROVE_CHECK(!(p->q_valid || p->pad_k || p->pad_v) || (g_win_attn && grove_win_attn_applicable(p)), GROVE_E_SHAPE,
+              "flash_attn_fwd: q_valid / pad_k / pad_v are window-kernel features, but this problem does not take the window kernels");
   if (g_win_attn && grove_win_attn_applicable(p)) {
     grove_win_attn_fwd_launch(p, s);
     GROVE_LAUNCH_CHECK();
@@ -828,8 +831,12 @@ extern "C" int grove_flash_attn_bwd(const grove_flash_attn_params* p, void* stre
   hipStream_t s = (hipStream_t)stream;
   GROVE_CHECK(!p->o_map || (g_win_attn && grove_win_attn_applicable(p) && p->q_valid && p->ld_do % 8 == 0), GROVE_E_SHAPE,
               "flash_attn_bwd: o_map (token-order o / d_o) is a window-kernel feature and needs q_valid");
-  if (g_win_attn && grove_win_attn_applicable(p) && p->ld_do % 8 == 0 && p->ld_dq % 4 == 0 && p->ld_dk % 4 == 0 && p->ld_dv % 4 == 0 &&
-      ((uintptr_t)p->d_o & 15) == 0 && ((uintptr_t)p->o & 15) == 0) {
+  const bool win = g_win_attn && grove_win_attn_applicable(p) && p->ld_do % 8 == 0 && p->ld_dq % 4 == 0 && p->ld_dk % 4 == 0 && p->ld_dv % 4 == 0 &&
+                   ((uintptr_t)p->d_o & 15) == 0 && ((uintptr_t)p->o & 15) == 0;
+  GROVE_CHECK(!(p->q_valid || p->pad_k || p->pad_v) || win, GROVE_E_SHAPE,
+              "flash_attn_bwd: q_valid / pad_k / pad_v are window-kernel features, but this problem does not take the window kernels "
+              "(shape, alignment of o / d_o / dq / dk / dv, or grove_flash_attn_set_window_kernels(0))");
+  if (win) {
     grove_win_attn_bwd_launch(p, s);  // one kernel: delta, dK / dV, then dQ / d rel (win_attn.hip)
     GROVE_LAUNCH_CHECK();
     return GROVE_OK;

@@ -98,3 +98,59 @@ def infer_clip(model, global_enc_images_all, grounding_enc_images_all, prompt_id
     return {"frame_indices": frames, "pred_bboxes": [per_frame[f][0] for f in frames],
             "logits_temp_objectness": [per_frame[f][1] for f in frames], "output_ids": row, "answer_ids": answer,
             "windows": all_indices, "centre": c}
+
+
+def update_and_sort_video_outputs(gathered_results):
+    """infer_iground.py:87-108: merge the per-rank result dicts in rank order; the first occurrence of a clip id wins (the
+    DistributedSampler pads the last round by wrap-around, so a clip can come back from two ranks)."""
+    video_outputs = {}
+    for process_results in gathered_results:
+        for clip_id, data in process_results.items():
+            if clip_id not in video_outputs:
+                video_outputs[clip_id] = data
+    return video_outputs
+
+
+def _to_host(x):
+    """Tensors of a result leave the device before they are pickled for the gather (the reference stores host lists too)."""
+    if torch.is_tensor(x):
+        return x.detach().cpu()
+    if isinstance(x, (list, tuple)):
+        return type(x)(_to_host(v) for v in x)
+    if isinstance(x, dict):
+        return {k: _to_host(v) for k, v in x.items()}
+    return x
+
+
+@torch.no_grad()
+def infer_dataset(model, clips, prompt_ids, *, rank=None, world=None, max_tokens_new=64, answer_ids_fn=None, token_embeddings=None,
+                  num_segments=8, gather=True, on_clip=None):
+    """The multi-rank inference job of infer_iground.py:150-293, 538-551: `clips` is an indexable dataset whose item i is
+    (clip_id, global_enc_images_all [1, 3, F, 336, 336], grounding_enc_images_all [1, 3, F, 512, 512], original_size) — or a callable
+    `clips.load(i)` style object with `__len__` / `__getitem__`; every rank takes the clip indices `shard_clips(len(clips), rank, world)`
+    (the un-shuffled DistributedSampler partition, wrap-around padded), runs `infer_clip` on each, then — exactly as the reference —
+    `barrier` + `all_gather_object` of the per-rank {clip_id: result} dicts and the first-wins merge on every rank. Replicas only:
+    there is no data-path collective, the gather moves the (host) results once at the end. Without an initialised process group
+    (or world == 1) it is the plain loop. Returns the merged dict (every rank holds it; the reference pickles rank 0's)."""
+    import torch.distributed as dist
+    from .train import shard_clips
+    if world is None:
+        world = dist.get_world_size() if dist.is_initialized() else 1
+    if rank is None:
+        rank = dist.get_rank() if dist.is_initialized() else 0
+    mine = {}
+    for i in shard_clips(len(clips), rank, world):
+        clip_id, g_all, s_all, size = clips[i]
+        if clip_id in mine:  # wrap-around padding handed this rank a clip twice
+            continue
+        res = infer_clip(model, g_all.to(model.dev), s_all.to(model.dev), prompt_ids, size, max_tokens_new=max_tokens_new,
+                         answer_ids_fn=answer_ids_fn, token_embeddings=token_embeddings, num_segments=num_segments)
+        mine[clip_id] = _to_host(res)
+        if on_clip is not None:
+            on_clip(clip_id, mine[clip_id])
+    if world > 1 and gather:
+        dist.barrier()                                     # infer_iground.py:290
+        parts = [None for _ in range(world)]
+        dist.all_gather_object(parts, mine)                # :291-292
+        return update_and_sort_video_outputs(parts)        # :293
+    return mine

@@ -114,6 +114,7 @@ class GROVEForCausalLM(torch.nn.Module):
         self._build_engines()
         self._ctx = None
         self._grad_ready_cb = None  # set by GroveEngine: called with (lo, hi, stream) when flat-gradient slice [lo, hi) is final
+        self._sparse_embed = None   # set by GroveEngine (N > 1): the GradExchange that moves embed_tokens' gradient as touched rows
         self._weights_event = None  # set by GroveEngine.step: recorded behind the optimizer update on its own stream
 
     def set_weights_event(self, ev):
@@ -436,6 +437,15 @@ class GROVEForCausalLM(torch.nn.Module):
             hp.n_gt = n_gt
             hp.gt, hp.vis = gt.to(self.dev), vis.to(self.dev)
             dev_t += [hp.rows, hp.tgt, hp.gt, hp.vis]
+        if self._sparse_embed is not None and not inference:
+            # embed_tokens' gradient touches only the text-token rows of this batch: the distinct ids (sorted) and, per hidden row, the
+            # position of its id in that list (-1 for visual rows) — the sparse gradient exchange sends (ids, rows) instead of the table
+            tok_c = plan.tok.cpu()
+            ids_u = torch.unique(tok_c[tok_c >= 0])
+            comp = torch.full_like(tok_c, -1)
+            comp[tok_c >= 0] = torch.searchsorted(ids_u, tok_c[tok_c >= 0]).to(torch.int32)
+            hp.embed_ids, hp.embed_compact = ids_u.to(torch.int32), comp.to(self.dev)
+            dev_t.append(hp.embed_compact)
         hp.device_tensors = dev_t
         return hp
 
@@ -478,6 +488,8 @@ class GROVEForCausalLM(torch.nn.Module):
         main.wait_stream(side)
         for t_ in hp.device_tensors:
             t_.record_stream(main)
+        if getattr(hp, "embed_ids", None) is not None:
+            self._sparse_embed.sparse_begin(int(hp.embed_ids.numel()))  # padded row count = MAX over ranks, resolved by backward time
         plan, S, det_rows, counts = hp.plan, hp.plan.S, hp.det_rows, hp.counts
         # 3. splice, LLaMA (llava_llama.py:88-109)
         self.wait_weights()
@@ -599,7 +611,8 @@ class GROVEForCausalLM(torch.nn.Module):
         if train:
             self._ctx = SimpleNamespace(tp=tp, sam_ctx=sam_ctx, llama_ctx=llama_ctx, plan=plan, feats=feats, ce_state=ce_state,
                                         det=(dv, te, inst_det_t, det_rows, n_det) if n_det else None, dec_state=dec_state,
-                                        dbox=dbox, dobj=dobj, N=N, F=F, hidden_shape=(plan.B * plan.S, H))
+                                        dbox=dbox, dobj=dobj, N=N, F=F, hidden_shape=(plan.B * plan.S, H),
+                                        embed=(hp.embed_ids, hp.embed_compact) if getattr(hp, "embed_ids", None) is not None else None)
         return out
 
     # ------------------------------------------------------------------ backward of the last training forward
@@ -670,15 +683,37 @@ class GROVEForCausalLM(torch.nn.Module):
             dfe = torch.zeros_like(c.feats.data)
             ops.copy_rows(dx, dfe, nv, H, idx_src=plan.vis_dst, idx_dst=plan.vis_src)
             c.feats.grad = dfe
-        ops.scatter_add_f32(dx, self._grad["model.embed_tokens.weight"], plan.tok, plan.B * plan.S, H)
+        sparse = None
+        if c.embed is not None and self._sparse_embed is not None:
+            # N > 1: this rank's rows go into a compact [K, H] fp32 block (K = max distinct rows over the ranks); the exchange
+            # all-gathers (ids, rows) and every rank sums all blocks into the (still zero) dense slice — see GradExchange.sparse_rows
+            ex = self._sparse_embed
+            ids_u, comp = c.embed
+            K = max(ex.sparse_kmax(), 1)
+            loc = torch.zeros((K, H), dtype=torch.float32, device=self.dev)
+            ops.scatter_add_f32(dx, loc, comp, plan.B * plan.S, H)
+            ids_pad = torch.full((K,), -1, dtype=torch.int32)
+            ids_pad[:ids_u.numel()] = ids_u
+            sparse = (ids_pad.to(self.dev), loc)
+        else:
+            ops.scatter_add_f32(dx, self._grad["model.embed_tokens.weight"], plan.tok, plan.B * plan.S, H)
         c.tp.backward()  # mm_projector
         # embed_tokens + projector are final HERE on the main stream, but their exchange is queued behind the SAM adapters' (below):
         # the communication stream is FIFO, and the adapters finish on the SAM stream while the LLaMA dgrad above is still running —
         # handed over first, this last group would hold them back until the end of the LLaMA sweep
         main_grads_done = None
-        if self._grad_ready_cb is not None:
+        if self._grad_ready_cb is not None or sparse is not None:
             main_grads_done = torch.cuda.Event()
             main_grads_done.record(main)
+
+        def last_group():
+            if sparse is not None:
+                n = "model.embed_tokens.weight"
+                lo = self._grad_off[n]
+                self._sparse_embed.sparse_rows(sparse[0], sparse[1], lo, lo + self._sd[n].numel(), H, event=main_grads_done)
+                self._grads_final(["model.mm_projector."], event=main_grads_done)
+            else:
+                self._grads_final(["model.embed_tokens.", "model.mm_projector."], event=main_grads_done)
 
         def adapter_done(j, stream):  # the SAM tower's own stream finishes adapter j's weight / bias / alpha gradients
             self._grads_final([SAM_PREFIX + f"adapters.{j}."], stream)
@@ -687,11 +722,11 @@ class GROVEForCausalLM(torch.nn.Module):
             with torch.cuda.stream(self._sam_stream):
                 d_emb.record_stream(self._sam_stream)
                 self.sam.backward(c.sam_ctx, ops.to_bf16(d_emb), on_adapter_done=lambda j: adapter_done(j, self._sam_stream))
-            self._grads_final(["model.embed_tokens.", "model.mm_projector."], event=main_grads_done)
+            last_group()
             main.wait_stream(self._sam_stream)
         else:
             self.sam.backward(c.sam_ctx, ops.to_bf16(d_emb), on_adapter_done=lambda j: adapter_done(j, None))
-            self._grads_final(["model.embed_tokens.", "model.mm_projector."], event=main_grads_done)
+            last_group()
         self._ctx = None
 
     # ------------------------------------------------------------------ generation (GROVE.py:412-451, llava_llama.py:57-180)

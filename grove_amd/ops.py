@@ -510,6 +510,14 @@ def scatter_add_f32(src, dst, idx, rows, Cc):
     return dst
 
 
+def scatter_add_rows_f32(src, dst, idx):
+    """dst (fp32 [*, C])[idx[r]] += src (fp32 [rows, C])[r]; idx -1 skips the row."""
+    rows, Cc = src.shape
+    _lib.check(_lib.lib().grove_scatter_add_rows_f32(_p(src), _p(dst), _p(idx), rows, Cc, src.stride(0), dst.stride(0), _stream()),
+               "grove_scatter_add_rows_f32")
+    return dst
+
+
 def colsum(x, out=None, accumulate=False):
     rows, Cc = x.shape
     if out is None:

@@ -147,30 +147,60 @@ class GradExchange:
     the slice is rounded into the bf16 wire buffer (DeepSpeed's communication dtype under bf16; fp32 optional) and exchanged on the
     communication stream in buckets, while the rest of the backward keeps the CUs busy. `finish()` (engine.step) makes the compute
     stream wait for the collectives and widens the wire buffer back into the fp32 buffer the optimizer reads.
-      mode "allreduce": one SUM all-reduce per bucket.
+      mode "allreduce": one SUM all-reduce per bucket (RCCL accumulates in the wire dtype).
       mode "rs_ag":     reduce-scatter + all-gather per bucket (the two halves of a ring all-reduce as separate RCCL calls: the form
                         a sharded optimizer update slots between; here the full replica updates everything, so the result is the same).
+      mode "a2a_f32":   FP32 ACCUMULATION of a bf16 wire: per bucket an all-to-all hands rank r chunk r of
+                        every rank's bucket (xGMI is point-to-point and fully connected: each chunk crosses ONE link, no ring hops),
+                        the rank sums its `world` copies in fp32 (grove_colsum_f32), rounds ONCE, and an all-gather distributes the
+                        shard sums — the same bytes per rank as reduce-scatter + all-gather, one rounding instead of world - 1.
+    `sparse_rows(...)`: the embedding table's gradient has at most B * L non-zero rows per rank (the text tokens of the batch) out of
+    32 K — it travels as an all-gather of (row ids, rows) and is summed in fp32 into the dense slice by every rank
+    (<= 512 rows x 8 KB per rank instead of 262 MB; SURVEY.md section 8(a) a7 "sparse rows"). The optimizer stays dense.
     On CPU tensors (gloo: the tests) the same code runs inline without streams."""
 
     def __init__(self, flat, world, bucket_elems, comm_dtype=torch.bfloat16, mode="allreduce", comm_stream=None):
-        assert mode in ("allreduce", "rs_ag")
+        assert mode in ("allreduce", "rs_ag", "a2a_f32")
         self.flat, self.world, self.mode = flat, world, mode
         self.wire = torch.empty(flat.numel(), dtype=comm_dtype, device=flat.device) if comm_dtype != torch.float32 else None
         # buckets are multiples of the world size so that reduce-scatter shards are equal
         self.bucket = max(world, bucket_elems // world * world)
         self.stream = comm_stream
         self.pending = []     # [lo, hi) ranges already handed to the communication stream this step
+        self.sparse_done = [] # [lo, hi) ranges whose SUM already sits in `flat` (sparse_rows): not widened from the wire
         self.handles = []
+        self._keep = []       # staging tensors of collectives in flight (freed at finish)
+        self._kmax = None
+
+    def _sum_copies(self, recv, out):
+        """out (wire dtype) [k] = round(sum over the `world` rows of recv [world, k]) with the sum in fp32."""
+        if recv.is_cuda:
+            acc = ops.colsum(recv)                       # fp32 [k]
+            if out.dtype == torch.float32:
+                out.copy_(acc)
+            else:
+                ops.to_bf16(acc, out=out)
+        else:
+            out.copy_(recv.float().sum(0).to(out.dtype))
 
     def _exchange(self, buf):
         n = buf.numel()
         for s0 in range(0, n, self.bucket):
             b = buf[s0:s0 + self.bucket]
-            if self.mode == "rs_ag" and b.numel() % self.world == 0:
+            if self.mode in ("rs_ag", "a2a_f32") and b.numel() % self.world == 0:
                 k = b.numel() // self.world
                 r = dist.get_rank()
                 shard = b[r * k:(r + 1) * k]  # in place: RCCL reduces into / gathers from the rank's own slice of the bucket
-                if b.is_cuda:  # stream-ordered on the communication stream
+                if self.mode == "a2a_f32":
+                    recv = torch.empty((self.world, k), dtype=b.dtype, device=b.device)
+                    dist.all_to_all_single(recv.view(-1), b)  # (stream-ordered on the communication stream; blocking on gloo)
+                    self._sum_copies(recv, shard)
+                    if b.is_cuda:
+                        self._keep.append(recv)
+                        self.handles.append(dist.all_gather_into_tensor(b, shard, async_op=True))
+                    else:
+                        dist.all_gather_into_tensor(b, shard.clone())
+                elif b.is_cuda:  # stream-ordered on the communication stream
                     self.handles.append(dist.reduce_scatter_tensor(shard, b, op=dist.ReduceOp.SUM, async_op=True))
                     self.handles.append(dist.all_gather_into_tensor(b, shard, async_op=True))
                 else:          # gloo (tests): no in-place aliasing, no ordering between queued operations
@@ -207,6 +237,69 @@ class GradExchange:
             self._exchange(buf)
         self.pending.append((lo, hi))
 
+    # ---- sparse rows (embed_tokens)
+    def sparse_begin(self, count):
+        """Forward time: this rank will contribute `count` distinct rows. The padded row count every rank uses is the MAX over
+        ranks; its tiny all-reduce is issued now (first in the communication queue of the step) and read at the end of the
+        backward, when it has long completed — no host stall in the step."""
+        t = torch.tensor([int(count)], dtype=torch.int32)
+        if not self.flat.is_cuda:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            self._kmax = (t, None)
+            return
+        with torch.cuda.stream(self.stream):
+            td = t.to(self.flat.device, non_blocking=True)
+            dist.all_reduce(td, op=dist.ReduceOp.MAX)
+            host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+            host.copy_(td, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self._kmax = (host, ev, td)
+
+    def sparse_kmax(self):
+        assert self._kmax is not None, "sparse_begin() was not called in this step's forward"
+        if self._kmax[1] is not None:
+            self._kmax[1].synchronize()
+        return int(self._kmax[0][0])
+
+    def sparse_rows(self, ids, rows, lo, hi, ld, producer_stream=None, event=None):
+        """ids int32 [K] (distinct row numbers of this rank, -1 = padding), rows [K, ld] fp32 (this rank's gradient rows in the
+        order of ids; padding rows ignored), K = the same on every rank (sparse_kmax()). The dense slice flat[lo:hi] viewed as
+        [*, ld] must be ZERO on entry; on return (stream-ordered) it holds the sum over all ranks. All-gather of ids and of the rows
+        in the wire dtype; the sum itself is fp32 (scatter-add of every rank's block)."""
+        K = ids.numel()
+        dense = self.flat[lo:hi].view(-1, ld)
+        wdt = self.wire.dtype if self.wire is not None else torch.float32
+        if not self.flat.is_cuda:
+            wr = rows.to(wdt)
+            all_ids = torch.empty(self.world * K, dtype=torch.int32)
+            all_rows = torch.empty((self.world * K, ld), dtype=wdt)
+            dist.all_gather_into_tensor(all_ids, ids)
+            dist.all_gather_into_tensor(all_rows.view(-1), wr.reshape(-1))
+            keep = all_ids >= 0
+            dense.index_add_(0, all_ids[keep].long(), all_rows[keep].float())
+        else:
+            ev = event
+            if ev is None:
+                ev = torch.cuda.Event()
+                ev.record(producer_stream if producer_stream is not None else torch.cuda.current_stream(self.flat.device))
+            with torch.cuda.stream(self.stream):
+                self.stream.wait_event(ev)
+                wr = rows if wdt == torch.float32 else ops.to_bf16(rows)
+                all_ids = torch.empty(self.world * K, dtype=torch.int32, device=ids.device)
+                all_rows = torch.empty((self.world * K, ld), dtype=wdt, device=ids.device)
+                dist.all_gather_into_tensor(all_ids, ids)
+                dist.all_gather_into_tensor(all_rows.view(-1), wr.view(-1))
+                if wdt == torch.float32:
+                    ops.scatter_add_rows_f32(all_rows, dense, all_ids)
+                else:
+                    ops.scatter_add_f32(all_rows, dense, all_ids, self.world * K, ld)
+                for t in (ids, rows, wr, all_ids, all_rows):
+                    t.record_stream(self.stream)
+        self.pending.append((lo, hi))
+        self.sparse_done.append((lo, hi))
+        self._kmax = None
+
     def finish(self):
         """Everything not handed over by ready() is exchanged now; then wait and widen. Returns the exchanged ranges."""
         covered = sorted(self.pending)
@@ -224,12 +317,17 @@ class GradExchange:
         self.handles = []
         if self.flat.is_cuda:
             torch.cuda.current_stream(self.flat.device).wait_stream(self.stream)
+        self._keep = []
         if self.wire is not None:
-            if self.flat.is_cuda:
-                ops.to_f32(self.wire, out=self.flat)
-            else:
-                self.flat.copy_(self.wire)
-        done, self.pending = self.pending, []
+            dense = [r for r in self.pending if r not in self.sparse_done]
+            if not self.sparse_done:
+                dense = [(0, self.flat.numel())]
+            for lo, hi in dense:  # (a sparse slice already holds its fp32 sum: the wire never carried it)
+                if self.flat.is_cuda:
+                    ops.to_f32(self.wire[lo:hi], out=self.flat[lo:hi])
+                else:
+                    self.flat[lo:hi].copy_(self.wire[lo:hi])
+        done, self.pending, self.sparse_done = self.pending, [], []
         return done
 
 
@@ -244,7 +342,7 @@ class GroveEngine:
     """Replica-per-GPU data-parallel engine with the DeepSpeed-engine surface train.py relies on."""
 
     def __init__(self, model: GROVEForCausalLM, args, total_steps=None, bucket_bytes=128 << 20, comm_dtype=torch.bfloat16,
-                 exchange="allreduce", overlap=True):
+                 exchange="allreduce", overlap=True, sparse_embed=True):
         self.module = model
         self.args = args
         self.dev = model.dev
@@ -285,6 +383,9 @@ class GroveEngine:
             self.exchange = GradExchange(g, self.world, bucket_bytes // (2 if comm_dtype == torch.bfloat16 else 4), comm_dtype, exchange,
                                          self.comm_stream)
         self.overlap = overlap
+        # embed_tokens' gradient as touched rows (all-gather of (ids, rows), fp32 sum) instead of the dense 131 M-element slice
+        self.sparse_embed = sparse_embed
+        self.exposed_comm_events = None  # (start, end) events around the wait for the collectives in the last step (N > 1)
         self.opt_stream = torch.cuda.Stream(device=self.dev)
         self.overlap_optimizer = True  # False: the compute stream waits for the update inside step() (A/B arm)
         self._grads_cleared = False
@@ -300,12 +401,19 @@ class GroveEngine:
         dist.broadcast(self.master, src=0)
         for _, _, _, w in self.slices:
             dist.broadcast(w, src=0)
+        # values derived from trainable tensors at build time (the SAM adapters' fp32 alpha scalars) follow the new weights;
+        # every other trainable tensor is read in place
+        self.module.sam.refresh_adapter_scalars()
 
     # ---- DeepSpeed-engine surface
     def __call__(self, **batch):
         if self.micro == 0 and not self._grads_cleared:
             self.module.zero_grad()
         self._grads_cleared = False
+        last_micro = self.micro + 1 >= self.args.grad_accumulation_steps
+        # (with gradient accumulation the touched rows are a union over micro-steps: the dense exchange serves that case)
+        self.module._sparse_embed = self.exchange if (self.exchange is not None and self.sparse_embed and last_micro and
+                                                      self.args.grad_accumulation_steps == 1 and self.module._train_mode) else None
         return self.module(**batch)
 
     def train(self):
@@ -327,7 +435,20 @@ class GroveEngine:
         self.micro += 1
 
     def _allreduce(self):
+        """Wait for (and, for groups not handed over from inside the backward, start) the gradient collectives. The two events
+        bracket what the compute stream WAITS here = the exposed communication of the step (bench.py prints it for N > 1)."""
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         self.exchanged_ranges = self.exchange.finish()
+        e1.record()
+        self.exposed_comm_events = (e0, e1)
+
+    def exposed_comm_ms(self):
+        """Device time the compute stream spent waiting for gradient collectives (+ widening the wire buffer) in the last step."""
+        if self.exposed_comm_events is None:
+            return None
+        self.exposed_comm_events[1].synchronize()
+        return self.exposed_comm_events[0].elapsed_time(self.exposed_comm_events[1])
 
     def step(self):
         a = self.args
@@ -546,7 +667,10 @@ def main(args, dims=None, log=print):
         dims = dims_from_checkpoint(args.grove_weights, sd, base=dims)
         model = initialize_model(args, dims, state_dict=None, device=device)
         from .checkpoint import load_grove_weights
-        load_grove_weights(model, args.grove_weights, sd=sd)
+        rep = load_grove_weights(model, args.grove_weights, sd=sd, log=log if rank == 0 else (lambda m: None))
+        if rank == 0:
+            log(f"missing keys: {len(rep.missing_keys)} ({len(rep.initialised)} trainable ones initialised like the reference's "
+                f"constructors, {len(rep.missing_frozen)} frozen left zero), unexpected keys: {len(rep.unexpected_keys)}")
         del sd
     else:
         sd = synthetic_state_dict(dims, device=device, dtype=torch.bfloat16)  # no checkpoints offline: deterministic random init

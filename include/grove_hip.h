@@ -476,6 +476,10 @@ int grove_copy_rows(const grove_rows_params* p, void* stream);
 /* dst_f32[idx[r], :] += src_bf16[r, :] with float atomics (embed_tokens / broadcast-row grads) */
 int grove_scatter_add_f32(const void* src, float* dst, const int32_t* idx, int32_t rows, int32_t C,
                           int32_t ld_src, int32_t ld_dst, void* stream);
+/* the same with fp32 source rows: dst_f32[idx[r], :] += src_f32[r, :] (idx -1 = skipped). Sums the all-gathered (row id, row) pairs of
+ * the sparse embed_tokens gradient exchange into the dense gradient (train.py:466-478's dense reduce-scatter replaced) */
+int grove_scatter_add_rows_f32(const float* src, float* dst, const int32_t* idx, int32_t rows, int32_t C,
+                               int32_t ld_src, int32_t ld_dst, void* stream);
 /* column sums of a bf16 [rows, ld] matrix into f32 out[C] (bias gradients); accumulate adds */
 int grove_colsum_f32(const void* x, float* out, int32_t rows, int32_t C, int32_t ld, int32_t accumulate, void* stream);
 /* out[0] += f * sum_i a[i]*b[i] (bf16 in, fp32 accumulate). scale_ptr NULL: f=1; mode 0: f=*scale_ptr;

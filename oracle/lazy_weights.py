@@ -1,0 +1,40 @@
+"""Weights for the CPU oracle at FULL dimensions without holding the 30 GB fp32 state dict on the host.
+
+TEST INFRASTRUCTURE ONLY (tests/, bench.py's cpu_baseline leg). The oracle only indexes / .get()s its state dict, so a mapping
+that regenerates one tensor per access from the name-keyed generator of grove_amd/synthetic.py (bit-identical on CPU and GPU) is
+enough; `gen_device` may be the GPU, which makes the 7.6e9 values in seconds. `fetch_seconds` accumulates the time spent
+generating / copying, so that a timed oracle run can report its own compute time.
+"""
+import time
+
+import torch
+
+
+class LazyRoundedWeights(dict):
+    """{name: fp32 tensor of the bf16-rounded synthetic weight}, generated on access."""
+
+    def __init__(self, d, gen_device="cpu"):
+        super().__init__()
+        from grove_amd.synthetic import param_shapes
+        self.d, self.shapes = d, param_shapes(d)
+        self._last = (None, None)
+        self.gen_device = gen_device
+        self.fetch_seconds = 0.0
+
+    def __contains__(self, k):
+        return k in self.shapes
+
+    def __getitem__(self, k):
+        from grove_amd.synthetic import det_tensor, init_spec
+        if self._last[0] == k:
+            return self._last[1]
+        t0 = time.perf_counter()
+        shape = self.shapes[k]
+        mean, std = init_spec(k, shape, self.d)
+        t = det_tensor(k, shape, std=std, mean=mean, device=self.gen_device).to(torch.bfloat16).float().cpu()
+        self._last = (k, t)
+        self.fetch_seconds += time.perf_counter() - t0
+        return t
+
+    def get(self, k, default=None):
+        return self[k] if k in self.shapes else default

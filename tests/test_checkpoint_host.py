@@ -82,3 +82,49 @@ def test_interpolate_only_what_does_not_fit():
     assert tuple(sd[p + "pos_embed"].shape) == (1, 4, 4, 4) and tuple(sd[p + "blocks.1.attn.rel_pos_h"].shape) == (7, 2)
     assert torch.equal(sd[p + "blocks.0.attn.rel_pos_h"], before[p + "blocks.0.attn.rel_pos_h"])  # a window block: untouched
     assert ck.interpolate_positional_embeddings(sd, img_size=64, patch_size=16, global_blocks=(1,)) == []  # idempotent
+
+
+def test_missing_trainable_keys_get_constructor_init_not_zeros():
+    """a base LLaVA checkpoint has no text_hidden_fcs / SAM adapters / box heads; they must come out like the
+    reference's freshly constructed modules (nn.Linear default U(+-1/sqrt(fan_in)), alpha 0), never all-zero, and be reported."""
+    import math
+    from types import SimpleNamespace
+    from grove_amd.model.GROVE import trainable_names
+    from grove_amd.synthetic import TINY, param_shapes, synthetic_state_dict
+    d = TINY
+    shapes = param_shapes(d)
+    full = synthetic_state_dict(d)
+    drop = [n for n in shapes if n.startswith("model.text_hidden_fcs.") or "adapters." in n or "bbox_prediction_head" in n
+            or n.endswith("layers.0.input_layernorm.weight")]
+    ckpt = {k: v for k, v in full.items() if k not in drop}
+    loaded = {}
+
+    class FakeModel:  # the host-side surface load_grove_weights uses (the real model needs a GPU)
+        dims = d
+        trainable = trainable_names(d)
+
+        def state_dict(self):
+            return {n: torch.zeros(s) for n, s in shapes.items()}
+
+        def load_state_dict(self, sd, strict=False):
+            loaded.update(sd)
+            return SimpleNamespace(missing_keys=[n for n in shapes if n not in sd], unexpected_keys=[n for n in sd if n not in shapes])
+
+    msgs = []
+    rep = ck.load_grove_weights(FakeModel(), "<memory>", sd=ckpt, log=msgs.append)
+    train = set(trainable_names(d))
+    assert set(rep.initialised) == {n for n in drop if n in train}
+    assert rep.missing_frozen == [n for n in shapes if n in drop and n not in train]  # the frozen norm weight + CLIP adapters: reported
+    assert len(msgs) == 2 and "constructor" in msgs[0] and "FROZEN" in msgs[1]
+    w = loaded["model.text_hidden_fcs.0.0.weight"]
+    bound = 1.0 / math.sqrt(w.shape[1])
+    assert w.abs().max() <= bound and w.std() > 0.5 * bound / math.sqrt(3) and abs(w.mean()) < 0.1 * bound
+    b = loaded["model.text_hidden_fcs.0.0.bias"]
+    assert b.abs().max() <= bound and b.abs().max() > 0
+    a = loaded["model.grounding_encoder.image_encoder.adapters.0.alpha"]
+    assert torch.equal(a, torch.zeros_like(a))                                   # image_encoder.py:45
+    cw = loaded["model.grounding_encoder.image_encoder.adapters.0.conv3d.weight"]
+    assert cw.abs().max() <= 1.0 / math.sqrt(cw.shape[1] * 27) and cw.abs().max() > 0
+    # deterministic per name: every rank builds the same tensors
+    rep2 = ck.init_missing_trainable(FakeModel(), drop)
+    assert all(torch.equal(rep2[n], loaded[n]) for n in rep2)

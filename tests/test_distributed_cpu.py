@@ -30,7 +30,7 @@ def _worker(rank, world, port, out):
     ok = ok and torch.equal(h, want) and (h - base * 3).abs().max().item() <= 3 * base.abs().max().item() * 2 ** -7
     # the overlapped exchange: groups handed over out of order as the backward finishes them, the rest at finish(); both modes
     from grove_amd.train import GradExchange
-    for mode in ("allreduce", "rs_ag"):
+    for mode in ("allreduce", "rs_ag", "a2a_f32"):
         for wire in (torch.bfloat16, torch.float32):
             base = torch.randn(1003, generator=torch.Generator().manual_seed(11))
             flat = base * (rank + 1)
@@ -44,6 +44,41 @@ def _worker(rank, world, port, out):
             else:
                 want = (base.to(torch.bfloat16).float() + (base * 2).to(torch.bfloat16).float())
                 ok = ok and (flat - want).abs().max().item() <= want.abs().max().item() * 2 ** -7
+    # fp32 accumulation of a bf16 wire (mode a2a_f32): the sum of the two ROUNDED contributions is exact in fp32 and rounded once —
+    # the ring forms round the running sum instead; here (two ranks) both give round(bf16(a) + bf16(2a))
+    base = torch.randn(960, generator=torch.Generator().manual_seed(13))
+    flat = base * (rank + 1)
+    ex = GradExchange(flat, world, 96, comm_dtype=torch.bfloat16, mode="a2a_f32")
+    ex.ready(0, 960)
+    ex.finish()
+    want = (base.to(torch.bfloat16).float() + (base * 2).to(torch.bfloat16).float()).to(torch.bfloat16).float()
+    ok = ok and torch.equal(flat, want)
+    # sparse embedding-row exchange: each rank touches a few rows of a [50, 8] table; padded to the max count over the ranks;
+    # the dense slice ends up holding the fp32 SUM of both ranks' rows (rows touched by both are added), everything else zero
+    H, V = 8, 50
+    for wire in (torch.bfloat16, torch.float32):
+        flat = torch.zeros(16 + V * H + 24)
+        flat[:16] = rank + 1.0          # a dense group before the table
+        flat[16 + V * H:] = 2.0 * (rank + 1)
+        ex = GradExchange(flat, world, 64, comm_dtype=wire, mode="allreduce")
+        my_ids = torch.tensor([3, 7, 20] if rank == 0 else [7, 41], dtype=torch.int32)
+        ex.sparse_begin(my_ids.numel())
+        K = ex.sparse_kmax()
+        assert K == 3
+        rows = torch.zeros(K, H)
+        rows[:my_ids.numel()] = (my_ids.float()[:, None] + 0.5) * (rank + 1)
+        ids = torch.full((K,), -1, dtype=torch.int32)
+        ids[:my_ids.numel()] = my_ids
+        ex.ready(0, 16)
+        ex.sparse_rows(ids, rows, 16, 16 + V * H, H)
+        done = ex.finish()
+        assert sorted(done) == [(0, 16), (16, 16 + V * H), (16 + V * H, flat.numel())], done
+        table = flat[16:16 + V * H].view(V, H)
+        want = torch.zeros(V, H)
+        want[3], want[20], want[41] = 3.5, 20.5, 2 * 41.5
+        want[7] = 7.5 + 2 * 7.5
+        ok = ok and torch.equal(table, want) and torch.equal(flat[:16], torch.full((16,), 3.0)) and \
+            torch.equal(flat[16 + V * H:], torch.full((24,), 6.0))
     mine = shard_clips(7, rank, world)
     gathered = [None] * world
     dist.all_gather_object(gathered, mine)
@@ -76,3 +111,52 @@ def test_warmup_decay_lr():
     # update k at gamma(k - 2)
     assert s.for_update(1) == 0.0 and s.for_update(2) == 0.0 and abs(s.for_update(3) - 3e-6) < 1e-15
     assert abs(s.for_update(102) - 3e-4) < 1e-12
+
+
+def _infer_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from types import SimpleNamespace
+    from grove_amd import infer
+
+    calls = []
+
+    def fake_infer_clip(model, g_all, s_all, prompt_ids, size, **kw):  # the per-clip driver needs a GPU; the job logic does not
+        calls.append(int(g_all.flatten()[0]))
+        return {"pred_bboxes": [g_all.flatten()[:4] + rank * 0.0], "frame_indices": [0], "by_rank": rank}
+
+    infer.infer_clip = fake_infer_clip
+    clips = [(f"clip{i}", torch.full((1, 3, 8, 2, 2), float(i)), torch.zeros(1, 3, 8, 2, 2), (640, 360)) for i in range(5)]
+    model = SimpleNamespace(dev=torch.device("cpu"))
+    merged = infer.infer_dataset(model, clips, torch.tensor([1, -200, 5]))
+    out[rank] = (calls, sorted(merged), {k: v["by_rank"] for k, v in merged.items()}, float(merged["clip3"]["pred_bboxes"][0][0]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_inference_job_shards_clips_and_gathers():
+    """infer_iground.py:290-293, 538-551 on two gloo ranks: the un-shuffled DistributedSampler partition (wrap-around padded), one
+    barrier + all_gather_object at the end, first-wins merge — every rank ends with every clip exactly once."""
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_infer_worker, args=(world, port, out), nprocs=world, join=True)
+    assert out[0][0] == [0, 2, 4] and out[1][0] == [1, 3, 0]          # 5 clips on 2 ranks: rank 1's last round wraps to clip 0
+    for r in range(world):
+        calls, keys, by_rank, v3 = out[r]
+        assert keys == [f"clip{i}" for i in range(5)]
+        assert by_rank == {"clip0": 0, "clip1": 1, "clip2": 0, "clip3": 1, "clip4": 0}   # duplicate clip0: rank 0's copy wins
+        assert v3 == 3.0
+
+
+def test_inference_job_single_process():
+    from types import SimpleNamespace
+    from grove_amd import infer
+    orig = infer.infer_clip
+    infer.infer_clip = lambda model, g, s, p, size, **kw: {"n": int(g.flatten()[0])}
+    try:
+        clips = [(f"c{i}", torch.full((1, 1), float(i)), torch.zeros(1, 1), (1, 1)) for i in range(3)]
+        res = infer.infer_dataset(SimpleNamespace(dev=torch.device("cpu")), clips, None)
+    finally:
+        infer.infer_clip = orig
+    assert res == {"c0": {"n": 0}, "c1": {"n": 1}, "c2": {"n": 2}}

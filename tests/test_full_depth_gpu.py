@@ -20,31 +20,7 @@ bf = torch.bfloat16
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-class LazyRoundedWeights(dict):
-    """{name: fp32 tensor of the bf16-rounded synthetic weight}, generated on access (the oracle only indexes / .get()s)."""
-
-    def __init__(self, d, gen_device="cpu"):
-        super().__init__()
-        from grove_amd.synthetic import param_shapes
-        self.d, self.shapes = d, param_shapes(d)
-        self._last = (None, None)
-        self.gen_device = gen_device  # the name-keyed generator is bit-identical on CPU and GPU; the GPU makes 7.6e9 values in seconds
-
-    def __contains__(self, k):
-        return k in self.shapes
-
-    def __getitem__(self, k):
-        from grove_amd.synthetic import det_tensor, init_spec
-        if self._last[0] == k:
-            return self._last[1]
-        shape = self.shapes[k]
-        mean, std = init_spec(k, shape, self.d)
-        t = det_tensor(k, shape, std=std, mean=mean, device=self.gen_device).to(bf).float().cpu()
-        self._last = (k, t)
-        return t
-
-    def get(self, k, default=None):
-        return self[k] if k in self.shapes else default
+from oracle.lazy_weights import LazyRoundedWeights  # noqa: E402  (moved: bench.py's measured CPU baseline uses it too)
 
 
 def rel(a, b):
@@ -133,3 +109,230 @@ def test_full_depth_inference_vs_fp32_oracle(dev, which):
     assert res["box_l1_bf16_pe_vs_oracle_bf16_pe"] <= 1e-3, res
     assert res["objectness_logit_abs_err"] <= 5e-2 and res["objectness_logit_abs_err_bf16_pe"] <= 5e-2, res
     assert res["llama_hidden_rel_max"] <= 3e-2 and res["clip_hidden_m2_rel_max"] <= 3e-2 and res["sam_embeddings_rel_max"] <= 3e-2, res
+
+
+GROUPS = (("embed_tokens", "model.embed_tokens."), ("lm_head", "lm_head."), ("mm_projector", "model.mm_projector."),
+          ("text_hidden_fcs", "model.text_hidden_fcs."), ("box_decoder", "model.grounding_encoder.mask_decoder."),
+          ("sam_adapter_0", "model.grounding_encoder.image_encoder.adapters.0."), ("sam_adapter_1", "model.grounding_encoder.image_encoder.adapters.1."),
+          ("sam_adapter_2", "model.grounding_encoder.image_encoder.adapters.2."), ("sam_adapter_3", "model.grounding_encoder.image_encoder.adapters.3."))
+
+
+@pytest.mark.parametrize("which", ["deep_narrow"] + (["full"] if os.environ.get("GROVE_FULL_TRAIN_PARITY") else []))
+def test_full_depth_training_vs_oracle_autograd(dev, which):
+    """the configuration the headline bench times — a `train=True` model (bf16 residual streams, bf16 box
+    decoder, tape + saved activations) — at FULL DEPTH: 32 LLaMA layers of dgrad, 24 SAM blocks of dgrad, 4 Conv3d adapters with
+    weight gradients, against torch autograd through the fp32 CPU oracle on the same bf16-rounded weights: the five loss terms
+    within 1 %, cosine > 0.98 and norm ratio in [0.9, 1.1] for every trainable gradient GROUP (the per-tensor figures go to
+    gpurun_out/full_depth_training_parity_<which>.json). `which = full` (full width: ~50 GB of host memory for the oracle's
+    autograd graph) runs only with GROVE_FULL_TRAIN_PARITY=1; its figures are committed under profiles/."""
+    from grove_amd import GROVEForCausalLM
+    from grove_amd.model.GROVE import trainable_names
+    from grove_amd.synthetic import FULL, synthetic_batch, synthetic_state_dict
+    from oracle import grove_oracle as O
+    d = FULL if which == "full" else deep_narrow_dims()
+    names = trainable_names(d)
+    sd_dev = synthetic_state_dict(d, device=dev, dtype=bf)
+    model = GROVEForCausalLM(dims=d, device=dev, state_dict=sd_dev, det_token_idx=d.det_token_idx, num_frames=8, pe_dtype=torch.float32, train=True)
+    batch = synthetic_batch(d, B=1, T=8, L=128, n_det=3, seed=11)
+    kw = batch.as_kwargs()
+    kd = dict(kw)
+    for k in ("global_enc_images", "grounding_enc_images"):
+        kd[k] = kw[k].to(dev).to(bf)
+        kw[k] = kw[k].to(bf).float()
+    for k in ("input_ids", "labels", "attention_masks", "offset"):
+        kd[k] = kw[k].to(dev)
+    model.zero_grad()
+    out = model(**kd)
+    model.backward(out["loss"])
+    torch.cuda.synchronize()
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    t0 = time.time()
+    sdg = {k: v.float().cpu().requires_grad_(k in names) for k, v in sd_dev.items()}
+    del sd_dev
+    ref = O.model_forward(sdg, d, **kw)
+    ref["loss"].backward()
+    t_cpu = time.time() - t0
+    terms = ("loss", "ce_loss", "giou_loss", "l1_loss", "temp_objectness_loss")
+    loss_rel = {k: abs(float(out[k]) - float(ref[k])) / max(abs(float(ref[k])), 1e-12) for k in terms}
+    per_tensor, groups = {}, {}
+    gs = {g: ([], []) for g, _ in GROUPS}
+    for n in names:
+        g, r = model._grad[n].detach().float().cpu(), sdg[n].grad
+        if n.endswith("conv3d.weight"):
+            g = g.view(r.shape[0], 3, 3, 3, r.shape[1]).permute(0, 4, 1, 2, 3)
+        g, r = g.reshape(-1), r.reshape(-1)
+        per_tensor[n] = {"cos": float(torch.nn.functional.cosine_similarity(g, r, dim=0)) if float(r.norm()) > 1e-9 else None,
+                         "norm_ratio": float(g.norm() / r.norm().clamp_min(1e-20)), "ref_norm": float(r.norm())}
+        for gname, pre in GROUPS:
+            if n.startswith(pre):
+                gs[gname][0].append(g)
+                gs[gname][1].append(r)
+    for gname, (a, b) in gs.items():
+        a, b = torch.cat(a), torch.cat(b)
+        groups[gname] = {"cos": float(torch.nn.functional.cosine_similarity(a, b, dim=0)), "norm_ratio": float(a.norm() / b.norm()), "elements": int(a.numel())}
+    allg = torch.cat([torch.cat(a) for a, _ in gs.values()])
+    allr = torch.cat([torch.cat(b) for _, b in gs.values()])
+    res = {"config": ("FULL dims" if which == "full" else "full depth at quarter width (LLaMA 32x1024, CLIP 24x256, SAM 32x320)") +
+           ", train=True model (bf16 streams, bf16 decoder), B=1, T=8, L=128, n_det=3, fwd + bwd vs torch autograd through the fp32 oracle",
+           "loss_terms_rel_err": loss_rel, "losses": {k: float(out[k]) for k in terms}, "oracle_losses": {k: float(ref[k]) for k in terms},
+           "gradient_groups": groups, "whole_gradient": {"cos": float(torch.nn.functional.cosine_similarity(allg, allr, dim=0)),
+                                                         "norm_ratio": float(allg.norm() / allr.norm()), "elements": int(allg.numel())},
+           "box_l1_train_mode_vs_oracle": (out["flat_boxes"].detach().cpu() - ref["flat_boxes"].detach()).abs().mean().item(),
+           "objectness_logit_abs_err": (out["flat_logits"].detach().cpu() - ref["flat_logits"].detach()).abs().max().item(),
+           "worst_tensors": sorted(((v["cos"], n) for n, v in per_tensor.items() if v["cos"] is not None))[:8],
+           "oracle_cpu_seconds": round(t_cpu, 1)}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", f"full_depth_training_parity_{which}.json"), "w") as fh:
+        json.dump(res, fh, indent=1)
+    print(json.dumps(res))
+    assert max(loss_rel.values()) <= 1e-2, loss_rel
+    bad = {g: v for g, v in groups.items() if not (v["cos"] > 0.98 and 0.9 < v["norm_ratio"] < 1.1)}
+    assert not bad, bad
+    # training models keep the reference's bf16 streams and the bf16 decoder (DESIGN section 5): their boxes sit above the inference
+    # models' figure; the bound here is that configuration's own (1.2-1.5e-3 measured at full depth), the losses above are the gate
+    assert res["box_l1_train_mode_vs_oracle"] <= 2.5e-3, res["box_l1_train_mode_vs_oracle"]
+
+
+def test_full_size_greedy_ids_vs_oracle(dev):
+    """caption token ids at FULL size (LLaMA-7B geometry, CLIP ViT-L), not the HIP path against itself:
+    `generate` (prefill + cached GEMV steps from one HIP graph) produces 4 new tokens; the fp32 CPU oracle recomputes every step
+    uncached on the same prefix (HF greedy = argmax of the last position, GROVE.py:418-422). A token must equal the oracle's
+    argmax unless the oracle's margin over the token the HIP path chose is inside twice the measured logit error of that step
+    (a bf16 path cannot resolve a smaller margin); the margins and errors are written to gpurun_out/."""
+    from grove_amd import GROVEForCausalLM
+    from grove_amd.synthetic import FULL, synthetic_batch, synthetic_state_dict
+    from oracle import grove_oracle as O
+    import torch.nn.functional as Fn
+    d = FULL
+    sd_dev = synthetic_state_dict(d, device=dev, dtype=bf)
+    model = GROVEForCausalLM(dims=d, device=dev, state_dict=sd_dev, det_token_idx=d.det_token_idx, num_frames=8)
+    del sd_dev
+    torch.cuda.empty_cache()
+    batch = synthetic_batch(d, B=1, T=8, L=64, n_det=1, seed=5)
+    gi = batch.global_enc_images.to(bf)
+    prompt = batch.input_ids[:, :40].contiguous()  # BOS, prompt ids, one -200, prompt ids (un-padded: quirk Q9)
+    new = 4
+    feats, _ = model(mode="encode_images", images=gi.to(dev))
+    seqs = model.generate(input_ids=prompt.to(dev), image_features=feats, max_new_tokens=new, eos_token_id=-1)
+    seqs_nc = model.generate(input_ids=prompt.to(dev), image_features=feats, max_new_tokens=new, eos_token_id=-1, use_cache=False)
+    seqs = seqs.cpu()
+    assert torch.equal(seqs, seqs_nc.cpu()), "cached and uncached HIP streams differ"
+    sd = LazyRoundedWeights(d, gen_device=dev)
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    t0 = time.time()
+    steps = []
+    with torch.no_grad():
+        feats_o, _ = O.encode_images(sd, d, gi.float())
+        for t in range(new):
+            prefix = seqs[:, :40 + t]
+            embeds, _, _ = O.splice(sd, prefix, None, None, feats_o)
+            hidden_o = O.llama_forward(sd, d, embeds, None)
+            logits_o = Fn.linear(hidden_o[:, -1], sd["lm_head.weight"])[0]
+            lh = model.lm_forward(input_ids=prefix.to(dev), image_features=feats, use_cache=False, last_logits_only=True).logits.float().cpu().reshape(-1)[:d.vocab]
+            err = (lh - logits_o).abs().max().item()
+            top2 = logits_o.topk(2)
+            tok = int(seqs[0, 40 + t])
+            steps.append({"step": t, "hip_token": tok, "oracle_argmax": int(top2.indices[0]), "oracle_top2_gap": float(top2.values[0] - top2.values[1]),
+                          "oracle_margin_over_hip_token": float(top2.values[0] - logits_o[tok]), "logit_abs_err": err,
+                          "logit_rel_rms": float((lh - logits_o).pow(2).mean().sqrt() / logits_o.pow(2).mean().sqrt())})
+    res = {"config": "FULL dims, B=1, T=8, prompt 40 ids (+575 visual), 4 greedy tokens; oracle = fp32 CPU, uncached, same prefix", "steps": steps,
+           "ids_equal": all(s["hip_token"] == s["oracle_argmax"] for s in steps), "oracle_cpu_seconds": round(time.time() - t0, 1)}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "full_size_greedy_parity.json"), "w") as fh:
+        json.dump(res, fh, indent=1)
+    print(json.dumps(res))
+    for s in steps:
+        assert s["hip_token"] == s["oracle_argmax"] or s["oracle_margin_over_hip_token"] <= 2 * s["logit_abs_err"], s
+        assert s["logit_abs_err"] <= 0.1, s  # logits are O(1): a looser path than ~1 % of the logit scale would be a defect
+
+
+def test_full_depth_box_l1_over_seeds(dev):
+    """How much of the full-depth box figure is the case, not the kernels? The box metric amplifies last-bit differences of the
+    text path (re-ordering two fp32 partial sums of one GEMM moved it by 1.3e-4 in round 2: the stream-K fix-up adds a tile's K ranges
+    in K order, deterministically, but not in the order of an un-split accumulation chain — both are valid fp32 sums). So the figure
+    is reported as a distribution: the deep-narrow model (full depth, quarter width) on four input seeds; mean <= 1e-3 is the gate."""
+    from grove_amd import GROVEForCausalLM
+    from grove_amd.synthetic import synthetic_batch, synthetic_state_dict
+    from oracle import grove_oracle as O
+    d = deep_narrow_dims()
+    sd_dev = synthetic_state_dict(d, device=dev, dtype=bf)
+    model = GROVEForCausalLM(dims=d, device=dev, state_dict=sd_dev, det_token_idx=d.det_token_idx, num_frames=8, pe_dtype=torch.float32)
+    sd = {k: v.float().cpu() for k, v in sd_dev.items()}
+    del sd_dev
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    vals, maxs = [], []
+    for seed in (21, 22, 23, 24):
+        batch = synthetic_batch(d, B=1, T=8, L=128, n_det=3, seed=seed)
+        kw = batch.as_kwargs(inference=True)
+        kd = dict(kw)
+        for k in ("global_enc_images", "grounding_enc_images"):
+            kd[k] = kw[k].to(dev).to(bf)
+            kw[k] = kw[k].to(bf).float()
+        for k in ("input_ids", "labels", "attention_masks", "offset"):
+            kd[k] = kw[k].to(dev)
+        out = model(**kd)
+        with torch.no_grad():
+            ref = O.model_forward(sd, d, **kw)
+        e = (out["flat_boxes"].cpu() - ref["flat_boxes"]).abs()
+        vals.append(e.mean().item())
+        maxs.append(e.max().item())
+    res = {"config": "full depth at quarter width, inference model, B=1, T=8, L=128, n_det=3, seeds 21-24", "box_l1": vals, "box_l1_max": maxs,
+           "mean": sum(vals) / len(vals)}
+    with open(os.path.join(ROOT, "gpurun_out", "full_depth_box_l1_seeds.json"), "w") as fh:
+        json.dump(res, fh, indent=1)
+    print(json.dumps(res))
+    assert res["mean"] <= 1e-3 and max(vals) <= 1.3e-3, res
+
+
+# measured x 1.5 (VERDICT r2 item 1: "the assert at 1.5x measured, not 2x"); the figures and the precision-policy table are in DESIGN.md section 8
+FP8_BOUNDS = {"deep_narrow": {"box_l1": 1.5e-2, "hidden_rms": 0.15}, "full": {"box_l1": 1.5e-2, "hidden_rms": 0.15}}
+
+
+@pytest.mark.parametrize("which", ["deep_narrow", "full"])
+def test_full_depth_fp8_inference_vs_fp32_oracle(dev, which):
+    """BASELINE config 5's arithmetic at full depth: `gemm_dtype="fp8"` (every CLIP / LLaMA linear layer with K % 128 == 0 on the e4m3
+    MFMA GEMM) against the fp32 oracle. e4m3 keeps 3 mantissa bits: ~3.6 % rms rounding per operand, ~5 % per GEMM output on any data
+    whose blocks are not dominated by outliers — scaling granularity does not change that (tools/fp8_policy_study.py: per-32 block
+    scales 1.01e-2 vs per-row 0.95e-2 box L1 on this model), so this configuration has its OWN tolerance, stated here and in DESIGN
+    section 8: it does not meet the 1e-3 of the bf16 path, and is fenced as such."""
+    from grove_amd import GROVEForCausalLM
+    from grove_amd.synthetic import FULL, synthetic_batch, synthetic_state_dict
+    from oracle import grove_oracle as O
+    d = FULL if which == "full" else deep_narrow_dims()
+    sd_dev = synthetic_state_dict(d, device=dev, dtype=bf)
+    model = GROVEForCausalLM(dims=d, device=dev, state_dict=sd_dev, det_token_idx=d.det_token_idx, num_frames=8, pe_dtype=torch.float32, gemm_dtype="fp8")
+    n_q = sum(1 for L in model.llama.layers for k in L if k.endswith("_q"))
+    del sd_dev
+    torch.cuda.empty_cache()
+    batch = synthetic_batch(d, B=1, T=8, L=128, n_det=3, seed=11)
+    kw = batch.as_kwargs(inference=True)
+    kd = dict(kw)
+    for k in ("global_enc_images", "grounding_enc_images"):
+        kd[k] = kw[k].to(dev).to(bf)
+    for k in ("input_ids", "labels", "attention_masks", "offset"):
+        kd[k] = kw[k].to(dev)
+    out = model(**kd)
+    feats_h, _ = model(mode="encode_images", images=kd["global_enc_images"])
+    torch.cuda.synchronize()
+    sd = LazyRoundedWeights(d, gen_device=dev)
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    gi, si = kw["global_enc_images"].to(bf).float(), kw["grounding_enc_images"].to(bf).float()
+    with torch.no_grad():
+        emb_o = O.sam_image_encoder(sd, d, si)
+        feats_o, _ = O.encode_images(sd, d, gi)
+        embeds, _, _ = O.splice(sd, kw["input_ids"], None, None, feats_o)
+        hidden_o = O.llama_forward(sd, d, embeds, None)
+        pemb = O.pred_embeddings(sd, d, hidden_o, O.det_token_mask(d, kw["input_ids"]))
+        _, _, box_o, obj_o = O.decode_boxes(sd, d, pemb, emb_o, kw["original_size_list"], O.dense_pe(sd, d), True)
+    res = {"config": ("FULL dims" if which == "full" else "full depth at quarter width") + ", gemm_dtype=fp8 (CLIP + LLaMA linear layers, e4m3, per-row / "
+           "per-output-channel scales), B=1, T=8, L=128, n_det=3, inference forward vs fp32 oracle",
+           "llama_projections_quantised": n_q, "box_l1_vs_oracle": (out["flat_boxes"].cpu() - box_o).abs().mean().item(),
+           "box_l1_max": (out["flat_boxes"].cpu() - box_o).abs().max().item(),
+           "objectness_logit_abs_err": (out["flat_logits"].cpu() - obj_o).abs().max().item(),
+           "llama_hidden_rel_rms": rel_rms(out["hidden"], hidden_o), "projected_features_rel_rms": rel_rms(feats_h, feats_o),
+           "bounds": FP8_BOUNDS[which]}
+    with open(os.path.join(ROOT, "gpurun_out", f"full_depth_fp8_parity_{which}.json"), "w") as fh:
+        json.dump(res, fh, indent=1)
+    print(json.dumps(res))
+    assert n_q > 0
+    assert res["box_l1_vs_oracle"] <= FP8_BOUNDS[which]["box_l1"] and res["llama_hidden_rel_rms"] <= FP8_BOUNDS[which]["hidden_rms"], res

@@ -241,12 +241,36 @@ def test_bench_self_launches_ranks(tmp_path):
     # the exchange variants reach the same loss: group-by-group from inside the backward (default), after the backward, and the
     # reduce-scatter + all-gather form
     losses = [res["config"]["last_loss"]]
-    for extra in (["--no_comm_overlap"], ["--exchange", "rs_ag"]):
+    assert res["config"]["exposed_comm_ms"] is not None and "touched rows" in res["config"]["gradient_exchange"]
+    for extra in (["--no_comm_overlap"], ["--exchange", "rs_ag"], ["--exchange", "a2a_f32"], ["--dense_embed"]):
         q = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dims", "tiny", "--steps", "2", "--warmup", "1",
                             "--frames", "8", "--text_len", "48", "--no_cpu_baseline"] + extra, env=env, capture_output=True, text=True, timeout=900)
         assert q.returncode == 0, q.stderr[-2000:]
         losses.append(json.loads([ln for ln in q.stdout.splitlines() if ln.strip()][0])["config"]["last_loss"])
     assert max(losses) - min(losses) <= 2e-3 * max(1.0, abs(losses[0])), losses
+
+
+def test_bench_infer_mode_runs_on_two_ranks(tmp_path):
+    """BASELINE config 5 is an 8-GPU inference job: `bench.py --mode infer --gpus 2` launches its own ranks (replicas: clips sharded
+    by rank, no data-path collective), times under barrier + max over ranks and ends with the reference's all_gather_object of the
+    per-clip results (infer_iground.py:290-293). One-GPU rehearsal over gloo, fp8 and bf16."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GROVE_BENCH_BACKEND="gloo", GROVE_BENCH_ONE_GPU="1")
+    env.pop("WORLD_SIZE", None)
+    for dtype in ("bf16",):
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--mode", "infer", "--dtype", dtype, "--gpus", "2", "--dims", "tiny",
+                            "--steps", "2", "--warmup", "1", "--frames", "16", "--batch", "1", "--text_len", "48", "--no_cpu_baseline"],
+                           env=env, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-2000:]
+        lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1, p.stdout
+        res = json.loads(lines[0])
+        assert res["n_gpus"] == 2 and res["config"]["ranks"] == 2 and res["config"]["ranks_gathered"] == 2
+        assert res["config"]["collective_backend"] == "gloo" and res["value"] > 0 and res["dtype"] == dtype
 
 
 def test_optimizer_stream_overlap_is_race_free(dev):

@@ -1,0 +1,174 @@
+"""Which fp8 precision policy keeps the boxes inside the 1e-3 L1 tolerance? (CPU study, no GPU: fake-quantised oracle)
+
+Every linear layer of the CLIP tower / LLaMA stack that a policy puts in fp8 is evaluated as the HIP path does it: activation
+rounded to bf16, quantised per row to e4m3 (amax / 448), weight quantised per output channel, fp32 accumulate, bf16 output.
+Policies (LLaMA; CLIP is `clip8` on/off):
+  all8        every projection of every layer in fp8                          (round 2's path)
+  det16       + the rows of the [DET] positions computed in bf16 (row-selective precision: their q/k/v, o, gate/up, down)
+  det16_kv16  + k_proj / v_proj of ALL rows in bf16
+  lastN       the last N layers entirely in bf16
+Usage: python tools/fp8_policy_study.py [tiny|deep_narrow]
+"""
+import json
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+bf = torch.bfloat16
+E4 = torch.float8_e4m3fn
+
+
+def q8(x, blk=0):
+    """per-row (blk=0) or per-(row, blk-wide block) amax/448 e4m3 fake quantisation of the last dim."""
+    x = x.float()
+    if blk:
+        sh = x.shape
+        xb = x.reshape(*sh[:-1], sh[-1] // blk, blk)
+        s = xb.abs().amax(-1, keepdim=True).clamp_min(1e-30) / 448.0
+        return ((xb / s).to(E4).float() * s).reshape(sh)
+    s = x.abs().amax(-1, keepdim=True).clamp_min(1e-30) / 448.0
+    return (x / s).to(E4).float() * s
+
+
+def r16(x):
+    return x.to(bf).float()
+
+
+class Policy:
+    def __init__(self, name, clip8=True, llama8=True, det16=False, kv16=False, last_bf16=0, blk=0, first_bf16=0, o16=False, down16=False):
+        self.__dict__.update(locals())
+
+
+def lin8(x, w, b, pol):
+    y = F.linear(q8(r16(x), pol.blk), q8(w, pol.blk), b)
+    return r16(y)
+
+
+def lin16(x, w, b=None):
+    return r16(F.linear(r16(x), w, b))
+
+
+def main():
+    which = sys.argv[1] if len(sys.argv) > 1 else "tiny"
+    from grove_amd.synthetic import TINY, synthetic_batch, synthetic_state_dict
+    from oracle import grove_oracle as O
+    from tests.test_full_depth_gpu import deep_narrow_dims
+    import dataclasses
+    if which == "tiny":
+        d = dataclasses.replace(TINY, clip_dim=128, clip_heads=2, clip_mlp=256)
+        B, L, n_det, seed = 2, 40, 3, 2
+    else:
+        d = deep_narrow_dims()
+        B, L, n_det, seed = 1, 128, 3, 11
+    torch.set_num_threads(os.cpu_count() or 8)
+    sd = {k: v.to(bf).float() for k, v in synthetic_state_dict(d).items()}
+    batch = synthetic_batch(d, B=B, T=8, L=L, n_det=n_det, seed=seed)
+    kw = batch.as_kwargs(inference=True)
+    gi, si = kw["global_enc_images"].to(bf).float(), kw["grounding_enc_images"].to(bf).float()
+    ids = kw["input_ids"]
+    with torch.no_grad():
+        emb_o = O.sam_image_encoder(sd, d, si)
+        feats_o, _ = O.encode_images(sd, d, gi)
+        embeds_o, _, _ = O.splice(sd, ids, None, None, feats_o)
+        hidden_o = O.llama_forward(sd, d, embeds_o, None)
+        mask = O.det_token_mask(d, ids)
+        pe = O.dense_pe(sd, d)
+        _, _, box_o, obj_o = O.decode_boxes(sd, d, O.pred_embeddings(sd, d, hidden_o, mask), emb_o, kw["original_size_list"], pe, True)
+    S = hidden_o.shape[1]
+    det_pos = [(575 + (ids[b, 1:] == d.det_token_idx).nonzero().flatten()) for b in range(B)]
+
+    def clip_feats(pol):
+        if not pol.clip8:
+            f, _ = O.encode_images(sd, d, gi)
+            return f
+        orig = O._lin
+
+        def lin(sd_, name, x):
+            if name.startswith(O.V + "encoder.layers."):
+                return lin8(x, sd_[name + ".weight"], sd_.get(name + ".bias"), pol)
+            return orig(sd_, name, x)
+        O._lin = lin
+        try:
+            f, _ = O.encode_images(sd, d, gi)
+        finally:
+            O._lin = orig
+        return f
+
+    def llama(pol, embeds):
+        Bc, S_, H = embeds.shape
+        nh, hd = d.n_heads, d.head_dim
+        cos, sin = O._rope_cos_sin(d, torch.arange(S_))
+        neg = torch.finfo(torch.float32).min
+        add = torch.full((S_, S_), neg).triu(1)[None, None]
+        x = embeds
+
+        def proj(name, h, li, kind):
+            w = sd[name + ".weight"]
+            full16 = (not pol.llama8) or li >= d.n_layers - pol.last_bf16 or li < pol.first_bf16 or (pol.kv16 and kind in ("k", "v")) \
+                or (pol.o16 and kind == "o") or (pol.down16 and kind == "down")
+            if full16:
+                return lin16(h, w)
+            y = lin8(h, w, None, pol)
+            if pol.det16:
+                for b in range(Bc):
+                    y[b, det_pos[b]] = lin16(h[b, det_pos[b]], w)
+            return y
+        for i in range(d.n_layers):
+            p = f"model.layers.{i}."
+            h = O.rms_norm(x, sd[p + "input_layernorm.weight"], d.rms_eps)
+            sh = lambda t: t.view(Bc, S_, nh, hd).transpose(1, 2)  # noqa: E731
+            q, k, v = (sh(proj(p + f"self_attn.{n}_proj", h, i, n)) for n in "qkv")
+            q = q * cos + O._rotate_half(q) * sin
+            k = k * cos + O._rotate_half(k) * sin
+            att = torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5 + add, -1)
+            o = r16((att @ v).transpose(1, 2).reshape(Bc, S_, H))
+            x = x + proj(p + "self_attn.o_proj", o, i, "o")
+            h = O.rms_norm(x, sd[p + "post_attention_layernorm.weight"], d.rms_eps)
+            a = r16(F.silu(proj(p + "mlp.gate_proj", h, i, "gate")) * proj(p + "mlp.up_proj", h, i, "up"))
+            x = x + proj(p + "mlp.down_proj", a, i, "down")
+        return O.rms_norm(x, sd["model.norm.weight"], d.rms_eps)
+
+    def rms(a, b):
+        return ((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt()).item()
+
+    pols = [Policy("bf16 (no fp8)", clip8=False, llama8=False),
+            Policy("all8"),
+            Policy("all8 blk32", blk=32),
+            Policy("clip16 llama8", clip8=False),
+            Policy("clip8 llama16", llama8=False),
+            Policy("det16", det16=True),
+            Policy("det16 clip16", det16=True, clip8=False),
+            Policy("det16_kv16", det16=True, kv16=True),
+            Policy("det16_kv16 clip16", det16=True, kv16=True, clip8=False),
+            Policy("last2", last_bf16=2), Policy("last8", last_bf16=8),
+            Policy("det16 last4", det16=True, last_bf16=4),
+            Policy("det16_kv16_o16", det16=True, kv16=True, o16=True),
+            ]
+    rows = []
+    with torch.no_grad():
+        cache = {}
+        for pol in pols:
+            ck = (pol.clip8, pol.blk)
+            if ck not in cache:
+                cache[ck] = clip_feats(pol)
+            feats = cache[ck]
+            embeds, _, _ = O.splice(sd, ids, None, None, feats)
+            hidden = llama(pol, embeds)
+            _, _, box, obj = O.decode_boxes(sd, d, O.pred_embeddings(sd, d, hidden, mask), emb_o, kw["original_size_list"], pe, True)
+            det_err = torch.cat([hidden[b, det_pos[b]] - hidden_o[b, det_pos[b]] for b in range(B)]).pow(2).mean().sqrt() / \
+                torch.cat([hidden_o[b, det_pos[b]] for b in range(B)]).pow(2).mean().sqrt()
+            r = {"policy": pol.name, "feat_rms": rms(feats, feats_o), "hidden_rms": rms(hidden, hidden_o), "det_rows_rms": det_err.item(),
+                 "box_l1": (box - box_o).abs().mean().item(), "box_max": (box - box_o).abs().max().item(),
+                 "obj_abs": (obj - obj_o).abs().max().item()}
+            rows.append(r)
+            print(json.dumps(r), flush=True)
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(f"gpurun_out/fp8_policy_study_{which}.json", "w") as fh:
+        json.dump(rows, fh, indent=1)
+
+
+if __name__ == "__main__":
+    main()
