@@ -346,8 +346,23 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(const grove_gemm_params p, 
   gemm_epilogue<MI, NJ>(p, vec_ok, acc, m0 + wm * WM, n0 + wn * WN, fr, fq, b1, b2, nsplit);
 }
 
+// What the current grove_gemm_* call was given / asked for (the entry points set it, launch_pp_act reads it: the dispatcher's
+// fifteen launch sites stay as they are). Thread-local: the library holds no mutable state shared between threads.
+struct gemm_call_ctx {
+  const void* image;
+  size_t image_bytes;
+  void* scratch;
+  size_t scratch_bytes;
+  int mode;                 // 0 = launch, 1 = plan only (fill *plan), 2 = write the image into host_image
+  grove_gemm_plan* plan;
+  void* host_image;
+  size_t host_image_bytes;
+};
+static thread_local gemm_call_ctx t_call = {nullptr, 0, nullptr, 0, 0, nullptr, nullptr, 0};
+
 template <int BK, bool GLDS, int NJ, int MI>
 int launch(const grove_gemm_params& p, int vec_ok, hipStream_t s) {
+  if (t_call.mode) return GROVE_OK;  // plan / image requests: the non-persistent kernels need no workspace (sizes stay 0)
   constexpr int BN_ = 32 * NJ;
   constexpr int BM_ = 32 * MI;
   const int tiles_m = (p.M + BM_ - 1) / BM_, tiles_n = (p.N + BN_ - 1) / BN_;
@@ -1140,20 +1155,20 @@ inline sk_plan plan_stream_k(long tiles, int nk, int G, int mode) {  // mode: 0 
   return pl;
 }
 
-// The work list of a shape (see pp_work) and the fix-up's list of split tiles, built once and kept on the device.
+// The work list of a shape (see pp_work) and the fix-up's list of split tiles. Round 3: both live in CALLER-OWNED memory — the
+// library allocates nothing (grove_hip.h "Workspaces of the persistent GEMMs"): the caller asks grove_gemm_plan for the sizes, has
+// grove_gemm_plan_image write the lists into a host buffer, uploads that image once per plan key, and passes image + scratch
+// (the stream-K partial tiles) with every launch.
 struct pp_table_key {
   int dev, bm, tiles_m, tiles_n, nk, G, S;
-  bool operator<(const pp_table_key& o) const {
-    return std::tie(dev, bm, tiles_m, tiles_n, nk, G, S) < std::tie(o.dev, o.bm, o.tiles_m, o.tiles_n, o.nk, o.G, o.S);
-  }
 };
-struct pp_table_dev { i32x4_t* table; i32x4_t* fixups; int n_fixups, n_slots; };
-static std::map<pp_table_key, pp_table_dev> g_pp_tables;
-static std::mutex g_pp_mutex;
+struct pp_table_dev { const i32x4_t* table; const i32x4_t* fixups; int n_fixups, n_slots; };
 
-inline bool stream_capturing(hipStream_t s) {
-  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  return hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
+inline uint64_t plan_key(const pp_table_key& k) {  // the image depends on exactly these (not on the epilogue or the operand type)
+  uint64_t h = 1469598103934665603ull;
+  const int v[6] = {k.bm, k.tiles_m, k.tiles_n, k.nk, k.G, k.S};
+  for (int i = 0; i < 6; ++i) h = (h ^ (uint64_t)(uint32_t)v[i]) * 1099511628211ull;
+  return h;
 }
 
 // the lists of a shape on the host: `t` = the work list (rows of G entries, see pp_work), `fix` = the split tiles {m0, n0, first slot, parts}
@@ -1195,78 +1210,56 @@ inline void build_work_list(const pp_table_key& key, const sk_plan& pl, std::vec
     }
 }
 
-inline const pp_table_dev* pp_table(const pp_table_key& key, const sk_plan& pl, hipStream_t s) {
-  std::lock_guard<std::mutex> lk(g_pp_mutex);
-  auto it = g_pp_tables.find(key);
-  if (it != g_pp_tables.end()) return &it->second;
-  if (stream_capturing(s)) return nullptr;  // no allocation inside a capture: run the shape once before capturing
-  std::vector<i32x4_t> t, fix;
-  build_work_list(key, pl, t, fix);
-  pp_table_dev d{nullptr, nullptr, (int)fix.size(), key.S ? pl.tail * pl.parts : 0};
-  bool ok = hipMalloc((void**)&d.table, t.size() * sizeof(i32x4_t)) == hipSuccess &&
-            hipMemcpy(d.table, t.data(), t.size() * sizeof(i32x4_t), hipMemcpyHostToDevice) == hipSuccess;
-  if (ok && !fix.empty())
-    ok = hipMalloc((void**)&d.fixups, fix.size() * sizeof(i32x4_t)) == hipSuccess &&
-         hipMemcpy(d.fixups, fix.data(), fix.size() * sizeof(i32x4_t), hipMemcpyHostToDevice) == hipSuccess;
-  if (!ok) {
-    (void)hipGetLastError();
-    return nullptr;
-  }
-  return &(g_pp_tables[key] = d);
-}
-
-// workspace of the stream-K parts: one per (device, stream) — launches on one stream are ordered, launches on two streams may
-// overlap. G slots: a block holds at most one part.
-struct sk_workspace { int dev; hipStream_t stream; float* ws; };
-static sk_workspace g_sk_ws[16];
-static int g_sk_ws_n = 0;
-inline float* stream_k_workspace(hipStream_t s, int dev, int G) {
-  std::lock_guard<std::mutex> lk(g_pp_mutex);
-  for (int i = 0; i < g_sk_ws_n; ++i)
-    if (g_sk_ws[i].dev == dev && g_sk_ws[i].stream == s) return g_sk_ws[i].ws;
-  if (g_sk_ws_n == 16 || stream_capturing(s)) return nullptr;
-  sk_workspace w{dev, s, nullptr};
-  if (hipMalloc((void**)&w.ws, P_SLOT * G) != hipSuccess) {
-    (void)hipGetLastError();
-    return nullptr;
-  }
-  g_sk_ws[g_sk_ws_n++] = w;
-  return w.ws;
-}
-
 template <int BM, bool GATHER, int ACT, bool FP8 = false>
 int launch_pp_act(const grove_gemm_params& p, hipStream_t s, const float* row_scale = nullptr, const float* col_scale = nullptr) {
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + P_BN - 1) / P_BN;
   const size_t lds = 2 * (size_t)P_STAGE;
+  const int G = num_cus(), nk = p.K / P_BK;
+  const long tiles = (long)tiles_m * tiles_n;
+  GROVE_CHECK(tiles < (1L << 24) && nk < 65536, GROVE_E_SHAPE, "gemm: %d x %d tiles x %d K tiles overflow the pipelined kernel's work list", tiles_m, tiles_n, nk);
+  const sk_plan pl = plan_stream_k(tiles, nk, G, g_gemm_stream_k);
+  const int grid = pl.S ? G : (int)(tiles < G ? tiles : G);  // (the list is laid out for this grid: its row stride and wgid map)
+  const pp_table_key key{0, BM, tiles_m, tiles_n, nk, grid, pl.S};
+  const int n_dp_max = pl.S ? pl.rounds : (int)((tiles + G - 1) / G);
+  const size_t list_bytes = (size_t)(1 + n_dp_max + 1) * grid * sizeof(i32x4_t);
+  const int n_fix = pl.S ? pl.tail : 0, n_slots = pl.S ? pl.tail * pl.parts : 0;
+  const size_t image_bytes = list_bytes + (size_t)n_fix * sizeof(i32x4_t);
+  const size_t scratch_bytes = (size_t)n_slots * P_SLOT;
+  if (t_call.mode == 1) {  // grove_gemm_make_plan: sizes and key only
+    grove_gemm_plan* o = t_call.plan;
+    o->bm = BM, o->tiles_m = tiles_m, o->tiles_n = tiles_n, o->k_tiles = nk, o->grid = grid, o->stream_k = pl.S;
+    o->image_bytes = (int64_t)image_bytes, o->scratch_bytes = (int64_t)scratch_bytes;
+    o->key = plan_key(key);
+    return GROVE_OK;
+  }
+  if (t_call.mode == 2) {  // grove_gemm_plan_image: the lists, as the device will read them
+    GROVE_CHECK(t_call.host_image && t_call.host_image_bytes >= image_bytes, GROVE_E_WORKSPACE, "gemm_plan_image: buffer of %zu bytes, the image needs %zu",
+                t_call.host_image_bytes, image_bytes);
+    std::vector<i32x4_t> t, fix;
+    build_work_list(key, pl, t, fix);
+    GROVE_CHECK(t.size() * sizeof(i32x4_t) == list_bytes && (int)fix.size() == n_fix, GROVE_E_WORKSPACE, "gemm_plan_image: list size mismatch");
+    memcpy(t_call.host_image, t.data(), list_bytes);
+    if (n_fix) memcpy((char*)t_call.host_image + list_bytes, fix.data(), (size_t)n_fix * sizeof(i32x4_t));
+    return GROVE_OK;
+  }
+  GROVE_CHECK(t_call.image && t_call.image_bytes >= image_bytes && ((uintptr_t)t_call.image & 15) == 0, GROVE_E_WORKSPACE,
+              "gemm: the persistent kernel needs its work-list image (%zu bytes, 16-byte aligned; got %zu): grove_gemm_make_plan + grove_gemm_plan_image", image_bytes,
+              t_call.image_bytes);
+  GROVE_CHECK(!scratch_bytes || (t_call.scratch && t_call.scratch_bytes >= scratch_bytes && ((uintptr_t)t_call.scratch & 15) == 0), GROVE_E_WORKSPACE,
+              "gemm: this launch cuts %d tiles into stream-K parts and needs %zu bytes of scratch (got %zu)", n_fix, scratch_bytes, t_call.scratch_bytes);
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<BM, GATHER, ACT, FP8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  const int G = num_cus(), nk = p.K / P_BK;
-  const long tiles = (long)tiles_m * tiles_n;
-  GROVE_CHECK(tiles < (1L << 24) && nk < 65536, GROVE_E_SHAPE, "gemm: %d x %d tiles x %d K tiles overflow the pipelined kernel's work list", tiles_m, tiles_n, nk);
   g_gemm_last_epilogue = ACT;
-  int dev = 0;
-  hipGetDevice(&dev);
-  pp_work work{nullptr, nullptr, row_scale, col_scale};
-  sk_plan pl = plan_stream_k(tiles, nk, G, g_gemm_stream_k);
-  if (pl.S && !(work.ws = stream_k_workspace(s, dev, G))) pl = plan_stream_k(tiles, nk, G, 0);
-  const int grid = pl.S ? G : (int)(tiles < G ? tiles : G);  // (the list is laid out for this grid: its row stride and wgid map)
-  if (pl.S) {  // keep the whole-tile list of the shape at hand too: a later launch inside a stream capture on a stream without a
-               // workspace falls back to it and must not have to allocate
-    const int grid0 = (int)(tiles < G ? tiles : G);
-    (void)pp_table(pp_table_key{dev, BM, tiles_m, tiles_n, nk, grid0, 0}, plan_stream_k(tiles, nk, G, 0), s);
-  }
-  const pp_table_dev* td = pp_table(pp_table_key{dev, BM, tiles_m, tiles_n, nk, grid, pl.S}, pl, s);
-  GROVE_CHECK(td != nullptr, GROVE_E_HIP, "gemm: no work list for %d x %d tiles (first use of a shape inside a stream capture, or out of memory)", tiles_m, tiles_n);
-  GROVE_CHECK(td->n_slots <= G, GROVE_E_WORKSPACE, "gemm: %d stream-K parts for %d slots", td->n_slots, G);
-  work.table = td->table;
+  const pp_table_dev td{(const i32x4_t*)t_call.image, (const i32x4_t*)((const char*)t_call.image + list_bytes), n_fix, n_slots};
+  pp_work work{td.table, (float*)t_call.scratch, row_scale, col_scale};
   g_gemm_last_stream_k = pl.S;
   hipLaunchKernelGGL((gemm_nt_pp_kernel<BM, GATHER, ACT, FP8>), dim3(grid, 1, 1), dim3(P_NT), lds, s, p, work);
   GROVE_LAUNCH_CHECK();
-  if (td->n_fixups) {
-    hipLaunchKernelGGL((gemm_pp_fixup_kernel<BM, ACT, FP8>), dim3(td->n_fixups * (8 / FIX_WAVES), 1, 1), dim3(64 * FIX_WAVES), 0, s, p, (const i32x4_t*)td->fixups,
+  if (td.n_fixups) {
+    hipLaunchKernelGGL((gemm_pp_fixup_kernel<BM, ACT, FP8>), dim3(td.n_fixups * (8 / FIX_WAVES), 1, 1), dim3(64 * FIX_WAVES), 0, s, p, td.fixups,
                        (const float*)work.ws, work);
     GROVE_LAUNCH_CHECK();
   }
@@ -1330,7 +1323,15 @@ extern "C" int grove_gemm_set_staging(int use_lds_dma) {
 
 // The e4m3 GEMM (grove_gemm_fp8, gemm_fp8.hip) on the FP8 instances of the pipelined kernel: same staging stream and phase
 // structure, twice the math per byte. Returns 1 when the problem does not fit them (the caller falls back to its own kernel).
+// (gemm_fp8.hip's entry points set the call context through these: mode 0 launch / 1 plan / 2 image, as above)
+void grove_gemm_ctx_set(const grove_gemm_workspace* w, int mode, grove_gemm_plan* plan, void* host_image, size_t host_bytes) {
+  t_call = gemm_call_ctx{w ? w->image : nullptr, w ? w->image_bytes : 0, w ? w->scratch : nullptr, w ? w->scratch_bytes : 0, mode, plan, host_image, host_bytes};
+}
+void grove_gemm_ctx_clear() { t_call = gemm_call_ctx{nullptr, 0, nullptr, 0, 0, nullptr, nullptr, 0}; }
+bool grove_gemm_ctx_has_image() { return t_call.mode != 0 || t_call.image != nullptr; }
+
 int grove_gemm_fp8_pipelined(const grove_gemm_fp8_params* q, hipStream_t s) {
+  if (!grove_gemm_ctx_has_image()) return 1;  // no work-list image: the caller's own (two-barrier) kernel runs
   const bool al = ((((uintptr_t)q->C | (uintptr_t)q->bias | (uintptr_t)q->residual | (uintptr_t)q->scale_b) & 15) == 0) && q->ldc % 8 == 0 &&
                   (!q->residual || q->ldr % 8 == 0);
   if (!al || q->N % 8 != 0 || q->K % 128 != 0 || q->lda % 16 != 0 || q->ldb % 16 != 0) return 1;
@@ -1383,7 +1384,47 @@ extern "C" int grove_gemm_last_stream_k(void) { return g_gemm_last_stream_k; }
 extern "C" int grove_gemm_last_variant(void) { return g_gemm_last_variant; }
 extern "C" int grove_gemm_last_epilogue(void) { return g_gemm_last_epilogue; }
 
-extern "C" int grove_gemm_bf16(const grove_gemm_params* pp, void* stream) {
+static int gemm_bf16_dispatch(const grove_gemm_params* pp, void* stream);
+
+namespace {
+struct call_guard {  // the call context never outlives its call
+  ~call_guard() { t_call = gemm_call_ctx{nullptr, 0, nullptr, 0, 0, nullptr, nullptr, 0}; }
+};
+inline void set_launch_ctx(const grove_gemm_workspace* w) {
+  t_call = gemm_call_ctx{w ? w->image : nullptr, w ? w->image_bytes : 0, w ? w->scratch : nullptr, w ? w->scratch_bytes : 0, 0, nullptr, nullptr, 0};
+}
+}  // namespace
+
+extern "C" int grove_gemm_bf16(const grove_gemm_params* pp, const grove_gemm_workspace* w, void* stream) {
+  call_guard g;
+  set_launch_ctx(w);
+  return gemm_bf16_dispatch(pp, stream);
+}
+
+extern "C" int grove_gemm_make_plan(const grove_gemm_params* pp, grove_gemm_plan* out) {
+  GROVE_CHECK(out != nullptr, GROVE_E_SHAPE, "gemm_plan: null output");
+  memset(out, 0, sizeof(*out));
+  call_guard g;
+  t_call = gemm_call_ctx{nullptr, 0, nullptr, 0, 1, out, nullptr, 0};
+  const int rc = gemm_bf16_dispatch(pp, nullptr);
+  out->variant = g_gemm_last_variant;
+  return rc;
+}
+
+extern "C" int grove_gemm_plan_image(const grove_gemm_params* pp, void* host_image, size_t bytes) {
+  call_guard g;
+  t_call = gemm_call_ctx{nullptr, 0, nullptr, 0, 2, nullptr, host_image, bytes};
+  return gemm_bf16_dispatch(pp, nullptr);
+}
+
+size_t grove_gemm_workspace_bytes_impl(const grove_gemm_params* pp) {
+  grove_gemm_plan pl;
+  if (grove_gemm_make_plan(pp, &pl) != GROVE_OK) return 0;
+  return (size_t)pl.image_bytes + (size_t)pl.scratch_bytes;
+}
+extern "C" size_t grove_gemm_workspace_bytes(const grove_gemm_params* pp) { return grove_gemm_workspace_bytes_impl(pp); }
+
+static int gemm_bf16_dispatch(const grove_gemm_params* pp, void* stream) {
   GROVE_CHECK(pp != nullptr, GROVE_E_SHAPE, "gemm: null params");
   grove_gemm_params p = *pp;
   if (p.batch1 <= 0) p.batch1 = 1;
@@ -1424,7 +1465,8 @@ extern "C" int grove_gemm_bf16(const grove_gemm_params* pp, void* stream) {
                        (!p.residual || ((((uintptr_t)p.residual & 15) == 0) && p.ldr % 8 == 0));
   const bool pp_act = pp_act_ok(p);  // compiled-in epilogues
   const bool maps = p.n_group || p.k_group;
-  const bool p256_ok = g_gemm_glds && bk64 && (!p.a_idx || (long)p.a_taps * p.M >= 8) && bt == 1 && p.split_k <= 1 && !p.accumulate && wide_ok && p.N % 8 == 0 && pp_act;
+  const bool have_ws = t_call.mode != 0 || t_call.image != nullptr;  // no work-list image given: only the non-persistent kernels can run
+  const bool p256_ok = have_ws && g_gemm_glds && bk64 && (!p.a_idx || (long)p.a_taps * p.M >= 8) && bt == 1 && p.split_k <= 1 && !p.accumulate && wide_ok && p.N % 8 == 0 && pp_act;
   // Tile choice by a measured cost model (tools/bench_gemm_tiles.py, microseconds): time = rounds of resident blocks x
   // (K tiles x per-K-tile time + fixed per-tile time). The 128- and 192-row kernels keep 2 blocks per CU (512 slots; a
   // lone block of a partial round still takes a full round); the pipelined kernels are persistent, one block per CU,

@@ -12,6 +12,7 @@
 // products are formed transposed (B fragment as the MFMA's A operand) so that a lane owns four consecutive output columns. Operand map (checked on hardware with
 // exact integer data, tests/test_kernels_gpu.py): lane l holds row l & 15, bytes k = 32 (l >> 4) .. + 31 of the 128-deep step.
 #include "common.h"
+#include <string.h>
 
 namespace {
 
@@ -173,8 +174,11 @@ extern "C" int grove_gemm_fp8_set_pipelined(int on) {
   return GROVE_OK;
 }
 
-extern "C" int grove_gemm_fp8(const grove_gemm_fp8_params* p, void* stream) {
-  GROVE_CHECK(p && p->M > 0 && p->N > 0 && p->K > 0 && p->A && p->B && p->C && p->scale_a && p->scale_b, GROVE_E_SHAPE, "gemm_fp8: bad arguments");
+void grove_gemm_ctx_set(const grove_gemm_workspace* w, int mode, grove_gemm_plan* plan, void* host_image, size_t host_bytes);
+void grove_gemm_ctx_clear();
+
+static int gemm_fp8_run(const grove_gemm_fp8_params* p, int mode, void* stream) {
+  GROVE_CHECK(p && p->M > 0 && p->N > 0 && p->K > 0 && (mode || (p->A && p->B && p->C && p->scale_a && p->scale_b)), GROVE_E_SHAPE, "gemm_fp8: bad arguments");
   GROVE_CHECK(p->K % F8_BK == 0, GROVE_E_SHAPE, "gemm_fp8: K=%d must be a multiple of %d", p->K, F8_BK);
   GROVE_CHECK(p->lda % 16 == 0 && p->ldb % 16 == 0 && ((uintptr_t)p->A & 15) == 0 && ((uintptr_t)p->B & 15) == 0, GROVE_E_ALIGN,
               "gemm_fp8: operand rows must be 16-byte aligned");
@@ -182,12 +186,36 @@ extern "C" int grove_gemm_fp8(const grove_gemm_fp8_params* p, void* stream) {
     const int rc = grove_gemm_fp8_pipelined(p, (hipStream_t)stream);
     if (rc <= 0) return rc;
   }
+  if (mode) return GROVE_OK;  // plan / image request for a problem the two-barrier kernel runs: no workspace (sizes stay 0)
   const int tiles = ((p->M + F8_BM - 1) / F8_BM) * ((p->N + F8_BN - 1) / F8_BN);
   const size_t lds = 4 * F8_TILE;
   hipFuncSetAttribute((const void*)gemm_fp8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(gemm_fp8_kernel, dim3(tiles), dim3(F8_NT), lds, (hipStream_t)stream, *p);
   GROVE_LAUNCH_CHECK();
   return GROVE_OK;
+}
+
+extern "C" int grove_gemm_fp8(const grove_gemm_fp8_params* p, const grove_gemm_workspace* w, void* stream) {
+  grove_gemm_ctx_set(w, 0, nullptr, nullptr, 0);
+  const int rc = gemm_fp8_run(p, 0, stream);
+  grove_gemm_ctx_clear();
+  return rc;
+}
+
+extern "C" int grove_gemm_fp8_make_plan(const grove_gemm_fp8_params* p, grove_gemm_plan* out) {
+  GROVE_CHECK(out != nullptr, GROVE_E_SHAPE, "gemm_fp8_plan: null output");
+  memset(out, 0, sizeof(*out));
+  grove_gemm_ctx_set(nullptr, 1, out, nullptr, 0);
+  const int rc = gemm_fp8_run(p, 1, nullptr);
+  grove_gemm_ctx_clear();
+  return rc;
+}
+
+extern "C" int grove_gemm_fp8_plan_image(const grove_gemm_fp8_params* p, void* host_image, size_t bytes) {
+  grove_gemm_ctx_set(nullptr, 2, nullptr, host_image, bytes);
+  const int rc = gemm_fp8_run(p, 2, nullptr);
+  grove_gemm_ctx_clear();
+  return rc;
 }
 
 extern "C" int grove_quant_fp8_rows(const void* x, void* q, float* scale, int32_t rows, int32_t K, int32_t ld_x, int32_t ld_q, void* stream) {

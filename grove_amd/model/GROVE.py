@@ -95,6 +95,7 @@ class GROVEForCausalLM(torch.nn.Module):
         self.stream_dtype = kwargs.get("stream_dtype", None)  # None: fp32 for inference models, bf16 for training models
         # "bf16" (default) or "fp8": the linear layers of the CLIP tower and the LLaMA stack on the e4m3 MFMA GEMM (config 5; inference)
         self.gemm_dtype = kwargs.get("gemm_dtype", "bf16")
+        self.fp8_policy = kwargs.get("fp8_policy", "det16_kv16")  # which LLaMA GEMMs / rows stay bf16 under gemm_dtype="fp8" (LlamaStack)
         self.dev = torch.device(device)
         if self.dev.type != "cuda":
             raise RuntimeError("grove_amd runs on MI355X only: there is no CPU path (use oracle/ for a CPU check)")
@@ -221,7 +222,7 @@ class GROVEForCausalLM(torch.nn.Module):
         if fp8 and tr:
             raise ValueError("gemm_dtype='fp8' is an inference configuration (BASELINE config 5): build the model with train=False")
         self.clip = ClipTower(sd, d, dev, fp32_stream=f32s, fp8=fp8)
-        self.llama = LlamaStack(sd, d, dev, train=tr, fp32_stream=f32s, fp8=fp8)
+        self.llama = LlamaStack(sd, d, dev, train=tr, fp32_stream=f32s, fp8=fp8, fp8_policy=self.fp8_policy)
         self.sam = SamEncoder(sd, d, dev, train=tr, grads=self._grad, fp32_stream=f32s)
         self.decoder = BoxDecoder(sd, d, dev, grads=self._grad, pe_dtype=self.pe_dtype)
 
@@ -494,7 +495,8 @@ class GROVEForCausalLM(torch.nn.Module):
         # 3. splice, LLaMA (llava_llama.py:88-109)
         self.wait_weights()
         x = self._embed(plan, feats.data)
-        hidden, llama_ctx = self.llama.forward(x, plan.B, plan.S, kv_len=plan.kv_len, save=train)
+        hidden, llama_ctx = self.llama.forward(x, plan.B, plan.S, kv_len=plan.kv_len, save=train,
+                                               precise_rows=det_rows if self.gemm_dtype == "fp8" else None)
         # 1. grounding encoder (GROVE.py:162). It shares nothing with the CLIP -> LLaMA tower until the decoder, so it runs on its
         # own stream: the two kernel sequences interleave on the CUs and fill each other's partial rounds and tails
         # (same-box A/B: -11 ms per step, forward and backward). `tower_overlap = False` serialises them.
@@ -856,26 +858,43 @@ class GROVEForCausalLM(torch.nn.Module):
         cache = out.past_key_values
         hiddens = [out.hidden_states]
         logits = out.logits
-        step_fn = None
+        if use_graph and max_new_tokens > 1:
+            # first token from the prompt step's logits (one host read), every later step on the device: see LlamaStack.greedy_graph
+            nxt = pick(logits)
+            ids = torch.cat([ids, nxt[:, None]], 1)
+            finished = finished | (nxt == eos)
+            if bool(finished.all()):
+                return result(ids, hiddens, cache)
+            n_steps = max_new_tokens - 1
+            replay, st = self.llama.greedy_graph(B, cache.layers, embed, lm_head, nxt.to(self.dev), cache.length, n_steps, d.vocab, eos, pad,
+                                                 finished.to(self.dev))
+            done, CHECK = 0, 8  # the host looks at `finished` every CHECK steps only; steps run past the stop are cut off below
+            while done < n_steps:
+                for _ in range(min(CHECK, n_steps - done)):
+                    replay()
+                    done += 1
+                if done < n_steps and bool(st["finished"].all()):
+                    break
+            new_ids = st["ids_out"][:, :done].to(ids.device)
+            # HF's stop rule, applied after the fact: the loop ends with the first step after which every row is finished
+            fin = finished[:, None].to(new_ids.device) | ((new_ids == eos).cumsum(1) > 0)
+            allfin = fin.all(0).nonzero().flatten()
+            used = int(allfin[0]) + 1 if allfin.numel() else done
+            ids = torch.cat([ids, new_ids[:, :used]], 1)
+            hid = st["hid_out"][:used]
+            hiddens += [hid[j].view(B, 1, H).clone() for j in range(used)]
+            cache.length += used
+            return result(ids, hiddens, cache)
         for step in range(max_new_tokens):
             nxt = pick(logits)
             ids = torch.cat([ids, nxt[:, None]], 1)
             finished = finished | (nxt == eos)
             if bool(finished.all()) or step == max_new_tokens - 1:
                 break  # the last generated token is never fed back (quirk Q3)
-            if use_graph:
-                xt = torch.empty((B, H), dtype=bf, device=self.dev)
-                ops.copy_rows(embed, xt, B, H, idx_src=nxt.to(self.dev).to(torch.int32))
-                if step_fn is None:
-                    step_fn = self.llama.decode_graph(B, cache.layers, xt, cache.length, lm_head)
-                last, logits = step_fn(xt, cache.length)
-                cache.length += 1
-                hiddens.append(last.view(B, 1, H).clone())
-            else:
-                out = self.forward(past_key_values=cache, input_ids=ids[:, -1:], image_features=image_features,
-                                   token_embeddings=token_embeddings, use_cache=True)
-                logits = out.logits
-                hiddens.append(out.hidden_states)
+            out = self.forward(past_key_values=cache, input_ids=ids[:, -1:], image_features=image_features,
+                               token_embeddings=token_embeddings, use_cache=True)
+            logits = out.logits
+            hiddens.append(out.hidden_states)
         return result(ids, hiddens, cache)
 
     def generate_greedy(self, image_features, input_ids, max_new_tokens, token_embeddings=None, eos_token_id=None, pad_token_id=None,

@@ -15,13 +15,19 @@ from .attention import attention_bwd, attention_fwd
 
 
 class LlamaStack:
-    def __init__(self, sd, d, device, train=False, fp32_stream=None, fp8=False):
+    def __init__(self, sd, d, device, train=False, fp32_stream=None, fp8=False, fp8_policy="det16_kv16"):
         self.d, self.dev, self.train = d, device, train
         self.fp32_stream = (not train) if fp32_stream is None else fp32_stream
         # fp8 (BASELINE config 5): the four projections of every layer run on the e4m3 block-scaled MFMA GEMM (grove_gemm_fp8) with
         # per-output-channel weight scales made here and per-row activation scales made on the fly; inference only (no fp8 dgrad)
+        # fp8_policy (tools/fp8_policy_study.py, DESIGN section 8 — e4m3's 3 mantissa bits cost ~5 % per GEMM output whatever the scales):
+        #   "all"        every projection of every layer in e4m3 (round 2);
+        #   "det16_kv16" k_proj / v_proj of all rows stay bf16 (16.6 % of the stack's FLOPs: every later row attends to them) and the
+        #                rows passed as `precise_rows` (the [DET] positions, whose hidden state feeds the box head) are recomputed in
+        #                bf16 after each e4m3 GEMM (a few rows: one pass over the bf16 weights) — halves the box error.
         assert not (fp8 and train), "the fp8 path is inference-only"
-        self.fp8 = fp8
+        assert fp8_policy in ("all", "det16_kv16")
+        self.fp8, self.fp8_policy = fp8, fp8_policy
         self.layers = []
         for i in range(d.n_layers):
             p = f"model.layers.{i}."
@@ -40,16 +46,37 @@ class LlamaStack:
                 for k in ("wqkv", "wo", "wgu", "wd"):
                     if L[k].shape[1] % 128 == 0:
                         L[k + "_q"] = ops.quant_fp8_rows(L[k])
+                if fp8_policy == "det16_kv16" and "wqkv_q" in L:
+                    H = d.hidden
+                    L["wq_q"] = (L["wqkv_q"][0][:H], L["wqkv_q"][1][:H])  # (row-wise scales: the q rows of the fused copy are q_proj's own)
+                    L["wq"], L["wkv"] = wqkv[:H], wqkv[H:]
             self.layers.append(L)
         self.norm = sd["model.norm.weight"]
 
-    def _lin(self, L, k, x, residual=None):
-        """x @ L[k].T (+ residual): the fp8 GEMM when this stack is quantised (and K fits its 128-byte K tile), else the bf16 one."""
+    def _lin(self, L, k, x, residual=None, precise_rows=None):
+        """x @ L[k].T (+ residual): the fp8 GEMM when this stack is quantised (and K fits its 128-byte K tile), else the bf16 one.
+        precise_rows (policy det16_kv16): those rows of the result are recomputed by the bf16 GEMM (gathered A rows, scattered C rows)."""
         if (k + "_q") in L:
-            return ops.linear_fp8(x, L[k + "_q"][0], L[k + "_q"][1], residual=residual)
+            y = ops.linear_fp8(x, L[k + "_q"][0], L[k + "_q"][1], residual=residual)
+            if precise_rows is not None:
+                ops.linear(x, L[k], residual=residual, a_idx=precise_rows, c_idx=precise_rows, M=int(precise_rows.numel()), out=y)
+            return y
         return ops.linear(x, L[k], residual=residual)
 
-    def forward(self, x, B, S, kv_len=None, save=False, kv_cache=None):
+    def _qkv(self, L, h, precise_rows=None):
+        """The fused q|k|v activation [rows, 3H]. Policy det16_kv16: q from the e4m3 GEMM, k|v from the bf16 one (two launches writing
+        the two column ranges of one tensor), the precise rows of q recomputed in bf16."""
+        if "wq_q" not in L:
+            return self._lin(L, "wqkv", h, precise_rows=precise_rows if self.fp8_policy == "det16_kv16" else None)
+        H = self.d.hidden
+        qkv = torch.empty((h.shape[0], 3 * H), dtype=torch.bfloat16, device=self.dev)
+        ops.linear_fp8(h, L["wq_q"][0], L["wq_q"][1], out=qkv[:, :H])
+        ops.linear(h, L["wkv"], out=qkv[:, H:])
+        if precise_rows is not None:
+            ops.linear(h, L["wq"], a_idx=precise_rows, c_idx=precise_rows, M=int(precise_rows.numel()), out=qkv[:, :H])
+        return qkv
+
+    def forward(self, x, B, S, kv_len=None, save=False, kv_cache=None, precise_rows=None):
         """x: bf16 [B*S, H] input embeddings (consumed). kv_len: int32 [B] valid lengths or None.
         kv_cache: optional list (one per layer) of bf16 [B, S_max, 2H] tensors that receive the rotated keys | values of
         positions 0..S-1 (the prefill of a cached decode). Returns (final-norm hidden [B*S, H], ctx).
@@ -65,6 +92,7 @@ class LlamaStack:
         pos = torch.arange(S, dtype=torch.int32, device=self.dev).repeat(B)
         saved = []
         f32 = self.fp32_stream
+        pr = precise_rows if (self.fp8 and self.fp8_policy == "det16_kv16" and precise_rows is not None and precise_rows.numel()) else None
         res = ops.to_f32(x) if f32 else None
         t = None  # fp32 stream: branch output not yet added to the stream
         for li, L in enumerate(self.layers):
@@ -74,20 +102,20 @@ class LlamaStack:
             else:
                 xb = x
                 h = ops.rmsnorm(x, L["ln1"], d.rms_eps)
-            qkv = self._lin(L, "wqkv", h)
+            qkv = self._qkv(L, h, pr) if self.fp8 else ops.linear(h, L["wqkv"])
             ops.rope_(qkv, pos, 0, 2 * nh, hd, d.rope_theta)
             if kv_cache is not None:
                 kv_cache[li][:, :S].copy_(qkv.view(B, S, 3 * H)[:, :, H:])
             o, actx = attention_fwd(qkv, B, S, nh, hd, 0, H, 2 * H, hd ** -0.5, causal=True, kv_len=kv_len, save=save)
             if f32:
-                t = self._lin(L, "wo", o)
+                t = self._lin(L, "wo", o, precise_rows=pr)
                 x1b = torch.empty_like(x) if save else None
                 h2 = ops.rmsnorm(t, L["ln2"], d.rms_eps, res=res, res_bf16=x1b)
             else:
-                x1b = self._lin(L, "wo", o, residual=x)
+                x1b = self._lin(L, "wo", o, residual=x, precise_rows=pr)
                 h2 = ops.rmsnorm(x1b, L["ln2"], d.rms_eps)
             if "wgu_q" in L:
-                gu = self._lin(L, "wgu", h2)
+                gu = self._lin(L, "wgu", h2, precise_rows=pr)
                 a = ops.swiglu(gu, I)
             elif "wgu_sw" in L and h2.shape[0] >= 1024:  # (the fused epilogue lives in the pipelined kernel: big GEMMs only)
                 gu = torch.empty((h2.shape[0], 2 * I), dtype=torch.bfloat16, device=self.dev) if save else None
@@ -96,9 +124,9 @@ class LlamaStack:
                 gu = ops.linear(h2, L["wgu"])
                 a = ops.swiglu(gu, I)
             if f32:
-                t = self._lin(L, "wd", a)
+                t = self._lin(L, "wd", a, precise_rows=pr)
             else:
-                x = self._lin(L, "wd", a, residual=x1b)
+                x = self._lin(L, "wd", a, residual=x1b, precise_rows=pr)
             if save:
                 saved.append((xb, qkv, actx, x1b, gu))
         if f32:
@@ -167,6 +195,51 @@ class LlamaStack:
             graph.replay()
             return out, logits
         return step
+
+    def greedy_graph(self, B, kv_cache, embed, lm_head, first_tok, t0, max_steps, vocab, eos, pad, finished0):
+        """The WHOLE greedy step on the device, captured once: embedding gather of the current token -> the cached step
+        (_decode_body) -> argmax over the [B, V] logits -> HF's finished / pad bookkeeping -> the token, its position and the step
+        counter advance in place, the step's final-norm hidden row and the picked id land in `hid_out[step]` / `ids_out[:, step]`.
+        Nothing per token comes back to the host, so a run of steps is a run of graph replays with no stream sync between them
+        (round 2 read `finished.all()` and the argmax back every token: the GPU idled while the host queued the next replay).
+        Returns (replay, state): state = dict(ids_out [B, max_steps] int64, hid_out [max_steps, B, H], finished [B] bool,
+        step [1] int64). The warm-up pass is the real first step (see decode_graph), so the capture starts at step 0 again with
+        the state rewound — the K|V row it appended is rewritten with identical bytes."""
+        dev, H = self.dev, self.d.hidden
+        tok = first_tok.to(torch.int32).clone()
+        pos = torch.full((B,), int(t0), dtype=torch.int32, device=dev)
+        step_i = torch.zeros(1, dtype=torch.int64, device=dev)
+        finished = finished0.clone()
+        ids_out = torch.full((B, max_steps), int(pad), dtype=torch.int64, device=dev)
+        hid_out = torch.zeros((max_steps, B, H), dtype=torch.bfloat16, device=dev)
+        x_in = torch.empty((B, H), dtype=torch.bfloat16, device=dev)
+        pad_t = torch.full((B,), int(pad), dtype=torch.int64, device=dev)
+
+        def body():
+            ops.copy_rows(embed, x_in, B, H, idx_src=tok)
+            out, logits = self._decode_body(x_in, pos, kv_cache, lm_head)
+            nxt = logits.view(B, -1)[:, :vocab].argmax(-1)          # index selection over one [B, V] block, as generate()'s pick
+            nxt = torch.where(finished, pad_t, nxt)
+            finished.logical_or_(nxt == eos)
+            hid_out.index_copy_(0, step_i, out.view(1, B, H))
+            ids_out.index_copy_(1, step_i, nxt.view(B, 1))
+            tok.copy_(nxt)
+            pos.add_(1)
+            step_i.add_(1)
+        keep = (tok.clone(), finished.clone())
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            body()                                                  # warm-up = the real step 0
+        torch.cuda.current_stream(dev).wait_stream(side)
+        tok.copy_(keep[0]); finished.copy_(keep[1]); pos.fill_(int(t0)); step_i.zero_()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            body()
+        # the graph's nodes hold raw ADDRESSES: every tensor they touch must outlive the replays (dropping tok / pos / x_in here hands
+        # their memory back to the allocator while the graph still reads and writes it)
+        return graph.replay, dict(ids_out=ids_out, hid_out=hid_out, finished=finished, step=step_i,
+                                  _keep=(graph, tok, pos, x_in, pad_t, kv_cache, embed, lm_head))
 
     def backward(self, ctx, d_out):
         """dgrad through the frozen stack. d_out: bf16 [B*S, H] gradient of the post-norm hidden.

@@ -48,6 +48,50 @@ def pad_to(n, m):
     return (n + m - 1) // m * m
 
 
+# ---- caller-owned workspaces of the persistent GEMMs (grove_hip.h "Workspaces of the persistent GEMMs")
+# The library allocates nothing: this front end keeps, per device, ONE device image of every plan key it has launched (the work list:
+# read-only, shared by all streams / epilogues / bf16 and fp8) and, per (device, stream), ONE scratch tensor for the stream-K partial
+# tiles (launches of a stream are ordered, so they can share it; two streams may overlap, so they cannot). All of it is torch memory.
+_gemm_images = {}    # (device index, plan key) -> uint8 device tensor
+_gemm_scratch = {}   # (device index, stream handle) -> uint8 device tensor (grown on demand)
+
+
+def gemm_workspace(plan, image_fn, device):
+    """GemmWorkspace for `plan` (a filled _lib.GemmPlan) on the current stream, or None when the kernel needs none.
+    image_fn(host_buffer, nbytes): the library call that writes the plan image into a host buffer."""
+    if plan.image_bytes == 0:
+        return None
+    dev = device.index if device.index is not None else torch.cuda.current_device()
+    key = (dev, int(plan.key))
+    img = _gemm_images.get(key)
+    if img is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("grove_amd: first use of a GEMM shape inside a stream capture — its work-list image has to be uploaded "
+                               "first (run the shape once before capturing; the C-ABI itself is capture-safe with a caller workspace)")
+        n = int(plan.image_bytes)
+        host = torch.empty(n, dtype=torch.uint8)
+        image_fn(C.c_void_p(host.data_ptr()), C.c_size_t(n))
+        img = host.to(device)  # (one synchronous upload per plan key for the life of the process)
+        _gemm_images[key] = img
+    w = _lib.GemmWorkspace()
+    w.image, w.image_bytes = C.c_void_p(img.data_ptr()), img.numel()
+    if plan.scratch_bytes:
+        skey = (dev, torch.cuda.current_stream().cuda_stream)
+        sc = _gemm_scratch.get(skey)
+        if sc is None or sc.numel() < plan.scratch_bytes:
+            if torch.cuda.is_current_stream_capturing():
+                # a capture stream the cache has not seen: a temporary from the graph's private pool. The scratch is live only between
+                # the GEMM launch and its fix-up launch (both inside this call), and the pool re-issues a freed block only to LATER
+                # nodes of the same capture, which run after them — so it is not kept
+                sc = torch.empty(int(plan.scratch_bytes), dtype=torch.uint8, device=device)
+            else:
+                sc = torch.empty(max(int(plan.scratch_bytes), 64 << 20), dtype=torch.uint8, device=device)
+                _gemm_scratch[skey] = sc
+        w.scratch, w.scratch_bytes = C.c_void_p(sc.data_ptr()), sc.numel()
+        w._keep = sc
+    return w
+
+
 def gemm_raw(A, B, Cout, M, N, K, lda, ldb, ldc, *, bias=None, residual=None, ldr=0, aux=None, scale_ptr=None,
              scale_tanh=False, a_idx=None, a_taps=1, c_idx=None, r_idx=None, batch=(1, 1), sA=(0, 0), sB=(0, 0),
              sC=(0, 0), sR=(0, 0), act=ACT_NONE, accumulate=False, alpha=1.0, split_k=0, ld_aux=0, n_map=(0, 0), k_map=(0, 0),
@@ -72,7 +116,12 @@ def gemm_raw(A, B, Cout, M, N, K, lda, ldb, ldc, *, bias=None, residual=None, ld
     p.residual_mul = int(residual_mul)
     p.n_group, p.n_pad = n_map
     p.k_group, p.k_pad = k_map
-    _lib.check(_lib.lib().grove_gemm_bf16(C.byref(p), _stream()), "grove_gemm_bf16")
+    lib = _lib.lib()
+    st = _stream()
+    plan = _lib.GemmPlan()
+    _lib.check(lib.grove_gemm_make_plan(C.byref(p), C.byref(plan)), "grove_gemm_make_plan")
+    w = gemm_workspace(plan, lambda buf, n: _lib.check(lib.grove_gemm_plan_image(C.byref(p), buf, n), "grove_gemm_plan_image"), Cout.device)
+    _lib.check(lib.grove_gemm_bf16(C.byref(p), C.byref(w) if w is not None else None, st), "grove_gemm_bf16")
     return Cout
 
 
@@ -651,7 +700,12 @@ def linear_fp8(x, wq, w_scale, bias=None, *, act=ACT_NONE, residual=None, out=No
     p.M, p.N, p.K, p.lda, p.ldb, p.ldc = M, N, K, aq.stride(0), wq.stride(0), out.stride(0)
     p.ldr = residual.stride(0) if residual is not None else 0
     p.act = act
-    _lib.check(_lib.lib().grove_gemm_fp8(C.byref(p), _stream()), "grove_gemm_fp8")
+    lib = _lib.lib()
+    st = _stream()
+    plan = _lib.GemmPlan()
+    _lib.check(lib.grove_gemm_fp8_make_plan(C.byref(p), C.byref(plan)), "grove_gemm_fp8_make_plan")
+    w = gemm_workspace(plan, lambda buf, n: _lib.check(lib.grove_gemm_fp8_plan_image(C.byref(p), buf, n), "grove_gemm_fp8_plan_image"), out.device)
+    _lib.check(lib.grove_gemm_fp8(C.byref(p), C.byref(w) if w is not None else None, st), "grove_gemm_fp8")
     return out
 
 

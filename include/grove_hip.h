@@ -8,9 +8,15 @@
  * /root/reference) that it replaces, not a reference FFI symbol.
  *
  * Conventions
- *  - plain pointers + sizes only; every buffer is caller-owned device memory (in practice a
- *    torch tensor); the library never allocates, frees or retains pointers across calls.
- *  - all calls are asynchronous on `stream` (a hipStream_t passed as void*), graph-capturable.
+ *  - plain pointers + sizes only; every buffer — inputs, outputs AND workspaces — is caller-owned device memory (in
+ *    practice a torch tensor). The library never allocates or frees device memory (there is no hipMalloc / hipFree /
+ *    hipMemcpy in it) and retains no pointer across calls; the only kernels that need memory beyond their operands are the
+ *    persistent GEMMs, whose work-list image and stream-K scratch the caller supplies (grove_gemm_workspace, below).
+ *  - all calls are asynchronous on `stream` (a hipStream_t passed as void*) and graph-capturable on any stream, first use
+ *    of a shape included (nothing is allocated or copied behind the call).
+ *  - no mutable state shared between threads drives results: the grove_*_set_* switches are process-wide TEST / A-B knobs
+ *    (kernel-selection overrides; every setting computes the same function), never needed by a caller; the
+ *    grove_*_last_* getters are measurement aids of the calling process.
  *  - return 0 on success, negative GROVE_E_* otherwise; grove_last_error() has the text.
  *  - bf16 tensors are raw uint16 storage ("bf16"); accumulation is always fp32.
  */
@@ -102,7 +108,38 @@ typedef struct grove_gemm_params {
    *   residual_mul: the residual operand multiplies the result (v *= residual[row_r(m), n]) instead of being added. */
   int32_t aux_grad, residual_mul;
 } grove_gemm_params;
-int grove_gemm_bf16(const grove_gemm_params* p, void* stream);
+
+/* Workspaces of the persistent GEMMs (`grove_<op>_workspace_bytes` + `workspace, ws_bytes` arguments).
+ * The persistent pipelined kernels (GROVE_GEMM_PP*) walk a host-made WORK LIST (which output tiles / K ranges each of the
+ * resident blocks computes) and, when the last round of tiles is cut into K ranges (stream-K), park the raw fp32 partial
+ * tiles in SCRATCH until the fix-up launch sums them. Both belong to the caller:
+ *   1. grove_gemm_make_plan(p, &plan)                  host only: which kernel the call will run, image_bytes, scratch_bytes, key;
+ *   2. grove_gemm_plan_image(p, host_buf, bytes)  host only: writes the image (work list + fix-up list) into a host buffer;
+ *      the caller uploads it to device memory ONCE per plan.key (read-only afterwards, shareable by all streams, by bf16 and
+ *      fp8 launches, and by every epilogue: the key depends on tile geometry only);
+ *   3. grove_gemm_bf16(p, &ws, stream)            ws.image = that device image, ws.scratch = scratch_bytes of device memory
+ *      that no other launch IN FLIGHT uses (one scratch buffer per stream is enough: launches of a stream are ordered).
+ * A call without an image (ws NULL / image NULL) runs the non-persistent kernels; a problem only the persistent kernel
+ * implements (padded-head maps, SWIGLU_PAIR, fp8 pipelined) then fails with GROVE_E_WORKSPACE. Too small an image / scratch:
+ * GROVE_E_WORKSPACE. grove_gemm_workspace_bytes(p) = image_bytes + scratch_bytes of the plan (0: none needed). */
+typedef struct grove_gemm_workspace {
+  const void* image;   /* device copy of the plan image (16-byte aligned) or NULL */
+  size_t image_bytes;
+  void* scratch;       /* stream-K partial tiles (16-byte aligned) or NULL when the plan's scratch_bytes is 0 */
+  size_t scratch_bytes;
+} grove_gemm_workspace;
+typedef struct grove_gemm_plan {
+  int32_t variant;                 /* enum grove_gemm_variant the call will launch (bf16 entry; 0 for the fp8 entry) */
+  int32_t bm, tiles_m, tiles_n;    /* persistent kernels: tile rows (192 / 256), output tiles */
+  int32_t k_tiles, grid, stream_k; /* K tiles of 64 (128 fp8 codes), resident blocks, K tiles per stream-K part (0 = whole tiles) */
+  int32_t reserved;
+  int64_t image_bytes, scratch_bytes;
+  uint64_t key;                    /* equal keys (on devices with equal CU counts) <=> identical images */
+} grove_gemm_plan;
+int grove_gemm_make_plan(const grove_gemm_params* p, grove_gemm_plan* out);
+int grove_gemm_plan_image(const grove_gemm_params* p, void* host_image, size_t bytes);
+size_t grove_gemm_workspace_bytes(const grove_gemm_params* p);
+int grove_gemm_bf16(const grove_gemm_params* p, const grove_gemm_workspace* ws, void* stream);
 /* Which kernel the last grove_gemm_bf16 call launched (measurement aid: bench.py prices each kernel on its own launches). */
 enum grove_gemm_variant {
   GROVE_GEMM_T128X128 = 1, /* gemm_nt_kernel, 128 x 128 tile */
@@ -118,8 +155,9 @@ int grove_gemm_last_variant(void);
  * -1 = plain (act NONE, alpha 1, no scale), else the enum grove_act value. Meaningless after a non-pipelined launch. */
 int grove_gemm_last_epilogue(void);
 /* Stream-K tail of the pipelined kernels. When the output tiles do not fill a last round of the persistent grid (at most half
- * of the CUs would work), that round's tiles are cut into 2..4 equal K ranges, one block each; the raw fp32 parts go through a
- * per-stream workspace and a fix-up launch sums them in K order and runs the epilogue (deterministic). mode 1 (default) =
+ * of the CUs would work), that round's tiles are cut into 2..4 equal K ranges, one block each; the raw fp32 parts go through the
+ * caller's scratch (grove_gemm_workspace) and a fix-up launch sums them in K order and runs the epilogue (deterministic). TEST / A-B
+ * knob, like every grove_*_set_*: plan, image and launch must run under the same setting. mode 1 (default) =
  * where the cost model says it pays, 0 = never (whole tiles only), 2 = wherever it applies (tests).
  * grove_gemm_last_stream_k: K tiles per part of the last pipelined launch, 0 = it ran whole tiles only. */
 int grove_gemm_set_stream_k(int mode);
@@ -558,7 +596,11 @@ typedef struct grove_gemm_fp8_params {
   const void* residual;    /* bf16 [M, ldr] or NULL */
   int32_t M, N, K, lda, ldb, ldc, ldr, act;
 } grove_gemm_fp8_params;
-int grove_gemm_fp8(const grove_gemm_fp8_params* p, void* stream);
+/* workspace protocol as grove_gemm_bf16 (the FP8 instances of the persistent kernel share its images: equal plan keys, equal bytes);
+ * without an image the two-barrier kernel of gemm_fp8.hip runs (no workspace) */
+int grove_gemm_fp8_make_plan(const grove_gemm_fp8_params* p, grove_gemm_plan* out);
+int grove_gemm_fp8_plan_image(const grove_gemm_fp8_params* p, void* host_image, size_t bytes);
+int grove_gemm_fp8(const grove_gemm_fp8_params* p, const grove_gemm_workspace* ws, void* stream);
 /* 1 (default): problems that fit them (K % 128 == 0, N % 8 == 0, 16-byte aligned operands, act NONE / QUICKGELU) run on the FP8
  * instances of the persistent pipelined kernel; 0: always the two-barrier kernel (A/B arm of tests and tools) */
 int grove_gemm_fp8_set_pipelined(int on);

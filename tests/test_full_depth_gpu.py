@@ -285,11 +285,12 @@ def test_full_depth_box_l1_over_seeds(dev):
 
 
 # measured x 1.5 ("the assert at 1.5x measured, not 2x"); the figures and the precision-policy table are in DESIGN.md section 8
-FP8_BOUNDS = {"deep_narrow": {"box_l1": 1.5e-2, "hidden_rms": 0.15}, "full": {"box_l1": 1.5e-2, "hidden_rms": 0.15}}
+FP8_BOUNDS = {("deep_narrow", "all"): {"box_l1": 1.6e-2, "hidden_rms": 0.15}, ("deep_narrow", "det16_kv16"): {"box_l1": 1.6e-2, "hidden_rms": 0.15},
+              ("full", "det16_kv16"): {"box_l1": 2.5e-2, "hidden_rms": 0.19}}
 
 
-@pytest.mark.parametrize("which", ["deep_narrow", "full"])
-def test_full_depth_fp8_inference_vs_fp32_oracle(dev, which):
+@pytest.mark.parametrize("which,policy", [("deep_narrow", "all"), ("deep_narrow", "det16_kv16"), ("full", "det16_kv16")])
+def test_full_depth_fp8_inference_vs_fp32_oracle(dev, which, policy):
     """BASELINE config 5's arithmetic at full depth: `gemm_dtype="fp8"` (every CLIP / LLaMA linear layer with K % 128 == 0 on the e4m3
     MFMA GEMM) against the fp32 oracle. e4m3 keeps 3 mantissa bits: ~3.6 % rms rounding per operand, ~5 % per GEMM output on any data
     whose blocks are not dominated by outliers — scaling granularity does not change that (tools/fp8_policy_study.py: per-32 block
@@ -300,8 +301,9 @@ def test_full_depth_fp8_inference_vs_fp32_oracle(dev, which):
     from oracle import grove_oracle as O
     d = FULL if which == "full" else deep_narrow_dims()
     sd_dev = synthetic_state_dict(d, device=dev, dtype=bf)
-    model = GROVEForCausalLM(dims=d, device=dev, state_dict=sd_dev, det_token_idx=d.det_token_idx, num_frames=8, pe_dtype=torch.float32, gemm_dtype="fp8")
-    n_q = sum(1 for L in model.llama.layers for k in L if k.endswith("_q"))
+    model = GROVEForCausalLM(dims=d, device=dev, state_dict=sd_dev, det_token_idx=d.det_token_idx, num_frames=8, pe_dtype=torch.float32, gemm_dtype="fp8",
+                             fp8_policy=policy)
+    n_q = sum(1 for L in model.llama.layers for k in ("wqkv_q", "wo_q", "wgu_q", "wd_q") if k in L)
     del sd_dev
     torch.cuda.empty_cache()
     batch = synthetic_batch(d, B=1, T=8, L=128, n_det=3, seed=11)
@@ -326,13 +328,13 @@ def test_full_depth_fp8_inference_vs_fp32_oracle(dev, which):
         _, _, box_o, obj_o = O.decode_boxes(sd, d, pemb, emb_o, kw["original_size_list"], O.dense_pe(sd, d), True)
     res = {"config": ("FULL dims" if which == "full" else "full depth at quarter width") + ", gemm_dtype=fp8 (CLIP + LLaMA linear layers, e4m3, per-row / "
            "per-output-channel scales), B=1, T=8, L=128, n_det=3, inference forward vs fp32 oracle",
-           "llama_projections_quantised": n_q, "box_l1_vs_oracle": (out["flat_boxes"].cpu() - box_o).abs().mean().item(),
+           "fp8_policy": policy, "llama_projections_quantised": n_q, "box_l1_vs_oracle": (out["flat_boxes"].cpu() - box_o).abs().mean().item(),
            "box_l1_max": (out["flat_boxes"].cpu() - box_o).abs().max().item(),
            "objectness_logit_abs_err": (out["flat_logits"].cpu() - obj_o).abs().max().item(),
            "llama_hidden_rel_rms": rel_rms(out["hidden"], hidden_o), "projected_features_rel_rms": rel_rms(feats_h, feats_o),
-           "bounds": FP8_BOUNDS[which]}
-    with open(os.path.join(ROOT, "gpurun_out", f"full_depth_fp8_parity_{which}.json"), "w") as fh:
+           "bounds": FP8_BOUNDS[(which, policy)]}
+    with open(os.path.join(ROOT, "gpurun_out", f"full_depth_fp8_parity_{which}_{policy}.json"), "w") as fh:
         json.dump(res, fh, indent=1)
     print(json.dumps(res))
     assert n_q > 0
-    assert res["box_l1_vs_oracle"] <= FP8_BOUNDS[which]["box_l1"] and res["llama_hidden_rel_rms"] <= FP8_BOUNDS[which]["hidden_rms"], res
+    assert res["box_l1_vs_oracle"] <= FP8_BOUNDS[(which, policy)]["box_l1"] and res["llama_hidden_rel_rms"] <= FP8_BOUNDS[(which, policy)]["hidden_rms"], res
