@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-FP8_BOX_L1_BOUND = 1.5e-2  # e4m3's own figure on the tiny case (1.03e-2 measured and predicted, tools/fp8_policy_study.py) x 1.5
+FP8_BOX_L1_BOUND = 9.5e-3  # e4m3's own figure on the tiny case (policy det16_kv16: 6.3e-3 measured, 6.1e-3 predicted by tools/fp8_policy_study.py) x 1.5
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak of MI355X (MI355X_MICROARCH.md, chip-level parameters)
 
 

@@ -1467,7 +1467,7 @@ static int gemm_bf16_dispatch(const grove_gemm_params* pp, void* stream) {
   const bool maps = p.n_group || p.k_group;
   const bool have_ws = t_call.mode != 0 || t_call.image != nullptr;  // no work-list image given: only the non-persistent kernels can run
   const bool p256_ok = have_ws && g_gemm_glds && bk64 && (!p.a_idx || (long)p.a_taps * p.M >= 8) && bt == 1 && p.split_k <= 1 && !p.accumulate && wide_ok && p.N % 8 == 0 && pp_act;
-  // Tile choice by a measured cost model (tools/bench_gemm_tiles.py, microseconds): time = rounds of resident blocks x
+  // Tile choice by a measured cost model (tools/bench_gemm.py tiles, microseconds): time = rounds of resident blocks x
   // (K tiles x per-K-tile time + fixed per-tile time). The 128- and 192-row kernels keep 2 blocks per CU (512 slots; a
   // lone block of a partial round still takes a full round); the pipelined kernels are persistent, one block per CU,
   // and a partly filled chip runs each block faster (L2, clocks).

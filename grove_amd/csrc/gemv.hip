@@ -160,27 +160,49 @@ extern "C" int grove_gemv_bf16(const grove_gemv_params* pp, void* stream) {
 
 // ----------------------------------------------------------------------------------------------------------------------
 // Fused decode attention: RoPE(q, k) + cache append + one-query attention. One block per (sequence, head).
-// Scores: the hd/8 lanes of a group cover one key row (16 B each, contiguous), 16 rows per pass, 4 passes in flight; the partial
-// dot products are summed across the group's lanes. Values: the same lane map; the 16 partial sums are reduced through LDS.
-// HBM-bound on the cache read (2 * S * H * hd * 2 B per layer per sequence).
+// HBM-bound on the cache read (2 * S * H * hd * 2 B per layer per sequence) — and, with one block per head, LATENCY-bound: a CU
+// streams what it keeps in flight per memory round trip. Round 3: DA_U = 16 rows in flight per lane (64 KB per block per trip
+// instead of 16 KB: the 650-key cache of a head is three trips instead of eleven), the first trip of key rows issued BEFORE the
+// position is known (rows below S_max are allocated and zero beyond the sequence, so the speculative read is safe and simply
+// masked), the first trip of value rows issued before the softmax reductions, and the new token's own key / value taken from
+// LDS instead of being read back from the cache row the kernel has just written (no fence between the append and the reads:
+// the cached rows 0..t-1 do not depend on it).
+// Scores: the hd/8 lanes of a group cover one key row (16 B each, contiguous), 256 / (hd/8) rows per pass; the partial dot
+// products are summed across the group's lanes. Values: the same lane map; the partial sums are reduced through LDS.
 // ----------------------------------------------------------------------------------------------------------------------
 namespace {
 constexpr int DA_THREADS = 256;
 constexpr int DA_MAXS = 4096;  // scores kept in LDS
+constexpr int DA_U = 16;       // cache rows in flight per lane
 
 template <int HD>
 __global__ __launch_bounds__(DA_THREADS) void decode_attn_kernel(const grove_decode_attn_params p) {
   __shared__ float q_s[HD];
+  __shared__ float kn_s[HD];   // the new token's rotated key / value (fp32 of the bf16 values the cache row holds)
+  __shared__ float vn_s[HD];
   __shared__ float sc[DA_MAXS];
   __shared__ float red[DA_THREADS / 64];
   __shared__ float part[16][HD + 1];
   const int tid = threadIdx.x;
   const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
-  const int t = p.pos[b];  // the new token's position; keys 0..t are visible
   const int HH = p.H * HD;
   bf16_raw* qkv = (bf16_raw*)p.qkv + (int64_t)b * p.ld_qkv;
   bf16_raw* kc = (bf16_raw*)p.cache + ((int64_t)b * p.S_max) * 2 * HH + h * HD;  // key row j at kc + j * 2HH; value at + HH
-  // rotate q (-> LDS, fp32 of the bf16-rounded value, as the unfused path stores it) and k (-> cache), copy v
+  constexpr int CPR = HD / 8;           // 16-byte chunks per row
+  constexpr int G = DA_THREADS / CPR;   // rows per pass (16 for hd 128, 32 for hd 64)
+  const int g = tid / CPR, c = tid - g * CPR;
+  const bf16_raw* kbase = kc + c * 8;
+  const bf16_raw* vbase = kc + HH + c * 8;
+  const u32x4_t zero4 = u32x4_t{0u, 0u, 0u, 0u};
+  // trip 0 of the key rows, before anything else (speculative: masked by the position below)
+  u32x4_t kv[DA_U];
+#pragma unroll
+  for (int u = 0; u < DA_U; ++u) {
+    const int j = g + u * G;
+    kv[u] = j < p.S_max ? *(const u32x4_t*)(kbase + (int64_t)j * 2 * HH) : zero4;
+  }
+  const int t = p.pos[b];  // the new token's position; cached keys 0..t-1 + the new one are visible
+  // rotate q (-> LDS, fp32 of the bf16-rounded value, as the unfused path stores it) and k (-> cache + LDS), copy v
   if (tid < HD / 2) {
     const float inv_freq = powf(p.theta, -2.f * (float)tid / (float)HD);
     float sn, cs;
@@ -191,51 +213,72 @@ __global__ __launch_bounds__(DA_THREADS) void decode_attn_kernel(const grove_dec
     q_s[tid + HD / 2] = bf2f(f2bf(q2 * cs + q1 * sn));
     const bf16_raw* k = qkv + HH + h * HD;
     const float k1 = bf2f(k[tid]), k2 = bf2f(k[tid + HD / 2]);
-    kc[(int64_t)t * 2 * HH + tid] = f2bf(k1 * cs - k2 * sn);
-    kc[(int64_t)t * 2 * HH + tid + HD / 2] = f2bf(k2 * cs + k1 * sn);
+    const bf16_raw r1 = f2bf(k1 * cs - k2 * sn), r2 = f2bf(k2 * cs + k1 * sn);
+    kc[(int64_t)t * 2 * HH + tid] = r1;
+    kc[(int64_t)t * 2 * HH + tid + HD / 2] = r2;
+    kn_s[tid] = bf2f(r1);
+    kn_s[tid + HD / 2] = bf2f(r2);
   } else if (tid < HD / 2 + HD / 8) {
-    const int c = tid - HD / 2;
-    *(u32x4_t*)(kc + (int64_t)t * 2 * HH + HH + c * 8) = *(const u32x4_t*)(qkv + 2 * HH + h * HD + c * 8);
+    const int cc = tid - HD / 2;
+    const u32x4_t vv = *(const u32x4_t*)(qkv + 2 * HH + h * HD + cc * 8);
+    *(u32x4_t*)(kc + (int64_t)t * 2 * HH + HH + cc * 8) = vv;
+    const float f[8] = {bf_lo(vv.x), bf_hi(vv.x), bf_lo(vv.y), bf_hi(vv.y), bf_lo(vv.z), bf_hi(vv.z), bf_lo(vv.w), bf_hi(vv.w)};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) vn_s[cc * 8 + e] = f[e];
   }
-  __syncthreads();  // block-wide visibility of the appended row (same block reads it back below)
-  __threadfence_block();
-  const int Lk = t + 1;
-  constexpr int CPR = HD / 8;           // 16-byte chunks per row
-  constexpr int G = DA_THREADS / CPR;   // rows per pass (16 for hd 128, 32 for hd 64)
-  const int g = tid / CPR, c = tid - g * CPR;
+  __syncthreads();
   float mx = -INFINITY;
-  {
-    // the CPR lanes of a group read one key row (contiguous 16-byte pieces), each against its 8 q values; 4 rows in flight per lane
-    float qv[8];
+  float qv[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) qv[e] = q_s[c * 8 + e];
-    const bf16_raw* kbase = kc + c * 8;
-    auto dot8 = [&](const u32x4_t kv) {
-      float s = bf_lo(kv.x) * qv[0];
-      s = fmaf(bf_hi(kv.x), qv[1], s);
-      s = fmaf(bf_lo(kv.y), qv[2], s); s = fmaf(bf_hi(kv.y), qv[3], s);
-      s = fmaf(bf_lo(kv.z), qv[4], s); s = fmaf(bf_hi(kv.z), qv[5], s);
-      s = fmaf(bf_lo(kv.w), qv[6], s); s = fmaf(bf_hi(kv.w), qv[7], s);
-      return s;
-    };
-    auto finish = [&](float s, int j) {  // sum over the group's lanes (CPR = 4, 8 or 16 consecutive lanes)
+  for (int e = 0; e < 8; ++e) qv[e] = q_s[c * 8 + e];
+  auto dot8 = [&](const u32x4_t k4) {
+    float s = bf_lo(k4.x) * qv[0];
+    s = fmaf(bf_hi(k4.x), qv[1], s);
+    s = fmaf(bf_lo(k4.y), qv[2], s); s = fmaf(bf_hi(k4.y), qv[3], s);
+    s = fmaf(bf_lo(k4.z), qv[4], s); s = fmaf(bf_hi(k4.z), qv[5], s);
+    s = fmaf(bf_lo(k4.w), qv[6], s); s = fmaf(bf_hi(k4.w), qv[7], s);
+    return s;
+  };
+  auto group_sum = [&](float s) {  // sum over the group's lanes (CPR = 4, 8 or 16 consecutive lanes)
 #pragma unroll
-      for (int off = CPR / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-      s *= p.alpha;
-      if (c == 0) sc[j] = s;
-      mx = fmaxf(mx, s);
-    };
-    int j = g;
-    for (; j + 3 * G < Lk; j += 4 * G) {
-      u32x4_t kv[4];
+    for (int off = CPR / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    return s;
+  };
+  for (int j0 = 0; j0 < t; j0 += G * DA_U) {
+    if (j0 > 0) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) kv[u] = *(const u32x4_t*)(kbase + (int64_t)(j + u * G) * 2 * HH);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) finish(dot8(kv[u]), j + u * G);
+      for (int u = 0; u < DA_U; ++u) {
+        const int j = min(j0 + g + u * G, t - 1);  // (clamped: an address inside the sequence; the row is masked below)
+        kv[u] = *(const u32x4_t*)(kbase + (int64_t)j * 2 * HH);
+      }
     }
-    for (; j < Lk; j += G) finish(dot8(*(const u32x4_t*)(kbase + (int64_t)j * 2 * HH)), j);
+#pragma unroll
+    for (int u = 0; u < DA_U; ++u) {
+      const int j = j0 + g + u * G;
+      const float s = group_sum(dot8(kv[u])) * p.alpha;
+      if (j < t) {
+        if (c == 0) sc[j] = s;
+        mx = fmaxf(mx, s);
+      }
+    }
+  }
+  // trip 0 of the value rows goes out now: the softmax reductions below run under its latency
+  u32x4_t vv[DA_U];
+#pragma unroll
+  for (int u = 0; u < DA_U; ++u) {
+    const int j = min(g + u * G, max(t - 1, 0));
+    vv[u] = *(const u32x4_t*)(vbase + (int64_t)j * 2 * HH);
+  }
+  if (g == 0) {  // the new token itself, from LDS
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s = fmaf(kn_s[c * 8 + e], qv[e], s);
+    s = group_sum(s) * p.alpha;
+    if (c == 0) sc[t] = s;
+    mx = fmaxf(mx, s);
   }
   mx = block_max<DA_THREADS>(mx, red);
+  const int Lk = t + 1;
   float sum = 0.f;
   for (int j = tid; j < Lk; j += DA_THREADS) {
     const float e = __expf(sc[j] - mx);
@@ -244,24 +287,33 @@ __global__ __launch_bounds__(DA_THREADS) void decode_attn_kernel(const grove_dec
   }
   sum = block_sum<DA_THREADS>(sum, red);  // (its barriers also publish sc[])
   const float inv = 1.f / sum;
-  // o[d] = sum_j p_j v_j[d]: lane group g = tid / (HD/8) takes rows j = g, g + G, ...; chunk c = tid % (HD/8)
+  // o[d] = sum_j p_j v_j[d]: lane group g takes rows j = g, g + G, ...; chunk c = tid % (HD/8)
   float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  auto pv = [&](float pj, const u32x4_t vv) {
-    o[0] = fmaf(pj, bf_lo(vv.x), o[0]); o[1] = fmaf(pj, bf_hi(vv.x), o[1]);
-    o[2] = fmaf(pj, bf_lo(vv.y), o[2]); o[3] = fmaf(pj, bf_hi(vv.y), o[3]);
-    o[4] = fmaf(pj, bf_lo(vv.z), o[4]); o[5] = fmaf(pj, bf_hi(vv.z), o[5]);
-    o[6] = fmaf(pj, bf_lo(vv.w), o[6]); o[7] = fmaf(pj, bf_hi(vv.w), o[7]);
+  auto pv = [&](float pj, const u32x4_t v4) {
+    o[0] = fmaf(pj, bf_lo(v4.x), o[0]); o[1] = fmaf(pj, bf_hi(v4.x), o[1]);
+    o[2] = fmaf(pj, bf_lo(v4.y), o[2]); o[3] = fmaf(pj, bf_hi(v4.y), o[3]);
+    o[4] = fmaf(pj, bf_lo(v4.z), o[4]); o[5] = fmaf(pj, bf_hi(v4.z), o[5]);
+    o[6] = fmaf(pj, bf_lo(v4.w), o[6]); o[7] = fmaf(pj, bf_hi(v4.w), o[7]);
   };
-  const bf16_raw* vbase = kc + HH + c * 8;
-  int j = g;
-  for (; j + 7 * G < Lk; j += 8 * G) {  // 8 value rows in flight per lane
-    u32x4_t vv[8];
+  for (int j0 = 0; j0 < t; j0 += G * DA_U) {
+    if (j0 > 0) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) vv[u] = *(const u32x4_t*)(vbase + (int64_t)(j + u * G) * 2 * HH);
+      for (int u = 0; u < DA_U; ++u) {
+        const int j = min(j0 + g + u * G, t - 1);
+        vv[u] = *(const u32x4_t*)(vbase + (int64_t)j * 2 * HH);
+      }
+    }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) pv(sc[j + u * G], vv[u]);
+    for (int u = 0; u < DA_U; ++u) {
+      const int j = j0 + g + u * G;
+      pv(j < t ? sc[j] : 0.f, vv[u]);
+    }
   }
-  for (; j < Lk; j += G) pv(sc[j], *(const u32x4_t*)(vbase + (int64_t)j * 2 * HH));
+  if (g == 0) {  // the new token's value, from LDS
+    const float pj = sc[t];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = fmaf(pj, vn_s[c * 8 + e], o[e]);
+  }
   // reduce the G row groups, 16 at a time, through the LDS scratch
   for (int base = 0; base < G; base += 16) {
     __syncthreads();

@@ -285,8 +285,10 @@ def test_full_depth_box_l1_over_seeds(dev):
 
 
 # measured x 1.5 ("the assert at 1.5x measured, not 2x"); the figures and the precision-policy table are in DESIGN.md section 8
-FP8_BOUNDS = {("deep_narrow", "all"): {"box_l1": 1.6e-2, "hidden_rms": 0.15}, ("deep_narrow", "det16_kv16"): {"box_l1": 1.6e-2, "hidden_rms": 0.15},
-              ("full", "det16_kv16"): {"box_l1": 2.5e-2, "hidden_rms": 0.19}}
+# measured (profiles/r03_full_depth_fp8_parity_*.json): deep_narrow all 1.06e-2 / 9.6 %, deep_narrow det16_kv16 6.5e-3 / 8.7 %,
+# full det16_kv16 1.29e-2 / 11.4 % (full "all": 1.65e-2 / 12.2 %, profiles/r03_full_depth_fp8_parity_full_all8.json)
+FP8_BOUNDS = {("deep_narrow", "all"): {"box_l1": 1.6e-2, "hidden_rms": 0.145}, ("deep_narrow", "det16_kv16"): {"box_l1": 1.0e-2, "hidden_rms": 0.13},
+              ("full", "det16_kv16"): {"box_l1": 1.95e-2, "hidden_rms": 0.17}}
 
 
 @pytest.mark.parametrize("which,policy", [("deep_narrow", "all"), ("deep_narrow", "det16_kv16"), ("full", "det16_kv16")])

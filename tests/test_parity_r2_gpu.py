@@ -395,10 +395,12 @@ def test_mask_branch_matches_oracle_and_reference_golden(dev):
 
 # ---------------------------------------------------------------------------------------------- fp8 ViT + LLaMA path (config 5)
 def test_fp8_vit_llama_path_vs_oracle_and_bf16(dev):
-    """gemm_dtype="fp8": every linear layer of the CLIP tower and the LLaMA stack on the e4m3 MFMA GEMM (per-output-channel weight
+    """gemm_dtype="fp8": the linear layers of the CLIP tower and the LLaMA stack on the e4m3 MFMA GEMM (per-output-channel weight
     scales, per-row activation scales), everything else unchanged. e4m3 carries 3 mantissa bits (2^-4 relative rounding per element),
-    so the bounds are the quantisation's, not bf16's — measured on this case: projected features 7.4 % rms and LLaMA hidden state
-    9.4 % rms from the fp32 oracle (bf16: < 1 %), boxes 1.1e-2 L1 (bf16 model: 2.8e-4). The asserts hold those figures with margin."""
+    so the bounds are the quantisation's, not bf16's, at 1.5x the measured figures. Measured on this case:
+      policy "all" (round 2: everything e4m3)            projected features 7.4 % rms, hidden 9.3 % rms, boxes 1.03e-2 L1
+      policy "det16_kv16" (default: k/v + [DET] rows bf16)  hidden 8.7 % rms, boxes 6.3e-3 L1          (bf16 model: 2.8e-4)
+    tools/fp8_policy_study.py predicts both from a fake-quantised oracle on the CPU (1.03e-2 / 6.1e-3); DESIGN section 8 has the table."""
     import dataclasses
     from grove_amd import GROVEForCausalLM
     from grove_amd.synthetic import TINY, synthetic_batch, synthetic_state_dict
@@ -407,6 +409,9 @@ def test_fp8_vit_llama_path_vs_oracle_and_bf16(dev):
     sd = synthetic_state_dict(d)
     sd_r = {k: v.to(bf).float() for k, v in sd.items()}
     m8 = GROVEForCausalLM(dims=d, device=dev, state_dict=sd, det_token_idx=d.det_token_idx, num_frames=8, pe_dtype=torch.float32, gemm_dtype="fp8")
+    m8a = GROVEForCausalLM(dims=d, device=dev, state_dict=sd, det_token_idx=d.det_token_idx, num_frames=8, pe_dtype=torch.float32, gemm_dtype="fp8",
+                           fp8_policy="all")
+    assert m8.fp8_policy == "det16_kv16" and all("wq_q" in L and "wkv" in L for L in m8.llama.layers) and not any("wq_q" in L for L in m8a.llama.layers)
     m16 = GROVEForCausalLM(dims=d, device=dev, state_dict=sd, det_token_idx=d.det_token_idx, num_frames=8, pe_dtype=torch.float32)
     assert all("wqkv_q" in L and "wd_q" in L for L in m8.llama.layers) and all("w1_q" in L for L in m8.clip.layers)
     with pytest.raises(ValueError):
@@ -414,7 +419,7 @@ def test_fp8_vit_llama_path_vs_oracle_and_bf16(dev):
     batch = synthetic_batch(d, B=2, T=8, L=40, n_det=3, seed=2)
     kw = to_dev(batch, dev)
     kw["inference"] = True
-    o8, o16 = m8(**kw), m16(**kw)
+    o8, o8a, o16 = m8(**kw), m8a(**kw), m16(**kw)
     kwo = batch.as_kwargs(inference=True)
     kwo["global_enc_images"], kwo["grounding_enc_images"] = kwo["global_enc_images"].to(bf).float(), kwo["grounding_enc_images"].to(bf).float()
     with torch.no_grad():
@@ -428,10 +433,14 @@ def test_fp8_vit_llama_path_vs_oracle_and_bf16(dev):
     e_feat, e_hid = rms(feats8, feats_o), rms(o8["hidden"], ref["hidden"])
     l1_8 = (o8["flat_boxes"].cpu() - ref["flat_boxes"]).abs().mean().item()
     l1_16 = (o16["flat_boxes"].cpu() - ref["flat_boxes"]).abs().mean().item()
-    print(f"fp8: projected features rms {e_feat:.3e}, llama hidden rms {e_hid:.3e}, box L1 {l1_8:.3e} (bf16 model {l1_16:.3e})")
-    assert 1e-3 < e_feat < 0.12 and 1e-3 < e_hid < 0.15, (e_feat, e_hid)   # really quantised, and within the fp8 budget
-    assert l1_16 < 1e-3 and l1_8 < 2e-2, (l1_16, l1_8)
-    assert (o8["flat_logits"].cpu() - ref["flat_logits"]).abs().max().item() < 0.5
+    l1_8a = (o8a["flat_boxes"].cpu() - ref["flat_boxes"]).abs().mean().item()
+    obj8 = (o8["flat_logits"].cpu() - ref["flat_logits"]).abs().max().item()
+    print(f"fp8: projected features rms {e_feat:.3e}, llama hidden rms {e_hid:.3e}, box L1 {l1_8:.3e} (policy all {l1_8a:.3e}, bf16 model {l1_16:.3e}), "
+          f"objectness {obj8:.3e}")
+    assert 1e-3 < e_feat < 0.11 and 1e-3 < e_hid < 0.13, (e_feat, e_hid)   # really quantised, and within the fp8 budget
+    assert l1_16 < 1e-3 and l1_8 < 9.5e-3 and l1_8a < 1.55e-2, (l1_16, l1_8, l1_8a)  # 1.5 x (6.3e-3, 1.03e-2)
+    assert l1_8 < l1_8a, "keeping k/v and the [DET] rows in bf16 must not make the boxes worse"
+    assert obj8 < 0.2
 
 
 def test_T32_inference_windows_and_masks(dev):
