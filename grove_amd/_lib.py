@@ -122,7 +122,7 @@ class GemvParams(C.Structure):
 
 class DecodeAttnParams(C.Structure):
     _fields_ = [("qkv", c_vp), ("cache", c_vp), ("out", c_vp), ("pos", c_vp), ("B", c_i32), ("H", c_i32), ("hd", c_i32),
-                ("S_max", c_i32), ("ld_qkv", c_i32), ("theta", c_f32), ("alpha", c_f32)]
+                ("S_max", c_i32), ("ld_qkv", c_i32), ("theta", c_f32), ("alpha", c_f32), ("partial", c_vp), ("n_split", c_i32)]
 
 
 class ResampleParams(C.Structure):

@@ -19,6 +19,22 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_kernel(const grove_gemv_param
   const int K = p.K;
   const bf16_raw* __restrict__ X = (const bf16_raw*)p.x;
   __shared__ float red[GV_THREADS / 64];
+  // The weight stream starts BEFORE the x prologue (round 3): the first trip of this wave's rows (4 chunks x GV_RW rows = 16 / 8
+  // loads of 16 B per lane) does not depend on x, and the prologue — x into LDS, the folded RMSNorm's block reduction or the SwiGLU —
+  // is 2-3 us during which the HBM pipe of this CU would otherwise sit idle (129 such kernels per generated token).
+  const int n0 = (blockIdx.x * (GV_THREADS / 64) + wave) * GV_RW;
+  const bf16_raw* __restrict__ W = (const bf16_raw*)p.W;
+  const bf16_raw* wrow[GV_RW];
+#pragma unroll
+  for (int r = 0; r < GV_RW; ++r) wrow[r] = W + (int64_t)min(n0 + r, p.N - 1) * p.ldw;
+  const bool prefetched = K >= 2048;
+  u32x4_t pre[4][GV_RW];
+  if (prefetched) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int r = 0; r < GV_RW; ++r) pre[q][r] = __builtin_nontemporal_load((const u32x4_t*)(wrow[r] + lane * 8 + q * 512));
+  }
   if (p.x_mode == GROVE_GEMV_X_SWIGLU) {
     // x' = silu(gate) * up of a fused [M, 2K] gate|up row (HF LlamaMLP), rounded to bf16 like grove_swiglu_fwd
     for (int c = tid; c < MX * (K >> 3); c += GV_THREADS) {
@@ -54,22 +70,14 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_kernel(const grove_gemv_param
       }
     }
   }
-  const int n0 = (blockIdx.x * (GV_THREADS / 64) + wave) * GV_RW;
   if (n0 >= p.N) return;
-  const bf16_raw* __restrict__ W = (const bf16_raw*)p.W;
-  const bf16_raw* wrow[GV_RW];
-#pragma unroll
-  for (int r = 0; r < GV_RW; ++r) wrow[r] = W + (int64_t)min(n0 + r, p.N - 1) * p.ldw;
   float acc[GV_RW][MX];
 #pragma unroll
   for (int r = 0; r < GV_RW; ++r)
 #pragma unroll
     for (int b = 0; b < MX; ++b) acc[r][b] = 0.f;
 
-  auto step = [&](int k) {  // k: this lane's chunk start
-    u32x4_t wv[GV_RW];
-#pragma unroll
-    for (int r = 0; r < GV_RW; ++r) wv[r] = __builtin_nontemporal_load((const u32x4_t*)(wrow[r] + k));
+  auto mac = [&](const u32x4_t (&wv)[GV_RW], int k) {  // k: this lane's chunk start
 #pragma unroll
     for (int b = 0; b < MX; ++b) {
       const u32x4_t xv = *(const u32x4_t*)(xs + b * K + k);
@@ -86,7 +94,18 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_kernel(const grove_gemv_param
       }
     }
   };
+  auto step = [&](int k) {
+    u32x4_t wv[GV_RW];
+#pragma unroll
+    for (int r = 0; r < GV_RW; ++r) wv[r] = __builtin_nontemporal_load((const u32x4_t*)(wrow[r] + k));
+    mac(wv, k);
+  };
   int k = lane * 8;
+  if (prefetched) {  // the trip that was issued before the prologue
+#pragma unroll
+    for (int q = 0; q < 4; ++q) mac(pre[q], k + q * 512);
+    k += 2048;
+  }
   for (; k + 1536 < K; k += 2048) {  // four chunks per trip: 4 * GV_RW 16-byte loads in flight per lane
     step(k);
     step(k + 512);
@@ -99,6 +118,36 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_kernel(const grove_gemv_param
   for (int r = 0; r < GV_RW; ++r)
 #pragma unroll
     for (int b = 0; b < MX; ++b) acc[r][b] = wave_sum(acc[r][b]);
+  if (p.act == GROVE_ACT_SWIGLU_PAIR) {
+    // W rows interleaved [4 gate, 4 up] per 8 (ops.swiglu_interleave; GV_RW = 4): wave 2i holds gate rows, wave 2i + 1 the matching up
+    // rows. The pair meets in LDS and the even wave writes silu(gate) * up — HF LlamaMLP's activation — as N / 2 outputs, rounded
+    // through bf16 exactly like grove_swiglu_fwd, so the down projection's GEMV reads its input as is (its 512 blocks no longer
+    // each recompute the SwiGLU of all 11008 elements in their prologue).
+    __shared__ float pair_s[GV_THREADS / 64][GV_RW][MX];
+    if (lane == 0) {
+#pragma unroll
+      for (int r = 0; r < GV_RW; ++r)
+#pragma unroll
+        for (int b = 0; b < MX; ++b) pair_s[wave][r][b] = acc[r][b];
+    }
+    __syncthreads();
+    if (lane == 0 && (wave & 1) == 0) {
+#pragma unroll
+      for (int r = 0; r < GV_RW; ++r) {
+        const int n = n0 + r;          // a gate row of the interleaved matrix: rows 8q .. 8q + 3 -> output column 4q + r
+        if (n >= p.N) continue;
+        const int col = (n >> 3) * 4 + (n & 3);
+#pragma unroll
+        for (int b = 0; b < MX; ++b) {
+          const float gt = bf2f(f2bf(pair_s[wave][r][b])), up = bf2f(f2bf(pair_s[wave + 1][r][b]));
+          const float v = gt * fast_sigmoid(gt) * up;
+          if (p.y_dtype == GROVE_BF16) ((bf16_raw*)p.y)[(int64_t)b * p.ldy + col] = f2bf(v);
+          else ((float*)p.y)[(int64_t)b * p.ldy + col] = v;
+        }
+      }
+    }
+    return;
+  }
   if (lane == 0) {
     const bf16_raw* bias = (const bf16_raw*)p.bias;
 #pragma unroll
@@ -134,6 +183,7 @@ int launch_gemv_rw(const grove_gemv_params& p, hipStream_t s) {
 template <int MX>
 int launch_gemv(const grove_gemv_params& p, hipStream_t s) {
   // 4 rows per wave amortise the x reads; below ~3 blocks per CU take 2 rows per wave for more loads in flight
+  if (p.act == GROVE_ACT_SWIGLU_PAIR) return launch_gemv_rw<MX, 4>(p, s);  // (the pairing is laid out for 4 rows per wave)
   return p.N >= 12288 ? launch_gemv_rw<MX, 4>(p, s) : launch_gemv_rw<MX, 2>(p, s);
 }
 }  // namespace
@@ -149,6 +199,8 @@ extern "C" int grove_gemv_bf16(const grove_gemv_params* pp, void* stream) {
   GROVE_CHECK(p.y_dtype == GROVE_BF16 || p.y_dtype == GROVE_F32, GROVE_E_DTYPE, "gemv: bad y_dtype %d", p.y_dtype);
   GROVE_CHECK(p.x_mode >= GROVE_GEMV_X_PLAIN && p.x_mode <= GROVE_GEMV_X_SWIGLU, GROVE_E_SHAPE, "gemv: bad x_mode %d", p.x_mode);
   GROVE_CHECK(p.x_mode != GROVE_GEMV_X_RMSNORM || p.norm_weight, GROVE_E_SHAPE, "gemv: x_mode rmsnorm needs norm_weight");
+  GROVE_CHECK(p.act != GROVE_ACT_SWIGLU_PAIR || (p.N % 16 == 0 && !p.bias && !p.residual), GROVE_E_SHAPE,
+              "gemv: act SWIGLU_PAIR needs N %% 16 == 0 (whole wave pairs), no bias, no residual");
   hipStream_t s = (hipStream_t)stream;
   switch (p.M) {
     case 1: return launch_gemv<1>(p, s);
@@ -173,36 +225,49 @@ extern "C" int grove_gemv_bf16(const grove_gemv_params* pp, void* stream) {
 namespace {
 constexpr int DA_THREADS = 256;
 constexpr int DA_MAXS = 4096;  // scores kept in LDS
-constexpr int DA_U = 16;       // cache rows in flight per lane
+constexpr int DA_U = 8;        // cache rows in flight per lane and trip
 
+// One block = one (sequence, head, split). A CU pulls ~10 B / clock from HBM whatever it keeps in flight (6 TB/s over 256 CUs), so
+// one block per head — 32 blocks for the 7B decoder at B = 1 — streams the 333 KB of a head's keys and values in ~15 us however the
+// loads are arranged (measured: 16 -> 19 us per launch with 4, 8 or 16 rows in flight per lane, position-major or head-major cache).
+// Round 3: the keys of a head are dealt to n_split blocks by passes of G rows (pass i -> split i % n_split), every block keeps its own
+// softmax statistics (max m, sum l) and un-normalised output, and decode_attn_merge_kernel combines the n_split partial results —
+// flash-decoding with the merge as a second, tiny launch (deterministic; no tickets, fences or atomics).
 template <int HD>
 __global__ __launch_bounds__(DA_THREADS) void decode_attn_kernel(const grove_decode_attn_params p) {
   __shared__ float q_s[HD];
   __shared__ float kn_s[HD];   // the new token's rotated key / value (fp32 of the bf16 values the cache row holds)
   __shared__ float vn_s[HD];
-  __shared__ float sc[DA_MAXS];
+  __shared__ float sc[DA_MAXS + 64];  // (+ the new token's slot behind a full last pass)
   __shared__ float red[DA_THREADS / 64];
   __shared__ float part[16][HD + 1];
   const int tid = threadIdx.x;
-  const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
+  const int NS = p.n_split > 1 ? p.n_split : 1;
+  const int bh = blockIdx.x / NS, sp = blockIdx.x - bh * NS;
+  const int b = bh / p.H, h = bh - b * p.H;
   const int HH = p.H * HD;
   bf16_raw* qkv = (bf16_raw*)p.qkv + (int64_t)b * p.ld_qkv;
-  bf16_raw* kc = (bf16_raw*)p.cache + ((int64_t)b * p.S_max) * 2 * HH + h * HD;  // key row j at kc + j * 2HH; value at + HH
+  // cache layout [B, 2 (keys, values), H, S_max, hd]: the rows of one head are contiguous
+  bf16_raw* kc = (bf16_raw*)p.cache + (((int64_t)b * 2) * p.H + h) * p.S_max * HD;      // key row j at kc + j * HD
+  bf16_raw* vc = (bf16_raw*)p.cache + (((int64_t)b * 2 + 1) * p.H + h) * p.S_max * HD;  // value row j at vc + j * HD
   constexpr int CPR = HD / 8;           // 16-byte chunks per row
   constexpr int G = DA_THREADS / CPR;   // rows per pass (16 for hd 128, 32 for hd 64)
   const int g = tid / CPR, c = tid - g * CPR;
   const bf16_raw* kbase = kc + c * 8;
-  const bf16_raw* vbase = kc + HH + c * 8;
-  const u32x4_t zero4 = u32x4_t{0u, 0u, 0u, 0u};
-  // trip 0 of the key rows, before anything else (speculative: masked by the position below)
+  const bf16_raw* vbase = vc + c * 8;
+  const int t = p.pos[b];  // the new token's position; cached keys 0..t-1 + the new one are visible
+  const int npass = (t + G - 1) / G;                 // passes over the cached rows 0..t-1; this block takes sp, sp + NS, ...
+  const int mine = npass > sp ? (npass - sp + NS - 1) / NS : 0;
+  auto row_of = [&](int i) { return (sp + NS * i) * G + g; };  // row of my i-th pass for this lane group
+  // first trip of key rows before the rotation (they do not depend on it)
   u32x4_t kv[DA_U];
 #pragma unroll
   for (int u = 0; u < DA_U; ++u) {
-    const int j = g + u * G;
-    kv[u] = j < p.S_max ? *(const u32x4_t*)(kbase + (int64_t)j * 2 * HH) : zero4;
+    const int j = min(row_of(min(u, max(mine - 1, 0))), max(t - 1, 0));  // (clamped inside the sequence; masked below)
+    kv[u] = *(const u32x4_t*)(kbase + (int64_t)j * HD);
   }
-  const int t = p.pos[b];  // the new token's position; cached keys 0..t-1 + the new one are visible
-  // rotate q (-> LDS, fp32 of the bf16-rounded value, as the unfused path stores it) and k (-> cache + LDS), copy v
+  // rotate q (-> LDS, fp32 of the bf16-rounded value, as the unfused path stores it); split 0 also rotates k, appends k | v to
+  // the cache and keeps them in LDS (the new token's own score and value never come back from memory)
   if (tid < HD / 2) {
     const float inv_freq = powf(p.theta, -2.f * (float)tid / (float)HD);
     float sn, cs;
@@ -211,17 +276,19 @@ __global__ __launch_bounds__(DA_THREADS) void decode_attn_kernel(const grove_dec
     const float q1 = bf2f(q[tid]), q2 = bf2f(q[tid + HD / 2]);
     q_s[tid] = bf2f(f2bf(q1 * cs - q2 * sn));
     q_s[tid + HD / 2] = bf2f(f2bf(q2 * cs + q1 * sn));
-    const bf16_raw* k = qkv + HH + h * HD;
-    const float k1 = bf2f(k[tid]), k2 = bf2f(k[tid + HD / 2]);
-    const bf16_raw r1 = f2bf(k1 * cs - k2 * sn), r2 = f2bf(k2 * cs + k1 * sn);
-    kc[(int64_t)t * 2 * HH + tid] = r1;
-    kc[(int64_t)t * 2 * HH + tid + HD / 2] = r2;
-    kn_s[tid] = bf2f(r1);
-    kn_s[tid + HD / 2] = bf2f(r2);
-  } else if (tid < HD / 2 + HD / 8) {
+    if (sp == 0) {
+      const bf16_raw* k = qkv + HH + h * HD;
+      const float k1 = bf2f(k[tid]), k2 = bf2f(k[tid + HD / 2]);
+      const bf16_raw r1 = f2bf(k1 * cs - k2 * sn), r2 = f2bf(k2 * cs + k1 * sn);
+      kc[(int64_t)t * HD + tid] = r1;
+      kc[(int64_t)t * HD + tid + HD / 2] = r2;
+      kn_s[tid] = bf2f(r1);
+      kn_s[tid + HD / 2] = bf2f(r2);
+    }
+  } else if (sp == 0 && tid < HD / 2 + HD / 8) {
     const int cc = tid - HD / 2;
     const u32x4_t vv = *(const u32x4_t*)(qkv + 2 * HH + h * HD + cc * 8);
-    *(u32x4_t*)(kc + (int64_t)t * 2 * HH + HH + cc * 8) = vv;
+    *(u32x4_t*)(vc + (int64_t)t * HD + cc * 8) = vv;
     const float f[8] = {bf_lo(vv.x), bf_hi(vv.x), bf_lo(vv.y), bf_hi(vv.y), bf_lo(vv.z), bf_hi(vv.z), bf_lo(vv.w), bf_hi(vv.w)};
 #pragma unroll
     for (int e = 0; e < 8; ++e) vn_s[cc * 8 + e] = f[e];
@@ -244,50 +311,54 @@ __global__ __launch_bounds__(DA_THREADS) void decode_attn_kernel(const grove_dec
     for (int off = CPR / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
     return s;
   };
-  for (int j0 = 0; j0 < t; j0 += G * DA_U) {
-    if (j0 > 0) {
+  // scores of my rows: sc[i * G + g] for my pass i (local numbering)
+  for (int i0 = 0; i0 < mine; i0 += DA_U) {
+    if (i0 > 0) {
 #pragma unroll
       for (int u = 0; u < DA_U; ++u) {
-        const int j = min(j0 + g + u * G, t - 1);  // (clamped: an address inside the sequence; the row is masked below)
-        kv[u] = *(const u32x4_t*)(kbase + (int64_t)j * 2 * HH);
+        const int j = min(row_of(min(i0 + u, mine - 1)), t - 1);
+        kv[u] = *(const u32x4_t*)(kbase + (int64_t)j * HD);
       }
     }
 #pragma unroll
     for (int u = 0; u < DA_U; ++u) {
-      const int j = j0 + g + u * G;
+      const int i = i0 + u;
       const float s = group_sum(dot8(kv[u])) * p.alpha;
-      if (j < t) {
-        if (c == 0) sc[j] = s;
+      if (i < mine && row_of(i) < t) {
+        if (c == 0) sc[i * G + g] = s;
         mx = fmaxf(mx, s);
+      } else if (i < mine && c == 0) {
+        sc[i * G + g] = -INFINITY;  // a row of my last pass beyond the sequence
       }
     }
   }
-  // trip 0 of the value rows goes out now: the softmax reductions below run under its latency
+  // first trip of the value rows goes out now: the softmax reductions below run under its latency
   u32x4_t vv[DA_U];
 #pragma unroll
   for (int u = 0; u < DA_U; ++u) {
-    const int j = min(g + u * G, max(t - 1, 0));
-    vv[u] = *(const u32x4_t*)(vbase + (int64_t)j * 2 * HH);
+    const int j = min(row_of(min(u, max(mine - 1, 0))), max(t - 1, 0));
+    vv[u] = *(const u32x4_t*)(vbase + (int64_t)j * HD);
   }
-  if (g == 0) {  // the new token itself, from LDS
+  const int nloc = mine * G;   // local score slots (the new token's score goes to slot nloc of split 0)
+  if (sp == 0 && g == 0) {     // the new token itself, from LDS
     float s = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) s = fmaf(kn_s[c * 8 + e], qv[e], s);
     s = group_sum(s) * p.alpha;
-    if (c == 0) sc[t] = s;
+    if (c == 0) sc[nloc] = s;
     mx = fmaxf(mx, s);
   }
   mx = block_max<DA_THREADS>(mx, red);
-  const int Lk = t + 1;
+  const int nsc = nloc + (sp == 0 ? 1 : 0);
+  const float m_use = mx == -INFINITY ? 0.f : mx;  // a split without rows: every exp below is exp(-inf) = 0
   float sum = 0.f;
-  for (int j = tid; j < Lk; j += DA_THREADS) {
-    const float e = __expf(sc[j] - mx);
+  for (int j = tid; j < nsc; j += DA_THREADS) {
+    const float e = __expf(sc[j] - m_use);
     sc[j] = e;
     sum += e;
   }
   sum = block_sum<DA_THREADS>(sum, red);  // (its barriers also publish sc[])
-  const float inv = 1.f / sum;
-  // o[d] = sum_j p_j v_j[d]: lane group g takes rows j = g, g + G, ...; chunk c = tid % (HD/8)
+  // o[d] = sum_j p_j v_j[d] over my rows: lane group g takes row g of each of my passes; chunk c = tid % (HD/8)
   float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   auto pv = [&](float pj, const u32x4_t v4) {
     o[0] = fmaf(pj, bf_lo(v4.x), o[0]); o[1] = fmaf(pj, bf_hi(v4.x), o[1]);
@@ -295,22 +366,22 @@ __global__ __launch_bounds__(DA_THREADS) void decode_attn_kernel(const grove_dec
     o[4] = fmaf(pj, bf_lo(v4.z), o[4]); o[5] = fmaf(pj, bf_hi(v4.z), o[5]);
     o[6] = fmaf(pj, bf_lo(v4.w), o[6]); o[7] = fmaf(pj, bf_hi(v4.w), o[7]);
   };
-  for (int j0 = 0; j0 < t; j0 += G * DA_U) {
-    if (j0 > 0) {
+  for (int i0 = 0; i0 < mine; i0 += DA_U) {
+    if (i0 > 0) {
 #pragma unroll
       for (int u = 0; u < DA_U; ++u) {
-        const int j = min(j0 + g + u * G, t - 1);
-        vv[u] = *(const u32x4_t*)(vbase + (int64_t)j * 2 * HH);
+        const int j = min(row_of(min(i0 + u, mine - 1)), t - 1);
+        vv[u] = *(const u32x4_t*)(vbase + (int64_t)j * HD);
       }
     }
 #pragma unroll
     for (int u = 0; u < DA_U; ++u) {
-      const int j = j0 + g + u * G;
-      pv(j < t ? sc[j] : 0.f, vv[u]);
+      const int i = i0 + u;
+      pv(i < mine ? sc[i * G + g] : 0.f, vv[u]);  // (rows beyond the sequence carry exp(-inf) = 0)
     }
   }
-  if (g == 0) {  // the new token's value, from LDS
-    const float pj = sc[t];
+  if (sp == 0 && g == 0) {  // the new token's value, from LDS
+    const float pj = sc[nloc];
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = fmaf(pj, vn_s[c * 8 + e], o[e]);
   }
@@ -331,7 +402,35 @@ __global__ __launch_bounds__(DA_THREADS) void decode_attn_kernel(const grove_dec
     }
   }
   __syncthreads();
-  if (tid < HD) ((bf16_raw*)p.out)[(int64_t)b * HH + h * HD + tid] = f2bf(q_s[tid] * inv);
+  if (NS == 1) {
+    if (tid < HD) ((bf16_raw*)p.out)[(int64_t)b * HH + h * HD + tid] = f2bf(q_s[tid] / sum);
+  } else {  // partial result {m, l, o[HD]} of this split
+    float* pr = (float*)p.partial + ((int64_t)bh * NS + sp) * (HD + 2);
+    if (tid < HD) pr[2 + tid] = q_s[tid];
+    if (tid == 0) {
+      pr[0] = mx;
+      pr[1] = sum;
+    }
+  }
+}
+
+// out[b, h, :] = sum_s exp(m_s - M) o_s / sum_s exp(m_s - M) l_s  over the n_split partial results of a head
+template <int HD>
+__global__ __launch_bounds__(HD) void decode_attn_merge_kernel(const grove_decode_attn_params p) {
+  const int bh = blockIdx.x, d = threadIdx.x;
+  const int NS = p.n_split;
+  const float* pr = (const float*)p.partial + (int64_t)bh * NS * (HD + 2);
+  float M = -INFINITY;
+  for (int s = 0; s < NS; ++s) M = fmaxf(M, pr[s * (HD + 2)]);
+  float L = 0.f, o = 0.f;
+  for (int s = 0; s < NS; ++s) {
+    const float m = pr[s * (HD + 2)];
+    const float w = m == -INFINITY ? 0.f : __expf(m - M);
+    L = fmaf(w, pr[s * (HD + 2) + 1], L);
+    o = fmaf(w, pr[s * (HD + 2) + 2 + d], o);
+  }
+  const int b = bh / p.H, h = bh - b * p.H;
+  ((bf16_raw*)p.out)[(int64_t)b * p.H * HD + h * HD + d] = f2bf(o / L);
 }
 }  // namespace
 
@@ -341,10 +440,20 @@ extern "C" int grove_decode_attn(const grove_decode_attn_params* pp, void* strea
   GROVE_CHECK(p.B > 0 && p.H > 0 && (p.hd == 64 || p.hd == 128 || p.hd == 32), GROVE_E_SHAPE, "decode_attn: B=%d H=%d hd=%d (hd must be 32, 64 or 128)", p.B, p.H, p.hd);
   GROVE_CHECK(p.S_max > 0 && p.S_max <= DA_MAXS, GROVE_E_SHAPE, "decode_attn: S_max=%d must be <= %d", p.S_max, DA_MAXS);
   GROVE_CHECK(p.ld_qkv % 8 == 0 && ((uintptr_t)p.qkv & 15) == 0 && ((uintptr_t)p.cache & 15) == 0, GROVE_E_ALIGN, "decode_attn: qkv/cache alignment");
+  GROVE_CHECK(p.n_split <= 1 || (p.partial != nullptr && p.n_split <= 64), GROVE_E_WORKSPACE,
+              "decode_attn: n_split=%d needs the caller's partial-result buffer (B * H * n_split * (hd + 2) floats)", p.n_split);
   hipStream_t s = (hipStream_t)stream;
-  if (p.hd == 128) hipLaunchKernelGGL(decode_attn_kernel<128>, dim3(p.B * p.H), dim3(DA_THREADS), 0, s, p);
-  else if (p.hd == 64) hipLaunchKernelGGL(decode_attn_kernel<64>, dim3(p.B * p.H), dim3(DA_THREADS), 0, s, p);
-  else hipLaunchKernelGGL(decode_attn_kernel<32>, dim3(p.B * p.H), dim3(DA_THREADS), 0, s, p);
+  const int NS = p.n_split > 1 ? p.n_split : 1;
+  const dim3 grid(p.B * p.H * NS);
+  if (p.hd == 128) hipLaunchKernelGGL(decode_attn_kernel<128>, grid, dim3(DA_THREADS), 0, s, p);
+  else if (p.hd == 64) hipLaunchKernelGGL(decode_attn_kernel<64>, grid, dim3(DA_THREADS), 0, s, p);
+  else hipLaunchKernelGGL(decode_attn_kernel<32>, grid, dim3(DA_THREADS), 0, s, p);
   GROVE_LAUNCH_CHECK();
+  if (NS > 1) {
+    if (p.hd == 128) hipLaunchKernelGGL(decode_attn_merge_kernel<128>, dim3(p.B * p.H), dim3(128), 0, s, p);
+    else if (p.hd == 64) hipLaunchKernelGGL(decode_attn_merge_kernel<64>, dim3(p.B * p.H), dim3(64), 0, s, p);
+    else hipLaunchKernelGGL(decode_attn_merge_kernel<32>, dim3(p.B * p.H), dim3(32), 0, s, p);
+    GROVE_LAUNCH_CHECK();
+  }
   return GROVE_OK;
 }

@@ -44,16 +44,23 @@ def trainable_names(d: GroveDims):
 
 
 class KVCache:
-    """`past_key_values` of the cached LM step: per layer one bf16 [B, capacity, 2*hidden] tensor holding the rotated keys |
-    values of positions 0..length-1 (zero beyond: the decode kernel reads whole tiles and masks by position). Falsy while
-    empty, like the `past_key_values` test in prepare_inputs_for_generation (llava_llama.py:158-159)."""
+    """`past_key_values` of the cached LM step: per layer one bf16 [B, 2, heads, capacity, head_dim] tensor — plane 0 the rotated
+    keys, plane 1 the values of positions 0..length-1, head-major so that the positions of one head are contiguous rows (what
+    grove_decode_attn streams); zero beyond `length` (the decode kernel reads ahead of the position and masks). Falsy while
+    empty, like the `past_key_values` test in prepare_inputs_for_generation (llava_llama.py:158-159). `rows(layer, lo, hi)` gives
+    the position-major [B, hi-lo, 2*hidden] keys | values view HF's cache tensors correspond to."""
 
     def __init__(self, layers, length=0):
         self.layers, self.length = layers, length
 
     @property
     def capacity(self):
-        return self.layers[0].shape[1] if self.layers else 0
+        return self.layers[0].shape[3] if self.layers else 0
+
+    def rows(self, layer, lo, hi):
+        t = self.layers[layer][:, :, :, lo:hi]                      # [B, 2, heads, n, hd]
+        B, _, nh, n, hd = t.shape
+        return t.permute(0, 3, 1, 2, 4).reshape(B, n, 2 * nh * hd)  # keys | values per position
 
     def __len__(self):
         return len(self.layers) if self.length > 0 else 0
@@ -68,8 +75,8 @@ class KVCache:
             return
         cap = max(n, self.capacity + 256)
         for i, t in enumerate(self.layers):
-            g = torch.zeros((t.shape[0], cap, t.shape[2]), dtype=t.dtype, device=t.device)
-            g[:, :self.length].copy_(t[:, :self.length])
+            g = torch.zeros(t.shape[:3] + (cap, t.shape[4]), dtype=t.dtype, device=t.device)
+            g[:, :, :, :self.length].copy_(t[:, :, :, :self.length])
             self.layers[i] = g
 
 

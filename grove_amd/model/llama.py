@@ -78,8 +78,8 @@ class LlamaStack:
 
     def forward(self, x, B, S, kv_len=None, save=False, kv_cache=None, precise_rows=None):
         """x: bf16 [B*S, H] input embeddings (consumed). kv_len: int32 [B] valid lengths or None.
-        kv_cache: optional list (one per layer) of bf16 [B, S_max, 2H] tensors that receive the rotated keys | values of
-        positions 0..S-1 (the prefill of a cached decode). Returns (final-norm hidden [B*S, H], ctx).
+        kv_cache: optional list (one per layer) of bf16 [B, 2, heads, S_max, hd] tensors (KVCache layout) that receive the rotated keys
+        and the values of positions 0..S-1 (the prefill of a cached decode). Returns (final-norm hidden [B*S, H], ctx).
         Residual stream, `self.fp32_stream` (default: models built for inference):
           fp32: the stream is held in FP32 (`res`); each branch output (o_proj, down_proj; bf16 from the GEMM) is added to it inside
                 the RMSNorm kernel that follows (grove_rmsnorm_fwd, residual-stream form), so it is never rounded to bf16 between the
@@ -105,7 +105,7 @@ class LlamaStack:
             qkv = self._qkv(L, h, pr) if self.fp8 else ops.linear(h, L["wqkv"])
             ops.rope_(qkv, pos, 0, 2 * nh, hd, d.rope_theta)
             if kv_cache is not None:
-                kv_cache[li][:, :S].copy_(qkv.view(B, S, 3 * H)[:, :, H:])
+                kv_cache[li][:, :, :, :S].copy_(qkv.view(B, S, 3, nh, hd)[:, :, 1:].permute(0, 2, 3, 1, 4))  # (a strided copy: layout only)
             o, actx = attention_fwd(qkv, B, S, nh, hd, 0, H, 2 * H, hd ** -0.5, causal=True, kv_len=kv_len, save=save)
             if f32:
                 t = self._lin(L, "wo", o, precise_rows=pr)
@@ -143,12 +143,12 @@ class LlamaStack:
     def new_kv_cache(self, B, S_max):
         d = self.d
         # zero-filled: the graph-replayed step reads whole 64-key tiles and masks by kv_len; 0 * stale NaN would poison P V
-        return [torch.zeros((B, S_max, 2 * d.hidden), dtype=torch.bfloat16, device=self.dev) for _ in self.layers]
+        return [torch.zeros((B, 2, d.n_heads, S_max, d.head_dim), dtype=torch.bfloat16, device=self.dev) for _ in self.layers]
 
     def _decode_body(self, x, pos, kv_cache, lm_head=None):
-        """The launches of one cached step: five per layer — RMSNorm folded into the q|k|v GEMV, RoPE + cache append +
-        one-query attention in one kernel, o_proj GEMV (+residual), RMSNorm folded into the gate|up GEMV, SwiGLU folded into
-        the down GEMV (+residual). Everything that changes from step to step (the position) is DEVICE data, so the same
+        """The launches of one cached step: six per layer — RMSNorm folded into the q|k|v GEMV, RoPE + cache append + one-query
+        attention over n_split blocks per head + the merge of their partial results, o_proj GEMV (+residual), RMSNorm folded into
+        the gate|up GEMV whose epilogue applies the SwiGLU, down GEMV (+residual). Everything that changes from step to step (the position) is DEVICE data, so the same
         sequence can be replayed from a captured HIP graph."""
         d = self.d
         nh, hd = d.n_heads, d.head_dim
@@ -156,8 +156,12 @@ class LlamaStack:
             qkv = ops.gemv(x, L["wqkv"], rms_weight=L["ln1"], eps=d.rms_eps)
             o = ops.decode_attn(qkv, kv, pos, nh, hd, d.rope_theta, hd ** -0.5)
             x1 = ops.gemv(o, L["wo"], residual=x)
-            gu = ops.gemv(x1, L["wgu"], rms_weight=L["ln2"], eps=d.rms_eps)
-            x = ops.gemv(gu, L["wd"], residual=x1, swiglu=True)
+            if "wgu_sw" in L and (2 * d.mlp) % 16 == 0:  # SwiGLU in the gate|up GEMV's epilogue (rows interleaved 4 gate / 4 up)
+                a = ops.gemv(x1, L["wgu_sw"], rms_weight=L["ln2"], eps=d.rms_eps, act=ops.ACT_SWIGLU_PAIR)
+                x = ops.gemv(a, L["wd"], residual=x1)
+            else:
+                gu = ops.gemv(x1, L["wgu"], rms_weight=L["ln2"], eps=d.rms_eps)
+                x = ops.gemv(gu, L["wd"], residual=x1, swiglu=True)
         out = ops.rmsnorm(x, self.norm, d.rms_eps)
         logits = ops.gemv(x, lm_head, out_dtype=torch.float32, rms_weight=self.norm, eps=d.rms_eps) if lm_head is not None else None
         return out, logits

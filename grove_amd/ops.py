@@ -349,8 +349,8 @@ def gemv(x, w, bias=None, *, act=ACT_NONE, residual=None, out_dtype=bf16, out=No
         xp = torch.zeros((mx, x.shape[1]), dtype=bf16, device=x.device)
         xp[:M] = x
         x = xp
-    if out is None:
-        out = torch.empty((M, N), dtype=out_dtype, device=x.device)
+    if out is None:  # ACT_SWIGLU_PAIR: w rows interleaved [4 gate, 4 up] (swiglu_interleave), the result is silu(gate) * up: N / 2 columns
+        out = torch.empty((M, N // 2 if act == ACT_SWIGLU_PAIR else N), dtype=out_dtype, device=x.device)
     p = _lib.GemvParams()
     p.x, p.W, p.y, p.bias, p.residual = _p(x), _p(w), _p(out), _p(bias), _p(residual)
     p.M, p.N, p.K = M, N, K
@@ -364,15 +364,32 @@ def gemv(x, w, bias=None, *, act=ACT_NONE, residual=None, out_dtype=bf16, out=No
     return out
 
 
-def decode_attn(qkv, cache, pos, H, hd, theta, alpha, out=None):
-    """RoPE(q, k) + cache append + one-query attention for the new token of every sequence (grove_decode_attn)."""
-    B, S_max = cache.shape[0], cache.shape[1]
+_decode_partial = {}  # (device index, floats) -> f32 scratch of the split decode attention (launches of a stream are ordered: shared)
+
+
+def decode_attn(qkv, cache, pos, H, hd, theta, alpha, out=None, n_split=None):
+    """RoPE(q, k) + cache append + one-query attention for the new token of every sequence (grove_decode_attn).
+    cache: bf16 [B, 2, H, S_max, hd] (keys / values planes, head-major), contiguous."""
+    assert cache.dim() == 5 and cache.shape[1] == 2 and cache.shape[2] == H and cache.shape[4] == hd and cache.is_contiguous()
+    B, S_max = cache.shape[0], cache.shape[3]
     if out is None:
         out = torch.empty((B, H * hd), dtype=bf16, device=qkv.device)
     p = _lib.DecodeAttnParams()
     p.qkv, p.cache, p.out, p.pos = _p(qkv), _p(cache), _p(out), _p(pos)
     p.B, p.H, p.hd, p.S_max, p.ld_qkv = B, H, hd, S_max, qkv.stride(0)
     p.theta, p.alpha = float(theta), float(alpha)
+    if n_split is None:  # one CU streams ~23 GB/s: spread a head over up to 8 blocks while the grid stays within one wave of CUs
+        n_split = max(1, min(8, 256 // (B * H)))
+    if n_split > 1:
+        n = B * H * n_split * (hd + 2)
+        key = (qkv.device.index, torch.cuda.current_stream().cuda_stream)
+        buf = _decode_partial.get(key)
+        if buf is None or buf.numel() < n:
+            buf = torch.empty(max(n, 1 << 16), dtype=torch.float32, device=qkv.device)
+            if not torch.cuda.is_current_stream_capturing():
+                _decode_partial[key] = buf
+        p.partial, p.n_split = _p(buf), n_split
+        p._keep = buf
     _lib.check(_lib.lib().grove_decode_attn(C.byref(p), _stream()), "grove_decode_attn")
     return out
 

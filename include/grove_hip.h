@@ -413,6 +413,8 @@ int grove_rope_inplace(const grove_rope_params* p, void* stream);
  * x: bf16 [M, ldx]; W: bf16 [N, ldw] (nn.Linear layout); y: bf16 or f32 [M, ldy]. HBM-bound: every
  * weight byte is read once. For M of 3 (5..7) the kernel reads 4 (8) x rows: x must have that many
  * addressable rows (the wrapper pads).
+ * act GROVE_ACT_SWIGLU_PAIR (HF LlamaMLP's silu(gate) * up in the gate|up projection's epilogue): W rows interleaved
+ * [4 gate, 4 up] per 8 as for grove_gemm_bf16, N % 16 == 0, no bias / residual; y gets N / 2 columns.
  * ------------------------------------------------------------------------------------------ */
 enum grove_gemv_x_mode {
   GROVE_GEMV_X_PLAIN = 0,
@@ -438,7 +440,9 @@ int grove_gemv_bf16(const grove_gemv_params* p, void* stream);
 /* One cached decode step of causal self-attention for ONE new token per sequence (HF LlamaAttention with a KV cache):
  * rotates q and k of the new token in place (rotate-half RoPE at position pos[b], fp32), appends k | v to the cache row
  * pos[b] and attends the query to cache rows 0..pos[b]. qkv: bf16 [B, ld_qkv] = q | k | v (H heads of hd each);
- * cache: bf16 [B, S_max, 2*H*hd] = keys | values; out: bf16 [B, H*hd]. hd must be 64 or 128. */
+ * cache: bf16 [B, 2, H, S_max, hd] = (keys, values) planes, head-major — the positions of one head are contiguous rows, which is what
+ * the one-block-per-head stream reads (round 2's [B, S_max, 2*H*hd] put every row of a head in its own DRAM page);
+ * out: bf16 [B, H*hd]. hd must be 32, 64 or 128. */
 typedef struct grove_decode_attn_params {
   void* qkv;
   void* cache;
@@ -446,6 +450,11 @@ typedef struct grove_decode_attn_params {
   const int32_t* pos; /* [B] device */
   int32_t B, H, hd, S_max, ld_qkv;
   float theta, alpha;
+  /* flash-decoding split: the cached rows of a head are dealt to n_split blocks (one CU streams ~23 GB/s: 32 heads alone cannot
+   * use the chip), partial {max, sum, output} per block in the caller's `partial` (f32 [B, H, n_split, hd + 2]), merged by a second
+   * launch. n_split <= 1 (partial may be NULL): one block per head. */
+  void* partial;
+  int32_t n_split;
 } grove_decode_attn_params;
 int grove_decode_attn(const grove_decode_attn_params* p, void* stream);
 

@@ -883,6 +883,14 @@ def test_gemv_fused_rmsnorm_and_swiglu(dev):
     gu = rnd(M, 2 * K, seed=4).to(dev)
     y = ops.gemv(gu, w, swiglu=True)
     close(y, ops.gemv(ops.swiglu(gu, K), w), 2 ** -8, "gemv swiglu-fused vs swiglu kernel + gemv")
+    # SwiGLU in the EPILOGUE of the gate|up GEMV (rows interleaved 4 gate / 4 up; round 3): bit-identical to GEMV + swiglu kernel
+    I, Kx = 96, 2304  # (K >= 2048: the weight trip that is issued before the x prologue, plus a ragged tail)
+    wgu = rnd(2 * I, Kx, seed=21, scale=0.1).to(dev)
+    xs = rnd(M, Kx, seed=22).to(dev)
+    nw = rnd(Kx, seed=23).to(dev)
+    ref = ops.swiglu(ops.gemv(xs, wgu, rms_weight=nw, eps=1e-5), I)
+    got = ops.gemv(xs, ops.swiglu_interleave(wgu), rms_weight=nw, eps=1e-5, act=ops.ACT_SWIGLU_PAIR)
+    assert got.shape == (M, I) and torch.equal(got, ref), (got.float() - ref.float()).abs().max().item()
 
 
 @pytest.mark.parametrize("B,H,hd,t,Smax", [(2, 4, 32, 36, 64), (1, 8, 128, 699, 768), (3, 2, 64, 0, 16), (2, 32, 128, 1500, 2048)])
@@ -891,19 +899,19 @@ def test_decode_attention_fused(dev, B, H, hd, t, Smax):
     from grove_amd import ops
     Hd = H * hd
     qkv = rnd(B, 3 * Hd, seed=5).to(dev)
-    cache = rnd(B, Smax, 2 * Hd, seed=6).to(dev)
+    cache = rnd(B, 2, H, Smax, hd, seed=6).to(dev)             # [B, keys / values, head, position, hd]: the KVCache layout
     pos = torch.full((B,), t, dtype=torch.int32, device=dev)
     ref_qkv, ref_cache = qkv.clone(), cache.clone()
     ops.rope_(ref_qkv, pos, 0, 2 * H, hd, 10000.0)
-    ref_cache[:, t] = ref_qkv[:, Hd:]
+    ref_cache[:, :, :, t] = ref_qkv[:, Hd:].view(B, 2, H, hd)
     q = ref_qkv[:, :Hd].float().cpu().view(B, H, 1, hd)
-    k = ref_cache[:, :t + 1, :Hd].float().cpu().view(B, t + 1, H, hd).permute(0, 2, 1, 3)
-    v = ref_cache[:, :t + 1, Hd:].float().cpu().view(B, t + 1, H, hd).permute(0, 2, 1, 3)
+    k = ref_cache[:, 0, :, :t + 1].float().cpu()               # [B, H, t + 1, hd]
+    v = ref_cache[:, 1, :, :t + 1].float().cpu()
     ref = (torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, -1) @ v).view(B, Hd)
     o = ops.decode_attn(qkv, cache, pos, H, hd, 10000.0, hd ** -0.5)
     close(o, ref, 2 ** -7, "fused decode attention")
-    assert torch.equal(cache[:, t], ref_cache[:, t]), "appended key|value row"
-    assert torch.equal(cache[:, :t], ref_cache[:, :t]) and torch.equal(cache[:, t + 1:], ref_cache[:, t + 1:])
+    assert torch.equal(cache[:, :, :, t], ref_cache[:, :, :, t]), "appended key / value row"
+    assert torch.equal(cache[:, :, :, :t], ref_cache[:, :, :, :t]) and torch.equal(cache[:, :, :, t + 1:], ref_cache[:, :, :, t + 1:])
 
 
 @pytest.mark.parametrize("tile_m", [256, 193])

@@ -254,7 +254,7 @@ def test_forward_past_key_values_is_one_cached_lm_step(gen_setup):
         if step == 0:
             assert tuple(out.logits.shape) == (2, prompt.shape[1] + 575, d.vocab) or out.logits.shape[-1] >= d.vocab
             S0 = out.hidden_states.shape[1]
-            prefill_rows = [layer[:, :S0].clone() for layer in past.layers]
+            prefill_rows = [past.rows(li, 0, S0).clone() for li in range(len(past.layers))]
             assert past.get_seq_length() == S0
         hiddens.append(out.hidden_states)
         nxt = out.logits[:, -1, :d.vocab].float().argmax(-1)
@@ -270,14 +270,14 @@ def test_forward_past_key_values_is_one_cached_lm_step(gen_setup):
     assert rel(hid_gen, hid_loop) < 1e-3, "graph-replayed steps vs eager cached steps"
     # the prompt's keys | values are untouched by the decode steps, eager or graph (position 0 = BOS, the attention sink)
     for li, rows in enumerate(prefill_rows):
-        assert torch.equal(past.layers[li][:, :S0], rows), f"eager steps changed prefilled rows of layer {li}"
-        assert torch.equal(gen.past_key_values.layers[li][:, :S0], rows), f"graph warm-up / replay changed prefilled rows of layer {li}"
+        assert torch.equal(past.rows(li, 0, S0), rows), f"eager steps changed prefilled rows of layer {li}"
+        assert torch.equal(gen.past_key_values.rows(li, 0, S0), rows), f"graph warm-up / replay changed prefilled rows of layer {li}"
         assert float(rows[:, 0].float().abs().max()) > 0
     # and the appended rows agree between the two
     n = past.get_seq_length()
     assert n == gen.past_key_values.get_seq_length()
     for li in range(len(prefill_rows)):
-        assert rel(gen.past_key_values.layers[li][:, S0:n], past.layers[li][:, S0:n]) < 1e-3
+        assert rel(gen.past_key_values.rows(li, S0, n), past.rows(li, S0, n)) < 1e-3
 
 
 def test_evaluate_goes_through_generate(gen_setup, dev, monkeypatch):

@@ -8,7 +8,7 @@ from grove_amd import ops
 dev = torch.device("cuda:0")
 bf = torch.bfloat16
 B, H, hd, S, Smax = 1, 32, 128, 650, 720
-caches = [torch.randn(B, Smax, 2 * H * hd, device=dev).to(bf) for _ in range(32)]
+caches = [torch.randn(B, 2, H, Smax, hd, device=dev).to(bf) for _ in range(32)]
 qkv = torch.randn(B, 3 * H * hd, device=dev).to(bf)
 pos = torch.full((B,), S, dtype=torch.int32, device=dev)
 out = torch.empty(B, H * hd, device=dev, dtype=bf)
