@@ -247,10 +247,13 @@ class GradExchange:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             self._kmax = (t, None)
             return
+        if getattr(self, "_kmax_host", None) is None:  # one pinned word and one device word for the life of the exchange
+            self._kmax_host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+            self._kmax_dev = torch.empty(1, dtype=torch.int32, device=self.flat.device)
+        host, td = self._kmax_host, self._kmax_dev
         with torch.cuda.stream(self.stream):
-            td = t.to(self.flat.device, non_blocking=True)
+            td.fill_(int(count))
             dist.all_reduce(td, op=dist.ReduceOp.MAX)
-            host = torch.empty(1, dtype=torch.int32, pin_memory=True)
             host.copy_(td, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self.stream)
