@@ -584,7 +584,7 @@ def main():
     all_n, all_f, all_s = (sum(v[i] for v in per_kernel.values()) for i in range(3))
     traffic = None
     try:  # memory-side bytes per launch from the committed PMC passes (profiles/, collected as the microarch guide prescribes)
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_gemm_traffic.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r03_pmc_gemm_traffic.json")) as fh:
             traffic = json.load(fh)["launch_weighted_mean_bytes"].get(dom[dom.index("<"):dom.index(",")] + ">")
     except Exception:
         pass
@@ -624,6 +624,18 @@ def main():
                 except Exception as e:
                     res["greedy_decode"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is a rank-0, N = 1 figure (other N: GPU numbers only)
+            try:  # recorded by the last `pytest -m gpu` run of tests/test_full_depth_gpu.py (committed under profiles/): not measured in this run
+                rec = {}
+                for key, fn, field in (("box_l1_vs_oracle_full", "r03_full_depth_parity_full.json", "box_l1_vs_oracle_full"),
+                                       ("box_l1_deep_narrow_mean_4_seeds", "r03_full_depth_box_l1_seeds.json", "mean"),
+                                       ("train_mode_loss_rel_err_deep_narrow", "r03_full_depth_training_parity_deep_narrow.json", "loss_terms_rel_err"),
+                                       ("train_mode_whole_gradient_deep_narrow", "r03_full_depth_training_parity_deep_narrow.json", "whole_gradient"),
+                                       ("greedy_ids_equal_full_size", "r03_full_size_greedy_parity.json", "ids_equal")):
+                    with open(os.path.join(ROOT, "profiles", fn)) as fh:
+                        rec[key] = json.load(fh)[field]
+                res["full_depth_parity_recorded"] = rec
+            except Exception:
+                pass
             try:
                 res["box_l1_vs_oracle_tiny"] = round(tiny_box_l1(dev), 6)
                 res["train_parity_vs_oracle_tiny"] = tiny_train_parity(dev)
