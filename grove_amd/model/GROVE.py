@@ -445,7 +445,7 @@ class GROVEForCausalLM(torch.nn.Module):
             hp.n_gt = n_gt
             hp.gt, hp.vis = gt.to(self.dev), vis.to(self.dev)
             dev_t += [hp.rows, hp.tgt, hp.gt, hp.vis]
-        if self._sparse_embed is not None and not inference:
+        if self._sparse_embed is not None and not inference and self._train_mode:  # (a loss-only validation forward has no backward to serve)
             # embed_tokens' gradient touches only the text-token rows of this batch: the distinct ids (sorted) and, per hidden row, the
             # position of its id in that list (-1 for visual rows) — the sparse gradient exchange sends (ids, rows) instead of the table
             tok_c = plan.tok.cpu()

@@ -85,7 +85,12 @@ class WarmupDecayLR:
         """Learning rate of the k-th optimizer update (k = 1, 2, ...) under DeepSpeed's calling order: the scheduler is built with
         last_batch_iteration = -1, which writes warmup_min_lr (0, train.py:472) into the optimizer — the value update 1 uses —
         and the engine steps the scheduler AFTER every optimizer update (iteration 0 after update 1, gamma(0) = 0 for update 2,
-        gamma(1) for update 3, ...). So update k runs with gamma(k - 2): the first two updates have lr = 0."""
+        gamma(1) for update 3, ...). So update k runs with gamma(k - 2): the first two updates have lr = 0.
+        UNPINNED: this rests on deepspeed==0.15.1's `WarmupLR.__init__` writing `warmup_min_lr` into the optimizer's
+        param groups when `last_batch_iteration == -1` (deepspeed/runtime/lr_schedules.py, `_format_param` / `update_lr` called from
+        `__init__`) and on `DeepSpeedEngine._take_model_step` calling `lr_scheduler.step()` after `optimizer.step()`. DeepSpeed is not
+        installed offline, so no lr trace of the reference stack could be captured into tests/golden; older DeepSpeed releases left
+        the optimizer's base lr for update 1. `get(step)` is the closed form either way; only the index shift is version dependent."""
         return self.get(max(k - 2, 0))
 
     def get(self, step):
