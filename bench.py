@@ -500,9 +500,13 @@ def main():
                     help="N > 1: exchange embed_tokens' gradient densely (131 M elements) instead of as touched rows (A/B arm)")
     ap.add_argument("--no_comm_overlap", action="store_true",
                     help="N > 1: exchange all gradients after the backward instead of group by group from inside it (exposed-communication A/B)")
+    ap.add_argument("--gemm_blocks", type=int, default=0,
+                    help="N > 1 A/B: resident blocks of the persistent GEMMs (0 = one per CU); fewer leaves CUs to the overlapped RCCL kernels")
     ap.add_argument("--serial_towers", action="store_true",
                     help="run the SAM tower on the main stream as well (no kernel overlap): how profiles/*_kernel_stats are collected")
     args = ap.parse_args()
+    if args.gemm_blocks:
+        os.environ["GROVE_GEMM_BLOCKS"] = str(args.gemm_blocks)  # (read when the library is loaded, in every rank)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus, sys.argv[1:]))
 
@@ -602,6 +606,7 @@ def main():
                                              ("after the backward" if args.no_comm_overlap else "overlapped with the backward (per parameter group)") +
                                              (", embed_tokens dense" if args.dense_embed else ", embed_tokens as touched rows (all-gather of ids + rows, fp32 sum)")),
                        "exposed_comm_ms": (None if exposed_ms is None else round(exposed_ms, 3)),
+                       "gemm_persistent_blocks": args.gemm_blocks or "one per CU",
                        "collective_backend": (dist.get_backend() if world > 1 else None),
                        "frames_per_sec_per_gpu": round(frames / dt / world, 3), "last_loss": round(loss, 4),
                        "towers": "serial" if args.serial_towers else "SAM tower on a second stream beside CLIP->LLaMA (roofline: one extra step with the towers serialised)"},

@@ -1118,6 +1118,7 @@ __global__ __launch_bounds__(64 * FIX_WAVES) void gemm_pp_fixup_kernel(const gro
 }
 
 static int g_num_cus = 0;
+static int g_persistent_blocks = 0;   // 0 = one resident block per CU; else the grid of the persistent kernels (grove_gemm_set_persistent_blocks)
 static int g_gemm_last_epilogue = 0;  // ACT template argument of the last pipelined launch (see grove_gemm_last_epilogue)
 static int g_gemm_stream_k = 1;       // plan_stream_k mode (grove_gemm_set_stream_k)
 static int g_gemm_last_stream_k = 0;  // S of the last pipelined launch
@@ -1129,7 +1130,7 @@ inline int num_cus() {
     hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
     g_num_cus = n > 0 ? n : 256;
   }
-  return g_num_cus;
+  return g_persistent_blocks > 0 && g_persistent_blocks < g_num_cus ? g_persistent_blocks : g_num_cus;
 }
 
 // Stream-K plan for `tiles` output tiles of nk K tiles on G blocks: after the whole rounds, a partial round of `tail` tiles
@@ -1376,6 +1377,14 @@ extern "C" int grove_gemm_work_list(int bm, int tiles_m, int tiles_n, int nk, in
   return (int)(t.size() / grid);
 }
 
+// The persistent kernels launch one block per CU and a block owns its CU for the whole GEMM: when another long-lived kernel (an RCCL
+// collective overlapped with the backward at N > 1) holds some CUs, the blocks dealt to them wait for a free CU — i.e. for another
+// block's whole share — and the GEMM takes up to twice as long. `n` < CU count makes plans, images and launches use n resident
+// blocks, leaving the other CUs to the collective (0 = all CUs). A/B knob for the first multi-GPU run: unmeasured (no N > 1 hardware).
+extern "C" int grove_gemm_set_persistent_blocks(int n) {
+  g_persistent_blocks = n < 0 ? 0 : n;
+  return GROVE_OK;
+}
 extern "C" int grove_gemm_set_stream_k(int mode) {
   g_gemm_stream_k = mode < 0 ? 0 : mode > 2 ? 2 : mode;
   return GROVE_OK;

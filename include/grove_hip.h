@@ -161,6 +161,10 @@ int grove_gemm_last_epilogue(void);
  * where the cost model says it pays, 0 = never (whole tiles only), 2 = wherever it applies (tests).
  * grove_gemm_last_stream_k: K tiles per part of the last pipelined launch, 0 = it ran whole tiles only. */
 int grove_gemm_set_stream_k(int mode);
+/* Grid of the persistent kernels: 0 (default) = one block per CU, n < CU count = n resident blocks — leaves CUs to an overlapped
+ * RCCL collective at N > 1, which would otherwise make the blocks dealt to its CUs wait for another block's whole share (TEST / A-B
+ * knob like the other setters: plan, image and launch under one setting; `bench.py --gemm_blocks n`). */
+int grove_gemm_set_persistent_blocks(int n);
 /* Host-only view of the persistent kernels' work list (needs no device): what each of the `grid` = min(tiles, num_cus) (num_cus with a
  * stream-K tail) blocks does for tiles_m x tiles_n output tiles of bm x 256 (bm = 192 / 256) with nk K tiles of 64.
  * list: int32 [rows][grid][4] — row 0 = {K tiles of the block's stream, its segments, 0, 0}, row 1 + i = segment {m0, n0, k0 | k1 << 16,
