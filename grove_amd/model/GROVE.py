@@ -937,8 +937,12 @@ class GROVEForCausalLM(torch.nn.Module):
             det_rows = det_rows.to(self.dev)
             drows = torch.empty((n_det, H), dtype=bf, device=self.dev)
             ops.copy_rows(hidden.view(B * S, H), drows, n_det, H, idx_src=det_rows)
-            h1 = ops.linear(drows, self._sd["model.text_hidden_fcs.0.0.weight"], self._sd["model.text_hidden_fcs.0.0.bias"], act=ops.ACT_RELU)
-            te = ops.linear(h1, self._sd["model.text_hidden_fcs.0.2.weight"], self._sd["model.text_hidden_fcs.0.2.bias"])
+            if self.decoder.precise:  # the box path in fp32 from the (bf16) hidden rows on, as model_forward(inference=True) runs it
+                h1 = ops.linear_f32(ops.to_f32(drows), self._sd["model.text_hidden_fcs.0.0.weight"], self._sd["model.text_hidden_fcs.0.0.bias"], act=ops.ACT_RELU)
+                te = ops.linear_f32(h1, self._sd["model.text_hidden_fcs.0.2.weight"], self._sd["model.text_hidden_fcs.0.2.bias"])
+            else:
+                h1 = ops.linear(drows, self._sd["model.text_hidden_fcs.0.0.weight"], self._sd["model.text_hidden_fcs.0.0.bias"], act=ops.ACT_RELU)
+                te = ops.linear(h1, self._sd["model.text_hidden_fcs.0.2.weight"], self._sd["model.text_hidden_fcs.0.2.bias"])
             inst_det, inst_frame, base = [], [], 0
             for b in range(B):
                 for t in range(Tseq):
@@ -946,8 +950,11 @@ class GROVEForCausalLM(torch.nn.Module):
                     inst_frame += [b * Tseq + t] * counts[b]
                 base += counts[b]
             N = len(inst_det)
-            text = torch.empty((N, d.out_dim), dtype=bf, device=self.dev)
-            ops.copy_rows(te, text, N, d.out_dim, idx_src=torch.tensor(inst_det, dtype=torch.int32, device=self.dev))
+            if te.dtype == torch.float32:
+                text = te.index_select(0, torch.tensor(inst_det, dtype=torch.int64, device=self.dev))  # (row selection)
+            else:
+                text = torch.empty((N, d.out_dim), dtype=bf, device=self.dev)
+                ops.copy_rows(te, text, N, d.out_dim, idx_src=torch.tensor(inst_det, dtype=torch.int32, device=self.dev))
             box, obj, _ = self.decoder.forward(emb_rows.view(F * g2, -1), Var(text), torch.tensor(inst_frame, dtype=torch.int32, device=self.dev))
             box_c, obj_c, off = box.cpu(), obj.cpu(), 0
             thr = self.config.temp_objectness_threshold
