@@ -150,6 +150,17 @@ def test_full_depth_training_vs_oracle_autograd(dev, which):
     sdg = {k: v.float().cpu().requires_grad_(k in names) for k, v in sd_dev.items()}
     del sd_dev
     ref = O.model_forward(sdg, d, **kw)
+    # diagnostic: how much of a gradient-norm difference on the box path is the LOSS SURFACE at two different forward results (GIoU's
+    # gradient is piecewise smooth: an edge of the enclosing / intersection box changing hands moves it discontinuously), not a backward
+    # defect? d(giou + l1) / d boxes at the oracle's own boxes vs at the HIP path's boxes, both by torch autograd.
+    g0 = torch.autograd.grad(ref["giou_loss"] + ref["l1_loss"], ref["flat_boxes"], retain_graph=True)[0]
+    hb = out["flat_boxes"].detach().float().cpu().requires_grad_(True)
+    nd = hb.shape[0] // 8
+    lc = O.loss_components(torch.zeros(()), [[hb[t * nd:(t + 1) * nd] for t in range(8)]],
+                           [[ref["flat_logits"].detach()[t * nd:(t + 1) * nd] for t in range(8)]], kw["bboxes_list"], kw["temp_objectness_labels_list"])
+    g1 = torch.autograd.grad(lc["giou_loss"] + lc["l1_loss"], hb)[0]
+    box_grad_surface = {"norm_ratio_at_hip_boxes_vs_oracle_boxes": float(g1.norm() / g0.norm()),
+                        "cos": float(torch.nn.functional.cosine_similarity(g1.flatten(), g0.flatten(), dim=0))}
     ref["loss"].backward()
     t_cpu = time.time() - t0
     terms = ("loss", "ce_loss", "giou_loss", "l1_loss", "temp_objectness_loss")
@@ -177,9 +188,13 @@ def test_full_depth_training_vs_oracle_autograd(dev, which):
            "loss_terms_rel_err": loss_rel, "losses": {k: float(out[k]) for k in terms}, "oracle_losses": {k: float(ref[k]) for k in terms},
            "gradient_groups": groups, "whole_gradient": {"cos": float(torch.nn.functional.cosine_similarity(allg, allr, dim=0)),
                                                          "norm_ratio": float(allg.norm() / allr.norm()), "elements": int(allg.numel())},
+           "box_loss_gradient_at_hip_boxes_vs_oracle_boxes": box_grad_surface,
            "box_l1_train_mode_vs_oracle": (out["flat_boxes"].detach().cpu() - ref["flat_boxes"].detach()).abs().mean().item(),
            "objectness_logit_abs_err": (out["flat_logits"].detach().cpu() - ref["flat_logits"].detach()).abs().max().item(),
            "worst_tensors": sorted(((v["cos"], n) for n, v in per_tensor.items() if v["cos"] is not None))[:8],
+           "largest_box_path_tensors": [(n, round(v["cos"], 4), round(v["norm_ratio"], 4), v["ref_norm"]) for n, v in
+                                        sorted(per_tensor.items(), key=lambda kv: -kv[1]["ref_norm"])
+                                        if v["cos"] is not None and ("mask_decoder" in n or "text_hidden_fcs" in n)][:16],
            "oracle_cpu_seconds": round(t_cpu, 1)}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", f"full_depth_training_parity_{which}.json"), "w") as fh:
