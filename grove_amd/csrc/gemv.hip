@@ -49,6 +49,63 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_kernel(const grove_gemv_param
       *(u32x4_t*)(xs + b * K + kc * 8) = u32x4_t{pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
     }
     __syncthreads();
+  } else if (p.x_f32) {
+    // x is the FP32 residual stream of the decode step (round 3: 32 layers of bf16 rounding of the stream put the generated rows'
+    // hidden state at 1.2 % rms from the fp32 oracle against 0.5 % for the prefill rows — tools/decode_precision_probe.py): the
+    // statistics and the normalisation run on the fp32 values, the MFMA-free products on their bf16 rounding as everywhere else
+    const float* __restrict__ XF = (const float*)p.x;
+    const bf16_raw* nw = (const bf16_raw*)p.norm_weight;
+    constexpr int XV = 4;  // float4 chunks a thread keeps: K <= 256 * 4 * XV = 4096 (the 7B hidden size) in ONE pass over global memory (16-byte loads)
+    const int nq = K >> 2;  // (K % 8 == 0)
+    for (int b = 0; b < MX; ++b) {
+      const f32x4_t* xr = (const f32x4_t*)(XF + (int64_t)b * p.ldx);
+      if (nq <= GV_THREADS * XV) {
+        f32x4_t v[XV];
+#pragma unroll
+        for (int i = 0; i < XV; ++i) {
+          const int q = tid + i * GV_THREADS;
+          v[i] = q < nq ? xr[q] : f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
+        float rstd = 1.f;
+        if (p.x_mode == GROVE_GEMV_X_RMSNORM) {
+          float ss = 0.f;
+#pragma unroll
+          for (int i = 0; i < XV; ++i) ss += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+          rstd = rsqrtf(block_sum<GV_THREADS>(ss, red) / (float)K + p.eps);
+        }
+#pragma unroll
+        for (int i = 0; i < XV; ++i) {
+          const int q = tid + i * GV_THREADS;
+          if (q >= nq) continue;
+          float o[4] = {v[i][0], v[i][1], v[i][2], v[i][3]};
+          if (p.x_mode == GROVE_GEMV_X_RMSNORM) {
+            const u32x2_t w2 = *(const u32x2_t*)(nw + q * 4);
+            o[0] *= rstd * bf_lo(w2.x), o[1] *= rstd * bf_hi(w2.x), o[2] *= rstd * bf_lo(w2.y), o[3] *= rstd * bf_hi(w2.y);
+          }
+          *(u32x2_t*)(xs + b * K + q * 4) = u32x2_t{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+        }
+      } else {  // long rows: two passes over global memory
+        float rstd = 1.f;
+        if (p.x_mode == GROVE_GEMV_X_RMSNORM) {
+          float ss = 0.f;
+          for (int q = tid; q < nq; q += GV_THREADS) {
+            const f32x4_t a = xr[q];
+            ss += a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
+          }
+          rstd = rsqrtf(block_sum<GV_THREADS>(ss, red) / (float)K + p.eps);
+        }
+        for (int q = tid; q < nq; q += GV_THREADS) {
+          const f32x4_t a = xr[q];
+          float o[4] = {a[0], a[1], a[2], a[3]};
+          if (p.x_mode == GROVE_GEMV_X_RMSNORM) {
+            const u32x2_t w2 = *(const u32x2_t*)(nw + q * 4);
+            o[0] *= rstd * bf_lo(w2.x), o[1] *= rstd * bf_hi(w2.x), o[2] *= rstd * bf_lo(w2.y), o[3] *= rstd * bf_hi(w2.y);
+          }
+          *(u32x2_t*)(xs + b * K + q * 4) = u32x2_t{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+        }
+      }
+    }
+    __syncthreads();
   } else {
     for (int c = tid; c < MX * (K >> 3); c += GV_THREADS) {
       const int b = c / (K >> 3), kc = c - b * (K >> 3);
@@ -159,7 +216,7 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_kernel(const grove_gemv_param
         float v = acc[r][b];
         if (bias) v += bf2f(bias[n]);
         v = act_apply(p.act, v);
-        if (p.residual) v += bf2f(((const bf16_raw*)p.residual)[(int64_t)b * p.ldr + n]);
+        if (p.residual) v += p.res_f32 ? ((const float*)p.residual)[(int64_t)b * p.ldr + n] : bf2f(((const bf16_raw*)p.residual)[(int64_t)b * p.ldr + n]);
         if (p.y_dtype == GROVE_BF16) ((bf16_raw*)p.y)[(int64_t)b * p.ldy + n] = f2bf(v);
         else ((float*)p.y)[(int64_t)b * p.ldy + n] = v;
       }
@@ -195,6 +252,8 @@ extern "C" int grove_gemv_bf16(const grove_gemv_params* pp, void* stream) {
   GROVE_CHECK(p.N > 0 && p.K > 0 && p.K % 8 == 0, GROVE_E_SHAPE, "gemv: N=%d K=%d (K must be a multiple of 8)", p.N, p.K);
   GROVE_CHECK((size_t)(p.M <= 2 ? p.M : p.M <= 4 ? 4 : 8) * p.K * 2 <= 159 * 1024, GROVE_E_SHAPE, "gemv: M*K=%d*%d does not fit the LDS", p.M, p.K);
   GROVE_CHECK(p.ldx % 8 == 0 && p.ldw % 8 == 0, GROVE_E_ALIGN, "gemv: ldx=%d ldw=%d must be multiples of 8", p.ldx, p.ldw);
+  GROVE_CHECK(!p.x_f32 || p.x_mode != GROVE_GEMV_X_SWIGLU, GROVE_E_DTYPE, "gemv: x_mode swiglu reads a bf16 gate|up row");
+  GROVE_CHECK(!p.x_f32 || (p.ldx % 4 == 0 && ((uintptr_t)p.x & 15) == 0), GROVE_E_ALIGN, "gemv: fp32 x rows must be 16-byte aligned");
   GROVE_CHECK(((uintptr_t)p.x & 15) == 0 && ((uintptr_t)p.W & 15) == 0, GROVE_E_ALIGN, "gemv: x/W must be 16-byte aligned");
   GROVE_CHECK(p.y_dtype == GROVE_BF16 || p.y_dtype == GROVE_F32, GROVE_E_DTYPE, "gemv: bad y_dtype %d", p.y_dtype);
   GROVE_CHECK(p.x_mode >= GROVE_GEMV_X_PLAIN && p.x_mode <= GROVE_GEMV_X_SWIGLU, GROVE_E_SHAPE, "gemv: bad x_mode %d", p.x_mode);

@@ -781,8 +781,9 @@ class GROVEForCausalLM(torch.nn.Module):
             ops.copy_rows(embed, xt, B, H, idx_src=nxt)
             hidden, logits = self.llama.decode_step(xt, t, cache.layers, lm_head)
             cache.length = t + 1
+            h32 = self.llama.last_decode_hidden_f32
             return SimpleNamespace(loss=None, logits=logits.view(B, 1, -1), past_key_values=cache, hidden_states=hidden.view(B, 1, H),
-                                   attentions=None)
+                                   hidden_states_f32=h32.view(B, 1, H) if h32 is not None else None, attentions=None)
         if image_features is None and images is not None:
             image_features, image_forward_outs = self.encode_images(images)
         plan = self._splice_plan(input_ids, None, None, list(range(B)))
@@ -805,7 +806,10 @@ class GROVEForCausalLM(torch.nn.Module):
                       else ops.linear(last, lm_head, out_dtype=torch.float32)).view(B, 1, -1)
         else:
             logits = ops.linear(h0, lm_head).view(B, S, -1)
-        return SimpleNamespace(loss=None, logits=logits, past_key_values=cache, hidden_states=h0.view(B, S, H), attentions=None)
+        # (extra to HF: the same hidden states in fp32, normalised from the fp32 residual stream of an inference model — evaluate()'s box path)
+        f32fn = getattr(self.llama, "_final_norm_f32", None)
+        return SimpleNamespace(loss=None, logits=logits, past_key_values=cache, hidden_states=h0.view(B, S, H),
+                               hidden_states_f32=f32fn().view(B, S, H) if f32fn is not None else None, attentions=None)
 
     @torch.no_grad()
     def generate(self, images=None, input_ids=None, bboxes=None, image_features=None, image_forward_outs=None, images_dtype=None,
@@ -839,18 +843,23 @@ class GROVEForCausalLM(torch.nn.Module):
             nxt = logits.reshape(B, -1).argmax(-1).to(ids.device)  # argmax over one [B, V] row block (index selection, not arithmetic)
             return torch.where(finished, torch.full_like(nxt, pad), nxt)
 
+        hiddens32 = []  # parallel to `hiddens` when the model keeps fp32 residual streams (None entries otherwise)
+
         def result(seqs, hiddens, cache):
             if not return_dict_in_generate:
                 return seqs
+            ok32 = output_hidden_states and len(hiddens32) == len(hiddens) and all(h is not None for h in hiddens32)
             return SimpleNamespace(sequences=seqs, hidden_states=tuple(hiddens) if output_hidden_states else None,
+                                   hidden_states_f32=tuple(hiddens32) if ok32 else None,
                                    past_key_values=cache, scores=None, attentions=None)
 
         if not use_cache or B > 8:
-            hidden, S, S0 = None, 0, None
+            hidden, hidden32, S, S0 = None, None, 0, None
             for _ in range(max_new_tokens):
                 out = self.lm_forward(input_ids=ids, image_features=image_features, token_embeddings=token_embeddings,
                                       use_cache=False, last_logits_only=True)
                 hidden = out.hidden_states
+                hidden32 = out.hidden_states_f32
                 S = hidden.shape[1]
                 S0 = S if S0 is None else S0
                 nxt = pick(out.logits)
@@ -858,12 +867,15 @@ class GROVEForCausalLM(torch.nn.Module):
                 finished = finished | (nxt == eos)
                 if bool(finished.all()):
                     break
+            if hidden32 is not None:
+                hiddens32 += [hidden32[:, :S0]] + [hidden32[:, j:j + 1] for j in range(S0, S)]
             return result(ids, [hidden[:, :S0]] + [hidden[:, j:j + 1] for j in range(S0, S)], None)
 
         out = self.lm_forward(input_ids=ids, image_features=image_features, token_embeddings=token_embeddings, use_cache=True,
                               past_key_values=self.new_kv_cache(B, ids.shape[1] + 575 + max_new_tokens), last_logits_only=True)
         cache = out.past_key_values
         hiddens = [out.hidden_states]
+        hiddens32.append(out.hidden_states_f32)
         logits = out.logits
         if use_graph and max_new_tokens > 1:
             # first token from the prompt step's logits (one host read), every later step on the device: see LlamaStack.greedy_graph
@@ -890,6 +902,7 @@ class GROVEForCausalLM(torch.nn.Module):
             ids = torch.cat([ids, new_ids[:, :used]], 1)
             hid = st["hid_out"][:used]
             hiddens += [hid[j].view(B, 1, H).clone() for j in range(used)]
+            hiddens32 += [st["hid_out_f32"][j].view(B, 1, H).clone() if st["hid_out_f32"] is not None else None for j in range(used)]
             cache.length += used
             return result(ids, hiddens, cache)
         for step in range(max_new_tokens):
@@ -902,6 +915,7 @@ class GROVEForCausalLM(torch.nn.Module):
                                token_embeddings=token_embeddings, use_cache=True)
             logits = out.logits
             hiddens.append(out.hidden_states)
+            hiddens32.append(out.hidden_states_f32)
         return result(ids, hiddens, cache)
 
     def generate_greedy(self, image_features, input_ids, max_new_tokens, token_embeddings=None, eos_token_id=None, pad_token_id=None,
@@ -922,6 +936,8 @@ class GROVEForCausalLM(torch.nn.Module):
             output_hidden_states=True, return_dict_in_generate=True, do_sample=False, use_cache=use_cache, synced_gpus=False)
         ids = generation_outputs.sequences
         hidden = torch.cat(generation_outputs.hidden_states, dim=1).contiguous()  # GROVE.py:423-426
+        h32 = getattr(generation_outputs, "hidden_states_f32", None)
+        hidden32 = torch.cat(h32, dim=1).contiguous() if (h32 is not None and self.decoder.precise) else None
         B, S, H = hidden.shape
         det_rows, counts = self._det_rows(ids.cpu(), S, trailing_pad=False)
         Tseq = self.config.num_frames
@@ -937,8 +953,10 @@ class GROVEForCausalLM(torch.nn.Module):
             det_rows = det_rows.to(self.dev)
             drows = torch.empty((n_det, H), dtype=bf, device=self.dev)
             ops.copy_rows(hidden.view(B * S, H), drows, n_det, H, idx_src=det_rows)
-            if self.decoder.precise:  # the box path in fp32 from the (bf16) hidden rows on, as model_forward(inference=True) runs it
-                h1 = ops.linear_f32(ops.to_f32(drows), self._sd["model.text_hidden_fcs.0.0.weight"], self._sd["model.text_hidden_fcs.0.0.bias"], act=ops.ACT_RELU)
+            if self.decoder.precise:  # the box path in fp32, as model_forward(inference=True) runs it: from the fp32 hidden rows of the
+                # fp32 residual streams (prefill AND cached decode steps) when the model keeps them, else from the bf16 rows
+                rows32 = hidden32.view(B * S, H).index_select(0, det_rows.long()) if hidden32 is not None else ops.to_f32(drows)
+                h1 = ops.linear_f32(rows32, self._sd["model.text_hidden_fcs.0.0.weight"], self._sd["model.text_hidden_fcs.0.0.bias"], act=ops.ACT_RELU)
                 te = ops.linear_f32(h1, self._sd["model.text_hidden_fcs.0.2.weight"], self._sd["model.text_hidden_fcs.0.2.bias"])
             else:
                 h1 = ops.linear(drows, self._sd["model.text_hidden_fcs.0.0.weight"], self._sd["model.text_hidden_fcs.0.0.bias"], act=ops.ACT_RELU)

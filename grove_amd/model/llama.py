@@ -133,10 +133,12 @@ class LlamaStack:
             xl = torch.empty_like(x) if save else None
             out = ops.rmsnorm(t, self.norm, d.rms_eps, res=res, res_bf16=xl)
             self.last_stream = res  # fp32 pre-norm stream of this forward: the box path re-normalises its [DET] rows in fp32
+            self._final_norm_f32 = lambda: ops.rmsnorm(None, self.norm, d.rms_eps, res=res, out_dtype=torch.float32)
         else:
             xl = x
             out = ops.rmsnorm(x, self.norm, d.rms_eps)
             self.last_stream = x
+            self._final_norm_f32 = None
         ctx = (saved, xl, pos, B, S) if save else None
         return out, ctx
 
@@ -152,17 +154,30 @@ class LlamaStack:
         sequence can be replayed from a captured HIP graph."""
         d = self.d
         nh, hd = d.n_heads, d.head_dim
+        # Residual stream of the step (self.fp32_stream, as in forward()): FP32 for inference models — x arrives as the bf16 embedding,
+        # is widened once, every GEMV that reads it normalises the fp32 values, o_proj / down add into it in fp32 — so the 64
+        # residual adds of a token are not rounded to bf16 one by one (generated rows: hidden state 1.18 % -> see DESIGN 7a);
+        # bf16 (what the reference stores) for training models.
+        f32 = self.fp32_stream
+        sdt = torch.float32 if f32 else torch.bfloat16
+        if f32 and x.dtype != torch.float32:
+            x = ops.to_f32(x)
         for L, kv in zip(self.layers, kv_cache):
             qkv = ops.gemv(x, L["wqkv"], rms_weight=L["ln1"], eps=d.rms_eps)
             o = ops.decode_attn(qkv, kv, pos, nh, hd, d.rope_theta, hd ** -0.5)
-            x1 = ops.gemv(o, L["wo"], residual=x)
+            x1 = ops.gemv(o, L["wo"], residual=x, out_dtype=sdt)
             if "wgu_sw" in L and (2 * d.mlp) % 16 == 0:  # SwiGLU in the gate|up GEMV's epilogue (rows interleaved 4 gate / 4 up)
                 a = ops.gemv(x1, L["wgu_sw"], rms_weight=L["ln2"], eps=d.rms_eps, act=ops.ACT_SWIGLU_PAIR)
-                x = ops.gemv(a, L["wd"], residual=x1)
+                x = ops.gemv(a, L["wd"], residual=x1, out_dtype=sdt)
             else:
                 gu = ops.gemv(x1, L["wgu"], rms_weight=L["ln2"], eps=d.rms_eps)
-                x = ops.gemv(gu, L["wd"], residual=x1, swiglu=True)
-        out = ops.rmsnorm(x, self.norm, d.rms_eps)
+                x = ops.gemv(gu, L["wd"], residual=x1, swiglu=True, out_dtype=sdt)
+        if f32:
+            out = ops.rmsnorm(None, self.norm, d.rms_eps, res=x)
+            self.last_decode_hidden_f32 = ops.rmsnorm(None, self.norm, d.rms_eps, res=x, out_dtype=torch.float32)  # the box path's rows
+        else:
+            out = ops.rmsnorm(x, self.norm, d.rms_eps)
+            self.last_decode_hidden_f32 = None
         logits = ops.gemv(x, lm_head, out_dtype=torch.float32, rms_weight=self.norm, eps=d.rms_eps) if lm_head is not None else None
         return out, logits
 
@@ -216,6 +231,7 @@ class LlamaStack:
         finished = finished0.clone()
         ids_out = torch.full((B, max_steps), int(pad), dtype=torch.int64, device=dev)
         hid_out = torch.zeros((max_steps, B, H), dtype=torch.bfloat16, device=dev)
+        hid32 = torch.zeros((max_steps, B, H), dtype=torch.float32, device=dev) if self.fp32_stream else None
         x_in = torch.empty((B, H), dtype=torch.bfloat16, device=dev)
         pad_t = torch.full((B,), int(pad), dtype=torch.int64, device=dev)
 
@@ -226,6 +242,8 @@ class LlamaStack:
             nxt = torch.where(finished, pad_t, nxt)
             finished.logical_or_(nxt == eos)
             hid_out.index_copy_(0, step_i, out.view(1, B, H))
+            if hid32 is not None:
+                hid32.index_copy_(0, step_i, self.last_decode_hidden_f32.view(1, B, H))
             ids_out.index_copy_(1, step_i, nxt.view(B, 1))
             tok.copy_(nxt)
             pos.add_(1)
@@ -242,7 +260,7 @@ class LlamaStack:
             body()
         # the graph's nodes hold raw ADDRESSES: every tensor they touch must outlive the replays (dropping tok / pos / x_in here hands
         # their memory back to the allocator while the graph still reads and writes it)
-        return graph.replay, dict(ids_out=ids_out, hid_out=hid_out, finished=finished, step=step_i,
+        return graph.replay, dict(ids_out=ids_out, hid_out=hid_out, hid_out_f32=hid32, finished=finished, step=step_i,
                                   _keep=(graph, tok, pos, x_in, pad_t, kv_cache, embed, lm_head))
 
     def backward(self, ctx, d_out):

@@ -339,14 +339,16 @@ def flash_attn(qkv, B, L, H, hs, q_off, k_off, v_off, alpha, *, causal=False, kv
 
 def gemv(x, w, bias=None, *, act=ACT_NONE, residual=None, out_dtype=bf16, out=None, rms_weight=None, eps=0.0, swiglu=False):
     """y = act(x' @ w.T + bias) + residual for 1..8 rows of x (the cached decode step): the weight-streaming kernel.
-    x' = x, or rmsnorm(x) * rms_weight (rms_weight given), or silu(gate) * up of a fused [M, 2K] row (swiglu=True)."""
+    x' = x, or rmsnorm(x) * rms_weight (rms_weight given), or silu(gate) * up of a fused [M, 2K] row (swiglu=True).
+    x and residual may be fp32 (the decode step's fp32 residual stream): norm statistics then run on the fp32 values."""
     _chk_dev(x, w)
     M = x.shape[0]
     N, K = w.shape
     assert x.shape[1] == (2 * K if swiglu else K) and x.stride(1) == 1 and w.stride(1) == 1
+    assert x.dtype in (bf16, torch.float32) and (residual is None or residual.dtype in (bf16, torch.float32))
     mx = 1 if M == 1 else 2 if M == 2 else 4 if M <= 4 else 8
     if mx != M:  # the kernel reads mx rows
-        xp = torch.zeros((mx, x.shape[1]), dtype=bf16, device=x.device)
+        xp = torch.zeros((mx, x.shape[1]), dtype=x.dtype, device=x.device)
         xp[:M] = x
         x = xp
     if out is None:  # ACT_SWIGLU_PAIR: w rows interleaved [4 gate, 4 up] (swiglu_interleave), the result is silu(gate) * up: N / 2 columns
@@ -360,6 +362,8 @@ def gemv(x, w, bias=None, *, act=ACT_NONE, residual=None, out_dtype=bf16, out=No
     p.y_dtype = F32 if out.dtype == torch.float32 else BF16
     p.norm_weight, p.eps = _p(rms_weight), float(eps)
     p.x_mode = 2 if swiglu else 1 if rms_weight is not None else 0
+    p.x_f32 = int(x.dtype == torch.float32)
+    p.res_f32 = int(residual is not None and residual.dtype == torch.float32)
     _lib.check(_lib.lib().grove_gemv_bf16(C.byref(p), _stream()), "grove_gemv_bf16")
     return out
 

@@ -438,6 +438,9 @@ typedef struct grove_gemv_params {
   int32_t y_dtype; /* GROVE_BF16 / GROVE_F32 */
   int32_t x_mode;  /* grove_gemv_x_mode */
   float eps;
+  /* the decode step's residual stream in FP32 (inference models): x is f32 [M, ldx] (x_mode PLAIN / RMSNORM: statistics and
+   * normalisation on the fp32 values), residual is f32 [M, ldr]; combine with y_dtype F32 for the stream's next value */
+  int32_t x_f32, res_f32;
 } grove_gemv_params;
 int grove_gemv_bf16(const grove_gemv_params* p, void* stream);
 

@@ -874,6 +874,7 @@ def test_gemv_fused_rmsnorm_and_swiglu(dev):
     from grove_amd import ops
     M, K, N = 2, 1024, 520
     x, w, nw = rnd(M, K, seed=1).to(dev), rnd(N, K, seed=2, scale=0.05).to(dev), rnd(K, seed=3).to(dev)
+    nw0 = nw
     y = ops.gemv(x, w, rms_weight=nw, eps=1e-5)
     y_ref = ops.gemv(ops.rmsnorm(x, nw, 1e-5), w)
     close(y, y_ref, 2 ** -8, "gemv rmsnorm-fused vs rmsnorm kernel + gemv")
@@ -891,6 +892,17 @@ def test_gemv_fused_rmsnorm_and_swiglu(dev):
     ref = ops.swiglu(ops.gemv(xs, wgu, rms_weight=nw, eps=1e-5), I)
     got = ops.gemv(xs, ops.swiglu_interleave(wgu), rms_weight=nw, eps=1e-5, act=ops.ACT_SWIGLU_PAIR)
     assert got.shape == (M, I) and torch.equal(got, ref), (got.float() - ref.float()).abs().max().item()
+    # the decode step's FP32 residual stream (round 3): x fp32 with the norm folded (statistics on the fp32 values), fp32 residual, fp32 out
+    xf32 = (x.float() * 1.001).contiguous()                      # values that are NOT bf16-representable
+    res32 = rnd(M, N, seed=31).to(dev).float() * 1.003
+    y32 = ops.gemv(xf32, w, rms_weight=nw0, eps=1e-5, residual=res32, out_dtype=torch.float32)
+    xc = xf32.cpu()
+    refn = (xc * torch.rsqrt(xc.pow(2).mean(-1, keepdim=True) + 1e-5) * nw0.float().cpu()).to(bf16).float()
+    ref32 = refn @ w.float().cpu().t() + res32.cpu()
+    assert y32.dtype == torch.float32
+    close(y32, ref32, 2 ** -10, "gemv with fp32 x (norm folded) + fp32 residual vs fp32")
+    yp = ops.gemv(xf32, w, out_dtype=torch.float32)               # plain fp32 x: rounded to bf16 for the products
+    close(yp, xc.to(bf16).float() @ w.float().cpu().t(), 2 ** -10, "gemv with plain fp32 x")
 
 
 @pytest.mark.parametrize("B,H,hd,t,Smax", [(2, 4, 32, 36, 64), (1, 8, 128, 699, 768), (3, 2, 64, 0, 16), (2, 32, 128, 1500, 2048)])
