@@ -145,6 +145,12 @@ class GemmFp8Params(C.Structure):
                 ("M", c_i32), ("N", c_i32), ("K", c_i32), ("lda", c_i32), ("ldb", c_i32), ("ldc", c_i32), ("ldr", c_i32), ("act", c_i32)]
 
 
+class GreedyPickParams(C.Structure):
+    _fields_ = [("logits", c_vp), ("ld_logits", c_i64), ("finished", c_vp), ("tok", c_vp), ("pos", c_vp), ("ids_out", c_vp), ("ld_ids", c_i64),
+                ("hidden", c_vp), ("hid_out", c_vp), ("hidden_f32", c_vp), ("hid_out_f32", c_vp),
+                ("B", c_i32), ("V", c_i32), ("H", c_i32), ("eos", c_i32), ("pad", c_i32), ("pos0", c_i32), ("max_steps", c_i32)]
+
+
 class GemmWorkspace(C.Structure):
     _fields_ = [("image", c_vp), ("image_bytes", C.c_size_t), ("scratch", c_vp), ("scratch_bytes", C.c_size_t)]
 
@@ -162,12 +168,12 @@ STRUCTS = {
     "grove_box_head_bwd_params": BoxHeadBwdParams, "grove_flash_attn_params": FlashAttnParams,
     "grove_gemm_tn_params": GemmTnParams, "grove_gemv_params": GemvParams, "grove_decode_attn_params": DecodeAttnParams, "grove_resample_params": ResampleParams,
     "grove_normalize_params": NormalizeParams, "grove_gemm_f32_params": GemmF32Params, "grove_gemm_fp8_params": GemmFp8Params,
-    "grove_gemm_workspace": GemmWorkspace, "grove_gemm_plan": GemmPlan,
+    "grove_gemm_workspace": GemmWorkspace, "grove_gemm_plan": GemmPlan, "grove_greedy_pick_params": GreedyPickParams,
 }
 
 # every symbol include/grove_hip.h declares (tests/test_abi.py checks the header against this list)
 SYMBOLS = [
-    "grove_version", "grove_last_error", "grove_sizeof", "grove_gemm_bf16", "grove_gemm_make_plan", "grove_gemm_plan_image", "grove_gemm_workspace_bytes", "grove_gemm_fp8_make_plan", "grove_gemm_fp8_plan_image", "grove_gemm_last_variant", "grove_gemm_last_epilogue", "grove_gemm_set_staging", "grove_gemm_set_stream_k", "grove_gemm_set_persistent_blocks", "grove_gemm_work_list", "grove_gemm_last_stream_k", "grove_gemm_set_tile_n", "grove_gemm_set_tile_m", "grove_gemm_set_bk", "grove_gemm_tn_bf16", "grove_gemm_tn_set_pipelined", "grove_gemm_tn_set_split_tail", "grove_gemm_tn_last_parts", "grove_gemv_bf16", "grove_decode_attn", "grove_resample_u8", "grove_normalize_pack",
+    "grove_version", "grove_last_error", "grove_sizeof", "grove_gemm_bf16", "grove_gemm_make_plan", "grove_gemm_plan_image", "grove_gemm_workspace_bytes", "grove_gemm_fp8_make_plan", "grove_gemm_fp8_plan_image", "grove_gemm_last_variant", "grove_gemm_last_epilogue", "grove_gemm_set_staging", "grove_gemm_set_stream_k", "grove_gemm_set_persistent_blocks", "grove_gemm_work_list", "grove_gemm_last_stream_k", "grove_gemm_set_tile_n", "grove_gemm_set_tile_m", "grove_gemm_set_bk", "grove_gemm_tn_bf16", "grove_gemm_tn_set_pipelined", "grove_gemm_tn_set_split_tail", "grove_gemm_tn_last_parts", "grove_gemv_bf16", "grove_decode_attn", "grove_greedy_pick", "grove_resample_u8", "grove_normalize_pack",
     "grove_transpose_bf16", "grove_layernorm_fwd", "grove_rmsnorm_fwd", "grove_layernorm_bwd", "grove_rmsnorm_bwd",
     "grove_flash_attn_fwd", "grove_flash_attn_bwd", "grove_flash_attn_set_window_kernels", "grove_flash_attn_window_kernels_on", "grove_softmax_fwd", "grove_softmax_bwd", "grove_relpos_fwd", "grove_relpos_bwd", "grove_rel_bias_fwd", "grove_rel_bias_bwd", "grove_rope_inplace",
     "grove_swiglu_fwd", "grove_swiglu_bwd", "grove_act_bwd", "grove_act_fwd", "grove_resize_bilinear_f32", "grove_add_bf16", "grove_add_bcast_rows",

@@ -46,6 +46,7 @@ extern "C" int grove_sizeof(const char* name) {
   SZ(grove_normalize_params);
   SZ(grove_gemm_f32_params);
   SZ(grove_gemm_fp8_params);
+  SZ(grove_greedy_pick_params);
   SZ(grove_gemm_workspace);
   SZ(grove_gemm_plan);
 #undef SZ

@@ -508,6 +508,66 @@ __global__ __launch_bounds__(HD) void decode_attn_merge_kernel(const grove_decod
 }
 }  // namespace
 
+// ----------------------------------------------------------------------------------------------------------------------
+// One launch for everything HF's greedy loop does between two decoder steps (GenerationMixin greedy search as GROVE.py:418-422 drives
+// it): argmax over the [V] logits of every sequence (first maximum), finished rows emit pad, a row finishes at eos, the token becomes
+// the next input, the position advances, and the step's id / hidden row are filed under the step number (= pos - pos0: no counter
+// shared between blocks). One block per sequence. Replaces nine small torch launches per generated token inside the captured step.
+// ----------------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int GP_THREADS = 1024;
+__global__ __launch_bounds__(GP_THREADS) void greedy_pick_kernel(const grove_greedy_pick_params p) {
+  __shared__ float vmax[GP_THREADS / 64];
+  __shared__ int imax[GP_THREADS / 64];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* lg = p.logits + (int64_t)b * p.ld_logits;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int i = tid; i < p.V; i += GP_THREADS) {
+    const float v = lg[i];
+    if (v > best || (v == best && i < bi)) best = v, bi = i;  // (NaN never wins: torch.argmax would return it; logits are finite here)
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ov = __shfl_xor(best, off, 64);
+    const int oi = __shfl_xor(bi, off, 64);
+    if (ov > best || (ov == best && oi < bi)) best = ov, bi = oi;
+  }
+  if (lane == 0) vmax[wave] = best, imax[wave] = bi;
+  __syncthreads();
+  const int step = p.pos[b] - p.pos0;  // (read by every thread before thread 0 advances it below: barrier first)
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < GP_THREADS / 64; ++w)
+      if (vmax[w] > best || (vmax[w] == best && imax[w] < bi)) best = vmax[w], bi = imax[w];
+    int nxt = p.finished[b] ? p.pad : bi;
+    if (nxt == p.eos) p.finished[b] = 1;
+    p.tok[b] = nxt;
+    p.pos[b] = p.pos0 + step + 1;
+    if (step >= 0 && step < p.max_steps) p.ids_out[(int64_t)b * p.ld_ids + step] = (int64_t)nxt;
+  }
+  if (step < 0 || step >= p.max_steps) return;
+  if (p.hidden && p.hid_out) {
+    const bf16_raw* src = (const bf16_raw*)p.hidden + (int64_t)b * p.H;
+    bf16_raw* dst = (bf16_raw*)p.hid_out + ((int64_t)step * p.B + b) * p.H;
+    for (int i = tid; i < p.H; i += GP_THREADS) dst[i] = src[i];
+  }
+  if (p.hidden_f32 && p.hid_out_f32) {
+    const float* src = p.hidden_f32 + (int64_t)b * p.H;
+    float* dst = p.hid_out_f32 + ((int64_t)step * p.B + b) * p.H;
+    for (int i = tid; i < p.H; i += GP_THREADS) dst[i] = src[i];
+  }
+}
+}  // namespace
+
+extern "C" int grove_greedy_pick(const grove_greedy_pick_params* pp, void* stream) {
+  GROVE_CHECK(pp && pp->logits && pp->finished && pp->tok && pp->pos && pp->ids_out && pp->B > 0 && pp->V > 0 && pp->max_steps > 0, GROVE_E_SHAPE,
+              "greedy_pick: bad arguments");
+  hipLaunchKernelGGL(greedy_pick_kernel, dim3(pp->B), dim3(GP_THREADS), 0, (hipStream_t)stream, *pp);
+  GROVE_LAUNCH_CHECK();
+  return GROVE_OK;
+}
+
 extern "C" int grove_decode_attn(const grove_decode_attn_params* pp, void* stream) {
   GROVE_CHECK(pp != nullptr, GROVE_E_SHAPE, "decode_attn: null params");
   const grove_decode_attn_params& p = *pp;

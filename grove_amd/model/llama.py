@@ -217,51 +217,42 @@ class LlamaStack:
 
     def greedy_graph(self, B, kv_cache, embed, lm_head, first_tok, t0, max_steps, vocab, eos, pad, finished0):
         """The WHOLE greedy step on the device, captured once: embedding gather of the current token -> the cached step
-        (_decode_body) -> argmax over the [B, V] logits -> HF's finished / pad bookkeeping -> the token, its position and the step
-        counter advance in place, the step's final-norm hidden row and the picked id land in `hid_out[step]` / `ids_out[:, step]`.
+        (_decode_body) -> grove_greedy_pick: argmax over the [B, V] logits, HF's finished / pad bookkeeping, the token and its
+        position advance in place, the step's final-norm hidden row and the picked id land in `hid_out[step]` / `ids_out[:, step]`.
         Nothing per token comes back to the host, so a run of steps is a run of graph replays with no stream sync between them
         (round 2 read `finished.all()` and the argmax back every token: the GPU idled while the host queued the next replay).
-        Returns (replay, state): state = dict(ids_out [B, max_steps] int64, hid_out [max_steps, B, H], finished [B] bool,
-        step [1] int64). The warm-up pass is the real first step (see decode_graph), so the capture starts at step 0 again with
+        Returns (replay, state): state = dict(ids_out [B, max_steps] int64, hid_out [max_steps, B, H] (+ hid_out_f32 for fp32-stream
+        models), finished [B] bool, pos [B] int32). The warm-up pass is the real first step (see decode_graph), so the capture starts at step 0 again with
         the state rewound — the K|V row it appended is rewritten with identical bytes."""
         dev, H = self.dev, self.d.hidden
         tok = first_tok.to(torch.int32).clone()
         pos = torch.full((B,), int(t0), dtype=torch.int32, device=dev)
-        step_i = torch.zeros(1, dtype=torch.int64, device=dev)
         finished = finished0.clone()
         ids_out = torch.full((B, max_steps), int(pad), dtype=torch.int64, device=dev)
         hid_out = torch.zeros((max_steps, B, H), dtype=torch.bfloat16, device=dev)
         hid32 = torch.zeros((max_steps, B, H), dtype=torch.float32, device=dev) if self.fp32_stream else None
         x_in = torch.empty((B, H), dtype=torch.bfloat16, device=dev)
-        pad_t = torch.full((B,), int(pad), dtype=torch.int64, device=dev)
 
         def body():
             ops.copy_rows(embed, x_in, B, H, idx_src=tok)
             out, logits = self._decode_body(x_in, pos, kv_cache, lm_head)
-            nxt = logits.view(B, -1)[:, :vocab].argmax(-1)          # index selection over one [B, V] block, as generate()'s pick
-            nxt = torch.where(finished, pad_t, nxt)
-            finished.logical_or_(nxt == eos)
-            hid_out.index_copy_(0, step_i, out.view(1, B, H))
-            if hid32 is not None:
-                hid32.index_copy_(0, step_i, self.last_decode_hidden_f32.view(1, B, H))
-            ids_out.index_copy_(1, step_i, nxt.view(B, 1))
-            tok.copy_(nxt)
-            pos.add_(1)
-            step_i.add_(1)
+            # argmax + finished / pad bookkeeping + filing the id and the hidden row(s) under the step number + tok / pos advance: one launch
+            ops.greedy_pick(logits.view(B, -1), vocab, finished, tok, pos, ids_out, eos, pad, int(t0), hidden=out, hid_out=hid_out,
+                            hidden_f32=self.last_decode_hidden_f32 if hid32 is not None else None, hid_out_f32=hid32)
         keep = (tok.clone(), finished.clone())
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             body()                                                  # warm-up = the real step 0
         torch.cuda.current_stream(dev).wait_stream(side)
-        tok.copy_(keep[0]); finished.copy_(keep[1]); pos.fill_(int(t0)); step_i.zero_()
+        tok.copy_(keep[0]); finished.copy_(keep[1]); pos.fill_(int(t0))
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             body()
         # the graph's nodes hold raw ADDRESSES: every tensor they touch must outlive the replays (dropping tok / pos / x_in here hands
         # their memory back to the allocator while the graph still reads and writes it)
-        return graph.replay, dict(ids_out=ids_out, hid_out=hid_out, hid_out_f32=hid32, finished=finished, step=step_i,
-                                  _keep=(graph, tok, pos, x_in, pad_t, kv_cache, embed, lm_head))
+        return graph.replay, dict(ids_out=ids_out, hid_out=hid_out, hid_out_f32=hid32, finished=finished, pos=pos,
+                                  _keep=(graph, tok, pos, x_in, kv_cache, embed, lm_head))
 
     def backward(self, ctx, d_out):
         """dgrad through the frozen stack. d_out: bf16 [B*S, H] gradient of the post-norm hidden.

@@ -368,6 +368,20 @@ def gemv(x, w, bias=None, *, act=ACT_NONE, residual=None, out_dtype=bf16, out=No
     return out
 
 
+def greedy_pick(logits, V, finished, tok, pos, ids_out, eos, pad, pos0, hidden=None, hid_out=None, hidden_f32=None, hid_out_f32=None):
+    """HF's greedy bookkeeping between two decoder steps in one launch (grove_greedy_pick): everything in place on device tensors."""
+    B = logits.shape[0]
+    assert logits.dtype == torch.float32 and finished.dtype == torch.bool and tok.dtype == torch.int32 and pos.dtype == torch.int32
+    assert ids_out.dtype == torch.int64 and ids_out.stride(1) == 1
+    p = _lib.GreedyPickParams()
+    p.logits, p.ld_logits, p.finished, p.tok, p.pos = _p(logits), logits.stride(0), _p(finished), _p(tok), _p(pos)
+    p.ids_out, p.ld_ids = _p(ids_out), ids_out.stride(0)
+    p.hidden, p.hid_out, p.hidden_f32, p.hid_out_f32 = _p(hidden), _p(hid_out), _p(hidden_f32), _p(hid_out_f32)
+    p.B, p.V, p.H = B, int(V), int(hidden.shape[-1]) if hidden is not None else (int(hidden_f32.shape[-1]) if hidden_f32 is not None else 0)
+    p.eos, p.pad, p.pos0, p.max_steps = int(eos), int(pad), int(pos0), int(ids_out.shape[1])
+    _lib.check(_lib.lib().grove_greedy_pick(C.byref(p), _stream()), "grove_greedy_pick")
+
+
 _decode_partial = {}  # (device index, floats) -> f32 scratch of the split decode attention (launches of a stream are ordered: shared)
 
 

@@ -465,6 +465,27 @@ typedef struct grove_decode_attn_params {
 } grove_decode_attn_params;
 int grove_decode_attn(const grove_decode_attn_params* p, void* stream);
 
+/* HF greedy search between two decoder steps, on the device (GenerationMixin as GROVE.py:418-422 uses it: num_beams 1, do_sample
+ * False; llava_llama.py:144-180 feeds the picked token back): per sequence b — nxt = finished[b] ? pad : argmax(logits[b, :V]) (first
+ * maximum); finished[b] |= nxt == eos; tok[b] = nxt; step = pos[b] - pos0; ids_out[b, step] = nxt; hid_out[step, b, :] = hidden[b, :]
+ * (bf16, and the fp32 pair when given); pos[b] += 1. Everything is device data, so the whole decode step — gather, 32 layers, this —
+ * replays from one HIP graph with no host read-back per token. */
+typedef struct grove_greedy_pick_params {
+  const float* logits;     /* f32 [B, ld_logits] */
+  int64_t ld_logits;
+  uint8_t* finished;       /* [B] 0 / 1 (torch.bool storage) */
+  int32_t* tok;            /* [B] out */
+  int32_t* pos;            /* [B] in / out */
+  int64_t* ids_out;        /* [B, ld_ids] */
+  int64_t ld_ids;
+  const void* hidden;      /* bf16 [B, H] or NULL */
+  void* hid_out;           /* bf16 [max_steps, B, H] or NULL */
+  const float* hidden_f32; /* f32 [B, H] or NULL */
+  float* hid_out_f32;      /* f32 [max_steps, B, H] or NULL */
+  int32_t B, V, H, eos, pad, pos0, max_steps;
+} grove_greedy_pick_params;
+int grove_greedy_pick(const grove_greedy_pick_params* p, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Frame preprocessing on the device. One separable pass of Pillow's 8-bit resampler
  * (ImagingResample: 22-bit fixed-point coefficients, half-up rounding, uint8 clamp) over uint8 RGB frames

@@ -1384,3 +1384,29 @@ def test_gemm_stream_k_shape_inside_a_stream_capture(dev):
     finally:
         L.grove_gemm_set_tile_m(0)
         L.grove_gemm_set_stream_k(1)
+
+
+def test_greedy_pick_is_hf_greedy_bookkeeping(dev):
+    """grove_greedy_pick against the torch ops it replaces in the captured decode step: first-maximum argmax over V columns of a wider row,
+    finished rows emit pad, a row finishes at eos, token / position advance, id and hidden rows filed under step = pos - pos0."""
+    from grove_amd import ops
+    B, V, ld, H, steps, pos0 = 3, 1000, 1024, 64, 5, 17
+    g = torch.Generator().manual_seed(4)
+    logits = torch.randn(B, ld, generator=g)
+    logits[:, V:] = 100.0                      # columns beyond V must be ignored
+    logits[0, 123] = logits[0, 777] = 50.0     # a tie: the FIRST maximum wins
+    logits[1, 2] = 60.0                        # row 1 picks eos (= 2) -> finishes
+    logits = logits.to(dev)
+    finished = torch.tensor([False, False, True], device=dev)   # row 2 was finished before: emits pad whatever its logits say
+    tok = torch.zeros(B, dtype=torch.int32, device=dev)
+    pos = torch.full((B,), pos0 + 3, dtype=torch.int32, device=dev)  # step 3
+    ids_out = torch.full((B, steps), -7, dtype=torch.int64, device=dev)
+    hidden = torch.randn(B, H, generator=g).to(bf16).to(dev)
+    hidden32 = torch.randn(B, H, generator=g).to(dev)
+    hid_out = torch.zeros(steps, B, H, dtype=bf16, device=dev)
+    hid32_out = torch.zeros(steps, B, H, device=dev)
+    ops.greedy_pick(logits, V, finished, tok, pos, ids_out, eos=2, pad=0, pos0=pos0, hidden=hidden, hid_out=hid_out, hidden_f32=hidden32, hid_out_f32=hid32_out)
+    torch.cuda.synchronize()
+    assert tok.tolist() == [123, 2, 0] and finished.tolist() == [False, True, True] and pos.tolist() == [pos0 + 4] * 3
+    assert ids_out[:, 3].tolist() == [123, 2, 0] and (ids_out[:, [0, 1, 2, 4]] == -7).all()
+    assert torch.equal(hid_out[3], hidden) and torch.equal(hid32_out[3], hidden32) and hid_out[[0, 1, 2, 4]].abs().sum() == 0
