@@ -264,6 +264,29 @@ def test_sliding_window_inference_driver(setup, dev):
     assert n_box > 0
 
 
+def test_inference_job_over_a_clip_list_matches_per_clip_driver(setup, dev):
+    """infer_dataset (the job of infer_iground.py:150-293 around the per-clip driver): a list of clips through the single-process form gives,
+    per clip id, exactly what infer_clip gives for that clip (host tensors, frame order); the two-rank form is tests/test_distributed_cpu.py."""
+    from grove_amd.infer import infer_clip, infer_dataset
+    from grove_amd.synthetic import synthetic_batch
+    model, sd, d = setup
+    clips = []
+    for seed in (11, 12):
+        b = synthetic_batch(d, B=1, T=16, L=24, n_det=2, seed=seed)
+        clips.append((f"vid{seed}", b.global_enc_images.to(bf), b.grounding_enc_images.to(bf), b.original_size_list[0]))
+    prompt = synthetic_batch(d, B=1, T=16, L=24, n_det=2, seed=11).input_ids[0, :20].clone()
+    seen = []
+    res = infer_dataset(model, clips, prompt, max_tokens_new=3, on_clip=lambda cid, r: seen.append(cid))
+    assert sorted(res) == ["vid11", "vid12"] and seen == ["vid11", "vid12"]
+    for cid, g_all, s_all, size in clips:
+        one = infer_clip(model, g_all.to(dev), s_all.to(dev), prompt, size, max_tokens_new=3)
+        r = res[cid]
+        assert r["frame_indices"] == one["frame_indices"] == list(range(16)) and torch.equal(r["output_ids"], one["output_ids"].cpu())
+        for f in range(16):
+            assert not r["pred_bboxes"][f].is_cuda and torch.equal(r["pred_bboxes"][f], one["pred_bboxes"][f].cpu())
+            assert torch.equal(r["logits_temp_objectness"][f], one["logits_temp_objectness"][f].cpu())
+
+
 def test_full_width_towers_match_oracle(dev):
     """The three towers at the REAL widths (LLaMA 4096 / 11008, CLIP 1024 / 4096, SAM 1280 / 5120, 16 x 80 heads, 14 x 14 windows)
     with the depths cut to what one pass needs (1 LLaMA layer, 3 CLIP layers + their adapter, 1 windowed + 1 global SAM block, 1 adapter), against
