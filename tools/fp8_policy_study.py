@@ -38,7 +38,7 @@ def r16(x):
 
 
 class Policy:
-    def __init__(self, name, clip8=True, llama8=True, det16=False, kv16=False, last_bf16=0, blk=0, first_bf16=0, o16=False, down16=False):
+    def __init__(self, name, clip8=True, llama8=True, det16=False, kv16=False, last_bf16=0, blk=0, first_bf16=0, o16=False, down16=False, det_from=0):
         self.__dict__.update(locals())
 
 
@@ -112,7 +112,7 @@ def main():
             if full16:
                 return lin16(h, w)
             y = lin8(h, w, None, pol)
-            if pol.det16:
+            if pol.det16 and li >= pol.det_from:
                 for b in range(Bc):
                     y[b, det_pos[b]] = lin16(h[b, det_pos[b]], w)
             return y
@@ -146,6 +146,9 @@ def main():
             Policy("last2", last_bf16=2), Policy("last8", last_bf16=8),
             Policy("det16 last4", det16=True, last_bf16=4),
             Policy("det16_kv16_o16", det16=True, kv16=True, o16=True),
+            Policy("kv16 only", kv16=True),
+            Policy("kv16 + det16 from layer 16", det16=True, kv16=True, det_from=16),
+            Policy("kv16 + det16 from layer 24", det16=True, kv16=True, det_from=24),
             ]
     rows = []
     with torch.no_grad():
