@@ -1117,11 +1117,209 @@ __global__ __launch_bounds__(64 * FIX_WAVES) void gemm_pp_fixup_kernel(const gro
   else gemm_epilogue_wide<MIH, BMH, ACT>(p, acc, mw0, nw0, fr, fq, ACT < 0 ? 1.f : scale);
 }
 
+#ifdef GROVE_EXPERIMENT_W4
+// =====================================================================================================
+// EXPERIMENT (round 3), compiled only with -DGROVE_EXPERIMENT_W4 (`make W4=1`; tools/bench_gemm.py waves): measured 10-25 % SLOWER than
+// the eight-wave kernel above, bit-identical results. Kept as the record of why: DESIGN.md section 7a "four-wave form".
+// FOUR-WAVE form of the 256 x 256 kernel: ONE wave per SIMD, wave tile 128 x 128 (two of the eight-wave kernel's wave tiles side by
+// side), 512 registers per wave. Same work list, same epilogues and same stream-K slots as the eight-wave kernel (wave (wr, wc2) here
+// = waves (wr, 2 wc2) and (wr, 2 wc2 + 1) there) and the same sum order, so the two are interchangeable per launch, bit for bit.
+// What changes is the K loop. There is no second wave on the SIMD to run MFMAs while this one waits, so nothing may ever wait:
+//   * the unit is a k-step of 32 (64 MFMAs per wave), staged into a ring of W4_NS = 5 LDS stages of 32 KB (four regions A_lo, B_lo, B_hi,
+//     A_hi of 128 rows x 64 B): the loads of k-step t + 5 are issued during k-step t, four k-steps (~4000 MFMA cycles) before their sync
+//     (a first cut with two 64-deep stages, i.e. one K tile of lookahead, stalled ~1900 cycles per K tile on vmcnt: 52 % MFMA-busy);
+//   * the loop is software-pipelined across its one barrier per k-step:
+//       sync(t):   my loads of k-step t + 1 landed (counted vmcnt: k-steps t + 2 .. t + 4 stay in flight), my fragment reads of stage
+//                  t retired (lgkmcnt(0)); barrier
+//       body(t):   64 MFMAs on the fragments of k-step t (registers) || 8 LDS-DMA loads of k-step t + 5 into stage t (free: everyone's
+//                  reads of it retired before the barrier) || 16 ds_reads of the fragments of k-step t + 1 into the other register buffer
+//     RAW: a wave retires its own loads of k-step t + 1 before barrier(t) and everyone reads them after it. WAR: see body(t).
+// hipcc cannot allocate this loop (256 accumulators + 128 fragment registers: it parks fragments in AGPRs and spills accumulators,
+// with builtins and with inline asm under register-class constraints alike), so a k-step is ONE hand-scheduled asm statement with
+// FIXED registers — accumulators a[0:255], fragments v[128:255], read bases v[126:127] — generated by tools/gen/gen_gemm_w4_body.py
+// (gemm_w4_body.inc). The fixed registers carry values from one statement to the next, which the compiler does not know: everything
+// between two bodies is scalar (loop control, the staging stream's scalar bases), no fragment is kept across an epilogue (re-read
+// after it), the accumulators leave through w4_read_acc, and tools/gen/check_w4_isa.py greps the ISA for compiler-made uses.
+// RESULT (tools/bench_gemm.py waves, ablations of the body by W4X_* switches of the generator, (8192)^3, eight-wave kernel 1.49-1.54 PFLOP/s):
+//   MFMAs only 1.87 | + reads + barrier 1.59 | + loads, no reads 1.39 | everything 1.34 (loads in the first 8 gaps: 1.19) | no barrier 1.40
+// The 8 LDS-DMA instructions of a k-step cost the issuing wave 60+ cycles EACH (MI355X_MICROARCH.md, "LDS-DMA piece issue cost") and
+// with one wave per SIMD nobody issues MFMAs meanwhile: ~480 of a k-step's 1024 MFMA cycles. The eight-wave form pays the same issue
+// cost inside the memory segment of the wave that is NOT on the matrix pipe — that alternation is what hides it, and why it stays.
+// Staging addresses: a scalar base per operand (tile origin + K offset) plus a 32-bit per-lane row offset that is the SAME for every
+// tile — which is why this form takes M % 256 == 0 and N % 256 == 0 only (no clamped edge rows). Past the end of its stream a block
+// keeps re-issuing the last k-step's loads into free stages, so that the counted vmcnt means the same thing in every body.
+__device__ __forceinline__ const char* uniform_ptr(const char* p) {
+  const uint64_t a = (uint64_t)p;
+  return (const char*)((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a) |
+                       ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32)) << 32));
+}
+struct w4_operands {
+  unsigned ra, rb;        // LDS byte offsets of my A / B fragment reads inside a stage (region and fragment offsets are immediates)
+  unsigned vo[8];         // [region * 2 + i]: byte offset of my chunk from the operand's scalar base
+  unsigned st;            // LDS byte offset of the stage the current k-step's fragments came from (scalar)
+  unsigned ldst;          // LDS byte address my LDS-DMA instructions start from inside a stage (lds base + wave * 1024; scalar)
+  const char *sba, *sbb;  // A + (m0 * lda + k * 32) * 2 and B + (n0 * ldb + k * 32) * 2 of the k-step being issued
+};
+#include "gemm_w4_body.inc"
+
+constexpr int W4_NT = 256, W4_BK = 32, W4_REGION = 8192, W4_STAGE = 4 * W4_REGION;
+template <int ACT>
+__global__ __launch_bounds__(W4_NT) void gemm_nt_w4_kernel(const grove_gemm_params p, const pp_work work) {
+  constexpr int BM = 256, BMH = 128, WRH = 64, MIH = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc2 = wave & 1;
+  const int fr = lane & 15, fq = lane >> 4;
+  const char* __restrict__ A = (const char*)p.A;
+  const char* __restrict__ B = (const char*)p.B;
+
+  const int G = gridDim.x;
+  const int xcd = blockIdx.x & 7, q8 = G >> 3, r8 = G & 7;
+  const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+  const i32x4_t* my_work = work.table + wgid;
+  const i32x4_t head = sload4(my_work);
+  const int NT = head[0], nseg = head[1];
+  if (NT == 0) return;
+
+  w4_operands o;
+  o.sba = o.sbb = nullptr;
+  o.st = 0;
+  // The per-lane operands of the bodies. Called again after every epilogue (on a laundered lane id, so that they ARE recomputed): kept
+  // live across an epilogue, which needs most of the VGPRs, these registers get spilled — and hipcc spills into AGPRs, i.e. into the
+  // accumulators it knows nothing about.
+  auto init_o = [&]() {
+    int t = tid;
+    asm volatile("" : "+v"(t));
+    const int ln = t & 63;
+    const int fr_ = ln & 15, fq_ = ln >> 4;
+    // staging: a region = 128 rows x 4 chunks = 2 LDS-DMA instructions per thread (rows st_r and st_r + 64: same swizzle band)
+    const int st_c = t & 3, st_r = t >> 2;
+    const unsigned lc = (unsigned)swz<32>(st_r, st_c) * 16;
+    const unsigned lda2 = (unsigned)p.lda * 2, ldb2 = (unsigned)p.ldb * 2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = st_r + 64 * i;
+      const int pn = (r & ~31) | (((r & 15) >> 2) * 8 + ((r >> 4) & 1) * 4 + (r & 3));  // (see gemm_nt_pp_kernel: permuted B rows)
+      o.vo[0 * 2 + i] = (unsigned)r * lda2 + lc;
+      o.vo[3 * 2 + i] = (unsigned)(BMH + r) * lda2 + lc;
+      o.vo[1 * 2 + i] = (unsigned)pn * ldb2 + lc;
+      o.vo[2 * 2 + i] = (unsigned)(128 + pn) * ldb2 + lc;
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned kc = (unsigned)swz<32>(fr_, fq_) * 16;  // (row bases are multiples of 16: the band depends on fr only)
+    o.ra = lds0 + (wr * WRH + fr_) * 64 + kc;
+    o.rb = lds0 + (wc2 * 64 + fr_) * 64 + kc;
+    o.ldst = __builtin_amdgcn_readfirstlane(lds0 + wave * 1024);
+  };
+  init_o();
+  // the staging stream, in k-steps: is_k in [2 k0, 2 k1) of segment is_seg; at the end of the stream it stays on the last k-step
+  int is_seg = 0, is_k, is_kend;
+  auto seg_src = [&](const i32x4_t e) {
+    is_k = 2 * (e[2] & 0xffff), is_kend = 2 * (int)((unsigned)e[2] >> 16);
+    o.sba = uniform_ptr(A + ((int64_t)e[0] * p.lda + (int64_t)is_k * W4_BK) * 2);
+    o.sbb = uniform_ptr(B + ((int64_t)e[1] * p.ldb + (int64_t)is_k * W4_BK) * 2);
+  };
+  seg_src(sload4(my_work + G));
+  auto advance_issue = [&]() {  // scalar only
+    if (is_k + 1 < is_kend) {
+      ++is_k;
+      o.sba += W4_BK * 2;
+      o.sbb += W4_BK * 2;
+    } else if (is_seg + 1 < nseg) {
+      ++is_seg;
+      seg_src(sload4(my_work + (is_seg + 1) * G));
+    }
+  };
+  auto read_p0 = [&]() {  // the fragments of the k-step in stage o.st into register buffer 0
+    unsigned st = __builtin_amdgcn_readfirstlane(o.st);
+    asm volatile(W4_READ_P0 : : [st] "s"(st), [ra] "v"(o.ra), [rb] "v"(o.rb) : W4_CLOBBERS);
+  };
+
+  float scale = 1.f;
+  if (p.scale_ptr) {
+    scale = *p.scale_ptr;
+    if (p.scale_tanh) scale = tanhf(scale);
+  }
+  asm volatile("" ::"v"(scale));
+  // prologue: k-steps 0 .. NS - 1 of my stream in flight (nothing lives in the fixed registers yet), the first landed and in registers
+#pragma unroll
+  for (int sgi = 0; sgi < W4_NS; ++sgi) {
+    if (sgi) advance_issue();
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+      char* dst = smem + sgi * W4_STAGE + (n >> 1) * W4_REGION + wave * (64 * 16) + (n & 1) * (W4_NT * 16);
+      const char* sb = ((n >> 1) == 0 || (n >> 1) == 3) ? o.sba : o.sbb;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sb + o.vo[n]), (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * (W4_NS - 1)) : "memory");
+  __builtin_amdgcn_s_barrier();
+  read_p0();
+
+  const bool fast_addr = p.c_dtype == GROVE_BF16 && !p.c_idx && !p.r_idx && !p.n_group;
+  bool relax = false;  // the last epilogue left at least 32 vector-memory operations behind the staged loads
+  for (int sg = 0; sg < nseg; ++sg) {
+    const i32x4_t e = sload4(my_work + (sg + 1) * G);
+    const int m0 = e[0], n0 = e[1], nks = (int)((unsigned)e[2] >> 16) - (e[2] & 0xffff), part = e[3];
+    for (int k = 0; k < nks; ++k) {  // two k-steps per K tile of the list; every body issues the stream's next k-step first
+      advance_issue();
+      if (k == 0) {  // a segment's first k-step starts the accumulators from the MFMA's zero operand
+        if (relax) w4_body<0, 1, 1, W4_VMC_RELAX>(o);
+        else w4_body<0, 1, 1, W4_VMC>(o);
+        relax = false;
+      } else {
+        w4_body<0, 1, 0, W4_VMC>(o);
+      }
+      advance_issue();
+      if (k == nks - 1) w4_body<1, 0, 0, W4_VMC>(o);  // (the next k-step's fragments would not survive the epilogue)
+      else w4_body<1, 1, 0, W4_VMC>(o);
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs' results (the compiler's hazard recogniser does not see inside the bodies)
+    f32x4_t acc[2 * MIH][4];
+    if (__builtin_expect(part != 0, 0)) {
+      // stream-K part: the raw accumulators to the slots of the two eight-wave-form waves this wave stands for
+      auto put = [&](const int c) {
+        char* wb = (char*)work.ws + ((size_t)(part - 1) * 8 + (wr * 4 + wc2 * 2 + c)) * 32768;
+        int lo = lane * 16;
+#pragma unroll
+        for (int i = 0; i < 2 * MIH; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) *(f32x4_t*)(wb + (i * 4 + j) * 1024 + lo) = acc[i][j];
+      };
+      w4_read_acc<0>(acc);
+      put(0);
+      w4_read_acc<1>(acc);
+      put(1);
+      relax = false;
+    } else {
+      const int mw0 = m0 + wr * WRH;
+      const bool interior = fast_addr && m0 + BM <= p.M && n0 + P_BN <= p.N;
+      auto epi = [&](const int c) {
+        const int nw0 = n0 + (wc2 * 2 + c) * 32;
+        if (interior) gemm_epilogue_fast<MIH, BMH, ACT>(p, acc, mw0, nw0, fr, fq, ACT < 0 ? 1.f : scale);
+        else gemm_epilogue_wide<MIH, BMH, ACT>(p, acc, mw0, nw0, fr, fq, ACT < 0 ? 1.f : scale);
+      };
+      w4_read_acc<0>(acc);
+      epi(0);
+      w4_read_acc<1>(acc);
+      epi(1);
+      relax = interior;  // at least 32 vector-memory operations were issued after the staged loads: the counted wait may allow 32 more
+    }
+    init_o();
+    if (sg + 1 < nseg) read_p0();  // the next segment's first k-step (landed and visible since the last body's sync)
+  }
+}
+#endif  // GROVE_EXPERIMENT_W4
+
 static int g_num_cus = 0;
 static int g_persistent_blocks = 0;   // 0 = one resident block per CU; else the grid of the persistent kernels (grove_gemm_set_persistent_blocks)
 static int g_gemm_last_epilogue = 0;  // ACT template argument of the last pipelined launch (see grove_gemm_last_epilogue)
 static int g_gemm_stream_k = 1;       // plan_stream_k mode (grove_gemm_set_stream_k)
 static int g_gemm_last_stream_k = 0;  // S of the last pipelined launch
+#ifdef GROVE_EXPERIMENT_W4
+static int g_gemm_waves = 8;          // 8 = the eight-wave pipelined kernel, 4 = gemm_nt_w4_kernel where it applies (grove_gemm_set_waves)
+#endif
 
 inline int num_cus() {
   if (g_num_cus == 0) {
@@ -1257,7 +1455,21 @@ int launch_pp_act(const grove_gemm_params& p, hipStream_t s, const float* row_sc
   const pp_table_dev td{(const i32x4_t*)t_call.image, (const i32x4_t*)((const char*)t_call.image + list_bytes), n_fix, n_slots};
   pp_work work{td.table, (float*)t_call.scratch, row_scale, col_scale};
   g_gemm_last_stream_k = pl.S;
-  hipLaunchKernelGGL((gemm_nt_pp_kernel<BM, GATHER, ACT, FP8>), dim3(grid, 1, 1), dim3(P_NT), lds, s, p, work);
+  bool w4 = false;
+#ifdef GROVE_EXPERIMENT_W4
+  if constexpr (BM == 256 && !GATHER && !FP8) {
+    w4 = g_gemm_waves == 4 && !p.k_group && p.M % 256 == 0 && p.N % 256 == 0 && 255ll * 2 * std::max(p.lda, p.ldb) < (1ll << 32);
+    if (w4) {
+      static bool attr4_set = false;
+      if (!attr4_set) {
+        hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_NS * W4_STAGE);
+        attr4_set = true;
+      }
+      hipLaunchKernelGGL((gemm_nt_w4_kernel<ACT>), dim3(grid, 1, 1), dim3(W4_NT), (size_t)W4_NS * W4_STAGE, s, p, work);
+    }
+  }
+#endif
+  if (!w4) hipLaunchKernelGGL((gemm_nt_pp_kernel<BM, GATHER, ACT, FP8>), dim3(grid, 1, 1), dim3(P_NT), lds, s, p, work);
   GROVE_LAUNCH_CHECK();
   if (td.n_fixups) {
     hipLaunchKernelGGL((gemm_pp_fixup_kernel<BM, ACT, FP8>), dim3(td.n_fixups * (8 / FIX_WAVES), 1, 1), dim3(64 * FIX_WAVES), 0, s, p, td.fixups,
@@ -1385,6 +1597,12 @@ extern "C" int grove_gemm_set_persistent_blocks(int n) {
   g_persistent_blocks = n < 0 ? 0 : n;
   return GROVE_OK;
 }
+#ifdef GROVE_EXPERIMENT_W4
+extern "C" int grove_gemm_set_waves(int waves) {  // 8 (default) or 4: the four-wave form of the 256-row instances (A/B knob)
+  g_gemm_waves = waves == 4 ? 4 : 8;
+  return GROVE_OK;
+}
+#endif
 extern "C" int grove_gemm_set_stream_k(int mode) {
   g_gemm_stream_k = mode < 0 ? 0 : mode > 2 ? 2 : mode;
   return GROVE_OK;

@@ -1,6 +1,7 @@
 """NT GEMM micro-benchmarks on the shapes of the full-size step (one script, three sub-commands; random data):
     python tools/bench_gemm.py tiles       auto kernel selection vs every forced variant (calibrates the cost model of grove_gemm_bf16)
     python tools/bench_gemm.py streamk     stream-K tail of the persistent kernels on vs off (time, TF/s, |diff| between the arms, error vs fp32)
+    python tools/bench_gemm.py waves       four-wave form of the 256-row instances vs the eight-wave form (bit equality, time)
     python tools/bench_gemm.py epilogues   epilogue variants of the persistent kernel vs the 128-row kernel (plain / GELU+aux / QuickGELU+aux / residual)
 (round 3: merged from bench_gemm_tiles.py, bench_gemm_streamk.py, bench_gemm_pipelined.py)"""
 import os
@@ -113,5 +114,40 @@ def epilogues():
     L.grove_gemm_set_tile_m(0)
 
 
+def waves():
+    """gemm_nt_w4_kernel (one wave per SIMD, hand-scheduled K loop; EXPERIMENT: needs a library built with `make -C grove_amd/csrc W4=1`,
+    e.g. into another file passed as GROVE_HIP_LIB) against the eight-wave kernel: same bits, time of both."""
+    assert hasattr(L, "grove_gemm_set_waves"), "this library was built without the experiment: make -C grove_amd/csrc W4=1"
+    shapes = [(32768, 1280, 5120), (32768, 5120, 1280), (32768, 3840, 1280), (32768, 1280, 3840), (32768, 1280, 1280), (32768, 4608, 1280),
+              (32768, 1280, 4608), (2816, 22016, 4096), (2816, 4096, 22016), (18432, 4096, 1024), (18432, 1024, 4096), (256, 256, 64), (512, 768, 192),
+              (4096, 4096, 4096), (8192, 8192, 8192)]
+    L.grove_gemm_set_tile_m(256)
+    tot = {8: 0.0, 4: 0.0}
+    for M, N, K in shapes:
+        a, b, bias, _ = operands(M, N, K)
+        res_in = torch.randn(M, N, device=dev).to(bf)
+        for label, kw in (("plain", {}), ("gelu+aux+res", dict(act=ops.ACT_GELU, residual=res_in, aux=torch.empty(M, N, device=dev, dtype=bf)))):
+            outs, t = {}, {8: 1e9, 4: 1e9}
+            for rnd_ in range(3):
+                for w in (8, 4):
+                    L.grove_gemm_set_waves(w)
+                    out = torch.empty(M, N, device=dev, dtype=bf)
+                    t[w] = min(t[w], timed(lambda: ops.linear(a, b, bias, out=out, **kw), 10))
+                    outs[w] = out
+                    if "aux" in kw:
+                        outs[(w, "aux")] = kw["aux"].clone()
+            same = torch.equal(outs[8], outs[4]) and ("aux" not in kw or torch.equal(outs[(8, "aux")], outs[(4, "aux")]))
+            S = L.grove_gemm_last_stream_k()
+            if label == "plain" and M >= 2048:
+                tot[8] += t[8]
+                tot[4] += t[4]
+            print(f"M={M} N={N} K={K} {label:13s} 8 waves {t[8]:8.1f}us ({2.0 * M * N * K / t[8] / 1e6:6.0f} TF)  4 waves {t[4]:8.1f}us ({2.0 * M * N * K / t[4] / 1e6:6.0f} TF)"
+                  f"  x{t[8] / t[4]:.3f}  stream-K S={S}  bit-equal={same}", flush=True)
+            assert same or os.environ.get("W4_NO_ASSERT"), (M, N, K, label)
+    L.grove_gemm_set_waves(8)
+    L.grove_gemm_set_tile_m(0)
+    print(f"sum over the plain large shapes: 8 waves {tot[8] / 1e3:.2f} ms, 4 waves {tot[4] / 1e3:.2f} ms")
+
+
 if __name__ == "__main__":
-    {"tiles": tiles, "streamk": streamk, "epilogues": epilogues}[sys.argv[1] if len(sys.argv) > 1 else "tiles"]()
+    {"tiles": tiles, "streamk": streamk, "epilogues": epilogues, "waves": waves}[sys.argv[1] if len(sys.argv) > 1 else "tiles"]()
