@@ -228,10 +228,31 @@ def test_bench_self_launches_ranks(tmp_path):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, GROVE_BENCH_BACKEND="gloo", GROVE_BENCH_ONE_GPU="1")
+    env = dict(os.environ, GROVE_BENCH_BACKEND="gloo", GROVE_BENCH_ONE_GPU="1", GLOO_SOCKET_IFNAME="lo")
     env.pop("WORLD_SIZE", None)
-    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dims", "tiny", "--steps", "2", "--warmup", "1",
-                        "--frames", "8", "--text_len", "48", "--no_cpu_baseline"], env=env, capture_output=True, text=True, timeout=900)
+    base = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dims", "tiny", "--steps", "2", "--warmup", "1",
+            "--frames", "8", "--text_len", "48", "--no_cpu_baseline"]
+
+    def run(extra):
+        # One retry on a hang: this rehearsal drives gloo collectives on CUDA tensors from two processes that share ONE GPU (not the
+        # product path, which is RCCL with a GPU per rank). A launch takes ~6 s; once in a dozen full-suite runs the first one never
+        # printed its line (both ranks connected, nothing after) — the retry keeps a rendezvous flake from hiding the tests behind it.
+        import signal
+        import types
+        for attempt in (0, 1):
+            proc = subprocess.Popen(base + extra, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+            try:
+                out, err = proc.communicate(timeout=300)
+                return types.SimpleNamespace(returncode=proc.returncode, stdout=out, stderr=err)
+            except subprocess.TimeoutExpired:
+                os.killpg(proc.pid, signal.SIGKILL)  # the launcher and both ranks: the session this call started, nothing else
+                out, err = proc.communicate()
+                if attempt:
+                    raise
+                import warnings
+                warnings.warn(f"two-rank rehearsal hung once and is retried: {err[-400:]!r}")
+
+    p = run([])
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, p.stdout
@@ -243,8 +264,7 @@ def test_bench_self_launches_ranks(tmp_path):
     losses = [res["config"]["last_loss"]]
     assert res["config"]["exposed_comm_ms"] is not None and "touched rows" in res["config"]["gradient_exchange"]
     for extra in (["--no_comm_overlap"], ["--exchange", "rs_ag"], ["--exchange", "a2a_f32"], ["--dense_embed"]):
-        q = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dims", "tiny", "--steps", "2", "--warmup", "1",
-                            "--frames", "8", "--text_len", "48", "--no_cpu_baseline"] + extra, env=env, capture_output=True, text=True, timeout=900)
+        q = run(extra)
         assert q.returncode == 0, q.stderr[-2000:]
         losses.append(json.loads([ln for ln in q.stdout.splitlines() if ln.strip()][0])["config"]["last_loss"])
     assert max(losses) - min(losses) <= 2e-3 * max(1.0, abs(losses[0])), losses
@@ -291,7 +311,10 @@ def test_optimizer_stream_overlap_is_race_free(dev):
         res.setdefault(overlap, []).append((torch.stack(losses).cpu(), engine.master.clone().cpu()))
     (l_a, w_a), (l_c, w_c) = res[True]
     (l_b, w_b), = res[False]
-    # (split-K / CE sums use fp32 atomics: run-to-run noise of the same configuration is the yardstick)
+    # (split-K / CE sums use fp32 atomics: run-to-run noise of the same configuration is the yardstick. tools/overlap_stress.py, 12 runs per
+    # arm: the third loss spreads over 9.1538 .. 9.1579 (std 1.1e-3 / 1.6e-3) in BOTH arms and the final weights of any two runs differ by
+    # 2.9-3.3e-3 in both — so one sample of |a - c| is a weak yardstick: it came out 3e-4 once and failed a 3.5e-3 difference that is
+    # ordinary. The loss bound is therefore the measured spread (1e-3 of the loss ~ 2x the peak-to-peak) on top of the sampled noise.)
     noise = max((w_a - w_c).abs().max().item(), 1e-7)
     assert (w_a - w_b).abs().max().item() <= 4 * noise + 1e-6, ((w_a - w_b).abs().max().item(), noise)
-    assert (l_a - l_b).abs().max().item() <= 1e-4 * l_b.abs().max().item() + 4 * (l_a - l_c).abs().max().item()
+    assert (l_a - l_b).abs().max().item() <= 1e-3 * l_b.abs().max().item() + 4 * (l_a - l_c).abs().max().item(), (l_a, l_b, l_c)
