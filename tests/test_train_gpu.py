@@ -219,6 +219,29 @@ def test_train_main_entry_point(dev, tmp_path):
     assert res3["global_step"] == 3
 
 
+def _run_rehearsal(cmd, env):
+    """Runs a two-rank one-GPU rehearsal command with ONE retry on a hang. These rehearsals drive gloo collectives on CUDA tensors from
+    two processes that share ONE GPU (not the product path, which is RCCL with a GPU per rank). A launch takes ~6 s; once in a dozen
+    full-suite runs one never printed its line (both ranks connected, nothing after) — the retry keeps a rendezvous flake from hiding
+    the tests behind it. A hung launch is killed as the process group THIS call started (launcher + ranks), nothing else."""
+    import os
+    import signal
+    import subprocess
+    import types
+    import warnings
+    for attempt in (0, 1):
+        proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+        try:
+            out, err = proc.communicate(timeout=300)
+            return types.SimpleNamespace(returncode=proc.returncode, stdout=out, stderr=err)
+        except subprocess.TimeoutExpired:
+            os.killpg(proc.pid, signal.SIGKILL)
+            out, err = proc.communicate()
+            if attempt:
+                raise
+            warnings.warn(f"two-rank rehearsal hung once and is retried: {err[-400:]!r}")
+
+
 def test_bench_self_launches_ranks(tmp_path):
     """`python bench.py --gpus 2` with no launcher around it (the shape of the driver's command) spawns its own two ranks before
     touching the GPU and prints ONE JSON line with n_gpus = 2. On this one-GPU box both ranks share cuda:0 and the collectives go
@@ -234,23 +257,7 @@ def test_bench_self_launches_ranks(tmp_path):
             "--frames", "8", "--text_len", "48", "--no_cpu_baseline"]
 
     def run(extra):
-        # One retry on a hang: this rehearsal drives gloo collectives on CUDA tensors from two processes that share ONE GPU (not the
-        # product path, which is RCCL with a GPU per rank). A launch takes ~6 s; once in a dozen full-suite runs the first one never
-        # printed its line (both ranks connected, nothing after) — the retry keeps a rendezvous flake from hiding the tests behind it.
-        import signal
-        import types
-        for attempt in (0, 1):
-            proc = subprocess.Popen(base + extra, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
-            try:
-                out, err = proc.communicate(timeout=300)
-                return types.SimpleNamespace(returncode=proc.returncode, stdout=out, stderr=err)
-            except subprocess.TimeoutExpired:
-                os.killpg(proc.pid, signal.SIGKILL)  # the launcher and both ranks: the session this call started, nothing else
-                out, err = proc.communicate()
-                if attempt:
-                    raise
-                import warnings
-                warnings.warn(f"two-rank rehearsal hung once and is retried: {err[-400:]!r}")
+        return _run_rehearsal(base + extra, env)
 
     p = run([])
     assert p.returncode == 0, p.stderr[-2000:]
@@ -279,12 +286,11 @@ def test_bench_infer_mode_runs_on_two_ranks(tmp_path):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, GROVE_BENCH_BACKEND="gloo", GROVE_BENCH_ONE_GPU="1")
+    env = dict(os.environ, GROVE_BENCH_BACKEND="gloo", GROVE_BENCH_ONE_GPU="1", GLOO_SOCKET_IFNAME="lo")
     env.pop("WORLD_SIZE", None)
     for dtype in ("bf16",):
-        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--mode", "infer", "--dtype", dtype, "--gpus", "2", "--dims", "tiny",
-                            "--steps", "2", "--warmup", "1", "--frames", "16", "--batch", "1", "--text_len", "48", "--no_cpu_baseline"],
-                           env=env, capture_output=True, text=True, timeout=900)
+        p = _run_rehearsal([sys.executable, os.path.join(root, "bench.py"), "--mode", "infer", "--dtype", dtype, "--gpus", "2", "--dims", "tiny",
+                            "--steps", "2", "--warmup", "1", "--frames", "16", "--batch", "1", "--text_len", "48", "--no_cpu_baseline"], env)
         assert p.returncode == 0, p.stderr[-2000:]
         lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
         assert len(lines) == 1, p.stdout
