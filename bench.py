@@ -32,11 +32,11 @@ PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak of MI355X (MI355X_MICROARCH.md
 def build(dims, dev, args):
     from grove_amd import train as T
     from grove_amd.synthetic import synthetic_state_dict
-    targs = T.parse_args([])
+    targs = T.shipped_args()  # --lora_r 0 --pretrained --train_mask_decoder: every shipped launch line (train_scripts/*.sh)
     targs.num_frames = args.frames
     targs.batch_size = args.batch
     sd = synthetic_state_dict(dims, device=dev, dtype=torch.bfloat16)
-    model = T.initialize_model(targs, dims, state_dict=sd, device=dev)
+    model = T.initialize_model(targs, dims=dims, state_dict=sd, device=dev)
     del sd
     torch.cuda.empty_cache()
     engine = T.GroveEngine(model, targs, total_steps=100000, exchange=getattr(args, "exchange", "allreduce"),

@@ -27,14 +27,18 @@ from .tape import Param, Tape, Var
 bf = torch.bfloat16
 
 
-def trainable_names(d: GroveDims):
+def trainable_names(d: GroveDims, train_mask_decoder=True):
     """The parameters that receive gradients under the shipped freeze policy
     (train.py::prepare_model_for_training :234-333 with --lora_r 0 --pretrained --train_mask_decoder).
     CLIP adapters are flagged trainable there too but the tower runs under no_grad (clip_encoder.py:55),
-    so they never get a gradient and are excluded."""
+    so they never get a gradient and are excluded. Without --train_mask_decoder (train.py:280-283 not taken)
+    only the box head and the temporal-objectness head of the decoder train (train.py:284-288)."""
     names = []
+    heads = (DEC_PREFIX + "bbox_prediction_head.", DEC_PREFIX + "temporal_objectness_head.")
     for n in param_shapes(d):
         if is_mask_branch(n):  # flagged trainable by --train_mask_decoder, but no gradient reaches them on the box ("query") path
+            continue
+        if n.startswith(DEC_PREFIX) and not train_mask_decoder and not n.startswith(heads):
             continue
         if n in ("model.embed_tokens.weight", "lm_head.weight") or n.startswith("model.mm_projector.") \
                 or n.startswith("model.text_hidden_fcs.") or n.startswith(DEC_PREFIX) \
@@ -94,7 +98,10 @@ class GROVEForCausalLM(torch.nn.Module):
         self.config.num_frames = kwargs.get("num_frames", 8) or 8              # GROVE.py:117
         self.config.temp_objectness_threshold = kwargs.get("temp_objectness_threshold", 0.5)
         self.config.use_temp_objectness = kwargs.get("use_temp_objectness", True)
-        self.config.train_mask_decoder = kwargs.get("train_mask_decoder", False)
+        # (the reference's constructor default is False, GROVE.py:45; every caller passes it from args, and every shipped launch line
+        # sets --train_mask_decoder: a directly constructed model gets the shipped policy)
+        self.config.train_mask_decoder = kwargs.get("train_mask_decoder", True)
+        self.config.bbox_token_idx = kwargs.get("bbox_token_idx", 32002)      # GROVE.py:115 (region prompts: never read on this path)
         self.config.out_dim = d.out_dim
         self.literal_T = kwargs.get("literal_T", False)
         # dense positional encoding dtype: bf16 reproduces the reference under model.to(bf16) (quirk Q10)
@@ -181,7 +188,7 @@ class GROVEForCausalLM(torch.nn.Module):
                     t.copy_(src.to(self.dev))
                 self._sd[name] = t
         if self._train_mode:
-            names = trainable_names(d)
+            names = trainable_names(d, self.config.train_mask_decoder)
             # every parameter starts on a 16-byte boundary of the flat fp32 buffer (vector / atomic epilogues)
             offs, off = {}, 0
             for n in names:

@@ -261,8 +261,9 @@ class BoxDecoder:
                  "dWo": G[M_ + "temporal_objectness_head.weight"].view(-1), "dbo": G[M_ + "temporal_objectness_head.bias"]}
         dhs = ops.box_head_bwd(state["hs"], self.sd[hp + "0.weight"], self.sd[hp + "2.weight"],
                                self.sd[M_ + "temporal_objectness_head.weight"], state["hidden"], state["box"], dbox, dobj, grads)
+        # (without --train_mask_decoder only the two heads train: the transformer's tensors have no gradient views)
         dq5 = ops.layernorm_bwd(state["q5"], self.sd[t + "norm_final_attn.weight"], ops.to_bf16(dhs), state["mean"], state["rstd"],
-                                dweight=G[t + "norm_final_attn.weight"], dbias=G[t + "norm_final_attn.bias"])
+                                dweight=G.get(t + "norm_final_attn.weight"), dbias=G.get(t + "norm_final_attn.bias"))
         dqueries = torch.zeros((N * 6, D), dtype=bf, device=self.dev)
         ops.copy_rows(dq5, dqueries, N, D, idx_dst=state["text_dst"])
         state["queries"].grad = dqueries
@@ -275,10 +276,11 @@ class BoxDecoder:
         dtext = torch.empty((N, D), dtype=bf, device=self.dev)
         ops.copy_rows(tg, dtext, N, D, idx_src=state["text_dst"])
         state["text"].grad = dtext
-        t_idx = torch.arange(N * 6, device=self.dev, dtype=torch.int32)
-        tok_of_row = torch.where(t_idx % 6 < 5, t_idx % 6, torch.full_like(t_idx, -1))
-        tokg = torch.zeros((5, D), dtype=torch.float32, device=self.dev)
-        ops.scatter_add_f32(tg, tokg, tok_of_row, N * 6, D)
-        ops.axpy(G[M_ + "iou_token.weight"].view(-1), tokg[0])
-        ops.axpy(G[M_ + "mask_tokens.weight"].view(-1), tokg[1:5].reshape(-1))
+        if G.get(M_ + "iou_token.weight") is not None:
+            t_idx = torch.arange(N * 6, device=self.dev, dtype=torch.int32)
+            tok_of_row = torch.where(t_idx % 6 < 5, t_idx % 6, torch.full_like(t_idx, -1))
+            tokg = torch.zeros((5, D), dtype=torch.float32, device=self.dev)
+            ops.scatter_add_f32(tg, tokg, tok_of_row, N * 6, D)
+            ops.axpy(G[M_ + "iou_token.weight"].view(-1), tokg[0])
+            ops.axpy(G[M_ + "mask_tokens.weight"].view(-1), tokg[1:5].reshape(-1))
         return None

@@ -24,54 +24,337 @@ from .model.GROVE import GROVEForCausalLM, trainable_names
 from .synthetic import GroveDims
 
 
+# Reference flags that only feed subsystems outside the hot path (datasets, tokenizer files, LoRA, logging). They are accepted with
+# the reference's names and defaults so that the shipped launch lines parse unchanged; what each one does here is listed.
+IGNORED_REFERENCE_FLAGS = {
+    "vision_pretrained": "SAM checkpoint path: the SAM weights come with the GROVE checkpoint (--version / --grove_weights)",
+    "vision_tower": "CLIP hub id: the CLIP ViT-L/14-336 geometry is fixed (GroveDims); weights come with the checkpoint",
+    "conv_type": "conversation template: text plumbing, the loader hands over token ids",
+    "tune_mm_mlp_adapter": "LLaVA stage-1 switch, unused by the reference's own code path",
+    "freeze_mm_mlp_adapter": "LLaVA stage-1 switch, unused by the reference's own code path",
+    "mm_use_im_start_end": "decides the prompt text the dataset builds; the splice handles either form",
+    "image_size": "must be 512 (SAM geometry the kernels are built for); checked",
+    "model_max_length": "tokenizer truncation length",
+    "lora_target_modules": "LoRA only (rejected: --lora_r must be 0)", "lora_alpha": "LoRA only", "lora_dropout": "LoRA only",
+    "with_region": "region encoder: constructed but never executed by GROVE (SURVEY.md section 2 row 10)",
+    "mm_vision_select_layer": "must be -2 (hidden_states[-2]; CLIP layer 24 is skipped on that ground); checked",
+    "pretrain_mm_mlp_adapter": "LLaVA stage-1 projector file", "video_dir": "dataset", "train_ann_dir": "dataset", "val_ann_dir": "dataset",
+    "train_keys": "dataset", "val_keys": "dataset", "frame_timestamps": "dataset", "num_classes_per_sample": "dataset",
+    "weight": "unused by the reference", "val_batch_size": "validation loader batch (synthetic loader: --batch_size)",
+    "workers": "DataLoader workers", "gradient_checkpointing": "activations are kept (288 GB HBM): no recompute, same gradients",
+    "use_mm_start_end": "tokenizer: adds <vid_start>/<vid_end>", "val_dataset": "GLaMM leftover, unused", "no_eval": "unused by the reference",
+}
+
+
 def parse_args(argv=None):
-    """Subset of train.py:40-112 that concerns the hot path (same names and defaults)."""
+    """train.py:40-112 — every flag of the reference with its name and default (so `train_scripts/*.sh` launch lines parse
+    unchanged), plus this build's own switches in a separate group. Flags that feed out-of-scope subsystems are accepted and
+    listed in IGNORED_REFERENCE_FLAGS; `--lora_r > 0`, `--precision != bf16` and a missing `--pretrained` are rejected by
+    `check_supported(args)` (called from main / initialize_model), not silently ignored."""
     p = argparse.ArgumentParser(description="GROVE Model Training (MI355X)")
-    p.add_argument("--precision", default="bf16", type=str)
-    p.add_argument("--num_frames", default=8, type=int)
+    # Model-specific settings (train.py:43-58)
+    p.add_argument("--version", default="MBZUAI/GLaMM-GCG")
+    p.add_argument("--vision_pretrained", default="./checkpoints/sam_vit_h_4b8939.pth", type=str)
+    p.add_argument("--vision-tower", default="openai/clip-vit-large-patch14-336", type=str)
+    p.add_argument("--conv_type", default="llava_v1", type=str, choices=["llava_v1", "llava_llama_2"])
+    p.add_argument("--tune_mm_mlp_adapter", action="store_true")
+    p.add_argument("--freeze_mm_mlp_adapter", action="store_true")
+    p.add_argument("--mm_use_im_start_end", action="store_true", default=True)
     p.add_argument("--out_dim", default=256, type=int)
+    p.add_argument("--image_size", default=512, type=int, help="Image size for grounding image encoder")
+    p.add_argument("--model_max_length", default=1536, type=int)
+    p.add_argument("--lora_target_modules", default="q_proj,v_proj", type=str)
+    p.add_argument("--with_region", action="store_true", default=True)
+    p.add_argument("--mm_vision_select_layer", default=-2, type=int)
+    p.add_argument("--pretrain_mm_mlp_adapter", default="", type=str)
+    p.add_argument("--precision", default="bf16", type=str)
+    # Dataset settings (train.py:60-69)
+    p.add_argument("--dataset", default="HowToGround", choices=["HowToGround", "ActivityNetEntities", "VidSTG"], type=str)
+    p.add_argument("--video_dir", default="/home/HowTo100M_small", type=str)
+    p.add_argument("--train_ann_dir", default="/home/train_annotations/", type=str)
+    p.add_argument("--val_ann_dir", default="/home/val_annotations/", type=str)
+    p.add_argument("--train_keys", default="/home/train_keys.pkl", type=str)
+    p.add_argument("--val_keys", default="/home/val_keys.pkl", type=str)
+    p.add_argument("--frame_timestamps", default="/home/ActivityNetEntities/timestamps_metadata.json")
+    p.add_argument("--num_classes_per_sample", default=3, type=int)
+    p.add_argument("--num_frames", default=8, type=int)
+    # Training settings (train.py:71-98)
+    p.add_argument("--pretrained", action="store_true")
+    p.add_argument("--grove_weights", default=None, type=str)
+    p.add_argument("--resume", default="", type=str)
+    p.add_argument("--auto_resume", action="store_true")
+    p.add_argument("--weight", default="", type=str)
     p.add_argument("--lr", default=0.0003, type=float)
     p.add_argument("--wd", default=0.0, type=float)
-    p.add_argument("--beta1", default=0.9, type=float)
-    p.add_argument("--beta2", default=0.95, type=float)
     p.add_argument("--epochs", default=10, type=int)
     p.add_argument("--steps_per_epoch", default=500, type=int)
-    p.add_argument("--batch_size", default=1, type=int)
+    p.add_argument("--batch_size", default=1, type=int, help="batch size per device per step")
     p.add_argument("--grad_accumulation_steps", default=1, type=int)
+    p.add_argument("--val_batch_size", default=1, type=int)
+    p.add_argument("--workers", default=0, type=int)
+    p.add_argument("--lora_r", default=8, type=int)
+    p.add_argument("--lora_alpha", default=16, type=int)
+    p.add_argument("--lora_dropout", default=0.05, type=float)
     p.add_argument("--ce_loss_weight", default=1.0, type=float)
     p.add_argument("--giou_loss_weight", default=1.0, type=float)
     p.add_argument("--temp_objectness_loss_weight", default=1.0, type=float)
-    p.add_argument("--train_mask_decoder", action="store_true", default=True)
+    p.add_argument("--beta1", default=0.9, type=float)
+    p.add_argument("--beta2", default=0.95, type=float)
+    p.add_argument("--gradient_checkpointing", action="store_true", default=True)
+    p.add_argument("--train_mask_decoder", action="store_true", default=False)
+    p.add_argument("--use_mm_start_end", action="store_true", default=True)
     p.add_argument("--print_freq", default=1, type=int)
-    p.add_argument("--local_rank", default=int(os.environ.get("LOCAL_RANK", 0)), type=int)
-    p.add_argument("--log_dir", default="./output", type=str)
-    p.add_argument("--exp_name", default="grove", type=str)
     p.add_argument("--start_epoch", default=0, type=int)
-    p.add_argument("--eval_only", action="store_true", default=False)
-    p.add_argument("--auto_resume", action="store_true", default=False)
-    p.add_argument("--resume", default="", type=str)
-    p.add_argument("--grove_weights", default="", type=str, help="consolidated pytorch_model.bin / HF directory to start from")
-    p.add_argument("--val_batches", default=2, type=int, help="validation batches per epoch (synthetic loader)")
-    # synthetic-data stand-ins for the dataset arguments (datasets / tokenizer are out of scope, SURVEY.md section 8)
-    p.add_argument("--dims", default="full", choices=["full", "tiny"], help="architecture size when no checkpoint gives it")
-    p.add_argument("--text_len", default=128, type=int)
-    p.add_argument("--n_det", default=3, type=int)
-    return p.parse_args(argv)
+    p.add_argument("--local_rank", default=int(os.environ.get("LOCAL_RANK", 0)), type=int, help="node rank")
+    # Evaluation settings (train.py:100-106)
+    p.add_argument("--val_dataset", default="RefCOCOgRegVal", type=str)
+    p.add_argument("--bbox_validation", action="store_true")
+    p.add_argument("--no_eval", action="store_true")
+    p.add_argument("--eval_only", action="store_true")
+    # Experiment settings (train.py:108-110)
+    p.add_argument("--log_base_dir", default="/home/grove_checkpoints", type=str)
+    p.add_argument("--exp_name", default="iGround", type=str)
+    # ---- this build's own switches (not in the reference)
+    g = p.add_argument_group("grove_amd")
+    g.add_argument("--log_dir", default=None, type=str, help="overrides <log_base_dir>/<exp_name> (train.py:116)")
+    g.add_argument("--val_batches", default=2, type=int, help="validation batches per epoch (synthetic loader)")
+    g.add_argument("--dims", default="full", choices=["full", "tiny"], help="architecture size when no checkpoint gives it")
+    g.add_argument("--text_len", default=128, type=int, help="synthetic loader: text ids per sample")
+    g.add_argument("--n_det", default=3, type=int, help="synthetic loader: [DET] tokens per sample")
+    g.add_argument("--exchange", default="allreduce", choices=["allreduce", "rs_ag", "a2a_f32"], help="N > 1 gradient exchange form")
+    g.add_argument("--dense_embed", action="store_true", help="N > 1: embed_tokens' gradient as the dense slice, not touched rows")
+    g.add_argument("--no_comm_overlap", action="store_true", help="N > 1: exchange after the backward, not from inside it")
+    args = p.parse_args(argv)
+    if args.log_dir is None:
+        args.log_dir = os.path.join(args.log_base_dir, args.exp_name)  # initialize_environment, train.py:116
+    return args
 
 
-def initialize_model(args, dims: GroveDims, state_dict=None, device=None):
-    """train.py:197-218: build GROVEForCausalLM in bf16 with the loss weights / token ids of `args`."""
+def shipped_args(extra=()):
+    """parse_args on the switches every shipped launch line passes (train_scripts/*.sh: `--lora_r 0 --pretrained
+    --train_mask_decoder`) — the configuration the build implements; tests and bench.py start from it."""
+    return parse_args(["--lora_r", "0", "--pretrained", "--train_mask_decoder"] + list(extra))
+
+
+def check_supported(args):
+    """Reject, loudly, the configurations of the reference's command line that this build does not implement."""
+    if getattr(args, "lora_r", 0) > 0:
+        raise NotImplementedError(
+            f"--lora_r {args.lora_r}: LoRA (peft, train.py:268-271) is out of scope — every shipped launch line passes --lora_r 0 "
+            "(train_scripts/*.sh); pass --lora_r 0")
+    if not getattr(args, "pretrained", True):
+        raise NotImplementedError(
+            "without --pretrained the reference rebuilds the whole SAM grounding encoder as trainable modules "
+            "(initialize_grove_model, train.py:273-274; GROVE.py:53-59): not a shipped configuration; pass --pretrained")
+    if getattr(args, "precision", "bf16") != "bf16":
+        raise NotImplementedError(f"--precision {args.precision}: the kernels compute in bf16 with fp32 accumulation (train.py:58 default)")
+    if getattr(args, "image_size", 512) != 512:
+        raise NotImplementedError(f"--image_size {args.image_size}: the grounding encoder is SAM ViT-H at 512 pixels (train.py:51 default)")
+    if getattr(args, "mm_vision_select_layer", -2) != -2:
+        raise NotImplementedError("--mm_vision_select_layer must be -2 (train.py:56 default): CLIP layer 24 is never computed")
+    if getattr(args, "bbox_validation", False):
+        raise NotImplementedError("--bbox_validation: that branch of validate_model_performance cannot run in the reference either "
+                                  "(train.py:816-819 reads keys model_forward no longer returns; SURVEY.md quirk Q8)")
+
+
+class SyntheticTokenizer:
+    """Stand-in for the LLaMA sentencepiece tokenizer when no tokenizer files are installed (there is no network): only the
+    surface train.py / infer_iground.py touch — len(), add_tokens(), unk/pad/eos/bos ids and tokenizer(text).input_ids for the
+    special-token lookups of setup_tokenizer_and_special_tokens (train.py:154-157). Base vocabulary 32000 (Vicuna-7B-v1.5) plus
+    the added tokens a GLaMM-GranD-Pretrained tokenizer already carries (non-special added tokens, which the slow LlamaTokenizer
+    emits behind a "▁" piece — hence the reference's `.input_ids[1]` for <bbox>, <p>, </p> and `.input_ids[0]` for [DET])."""
+    SPIECE_UNDERLINE_ID = 29871
+    PRETRAINED_ADDED = ("<im_start>", "<im_end>", "<bbox>", "<point>", "<p>", "</p>")
+
+    def __init__(self, base_vocab=32000, pretrained=True, model_max_length=1536):
+        self.base_vocab, self.model_max_length = base_vocab, model_max_length
+        self.unk_token, self.bos_token, self.eos_token = "<unk>", "<s>", "</s>"
+        self.unk_token_id, self.bos_token_id, self.eos_token_id = 0, 1, 2
+        self.pad_token = None
+        self.padding_side = "right"
+        self._added, self._special = {}, set()
+        if pretrained:
+            for t in self.PRETRAINED_ADDED:
+                self._added[t] = base_vocab + len(self._added)
+
+    @property
+    def pad_token_id(self):
+        return {self.unk_token: self.unk_token_id, self.eos_token: self.eos_token_id}.get(self.pad_token)
+
+    def __len__(self):
+        return self.base_vocab + len(self._added)
+
+    def add_tokens(self, tokens, special_tokens=False):
+        n = 0
+        for t in ([tokens] if isinstance(tokens, str) else tokens):
+            if t not in self._added:
+                self._added[t] = self.base_vocab + len(self._added)
+                n += 1
+            if special_tokens:
+                self._special.add(t)
+        return n
+
+    def convert_tokens_to_ids(self, t):
+        return self._added.get(t, self.unk_token_id)
+
+    def __call__(self, text, add_special_tokens=True):
+        from types import SimpleNamespace
+        ids = [self.bos_token_id] if add_special_tokens else []
+        if text in self._added:
+            ids += ([] if text in self._special else [self.SPIECE_UNDERLINE_ID]) + [self._added[text]]
+        else:  # no sentencepiece model offline: ordinary text maps to hashed ids (shape-only stand-in)
+            import zlib
+            ids += [3 + zlib.crc32(w.encode()) % (self.base_vocab - 3) for w in text.split()]
+        return SimpleNamespace(input_ids=ids)
+
+
+DEFAULT_VID_START_TOKEN, DEFAULT_VID_END_TOKEN = "<vid_start>", "<vid_end>"  # utils/utils.py
+
+
+def setup_tokenizer_and_special_tokens(args, tokenizer=None):
+    """train.py:124-159: load the tokenizer of `args.version` (when its files exist locally; a SyntheticTokenizer otherwise or when
+    one is passed in), pad = unk, add <vid_start>/<vid_end> (+ the region / phrase tokens unless --pretrained) and [DET], and
+    record `bbox_token_idx / det_token_idx / bop_token_idx / eop_token_idx` on `args` with the reference's index choices."""
+    if tokenizer is None:
+        if os.path.isdir(str(args.version)):
+            import transformers
+            tokenizer = transformers.AutoTokenizer.from_pretrained(args.version, model_max_length=args.model_max_length,
+                                                                   padding_side="right", use_fast=False)
+        else:
+            tokenizer = SyntheticTokenizer(pretrained=getattr(args, "pretrained", True), model_max_length=args.model_max_length)
+    tokenizer.pad_token = tokenizer.unk_token
+    if args.use_mm_start_end:
+        tokenizer.add_tokens([DEFAULT_VID_START_TOKEN, DEFAULT_VID_END_TOKEN], special_tokens=True)
+    if not args.pretrained:
+        tokenizer.add_tokens(["<bbox>", "<point>"] + ["[DET]"] + ["<p>", "</p>"], special_tokens=True)
+    else:
+        tokenizer.add_tokens(["[DET]"], special_tokens=True)
+
+    def second(text):  # `.input_ids[1]` (train.py:154,156,157): the id behind the "▁" piece; a one-piece result has no [1]
+        ids = tokenizer(text, add_special_tokens=False).input_ids
+        return ids[1] if len(ids) > 1 else ids[0]
+    args.bbox_token_idx = second("<bbox>")
+    args.det_token_idx = tokenizer("[DET]", add_special_tokens=False).input_ids[0]
+    args.bop_token_idx = second("<p>")
+    args.eop_token_idx = second("</p>")
+    return tokenizer
+
+
+def _reinit(model, names):
+    """Give `names` the value the reference's freshly constructed modules hold (checkpoint.constructor_init) and rebuild the
+    model's derived state."""
+    from .checkpoint import constructor_init
+    from .synthetic import det_uniform01, param_shapes
+    shapes = param_shapes(model.dims)
+    upd = {}
+    for n in names:
+        v = constructor_init(n, shapes[n])
+        if isinstance(v, tuple):
+            wshape = shapes.get(v[1], shapes[n])
+            fan_in = 1
+            for s_ in wshape[1:]:
+                fan_in *= int(s_)
+            v = (det_uniform01(n, shapes[n]) * 2.0 - 1.0) / math.sqrt(max(fan_in, 1))
+        upd[n] = v
+    if upd:
+        model.load_state_dict(upd, strict=False)
+    return sorted(upd)
+
+
+def initialize_custom_layers_in_model(model):
+    """train.py:162-191: fresh SAM spatio-temporal adapters (Conv3d default init, alpha 0), box head (Linear-ReLU-Linear) and —
+    with use_temp_objectness — temporal-objectness head. Returns the re-initialised names."""
+    from .model.decoder import M_
+    from .model.sam import S as SAM_PREFIX
+    from .synthetic import param_shapes
+    names = [n for n in param_shapes(model.dims) if n.startswith(SAM_PREFIX + "adapters.") or n.startswith(M_ + "bbox_prediction_head.")
+             or (model.config.use_temp_objectness and n.startswith(M_ + "temporal_objectness_head."))]
+    return _reinit(model, names)
+
+
+def initialize_custom_layers_in_global_encoder(vision_tower):
+    """train.py:222-230: fresh CLIP spatio-temporal adapters (alpha 0: an exact identity). Takes the model (this build has no
+    separate vision-tower module object; `model.get_vision_tower()` returns the model itself for this call)."""
+    from .synthetic import param_shapes
+    model = getattr(vision_tower, "_grove_model", vision_tower)
+    names = [n for n in param_shapes(model.dims) if ".vision_model.encoder.adapters." in n]
+    return _reinit(model, names)
+
+
+def setup_lora_config(model, args):
+    """train.py:336-359. LoRA / peft is out of scope (every shipped script passes --lora_r 0): importable, refuses to run."""
+    raise NotImplementedError("setup_lora_config: LoRA (peft) is out of scope for the MI355X hot path; run with --lora_r 0 "
+                              "(train_scripts/*.sh) — merged LoRA checkpoints load through checkpoint.read_state_dict")
+
+
+def interpolate_positional_embeddings(ds_model, *a, **k):
+    """train.py:561-576: SAM's absolute and global-block relative position tables from the 1024-pixel geometry to 512. Two forms:
+    `(state_dict, img_size, patch_size, global_blocks)` resizes a checkpoint's tables (checkpoint.interpolate_positional_embeddings:
+    what load_grove_weights calls); `(model)` — the reference's call — checks that the model's tables have the 512 geometry its
+    kernels are built for (they are allocated at that size and every checkpoint is resized while loading) and returns the keys it
+    had to change: none."""
+    if isinstance(ds_model, dict):
+        from .checkpoint import interpolate_positional_embeddings as on_state_dict
+        return on_state_dict(ds_model, *a, **k)
+    from .model.sam import S as SAM_PREFIX
+    d = ds_model.dims
+    g = d.sam_image // d.sam_patch
+    sd = ds_model._sd
+    assert sd[SAM_PREFIX + "pos_embed"].shape[1] == g, "SAM pos_embed is not at the model's geometry"
+    for i in d.sam_global:
+        assert sd[SAM_PREFIX + f"blocks.{i}.attn.rel_pos_h"].shape[0] == 2 * g - 1
+    return []
+
+
+def initialize_model(args, tokenizer=None, dims=None, state_dict=None, device=None):
+    """train.py:194-218 `initialize_model(args, tokenizer)`: GROVEForCausalLM in bf16 with the loss weights / token ids of `args`
+    (`from_pretrained(args.version)` when that is a local checkpoint directory; deterministic synthetic weights otherwise — there
+    are no checkpoints offline), custom layers re-initialised, token ids of the tokenizer on the config. The vocabulary is
+    len(tokenizer) (the reference resizes the embeddings afterwards, train.py:330; here the tables are allocated at that size).
+    `dims= / state_dict= / device=` are this build's additions (tests and bench.py build tiny / synthetic models)."""
+    from dataclasses import replace
+    from .synthetic import FULL, TINY
+    if isinstance(tokenizer, GroveDims):  # round-3 call form initialize_model(args, dims, ...)
+        tokenizer, dims = None, tokenizer
+    check_supported(args)
     device = device or torch.device("cuda", args.local_rank)
-    return GROVEForCausalLM(dims=dims, device=device, state_dict=state_dict, train=True,
-                            det_token_idx=getattr(args, "det_token_idx", dims.det_token_idx), num_frames=args.num_frames,
-                            out_dim=args.out_dim, ce_loss_weight=args.ce_loss_weight, giou_loss_weight=args.giou_loss_weight,
-                            temp_objectness_loss_weight=args.temp_objectness_loss_weight,
-                            train_mask_decoder=args.train_mask_decoder, use_temp_objectness=True)
+    if dims is None:
+        dims = FULL if getattr(args, "dims", "full") == "full" else TINY
+    if tokenizer is not None and state_dict is None and getattr(args, "dims", "full") == "full":
+        dims = replace(dims, vocab=len(tokenizer), det_token_idx=args.det_token_idx,
+                       bos_token_id=tokenizer.bos_token_id, eos_token_id=tokenizer.eos_token_id, pad_token_id=tokenizer.pad_token_id)
+    kw = dict(device=device, train=True, det_token_idx=getattr(args, "det_token_idx", dims.det_token_idx), num_frames=args.num_frames,
+              out_dim=args.out_dim, ce_loss_weight=args.ce_loss_weight, giou_loss_weight=args.giou_loss_weight,
+              temp_objectness_loss_weight=args.temp_objectness_loss_weight, train_mask_decoder=args.train_mask_decoder,
+              use_temp_objectness=getattr(args, "dataset", "HowToGround") == "HowToGround",   # train.py:203
+              bbox_token_idx=getattr(args, "bbox_token_idx", None))
+    if state_dict is None and os.path.isdir(str(getattr(args, "version", ""))):
+        model = GROVEForCausalLM.from_pretrained(args.version, torch_dtype=torch.bfloat16, low_cpu_mem_usage=True, dims=dims, **kw)
+        initialize_custom_layers_in_model(model)
+    else:
+        if state_dict is None:
+            from .synthetic import synthetic_state_dict
+            state_dict = synthetic_state_dict(dims, device=device, dtype=torch.bfloat16)
+        model = GROVEForCausalLM(dims=dims, state_dict=state_dict, **kw)
+    if tokenizer is not None:
+        model.config.eos_token_id, model.config.bos_token_id, model.config.pad_token_id = (
+            tokenizer.eos_token_id, tokenizer.bos_token_id, tokenizer.pad_token_id)
+    return model
 
 
-def prepare_model_for_training(model):
-    """train.py:234-333 freeze policy: returns the names that train (the rest is frozen by construction)."""
-    return trainable_names(model.dims)
+def prepare_model_for_training(model, tokenizer=None, args=None):
+    """train.py:234-333: the freeze policy. This build fixes the trainable set when the model is allocated (flat gradient buffer),
+    so the call VALIDATES that the model was built for the policy `args` asks for — --lora_r 0, --pretrained, the
+    --train_mask_decoder choice, len(tokenizer) rows in embed_tokens / lm_head (train.py:330 resize_token_embeddings) — and
+    returns the names that train. Gradient checkpointing (train.py:237) is not applied: activations are kept."""
+    if args is not None:
+        check_supported(args)
+        if bool(args.train_mask_decoder) != bool(model.config.train_mask_decoder):
+            raise RuntimeError("model was built with train_mask_decoder=%s, args say %s" % (model.config.train_mask_decoder, args.train_mask_decoder))
+    if tokenizer is not None and len(tokenizer) != model.dims.vocab and getattr(args, "dims", "full") == "full":
+        raise RuntimeError(f"len(tokenizer) = {len(tokenizer)} but the model's embedding tables have {model.dims.vocab} rows: build it with "
+                           "initialize_model(args, tokenizer)")
+    return list(model.trainable) if getattr(model, "trainable", None) is not None else trainable_names(model.dims, model.config.train_mask_decoder)
 
 
 class WarmupDecayLR:
@@ -557,16 +840,82 @@ class AverageMeter:
         self.avg = self.sum / self.count
 
 
-def train(data_iter, engine: GroveEngine, epoch, args, log=print):
-    """train.py:704-793: the hot loop. data_iter yields the collate dict (dataset/dataset.py:64-70)."""
-    trackers = {k: AverageMeter(k) for k in ("loss", "ce_loss", "giou_loss", "l1_loss", "temp_objectness_loss")}
+LOSS_KEYS = ("loss", "ce_loss", "giou_loss", "l1_loss", "temp_objectness_loss")
+
+
+class ScalarWriter:
+    """Stand-in for tensorboard's SummaryWriter (train.py:113-121; tensorboard is not installed): `add_scalar` appends one JSON
+    line to <log_dir>/scalars.jsonl."""
+
+    def __init__(self, log_dir):
+        os.makedirs(log_dir, exist_ok=True)
+        self.path = os.path.join(log_dir, "scalars.jsonl")
+
+    def add_scalar(self, tag, value, step):
+        import json
+        with open(self.path, "a") as fh:
+            fh.write(json.dumps({"tag": tag, "value": float(value), "step": int(step)}) + "\n")
+
+
+def initialize_environment(args):
+    """train.py:113-121: log directory <log_base_dir>/<exp_name> (or --log_dir) and, on rank 0, the scalar writer."""
+    if not getattr(args, "log_dir", None):
+        args.log_dir = os.path.join(args.log_base_dir, args.exp_name)
+    if not dist.is_initialized() or dist.get_rank() == 0:
+        try:
+            from torch.utils.tensorboard import SummaryWriter
+            return SummaryWriter(args.log_dir)
+        except Exception:
+            return ScalarWriter(args.log_dir)
+    return None
+
+
+def _to_device_batch(batch, dev):
+    """dict_to_cuda + `.bfloat16()` of the two image tensors (train.py:751-753); tensors already in HBM pass through."""
+    out = dict(batch)
+    for k, v in batch.items():
+        if torch.is_tensor(v) and v.device != dev:
+            out[k] = v.to(dev, non_blocking=True)
+    for k in ("global_enc_images", "grounding_enc_images"):
+        if k in out and torch.is_tensor(out[k]) and out[k].dtype != torch.bfloat16:
+            out[k] = out[k].bfloat16()
+    return out
+
+
+def train(data_loader, model, epoch, *rest, log=None):
+    """train.py:704-793, the hot loop, under BOTH call forms:
+      reference: train(data_loader, model_engine, epoch, scheduler, writer, dataset_iter, args, logger) -> dataset_iter
+                 (the iterator restarts from data_loader on StopIteration, train.py:707-713; lr goes to writer as "train/lr");
+      short:     train(data_iter, engine, epoch, args, log=print) -> data_iter  (an endless iterator: the synthetic loader).
+    Per step: grad_accumulation_steps micro-batches of engine(**batch) / engine.backward(loss) / engine.step(); every print_freq
+    steps the meters of all ranks are folded in ONE all-reduce (the reference issues one blocking all-reduce per meter,
+    utils/utils.py:72) and rank 0 logs the reference's line."""
+    engine = model
+    if len(rest) == 5:
+        scheduler, writer, dataset_iter, args, logger = rest
+        say = logger.info if logger is not None and hasattr(logger, "info") else (logger or log or print)
+    else:
+        args = rest[0]
+        say = rest[1] if len(rest) > 1 else (log or print)
+        scheduler, writer, dataset_iter, data_loader = engine.scheduler, None, data_loader, None
+
+    def next_input(it):
+        try:
+            return next(it), it
+        except StopIteration:
+            if data_loader is None:
+                raise
+            it = iter(data_loader)
+            return next(it), it
+
+    trackers = {k: AverageMeter(k) for k in LOSS_KEYS}
     batch_time = AverageMeter("Time")
     engine.train()
     end = time.time()
     for global_step in range(args.steps_per_epoch):
         for _ in range(args.grad_accumulation_steps):
-            batch = next(data_iter)
-            out = engine(**batch)
+            batch, dataset_iter = next_input(dataset_iter)
+            out = engine(**_to_device_batch(batch, engine.dev))
             vals = torch.stack([out[k].float() for k in trackers if k in out]).cpu()  # one D2H copy per micro-step
             for (k, tr), v in zip([(k, t) for k, t in trackers.items() if k in out], vals.tolist()):
                 tr.update(v, 1)
@@ -583,26 +932,56 @@ def train(data_iter, engine: GroveEngine, epoch, args, log=print):
                     tr.sum, tr.count = t[2 * i], t[2 * i + 1]
                     tr.avg = tr.sum / (tr.count + 1e-5)
             if engine.rank == 0:
-                log(f"Epoch: [{epoch}][{global_step + 1}/{args.steps_per_epoch}] time {batch_time.avg:.3f} " +
+                say(f"Epoch: [{epoch}][{global_step + 1}/{args.steps_per_epoch}] time {batch_time.avg:.3f} " +
                     " ".join(f"{k} {tr.avg:.4f}" for k, tr in trackers.items()))
+                if writer is not None:
+                    for k, tr in trackers.items():
+                        writer.add_scalar(f"train/{k}", tr.avg, global_step)
+                    writer.add_scalar("metrics/total_secs_per_batch", batch_time.avg, global_step)
             for tr in trackers.values():
                 tr.reset()
-    return data_iter
+        if global_step != 0 and writer is not None and engine.rank == 0:
+            writer.add_scalar("train/lr", scheduler.get_last_lr()[0], global_step)
+    return dataset_iter
 
 
 @torch.no_grad()
-def validate_model_performance(val_iter, engine: GroveEngine, n_batches, args):
-    """train.py:876-916 (the live loss-validation branch; the bbox branch cannot run in the reference, quirk Q8)."""
-    meters = {k: AverageMeter(k) for k in ("loss", "ce_loss", "giou_loss", "l1_loss", "temp_objectness_loss")}
+def validate_model_performance(validation_loader, training_model, *rest):
+    """train.py:796-916, the live loss-validation branch (876-916; the bbox branch cannot run in the reference, quirk Q8), under
+    both call forms:
+      reference: validate_model_performance(val_loader, model_engine, epoch, writer, args) -> avg_val_loss, the mean of the
+                 giou, l1 (and, for HowToGround, temp_objectness) meters (train.py:905-908); every batch of the loader is used;
+      short:     validate_model_performance(val_iter, engine, n_batches, args) -> {loss key: mean} incl. "val_loss" = the
+                 reference's figure (an endless iterator: n_batches are drawn)."""
+    engine = training_model
+    ref_form = len(rest) == 3
+    if ref_form:
+        epoch, writer, args = rest
+        n_batches = None
+    else:
+        n_batches, args = rest
+        epoch, writer = 0, None
+    if getattr(args, "bbox_validation", False):
+        check_supported(args)
+    use_obj = engine.module.config.use_temp_objectness
+    keys = [k for k in LOSS_KEYS if use_obj or k != "temp_objectness_loss"]
+    meters = {k: AverageMeter(k) for k in keys}
     engine.eval()
     was = engine.module._train_mode
     engine.module._train_mode = False  # loss only: no tape, no saved activations, no dlogits
     try:
-        for _ in range(n_batches):
-            out = engine.module(**next(val_iter))
+        it = iter(validation_loader)
+        i = 0
+        while n_batches is None or i < n_batches:
+            try:
+                batch = next(it)
+            except StopIteration:
+                break
+            out = engine.module(**_to_device_batch(batch, engine.dev))
             for k, m in meters.items():
                 if k in out:
                     m.update(float(out[k]), 1)
+            i += 1
     finally:
         engine.module._ctx = None
         engine.module._train_mode = was
@@ -613,14 +992,36 @@ def validate_model_performance(val_iter, engine: GroveEngine, n_batches, args):
         for i, m in enumerate(meters.values()):
             m.sum, m.count = t[2 * i], t[2 * i + 1]
             m.avg = m.sum / max(m.count, 1e-5)
-    return {k: m.avg for k, m in meters.items()}
+    parts = ["giou_loss", "l1_loss"] + (["temp_objectness_loss"] if use_obj else [])
+    avg_val_loss = sum(meters[k].avg for k in parts) / len(parts)      # train.py:905-908
+    if writer is not None and engine.rank == 0:
+        for k, m in meters.items():
+            writer.add_scalar(f"val/{k}", m.avg, epoch)
+    if ref_form:
+        return avg_val_loss
+    res = {k: m.avg for k, m in meters.items()}
+    res["val_loss"] = avg_val_loss
+    return res
 
 
-def save_checkpoint(engine: GroveEngine, args, epoch, metric_name, metric_value, is_best):
-    """train.py:685-701: only improving checkpoints are kept."""
-    if is_best:
-        save_dir = os.path.join(args.log_dir, "ckpt_model_best")
-        engine.save_checkpoint(save_dir)
+def save_checkpoint(model_engine, *rest):
+    """train.py:685-701: only improving checkpoints are kept, in <log_dir>/ckpt_model_best, with the reference's marker file
+    `epoch_<e>_val_<metric>_<value>.pth`. Call forms: the reference's (model_engine, tokenizer, args, epoch, metric_name,
+    metric_value, is_best) and the short one without the tokenizer."""
+    if len(rest) == 6:
+        _tokenizer, args, epoch, metric_name, metric_value, is_best = rest
+    else:
+        args, epoch, metric_name, metric_value, is_best = rest
+    if not is_best:
+        return None
+    save_dir = os.path.join(args.log_dir, "ckpt_model_best")
+    if model_engine.rank == 0:
+        os.makedirs(save_dir, exist_ok=True)
+        torch.save({"epoch": epoch, f"val_{metric_name}": metric_value}, os.path.join(save_dir, f"epoch_{epoch}_val_{metric_name}_{metric_value}.pth"))
+    if dist.is_initialized():
+        dist.barrier()
+    model_engine.save_checkpoint(save_dir)
+    return save_dir
 
 
 def synthetic_loader(dims, args, device, rank, world, seed0=0):
@@ -638,11 +1039,12 @@ def synthetic_loader(dims, args, device, rank, world, seed0=0):
 
 
 def resume_training_from_checkpoint(engine, args, log=print):
-    """train.py:489-500: --auto_resume picks `<log_dir>/ckpt_model_last_epoch` / `ckpt_model_best` when present, --resume names a
-    directory; the epoch to continue from is derived from the restored step count."""
+    """train.py:489-500: --auto_resume picks `<log_dir>/ckpt_model` (the reference's name), else `ckpt_model_last_epoch` /
+    `ckpt_model_best` (the directories save_checkpoint writes, train.py:688-690) when present, --resume names a directory; the
+    epoch to continue from is derived from the restored step count (the reference parses it out of the `latest` tag)."""
     path = args.resume
     if not path and args.auto_resume:
-        for name in ("ckpt_model_last_epoch", "ckpt_model_best"):
+        for name in ("ckpt_model", "ckpt_model_last_epoch", "ckpt_model_best"):
             cand = os.path.join(args.log_dir, name)
             if os.path.exists(os.path.join(cand, "latest")):
                 path = cand
@@ -653,42 +1055,62 @@ def resume_training_from_checkpoint(engine, args, log=print):
         log(f"Resume training from {path}, start from epoch {args.start_epoch}")
 
 
-def main(args, dims=None, log=print):
-    """train.py:609-680 for the hot path: model -> (optional fine-tune weights) -> engine -> resume -> epochs of
-    train() + loss validation + keep-the-best checkpointing, one process per GPU (launch with
-    `python -m torch.distributed.run --nproc-per-node N -m grove_amd.train ...`, or one plain process for N = 1)."""
-    from .synthetic import FULL, TINY, synthetic_state_dict
+def init_distributed(local_rank, timeout_s=1800):
+    """deepspeed.init_distributed() (train.py:932): one process per GPU, RCCL ("nccl" IS RCCL on ROCm) bound to this rank's device,
+    with a finite timeout so that a wedged first collective ends the job with a message instead of hanging it."""
+    import datetime
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    device = torch.device("cuda", args.local_rank)
-    torch.cuda.set_device(device)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        backend = os.environ.get("GROVE_BACKEND", "nccl")  # "nccl" IS RCCL on ROCm; gloo only for one-GPU rehearsals
-        dist.init_process_group(backend, **({"device_id": device} if backend == "nccl" else {}))
+        backend = os.environ.get("GROVE_BACKEND", "nccl")  # gloo only for one-GPU rehearsals
+        kw = {"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}
+        dist.init_process_group(backend, timeout=datetime.timedelta(seconds=timeout_s), **kw)
+    return world
+
+
+def main(args, dims=None, log=print):
+    """train.py:609-680 for the hot path, in the reference's order: tokenizer -> initialize_model -> prepare_model_for_training ->
+    interpolate_positional_embeddings -> (optional --grove_weights, non-strict) -> engine -> resume -> epochs of train() + loss
+    validation + keep-the-best checkpointing. One process per GPU (launch with `python -m torch.distributed.run --nproc-per-node N
+    -m grove_amd.train ...`, or one plain process for N = 1). Datasets are out of scope: the loaders are synthetic."""
+    from .synthetic import FULL, TINY
+    check_supported(args)
+    device = torch.device("cuda", args.local_rank)
+    torch.cuda.set_device(device)
+    world = init_distributed(args.local_rank)
     rank = dist.get_rank() if dist.is_initialized() else 0
+    tiny = dims is not None or args.dims == "tiny"
     if dims is None:
         dims = FULL if args.dims == "full" else TINY
+    tokenizer = setup_tokenizer_and_special_tokens(args)
+    if tiny:  # tiny test geometry: its own small vocabulary / [DET] id (no tokenizer is that small)
+        args.det_token_idx = dims.det_token_idx
     if args.grove_weights:
-        log(f"Fine-tuning using GROVE weights from {args.grove_weights}.")
-        from .checkpoint import dims_from_checkpoint, read_state_dict
+        from .checkpoint import dims_from_checkpoint, load_grove_weights, read_state_dict
         sd = read_state_dict(args.grove_weights)
         dims = dims_from_checkpoint(args.grove_weights, sd, base=dims)
-        model = initialize_model(args, dims, state_dict=None, device=device)
-        from .checkpoint import load_grove_weights
+        if not tiny:
+            args.det_token_idx = min(args.det_token_idx, dims.vocab - 1)
+        model = GROVEForCausalLM(dims=dims, device=device, state_dict=None, train=True, det_token_idx=args.det_token_idx,
+                                 num_frames=args.num_frames, out_dim=args.out_dim, ce_loss_weight=args.ce_loss_weight,
+                                 giou_loss_weight=args.giou_loss_weight, temp_objectness_loss_weight=args.temp_objectness_loss_weight,
+                                 train_mask_decoder=args.train_mask_decoder, use_temp_objectness=args.dataset == "HowToGround")
+    else:
+        model = initialize_model(args, None if tiny else tokenizer, dims=dims, device=device)
+    prepare_model_for_training(model, None if (tiny or args.grove_weights) else tokenizer, args)
+    interpolate_positional_embeddings(model)
+    if args.grove_weights:
+        log(f"Fine-tuning using GROVE weights from {args.grove_weights}.")
         rep = load_grove_weights(model, args.grove_weights, sd=sd, log=log if rank == 0 else (lambda m: None))
         if rank == 0:
             log(f"missing keys: {len(rep.missing_keys)} ({len(rep.initialised)} trainable ones initialised like the reference's "
                 f"constructors, {len(rep.missing_frozen)} frozen left zero), unexpected keys: {len(rep.unexpected_keys)}")
         del sd
-    else:
-        sd = synthetic_state_dict(dims, device=device, dtype=torch.bfloat16)  # no checkpoints offline: deterministic random init
-        model = initialize_model(args, dims, state_dict=sd, device=device)
-        del sd
-    prepare_model_for_training(model)
-    engine = GroveEngine(model, args)
+    engine = GroveEngine(model, args, exchange=args.exchange, overlap=not args.no_comm_overlap, sparse_embed=not args.dense_embed)
     resume_training_from_checkpoint(engine, args, log)
-    train_iter = synthetic_loader(dims, args, device, rank, world, seed0=0)
-    val_iter = synthetic_loader(dims, args, device, rank, world, seed0=10 ** 6)
+    train_iter = synthetic_loader(model.dims, args, device, rank, world, seed0=0)
+    val_iter = synthetic_loader(model.dims, args, device, rank, world, seed0=10 ** 6)
+    writer = initialize_environment(args) if rank == 0 else None
     if args.eval_only:
         val = validate_model_performance(val_iter, engine, args.val_batches, args)
         if rank == 0:
@@ -697,24 +1119,34 @@ def main(args, dims=None, log=print):
     best_val_loss = float("inf")
     val = None
     for epoch in range(args.start_epoch, args.epochs):
-        train_iter = train(train_iter, engine, epoch, args, log)
+        train_iter = train(None, engine, epoch, engine.scheduler, writer, train_iter, args, log)
         if dist.is_initialized():
             dist.barrier()
         val = validate_model_performance(val_iter, engine, args.val_batches, args)
-        cur = val["loss"]
+        cur = val["val_loss"]
         is_best = cur < best_val_loss
         best_val_loss = min(cur, best_val_loss)
         if rank == 0:
             log(f"Epoch: {epoch}, Current Validation Loss: {cur:.4f}, Best Validation Loss: {best_val_loss:}")
-        save_checkpoint(engine, args, epoch, "loss", f"{cur:.4f}", is_best)
+        save_checkpoint(engine, tokenizer, args, epoch, "loss", f"{cur:.4f}", is_best)
     return {"best_val_loss": best_val_loss, "last_val": val, "global_step": engine.global_step}
+
+
+def set_seed(seed):
+    """train.py:918-927."""
+    import random
+    import numpy as np
+    torch.manual_seed(seed)
+    torch.cuda.manual_seed_all(seed)
+    np.random.seed(seed)
+    random.seed(seed)
 
 
 if __name__ == "__main__":
     import sys
     _args = parse_args(sys.argv[1:])
     _args.local_rank = int(os.environ.get("LOCAL_RANK", _args.local_rank))
-    torch.manual_seed(42)
+    set_seed(42)
     main(_args)
     if dist.is_initialized():
         dist.destroy_process_group()

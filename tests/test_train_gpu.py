@@ -14,9 +14,9 @@ bf = torch.bfloat16
 def _engine(dev, lr=1e-3):
     from grove_amd import train as T
     from grove_amd.synthetic import TINY, synthetic_state_dict
-    args = T.parse_args([])
+    args = T.shipped_args()
     args.lr, args.steps_per_epoch, args.print_freq = lr, 4, 2
-    model = T.initialize_model(args, TINY, state_dict=synthetic_state_dict(TINY), device=dev)
+    model = T.initialize_model(args, dims=TINY, state_dict=synthetic_state_dict(TINY), device=dev)
     return T, args, TINY, T.GroveEngine(model, args, total_steps=1000)
 
 
@@ -200,7 +200,7 @@ def test_train_main_entry_point(dev, tmp_path):
     """train.py:609-680 / :929-937: `main(args)` = model -> engine -> epochs of train() + loss validation + keep-the-best
     checkpoint, on the synthetic loader; then --auto_resume continues from the saved step and --eval_only validates."""
     from grove_amd import train as T
-    argv = ["--dims", "tiny", "--epochs", "2", "--steps_per_epoch", "3", "--batch_size", "1", "--text_len", "40", "--n_det", "2",
+    argv = ["--lora_r", "0", "--pretrained", "--train_mask_decoder", "--dims", "tiny", "--epochs", "2", "--steps_per_epoch", "3", "--batch_size", "1", "--text_len", "40", "--n_det", "2",
             "--val_batches", "1", "--lr", "1e-3", "--log_dir", str(tmp_path), "--print_freq", "1"]
     args = T.parse_args(argv)
     logs = []
