@@ -237,10 +237,17 @@ def cpu_baseline(args, dev=None):
     cores = min(os.cpu_count() or 1, 64)  # torch CPU kernels stop scaling (and oversubscribe) beyond ~64 threads
     torch.set_num_threads(cores)
     mode = args.cpu_baseline
-    fwd_s, bwd_s, sampled, S = cpu_layer_samples(args)
+    if mode == "auto":  # the whole fwd+bwd MEASURED when the host can hold it (~80 GB: fp32 weights + autograd's saved activations)
+        mode = "train" if host_memory_available_gb() >= 128 else "window"
+    cpu = cpu_model_name()
+    if mode == "train":
+        fwd_s = bwd_s = sampled = 0.0
+        S = 575 + args.text_len
+    else:
+        fwd_s, bwd_s, sampled, S = cpu_layer_samples(args)
     if mode == "sampled":
         total = fwd_s + bwd_s
-        return {"value": round(8.0 / total, 4), "unit": "frames/s", "cores": cores, "kind": "port", "measured": False, "seconds_per_window": round(total, 1),
+        return {"value": round(8.0 / total, 4), "unit": "frames/s", "cores": cores, "cpu_model": cpu, "kind": "port", "measured": False, "seconds_per_window": round(total, 1),
                 "sample": (f"oracle fp32 at full dims, one 8-frame window: 1 CLIP layer fwd, 1 windowed + 1 global SAM block fwd+bwd, "
                            f"1 SAM adapter fwd+bwd, 1 LLaMA layer (S={S}) fwd+dgrad; {sampled:.1f} s measured, scaled by layer counts "
                            f"(stems/projector/decoder/lm_head <2% of FLOPs, not included) to {total:.0f} s per window")}
@@ -262,7 +269,8 @@ def cpu_baseline(args, dev=None):
         out["loss"].backward()
         t2 = time.perf_counter()
         total = t2 - t0
-        return {"value": round(8.0 / total, 4), "unit": "frames/s", "cores": cores, "kind": "port", "measured": True, "seconds_per_window": round(total, 1),
+        return {"value": round(8.0 / total, 4), "unit": "frames/s", "cores": cores, "cpu_model": cpu, "kind": "port", "measured": True, "seconds_per_window": round(total, 1),
+                "forward_seconds_measured": round(t1 - t0, 1), "backward_seconds_measured": round(t2 - t1, 1),
                 "sample": (f"oracle fp32 at full dims, ONE whole 8-frame window of the step (B=1, T=8, L={args.text_len}), forward {t1 - t0:.1f} s + "
                            f"backward through torch autograd {t2 - t1:.1f} s, timed end to end on {cores} threads")}
     sd = LazyRoundedWeights(d, gen_device=dev if dev is not None else "cpu")
@@ -271,7 +279,7 @@ def cpu_baseline(args, dev=None):
         O.model_forward(sd, d, **kw)
     t_fwd = time.perf_counter() - t0 - sd.fetch_seconds
     total = t_fwd + bwd_s
-    return {"value": round(8.0 / total, 4), "unit": "frames/s", "cores": cores, "kind": "port", "measured": True, "seconds_per_window": round(total, 1),
+    return {"value": round(8.0 / total, 4), "unit": "frames/s", "cores": cores, "cpu_model": cpu, "kind": "port", "measured": True, "seconds_per_window": round(total, 1),
             "forward_seconds_measured": round(t_fwd, 1), "forward_frames_per_s": round(8.0 / t_fwd, 4), "backward_seconds_from_layer_samples": round(bwd_s, 1),
             "sample": (f"oracle fp32 at full dims, ONE whole 8-frame window of the step (B=1, T=8, L={args.text_len}): the full forward (SAM + CLIP + projector "
                        f"+ LLaMA + box decoder) run and timed end to end = {t_fwd:.1f} s on {cores} threads (weight generation, {sd.fetch_seconds:.1f} s, excluded; "
@@ -337,26 +345,136 @@ def tiny_train_parity(dev):
         rs.append(r.reshape(-1))
     g, r = torch.cat(gs), torch.cat(rs)
     terms = ("ce_loss", "giou_loss", "l1_loss", "temp_objectness_loss")
-    return {"loss_rel_err_max": round(max(abs(float(out[k]) - float(ref[k])) / max(abs(float(ref[k])), 1e-12) for k in terms), 5),
+    return {"box_l1_train_mode": round(float((out["flat_boxes"].detach().cpu() - ref["flat_boxes"].detach()).abs().mean()), 6),
+            "loss_rel_err_max": round(max(abs(float(out[k]) - float(ref[k])) / max(abs(float(ref[k])), 1e-12) for k in terms), 5),
             "objectness_logit_abs_err": round(float((out["flat_logits"].detach().cpu() - ref["flat_logits"].detach()).abs().max()), 5),
             "grad_cosine": round(float(torch.nn.functional.cosine_similarity(g, r, dim=0)), 5),
             "grad_norm_ratio": round(float(g.norm() / r.norm()), 4), "trainable_elements": int(g.numel())}
 
 
-def self_launch(n, argv):
+class Progress:
+    """Per-rank stage marker + stall watchdog. `stage(name, limit_s)` prints the stage to stderr, writes it to
+    $GROVE_BENCH_PROGRESS_DIR/rank<r> (read by the self-launching parent when it has to kill a stalled run) and re-arms
+    faulthandler: a rank that sits in one stage longer than `limit_s` dumps the Python stack of every thread — i.e. WHICH call it
+    sat in — to stderr and exits non-zero, so a wedged first 8-GPU run ends in minutes with a record instead of burning the
+    driver's whole time limit. (RCCL's own watchdog reports a stuck collective after the process-group timeout, 120 s.)"""
+
+    def __init__(self, rank):
+        self.rank, self.dir = rank, os.environ.get("GROVE_BENCH_PROGRESS_DIR")
+        self.t0 = time.time()
+
+    def stage(self, name, limit_s=300):
+        import faulthandler
+        faulthandler.cancel_dump_traceback_later()
+        msg = f"[bench rank {self.rank}] +{time.time() - self.t0:6.1f}s stage: {name}"
+        print(msg, file=sys.stderr, flush=True)
+        if self.dir:
+            try:
+                with open(os.path.join(self.dir, f"rank{self.rank}"), "w") as fh:
+                    fh.write(f"{time.time():.1f} {name}\n")
+            except OSError:
+                pass
+        if limit_s:
+            faulthandler.dump_traceback_later(limit_s, exit=True, file=sys.stderr)
+
+    def done(self):
+        import faulthandler
+        faulthandler.cancel_dump_traceback_later()
+        self.stage("done", limit_s=0)
+
+
+def self_launch(n, argv, timeout_s=1500):
     """`python bench.py --gpus N` without a launcher around it: start N ranks (one per GPU) with torch.distributed.run as a CHILD
-    process and pass its single JSON line through. This parent never touches the GPU (no HIP call, no torch.cuda query), so
-    nothing is re-exec'ed from a GPU-initialised process; the child's exit code becomes ours."""
+    process (its own session / process group) and pass its single JSON line through. This parent never touches the GPU (no HIP
+    call, no torch.cuda query), so nothing is re-exec'ed from a GPU-initialised process; the child's exit code becomes ours. If the
+    child has not finished after `timeout_s` the parent prints every rank's last stage (Progress files), kills the child's process
+    group — exactly the processes this call started — and exits 124."""
+    import signal
     import socket
     import subprocess
+    import tempfile
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    pdir = tempfile.mkdtemp(prefix="grove_bench_progress_")
+    env["GROVE_BENCH_PROGRESS_DIR"] = pdir
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
-    return subprocess.run(cmd, env=env).returncode
+    proc = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        rc = proc.wait(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        now = time.time()
+        print(f"[bench] {n}-rank run exceeded {timeout_s} s; last stage of every rank:", file=sys.stderr)
+        for r in range(n):
+            try:
+                ts, name = open(os.path.join(pdir, f"rank{r}")).read().strip().split(" ", 1)
+                print(f"[bench]   rank {r}: '{name}' for {now - float(ts):.0f} s", file=sys.stderr)
+            except (OSError, ValueError):
+                print(f"[bench]   rank {r}: never reported a stage (stuck before / in the rendezvous)", file=sys.stderr)
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        proc.wait()
+        rc = 124
+    finally:
+        import shutil
+        shutil.rmtree(pdir, ignore_errors=True)
+    return rc
+
+
+def attention_flops(dims, windows, frames, S, train=True):
+    """Executed attention FLOPs of one step (2 x MAC; 4 L_q L_k d forward, 10 L_q L_k d backward per (batch, head); causal halves
+    LLaMA's): CLIP forward (23 layers), LLaMA fwd + bwd, SAM windowed blocks on the REAL tokens (1024 queries x 196 keys per frame
+    and head) and global blocks, backward for blocks after the first adapter (blocks 8-31)."""
+    d = dims
+    bwd = 2.5 if train else 0.0
+    tok = d.clip_tokens
+    clip = frames * (d.clip_layers - 1) * d.clip_heads * 4.0 * tok * tok * (d.clip_dim // d.clip_heads)
+    llama = windows * d.n_layers * d.n_heads * 2.0 * S * S * d.head_dim * (1.0 + bwd)
+    g2 = d.sam_grid ** 2
+    hd = d.sam_dim // d.sam_heads
+    first_grad = min(d.sam_global) + 1
+    n_win = d.sam_depth - len(d.sam_global)
+    n_win_bwd = sum(1 for i in range(first_grad, d.sam_depth) if i not in d.sam_global)
+    n_glob_bwd = sum(1 for i in d.sam_global if i >= first_grad)
+    win = frames * d.sam_heads * 4.0 * g2 * d.sam_window ** 2 * hd * (n_win + bwd * n_win_bwd)
+    glob = frames * d.sam_heads * 4.0 * g2 * g2 * hd * (len(d.sam_global) + bwd * n_glob_bwd)
+    return clip + llama + win + glob
+
+
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
+def host_memory_available_gb():
+    """min(MemAvailable, the cgroup's remaining allowance) in GB — what an in-process CPU baseline may use without being killed."""
+    avail = None
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable"):
+                avail = int(line.split()[1]) / 1e6
+    except OSError:
+        pass
+    for lim, cur in (("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory.current"),
+                     ("/sys/fs/cgroup/memory/memory.limit_in_bytes", "/sys/fs/cgroup/memory/memory.usage_in_bytes")):
+        try:
+            m = open(lim).read().strip()
+            if m != "max":
+                left = (int(m) - int(open(cur).read().strip())) / 1e9
+                avail = left if avail is None else min(avail, left)
+        except (OSError, ValueError):
+            pass
+    return avail if avail is not None else 0.0
 
 
 def infer_box_l1(dev, dtype):
@@ -488,9 +606,12 @@ def main():
     ap.add_argument("--text_len", type=int, default=128)
     ap.add_argument("--dims", default="full", choices=["full", "tiny"])
     ap.add_argument("--no_cpu_baseline", action="store_true")
-    ap.add_argument("--cpu_baseline", default="window", choices=["window", "train", "sampled"],
-                    help="CPU oracle leg: one whole window forward timed end to end (+ backward from layer samples; default), the whole "
-                         "window fwd+bwd timed (needs ~80 GB host memory), or per-layer samples only")
+    ap.add_argument("--cpu_baseline", default="auto", choices=["auto", "window", "train", "sampled"],
+                    help="CPU oracle leg: `train` = one whole window fwd+bwd through torch autograd, timed end to end (needs ~80 GB of host "
+                         "memory; what `auto` picks when the host has >= 128 GB available), `window` = the whole window forward timed + the "
+                         "backward from per-layer samples, `sampled` = per-layer samples only")
+    ap.add_argument("--launch_timeout", type=int, default=1500, help="--gpus N self-launch: seconds before the parent kills a stalled run")
+    ap.add_argument("--stage_timeout", type=int, default=300, help="seconds a rank may sit in one stage before it dumps its stacks and exits")
     ap.add_argument("--mode", default="train", choices=["train", "infer"],
                     help="train (default, the headline line: BASELINE config 3) or infer (config 5: inference + SAM masks, use --frames 32 --dtype fp8)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"], help="--mode infer: linear layers of the CLIP tower and the LLaMA stack")
@@ -508,7 +629,7 @@ def main():
     if args.gemm_blocks:
         os.environ["GROVE_GEMM_BLOCKS"] = str(args.gemm_blocks)  # (read when the library is loaded, in every rank)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(self_launch(args.gpus, sys.argv[1:]))
+        sys.exit(self_launch(args.gpus, sys.argv[1:], args.launch_timeout))
 
     # stdout carries exactly ONE line, the JSON: everything else that writes to fd 1 (RCCL prints its version banner there, from
     # every rank, when the box exports NCCL_DEBUG=VERSION — and flushes it at exit, i.e. AFTER a normal print) goes to stderr
@@ -523,21 +644,30 @@ def main():
     # moves the collectives through the host (RCCL refuses two ranks on one device); never set by the driver
     if os.environ.get("GROVE_BENCH_ONE_GPU"):
         local = 0
+    prog = Progress(rank)
+    prog.stage("rendezvous + process group", args.stage_timeout)
+    rccl_ranks = None
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        backend = os.environ.get("GROVE_BENCH_BACKEND", "nccl")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend)
+        from grove_amd.train import init_distributed
+        # 120 s: a collective that has not completed by then is wedged (a bucket is 128 MB); RCCL's watchdog then reports WHICH one
+        init_distributed(local, timeout_s=120, backend=os.environ.get("GROVE_BENCH_BACKEND", "nccl"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if world > 1:
+        prog.stage("first collective (all-reduce of ones)", args.stage_timeout)
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        rccl_ranks = int(ones.item())  # how many ranks the collective backend really summed over
+        assert rccl_ranks == dist.get_world_size() == world, (rccl_ranks, dist.get_world_size(), world)
     from grove_amd.synthetic import FULL, TINY
     dims = FULL if args.dims == "full" else TINY
 
     if args.mode == "infer":
+        prog.stage("inference bench", 3 * args.stage_timeout)
         line = infer_bench(args, dev, dims, world, rank)
+        line["config"]["rccl_ranks"] = rccl_ranks
+        prog.done()
         if rank == 0:
             if not args.no_cpu_baseline and world == 1:
                 try:  # parity figure of THIS mode's arithmetic (fp8: the quantised path's own figure)
@@ -550,6 +680,7 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         return
+    prog.stage("build model + engine (weights, broadcast)", 2 * args.stage_timeout)
     model, engine = build(dims, dev, args)
     model.tower_overlap = not args.serial_towers
     batch = make_batch(dims, dev, args, rank)
@@ -560,12 +691,15 @@ def main():
         engine.step()
         return out
 
+    prog.stage(f"warm-up ({args.warmup} steps)", args.stage_timeout)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    prog.stage("barrier before the timed region", args.stage_timeout)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    prog.stage(f"timed region ({args.steps} steps)", args.stage_timeout + 2 * args.steps)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
@@ -574,6 +708,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    prog.stage("max over ranks", args.stage_timeout)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -581,7 +716,9 @@ def main():
     frames = world * args.batch * args.frames * args.steps
     loss = float(out["loss"])
     exposed_ms = engine.exposed_comm_ms() if world > 1 else None  # last timed step: what the compute stream waited for the collectives
+    capped_launches = engine.exchange.reserved_launch_polls if (world > 1 and engine.exchange is not None) else None
 
+    prog.stage("instrumented step (per-kernel HIP events)", args.stage_timeout)
     per_kernel = instrumented_gemm_pass(engine, batch)
     dom = max(per_kernel, key=lambda k: per_kernel[k][2])  # the kernel that takes most of the step
     n_launch, flops, secs = per_kernel[dom]
@@ -606,8 +743,11 @@ def main():
                                              ("after the backward" if args.no_comm_overlap else "overlapped with the backward (per parameter group)") +
                                              (", embed_tokens dense" if args.dense_embed else ", embed_tokens as touched rows (all-gather of ids + rows, fp32 sum)")),
                        "exposed_comm_ms": (None if exposed_ms is None else round(exposed_ms, 3)),
-                       "gemm_persistent_blocks": args.gemm_blocks or "one per CU",
-                       "collective_backend": (dist.get_backend() if world > 1 else None),
+                       "gemm_persistent_blocks": args.gemm_blocks or ("one per CU" if world == 1 else
+                                                                      f"one per CU; CUs - {engine.exchange.reserve_cus} while gradient buckets are in flight "
+                                                                      f"({capped_launches} GEMM launches under the cap over the run)"),
+                       "collective_backend": (dist.get_backend() if world > 1 else None), "rccl_ranks": rccl_ranks,
+                       "rccl_max_channels": (os.environ.get("NCCL_MAX_NCHANNELS") if world > 1 else None),
                        "frames_per_sec_per_gpu": round(frames / dt / world, 3), "last_loss": round(loss, 4),
                        "towers": "serial" if args.serial_towers else "SAM tower on a second stream beside CLIP->LLaMA (roofline: one extra step with the towers serialised)"},
             "roofline": {"bound": "mfma", "achieved": round(flops / secs / 1e12, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
@@ -618,7 +758,16 @@ def main():
                          "all_gemm_kernels": {"launches_per_step": all_n, "flops_per_step": all_f, "achieved": round(all_f / all_s / 1e12, 2),
                                               "share_of_step": round(all_s / (dt / args.steps), 3)}},
         }
+        S_seq = 575 + args.text_len
+        attn_f = attention_flops(dims, args.batch * args.frames // 8, args.batch * args.frames, S_seq)
+        step_s = dt / args.steps
+        res["step_roofline"] = {"bound": "mfma", "achieved": round((all_f + attn_f) / step_s / 1e12, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                                "frac": round((all_f + attn_f) / step_s / 1e12 / PEAK_BF16_TFLOPS, 4),
+                                "flops_per_step": {"gemm_executed": all_f, "attention_executed": attn_f},
+                                "note": "all executed GEMM FLOPs (instrumented step) + attention FLOPs (4 LqLk d fwd, 10 bwd; real SAM tokens) / ms_per_step / peak: "
+                                        "the whole step incl. norms, element-wise passes, optimizer — not only the dominant kernel"}
         if args.dims == "full":
+            prog.stage("stage figures (ViT+LLaMA forward, decode)", 2 * args.stage_timeout)
             try:
                 res["fused_vit_llama_forward"] = vit_llama_forward(model, batch, dims)
             except Exception as e:
@@ -643,13 +792,16 @@ def main():
                 res["full_depth_parity_recorded"] = rec
             except Exception:
                 pass
+            prog.stage("parity figures + CPU baseline (oracle on the host cores)", 4 * args.stage_timeout)
             try:
-                res["box_l1_vs_oracle_tiny"] = round(tiny_box_l1(dev), 6)
-                res["train_parity_vs_oracle_tiny"] = tiny_train_parity(dev)
+                res["box_l1_vs_oracle_tiny"] = round(tiny_box_l1(dev), 6)  # inference model (fp32 streams, fp32 box path): the configuration boxes are emitted from
+                res["train_parity_vs_oracle_tiny"] = tiny_train_parity(dev)  # the training-mode model the step above times (incl. its own box L1)
                 res["cpu_baseline"] = cpu_baseline(args, dev)
             except Exception as e:  # the baseline is informational; never lose the measured line
                 res["cpu_baseline"] = {"error": repr(e)}
+        prog.done()
         os.write(real_stdout, (json.dumps(res) + "\n").encode())
+    prog.done()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -1597,6 +1597,7 @@ extern "C" int grove_gemm_set_persistent_blocks(int n) {
   g_persistent_blocks = n < 0 ? 0 : n;
   return GROVE_OK;
 }
+extern "C" int grove_gemm_persistent_blocks(void) { return g_persistent_blocks; }
 #ifdef GROVE_EXPERIMENT_W4
 extern "C" int grove_gemm_set_waves(int waves) {  // 8 (default) or 4: the four-wave form of the 256-row instances (A/B knob)
   g_gemm_waves = waves == 4 ? 4 : 8;

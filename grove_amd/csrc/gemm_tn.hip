@@ -480,7 +480,9 @@ int launch_tn_pp(const grove_gemm_tn_params& p, hipStream_t s) {
     attr_set = true;
   }
   const int tiles = tiles_m * tiles_n;
-  const int G = tiles < num_cus ? tiles : num_cus;
+  const int cap = grove_gemm_persistent_blocks();  // the resident-block cap of the persistent kernels (N > 1: CUs left to RCCL)
+  const int cus = cap > 0 && cap < num_cus ? cap : num_cus;
+  const int G = tiles < cus ? tiles : cus;
   // The partial last round (675 tiles on 256 CUs: 2 rounds + 163 tiles) is cut into 2-4 K ranges when that shortens it:
   // ceil(tail * parts / G) rounds of 1 / parts each, e.g. 163 x 3 = 489 units = 2 rounds of a third (0.67 instead of 1).
   // Measured (tools/bench_gemm_tn.py, (1280, 34560, 32768)): gathered taps 2.90-2.98 -> 2.85 ms; the plain form does not move

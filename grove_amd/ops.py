@@ -92,12 +92,27 @@ def gemm_workspace(plan, image_fn, device):
     return w
 
 
+# Set by train.GradExchange while gradient buckets are in flight on RCCL (N > 1): called before every persistent-GEMM launch so the
+# exchange can lift its CU reservation as soon as the host sees the collectives complete (None otherwise: no per-launch cost).
+_pre_gemm_hook = None
+
+
+def gemm_set_persistent_blocks(n: int):
+    """Resident blocks of the persistent GEMMs (0 = one per CU); returns the previous setting."""
+    lib = _lib.lib()
+    prev = int(lib.grove_gemm_persistent_blocks())
+    _lib.check(lib.grove_gemm_set_persistent_blocks(int(n)), "grove_gemm_set_persistent_blocks")
+    return prev
+
+
 def gemm_raw(A, B, Cout, M, N, K, lda, ldb, ldc, *, bias=None, residual=None, ldr=0, aux=None, scale_ptr=None,
              scale_tanh=False, a_idx=None, a_taps=1, c_idx=None, r_idx=None, batch=(1, 1), sA=(0, 0), sB=(0, 0),
              sC=(0, 0), sR=(0, 0), act=ACT_NONE, accumulate=False, alpha=1.0, split_k=0, ld_aux=0, n_map=(0, 0), k_map=(0, 0),
              aux_grad=False, residual_mul=False):
     """Direct call of grove_gemm_bf16; A/B/Cout are tensors whose storage the pointers refer to."""
     _chk_dev(A, B, Cout)
+    if _pre_gemm_hook is not None:
+        _pre_gemm_hook()
     p = _lib.GemmParams()
     p.A, p.B, p.C = _p(A), _p(B), _p(Cout)
     p.bias, p.residual, p.aux = _p(bias), _p(residual), _p(aux)
@@ -152,6 +167,8 @@ def linear(x, w, bias=None, *, act=ACT_NONE, residual=None, out=None, out_dtype=
 def wgrad(dy, x, grad, *, b_idx=None, b_taps=1, scale_ptr=None, scale_tanh=False, alpha=1.0, split_k=0, K=None):
     """grad[M, N] (fp32) += alpha * dy[K, M]^T @ x[K, N]  (x rows optionally gathered per tap)."""
     _chk_dev(dy, x, grad)
+    if _pre_gemm_hook is not None:
+        _pre_gemm_hook()
     p = _lib.GemmTnParams()
     p.A, p.B, p.C, p.scale_ptr, p.b_idx = _p(dy), _p(x), _p(grad), _p(scale_ptr), _p(b_idx)
     p.M, p.N = grad.shape[0], grad.shape[1]

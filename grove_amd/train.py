@@ -447,8 +447,20 @@ class GradExchange:
     (<= 512 rows x 8 KB per rank instead of 262 MB; SURVEY.md section 8(a) a7 "sparse rows"). The optimizer stays dense.
     On CPU tensors (gloo: the tests) the same code runs inline without streams."""
 
+    # CUs left to RCCL while gradient buckets are in flight (the rule behind `grove_gemm_set_persistent_blocks`; DESIGN.md section 6):
+    # a persistent GEMM block owns a whole CU (128 KB of LDS, 8 waves x 256 VGPRs), so a channel block of an RCCL kernel can only
+    # start on a CU that a GEMM block has left, and the NEXT persistent launch then finds that CU taken: the block dealt to it waits
+    # for another block's whole share — every GEMM launch overlapping the collective takes up to two rounds instead of one. With the
+    # grid capped at CUs - RESERVED_CUS both fit (the GEMMs lose RESERVED_CUS / CUs = 6 % for the few ms a bucket is in flight). 16 =
+    # the channel cap init_distributed() gives RCCL (NCCL_MAX_NCHANNELS, one block per channel): 16 CUs stream ~0.4 TB/s of HBM
+    # (23 GB/s per CU, measured on the decode kernels), above what seven xGMI links take (7 x 50 GB/s per direction).
+    RESERVED_CUS = 16
+
     def __init__(self, flat, world, bucket_elems, comm_dtype=torch.bfloat16, mode="allreduce", comm_stream=None):
         assert mode in ("allreduce", "rs_ag", "a2a_f32")
+        if mode == "a2a_f32" and comm_dtype != torch.bfloat16 and flat.is_cuda:
+            # (ADVICE r3: grove_colsum_f32 reads bf16 rows; an fp32 wire summed by a plain all-reduce IS fp32 accumulation already)
+            raise ValueError("exchange mode a2a_f32 = fp32 accumulation of a BF16 wire; with comm_dtype float32 use 'allreduce' or 'rs_ag'")
         self.flat, self.world, self.mode = flat, world, mode
         self.wire = torch.empty(flat.numel(), dtype=comm_dtype, device=flat.device) if comm_dtype != torch.float32 else None
         # buckets are multiples of the world size so that reduce-scatter shards are equal
@@ -459,6 +471,49 @@ class GradExchange:
         self.handles = []
         self._keep = []       # staging tensors of collectives in flight (freed at finish)
         self._kmax = None
+        self._inflight = []   # what the CU reservation waits for: Work handles / events of the buckets handed to RCCL
+        self._user_blocks = None
+        self.reserve_cus = self.RESERVED_CUS if (flat.is_cuda and os.environ.get("GROVE_RCCL_RESERVED_CUS") is None) else \
+            int(os.environ.get("GROVE_RCCL_RESERVED_CUS", "0"))
+        self.reserved_launch_polls = 0  # (diagnostic: how many GEMM launches ran under the cap in the last step)
+
+    # ---- CU reservation for the collectives in flight
+    def _reserve(self):
+        if not self.flat.is_cuda or self.reserve_cus <= 0 or self._user_blocks is not None:
+            return
+        cus = torch.cuda.get_device_properties(self.flat.device).multi_processor_count
+        self._user_blocks = ops.gemm_set_persistent_blocks(max(cus - self.reserve_cus, 8))
+        ops._pre_gemm_hook = self._poll
+
+    def _release(self):
+        if self._user_blocks is not None:
+            ops.gemm_set_persistent_blocks(self._user_blocks)
+            self._user_blocks = None
+        if ops._pre_gemm_hook == self._poll:
+            ops._pre_gemm_hook = None
+        self._inflight = []
+
+    def _poll(self):
+        """Before a persistent-GEMM launch while reserved: lift the cap once the host sees every handed-over collective complete."""
+        self.reserved_launch_polls += 1
+        for w in self._inflight:
+            done = w.is_completed() if hasattr(w, "is_completed") else w.query()
+            if not done:
+                return
+        self._release()
+
+    def _mark_inflight(self, n_handles_before):
+        """Called after collectives were queued on the communication stream: reserve CUs until they have completed."""
+        if not self.flat.is_cuda or self.reserve_cus <= 0:
+            return
+        new = self.handles[n_handles_before:]
+        if new:
+            self._inflight.extend(new)
+        else:  # collectives issued without a handle (stream-ordered on the communication stream): an event behind them
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+            self._inflight.append(ev)
+        self._reserve()
 
     def _sum_copies(self, recv, out):
         """out (wire dtype) [k] = round(sum over the `world` rows of recv [world, k]) with the sum in fp32."""
@@ -475,8 +530,10 @@ class GradExchange:
         n = buf.numel()
         for s0 in range(0, n, self.bucket):
             b = buf[s0:s0 + self.bucket]
-            if self.mode in ("rs_ag", "a2a_f32") and b.numel() % self.world == 0:
-                k = b.numel() // self.world
+            k = b.numel() // self.world
+            # shards: equal, and (a2a_f32: grove_colsum_f32 works on bf16 PAIRS) even — a ragged tail bucket takes the plain all-reduce;
+            # the test depends on sizes only, so every rank takes the same branch
+            if self.mode in ("rs_ag", "a2a_f32") and b.numel() % self.world == 0 and (self.mode == "rs_ag" or k % 2 == 0):
                 r = dist.get_rank()
                 shard = b[r * k:(r + 1) * k]  # in place: RCCL reduces into / gathers from the rank's own slice of the bucket
                 if self.mode == "a2a_f32":
@@ -516,6 +573,7 @@ class GradExchange:
         if ev is None:
             ev = torch.cuda.Event()
             ev.record(producer_stream if producer_stream is not None else torch.cuda.current_stream(self.flat.device))
+        n0 = len(self.handles)
         with torch.cuda.stream(self.stream):
             self.stream.wait_event(ev)
             buf = src
@@ -523,6 +581,7 @@ class GradExchange:
                 buf = self.wire[lo:hi]
                 ops.to_bf16(src, out=buf)
             self._exchange(buf)
+            self._mark_inflight(n0)
         self.pending.append((lo, hi))
 
     # ---- sparse rows (embed_tokens)
@@ -557,7 +616,10 @@ class GradExchange:
         """ids int32 [K] (distinct row numbers of this rank, -1 = padding), rows [K, ld] fp32 (this rank's gradient rows in the
         order of ids; padding rows ignored), K = the same on every rank (sparse_kmax()). The dense slice flat[lo:hi] viewed as
         [*, ld] must be ZERO on entry; on return (stream-ordered) it holds the sum over all ranks. All-gather of ids and of the rows
-        in the wire dtype; the sum itself is fp32 (scatter-add of every rank's block)."""
+        in the wire dtype; the sum itself is fp32, added RANK BY RANK in rank order (one scatter-add per rank's block: ids are distinct
+        inside a block, so nothing collides inside a launch, and the launches are stream-ordered) — a row touched by three or more
+        ranks is summed in the same order on every replica, so the replicas' embed_tokens gradients stay bit-identical (one
+        atomic scatter-add over all blocks summed such rows in a rank-dependent order)."""
         K = ids.numel()
         dense = self.flat[lo:hi].view(-1, ld)
         wdt = self.wire.dtype if self.wire is not None else torch.float32
@@ -567,8 +629,10 @@ class GradExchange:
             all_rows = torch.empty((self.world * K, ld), dtype=wdt)
             dist.all_gather_into_tensor(all_ids, ids)
             dist.all_gather_into_tensor(all_rows.view(-1), wr.reshape(-1))
-            keep = all_ids >= 0
-            dense.index_add_(0, all_ids[keep].long(), all_rows[keep].float())
+            for r in range(self.world):
+                blk_ids, blk = all_ids[r * K:(r + 1) * K], all_rows[r * K:(r + 1) * K]
+                keep = blk_ids >= 0
+                dense.index_add_(0, blk_ids[keep].long(), blk[keep].float())
         else:
             ev = event
             if ev is None:
@@ -581,12 +645,15 @@ class GradExchange:
                 all_rows = torch.empty((self.world * K, ld), dtype=wdt, device=ids.device)
                 dist.all_gather_into_tensor(all_ids, ids)
                 dist.all_gather_into_tensor(all_rows.view(-1), wr.view(-1))
-                if wdt == torch.float32:
-                    ops.scatter_add_rows_f32(all_rows, dense, all_ids)
-                else:
-                    ops.scatter_add_f32(all_rows, dense, all_ids, self.world * K, ld)
+                for r in range(self.world):
+                    blk_ids, blk = all_ids[r * K:(r + 1) * K], all_rows[r * K:(r + 1) * K]
+                    if wdt == torch.float32:
+                        ops.scatter_add_rows_f32(blk, dense, blk_ids)
+                    else:
+                        ops.scatter_add_f32(blk, dense, blk_ids, K, ld)
                 for t in (ids, rows, wr, all_ids, all_rows):
                     t.record_stream(self.stream)
+                self._mark_inflight(len(self.handles))
         self.pending.append((lo, hi))
         self.sparse_done.append((lo, hi))
         self._kmax = None
@@ -608,6 +675,7 @@ class GradExchange:
         self.handles = []
         if self.flat.is_cuda:
             torch.cuda.current_stream(self.flat.device).wait_stream(self.stream)
+            self._release()  # the compute stream now waits for the collectives: whatever is queued next runs after them
         self._keep = []
         if self.wire is not None:
             dense = [r for r in self.pending if r not in self.sparse_done]
@@ -633,7 +701,9 @@ class GroveEngine:
     """Replica-per-GPU data-parallel engine with the DeepSpeed-engine surface train.py relies on."""
 
     def __init__(self, model: GROVEForCausalLM, args, total_steps=None, bucket_bytes=128 << 20, comm_dtype=torch.bfloat16,
-                 exchange="allreduce", overlap=True, sparse_embed=True):
+                 exchange="allreduce", overlap=True, sparse_embed=True, force_exchange=False):
+        """force_exchange: build and run the gradient exchange on a ONE-rank group too (every collective of the N > 1 step is then
+        issued against the real backend with identity results: tests/test_train_gpu.py drives RCCL this way on a one-GPU box)."""
         self.module = model
         self.args = args
         self.dev = model.dev
@@ -668,9 +738,10 @@ class GroveEngine:
         self._norm = torch.zeros(1, dtype=torch.float32, device=g.device)
         # gradient exchange: bf16 on the wire like DeepSpeed under bf16 (engine.communication_data_type) or torch.float32; bucketed,
         # launched from inside the backward as each parameter group's gradients complete (GradExchange)
-        self.comm_stream = torch.cuda.Stream(device=self.dev) if self.world > 1 else None
+        comm = self.world > 1 or (force_exchange and dist.is_initialized())
+        self.comm_stream = torch.cuda.Stream(device=self.dev) if comm else None
         self.exchange = None
-        if self.world > 1:
+        if comm:
             self.exchange = GradExchange(g, self.world, bucket_bytes // (2 if comm_dtype == torch.bfloat16 else 4), comm_dtype, exchange,
                                          self.comm_stream)
         self.overlap = overlap
@@ -687,7 +758,7 @@ class GroveEngine:
         """Replicas start from rank 0's values (DeepSpeed broadcasts the module's parameters at initialize() and after a
         checkpoint load): the fp32 master copy and the bf16 trainable tensors; frozen tensors come from the same checkpoint /
         initialiser on every rank and are not sent."""
-        if self.world <= 1:
+        if self.exchange is None:
             return
         dist.broadcast(self.master, src=0)
         for _, _, _, w in self.slices:
@@ -746,7 +817,7 @@ class GroveEngine:
         if self.micro < a.grad_accumulation_steps:
             return
         self.micro = 0
-        if self.world > 1:
+        if self.exchange is not None:
             self._allreduce()
         g = self.module._flat_grad
         scale = 1.0 / (self.world * a.grad_accumulation_steps)
@@ -1055,14 +1126,17 @@ def resume_training_from_checkpoint(engine, args, log=print):
         log(f"Resume training from {path}, start from epoch {args.start_epoch}")
 
 
-def init_distributed(local_rank, timeout_s=1800):
+def init_distributed(local_rank, timeout_s=1800, backend=None):
     """deepspeed.init_distributed() (train.py:932): one process per GPU, RCCL ("nccl" IS RCCL on ROCm) bound to this rank's device,
-    with a finite timeout so that a wedged first collective ends the job with a message instead of hanging it."""
+    with a FINITE timeout so that a wedged collective ends the job with RCCL's own report of the stuck operation instead of hanging
+    it (the reference's inference scripts pass 2-4 h, infer_iground.py:495). RCCL gets at most 16 channels (NCCL_MAX_NCHANNELS,
+    overridable): its kernels then occupy at most the 16 CUs GradExchange leaves free while a bucket is in flight."""
     import datetime
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        backend = os.environ.get("GROVE_BACKEND", "nccl")  # gloo only for one-GPU rehearsals
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", str(GradExchange.RESERVED_CUS))
+        backend = backend or os.environ.get("GROVE_BACKEND", "nccl")  # gloo only for one-GPU rehearsals
         kw = {"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}
         dist.init_process_group(backend, timeout=datetime.timedelta(seconds=timeout_s), **kw)
     return world

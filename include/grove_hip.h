@@ -165,6 +165,11 @@ int grove_gemm_set_stream_k(int mode);
  * RCCL collective at N > 1, which would otherwise make the blocks dealt to its CUs wait for another block's whole share (TEST / A-B
  * knob like the other setters: plan, image and launch under one setting; `bench.py --gemm_blocks n`). */
 int grove_gemm_set_persistent_blocks(int n);
+/* The current setting (0 = one per CU); the persistent weight-gradient kernel (grove_gemm_tn_bf16) follows the same cap. Round 4:
+ * GroveEngine's gradient exchange lowers the cap to (CUs - 16) from the first bucket it hands to RCCL until the optimizer step has
+ * waited for the collectives (train.GradExchange: the RULE, not an A/B value), because a persistent block needs a whole CU
+ * (128 KB LDS, 8 x 256 VGPRs) and RCCL's channel blocks can only start on a CU a GEMM block has left. */
+int grove_gemm_persistent_blocks(void);
 /* Host-only view of the persistent kernels' work list (needs no device): what each of the `grid` = min(tiles, num_cus) (num_cus with a
  * stream-K tail) blocks does for tiles_m x tiles_n output tiles of bm x 256 (bm = 192 / 256) with nk K tiles of 64.
  * list: int32 [rows][grid][4] — row 0 = {K tiles of the block's stream, its segments, 0, 0}, row 1 + i = segment {m0, n0, k0 | k1 << 16,

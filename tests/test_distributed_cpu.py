@@ -102,6 +102,59 @@ def test_two_rank_gradient_exchange_and_sharding():
         assert meters == [3.0, 2.0, 2.0, 2.0]
 
 
+def _worker3(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from grove_amd.train import GradExchange
+    # rows touched by all three ranks with values whose fp32 sum depends on the order: (1e8 + 1) - 1e8 = 0 in fp32, 1 + (1e8 - 1e8) = 1
+    H, V = 4, 10
+    vals = {0: 1.0e8, 1: 1.0, 2: -1.0e8}
+    res = {}
+    for wire in (torch.float32, torch.bfloat16):
+        flat = torch.zeros(V * H + 8)
+        flat[V * H:] = float(rank)
+        ex = GradExchange(flat, world, 64, comm_dtype=wire, mode="allreduce")
+        my_ids = torch.tensor([[5, 2], [2, 5, 9], [5]][rank], dtype=torch.int32)
+        ex.sparse_begin(my_ids.numel())
+        K = ex.sparse_kmax()
+        rows = torch.zeros(K, H)
+        rows[:my_ids.numel()] = vals[rank]
+        ids = torch.full((K,), -1, dtype=torch.int32)
+        ids[:my_ids.numel()] = my_ids
+        ex.sparse_rows(ids, rows, 0, V * H, H)
+        ex.finish()
+        res[str(wire)] = flat.clone()
+    # a2a_f32 at world 3 with an odd shard (bucket 99 / 3 = 33: all-reduce fallback) and an even one
+    base = torch.randn(198 + 99, generator=torch.Generator().manual_seed(3))
+    flat = base * (rank + 1)
+    ex = GradExchange(flat, world, 198, comm_dtype=torch.bfloat16, mode="a2a_f32")
+    ex.finish()
+    res["a2a"] = flat.clone()
+    res["a2a_want"] = sum((base * (r + 1)).to(torch.bfloat16).float() for r in range(world))
+    out[rank] = res
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_three_rank_sparse_rows_sum_in_rank_order_on_every_replica():
+    """a token id touched by three or more ranks must be summed in the SAME order on every rank, or the replicas'
+    embed_tokens gradients differ bitwise and the master weights drift apart. Rank order: (1e8 + 1) + (-1e8) = 0 in fp32 for row 5
+    on every rank (any other order gives 1)."""
+    world, port = 3, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker3, args=(world, port, out), nprocs=world, join=True)
+    for key in ("torch.float32", "torch.bfloat16"):
+        for r in (1, 2):
+            assert torch.equal(out[0][key], out[r][key]), (key, r)
+    t = out[0]["torch.float32"][:40].view(10, 4)
+    assert t[5].tolist() == [0.0] * 4          # ((1e8) + 1) - 1e8 in rank order; 1.0 in any other
+    assert t[2].tolist() == [1.0e8] * 4 and t[9].tolist() == [1.0] * 4 and float(out[0]["torch.float32"][40]) == 3.0
+    for r in range(3):
+        assert (out[r]["a2a"] - out[r]["a2a_want"]).abs().max().item() <= out[r]["a2a_want"].abs().max().item() * 2 ** -7
+        assert torch.equal(out[r]["a2a"], out[0]["a2a"])
+
+
 def test_warmup_decay_lr():
     from grove_amd.train import WarmupDecayLR
     s = WarmupDecayLR(3e-4, 1000, 100)

@@ -87,15 +87,13 @@ def test_optimizer_step_matches_restated_adamw(dev):
     assert torch.equal(w.reshape(-1), engine.master[off:off + k].to(bf))
 
 
-def test_rccl_bucketed_allreduce_single_rank(dev):
-    """The GPU form of the gradient exchange (RCCL on a side stream, bucketed, compute stream waits) on a one-rank group:
-    the collective is the identity, but every call of the N > 1 path — init with device_id, async all_reduce under the comm
-    stream, event / stream waits — runs against the real RCCL."""
+@pytest.fixture(scope="module")
+def rccl_world1(dev):
+    """A ONE-rank process group on the real RCCL backend ("nccl" on ROCm), bound to the device like the N > 1 job's."""
     import os
     import socket
 
     import torch.distributed as dist
-    from grove_amd.train import allreduce_buckets
     if dist.is_initialized():
         pytest.skip("a process group already exists in this process")
     with socket.socket() as s:
@@ -103,25 +101,105 @@ def test_rccl_bucketed_allreduce_single_rank(dev):
         port = s.getsockname()[1]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-    try:
-        g = torch.arange(1 << 20, dtype=torch.float32, device=dev)
-        ref = g.clone()
-        g.mul_(2.0)  # work queued on the compute stream that the comm stream must wait for
-        allreduce_buckets(g, 300_000, torch.cuda.Stream(device=dev))
-        g.add_(1.0)  # ... and compute that must wait for the collective
-        torch.cuda.synchronize()
-        assert torch.equal(g, ref * 2 + 1)
-        # the bf16 wire format (the engine's default for N > 1): rounded into the comm buffer, reduced there by RCCL, widened back
-        h = torch.randn(1 << 20, device=dev)
-        want = h.to(bf).float()
-        allreduce_buckets(h, 300_000, torch.cuda.Stream(device=dev), torch.empty(1 << 20, dtype=bf, device=dev))
-        torch.cuda.synchronize()
-        assert torch.equal(h, want)
-        t = torch.tensor([1.0, 2.0], device=dev)
-        dist.all_reduce(t)
-        assert t.tolist() == [1.0, 2.0]
-    finally:
-        dist.destroy_process_group()
+    yield dist
+    dist.destroy_process_group()
+
+
+def test_rccl_bucketed_allreduce_single_rank(dev, rccl_world1):
+    """The GPU form of the gradient exchange (RCCL on a side stream, bucketed, compute stream waits) on a one-rank group:
+    the collective is the identity, but every call of the N > 1 path — init with device_id, async all_reduce under the comm
+    stream, event / stream waits — runs against the real RCCL."""
+    dist = rccl_world1
+    from grove_amd.train import allreduce_buckets
+    g = torch.arange(1 << 20, dtype=torch.float32, device=dev)
+    ref = g.clone()
+    g.mul_(2.0)  # work queued on the compute stream that the comm stream must wait for
+    allreduce_buckets(g, 300_000, torch.cuda.Stream(device=dev))
+    g.add_(1.0)  # ... and compute that must wait for the collective
+    torch.cuda.synchronize()
+    assert torch.equal(g, ref * 2 + 1)
+    # the bf16 wire format (the engine's default for N > 1): rounded into the comm buffer, reduced there by RCCL, widened back
+    h = torch.randn(1 << 20, device=dev)
+    want = h.to(bf).float()
+    allreduce_buckets(h, 300_000, torch.cuda.Stream(device=dev), torch.empty(1 << 20, dtype=bf, device=dev))
+    torch.cuda.synchronize()
+    assert torch.equal(h, want)
+    t = torch.tensor([1.0, 2.0], device=dev)
+    dist.all_reduce(t)
+    assert t.tolist() == [1.0, 2.0]
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+@pytest.mark.parametrize("sparse", [True, False])
+@pytest.mark.parametrize("mode,wire", [("allreduce", bf), ("allreduce", torch.float32), ("rs_ag", bf), ("rs_ag", torch.float32), ("a2a_f32", bf)])
+def test_engine_step_through_real_rccl_world1(dev, rccl_world1, mode, wire, sparse, overlap):
+    """the ENGINE's N > 1 step on backend nccl (= RCCL) with one rank — every collective the multi-GPU step
+    issues goes through real RCCL once: broadcast_parameters (master + every trainable tensor), the one-word MAX all-reduce of the
+    touched-row count, the two all_gather_into_tensor of (ids, rows), per-bucket all_reduce / reduce_scatter + all_gather /
+    all_to_all_single + all_gather, from inside the backward (overlap) or after it. With one rank every collective is the identity,
+    so the flat gradient after the exchange must equal, BIT FOR BIT, the gradient the backward left (fp32 wire) or its bf16 rounding
+    (bf16 wire), and embed_tokens' dense slice must equal the scatter of the touched rows — which also proves that no group was
+    handed to the exchange before its gradient was final. Small buckets so that every group spans several of them."""
+    from grove_amd import train as T
+    from grove_amd.synthetic import TINY, synthetic_state_dict
+    args = T.shipped_args()
+    args.lr = 1e-3
+    model = T.initialize_model(args, dims=TINY, state_dict=synthetic_state_dict(TINY), device=dev)
+    engine = T.GroveEngine(model, args, total_steps=1000, bucket_bytes=96 << 10, comm_dtype=wire, exchange=mode, overlap=overlap,
+                           sparse_embed=sparse, force_exchange=True)
+    assert engine.exchange is not None and engine.comm_stream is not None
+    sent = []
+    orig_sparse = engine.exchange.sparse_rows
+
+    def spy(ids, rows, lo, hi, ld, **k):
+        sent.append((ids.clone(), rows.clone(), lo, hi, ld))
+        return orig_sparse(ids, rows, lo, hi, ld, **k)
+    engine.exchange.sparse_rows = spy
+    batch = _batch(TINY, dev, 21)
+    out = engine(**batch)
+    engine.backward(out["loss"])
+    torch.cuda.synchronize()
+    g_raw = model._flat_grad.clone()           # ready() only reads the flat buffer: still what the backward left
+    engine._allreduce()                        # what step() does first: finish(), wait, widen
+    torch.cuda.synchronize()
+    got = model._flat_grad
+    want = g_raw if wire == torch.float32 else g_raw.to(bf).float()
+    if sparse:
+        assert len(sent) == 1, "embed_tokens' gradient did not travel as touched rows"
+        ids, rows, lo, hi, ld = sent[0]
+        dense = torch.zeros((hi - lo) // ld, ld, device=dev)
+        keep = ids >= 0
+        dense.index_add_(0, ids[keep].long(), rows[keep] if wire == torch.float32 else rows[keep].to(bf).float())
+        want = want.clone()
+        want[lo:hi] = dense.view(-1)
+        assert bool((rows[keep] != 0).any())
+    else:
+        assert not sent
+    assert torch.equal(got, want), (mode, wire, sparse, overlap, float((got - want).abs().max()))
+    assert sorted(engine.exchanged_ranges)[0][0] == 0 and max(hi for _, hi in engine.exchanged_ranges) == got.numel()
+    assert engine.exposed_comm_ms() is not None
+    if overlap:
+        assert len(engine.exchanged_ranges) >= 4   # groups were handed over from inside the backward, not in one piece at the end
+    # the CU reservation of the in-flight buckets is lifted again, and the update runs
+    from grove_amd import _lib, ops
+    assert _lib.lib().grove_gemm_persistent_blocks() == 0 and ops._pre_gemm_hook is None
+    engine.exchange.sparse_rows = orig_sparse
+    # ... and the whole step() runs, twice (second step: zero_grad, a new sparse_begin, the CU reservation taken and lifted again)
+    engine.scheduler.warm = 0
+    w0 = engine.master.clone()
+    engine.step()
+    out = engine(**batch)
+    engine.backward(out["loss"])
+    engine.step()
+    torch.cuda.synchronize()
+    assert engine.global_step == 2 and not torch.equal(engine.master, w0) and bool(torch.isfinite(engine.master).all())
+    assert _lib.lib().grove_gemm_persistent_blocks() == 0
+
+
+def test_a2a_f32_refuses_an_fp32_wire_on_the_gpu(dev):
+    from grove_amd.train import GradExchange
+    with pytest.raises(ValueError, match="a2a_f32"):
+        GradExchange(torch.zeros(64, device=dev), 2, 32, comm_dtype=torch.float32, mode="a2a_f32")
 
 
 def test_consolidated_checkpoint_export_import(dev, tmp_path):
