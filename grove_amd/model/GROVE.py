@@ -84,6 +84,24 @@ class KVCache:
             self.layers[i] = g
 
 
+class LMOutput(SimpleNamespace):
+    """Result of lm_forward (the fields of HF's CausalLMOutputWithPast that generation reads). `hidden_states_f32` — this build's extra:
+    the final-norm hidden states in fp32 from the fp32 residual stream of an inference model, what evaluate()'s box path reads — is
+    produced ON FIRST ACCESS (one more norm launch and an fp32 [B*S, H] tensor): the teacher-forced forward and the use_cache=False
+    loop never read it."""
+
+    def __init__(self, f32fn=None, f32shape=None, **kw):
+        super().__init__(**kw)
+        self._f32fn, self._f32shape, self._f32 = f32fn, f32shape, None
+
+    @property
+    def hidden_states_f32(self):
+        if self._f32 is None and self._f32fn is not None:
+            self._f32 = self._f32fn().view(self._f32shape)
+            self._f32fn = None  # (releases the residual stream the closure holds)
+        return self._f32
+
+
 class GROVEForCausalLM(torch.nn.Module):
     def __init__(self, config=None, dims: GroveDims = None, device="cuda", state_dict=None, train=False, **kwargs):
         super().__init__()
@@ -814,9 +832,8 @@ class GROVEForCausalLM(torch.nn.Module):
         else:
             logits = ops.linear(h0, lm_head).view(B, S, -1)
         # (extra to HF: the same hidden states in fp32, normalised from the fp32 residual stream of an inference model — evaluate()'s box path)
-        f32fn = getattr(self.llama, "_final_norm_f32", None)
-        return SimpleNamespace(loss=None, logits=logits, past_key_values=cache, hidden_states=h0.view(B, S, H),
-                               hidden_states_f32=f32fn().view(B, S, H) if f32fn is not None else None, attentions=None)
+        return LMOutput(f32fn=getattr(self.llama, "_final_norm_f32", None), f32shape=(B, S, H), loss=None, logits=logits,
+                        past_key_values=cache, hidden_states=h0.view(B, S, H), attentions=None)
 
     @torch.no_grad()
     def generate(self, images=None, input_ids=None, bboxes=None, image_features=None, image_forward_outs=None, images_dtype=None,
@@ -866,7 +883,6 @@ class GROVEForCausalLM(torch.nn.Module):
                 out = self.lm_forward(input_ids=ids, image_features=image_features, token_embeddings=token_embeddings,
                                       use_cache=False, last_logits_only=True)
                 hidden = out.hidden_states
-                hidden32 = out.hidden_states_f32
                 S = hidden.shape[1]
                 S0 = S if S0 is None else S0
                 nxt = pick(out.logits)
@@ -874,6 +890,7 @@ class GROVEForCausalLM(torch.nn.Module):
                 finished = finished | (nxt == eos)
                 if bool(finished.all()):
                     break
+            hidden32 = out.hidden_states_f32 if output_hidden_states else None  # (lazy: only the LAST step's rows are ever read)
             if hidden32 is not None:
                 hiddens32 += [hidden32[:, :S0]] + [hidden32[:, j:j + 1] for j in range(S0, S)]
             return result(ids, [hidden[:, :S0]] + [hidden[:, j:j + 1] for j in range(S0, S)], None)

@@ -380,7 +380,10 @@ def mask_decoder_query(sd, d, image_embeddings, image_pe, text_embeds, reps):
     hs, _ = two_way_transformer(sd, d, src, pos, tokens)
     qo = hs[:, 5:, :]
     box = torch.sigmoid(_lin(sd, M + "bbox_prediction_head.2", F.relu(_lin(sd, M + "bbox_prediction_head.0", qo)))).squeeze(1)
-    obj = _lin(sd, M + "temporal_objectness_head", qo).squeeze(-1).squeeze(-1)
+    if M + "temporal_objectness_head.weight" in sd:
+        obj = _lin(sd, M + "temporal_objectness_head", qo).squeeze(-1).squeeze(-1)
+    else:  # use_temp_objectness=False: the decoder has no such head (mask_decoder.py:83-87, 200-205)
+        obj = torch.zeros(qo.shape[0])
     return box, obj
 
 
@@ -459,8 +462,10 @@ def box_cxcywh_to_xyxy(b):
     return torch.stack((cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2), -1)
 
 
-def decode_boxes(sd, d, pred_emb_list, image_embeddings, orig_sizes, pe, infer, thr=0.5):
-    """_generate_and_postprocess_masks :270-331."""
+def decode_boxes(sd, d, pred_emb_list, image_embeddings, orig_sizes, pe, infer, thr=0.5, use_temp_objectness=True):
+    """_generate_and_postprocess_masks :270-331. use_temp_objectness=False (GROVE.py:282-289, 313-317; mask_decoder.py:83-87, 200-205:
+    the decoder has no objectness head): every box of a frame is kept at inference; the logits this function still returns are the
+    head's output on whatever weights `sd` holds and are NOT part of the reference's result in that mode (callers drop them)."""
     reps = [e.shape[0] for e in pred_emb_list]
     text = torch.cat(pred_emb_list, 0).unsqueeze(1)
     if text.shape[0] == 0:
@@ -478,7 +483,7 @@ def decode_boxes(sd, d, pred_emb_list, image_embeddings, orig_sizes, pe, infer, 
                 W, H = orig_sizes[i // T]
                 ub = torch.stack([b[:, 0] * W, b[:, 1] * H, b[:, 2] * W, b[:, 3] * H], -1)  # bbox_utils.py:25-44
                 ub = box_cxcywh_to_xyxy(ub)
-                bs.append(ub[torch.sigmoid(l_) > thr])
+                bs.append(ub[torch.sigmoid(l_) > thr] if use_temp_objectness else ub)
             else:
                 bs.append(b)
             ls.append(l_)
@@ -500,8 +505,9 @@ def giou_loss_sum(b1, b2, eps=1e-7):
     return (1 - (iou - (ac - union) / (ac + eps))).sum()
 
 
-def loss_components(ce_loss, boxes, logits, gt_boxes, gt_vis, w_ce=1.0, w_box=1.0, w_obj=1.0):
-    """_compute_loss_components_video :339-381 (everything in fp32)."""
+def loss_components(ce_loss, boxes, logits, gt_boxes, gt_vis, w_ce=1.0, w_box=1.0, w_obj=1.0, use_temp_objectness=True):
+    """_compute_loss_components_video :339-408 (everything in fp32). use_temp_objectness=False = the second branch (:383-408): GIoU + L1
+    on the rows the GROUND-TRUTH objectness marks visible, no BCE term, four keys."""
     giou = torch.zeros(())
     l1 = torch.zeros(())
     bce = torch.zeros(())
@@ -514,38 +520,46 @@ def loss_components(ce_loss, boxes, logits, gt_boxes, gt_vis, w_ce=1.0, w_box=1.
                 sel = pb[gv.bool()]
                 giou = giou + giou_loss_sum(box_cxcywh_to_xyxy(sel), box_cxcywh_to_xyxy(gb))
                 l1 = l1 + (sel - gb).abs().sum()
-            bce = bce + F.binary_cross_entropy_with_logits(pl, gv, reduction="sum")
+            if use_temp_objectness:
+                bce = bce + F.binary_cross_entropy_with_logits(pl, gv, reduction="sum")
             n_gt += gb.shape[0]
             n_pred += pb.shape[0]
     ce = ce_loss * w_ce
     giou = w_box * giou / (n_gt + 1e-8)
     l1 = w_box * l1 / (n_gt + 1e-8)
     bce = w_obj * bce / (n_pred + 1e-8)
+    if not use_temp_objectness:
+        return {"loss": ce + giou + l1, "ce_loss": ce, "giou_loss": giou, "l1_loss": l1}
     return {"loss": ce + giou + l1 + bce, "ce_loss": ce, "giou_loss": giou, "l1_loss": l1, "temp_objectness_loss": bce}
 
 
 def model_forward(sd, d, global_enc_images, grounding_enc_images, input_ids, labels, attention_masks, bboxes_list=None,
-                  temp_objectness_labels_list=None, original_size_list=None, inference=False, pe_dtype=torch.float32, **_):
+                  temp_objectness_labels_list=None, original_size_list=None, inference=False, pe_dtype=torch.float32,
+                  use_temp_objectness=True, token_embeddings=None, loss_weights=(1.0, 1.0, 1.0), **_):
     """GROVEForCausalLM.model_forward GROVE.py:156-198 (training: losses; inference: boxes + logits).
-    pe_dtype: dtype the dense positional encoding is evaluated in (bf16 reproduces the reference under model.to(bf16), Q10)."""
+    pe_dtype: dtype the dense positional encoding is evaluated in (bf16 reproduces the reference under model.to(bf16), Q10).
+    use_temp_objectness=False: GROVE.py:183-195 — inference returns every box and `logits_temp_objectness` None; training returns four
+    loss keys. token_embeddings: the dumped embedding table of embed_tokens.py (llava_with_region_arch.py:134-137). loss_weights =
+    (ce, giou [also weighs L1, GROVE.py:375], temp_objectness)."""
     image_embeddings = sam_image_encoder(sd, d, grounding_enc_images)
     mask = det_token_mask(d, input_ids)
     feats, _ = encode_images(sd, d, global_enc_images)
     if inference:
-        embeds, _, _ = splice(sd, input_ids, None, None, feats)
+        embeds, _, _ = splice(sd, input_ids, None, None, feats, token_embeddings=token_embeddings)
         hidden = llama_forward(sd, d, embeds, None)
         ce = None
     else:
-        embeds, new_labels, new_mask = splice(sd, input_ids, labels, attention_masks, feats)
+        embeds, new_labels, new_mask = splice(sd, input_ids, labels, attention_masks, feats, token_embeddings=token_embeddings)
         hidden = llama_forward(sd, d, embeds, new_mask)
         ce, _ = lm_loss(sd, hidden, new_labels)
     emb = pred_embeddings(sd, d, hidden, mask)
     pe = dense_pe(sd, d, dtype=pe_dtype).float()
-    boxes, logits, flat_box, flat_obj = decode_boxes(sd, d, emb, image_embeddings, original_size_list, pe, inference)
+    boxes, logits, flat_box, flat_obj = decode_boxes(sd, d, emb, image_embeddings, original_size_list, pe, inference,
+                                                     use_temp_objectness=use_temp_objectness)
     if inference:
-        return {"pred_bboxes": boxes, "logits_temp_objectness": logits, "flat_boxes": flat_box, "flat_logits": flat_obj,
-                "hidden": hidden, "image_embeddings": image_embeddings}
-    out = loss_components(ce, boxes, logits, bboxes_list, temp_objectness_labels_list)
+        return {"pred_bboxes": boxes, "logits_temp_objectness": logits if use_temp_objectness else None, "flat_boxes": flat_box,
+                "flat_logits": flat_obj, "hidden": hidden, "image_embeddings": image_embeddings}
+    out = loss_components(ce, boxes, logits, bboxes_list, temp_objectness_labels_list, *loss_weights, use_temp_objectness=use_temp_objectness)
     out.update({"flat_boxes": flat_box, "flat_logits": flat_obj, "hidden": hidden})
     return out
 

@@ -46,7 +46,7 @@ def _install():
     torch.Tensor.cuda = lambda self, *a, **k: self  # model/GROVE.py:203,260 hard-code .cuda()
 
 
-def build_reference_model(d: GroveDims, dtype=torch.float32):
+def build_reference_model(d: GroveDims, dtype=torch.float32, use_temp_objectness=True, loss_weights=(1.0, 1.0, 1.0)):
     """Builds model/GROVE.py::GROVEForCausalLM at dims `d`, SAM at 512 px (train.py:561-576
     semantics), and loads the deterministic synthetic state dict. Returns (model, state_dict)."""
     _install()
@@ -83,9 +83,10 @@ def build_reference_model(d: GroveDims, dtype=torch.float32):
     cfg.num_level_reg_features = 4
     cfg.pretrain_mm_mlp_adapter = None
     cfg.mm_use_im_start_end = True
-    model = G.GROVEForCausalLM(cfg, det_token_idx=d.det_token_idx, ce_loss_weight=1.0, giou_loss_weight=1.0,
-                               temp_objectness_loss_weight=1.0, out_dim=d.out_dim, num_frames=d.num_frames,
-                               use_temp_objectness=True, train_mask_decoder=True, with_region=True)
+    cfg.use_temp_objectness = use_temp_objectness  # (GROVEBaseModel reads it before _set_model_configurations' value is used, GROVE.py:53)
+    model = G.GROVEForCausalLM(cfg, det_token_idx=d.det_token_idx, ce_loss_weight=loss_weights[0], giou_loss_weight=loss_weights[1],
+                               temp_objectness_loss_weight=loss_weights[2], out_dim=d.out_dim, num_frames=d.num_frames,
+                               use_temp_objectness=use_temp_objectness, train_mask_decoder=True, with_region=True)
     model.get_model().initialize_vision_modules(model.get_model().config)
     # SAM at 512 px: absolute and global-block relative position tables at their post-interpolation size
     enc = model.get_model().grounding_encoder.image_encoder
@@ -97,6 +98,8 @@ def build_reference_model(d: GroveDims, dtype=torch.float32):
         enc.blocks[i].attn.rel_pos_w = torch.nn.Parameter(torch.zeros(2 * g - 1, hd))
     enc.img_size = d.sam_image
     sd = synthetic_state_dict(d)
+    if not use_temp_objectness:  # the reference's decoder then has no objectness head (mask_decoder.py:83-87)
+        sd = {k: v for k, v in sd.items() if "temporal_objectness_head" not in k}
     own = dict(model.state_dict())
     missing_in_model = [k for k in sd if k not in own]
     assert not missing_in_model, f"names not in the reference state dict: {missing_in_model[:5]}"

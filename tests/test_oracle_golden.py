@@ -144,3 +144,30 @@ def test_mask_branch(sd):
     near(iou3, g["iou_pred_multi"], what="iou multimask")
     near(full[:, :, ::2 * ps, ::2 * ps], g["masks_sub"], what="post-processed masks")
     near((full > 0).float().sum((1, 2, 3)), g["mask_area"], 1e-3, "mask areas")
+
+
+def test_use_temp_objectness_false(sd):
+    """`use_temp_objectness=False` (GROVE.py:183-195, 282-289, 313-317, 383-408; mask_decoder.py:83-87, 200-205) — the configuration
+    of the ANet / VidSTG fine-tunes and of four of the five inference drivers — against the reference built WITHOUT the objectness
+    head, with the shipped loss weights (1, 2, 2): four loss keys, gradients, and every box kept at inference with logits None."""
+    g = np.load(os.path.join(G, "tiny_no_objectness_seed7.npz"))
+    w = tuple(float(x) for x in g["loss_weights"])
+    names = [k[5:] for k in g.files if k.startswith("grad/")]
+    sd2 = {k: v for k, v in sd.items() if "temporal_objectness_head" not in k}
+    sdg = {k: v.clone().requires_grad_(k in names) for k, v in sd2.items()}
+    batch = synthetic_batch(TINY, B=2, T=8, L=48, n_det=2, seed=7, ragged=True)
+    out = O.model_forward(sdg, TINY, **batch.as_kwargs(inference=False), use_temp_objectness=False, loss_weights=w)
+    assert "temp_objectness_loss" not in out
+    for k in ("loss", "ce_loss", "giou_loss", "l1_loss"):
+        near(out[k], g["train/" + k], what=k)
+    out["loss"].backward()
+    for n in names:
+        ref = torch.from_numpy(g["grad/" + n])
+        near(sdg[n].grad / ref.abs().max(), ref / ref.abs().max(), 1e-4, "grad " + n)
+    ib = synthetic_batch(TINY, B=2, T=8, L=40, n_det=3, seed=8)
+    with torch.no_grad():
+        oi = O.model_forward(sd2, TINY, **ib.as_kwargs(inference=True), use_temp_objectness=False)
+    assert oi["logits_temp_objectness"] is None
+    counts = np.array([[x.shape[0] for x in l_] for l_ in oi["pred_bboxes"]])
+    assert (counts == g["infer/pred_bboxes_counts"]).all() and (counts == 3).all()  # nothing is thresholded away
+    near(flat(oi["pred_bboxes"]) / 640, g["infer/pred_bboxes"] / 640, what="all boxes kept")
