@@ -1316,6 +1316,7 @@ static int g_num_cus = 0;
 static int g_persistent_blocks = 0;   // 0 = one resident block per CU; else the grid of the persistent kernels (grove_gemm_set_persistent_blocks)
 static int g_gemm_last_epilogue = 0;  // ACT template argument of the last pipelined launch (see grove_gemm_last_epilogue)
 static int g_gemm_stream_k = 1;       // plan_stream_k mode (grove_gemm_set_stream_k)
+static int g_gemm_tap_skip = 1;       // temporal tap skipping of the Conv3d implicit GEMMs (grove_gemm_set_tap_skip; A/B knob)
 static int g_gemm_last_stream_k = 0;  // S of the last pipelined launch
 #ifdef GROVE_EXPERIMENT_W4
 static int g_gemm_waves = 8;          // 8 = the eight-wave pipelined kernel, 4 = gemm_nt_w4_kernel where it applies (grove_gemm_set_waves)
@@ -1360,53 +1361,136 @@ inline sk_plan plan_stream_k(long tiles, int nk, int G, int mode) {  // mode: 0 
 // (the stream-K partial tiles) with every launch.
 struct pp_table_key {
   int dev, bm, tiles_m, tiles_n, nk, G, S;
+  int ft = 0, T = 0, parts = 0;  // temporal tap skipping (see tap_skip): tile rows per frame, frames per group; parts of a split tail
 };
 struct pp_table_dev { const i32x4_t* table; const i32x4_t* fixups; int n_fixups, n_slots; };
 
 inline uint64_t plan_key(const pp_table_key& k) {  // the image depends on exactly these (not on the epilogue or the operand type)
   uint64_t h = 1469598103934665603ull;
-  const int v[6] = {k.bm, k.tiles_m, k.tiles_n, k.nk, k.G, k.S};
-  for (int i = 0; i < 6; ++i) h = (h ^ (uint64_t)(uint32_t)v[i]) * 1099511628211ull;
+  const int v[9] = {k.bm, k.tiles_m, k.tiles_n, k.nk, k.G, k.S, k.ft, k.T, k.parts};
+  for (int i = 0; i < 9; ++i) h = (h ^ (uint64_t)(uint32_t)v[i]) * 1099511628211ull;
   return h;
+}
+
+// Temporal tap skipping (grove_gemm_params.a_frame_rows / a_frames; the Conv3d 3 x 3 x 3 adapters as implicit GEMMs): the output rows
+// are frames of `ft` tiles, T frames per group, and the K range is three equal tap groups (temporal offset -1, 0, +1). For the rows of a
+// group's FIRST frame every row index of the first tap group is -1 (the temporal zero padding), for its LAST frame the last group's: a
+// third of those tiles' K range multiplies zeros. A tile's K range [ka, kb) leaves those K tiles out — the accumulators then miss
+// additions of +0.0 only, so whole tiles are bit-identical to the un-skipped GEMM.
+inline void tile_k_range(const pp_table_key& key, int m0, int& ka, int& kb) {
+  ka = 0, kb = key.nk;
+  if (!key.ft) return;
+  const int t = (m0 / key.bm / key.ft) % key.T;
+  if (t == 0) ka = key.nk / 3;
+  if (t == key.T - 1) kb = key.nk - key.nk / 3;
+}
+
+// tile L -> origin: bands of 8 tile rows, column-major inside a band (the last band may be shorter)
+inline void tile_origin(const pp_table_key& key, int L, int& m0, int& n0) {
+  const int per_band = 8 * key.tiles_n, band = L / per_band, in_band = L - band * per_band;
+  const int rows = std::min(8, key.tiles_m - band * 8);
+  m0 = (band * 8 + in_band % rows) * key.bm;
+  n0 = (in_band / rows) * P_BN;
+}
+
+// processing order of the tiles. Plain shapes: L itself. Tap-skipping shapes: the FULL tiles first, then the short ones, each class in
+// band order — a round of the persistent grid lasts as long as its longest tile, so short tiles only pay when they share rounds (and
+// the stream-K tail) with each other.
+inline void tile_order(const pp_table_key& key, std::vector<int>& order) {
+  const int tiles = key.tiles_m * key.tiles_n;
+  order.resize(tiles);
+  if (!key.ft) {
+    for (int L = 0; L < tiles; ++L) order[L] = L;
+    return;
+  }
+  int n = 0;
+  for (int pass = 0; pass < 2; ++pass)
+    for (int L = 0; L < tiles; ++L) {
+      int m0, n0, ka, kb;
+      tile_origin(key, L, m0, n0);
+      tile_k_range(key, m0, ka, kb);
+      if ((kb - ka == key.nk) == (pass == 0)) order[n++] = L;
+    }
+}
+
+// Plan of a tap-skipping shape: rounds of whole tiles in tile_order, then the partial round either whole or cut into `parts` K ranges
+// per tile (each tile's OWN range [ka, kb) in `parts` equal pieces). Same cost terms as plan_stream_k, with every round priced at its
+// longest tile.
+inline sk_plan plan_tap_skip(const pp_table_key& key0, int G, int mode, int* parts_out) {
+  pp_table_key key = key0;
+  const int tiles = key.tiles_m * key.tiles_n, nk = key.nk;
+  std::vector<int> order;
+  tile_order(key, order);
+  auto len = [&](int i) {
+    int m0, n0, ka, kb;
+    tile_origin(key, order[i], m0, n0);
+    tile_k_range(key, m0, ka, kb);
+    return kb - ka;
+  };
+  sk_plan pl;
+  pl.rounds = tiles / G, pl.tail = tiles % G, pl.S = 0, pl.parts = 1;
+  double whole = 0;
+  for (int r = 0; r < pl.rounds; ++r) {
+    int mx = 0;
+    for (int i = r * G; i < (r + 1) * G; ++i) mx = std::max(mx, len(i));
+    whole += mx;
+  }
+  int tail_max = 0, tail_min = nk;
+  for (int i = pl.rounds * G; i < tiles; ++i) tail_max = std::max(tail_max, len(i)), tail_min = std::min(tail_min, len(i));
+  pl.kt_units = whole + tail_max;
+  *parts_out = 1;
+  if (!mode || pl.tail == 0 || pl.rounds == 0) return pl;
+  const int s = std::min(G / pl.tail, 4);
+  if (s < 2 || tail_min < 2 * s) return pl;
+  for (int i = pl.rounds * G; i < tiles; ++i)  // every piece of every tail tile must hold at least one K tile
+    if ((s - 1) * ((len(i) + s - 1) / s) >= len(i)) return pl;
+  const int S = (tail_max + s - 1) / s;
+  const double pf = (double)(pl.tail * s) / G;
+  const double fixed = 5.0 + (SK_FIXED - 5.0) * pf * pf;
+  const double t = whole + S + fixed;
+  if (mode == 2 || t < 0.97 * pl.kt_units) pl.S = S, pl.parts = s, pl.kt_units = t, *parts_out = s;
+  return pl;
 }
 
 // the lists of a shape on the host: `t` = the work list (rows of G entries, see pp_work), `fix` = the split tiles {m0, n0, first slot, parts}
 inline void build_work_list(const pp_table_key& key, const sk_plan& pl, std::vector<i32x4_t>& t, std::vector<i32x4_t>& fix) {
-  const int G = key.G, nk = key.nk, bm = key.bm, S = key.S;
+  const int G = key.G, nk = key.nk, S = key.S;
   const int tiles = key.tiles_m * key.tiles_n;
-  // tile L -> origin: bands of 8 tile rows, column-major inside a band (the last band may be shorter)
-  auto origin = [&](int L, int& m0, int& n0) {
-    const int per_band = 8 * key.tiles_n, band = L / per_band, in_band = L - band * per_band;
-    const int rows = std::min(8, key.tiles_m - band * 8);
-    m0 = (band * 8 + in_band % rows) * bm;
-    n0 = (in_band / rows) * P_BN;
-  };
+  std::vector<int> order;
+  tile_order(key, order);
   const int n_dp_max = S ? pl.rounds : (tiles + G - 1) / G;
   const int rows = 1 + n_dp_max + 1;
   t.assign((size_t)rows * G, i32x4_t{0, 0, 0, 0});
   fix.clear();
   for (int w = 0; w < G; ++w) {
     int n = 0, NT = 0;
-    auto push = [&](int L, int k0, int k1, int part) {
-      int m0, n0;
-      origin(L, m0, n0);
+    auto push = [&](int L, int j, int part) {  // j < 0: the tile's whole K range; else piece j of pl.parts
+      int m0, n0, ka, kb;
+      tile_origin(key, L, m0, n0);
+      tile_k_range(key, m0, ka, kb);
+      int k0 = ka, k1 = kb;
+      if (j >= 0) {
+        const int Sa = key.ft ? (kb - ka + pl.parts - 1) / pl.parts : S;  // (plain shapes: pieces of S K tiles, the last one shorter)
+        k0 = ka + j * Sa, k1 = std::min(kb, ka + (j + 1) * Sa);
+      }
       t[(size_t)(1 + n) * G + w] = i32x4_t{m0, n0, k0 | (k1 << 16), part};
       ++n, NT += k1 - k0;
     };
     const int n_dp = S ? pl.rounds : (tiles - w + G - 1) / G;
-    for (int i = 0; i < n_dp; ++i) push(w + i * G, 0, nk, 0);
+    for (int i = 0; i < n_dp; ++i) push(order[w + i * G], -1, 0);
     if (S && w < pl.tail * pl.parts) {  // part-major: neighbouring blocks hold the same K range of neighbouring tiles
       const int j = w / pl.tail, a = w % pl.tail;
-      push(pl.rounds * G + a, j * S, std::min(nk, (j + 1) * S), 1 + a * pl.parts + j);  // slot: a tile's parts in K order
+      push(order[pl.rounds * G + a], j, 1 + a * pl.parts + j);  // slot: a tile's parts in K order
     }
     t[w] = i32x4_t{NT, n, 0, 0};
   }
   if (S)
     for (int a = 0; a < pl.tail; ++a) {
       int m0, n0;
-      origin(pl.rounds * G + a, m0, n0);
+      tile_origin(key, order[pl.rounds * G + a], m0, n0);
       fix.push_back(i32x4_t{m0, n0, a * pl.parts, pl.parts});
     }
+  (void)nk;
 }
 
 template <int BM, bool GATHER, int ACT, bool FP8 = false>
@@ -1416,9 +1500,16 @@ int launch_pp_act(const grove_gemm_params& p, hipStream_t s, const float* row_sc
   const int G = num_cus(), nk = p.K / P_BK;
   const long tiles = (long)tiles_m * tiles_n;
   GROVE_CHECK(tiles < (1L << 24) && nk < 65536, GROVE_E_SHAPE, "gemm: %d x %d tiles x %d K tiles overflow the pipelined kernel's work list", tiles_m, tiles_n, nk);
-  const sk_plan pl = plan_stream_k(tiles, nk, G, g_gemm_stream_k);
+  // temporal tap skipping (Conv3d adapters): whole tiles inside one frame, three equal tap groups on K-tile boundaries
+  pp_table_key skey{0, BM, tiles_m, tiles_n, nk, G, 0};
+  if (GATHER && g_gemm_tap_skip && p.a_frame_rows > 0 && p.a_frames >= 1 && p.a_frame_rows % BM == 0 && p.a_taps % 3 == 0 && nk % 3 == 0 &&
+      (nk / 3) % (p.a_taps / 3) == 0 && p.M % ((long)p.a_frame_rows * p.a_frames) == 0 && !p.k_group)
+    skey.ft = p.a_frame_rows / BM, skey.T = p.a_frames;
+  int sparts = 0;
+  const sk_plan pl = skey.ft ? plan_tap_skip(skey, G, g_gemm_stream_k, &sparts) : plan_stream_k(tiles, nk, G, g_gemm_stream_k);
   const int grid = pl.S ? G : (int)(tiles < G ? tiles : G);  // (the list is laid out for this grid: its row stride and wgid map)
-  const pp_table_key key{0, BM, tiles_m, tiles_n, nk, grid, pl.S};
+  pp_table_key key{0, BM, tiles_m, tiles_n, nk, grid, pl.S};
+  key.ft = skey.ft, key.T = skey.T, key.parts = skey.ft ? sparts : 0;
   const int n_dp_max = pl.S ? pl.rounds : (int)((tiles + G - 1) / G);
   const size_t list_bytes = (size_t)(1 + n_dp_max + 1) * grid * sizeof(i32x4_t);
   const int n_fix = pl.S ? pl.tail : 0, n_slots = pl.S ? pl.tail * pl.parts : 0;
@@ -1598,6 +1689,10 @@ extern "C" int grove_gemm_set_persistent_blocks(int n) {
   return GROVE_OK;
 }
 extern "C" int grove_gemm_persistent_blocks(void) { return g_persistent_blocks; }
+extern "C" int grove_gemm_set_tap_skip(int on) {
+  g_gemm_tap_skip = on ? 1 : 0;
+  return GROVE_OK;
+}
 #ifdef GROVE_EXPERIMENT_W4
 extern "C" int grove_gemm_set_waves(int waves) {  // 8 (default) or 4: the four-wave form of the 256-row instances (A/B knob)
   g_gemm_waves = waves == 4 ? 4 : 8;

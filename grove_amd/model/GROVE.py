@@ -169,7 +169,7 @@ class GROVEForCausalLM(torch.nn.Module):
             names = [n for n in self.trainable if n.startswith(pre)]
             if names:
                 lo = min(self._grad_off[n] for n in names)
-                hi = max(self._grad_off[n] + (self._sd[n].numel() + 3) // 4 * 4 for n in names)
+                hi = max(self._grad_off[n] + self._grad_slot[n] for n in names)
                 self._grad_ready_cb(lo, hi, stream, event)
 
     @classmethod
@@ -200,6 +200,15 @@ class GROVEForCausalLM(torch.nn.Module):
                 if src is not None:
                     packed.copy_(src.to(self.dev).permute(0, 2, 3, 4, 1))
                 self._sd[name] = packed.permute(0, 4, 1, 2, 3)
+            elif name == "lm_head.weight" and shape[0] % 8:
+                # the real vocabulary (32000 + the added special tokens, train.py:132-152, 330) is not a multiple of 8, which the
+                # weight-gradient GEMM's output rows must be: the storage (and, below, the gradient slot) carries zero rows up to the
+                # next multiple; the parameter everyone sees is the [:V] view of it
+                full = torch.zeros((ops.pad_to(shape[0], 8), shape[1]), dtype=bf, device=self.dev)
+                if src is not None:
+                    full[:shape[0]].copy_(src.to(self.dev))
+                self._lm_head_full = full
+                self._sd[name] = full[:shape[0]]
             else:
                 t = torch.zeros(shape, dtype=bf, device=self.dev)
                 if src is not None:
@@ -209,17 +218,22 @@ class GROVEForCausalLM(torch.nn.Module):
             names = trainable_names(d, self.config.train_mask_decoder)
             # every parameter starts on a 16-byte boundary of the flat fp32 buffer (vector / atomic epilogues)
             offs, off = {}, 0
+            slot = lambda n: (ops.pad_to(self._sd[n].shape[0], 8) * self._sd[n].shape[1] if n == "lm_head.weight" else self._sd[n].numel())
             for n in names:
                 offs[n] = off
-                off += (self._sd[n].numel() + 3) // 4 * 4
+                off += (slot(n) + 3) // 4 * 4
             self._flat_grad = torch.zeros(off, dtype=torch.float32, device=self.dev)
             self._grad_off = offs
+            self._grad_slot = {n: (slot(n) + 3) // 4 * 4 for n in names}  # elements of the flat buffer a parameter owns (padding included)
             for n in names:
                 k = self._sd[n].numel()
                 shape = tuple(self._sd[n].shape)
                 if n.endswith("conv3d.weight"):
                     shape = (shape[0], 27 * shape[1])  # gradient lives in the packed (tap-major) layout
                 self._grad[n] = self._flat_grad[offs[n]:offs[n] + k].view(shape)
+            if "lm_head.weight" in offs:  # the weight-gradient GEMM's target: all pad_to(V, 8) rows (the pad rows only ever receive zeros)
+                n = "lm_head.weight"
+                self._lm_head_grad_full = self._flat_grad[offs[n]:offs[n] + slot(n)].view(-1, self._sd[n].shape[1])
             self.trainable = names
 
     def state_dict(self, *a, **k):
@@ -682,7 +696,7 @@ class GROVEForCausalLM(torch.nn.Module):
         hv, dlogits, rows, R = c.ce_state
         if R > 0:
             Vv = d.vocab
-            ops.wgrad(dlogits, hv.data, self._grad["lm_head.weight"], K=R)
+            ops.wgrad(dlogits, hv.data, self._lm_head_grad_full, K=R)  # dlogits' pad columns are zero
             # dgrad: d h[R, H] = dlogits[R, V] . W[V, H]. W is K-major for this product, so it runs as the TN form on the weight
             # as stored — (d h)^T[H, R] = W^T . dlogits^T, K = V split over the chip by the kernel's own split-K — instead of an NT
             # GEMM on a transposed copy of the 262 MB matrix (the copy alone cost more than this whole sequence).

@@ -106,6 +106,9 @@ class SamEncoder:
             w2 = sd[S + "neck.2.weight"]  # [Co, Ci, 3, 3]
             self.neck_w2_d = w2.flip(2, 3).permute(1, 2, 3, 0).reshape(O, 9 * O).contiguous()
         self._idx = {}
+        # the Conv3d adapters' row-gather table (conv3d_gather_index(F // 8, 8, g, g)) has no temporal neighbour before a group's first
+        # and after its last frame: the promise that lets the GEMM planner skip those tap groups (grove_gemm_params.a_frame_rows)
+        self.conv_frames = (d.sam_grid * d.sam_grid, 8)
 
     @property
     def _zero_row(self):
@@ -241,13 +244,13 @@ class SamEncoder:
             x = res
             pre = torch.empty_like(x) if save else None
             y = ops.linear(x, A["w"], A["b"], act=ops.ACT_RELU, scale_ptr=A["alpha_f32"], scale_tanh=True, a_idx=conv_idx, a_taps=27,
-                           M=x.shape[0], residual=x, aux=pre)
+                           M=x.shape[0], residual=x, aux=pre, a_frames=self.conv_frames)
             return y, (x, pre)
         x = torch.empty((res.shape[0], res.shape[1]), dtype=torch.bfloat16, device=self.dev)
         ops.stream_add(res, t, res_bf16=x)
         pre = torch.empty_like(x) if save else None
         y = ops.linear(x, A["w"], A["b"], act=ops.ACT_RELU, scale_ptr=A["alpha_f32"], scale_tanh=True, a_idx=conv_idx, a_taps=27,
-                       M=x.shape[0], aux=pre)
+                       M=x.shape[0], aux=pre, a_frames=self.conv_frames)
         return y, (x, pre)
 
     def forward(self, images, save=False, upto=None, before_adapters=None):
@@ -405,5 +408,6 @@ class SamEncoder:
                 if wd is None or wd.shape != (C, 27 * C):
                     wd = A["w_d"] = torch.empty((C, 27 * C), dtype=torch.bfloat16, device=A["w"].device)
                 ops.transpose(A["w"], C, C, 27 * C, wd[:, 26 * C:], 27 * C, batch=(27, 1), s_in=(C, 0), s_out=(-C, 0))
-            dx = ops.linear(prod, A["w_d"], a_idx=conv_idx, a_taps=27, M=M, residual=dy, scale_ptr=a, scale_tanh=True)
+            dx = ops.linear(prod, A["w_d"], a_idx=conv_idx, a_taps=27, M=M, residual=dy, scale_ptr=a, scale_tanh=True,
+                            a_frames=self.conv_frames)  # (flipped taps: the first / last tap GROUP still pairs with the first / last frame)
         return dx

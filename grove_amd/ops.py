@@ -108,8 +108,9 @@ def gemm_set_persistent_blocks(n: int):
 def gemm_raw(A, B, Cout, M, N, K, lda, ldb, ldc, *, bias=None, residual=None, ldr=0, aux=None, scale_ptr=None,
              scale_tanh=False, a_idx=None, a_taps=1, c_idx=None, r_idx=None, batch=(1, 1), sA=(0, 0), sB=(0, 0),
              sC=(0, 0), sR=(0, 0), act=ACT_NONE, accumulate=False, alpha=1.0, split_k=0, ld_aux=0, n_map=(0, 0), k_map=(0, 0),
-             aux_grad=False, residual_mul=False):
-    """Direct call of grove_gemm_bf16; A/B/Cout are tensors whose storage the pointers refer to."""
+             aux_grad=False, residual_mul=False, a_frames=(0, 0)):
+    """Direct call of grove_gemm_bf16; A/B/Cout are tensors whose storage the pointers refer to.
+    a_frames = (rows per frame, frames per group): the temporal-padding promise about a_idx (grove_gemm_params.a_frame_rows)."""
     _chk_dev(A, B, Cout)
     if _pre_gemm_hook is not None:
         _pre_gemm_hook()
@@ -131,6 +132,7 @@ def gemm_raw(A, B, Cout, M, N, K, lda, ldb, ldc, *, bias=None, residual=None, ld
     p.residual_mul = int(residual_mul)
     p.n_group, p.n_pad = n_map
     p.k_group, p.k_pad = k_map
+    p.a_frame_rows, p.a_frames = a_frames
     lib = _lib.lib()
     st = _stream()
     plan = _lib.GemmPlan()
@@ -142,7 +144,7 @@ def gemm_raw(A, B, Cout, M, N, K, lda, ldb, ldc, *, bias=None, residual=None, ld
 
 def linear(x, w, bias=None, *, act=ACT_NONE, residual=None, out=None, out_dtype=bf16, aux=None, alpha=1.0,
            scale_ptr=None, scale_tanh=False, a_idx=None, a_taps=1, c_idx=None, r_idx=None, M=None, out_rows=None,
-           accumulate=False, ld_aux=0, n_map=(0, 0), k_map=(0, 0), out_cols=None, aux_grad=False, residual_mul=False):
+           accumulate=False, ld_aux=0, n_map=(0, 0), k_map=(0, 0), out_cols=None, aux_grad=False, residual_mul=False, a_frames=(0, 0)):
     """y = epilogue(x @ w.T): x [*, K] (row stride lda), w [N, K] (nn.Linear layout)."""
     K = w.shape[1]
     N = w.shape[0]
@@ -160,7 +162,7 @@ def linear(x, w, bias=None, *, act=ACT_NONE, residual=None, out=None, out_dtype=
     gemm_raw(x2, w, out, M, N, K, x2.stride(0), w.stride(0), out.stride(0), bias=bias, residual=residual, ldr=ldr,
              aux=aux, scale_ptr=scale_ptr, scale_tanh=scale_tanh, a_idx=a_idx, a_taps=a_taps, c_idx=c_idx, r_idx=r_idx,
              act=act, accumulate=accumulate, alpha=alpha, ld_aux=ld_aux, n_map=n_map, k_map=k_map,
-             aux_grad=aux_grad, residual_mul=residual_mul)
+             aux_grad=aux_grad, residual_mul=residual_mul, a_frames=a_frames)
     return out
 
 

@@ -107,6 +107,14 @@ typedef struct grove_gemm_params {
    *   aux_grad:     aux receives act'(v), the activation's derivative at the pre-activation, instead of v itself;
    *   residual_mul: the residual operand multiplies the result (v *= residual[row_r(m), n]) instead of being added. */
   int32_t aux_grad, residual_mul;
+  /* Temporal tap skipping (round 4; pipelined gathered-A kernel with 256-row tiles, a_taps % 3 == 0 — the Conv3d 3 x 3 x 3 adapters,
+   * image_encoder.py:43 / modeling_clip.py:594): a PROMISE about a_idx that lets the planner leave out K ranges that multiply zeros.
+   * The M output rows are frames of a_frame_rows rows (a multiple of 256), a_frames frames per group, and the taps are three equal
+   * groups in K order (temporal offset -1, 0, +1): a_idx[tap][m] == -1 for EVERY tap of the first group when m lies in the first
+   * frame of its group, and for every tap of the last group when m lies in the last frame (conv3d_gather_index builds exactly that:
+   * the temporal zero padding). Those tiles then run 2/3 of the K range; whole tiles stay bit-identical (the skipped products only
+   * ever added +0.0), a stream-K tail is cut at other K tiles (deterministic, different fp32 sum order). 0 / 0 = no promise. */
+  int32_t a_frame_rows, a_frames;
 } grove_gemm_params;
 
 /* Workspaces of the persistent GEMMs (`grove_<op>_workspace_bytes` + `workspace, ws_bytes` arguments).
@@ -170,6 +178,8 @@ int grove_gemm_set_persistent_blocks(int n);
  * waited for the collectives (train.GradExchange: the RULE, not an A/B value), because a persistent block needs a whole CU
  * (128 KB LDS, 8 x 256 VGPRs) and RCCL's channel blocks can only start on a CU a GEMM block has left. */
 int grove_gemm_persistent_blocks(void);
+/* A/B knob: 0 = ignore a_frame_rows / a_frames (every tile runs the whole K range), 1 (default) = skip. */
+int grove_gemm_set_tap_skip(int on);
 /* Host-only view of the persistent kernels' work list (needs no device): what each of the `grid` = min(tiles, num_cus) (num_cus with a
  * stream-K tail) blocks does for tiles_m x tiles_n output tiles of bm x 256 (bm = 192 / 256) with nk K tiles of 64.
  * list: int32 [rows][grid][4] — row 0 = {K tiles of the block's stream, its segments, 0, 0}, row 1 + i = segment {m0, n0, k0 | k1 << 16,

@@ -1410,3 +1410,51 @@ def test_greedy_pick_is_hf_greedy_bookkeeping(dev):
     assert tok.tolist() == [123, 2, 0] and finished.tolist() == [False, True, True] and pos.tolist() == [pos0 + 4] * 3
     assert ids_out[:, 3].tolist() == [123, 2, 0] and (ids_out[:, [0, 1, 2, 4]] == -7).all()
     assert torch.equal(hid_out[3], hidden) and torch.equal(hid32_out[3], hidden32) and hid_out[[0, 1, 2, 4]].abs().sum() == 0
+
+
+@pytest.mark.parametrize("Co,frames", [(640, 32), (256, 16), (1280, 16)])
+def test_conv3d_temporal_tap_skipping_is_bit_identical_on_whole_tiles(dev, Co, frames):
+    """Round 4: the Conv3d adapters' implicit GEMM with the temporal-padding promise (grove_gemm_params.a_frame_rows / a_frames):
+    first-frame tiles skip the first tap group's K range, last-frame tiles the last one's, and the short tiles are dealt to the
+    persistent blocks after the full ones. Skipped products only ever added +0.0, so every output tile that is not part of a stream-K
+    split is BIT-identical to the launch without the promise; split tiles (other K cut points, fp32 sum order) agree to one bf16 ulp.
+    Also against the fp32 gather reference."""
+    from grove_amd import _lib, ops
+    from grove_amd.model.indexing import conv3d_gather_index
+    L = _lib.lib()
+    T, H, W, Ci = 8, 32, 32, 128
+    G = frames // T
+    M = frames * H * W
+    x = rnd(M, Ci, seed=21).to(dev)
+    w = rnd(Co, 27 * Ci, seed=22, scale=0.03).to(dev)
+    bias = rnd(Co, seed=23).to(dev)
+    idx = conv3d_gather_index(G, T, H, W).to(dev)
+    kw = dict(act=ops.ACT_RELU, scale_ptr=torch.tensor([0.3]).to(dev), scale_tanh=True, a_idx=idx, a_taps=27, M=M)
+    try:
+        L.grove_gemm_set_tile_m(256)
+        L.grove_gemm_set_tap_skip(0)
+        ref = ops.linear(x, w, bias, a_frames=(H * W, T), **kw)
+        assert L.grove_gemm_last_variant() == 6
+        split_ref = L.grove_gemm_last_stream_k()
+        L.grove_gemm_set_tap_skip(1)
+        out = ops.linear(x, w, bias, a_frames=(H * W, T), **kw)
+        split = L.grove_gemm_last_stream_k()
+        plain = ops.linear(x, w, bias, **kw)       # no promise given: the un-skipped plan
+        assert torch.equal(plain, ref)
+    finally:
+        L.grove_gemm_set_tile_m(0)
+        L.grove_gemm_set_tap_skip(1)
+    same = (out == ref).all(dim=1)
+    if not (split or split_ref):
+        assert bool(same.all())
+    else:  # rows of split tiles may differ in the last bit; every other row is identical
+        frac = float(same.float().mean())
+        assert frac > 0.55, frac
+        assert (out.float() - ref.float()).abs().max().item() <= 2 ** -7 * ref.float().abs().max().item()
+    # fp32 gather reference on a sample of rows incl. first / last frames of a group
+    rows = torch.cat([torch.arange(0, 64), torch.arange(7 * H * W, 7 * H * W + 64), torch.arange(M - 64, M), torch.arange(3 * H * W + 500, 3 * H * W + 564)]).to(dev)
+    src = idx[:, rows].long()                                         # [27, n]
+    xg = torch.where((src >= 0)[..., None], x.float()[src.clamp_min(0)], torch.zeros(1, device=dev))   # [27, n, Ci]
+    pre = torch.einsum("tnc,otc->no", xg, w.float().view(Co, 27, Ci)) + bias.float()
+    want = torch.relu(pre) * math.tanh(0.3)
+    close(out[rows], want, 2 ** -7, "tap-skipping conv vs fp32 gather")
