@@ -198,6 +198,8 @@ def lib():
         for name in SYMBOLS:
             getattr(_lib, name).restype = C.c_int
         _lib.grove_gemm_workspace_bytes.restype = C.c_size_t
+        if os.environ.get("GROVE_GEMM_TAP_SKIP") is not None:  # A/B arm: 0 = the Conv3d GEMMs run every tap group on every tile
+            _lib.grove_gemm_set_tap_skip(int(os.environ["GROVE_GEMM_TAP_SKIP"]))
         if os.environ.get("GROVE_GEMM_BLOCKS") is not None:    # A/B runs at N > 1: resident blocks of the persistent GEMMs (grove_hip.h)
             _lib.grove_gemm_set_persistent_blocks(int(os.environ["GROVE_GEMM_BLOCKS"]))
         if os.environ.get("GROVE_GEMM_STREAM_K") is not None:  # A/B runs of whole programs: 0 = whole tiles only (grove_hip.h)
