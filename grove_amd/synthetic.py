@@ -287,14 +287,35 @@ def init_spec(name: str, shape, d: GroveDims):
     return (0.0, 0.02)
 
 
-def synthetic_state_dict(d: GroveDims, device="cpu", dtype=torch.float32, names=None):
+def outlier_channels(d: GroveDims):
+    """The hidden channels that carry the synthetic "massive activations" (three fixed ones, like LLaMA-2-7B's 1415 / 2533)."""
+    H = d.hidden
+    return (H // 8 + 3, H // 2 + 5, (3 * H) // 4 + 1)
+
+
+def synthetic_param(name: str, shape, d: GroveDims, device="cpu", outliers: float = 0.0):
+    """One synthetic parameter (fp32). outliers = F > 0: the rows / columns that WRITE three fixed hidden channels
+    of the LLaMA residual stream are scaled by F — embed_tokens' columns (every text token starts with them), o_proj of layer 0 and
+    down_proj of layers 0 and 1 (rows = output channels) — so that from the first layers on the stream carries activations F times
+    the typical magnitude in those channels at every position, as real LLaMA checkpoints do (N(0, 0.02) weights have none, so a
+    parity figure on them says nothing about outlier handling). Everything else is unchanged."""
+    mean, std = init_spec(name, shape, d)
+    t = det_tensor(name, shape, std=std, mean=mean, device=device, dtype=torch.float32)
+    if outliers and outliers > 0:
+        ch = list(outlier_channels(d))
+        if name == "model.embed_tokens.weight":
+            t[:, ch] *= outliers
+        elif name in ("model.layers.0.self_attn.o_proj.weight", "model.layers.0.mlp.down_proj.weight", "model.layers.1.mlp.down_proj.weight"):
+            t[ch, :] *= outliers
+    return t
+
+
+def synthetic_state_dict(d: GroveDims, device="cpu", dtype=torch.float32, names=None, outliers: float = 0.0):
     sd = {}
     for name, shape in param_shapes(d).items():
         if names is not None and name not in names:
             continue
-        mean, std = init_spec(name, shape, d)
-        t = det_tensor(name, shape, std=std, mean=mean, device=device, dtype=torch.float32)
-        sd[name] = t.to(dtype)
+        sd[name] = synthetic_param(name, shape, d, device, outliers).to(dtype)
     return sd
 
 

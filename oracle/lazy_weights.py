@@ -13,8 +13,9 @@ import torch
 class LazyRoundedWeights(dict):
     """{name: fp32 tensor of the bf16-rounded synthetic weight}, generated on access."""
 
-    def __init__(self, d, gen_device="cpu"):
+    def __init__(self, d, gen_device="cpu", outliers=0.0):
         super().__init__()
+        self.outliers = outliers
         from grove_amd.synthetic import param_shapes
         self.d, self.shapes = d, param_shapes(d)
         self._last = (None, None)
@@ -25,13 +26,11 @@ class LazyRoundedWeights(dict):
         return k in self.shapes
 
     def __getitem__(self, k):
-        from grove_amd.synthetic import det_tensor, init_spec
+        from grove_amd.synthetic import synthetic_param
         if self._last[0] == k:
             return self._last[1]
         t0 = time.perf_counter()
-        shape = self.shapes[k]
-        mean, std = init_spec(k, shape, self.d)
-        t = det_tensor(k, shape, std=std, mean=mean, device=self.gen_device).to(torch.bfloat16).float().cpu()
+        t = synthetic_param(k, self.shapes[k], self.d, self.gen_device, self.outliers).to(torch.bfloat16).float().cpu()
         self._last = (k, t)
         self.fetch_seconds += time.perf_counter() - t0
         return t

@@ -23,6 +23,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 from oracle.lazy_weights import LazyRoundedWeights  # noqa: E402  (moved: bench.py's measured CPU baseline uses it too)
 
 
+def tag(outliers):
+    return f"_outliers{int(outliers)}" if outliers else ""
+
+
 def rel(a, b):
     a, b = a.detach().float().cpu(), b.detach().float().cpu()
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-6)).item()
@@ -43,15 +47,14 @@ def deep_narrow_dims():
                                clip_mlp=1024, sam_dim=320, sam_heads=4)
 
 
-@pytest.mark.parametrize("which", ["deep_narrow", "full"])
-def test_full_depth_inference_vs_fp32_oracle(dev, which):
+def run_inference_parity(dev, which, outliers=0.0):
     from grove_amd import GROVEForCausalLM
     from grove_amd.model.decoder import BoxDecoder
     from grove_amd.synthetic import FULL, synthetic_batch, synthetic_state_dict
     from oracle import grove_oracle as O
     d = FULL if which == "full" else deep_narrow_dims()
     t0 = time.time()
-    sd_dev = synthetic_state_dict(d, device=dev, dtype=bf)
+    sd_dev = synthetic_state_dict(d, device=dev, dtype=bf, outliers=outliers)
     model = GROVEForCausalLM(dims=d, device=dev, state_dict=sd_dev, det_token_idx=d.det_token_idx, num_frames=8)  # pe_dtype: bf16 default
     del sd_dev
     torch.cuda.empty_cache()
@@ -69,7 +72,7 @@ def test_full_depth_inference_vs_fp32_oracle(dev, which):
     torch.cuda.synchronize()
     t_gpu = time.time() - t0
 
-    sd = LazyRoundedWeights(d, gen_device=dev)
+    sd = LazyRoundedWeights(d, gen_device=dev, outliers=outliers)
     torch.set_num_threads(min(os.cpu_count() or 1, 64))
     gi, si = kw["global_enc_images"].to(bf).float(), kw["grounding_enc_images"].to(bf).float()
     t0 = time.time()
@@ -102,9 +105,17 @@ def test_full_depth_inference_vs_fp32_oracle(dev, which):
         "targets": {"box_l1": 1e-3, "objectness": 5e-2, "hidden_rel": 3e-2},
     }
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", f"full_depth_parity_{which}.json"), "w") as fh:
+    res["outliers"] = outliers
+    res["llama_stream_abs_max_oracle"] = float(hidden_o.abs().max())
+    with open(os.path.join(ROOT, "gpurun_out", f"full_depth_parity_{which}{tag(outliers)}.json"), "w") as fh:
         json.dump(res, fh, indent=1)
     print(json.dumps(res))
+    return res
+
+
+@pytest.mark.parametrize("which", ["deep_narrow", "full"])
+def test_full_depth_inference_vs_fp32_oracle(dev, which):
+    res = run_inference_parity(dev, which)
     assert res["box_l1_vs_oracle_full"] <= 1e-3, res
     assert res["box_l1_bf16_pe_vs_oracle_bf16_pe"] <= 1e-3, res
     assert res["objectness_logit_abs_err"] <= 5e-2 and res["objectness_logit_abs_err_bf16_pe"] <= 5e-2, res
@@ -117,8 +128,7 @@ GROUPS = (("embed_tokens", "model.embed_tokens."), ("lm_head", "lm_head."), ("mm
           ("sam_adapter_2", "model.grounding_encoder.image_encoder.adapters.2."), ("sam_adapter_3", "model.grounding_encoder.image_encoder.adapters.3."))
 
 
-@pytest.mark.parametrize("which", ["deep_narrow"] + (["full"] if os.environ.get("GROVE_FULL_TRAIN_PARITY") else []))
-def test_full_depth_training_vs_oracle_autograd(dev, which):
+def run_training_parity(dev, which, outliers=0.0):
     """the configuration the headline bench times — a `train=True` model (bf16 residual streams, bf16 box
     decoder, tape + saved activations) — at FULL DEPTH: 32 LLaMA layers of dgrad, 24 SAM blocks of dgrad, 4 Conv3d adapters with
     weight gradients, against torch autograd through the fp32 CPU oracle on the same bf16-rounded weights: the five loss terms
@@ -131,7 +141,7 @@ def test_full_depth_training_vs_oracle_autograd(dev, which):
     from oracle import grove_oracle as O
     d = FULL if which == "full" else deep_narrow_dims()
     names = trainable_names(d)
-    sd_dev = synthetic_state_dict(d, device=dev, dtype=bf)
+    sd_dev = synthetic_state_dict(d, device=dev, dtype=bf, outliers=outliers)
     model = GROVEForCausalLM(dims=d, device=dev, state_dict=sd_dev, det_token_idx=d.det_token_idx, num_frames=8, pe_dtype=torch.float32, train=True)
     batch = synthetic_batch(d, B=1, T=8, L=128, n_det=3, seed=11)
     kw = batch.as_kwargs()
@@ -197,9 +207,17 @@ def test_full_depth_training_vs_oracle_autograd(dev, which):
                                         if v["cos"] is not None and ("mask_decoder" in n or "text_hidden_fcs" in n)][:16],
            "oracle_cpu_seconds": round(t_cpu, 1)}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", f"full_depth_training_parity_{which}.json"), "w") as fh:
+    res["outliers"] = outliers
+    with open(os.path.join(ROOT, "gpurun_out", f"full_depth_training_parity_{which}{tag(outliers)}.json"), "w") as fh:
         json.dump(res, fh, indent=1)
     print(json.dumps(res))
+    return res
+
+
+@pytest.mark.parametrize("which", ["deep_narrow"] + (["full"] if os.environ.get("GROVE_FULL_TRAIN_PARITY") else []))
+def test_full_depth_training_vs_oracle_autograd(dev, which):
+    res = run_training_parity(dev, which)
+    loss_rel, groups = res["loss_terms_rel_err"], res["gradient_groups"]
     assert max(loss_rel.values()) <= 1e-2, loss_rel
     bad = {g: v for g, v in groups.items() if not (v["cos"] > 0.98 and 0.9 < v["norm_ratio"] < 1.1)}
     assert not bad, bad
@@ -307,8 +325,7 @@ FP8_BOUNDS = {("deep_narrow", "all"): {"box_l1": 1.6e-2, "hidden_rms": 0.145}, (
               ("full", "det16_kv16"): {"box_l1": 1.95e-2, "hidden_rms": 0.17}}
 
 
-@pytest.mark.parametrize("which,policy", [("deep_narrow", "all"), ("deep_narrow", "det16_kv16"), ("full", "det16_kv16")])
-def test_full_depth_fp8_inference_vs_fp32_oracle(dev, which, policy):
+def run_fp8_parity(dev, which, policy, outliers=0.0):
     """BASELINE config 5's arithmetic at full depth: `gemm_dtype="fp8"` (every CLIP / LLaMA linear layer with K % 128 == 0 on the e4m3
     MFMA GEMM) against the fp32 oracle. e4m3 keeps 3 mantissa bits: ~3.6 % rms rounding per operand, ~5 % per GEMM output on any data
     whose blocks are not dominated by outliers — scaling granularity does not change that (tools/fp8_policy_study.py: per-32 block
@@ -318,7 +335,7 @@ def test_full_depth_fp8_inference_vs_fp32_oracle(dev, which, policy):
     from grove_amd.synthetic import FULL, synthetic_batch, synthetic_state_dict
     from oracle import grove_oracle as O
     d = FULL if which == "full" else deep_narrow_dims()
-    sd_dev = synthetic_state_dict(d, device=dev, dtype=bf)
+    sd_dev = synthetic_state_dict(d, device=dev, dtype=bf, outliers=outliers)
     model = GROVEForCausalLM(dims=d, device=dev, state_dict=sd_dev, det_token_idx=d.det_token_idx, num_frames=8, pe_dtype=torch.float32, gemm_dtype="fp8",
                              fp8_policy=policy)
     n_q = sum(1 for L in model.llama.layers for k in ("wqkv_q", "wo_q", "wgu_q", "wd_q") if k in L)
@@ -334,7 +351,7 @@ def test_full_depth_fp8_inference_vs_fp32_oracle(dev, which, policy):
     out = model(**kd)
     feats_h, _ = model(mode="encode_images", images=kd["global_enc_images"])
     torch.cuda.synchronize()
-    sd = LazyRoundedWeights(d, gen_device=dev)
+    sd = LazyRoundedWeights(d, gen_device=dev, outliers=outliers)
     torch.set_num_threads(min(os.cpu_count() or 1, 64))
     gi, si = kw["global_enc_images"].to(bf).float(), kw["grounding_enc_images"].to(bf).float()
     with torch.no_grad():
@@ -350,10 +367,17 @@ def test_full_depth_fp8_inference_vs_fp32_oracle(dev, which, policy):
            "box_l1_max": (out["flat_boxes"].cpu() - box_o).abs().max().item(),
            "objectness_logit_abs_err": (out["flat_logits"].cpu() - obj_o).abs().max().item(),
            "llama_hidden_rel_rms": rel_rms(out["hidden"], hidden_o), "projected_features_rel_rms": rel_rms(feats_h, feats_o),
-           "bounds": FP8_BOUNDS[(which, policy)]}
-    with open(os.path.join(ROOT, "gpurun_out", f"full_depth_fp8_parity_{which}_{policy}.json"), "w") as fh:
+           "bounds": FP8_BOUNDS[(which, policy)], "outliers": outliers, "n_q": n_q}
+    with open(os.path.join(ROOT, "gpurun_out", f"full_depth_fp8_parity_{which}_{policy}{tag(outliers)}.json"), "w") as fh:
         json.dump(res, fh, indent=1)
     print(json.dumps(res))
+    return res
+
+
+@pytest.mark.parametrize("which,policy", [("deep_narrow", "all"), ("deep_narrow", "det16_kv16"), ("full", "det16_kv16")])
+def test_full_depth_fp8_inference_vs_fp32_oracle(dev, which, policy):
+    res = run_fp8_parity(dev, which, policy)
+    n_q = res["n_q"]
     assert n_q > 0
     assert res["box_l1_vs_oracle"] <= FP8_BOUNDS[(which, policy)]["box_l1"] and res["llama_hidden_rel_rms"] <= FP8_BOUNDS[(which, policy)]["hidden_rms"], res
 
