@@ -62,7 +62,9 @@ def gemm_workspace(plan, image_fn, device):
     if plan.image_bytes == 0:
         return None
     dev = device.index if device.index is not None else torch.cuda.current_device()
-    key = (dev, int(plan.key))
+    # (the 64-bit FNV key alone could collide between two images of equal size; the geometry it hashes is part of the key)
+    key = (dev, int(plan.key), int(plan.bm), int(plan.tiles_m), int(plan.tiles_n), int(plan.k_tiles), int(plan.grid), int(plan.stream_k),
+           int(plan.image_bytes))
     img = _gemm_images.get(key)
     if img is None:
         if torch.cuda.is_current_stream_capturing():

