@@ -128,7 +128,7 @@ GROUPS = (("embed_tokens", "model.embed_tokens."), ("lm_head", "lm_head."), ("mm
           ("sam_adapter_2", "model.grounding_encoder.image_encoder.adapters.2."), ("sam_adapter_3", "model.grounding_encoder.image_encoder.adapters.3."))
 
 
-def run_training_parity(dev, which, outliers=0.0):
+def run_training_parity(dev, which, outliers=0.0, stream_dtype=None):
     """the configuration the headline bench times — a `train=True` model (bf16 residual streams, bf16 box
     decoder, tape + saved activations) — at FULL DEPTH: 32 LLaMA layers of dgrad, 24 SAM blocks of dgrad, 4 Conv3d adapters with
     weight gradients, against torch autograd through the fp32 CPU oracle on the same bf16-rounded weights: the five loss terms
@@ -142,7 +142,8 @@ def run_training_parity(dev, which, outliers=0.0):
     d = FULL if which == "full" else deep_narrow_dims()
     names = trainable_names(d)
     sd_dev = synthetic_state_dict(d, device=dev, dtype=bf, outliers=outliers)
-    model = GROVEForCausalLM(dims=d, device=dev, state_dict=sd_dev, det_token_idx=d.det_token_idx, num_frames=8, pe_dtype=torch.float32, train=True)
+    model = GROVEForCausalLM(dims=d, device=dev, state_dict=sd_dev, det_token_idx=d.det_token_idx, num_frames=8, pe_dtype=torch.float32, train=True,
+                             stream_dtype=stream_dtype)
     batch = synthetic_batch(d, B=1, T=8, L=128, n_det=3, seed=11)
     kw = batch.as_kwargs()
     kd = dict(kw)
@@ -208,7 +209,8 @@ def run_training_parity(dev, which, outliers=0.0):
            "oracle_cpu_seconds": round(t_cpu, 1)}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     res["outliers"] = outliers
-    with open(os.path.join(ROOT, "gpurun_out", f"full_depth_training_parity_{which}{tag(outliers)}.json"), "w") as fh:
+    res["stream_dtype"] = str(stream_dtype) if stream_dtype is not None else "default (bf16 for training models)"
+    with open(os.path.join(ROOT, "gpurun_out", f"full_depth_training_parity_{which}{tag(outliers)}{'_f32stream' if stream_dtype == torch.float32 else ''}.json"), "w") as fh:
         json.dump(res, fh, indent=1)
     print(json.dumps(res))
     return res
@@ -516,3 +518,25 @@ def test_generated_rows_hidden_precision_full_depth(dev):
     print(json.dumps(res))
     assert res["f32_decode_rows_hidden_rel_rms"] < 8e-3 and res["decode_rows_hidden_rel_rms"] < 8e-3, res   # measured 3.7e-3 / 4.1e-3
     assert res["box_l1_from_f32_decode_rows"] < 1e-3 and res["box_l1_from_f32_prefill_rows"] < 1e-3, res    # measured 3.2e-4 / 6.2e-4
+
+
+def test_outlier_stress_deep_narrow(dev):
+    """every precision figure so far came from N(0, 0.02)-like weights — no activation outliers. With
+    `outliers=1000` three hidden channels of the LLaMA residual stream carry values ~200x the typical magnitude at every position
+    (max ~2500; what LLaMA-7B's massive-activation channels do). Measured (profiles/r04_outlier_stress_deep_narrow.json,
+    r04_outlier_training_probe.json; baseline in brackets): inference box L1 7.5e-4 [4.7e-4], hidden 0.76 % rms [0.52 %]; training-mode
+    loss terms within 0.24 % [0.04 %], whole gradient cosine 0.993 [0.9985] with the bottom-of-stack groups' NORM off by up to 16 %
+    (embed_tokens 0.84, mm_projector 0.88 — and 1.09 / 1.16 with fp32 forward streams: bf16 rounding of a 1000:1 dynamic range along
+    32 layers of dgrad, not a sign of a wrong kernel: every group's cosine stays >= 0.989); fp8 det16_kv16 box L1 1.9e-2 [6.5e-3].
+    Asserts at ~1.5x the measured values."""
+    F = 1000.0
+    r = run_inference_parity(dev, "deep_narrow", outliers=F)
+    assert r["llama_stream_abs_max_oracle"] > 20.0        # the outliers really are in the stream (5.0 without)
+    assert r["box_l1_vs_oracle_full"] <= 1.1e-3 and r["llama_hidden_rel_rms"] <= 1.2e-2 and r["objectness_logit_abs_err"] <= 5e-2, r
+    t = run_training_parity(dev, "deep_narrow", outliers=F)
+    assert max(t["loss_terms_rel_err"].values()) <= 5e-3, t["loss_terms_rel_err"]
+    assert t["whole_gradient"]["cos"] >= 0.985, t["whole_gradient"]
+    bad = {g: v for g, v in t["gradient_groups"].items() if not (v["cos"] > 0.98 and 0.78 < v["norm_ratio"] < 1.2)}
+    assert not bad, bad
+    q = run_fp8_parity(dev, "deep_narrow", "det16_kv16", outliers=F)
+    assert q["box_l1_vs_oracle"] <= 2.9e-2 and q["llama_hidden_rel_rms"] <= 0.16, q
