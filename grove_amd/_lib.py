@@ -102,7 +102,8 @@ class BoxHeadBwdParams(C.Structure):
 class GemmTnParams(C.Structure):
     _fields_ = [("A", c_vp), ("B", c_vp), ("C", c_vp), ("scale_ptr", c_vp), ("b_idx", c_vp),
                 ("M", c_i32), ("N", c_i32), ("K", c_i32), ("lda", c_i32), ("ldb", c_i32), ("ldc", c_i32),
-                ("b_taps", c_i32), ("scale_tanh", c_i32), ("split_k", c_i32), ("alpha", c_f32)]
+                ("b_taps", c_i32), ("scale_tanh", c_i32), ("split_k", c_i32), ("alpha", c_f32),
+                ("b_frame_rows", c_i32), ("b_frames", c_i32)]
 
 
 class FlashAttnParams(C.Structure):
@@ -174,7 +175,7 @@ STRUCTS = {
 
 # every symbol include/grove_hip.h declares (tests/test_abi.py checks the header against this list)
 SYMBOLS = [
-    "grove_version", "grove_last_error", "grove_sizeof", "grove_gemm_bf16", "grove_gemm_make_plan", "grove_gemm_plan_image", "grove_gemm_workspace_bytes", "grove_gemm_fp8_make_plan", "grove_gemm_fp8_plan_image", "grove_gemm_last_variant", "grove_gemm_last_epilogue", "grove_gemm_set_staging", "grove_gemm_set_stream_k", "grove_gemm_set_persistent_blocks", "grove_gemm_persistent_blocks", "grove_gemm_set_tap_skip", "grove_gemm_work_list", "grove_gemm_last_stream_k", "grove_gemm_set_tile_n", "grove_gemm_set_tile_m", "grove_gemm_set_bk", "grove_gemm_tn_bf16", "grove_gemm_tn_set_pipelined", "grove_gemm_tn_set_split_tail", "grove_gemm_tn_last_parts", "grove_gemv_bf16", "grove_decode_attn", "grove_greedy_pick", "grove_resample_u8", "grove_normalize_pack",
+    "grove_version", "grove_last_error", "grove_sizeof", "grove_gemm_bf16", "grove_gemm_make_plan", "grove_gemm_plan_image", "grove_gemm_workspace_bytes", "grove_gemm_fp8_make_plan", "grove_gemm_fp8_plan_image", "grove_gemm_last_variant", "grove_gemm_last_epilogue", "grove_gemm_set_staging", "grove_gemm_set_stream_k", "grove_gemm_set_persistent_blocks", "grove_gemm_persistent_blocks", "grove_gemm_set_tap_skip", "grove_gemm_work_list", "grove_gemm_last_stream_k", "grove_gemm_set_tile_n", "grove_gemm_set_tile_m", "grove_gemm_set_bk", "grove_gemm_tn_bf16", "grove_gemm_tn_set_pipelined", "grove_gemm_tn_set_split_tail", "grove_gemm_tn_last_parts", "grove_gemm_tn_set_tap_skip", "grove_gemm_tn_last_skip", "grove_gemv_bf16", "grove_decode_attn", "grove_greedy_pick", "grove_resample_u8", "grove_normalize_pack",
     "grove_transpose_bf16", "grove_layernorm_fwd", "grove_rmsnorm_fwd", "grove_layernorm_bwd", "grove_rmsnorm_bwd",
     "grove_flash_attn_fwd", "grove_flash_attn_bwd", "grove_flash_attn_set_window_kernels", "grove_flash_attn_window_kernels_on", "grove_softmax_fwd", "grove_softmax_bwd", "grove_relpos_fwd", "grove_relpos_bwd", "grove_rel_bias_fwd", "grove_rel_bias_bwd", "grove_rope_inplace",
     "grove_swiglu_fwd", "grove_swiglu_bwd", "grove_act_bwd", "grove_act_fwd", "grove_resize_bilinear_f32", "grove_add_bf16", "grove_add_bcast_rows",
@@ -200,6 +201,7 @@ def lib():
         _lib.grove_gemm_workspace_bytes.restype = C.c_size_t
         if os.environ.get("GROVE_GEMM_TAP_SKIP") is not None:  # A/B arm: 0 = the Conv3d GEMMs run every tap group on every tile
             _lib.grove_gemm_set_tap_skip(int(os.environ["GROVE_GEMM_TAP_SKIP"]))
+            _lib.grove_gemm_tn_set_tap_skip(int(os.environ["GROVE_GEMM_TAP_SKIP"]))
         if os.environ.get("GROVE_GEMM_BLOCKS") is not None:    # A/B runs at N > 1: resident blocks of the persistent GEMMs (grove_hip.h)
             _lib.grove_gemm_set_persistent_blocks(int(os.environ["GROVE_GEMM_BLOCKS"]))
         if os.environ.get("GROVE_GEMM_STREAM_K") is not None:  # A/B runs of whole programs: 0 = whole tiles only (grove_hip.h)

@@ -169,6 +169,7 @@ __global__ __launch_bounds__(TNT) void gemm_tn_kernel(const grove_gemm_tn_params
 constexpr int Q_NT = 512, Q_BK = 64;
 int g_tn_split_tail = 1;  // cut the tiles of a partial last round into K ranges: 0 never, 1 gathered launches, 2 every launch (grove_gemm_tn_set_split_tail)
 int g_tn_last_parts = 1;  // K ranges per cut tile in the last pipelined launch
+int g_tn_last_skip = 0;   // the last pipelined launch skipped the temporal-padding K tiles
 constexpr int Q_ROWB = 256;                 // bytes per LDS row (128 bf16 columns)
 constexpr int Q_HALF = Q_BK * Q_ROWB;       // 16 KB
 constexpr int Q_STAGE = 4 * Q_HALF;
@@ -214,9 +215,18 @@ __device__ __forceinline__ bf16x8_t tr_join(const TrFrag& f) {
   return __builtin_bit_cast(bf16x8_t, (q_s16x8_t{f.lo[0], f.lo[1], f.lo[2], f.lo[3], f.hi[0], f.hi[1], f.hi[2], f.hi[3]}));
 }
 
-template <bool GATHER>
+// TSKIP (round 4; gathered launches with the temporal-padding promise b_frame_rows / b_frames, grove_hip.h): the N columns are three
+// equal tap groups (temporal offset -1, 0, +1) and the K rows are frames of fk K tiles, T frames per group. For the first tap group every
+// gathered row of a group's FIRST frame is the zero row, for the last tap group every row of its LAST frame: those K tiles only ever add
+// +0.0 and are left out. A tile of tap group 0 / 2 walks `run` = (T - 1) fk valid K tiles per T fk (LOGICAL K tiles; the physical one
+// adds the skipped frames back), and the tiles are dealt full ones (tap group 1) first, so that rounds and the cut tail hold tiles of
+// one length. Whole tiles stay bit-identical to the un-skipped launch.
+struct tn_skip {
+  int fk, T;  // K tiles per frame, frames per group
+};
+template <bool GATHER, bool TSKIP = false>
 __global__ __launch_bounds__(Q_NT) void gemm_tn_pp_kernel(const grove_gemm_tn_params p, const int tiles_m, const int tiles_n, const int tiles_whole,
-                                                          const int parts) {
+                                                          const int parts, const tn_skip sk = tn_skip{0, 0}) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -234,16 +244,35 @@ __global__ __launch_bounds__(Q_NT) void gemm_tn_pp_kernel(const grove_gemm_tn_pa
   const int tail_tiles = tiles - tiles_whole;
   const int units = tiles_whole + tail_tiles * parts;
   const int nk = p.K / Q_BK;
+  // TSKIP: tile order = tap group 1 (full) first, then groups 0 and 2; LOGICAL K tiles per tile
+  const int tiles_g = TSKIP ? tiles / 3 : 0;                                 // tiles of one tap group (tn-major: a contiguous third)
+  const int sk_run = TSKIP ? (sk.T - 1) * sk.fk : 0, sk_per = TSKIP ? sk.T * sk.fk : 1;
+  const int nk_short = TSKIP ? (nk / sk_per) * sk_run : nk;
+  auto tile_of = [&](int Lo) { return !TSKIP ? Lo : (Lo < tiles_g ? Lo + tiles_g : (Lo < 2 * tiles_g ? Lo - tiles_g : Lo)); };
+  auto grp_of = [&](int L) { return !TSKIP ? 1 : (L >= 2 * tiles_g) + (L >= tiles_g); };
   auto unit_of = [&](int u, int& L, int& ka, int& kb) {
     if (u < tiles_whole) {
-      L = u; ka = 0; kb = nk;
+      L = tile_of(u);
+      ka = 0;
+      kb = (TSKIP && grp_of(L) != 1) ? nk_short : nk;
     } else {
       const int v = u - tiles_whole;
       const int part = (v >= tail_tiles) + (v >= 2 * tail_tiles) + (v >= 3 * tail_tiles);
-      L = tiles_whole + v - part * tail_tiles;
-      ka = part * nk / parts;
-      kb = (part + 1) * nk / parts;
+      L = tile_of(tiles_whole + v - part * tail_tiles);
+      const int nkl = (TSKIP && grp_of(L) != 1) ? nk_short : nk;
+      ka = part * nkl / parts;
+      kb = (part + 1) * nkl / parts;
     }
+  };
+  // physical K tile of logical K tile k of a tile in tap group grp, and the valid tiles left in its run (TSKIP)
+  auto phys_of = [&](int k, int grp, int& left) {
+    if (!TSKIP || grp == 1) {
+      left = 0x7fffffff;
+      return k;
+    }
+    const int q = k / sk_run, r = k - q * sk_run;
+    left = sk_run - r;
+    return q * sk_per + r + (grp == 0 ? sk.fk : 0);
   };
   int NT = 0;
   for (int u = wgid; u < units; u += G) {
@@ -262,9 +291,12 @@ __global__ __launch_bounds__(Q_NT) void gemm_tn_pp_kernel(const grove_gemm_tn_pa
   const bf16_raw* pbrow[2];  // GATHER: my two B rows of the K tile being issued (nullptr = zero row)
   const int32_t* bidx = nullptr;
   int is_u = wgid, is_k = 0, is_kb = 0;
+  int is_kp = 0, is_left = 0x7fffffff, is_grp = 1;  // physical K tile being issued, valid tiles left in its run, tap group (TSKIP)
   auto set_tile = [&](int u) {  // consecutive tiles share the B panel
     int L;
     unit_of(u, L, is_k, is_kb);
+    is_grp = grp_of(L);
+    is_kp = phys_of(is_k, is_grp, is_left);
     const int tm = L % tiles_m, tn = L / tiles_m;
     const int m0 = tm * 256, n0 = tn * 256;
     const int tap = n0 / n_per_tap, nb0 = n0 - tap * n_per_tap;
@@ -291,17 +323,20 @@ __global__ __launch_bounds__(Q_NT) void gemm_tn_pp_kernel(const grove_gemm_tn_pa
     pbrow[1] = r1 >= 0 ? B + (int64_t)r1 * p.ldb : nullptr;
   };
   auto next_rows_base = [&]() -> const int32_t* {  // index window of the K tile AFTER (is_u, is_k)
-    int k2 = is_k + 1;
+    int k2 = is_k + 1, kp2 = is_kp + 1;
+    if (TSKIP && is_left == 1) kp2 += sk.fk;  // the run ends here: the next valid K tile is one frame on
     const int32_t* bb = bidx;
     if (k2 == is_kb) {
       int L2 = 0, kb2;
-      k2 = 0;
+      k2 = 0, kp2 = 0;
       if (is_u + G < units) {
+        int left2;
         unit_of(is_u + G, L2, k2, kb2);
+        kp2 = phys_of(k2, grp_of(L2), left2);
         bb = p.b_idx + (int64_t)(((L2 / tiles_m) * 256) / n_per_tap) * p.K;
       }
     }
-    return bb + k2 * Q_BK;
+    return bb + kp2 * Q_BK;
   };
   auto issue = [&](int x, int stream_t) {
     char* dst = smem + (stream_t & 1) * Q_STAGE + x * Q_HALF + wave * (64 * 16);
@@ -309,11 +344,11 @@ __global__ __launch_bounds__(Q_NT) void gemm_tn_pp_kernel(const grove_gemm_tn_pa
     for (int i = 0; i < 2; ++i) {
       const bf16_raw* src;
       if (x == 0 || x == 3) {
-        src = pa[x == 3] + (int64_t)(is_k * Q_BK + 32 * i + st_k) * p.lda;
+        src = pa[x == 3] + (int64_t)(is_kp * Q_BK + 32 * i + st_k) * p.lda;
       } else if (GATHER) {
         src = pbrow[i] ? pbrow[i] + colb[x == 2] : (const bf16_raw*)g_tn_zero_page;
       } else {
-        src = B + (int64_t)(is_k * Q_BK + 32 * i + st_k) * p.ldb + colb[x == 2];
+        src = B + (int64_t)(is_kp * Q_BK + 32 * i + st_k) * p.ldb + colb[x == 2];
       }
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(dst + i * (Q_NT * 16)), 16, 0, 0);
@@ -323,6 +358,9 @@ __global__ __launch_bounds__(Q_NT) void gemm_tn_pp_kernel(const grove_gemm_tn_pa
     if (++is_k == is_kb) {
       is_u += G;
       set_tile(is_u);
+    } else {
+      ++is_kp;
+      if (TSKIP && --is_left == 0) is_kp += sk.fk, is_left = sk_run;
     }
     if (GATHER) {
       take_rows();
@@ -379,7 +417,7 @@ __global__ __launch_bounds__(Q_NT) void gemm_tn_pp_kernel(const grove_gemm_tn_pa
   asm volatile("" ::"v"(scale));  // fetched and used before the loop (see gemm_nt_pp_kernel)
   set_tile(is_u);
   if (GATHER) {
-    prefetch_rows(bidx + is_k * Q_BK);
+    prefetch_rows(bidx + is_kp * Q_BK);
     take_rows();
     prefetch_rows(next_rows_base());
   }
@@ -465,6 +503,7 @@ __global__ __launch_bounds__(Q_NT) void gemm_tn_pp_kernel(const grove_gemm_tn_pa
 #undef QQ_READ_B
 }
 
+int g_tn_tap_skip = 1;  // honour b_frame_rows / b_frames (grove_gemm_tn_set_tap_skip; A/B knob)
 template <bool GATHER>
 int launch_tn_pp(const grove_gemm_tn_params& p, hipStream_t s) {
   const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 255) / 256;
@@ -473,6 +512,7 @@ int launch_tn_pp(const grove_gemm_tn_params& p, hipStream_t s) {
   static int num_cus = 0;
   if (!attr_set) {
     hipFuncSetAttribute((const void*)gemm_tn_pp_kernel<GATHER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if constexpr (GATHER) hipFuncSetAttribute((const void*)gemm_tn_pp_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     int dev = 0;
     hipGetDevice(&dev);
     hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -488,17 +528,31 @@ int launch_tn_pp(const grove_gemm_tn_params& p, hipStream_t s) {
   // Measured (tools/bench_gemm_tn.py, (1280, 34560, 32768)): gathered taps 2.90-2.98 -> 2.85 ms; the plain form does not move
   // (2.73 ms either way: at the board's power limit a launch costs its energy, not its rounds), so by default only gathered
   // launches are cut and plain ones keep their fixed sum order.
+  // temporal tap skipping: three equal tap groups of whole column tiles, frames of whole K tiles, K = whole groups of frames
+  tn_skip sk{0, 0};
+  if (GATHER && g_tn_tap_skip && p.b_frame_rows > 0 && p.b_frames >= 2 && p.b_taps % 3 == 0 && tiles_n % 3 == 0 && p.b_frame_rows % Q_BK == 0 &&
+      p.K % ((long)p.b_frame_rows * p.b_frames) == 0 && p.M % 256 == 0 && p.N % 256 == 0)
+    sk = tn_skip{p.b_frame_rows / Q_BK, p.b_frames};
+  const int nk_eff = sk.fk ? (p.K / Q_BK) / sk.T * (sk.T - 1) : p.K / Q_BK;  // K tiles of the tiles a cut tail holds (the short ones come last)
   int parts = 1, tail = tiles % G;
   if (tail && (g_tn_split_tail == 2 || (g_tn_split_tail == 1 && GATHER))) {
     double best = 1.0;
     for (int s2 = 2; s2 <= 4; ++s2) {
-      if (p.K / Q_BK / s2 < 32) break;
+      if (nk_eff / s2 < 32) break;
       const double c = (double)((tail * s2 + G - 1) / G) / s2 + 0.02 * s2;  // + the atomics of a part
       if (c < best) { best = c; parts = s2; }
     }
   }
   g_tn_last_parts = parts;
-  hipLaunchKernelGGL(gemm_tn_pp_kernel<GATHER>, dim3(G), dim3(Q_NT), lds, s, p, tiles_m, tiles_n, parts > 1 ? tiles - tail : tiles, parts);
+  g_tn_last_skip = sk.fk != 0;
+  if constexpr (GATHER) {
+    if (sk.fk) {
+      hipLaunchKernelGGL((gemm_tn_pp_kernel<true, true>), dim3(G), dim3(Q_NT), lds, s, p, tiles_m, tiles_n, parts > 1 ? tiles - tail : tiles, parts, sk);
+      GROVE_LAUNCH_CHECK();
+      return GROVE_OK;
+    }
+  }
+  hipLaunchKernelGGL((gemm_tn_pp_kernel<GATHER, false>), dim3(G), dim3(Q_NT), lds, s, p, tiles_m, tiles_n, parts > 1 ? tiles - tail : tiles, parts, sk);
   GROVE_LAUNCH_CHECK();
   return GROVE_OK;
 }
@@ -516,6 +570,11 @@ extern "C" int grove_gemm_tn_set_split_tail(int on) {
   return GROVE_OK;
 }
 extern "C" int grove_gemm_tn_last_parts(void) { return g_tn_last_parts; }
+extern "C" int grove_gemm_tn_set_tap_skip(int on) {
+  g_tn_tap_skip = on ? 1 : 0;
+  return GROVE_OK;
+}
+extern "C" int grove_gemm_tn_last_skip(void) { return g_tn_last_skip; }
 
 extern "C" int grove_gemm_tn_bf16(const grove_gemm_tn_params* pp, void* stream) {
   GROVE_CHECK(pp && pp->M > 0 && pp->N > 0 && pp->K > 0, GROVE_E_SHAPE, "gemm_tn: bad shape");

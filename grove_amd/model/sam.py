@@ -394,7 +394,7 @@ class SamEncoder:
         # one TN GEMM over the K-major operands with the per-tap row gather on x (no im2col, no transposes)
         gw = g[name + "conv3d.weight"].view(C, 27 * C)
         if C % 128 == 0:
-            ops.wgrad(prod, x, gw, b_idx=conv_idx, b_taps=27, scale_ptr=a, scale_tanh=True, K=M)
+            ops.wgrad(prod, x, gw, b_idx=conv_idx, b_taps=27, scale_ptr=a, scale_tanh=True, K=M, b_frames=self.conv_frames)
         else:  # tiny test dims: a 128-wide tile would straddle taps -> one launch per tap
             for tap in range(27):
                 ops.wgrad(prod, x, gw[:, tap * C:(tap + 1) * C], b_idx=conv_idx[tap:tap + 1], scale_ptr=a, scale_tanh=True, K=M)

@@ -168,8 +168,9 @@ def linear(x, w, bias=None, *, act=ACT_NONE, residual=None, out=None, out_dtype=
     return out
 
 
-def wgrad(dy, x, grad, *, b_idx=None, b_taps=1, scale_ptr=None, scale_tanh=False, alpha=1.0, split_k=0, K=None):
-    """grad[M, N] (fp32) += alpha * dy[K, M]^T @ x[K, N]  (x rows optionally gathered per tap)."""
+def wgrad(dy, x, grad, *, b_idx=None, b_taps=1, scale_ptr=None, scale_tanh=False, alpha=1.0, split_k=0, K=None, b_frames=(0, 0)):
+    """grad[M, N] (fp32) += alpha * dy[K, M]^T @ x[K, N]  (x rows optionally gathered per tap).
+    b_frames = (rows per frame, frames per group): the temporal-padding promise about b_idx (grove_gemm_tn_params.b_frame_rows)."""
     _chk_dev(dy, x, grad)
     if _pre_gemm_hook is not None:
         _pre_gemm_hook()
@@ -179,6 +180,7 @@ def wgrad(dy, x, grad, *, b_idx=None, b_taps=1, scale_ptr=None, scale_tanh=False
     p.K = K if K is not None else dy.shape[0]
     p.lda, p.ldb, p.ldc = dy.stride(0), x.stride(0), grad.stride(0)
     p.b_taps, p.scale_tanh, p.split_k, p.alpha = b_taps, int(scale_tanh), split_k, float(alpha)
+    p.b_frame_rows, p.b_frames = b_frames
     _lib.check(_lib.lib().grove_gemm_tn_bf16(C.byref(p), _stream()), "grove_gemm_tn_bf16")
     return grad
 

@@ -217,6 +217,12 @@ typedef struct grove_gemm_tn_params {
   int32_t scale_tanh;
   int32_t split_k;      /* 0 = auto */
   float alpha;
+  /* Temporal tap skipping (round 4; pipelined gathered kernel): the PROMISE of grove_gemm_params.a_frame_rows / a_frames for this
+   * product — the K rows are frames of b_frame_rows rows (a multiple of 64), b_frames frames per group; the taps are three equal groups
+   * in N order; b_idx[tap][k] == -1 for every tap of the first group when k lies in the first frame of its group and for every tap of
+   * the last group when k lies in the last frame. Those K tiles are skipped (1 / b_frames of the K range of two thirds of the output
+   * tiles) and the full tiles are dealt first. Whole tiles stay bit-identical. 0 / 0 = no promise. */
+  int32_t b_frame_rows, b_frames;
 } grove_gemm_tn_params;
 int grove_gemm_tn_bf16(const grove_gemm_tn_params* p, void* stream);
 /* kernel choice of grove_gemm_tn_bf16: -1 = auto (default), 0 = the 128 x 128 kernel always, 1 = the persistent pipelined
@@ -228,6 +234,9 @@ int grove_gemm_tn_set_pipelined(int mode);
  * 2 = every eligible launch. grove_gemm_tn_last_parts: K ranges per cut tile in the last pipelined launch. */
 int grove_gemm_tn_set_split_tail(int on);
 int grove_gemm_tn_last_parts(void);
+/* A/B knob: 0 = ignore b_frame_rows / b_frames; grove_gemm_tn_last_skip: whether the last pipelined launch skipped. */
+int grove_gemm_tn_set_tap_skip(int on);
+int grove_gemm_tn_last_skip(void);
 
 /* out[c, r] = in[r, c] for a batch of 2-D bf16 matrices (used for V^T, dY^T, X^T, NCHW<->NHWC).
  * rows beyond `rows` in the output's padded leading dim (ld_out > rows) are zero filled up to

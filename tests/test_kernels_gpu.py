@@ -1458,3 +1458,46 @@ def test_conv3d_temporal_tap_skipping_is_bit_identical_on_whole_tiles(dev, Co, f
     pre = torch.einsum("tnc,otc->no", xg, w.float().view(Co, 27, Ci)) + bias.float()
     want = torch.relu(pre) * math.tanh(0.3)
     close(out[rows], want, 2 ** -7, "tap-skipping conv vs fp32 gather")
+
+
+@pytest.mark.parametrize("G,T,Ci,Co,split", [(2, 8, 256, 512, 0), (4, 8, 512, 1280, 0), (2, 4, 512, 1280, 1)])
+def test_wgrad_conv3d_temporal_tap_skipping(dev, G, T, Ci, Co, split):
+    """Round 4: the Conv3d adapters' weight gradient (one gathered TN GEMM) with the temporal-padding promise
+    (grove_gemm_tn_params.b_frame_rows / b_frames): output tiles of the first tap group skip the K tiles of every group's first frame,
+    tiles of the last tap group those of the last frame, and the full tiles (middle tap group) are dealt first. The skipped products
+    only ever added +0.0: with whole tiles (split_tail off) the result is BIT-identical to the launch without the promise; with a cut
+    tail (fp32 atomics, other cut points) it agrees to fp32 sum-order noise. Also against the 128 x 128 kernel."""
+    from grove_amd import _lib, ops
+    from grove_amd.model.indexing import conv3d_gather_index
+    L = _lib.lib()
+    H = W = 32
+    Mtok = G * T * H * W
+    xx, dz = rnd(Mtok, Ci, seed=31).to(dev), rnd(Mtok, Co, seed=32).to(dev)
+    idx = conv3d_gather_index(G, T, H, W).to(dev)
+    z = lambda: torch.zeros(Co, 27 * Ci, dtype=torch.float32, device=dev)
+    try:
+        L.grove_gemm_tn_set_pipelined(1)
+        L.grove_gemm_tn_set_split_tail(split)
+        L.grove_gemm_tn_set_tap_skip(0)
+        ref = ops.wgrad(dz, xx, z(), b_idx=idx, b_taps=27, b_frames=(H * W, T))
+        assert L.grove_gemm_tn_last_skip() == 0
+        L.grove_gemm_tn_set_tap_skip(1)
+        out = ops.wgrad(dz, xx, z(), b_idx=idx, b_taps=27, b_frames=(H * W, T))
+        assert L.grove_gemm_tn_last_skip() == 1
+        plain = ops.wgrad(dz, xx, z(), b_idx=idx, b_taps=27)      # no promise: no skipping
+        assert L.grove_gemm_tn_last_skip() == 0
+        if not split:
+            assert torch.equal(plain, ref)
+            assert torch.equal(out, ref), (out - ref).abs().max().item()
+        else:
+            close(out, ref, 2e-6, "tap-skipping wgrad with a cut tail")
+        # accumulation onto existing values, twice (the optimizer's gradient buffer is accumulated into)
+        acc = ops.wgrad(dz, xx, out.clone(), b_idx=idx, b_taps=27, b_frames=(H * W, T))
+        close(acc, 2 * ref, 2e-6, "accumulating launch")
+        L.grove_gemm_tn_set_pipelined(0)
+        small = ops.wgrad(dz, xx, z(), b_idx=idx, b_taps=27)
+        close(out, small, 3e-6, "tap-skipping wgrad vs the 128 x 128 kernel")
+    finally:
+        L.grove_gemm_tn_set_pipelined(-1)
+        L.grove_gemm_tn_set_split_tail(1)
+        L.grove_gemm_tn_set_tap_skip(1)
