@@ -122,6 +122,8 @@ class GROVEForCausalLM(torch.nn.Module):
         self.config.bbox_token_idx = kwargs.get("bbox_token_idx", 32002)      # GROVE.py:115 (region prompts: never read on this path)
         self.config.out_dim = d.out_dim
         self.literal_T = kwargs.get("literal_T", False)
+        # last LLaMA layer on the rows a training step reads only (labelled + [DET] rows: the answer's tail); False = every row (A/B, tests)
+        self.llama_tail = kwargs.get("llama_tail", True)
         # dense positional encoding dtype: bf16 reproduces the reference under model.to(bf16) (quirk Q10)
         self.pe_dtype = kwargs.get("pe_dtype", torch.bfloat16)
         self.stream_dtype = kwargs.get("stream_dtype", None)  # None: fp32 for inference models, bf16 for training models
@@ -437,6 +439,7 @@ class GROVEForCausalLM(torch.nn.Module):
         [DET] rows and the (sequence, frame, det) instance order (GROVE.py:200-205, 248-268), and the ground truth per instance
         (GROVE.py:339-360). Everything the device needs is uploaded here; `device_tensors` lists those uploads."""
         hp = SimpleNamespace()
+        hp.tail_start, hp.det_rows_hidden = 0, None
         feat_row = list(range(B))  # image_features[cur_image_idx] (llava_with_region_arch.py:156): row b
         hp.plan = plan = self._splice_plan(ids, None if inference else labs, None if inference else amask, feat_row)
         S = plan.S
@@ -462,6 +465,20 @@ class GROVEForCausalLM(torch.nn.Module):
             bi, ti = valid.nonzero(as_tuple=True)
             hp.rows = (bi * S + ti).to(torch.int32).to(self.dev)
             hp.tgt = lab[bi, ti + 1].to(torch.int32).to(self.dev)
+            # LAST-LAYER TAIL: the only hidden states anything reads in a training step are the labelled rows of the shifted CE and the
+            # [DET] rows — all in the answer, behind the visual tokens and the prompt. s0 = the first such position over the batch; when
+            # the tail is at most half the sequence, LlamaStack runs its last layer's queries / MLP on positions >= s0 only and returns
+            # the compact [B * (S - s0), H] rows; the row tables below index that layout.
+            hp.tail_start = 0
+            if self.llama_tail and not self.llama.fp32_stream and self.gemm_dtype != "fp8" and (int(ti.numel()) or int(det_rows.numel())):
+                cand = ([int(ti.min())] if int(ti.numel()) else []) + ([int((det_rows % S).min())] if int(det_rows.numel()) else [])
+                s0 = min(cand)
+                if s0 > 0 and (S - s0) * 2 <= S:
+                    Lq = S - s0
+                    hp.tail_start = s0
+                    hp.rows = (bi * Lq + (ti - s0)).to(torch.int32).to(self.dev)
+                    hp.det_rows_hidden = ((det_rows // S) * Lq + (det_rows % S - s0)).to(torch.int32).to(self.dev)
+                    dev_t.append(hp.det_rows_hidden)
             # the per-frame GT tensors come to the host in TWO transfers
             v_all = torch.cat([vis_l[b][t].reshape(-1).float() for b in range(B) for t in range(Tseq)]).cpu()
             gb_rows = [boxes_l[b][t].reshape(-1, 4).shape[0] for b in range(B) for t in range(Tseq)]
@@ -542,7 +559,11 @@ class GROVEForCausalLM(torch.nn.Module):
         self.wait_weights()
         x = self._embed(plan, feats.data)
         hidden, llama_ctx = self.llama.forward(x, plan.B, plan.S, kv_len=plan.kv_len, save=train,
-                                               precise_rows=det_rows if self.gemm_dtype == "fp8" else None)
+                                               precise_rows=det_rows if self.gemm_dtype == "fp8" else None,
+                                               tail_start=hp.tail_start or None)
+        tail = hidden.shape[0] != plan.B * plan.S  # the last layer ran on the tail rows only: `hidden` is [B * (S - s0), H]
+        assert tail == bool(hp.tail_start), (tail, hp.tail_start)
+        det_rows_h = hp.det_rows_hidden if tail else det_rows  # where the [DET] rows sit in `hidden`
         # 1. grounding encoder (GROVE.py:162). It shares nothing with the CLIP -> LLaMA tower until the decoder, so it runs on its
         # own stream: the two kernel sequences interleave on the CUs and fill each other's partial rounds and tails
         # (same-box A/B: -11 ms per step, forward and backward). `tower_overlap = False` serialises them.
@@ -590,7 +611,7 @@ class GROVEForCausalLM(torch.nn.Module):
             inst_det_t, inst_frame_t, N = hp.inst_det_t, hp.inst_frame_t, hp.N
             if train or not self.decoder.precise:
                 drows = torch.empty((n_det, H), dtype=bf, device=self.dev)
-                ops.copy_rows(hidden, drows, n_det, H, idx_src=det_rows)
+                ops.copy_rows(hidden, drows, n_det, H, idx_src=det_rows_h)
                 dv = Var(drows)
                 h1 = tp.linear(dv, self.P("model.text_hidden_fcs.0.0.weight"), self.P("model.text_hidden_fcs.0.0.bias"), act=ops.ACT_RELU)
                 te = tp.linear(h1, self.P("model.text_hidden_fcs.0.2.weight"), self.P("model.text_hidden_fcs.0.2.bias"))
@@ -601,7 +622,7 @@ class GROVEForCausalLM(torch.nn.Module):
                 # the fp32 stream rows, text_hidden_fcs on the exact-fp32 MFMA GEMM, fp32 token side of the decoder (row gathers are
                 # index selection)
                 dv = te = None
-                srows = self.llama.last_stream.index_select(0, det_rows.long()).float()  # (already fp32 with the fp32 stream)
+                srows = self.llama.last_stream.index_select(0, det_rows_h.long()).float()  # (already fp32 with the fp32 stream)
                 hn = ops.rmsnorm(None, self._sd["model.norm.weight"], d.rms_eps, res=srows, out_dtype=torch.float32)
                 h1 = ops.linear_f32(hn, self._sd["model.text_hidden_fcs.0.0.weight"], self._sd["model.text_hidden_fcs.0.0.bias"], act=ops.ACT_RELU)
                 te32 = ops.linear_f32(h1, self._sd["model.text_hidden_fcs.0.2.weight"], self._sd["model.text_hidden_fcs.0.2.bias"])
@@ -658,8 +679,8 @@ class GROVEForCausalLM(torch.nn.Module):
         out["flat_boxes"], out["flat_logits"] = flat_box, flat_obj
         if train:
             self._ctx = SimpleNamespace(tp=tp, sam_ctx=sam_ctx, llama_ctx=llama_ctx, plan=plan, feats=feats, ce_state=ce_state,
-                                        det=(dv, te, inst_det_t, det_rows, n_det) if n_det else None, dec_state=dec_state,
-                                        dbox=dbox, dobj=dobj, N=N, F=F, hidden_shape=(plan.B * plan.S, H),
+                                        det=(dv, te, inst_det_t, det_rows_h, n_det) if n_det else None, dec_state=dec_state,
+                                        dbox=dbox, dobj=dobj, N=N, F=F, hidden_shape=(hidden.shape[0], H),
                                         embed=(hp.embed_ids, hp.embed_compact) if getattr(hp, "embed_ids", None) is not None else None)
         return out
 

@@ -76,7 +76,80 @@ class LlamaStack:
             ops.linear(h, L["wq"], a_idx=precise_rows, c_idx=precise_rows, M=int(precise_rows.numel()), out=qkv[:, :H])
         return qkv
 
-    def forward(self, x, B, S, kv_len=None, save=False, kv_cache=None, precise_rows=None):
+    def _tail_index(self, B, S, s0):
+        """int32 rows b*S + s0 + j (the last S - s0 positions of every sequence) and their positions (cached per geometry)."""
+        key = (B, S, s0)
+        if getattr(self, "_tail_cache", None) is None:
+            self._tail_cache = {}
+        if key not in self._tail_cache:
+            j = torch.arange(s0, S, dtype=torch.int32)
+            idx = (torch.arange(B, dtype=torch.int32)[:, None] * S + j[None]).reshape(-1)
+            self._tail_cache[key] = (idx.to(self.dev), j.repeat(B).to(self.dev))
+        return self._tail_cache[key]
+
+    def _last_layer_tail(self, L, x, B, S, s0, kv_len, save):
+        """The LAST layer when only the hidden states of positions >= s0 are consumed downstream (training: the labelled rows of the
+        shifted CE and the [DET] rows all lie in the answer, behind the 575 visual tokens and the prompt): keys / values of every
+        position, but queries, attention output, o_proj and the whole MLP for the tail rows only — the same values the full layer gives
+        at those rows (HF computes all S rows of every layer, llava_llama.py:100-109; nothing reads the others of the last one). bf16
+        stream form. Returns (x_out [B*Lq, H] compact tail rows, saved tuple)."""
+        d = self.d
+        H, nh, hd, I = d.hidden, d.n_heads, d.head_dim, d.mlp
+        Lq = S - s0
+        tail_idx, pos_t = self._tail_index(B, S, s0)
+        pos = torch.arange(S, dtype=torch.int32, device=self.dev).repeat(B)
+        h = ops.rmsnorm(x, L["ln1"], d.rms_eps)
+        kv = ops.linear(h, L["wqkv"][H:])                       # k | v of all rows
+        ops.rope_(kv, pos, 0, nh, hd, d.rope_theta)              # (keys only: the first nh heads of the k | v activation)
+        n_t = B * Lq
+        x_t = torch.empty((n_t, H), dtype=torch.bfloat16, device=self.dev)
+        h_t = torch.empty((n_t, H), dtype=torch.bfloat16, device=self.dev)
+        ops.copy_rows(x, x_t, n_t, H, idx_src=tail_idx)
+        ops.copy_rows(h, h_t, n_t, H, idx_src=tail_idx)
+        q_t = ops.linear(h_t, L["wqkv"][:H])
+        ops.rope_(q_t, pos_t, 0, nh, hd, d.rope_theta)
+        o_t, lse = ops.flash_attn_tail(q_t, kv, B, Lq, S, nh, hd, hd ** -0.5, kv_len=kv_len, want_lse=save)
+        x1_t = ops.linear(o_t, L["wo"], residual=x_t)
+        h2_t = ops.rmsnorm(x1_t, L["ln2"], d.rms_eps)
+        if "wgu_sw" in L and n_t >= 1024:
+            gu = torch.empty((n_t, 2 * I), dtype=torch.bfloat16, device=self.dev) if save else None
+            a = ops.linear(h2_t, L["wgu_sw"], act=ops.ACT_SWIGLU_PAIR, aux=gu, ld_aux=2 * I)
+        else:
+            gu = ops.linear(h2_t, L["wgu"])
+            a = ops.swiglu(gu, I)
+        x_out = ops.linear(a, L["wd"], residual=x1_t)
+        saved = ("tail", x, kv, q_t, o_t, lse, x1_t, gu, s0, kv_len) if save else None
+        return x_out, saved
+
+    def _last_layer_tail_bwd(self, L, saved, dx_t, B, S):
+        """dgrad of _last_layer_tail. dx_t: bf16 [B*Lq, H] gradient of the compact tail output; returns d x [B*S, H]."""
+        d = self.d
+        H, nh, hd, I = d.hidden, d.n_heads, d.head_dim, d.mlp
+        _, x, kv, q_t, o_t, lse, x1_t, gu, s0, kv_len = saved
+        Lq = S - s0
+        n_t = B * Lq
+        tail_idx, pos_t = self._tail_index(B, S, s0)
+        pos = torch.arange(S, dtype=torch.int32, device=self.dev).repeat(B)
+        da = ops.linear(dx_t, L["wd_t"])
+        dgu = ops.swiglu_bwd(gu, da, I)
+        dh2 = ops.linear(dgu, L["wgu_t"])
+        ops.rmsnorm_bwd(x1_t, L["ln2"], dh2, d.rms_eps, dx=dx_t, accumulate=True)    # dx_t now d x1 (tail rows)
+        do = ops.linear(dx_t, L["wo_t"])
+        dq_t = torch.empty_like(q_t)
+        dkv = torch.empty_like(kv)
+        ops.flash_attn_tail_bwd(q_t, kv, o_t, do, lse, dq_t, dkv, B, Lq, S, nh, hd, hd ** -0.5, kv_len=kv_len)
+        ops.rope_(dq_t, pos_t, 0, nh, hd, d.rope_theta, inverse=True)
+        ops.rope_(dkv, pos, 0, nh, hd, d.rope_theta, inverse=True)
+        wt = L["wqkv_t"]                                        # [H, 3H]: W^T of the fused projection (K-major for the dgrad)
+        dh = ops.linear(dkv, wt[:, H:])                          # all rows: d (k | v) . W_kv
+        dh_t = ops.linear(dq_t, wt[:, :H])                       # tail rows: d q . W_q
+        ops.copy_rows(dh_t, dh, n_t, H, idx_dst=tail_idx, accumulate=True)
+        dx = torch.zeros((B * S, H), dtype=torch.bfloat16, device=self.dev)
+        ops.copy_rows(dx_t, dx, n_t, H, idx_dst=tail_idx)        # the residual path of the tail rows
+        ops.rmsnorm_bwd(x, L["ln1"], dh, d.rms_eps, dx=dx, accumulate=True)
+        return dx
+
+    def forward(self, x, B, S, kv_len=None, save=False, kv_cache=None, precise_rows=None, tail_start=None):
         """x: bf16 [B*S, H] input embeddings (consumed). kv_len: int32 [B] valid lengths or None.
         kv_cache: optional list (one per layer) of bf16 [B, 2, heads, S_max, hd] tensors (KVCache layout) that receive the rotated keys
         and the values of positions 0..S-1 (the prefill of a cached decode). Returns (final-norm hidden [B*S, H], ctx).
@@ -95,7 +168,13 @@ class LlamaStack:
         pr = precise_rows if (self.fp8 and self.fp8_policy == "det16_kv16" and precise_rows is not None and precise_rows.numel()) else None
         res = ops.to_f32(x) if f32 else None
         t = None  # fp32 stream: branch output not yet added to the stream
+        use_tail = tail_start is not None and tail_start > 0 and not f32 and not self.fp8 and kv_cache is None
         for li, L in enumerate(self.layers):
+            if use_tail and li == len(self.layers) - 1:
+                x, sv = self._last_layer_tail(L, x, B, S, tail_start, kv_len, save)
+                if save:
+                    saved.append(sv)
+                continue
             if f32:
                 xb = torch.empty_like(x) if save else None
                 h = ops.rmsnorm(t, L["ln1"], d.rms_eps, res=res, res_bf16=xb)
@@ -261,7 +340,11 @@ class LlamaStack:
         saved, x_last, pos, B, S = ctx
         H, nh, hd, I = d.hidden, d.n_heads, d.head_dim, d.mlp
         dx = ops.rmsnorm_bwd(x_last, self.norm, d_out, d.rms_eps)
-        for L, (x, qkv, actx, x1, gu) in zip(reversed(self.layers), reversed(saved)):
+        for L, sv in zip(reversed(self.layers), reversed(saved)):
+            if isinstance(sv[0], str):  # ("tail", ...): the last layer ran on the tail rows only: d_out / dx are compact [B*Lq, H] here
+                dx = self._last_layer_tail_bwd(L, sv, dx, B, S)
+                continue
+            x, qkv, actx, x1, gu = sv
             # x2 = x1 + down(swiglu(gu));  dx is d x2
             da = ops.linear(dx, L["wd_t"])                      # [B*S, I]
             dgu = ops.swiglu_bwd(gu, da, I)

@@ -483,6 +483,43 @@ def flash_attn_bwd(qkv, out, d_out, lse, dqkv, B, L, H, hs, q_off, k_off, v_off,
     return drel
 
 
+def flash_attn_tail(q, kv, B, Lq, Lk, H, hs, alpha, *, kv_len=None, want_lse=False):
+    """Causal attention of the LAST Lq positions of every sequence against all Lk keys (bottom-right aligned causal mask: query i is
+    position Lk - Lq + i): q bf16 [B*Lq, >= H*hs] (head h at column h*hs), kv bf16 [B*Lk, >= 2*H*hs] (keys at column 0, values at
+    H*hs). Returns (out [B*Lq, H*hs], lse [B*H, Lq] or None). The general fused kernels with Lq != Lk (flash_attn.hip)."""
+    dev = q.device
+    out = torch.empty((B * Lq, H * hs), dtype=bf16, device=dev)
+    lse = torch.empty((B * H, Lq), dtype=torch.float32, device=dev) if want_lse else None
+    p = _lib.FlashAttnParams()
+    p.q, p.k, p.v, p.o = _p(q), _p(kv), _p(kv[:, H * hs:]), _p(out)
+    p.lse, p.kv_len = _p(lse), _p(kv_len)
+    p.sq, p.sk, p.sv, p.so = Lq * q.stride(0), Lk * kv.stride(0), Lk * kv.stride(0), Lq * out.stride(0)
+    p.B, p.H, p.Lq, p.Lk, p.hs = B, H, Lq, Lk, hs
+    p.ld_q, p.ld_k, p.ld_v, p.ld_o = q.stride(0), kv.stride(0), kv.stride(0), out.stride(0)
+    p.causal, p.alpha = 1, alpha
+    _lib.check(_lib.lib().grove_flash_attn_fwd(C.byref(p), _stream()), "grove_flash_attn_fwd")
+    return out, lse
+
+
+def flash_attn_tail_bwd(q, kv, out, d_out, lse, dq, dkv, B, Lq, Lk, H, hs, alpha, *, kv_len=None):
+    """Backward of flash_attn_tail: dq [B*Lq, >= H*hs] and dkv [B*Lk, >= 2*H*hs] (d keys | d values) are overwritten."""
+    dev = q.device
+    delta = torch.empty((B * H, Lq), dtype=torch.float32, device=dev)
+    p = _lib.FlashAttnParams()
+    p.q, p.k, p.v, p.o, p.d_o = _p(q), _p(kv), _p(kv[:, H * hs:]), _p(out), _p(d_out)
+    p.dq, p.dk, p.dv = _p(dq), _p(dkv), _p(dkv[:, H * hs:])
+    p.lse, p.delta, p.kv_len = _p(lse), _p(delta), _p(kv_len)
+    p.sq, p.sk, p.sv = Lq * q.stride(0), Lk * kv.stride(0), Lk * kv.stride(0)
+    p.so, p.sdo = Lq * out.stride(0), Lq * d_out.stride(0)
+    p.sdq, p.sdk, p.sdv = Lq * dq.stride(0), Lk * dkv.stride(0), Lk * dkv.stride(0)
+    p.B, p.H, p.Lq, p.Lk, p.hs = B, H, Lq, Lk, hs
+    p.ld_q, p.ld_k, p.ld_v = q.stride(0), kv.stride(0), kv.stride(0)
+    p.ld_o, p.ld_do = out.stride(0), d_out.stride(0)
+    p.ld_dq, p.ld_dk, p.ld_dv = dq.stride(0), dkv.stride(0), dkv.stride(0)
+    p.causal, p.alpha = 1, alpha
+    _lib.check(_lib.lib().grove_flash_attn_bwd(C.byref(p), _stream()), "grove_flash_attn_bwd")
+
+
 def rel_bias_applicable(nh, hp, rel_ld):
     """Shapes the matrix-core rel-pos streams take (grove_rel_bias_*); others go through the batched GEMM."""
     if os.environ.get("GROVE_REL_BIAS_STREAMS", "1") == "0":  # A/B arm of whole-program runs: the batched GEMMs

@@ -278,3 +278,36 @@ def test_vocabulary_not_a_multiple_of_eight(dev):
     assert g.sequences.shape[1] <= oids.shape[1] and int(g.sequences.max()) < d.vocab
     n = g.sequences.shape[1]
     assert (g.sequences.cpu()[:, :n] == oids[:, :n]).float().mean().item() > 0.9   # (near-tie logits may flip a token in bf16)
+
+
+def test_last_layer_tail_equals_the_full_last_layer(dev):
+    """Round 4: in a training step only the labelled rows and the [DET] rows of the LLaMA output are read, all in the answer's tail, so
+    the last layer runs its queries / o_proj / MLP on positions >= s0 only (keys and values of every position). Same losses and the same
+    gradients as the full last layer (`llama_tail=False`) up to accumulation-order noise — both against each other and, through the
+    other parity tests, against the oracle."""
+    from grove_amd import GROVEForCausalLM
+    from grove_amd.model.GROVE import trainable_names
+    from grove_amd.synthetic import TINY, synthetic_batch, synthetic_state_dict
+    d = TINY
+    sd = synthetic_state_dict(d)
+    batch = to_dev(synthetic_batch(d, B=2, T=8, L=48, n_det=2, seed=1, ragged=True), dev)
+    res = {}
+    for tail in (True, False):
+        m = GROVEForCausalLM(dims=d, device=dev, state_dict=sd, det_token_idx=d.det_token_idx, num_frames=8, pe_dtype=torch.float32, train=True,
+                             llama_tail=tail)
+        m.zero_grad()
+        out = m(**batch)
+        took = isinstance(m._ctx.llama_ctx[0][-1][0], str)
+        assert took == tail, "the tail path must be taken exactly when asked (the answer is < half of the 575 + L positions)"
+        m.backward(out["loss"])
+        torch.cuda.synchronize()
+        res[tail] = ({k: float(v) for k, v in out.items() if k.endswith("loss")}, m._flat_grad.clone(), {n: m._grad[n].clone() for n in trainable_names(d)})
+    for k in res[False][0]:
+        assert abs(res[True][0][k] - res[False][0][k]) <= 2e-3 * max(1.0, abs(res[False][0][k])), (k, res[True][0], res[False][0])
+    for n, gf in res[False][2].items():
+        gt = res[True][2][n]
+        a, b = gt.flatten().double(), gf.flatten().double()
+        if float(b.norm()) < 1e-9:
+            continue
+        cos = float(torch.nn.functional.cosine_similarity(a, b, dim=0))
+        assert cos > 0.995 and abs(float(a.norm() / b.norm()) - 1.0) < 2e-2, (n, cos, float(a.norm() / b.norm()))

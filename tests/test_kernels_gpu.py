@@ -1501,3 +1501,50 @@ def test_wgrad_conv3d_temporal_tap_skipping(dev, G, T, Ci, Co, split):
         L.grove_gemm_tn_set_pipelined(-1)
         L.grove_gemm_tn_set_split_tail(1)
         L.grove_gemm_tn_set_tap_skip(1)
+
+
+@pytest.mark.parametrize("B,H,hs,Lq,Lk,ragged", [(2, 4, 128, 54, 703, False), (3, 2, 64, 130, 300, True), (1, 4, 128, 1, 200, False), (2, 4, 32, 200, 333, True)])
+def test_flash_attention_tail_queries(dev, B, H, hs, Lq, Lk, ragged):
+    """The general fused kernels with Lq != Lk: causal attention of the LAST Lq positions against all Lk keys (bottom-right aligned
+    mask: query i is position Lk - Lq + i; per-sequence kv_len for right padding) — what LlamaStack's last layer runs when only the
+    answer's rows are consumed (round 4). Forward and backward against torch autograd in fp32."""
+    from grove_amd import ops
+    g = torch.Generator().manual_seed(5)
+    q = (torch.randn(B * Lq, H * hs, generator=g) * 0.7).to(bf16)
+    kv = (torch.randn(B * Lk, 2 * H * hs, generator=g) * 0.7).to(bf16)
+    do = torch.randn(B * Lq, H * hs, generator=g).to(bf16)
+    kv_len = torch.tensor([Lk - 7 * b for b in range(B)], dtype=torch.int32) if ragged else None
+    alpha = hs ** -0.5
+    out, lse = ops.flash_attn_tail(q.to(dev), kv.to(dev), B, Lq, Lk, H, hs, alpha, kv_len=kv_len.to(dev) if ragged else None, want_lse=True)
+    qr = q.float().view(B, Lq, H, hs).permute(0, 2, 1, 3).requires_grad_(True)
+    kr = kv.float()[:, :H * hs].reshape(B, Lk, H, hs).permute(0, 2, 1, 3).requires_grad_(True)
+    vr = kv.float()[:, H * hs:].reshape(B, Lk, H, hs).permute(0, 2, 1, 3).requires_grad_(True)
+    s = (qr @ kr.transpose(-1, -2)) * alpha
+    i = torch.arange(Lq)[:, None] + (Lk - Lq)
+    j = torch.arange(Lk)[None, :]
+    mask = (j > i)[None, None].expand(B, H, Lq, Lk).clone()
+    if ragged:
+        for b in range(B):
+            mask[b, :, :, int(kv_len[b]):] = True
+    valid_q = ~mask.all(-1)                                     # (a padded query past kv_len sees nothing: its row is unused)
+    s = s.masked_fill(mask, float("-inf"))
+    p = torch.softmax(s, -1).nan_to_num(0.0)
+    o_ref = p @ vr
+    got = out.float().cpu().view(B, Lq, H, hs).permute(0, 2, 1, 3)
+    sel = valid_q[..., None].expand_as(o_ref)
+    close(got[sel], o_ref.detach()[sel], 1.5e-2, "tail attention forward")
+    lse_ref = torch.logsumexp(s, -1)
+    assert (lse.float().cpu().view(B, H, Lq)[valid_q] - lse_ref.detach()[valid_q]).abs().max().item() < 2e-2
+    dor = do.float().view(B, Lq, H, hs).permute(0, 2, 1, 3) * valid_q[..., None]
+    (o_ref * dor).sum().backward()
+    dq = torch.empty_like(q).to(dev)
+    dkv = torch.empty_like(kv).to(dev)
+    do_dev = (dor.permute(0, 2, 1, 3).reshape(B * Lq, H * hs)).to(bf16).to(dev)
+    ops.flash_attn_tail_bwd(q.to(dev), kv.to(dev), out, do_dev, lse, dq, dkv, B, Lq, Lk, H, hs, alpha, kv_len=kv_len.to(dev) if ragged else None)
+    dq_ref = qr.grad.permute(0, 2, 1, 3).reshape(B * Lq, H * hs)
+    dk_ref = kr.grad.permute(0, 2, 1, 3).reshape(B * Lk, H * hs)
+    dv_ref = vr.grad.permute(0, 2, 1, 3).reshape(B * Lk, H * hs)
+    vq = valid_q.permute(0, 2, 1).reshape(B * Lq, H)[..., None].expand(-1, -1, hs).reshape(B * Lq, H * hs)
+    close(dq.float().cpu()[vq], dq_ref[vq], 2.5e-2, "tail attention dq")
+    close(dkv.float().cpu()[:, :H * hs], dk_ref, 2.5e-2, "tail attention dk")
+    close(dkv.float().cpu()[:, H * hs:], dv_ref, 2.5e-2, "tail attention dv")
