@@ -307,7 +307,7 @@ def test_last_layer_tail_equals_the_full_last_layer(dev):
     for n, gf in res[False][2].items():
         gt = res[True][2][n]
         a, b = gt.flatten().double(), gf.flatten().double()
-        if float(b.norm()) < 1e-9:
+        if float(b.norm()) < 1e-9 or n.endswith("k_proj.bias"):  # (a key bias shifts every score of a row alike: its gradient is pure rounding noise)
             continue
         cos = float(torch.nn.functional.cosine_similarity(a, b, dim=0))
         assert cos > 0.995 and abs(float(a.norm() / b.norm()) - 1.0) < 2e-2, (n, cos, float(a.norm() / b.norm()))
