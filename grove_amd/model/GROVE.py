@@ -123,7 +123,7 @@ class GROVEForCausalLM(torch.nn.Module):
         self.config.out_dim = d.out_dim
         self.literal_T = kwargs.get("literal_T", False)
         # last LLaMA layer on the rows a training step reads only (labelled + [DET] rows: the answer's tail); False = every row (A/B, tests)
-        self.llama_tail = kwargs.get("llama_tail", True)
+        self.llama_tail = kwargs.get("llama_tail", __import__("os").environ.get("GROVE_LLAMA_TAIL", "1") != "0")  # (env: whole-program A/B arm)
         # dense positional encoding dtype: bf16 reproduces the reference under model.to(bf16) (quirk Q10)
         self.pe_dtype = kwargs.get("pe_dtype", torch.bfloat16)
         self.stream_dtype = kwargs.get("stream_dtype", None)  # None: fp32 for inference models, bf16 for training models
