@@ -384,6 +384,20 @@ __global__ __launch_bounds__(NTHR) void flash_delta_kernel(const grove_flash_att
   if (t < n && l16 == 0) p.delta[t] = acc;
 }
 
+// Inverse rotate-half RoPE on a lane's accumulators (backward kernels' epilogues; grove_flash_attn_params.rope): the lane holds dims
+// dt * 16 + 4 g + r (r = 0..3) of ONE row for every 16-wide tile dt, i.e. both halves (dt and dt + DT / 2) of its rotation pairs.
+template <int HS>
+__device__ __forceinline__ void rope_inverse_acc(f32x4_t (&a)[HS / 16], const float* __restrict__ cs_row, int g) {
+  constexpr int DT = HS / 16;
+#pragma unroll
+  for (int dt = 0; dt < DT / 2; ++dt) {
+    const f32x4_t c = *(const f32x4_t*)(cs_row + dt * 16 + g * 4), s = *(const f32x4_t*)(cs_row + HS / 2 + dt * 16 + g * 4);
+    const f32x4_t y1 = a[dt], y2 = a[dt + DT / 2];
+    a[dt] = y1 * c + y2 * s;
+    a[dt + DT / 2] = y2 * c - y1 * s;
+  }
+}
+
 // ================================================================================ backward: dK, dV
 // block = 128 keys (wave = 32 keys, K/V fragments in registers); loops over 64-query tiles of Q and dO in LDS.
 template <int HS, int NRK>
@@ -566,6 +580,7 @@ __global__ __launch_bounds__(NTHR, (HS <= 96 ? 2 : 1)) void flash_bwd_dkv_kernel
   for (int nj = 0; nj < 2; ++nj) {
     const int kj = k0 + nj * 16 + fr;
     if (kj >= p.Lk) continue;
+    if (p.rope) rope_inverse_acc<HS>(dk[nj], p.rope + (int64_t)kj * HS, g);  // key j sits at position j
 #pragma unroll
     for (int dt = 0; dt < C::DT; ++dt) {
       const f32x4_t a = dk[nj][dt], c = dv[nj][dt];
@@ -736,6 +751,7 @@ __global__ __launch_bounds__(NTHR, 2) void flash_bwd_dq_kernel(const grove_flash
   for (int mi = 0; mi < 2; ++mi) {
     const int qi = q0 + mi * 16 + fr;
     if (qi >= p.Lq) continue;
+    if (p.rope) rope_inverse_acc<HS>(dq[mi], p.rope + (int64_t)(qi + p.Lk - p.Lq) * HS, g);  // query i sits at position i + Lk - Lq
 #pragma unroll
     for (int dt = 0; dt < C::DT; ++dt) {
       const f32x4_t o = dq[mi][dt];
@@ -828,10 +844,12 @@ extern "C" int grove_flash_attn_bwd(const grove_flash_attn_params* p, void* stre
   if (rc) return rc;
   GROVE_CHECK(p->o && p->d_o && p->lse && p->delta && p->dq && p->dk && p->dv, GROVE_E_SHAPE, "flash_attn_bwd: o, d_o, lse, delta, dq, dk, dv required");
   GROVE_CHECK(!p->drel || p->rel, GROVE_E_SHAPE, "flash_attn_bwd: drel needs rel");
+  GROVE_CHECK(!p->rope || (!p->q_valid && !p->o_map && ((uintptr_t)p->rope & 15) == 0), GROVE_E_SHAPE,
+              "flash_attn_bwd: rope (fused inverse RoPE) is a general-kernel feature with a 16-byte aligned table");
   hipStream_t s = (hipStream_t)stream;
   GROVE_CHECK(!p->o_map || (g_win_attn && grove_win_attn_applicable(p) && p->q_valid && p->ld_do % 8 == 0), GROVE_E_SHAPE,
               "flash_attn_bwd: o_map (token-order o / d_o) is a window-kernel feature and needs q_valid");
-  const bool win = g_win_attn && grove_win_attn_applicable(p) && p->ld_do % 8 == 0 && p->ld_dq % 4 == 0 && p->ld_dk % 4 == 0 && p->ld_dv % 4 == 0 &&
+  const bool win = g_win_attn && !p->rope && grove_win_attn_applicable(p) && p->ld_do % 8 == 0 && p->ld_dq % 4 == 0 && p->ld_dk % 4 == 0 && p->ld_dv % 4 == 0 &&
                    ((uintptr_t)p->d_o & 15) == 0 && ((uintptr_t)p->o & 15) == 0;
   GROVE_CHECK(!(p->q_valid || p->pad_k || p->pad_v) || win, GROVE_E_SHAPE,
               "flash_attn_bwd: q_valid / pad_k / pad_v are window-kernel features, but this problem does not take the window kernels "

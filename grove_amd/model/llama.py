@@ -76,6 +76,15 @@ class LlamaStack:
             ops.linear(h, L["wq"], a_idx=precise_rows, c_idx=precise_rows, M=int(precise_rows.numel()), out=qkv[:, :H])
         return qkv
 
+    fuse_rope_bwd = __import__("os").environ.get("GROVE_FUSE_ROPE_BWD", "1") != "0"  # inverse RoPE inside the attention backward kernels (A/B knob)
+
+    def _rope_table(self, S):
+        """cos | sin of positions 0 .. S-1 (f32 [>= S, head_dim], ops.rope_table), grown on demand."""
+        t = getattr(self, "_rope_cs", None)
+        if t is None or t.shape[0] < S:
+            t = self._rope_cs = ops.rope_table(self.d.head_dim, self.d.rope_theta, max(S, 1024), self.dev)
+        return t
+
     def _tail_index(self, B, S, s0):
         """int32 rows b*S + s0 + j (the last S - s0 positions of every sequence) and their positions (cached per geometry)."""
         key = (B, S, s0)
@@ -137,9 +146,12 @@ class LlamaStack:
         do = ops.linear(dx_t, L["wo_t"])
         dq_t = torch.empty_like(q_t)
         dkv = torch.empty_like(kv)
-        ops.flash_attn_tail_bwd(q_t, kv, o_t, do, lse, dq_t, dkv, B, Lq, S, nh, hd, hd ** -0.5, kv_len=kv_len)
-        ops.rope_(dq_t, pos_t, 0, nh, hd, d.rope_theta, inverse=True)
-        ops.rope_(dkv, pos, 0, nh, hd, d.rope_theta, inverse=True)
+        if self.fuse_rope_bwd:
+            ops.flash_attn_tail_bwd(q_t, kv, o_t, do, lse, dq_t, dkv, B, Lq, S, nh, hd, hd ** -0.5, kv_len=kv_len, rope=self._rope_table(S))
+        else:
+            ops.flash_attn_tail_bwd(q_t, kv, o_t, do, lse, dq_t, dkv, B, Lq, S, nh, hd, hd ** -0.5, kv_len=kv_len)
+            ops.rope_(dq_t, pos_t, 0, nh, hd, d.rope_theta, inverse=True)
+            ops.rope_(dkv, pos, 0, nh, hd, d.rope_theta, inverse=True)
         wt = L["wqkv_t"]                                        # [H, 3H]: W^T of the fused projection (K-major for the dgrad)
         dh = ops.linear(dkv, wt[:, H:])                          # all rows: d (k | v) . W_kv
         dh_t = ops.linear(dq_t, wt[:, :H])                       # tail rows: d q . W_q
@@ -355,8 +367,11 @@ class LlamaStack:
             # x1 = x + o_proj(attn(rope(qkv(rms(x)))))
             do = ops.linear(dx, L["wo_t"])                      # [B*S, H]
             dqkv = torch.empty_like(qkv)
-            attention_bwd(actx, qkv, do, dqkv)
-            ops.rope_(dqkv, pos, 0, 2 * nh, hd, d.rope_theta, inverse=True)
+            if actx.flash and self.fuse_rope_bwd:  # dq / dk come back un-rotated from the two backward kernels' epilogues
+                attention_bwd(actx, qkv, do, dqkv, rope=self._rope_table(S))
+            else:
+                attention_bwd(actx, qkv, do, dqkv)
+                ops.rope_(dqkv, pos, 0, 2 * nh, hd, d.rope_theta, inverse=True)
             dh = ops.linear(dqkv, L["wqkv_t"])
             del dqkv, do
             ops.rmsnorm_bwd(x, L["ln1"], dh, d.rms_eps, dx=dx, accumulate=True)     # dx now d x

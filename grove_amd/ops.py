@@ -452,8 +452,16 @@ def flash_attn_kv(q, k, v, B, H, Lq, Lk, hs, alpha, *, sq, sk, sv, ld_q, ld_k, l
     _lib.check(_lib.lib().grove_flash_attn_fwd(C.byref(p), _stream()), "grove_flash_attn_fwd")
     return out
 
+def rope_table(hd, theta, positions, device):
+    """f32 [positions, hd] = cos[hd / 2] | sin[hd / 2] of the rotate-half RoPE angles pos * theta^(-2 i / hd) (HF LlamaRotaryEmbedding:
+    inv_freq in fp32, angles in fp32): the table the backward attention kernels un-rotate dq / dk with (grove_flash_attn_params.rope)."""
+    inv_freq = 1.0 / (theta ** (torch.arange(0, hd, 2, dtype=torch.float32, device=device) / hd))
+    ang = torch.arange(positions, dtype=torch.float32, device=device)[:, None] * inv_freq[None]
+    return torch.cat([torch.cos(ang), torch.sin(ang)], 1).contiguous()
+
+
 def flash_attn_bwd(qkv, out, d_out, lse, dqkv, B, L, H, hs, q_off, k_off, v_off, alpha, *, causal=False, kv_len=None, rel=None,
-                   rel_hw=(0, 0), want_drel=False, hs_valid=0, q_valid=None, pad_row=None, o_map=None):
+                   rel_hw=(0, 0), want_drel=False, hs_valid=0, q_valid=None, pad_row=None, o_map=None, rope=None):
     dev = qkv.device
     ld, ldd = qkv.stride(0), dqkv.stride(0)
     delta = torch.empty((B * H, L), dtype=torch.float32, device=dev)
@@ -479,6 +487,9 @@ def flash_attn_bwd(qkv, out, d_out, lse, dqkv, B, L, H, hs, q_off, k_off, v_off,
     if pad_row is not None:
         assert q_valid is not None and pad_row.numel() == qkv.shape[1]
         p.pad_k, p.pad_v = _p(pad_row.view(-1)[k_off:]), _p(pad_row.view(-1)[v_off:])
+    if rope is not None:  # fused inverse RoPE of dq / dk: f32 [>= L, hs]
+        assert rope.dtype == torch.float32 and rope.shape[1] == hs and rope.shape[0] >= L and rope.is_contiguous()
+        p.rope = _p(rope)
     _lib.check(_lib.lib().grove_flash_attn_bwd(C.byref(p), _stream()), "grove_flash_attn_bwd")
     return drel
 
@@ -501,8 +512,9 @@ def flash_attn_tail(q, kv, B, Lq, Lk, H, hs, alpha, *, kv_len=None, want_lse=Fal
     return out, lse
 
 
-def flash_attn_tail_bwd(q, kv, out, d_out, lse, dq, dkv, B, Lq, Lk, H, hs, alpha, *, kv_len=None):
-    """Backward of flash_attn_tail: dq [B*Lq, >= H*hs] and dkv [B*Lk, >= 2*H*hs] (d keys | d values) are overwritten."""
+def flash_attn_tail_bwd(q, kv, out, d_out, lse, dq, dkv, B, Lq, Lk, H, hs, alpha, *, kv_len=None, rope=None):
+    """Backward of flash_attn_tail: dq [B*Lq, >= H*hs] and dkv [B*Lk, >= 2*H*hs] (d keys | d values) are overwritten.
+    rope (f32 [>= Lk, hs], ops.rope_table): dq / dk leave the kernels un-rotated (fused inverse RoPE)."""
     dev = q.device
     delta = torch.empty((B * H, Lq), dtype=torch.float32, device=dev)
     p = _lib.FlashAttnParams()
@@ -517,6 +529,9 @@ def flash_attn_tail_bwd(q, kv, out, d_out, lse, dq, dkv, B, Lq, Lk, H, hs, alpha
     p.ld_o, p.ld_do = out.stride(0), d_out.stride(0)
     p.ld_dq, p.ld_dk, p.ld_dv = dq.stride(0), dkv.stride(0), dkv.stride(0)
     p.causal, p.alpha = 1, alpha
+    if rope is not None:
+        assert rope.dtype == torch.float32 and rope.shape[1] == hs and rope.shape[0] >= Lk and rope.is_contiguous()
+        p.rope = _p(rope)
     _lib.check(_lib.lib().grove_flash_attn_bwd(C.byref(p), _stream()), "grove_flash_attn_bwd")
 
 

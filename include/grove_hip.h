@@ -379,6 +379,12 @@ typedef struct grove_flash_attn_params {
   const void* pad_k; const void* pad_v; /* with q_valid, window kernels only: bf16 rows [H*hs] = k / v of a padded position (a zero token's
                        projection = the bias), or NULL. Given, the k / v rows at padded positions are NOT read (the caller need not
                        fill them) and dk / dv there are NOT written */
+  const float* rope; /* backward, general kernels only (round 4): f32 [positions, hs] = cos[hs / 2] | sin[hs / 2] per position, or NULL.
+                       Given, q and k are the ROTATED tensors (rotate-half RoPE, HF apply_rotary_pos_emb) and dq / dk leave the kernels
+                       already rotated BACK to the un-rotated projections' gradients: dx1 = dy1 cos + dy2 sin, dx2 = dy2 cos - dy1 sin on
+                       the halves of every head, in the epilogues of the two backward kernels (a lane holds both halves of its dims) — the
+                       separate inverse-RoPE pass over dq | dk (46 MB read + written per LLaMA layer) is gone. Query i sits at position
+                       i + Lk - Lq (the causal mask's alignment), key j at position j. */
 } grove_flash_attn_params;
 int grove_flash_attn_fwd(const grove_flash_attn_params* p, void* stream);
 int grove_flash_attn_bwd(const grove_flash_attn_params* p, void* stream);

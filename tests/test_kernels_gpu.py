@@ -1548,3 +1548,31 @@ def test_flash_attention_tail_queries(dev, B, H, hs, Lq, Lk, ragged):
     close(dq.float().cpu()[vq], dq_ref[vq], 2.5e-2, "tail attention dq")
     close(dkv.float().cpu()[:, :H * hs], dk_ref, 2.5e-2, "tail attention dk")
     close(dkv.float().cpu()[:, H * hs:], dv_ref, 2.5e-2, "tail attention dv")
+
+
+@pytest.mark.parametrize("B,H,hs,L", [(2, 4, 128, 703), (2, 2, 64, 200), (1, 4, 32, 130)])
+def test_flash_attention_bwd_fused_inverse_rope(dev, B, H, hs, L):
+    """Round 4: the inverse RoPE of dq | dk inside the epilogues of the two backward kernels (grove_flash_attn_params.rope) against the
+    unfused sequence (backward, then grove_rope_inplace(inverse)): the fused form rotates the fp32 accumulators before the one bf16
+    rounding, the unfused one rounds, rotates and rounds again — equal to bf16 rounding; dv is untouched (bit-identical)."""
+    from grove_amd import ops
+    theta = 10000.0
+    g = torch.Generator().manual_seed(9)
+    qkv = (torch.randn(B * L, 3 * H * hs, generator=g) * 0.6).to(bf16).to(dev)
+    pos = torch.arange(L, dtype=torch.int32).repeat(B).to(dev)
+    ops.rope_(qkv, pos, 0, 2 * H, hs, theta)                      # q | k rotated, as the forward leaves them
+    do = torch.randn(B * L, H * hs, generator=g).to(bf16).to(dev)
+    alpha = hs ** -0.5
+    out, lse = ops.flash_attn(qkv, B, L, H, hs, 0, H * hs, 2 * H * hs, alpha, causal=True, want_lse=True)
+    ref = torch.empty_like(qkv)
+    ops.flash_attn_bwd(qkv, out, do, lse, ref, B, L, H, hs, 0, H * hs, 2 * H * hs, alpha, causal=True)
+    ops.rope_(ref, pos, 0, 2 * H, hs, theta, inverse=True)
+    got = torch.empty_like(qkv)
+    table = ops.rope_table(hs, theta, L + 5, dev)
+    ops.flash_attn_bwd(qkv, out, do, lse, got, B, L, H, hs, 0, H * hs, 2 * H * hs, alpha, causal=True, rope=table)
+    assert torch.equal(got[:, 2 * H * hs:], ref[:, 2 * H * hs:])   # dv
+    close(got[:, :2 * H * hs], ref[:, :2 * H * hs], 2 ** -6, "fused inverse RoPE of dq | dk")
+    # the table is HF's: cos / sin of pos * theta^(-2 i / hd) in fp32
+    inv = 1.0 / (theta ** (torch.arange(0, hs, 2, dtype=torch.float32) / hs))
+    ang = torch.arange(L + 5, dtype=torch.float32)[:, None] * inv[None]
+    assert (table.cpu() - torch.cat([ang.cos(), ang.sin()], 1)).abs().max().item() < 1e-5
