@@ -1575,4 +1575,5 @@ def test_flash_attention_bwd_fused_inverse_rope(dev, B, H, hs, L):
     # the table is HF's: cos / sin of pos * theta^(-2 i / hd) in fp32
     inv = 1.0 / (theta ** (torch.arange(0, hs, 2, dtype=torch.float32) / hs))
     ang = torch.arange(L + 5, dtype=torch.float32)[:, None] * inv[None]
-    assert (table.cpu() - torch.cat([ang.cos(), ang.sin()], 1)).abs().max().item() < 1e-5
+    # (fp32 angles up to ~700 rad: the device's argument reduction and the host's differ by ~1e-4 there; bf16 rounds at 4e-3)
+    assert (table.cpu() - torch.cat([ang.cos(), ang.sin()], 1)).abs().max().item() < 1e-3
