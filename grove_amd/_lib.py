@@ -73,7 +73,7 @@ class RelBiasParams(C.Structure):
 
 class RopeParams(C.Structure):
     _fields_ = [("x", c_vp), ("pos", c_vp), ("rows", c_i32), ("ld", c_i32), ("col0", c_i32), ("nheads", c_i32),
-                ("hd", c_i32), ("inverse", c_i32), ("theta", c_f32)]
+                ("hd", c_i32), ("inverse", c_i32), ("theta", c_f32), ("table", c_vp)]
 
 
 class RowsParams(C.Structure):

@@ -198,11 +198,21 @@ __global__ __launch_bounds__(256) void rope_vec_kernel(const grove_rope_params p
   const int row = (int)(t / ((int64_t)cph * ngroups));
   const float pos = (float)p.pos[row];
   float cs[8], sn[8];
+  if (p.table) {  // cos | sin of this position from the caller's table (two 32-byte reads instead of 8 x (powf + sincosf))
+    const float* t = p.table + (int64_t)p.pos[row] * p.hd + c * 8;
+    const f32x4_t c0 = *(const f32x4_t*)t, c1 = *(const f32x4_t*)(t + 4), s0 = *(const f32x4_t*)(t + half), s1 = *(const f32x4_t*)(t + half + 4);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const float inv_freq = powf(p.theta, -2.f * (float)(c * 8 + j) / (float)p.hd);
-    sincosf(pos * inv_freq, &sn[j], &cs[j]);
-    if (p.inverse) sn[j] = -sn[j];
+    for (int j = 0; j < 4; ++j) {
+      cs[j] = c0[j], cs[4 + j] = c1[j];
+      sn[j] = p.inverse ? -s0[j] : s0[j], sn[4 + j] = p.inverse ? -s1[j] : s1[j];
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float inv_freq = powf(p.theta, -2.f * (float)(c * 8 + j) / (float)p.hd);
+      sincosf(pos * inv_freq, &sn[j], &cs[j]);
+      if (p.inverse) sn[j] = -sn[j];
+    }
   }
   const int h0 = hg * ROPE_HG, h1 = min(p.nheads, h0 + ROPE_HG);
   bf16_raw* x = (bf16_raw*)p.x + (int64_t)row * p.ld + p.col0 + (int64_t)h0 * p.hd + c * 8;
@@ -302,6 +312,7 @@ extern "C" int grove_relpos_bwd(const grove_relpos_params* p, void* stream) {
 extern "C" int grove_rope_inplace(const grove_rope_params* p, void* stream) {
   GROVE_CHECK(p && p->rows > 0 && p->nheads > 0 && p->hd > 0 && (p->hd & 1) == 0, GROVE_E_SHAPE, "rope: bad shape");
   const bool vec = (p->hd % 16 == 0) && (p->ld % 8 == 0) && (p->col0 % 8 == 0) && (((uintptr_t)p->x & 15) == 0);
+  GROVE_CHECK(!p->table || (vec && ((uintptr_t)p->table & 15) == 0), GROVE_E_ALIGN, "rope: the cos | sin table needs the vector kernel (hd % 16 == 0, aligned x) and 16-byte alignment");
   if (vec) {
     const int64_t nv = (int64_t)p->rows * ((p->nheads + ROPE_HG - 1) / ROPE_HG) * (p->hd / 16);
     hipLaunchKernelGGL(rope_vec_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *p);

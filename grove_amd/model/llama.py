@@ -77,6 +77,7 @@ class LlamaStack:
         return qkv
 
     fuse_rope_bwd = __import__("os").environ.get("GROVE_FUSE_ROPE_BWD", "1") != "0"  # inverse RoPE inside the attention backward kernels (A/B knob)
+    rope_from_table = __import__("os").environ.get("GROVE_ROPE_TABLE", "1") != "0"   # forward RoPE reads cos | sin from the table (A/B knob)
 
     def _rope_table(self, S):
         """cos | sin of positions 0 .. S-1 (f32 [>= S, head_dim], ops.rope_table), grown on demand."""
@@ -109,14 +110,15 @@ class LlamaStack:
         pos = torch.arange(S, dtype=torch.int32, device=self.dev).repeat(B)
         h = ops.rmsnorm(x, L["ln1"], d.rms_eps)
         kv = ops.linear(h, L["wqkv"][H:])                       # k | v of all rows
-        ops.rope_(kv, pos, 0, nh, hd, d.rope_theta)              # (keys only: the first nh heads of the k | v activation)
+        rope_tab = self._rope_table(S) if (self.rope_from_table and hd % 16 == 0) else None
+        ops.rope_(kv, pos, 0, nh, hd, d.rope_theta, table=rope_tab)  # (keys only: the first nh heads of the k | v activation)
         n_t = B * Lq
         x_t = torch.empty((n_t, H), dtype=torch.bfloat16, device=self.dev)
         h_t = torch.empty((n_t, H), dtype=torch.bfloat16, device=self.dev)
         ops.copy_rows(x, x_t, n_t, H, idx_src=tail_idx)
         ops.copy_rows(h, h_t, n_t, H, idx_src=tail_idx)
         q_t = ops.linear(h_t, L["wqkv"][:H])
-        ops.rope_(q_t, pos_t, 0, nh, hd, d.rope_theta)
+        ops.rope_(q_t, pos_t, 0, nh, hd, d.rope_theta, table=rope_tab)
         o_t, lse = ops.flash_attn_tail(q_t, kv, B, Lq, S, nh, hd, hd ** -0.5, kv_len=kv_len, want_lse=save)
         x1_t = ops.linear(o_t, L["wo"], residual=x_t)
         h2_t = ops.rmsnorm(x1_t, L["ln2"], d.rms_eps)
@@ -181,6 +183,7 @@ class LlamaStack:
         res = ops.to_f32(x) if f32 else None
         t = None  # fp32 stream: branch output not yet added to the stream
         use_tail = tail_start is not None and tail_start > 0 and not f32 and not self.fp8 and kv_cache is None
+        rope_tab = self._rope_table(S) if (self.rope_from_table and hd % 16 == 0) else None  # cos | sin read, not evaluated per thread
         for li, L in enumerate(self.layers):
             if use_tail and li == len(self.layers) - 1:
                 x, sv = self._last_layer_tail(L, x, B, S, tail_start, kv_len, save)
@@ -194,7 +197,7 @@ class LlamaStack:
                 xb = x
                 h = ops.rmsnorm(x, L["ln1"], d.rms_eps)
             qkv = self._qkv(L, h, pr) if self.fp8 else ops.linear(h, L["wqkv"])
-            ops.rope_(qkv, pos, 0, 2 * nh, hd, d.rope_theta)
+            ops.rope_(qkv, pos, 0, 2 * nh, hd, d.rope_theta, table=rope_tab)
             if kv_cache is not None:
                 kv_cache[li][:, :, :, :S].copy_(qkv.view(B, S, 3, nh, hd)[:, :, 1:].permute(0, 2, 3, 1, 4))  # (a strided copy: layout only)
             o, actx = attention_fwd(qkv, B, S, nh, hd, 0, H, 2 * H, hd ** -0.5, causal=True, kv_len=kv_len, save=save)

@@ -584,9 +584,13 @@ def relpos(q, Rh, Rw, batch, heads, qhw, khw, hd, hd_stride, ld_q, *, rel=None, 
     return rel
 
 
-def rope_(x, pos, col0, nheads, hd, theta, inverse=False):
+def rope_(x, pos, col0, nheads, hd, theta, inverse=False, table=None):
+    """table (ops.rope_table, f32 [positions, hd]): read cos | sin instead of evaluating them per thread."""
     p = _lib.RopeParams()
     p.x, p.pos = _p(x), _p(pos)
+    if table is not None:
+        assert table.dtype == torch.float32 and table.shape[1] == hd and table.is_contiguous()
+        p.table = _p(table)
     p.rows, p.ld, p.col0, p.nheads, p.hd = x.shape[0], x.stride(0), col0, nheads, hd
     p.inverse, p.theta = int(inverse), theta
     _lib.check(_lib.lib().grove_rope_inplace(C.byref(p), _stream()), "grove_rope_inplace")

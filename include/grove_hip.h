@@ -437,6 +437,9 @@ typedef struct grove_rope_params {
   int32_t rows, ld, col0, nheads, hd;
   int32_t inverse;
   float theta;
+  const float* table; /* round 4: f32 [positions, hd] = cos[hd / 2] | sin[hd / 2] per position (the table of grove_flash_attn_params.rope), or
+                         NULL. Given (vector kernel: hd % 16 == 0), the angles are read from it instead of evaluating powf + sincosf eight
+                         times per thread: the pass becomes a plain HBM stream. 16-byte aligned, at least max(pos) + 1 rows. */
 } grove_rope_params;
 int grove_rope_inplace(const grove_rope_params* p, void* stream);
 

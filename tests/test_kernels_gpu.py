@@ -1577,3 +1577,20 @@ def test_flash_attention_bwd_fused_inverse_rope(dev, B, H, hs, L):
     ang = torch.arange(L + 5, dtype=torch.float32)[:, None] * inv[None]
     # (fp32 angles up to ~700 rad: the device's argument reduction and the host's differ by ~1e-4 there; bf16 rounds at 4e-3)
     assert (table.cpu() - torch.cat([ang.cos(), ang.sin()], 1)).abs().max().item() < 1e-3
+
+
+def test_rope_from_table_matches_evaluated_rope(dev):
+    """grove_rope_inplace with the cos | sin table (round 4: two 32-byte reads per thread instead of 8 x (powf + sincosf)) against the
+    evaluated form, forward and inverse: equal to bf16 rounding (the angles differ by fp32 argument-reduction noise only)."""
+    from grove_amd import ops
+    rows, H, hd, theta = 1406, 8, 128, 10000.0
+    x = rnd(rows, 3 * H * hd, seed=41).to(dev)
+    pos = (torch.arange(rows, dtype=torch.int32) % 703).to(dev)
+    table = ops.rope_table(hd, theta, 703, dev)
+    for inv in (False, True):
+        a, b = x.clone(), x.clone()
+        ops.rope_(a, pos, 0, 2 * H, hd, theta, inverse=inv)
+        ops.rope_(b, pos, 0, 2 * H, hd, theta, inverse=inv, table=table)
+        assert torch.equal(a[:, 2 * H * hd:], b[:, 2 * H * hd:])          # v untouched
+        assert (a.float() - b.float()).abs().max().item() <= 2 ** -7 * a.float().abs().max().item()
+        assert float((a != b).float().mean()) < 0.02                        # all but a few elements round identically
