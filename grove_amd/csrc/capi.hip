@@ -3,6 +3,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 
 static thread_local char g_err[512] = "";
 
@@ -12,6 +13,26 @@ void grove_set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+
+// deterministic mode: see common.h (det_wait / det_pass). The ticket ring is CALLER-OWNED like every other workspace (zeroed unsigned
+// words on the device the caller launches on; one process drives one GPU): a launch takes the next ticket and its last block puts the 0
+// back, so a ticket is reused only `n` ticketed launches later.
+static std::atomic<unsigned*> g_det_ring{nullptr};
+static std::atomic<unsigned> g_det_n{0}, g_det_next{0};
+bool grove_det_on() { return g_det_ring.load(std::memory_order_relaxed) != nullptr; }
+unsigned* grove_det_ticket() {
+  unsigned* ring = g_det_ring.load(std::memory_order_relaxed);
+  if (!ring) return nullptr;
+  return ring + g_det_next.fetch_add(1, std::memory_order_relaxed) % g_det_n.load(std::memory_order_relaxed);
+}
+extern "C" int grove_set_deterministic(void* tickets, int32_t n) {
+  GROVE_CHECK(!tickets || n >= 64, GROVE_E_SHAPE, "set_deterministic: the ticket ring needs at least 64 zeroed words");
+  g_det_ring.store(nullptr);
+  g_det_n.store(tickets ? (unsigned)n : 0u);
+  g_det_ring.store((unsigned*)tickets);
+  return GROVE_OK;
+}
+extern "C" int grove_deterministic(void) { return grove_det_on() ? 1 : 0; }
 
 extern "C" int grove_version(void) { return 1; }
 

@@ -152,6 +152,42 @@ __device__ __forceinline__ void act_apply_grad(int act, float x, float& y, float
   }
 }
 
+// ---------------------------------------------------------------- deterministic mode (grove_set_deterministic)
+// fp32 atomics make a sum depend on the order the blocks arrive in. In deterministic mode every kernel that adds to global memory
+// is handed a TICKET (a zeroed unsigned from a device ring, capi.hip): block b waits until the ticket reads b, adds, and passes b + 1
+// on (the last block puts the 0 back). Blocks are dispatched in linear-id order — per XCD in order too — so the lowest block that
+// has not passed yet is always resident or next to be dispatched: the wait cannot deadlock, and only the add phase is serialised.
+// With the ticket null (the default) each helper is a single uniform branch.
+__device__ __forceinline__ unsigned det_block_id() { return (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x; }
+__device__ __forceinline__ unsigned det_block_count() { return gridDim.x * gridDim.y * gridDim.z; }
+// one thread of the block does all of its adds
+__device__ __forceinline__ void det_wait(unsigned* t) {
+  if (!t) return;
+  const unsigned turn = det_block_id();
+  while (__hip_atomic_load(t, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != turn) __builtin_amdgcn_s_sleep(2);
+}
+__device__ __forceinline__ void det_pass(unsigned* t) {
+  if (!t) return;
+  const unsigned turn = det_block_id();
+  __threadfence();
+  __hip_atomic_store(t, turn + 1 == det_block_count() ? 0u : turn + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+// every thread of the block adds (each address at most once per block, or always from the same thread): call from ALL threads
+__device__ __forceinline__ void det_block_enter(unsigned* t) {
+  if (!t) return;
+  if (threadIdx.x == 0 && threadIdx.y == 0) det_wait(t);
+  __syncthreads();
+}
+__device__ __forceinline__ void det_block_leave(unsigned* t) {
+  if (!t) return;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0 && threadIdx.y == 0) det_pass(t);
+}
+// host: the mode, and the ticket of one launch (nullptr when the mode is off)
+bool grove_det_on();
+unsigned* grove_det_ticket();
+
 // error plumbing (host)
 void grove_set_error(const char* fmt, ...);
 #define GROVE_CHECK(cond, code, ...)         \

@@ -183,6 +183,23 @@ __global__ __launch_bounds__(EB) void scatter_add_f32src_kernel(const float* __r
   }
 }
 
+// Deterministic mode: one thread per destination column walks the source rows IN ORDER (plain read-modify-write: the only writer
+// of its column) — the serial definition of index_add. rows x C / 256 threads is a fraction of the chip; it is a debug mode.
+template <typename SRC>
+__global__ __launch_bounds__(EB) void scatter_add_det_kernel(const SRC* __restrict__ src, float* __restrict__ dst, const int32_t* __restrict__ idx, int rows,
+                                                             int C, int ld_src, int ld_dst) {
+  const int c = blockIdx.x * EB + threadIdx.x;
+  if (c >= C) return;
+  for (int r = 0; r < rows; ++r) {
+    const int d = idx ? idx[r] : r;
+    if (d < 0) continue;
+    float v;
+    if constexpr (sizeof(SRC) == 2) v = bf2f(src[(int64_t)r * ld_src + c]);
+    else v = src[(int64_t)r * ld_src + c];
+    dst[(int64_t)d * ld_dst + c] += v;
+  }
+}
+
 // column sums: block (64 column-pairs x 4 row lanes); each thread sums 2 adjacent columns over a
 // row slice, LDS-combine the 4 row lanes, one atomic per column per block.
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16_raw* __restrict__ x, float* __restrict__ out, int rows, int C, int ld, int rows_per_block) {
@@ -236,7 +253,7 @@ __global__ __launch_bounds__(EB) void cast_b2f_kernel(const bf16_raw* __restrict
 
 // out += f(scale) * sum_i a[i] * b[i]   (bf16 inputs, fp32 accumulate); mode 1: f = 1 - tanh(s)^2
 __global__ __launch_bounds__(EB) void dot_kernel(const bf16_raw* __restrict__ a, const bf16_raw* __restrict__ b, float* __restrict__ out, int64_t nvec,
-                                                 const float* __restrict__ scale_ptr, int mode) {
+                                                 const float* __restrict__ scale_ptr, int mode, unsigned* det) {
   __shared__ float scratch[4];
   float s = 0.f;
   for (int64_t t = (int64_t)blockIdx.x * EB + threadIdx.x; t < nvec; t += (int64_t)gridDim.x * EB) {
@@ -255,7 +272,9 @@ __global__ __launch_bounds__(EB) void dot_kernel(const bf16_raw* __restrict__ a,
       else if (mode == 2) f = tanhf(v);
       else f = v;
     }
+    det_wait(det);
     atomicAdd(out, s * f);
+    det_pass(det);
   }
 }
 
@@ -358,6 +377,12 @@ extern "C" int grove_copy_rows(const grove_rows_params* p, void* stream) {
 extern "C" int grove_scatter_add_f32(const void* src, float* dst, const int32_t* idx, int32_t rows, int32_t C, int32_t ld_src, int32_t ld_dst,
                                      void* stream) {
   GROVE_CHECK(rows > 0 && C > 0 && C % 2 == 0 && ld_src % 2 == 0, GROVE_E_SHAPE, "scatter_add: bad shape");
+  if (grove_det_on()) {
+    hipLaunchKernelGGL(scatter_add_det_kernel<bf16_raw>, dim3((C + EB - 1) / EB), dim3(EB), 0, (hipStream_t)stream, (const bf16_raw*)src, dst, idx, rows, C,
+                       ld_src, ld_dst);
+    GROVE_LAUNCH_CHECK();
+    return GROVE_OK;
+  }
   hipLaunchKernelGGL(scatter_add_kernel, grid_for((int64_t)rows * (C / 2)), dim3(EB), 0, (hipStream_t)stream, (const bf16_raw*)src, dst, idx, rows, C,
                      ld_src, ld_dst);
   GROVE_LAUNCH_CHECK();
@@ -366,6 +391,11 @@ extern "C" int grove_scatter_add_f32(const void* src, float* dst, const int32_t*
 extern "C" int grove_scatter_add_rows_f32(const float* src, float* dst, const int32_t* idx, int32_t rows, int32_t C, int32_t ld_src, int32_t ld_dst,
                                           void* stream) {
   GROVE_CHECK(rows > 0 && C > 0, GROVE_E_SHAPE, "scatter_add_rows_f32: bad shape");
+  if (grove_det_on()) {
+    hipLaunchKernelGGL(scatter_add_det_kernel<float>, dim3((C + EB - 1) / EB), dim3(EB), 0, (hipStream_t)stream, src, dst, idx, rows, C, ld_src, ld_dst);
+    GROVE_LAUNCH_CHECK();
+    return GROVE_OK;
+  }
   hipLaunchKernelGGL(scatter_add_f32src_kernel, grid_for((int64_t)rows * C), dim3(EB), 0, (hipStream_t)stream, src, dst, idx, rows, C, ld_src, ld_dst);
   GROVE_LAUNCH_CHECK();
   return GROVE_OK;
@@ -377,7 +407,7 @@ extern "C" int grove_colsum_f32(const void* x, float* out, int32_t rows, int32_t
     hipError_t e = hipMemsetAsync(out, 0, (size_t)C * sizeof(float), s);
     GROVE_CHECK(e == hipSuccess, GROVE_E_HIP, "colsum: memset failed");
   }
-  const int rpb = 256;
+  const int rpb = grove_det_on() ? rows : 256;  // deterministic mode: one block per column group, so one add per column
   dim3 grid((C + 127) / 128, (rows + rpb - 1) / rpb);
   hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, s, (const bf16_raw*)x, out, rows, C, ld, rpb);
   GROVE_LAUNCH_CHECK();
@@ -399,7 +429,8 @@ extern "C" int grove_cast_bf16_to_f32(const void* x, float* y, int64_t n, void* 
 extern "C" int grove_dot_bf16(const void* a, const void* b, float* out, int64_t n, const float* scale_ptr, int32_t mode, void* stream) {
   GROVE_CHECK(n > 0 && out, GROVE_E_SHAPE, "dot: bad args");
   CHECK_VEC8(n, "dot");
-  hipLaunchKernelGGL(dot_kernel, grid_for(n / 8), dim3(EB), 0, (hipStream_t)stream, (const bf16_raw*)a, (const bf16_raw*)b, out, n / 8, scale_ptr, mode);
+  hipLaunchKernelGGL(dot_kernel, grid_for(n / 8), dim3(EB), 0, (hipStream_t)stream, (const bf16_raw*)a, (const bf16_raw*)b, out, n / 8, scale_ptr, mode,
+                     grove_det_ticket());
   GROVE_LAUNCH_CHECK();
   return GROVE_OK;
 }

@@ -384,6 +384,7 @@ int launch(const grove_gemm_params& p, int vec_ok, hipStream_t s) {
     grove_set_error("gemm: split_k needs an accumulating f32 C without bias/act/residual/aux");
     return GROVE_E_SHAPE;
   }
+  if (grove_det_on()) split = 1;  // deterministic mode: no K ranges meeting in C through atomics (the tile's own read-add-store instead)
   dim3 grid(tiles_m * tiles_n, p.batch1 * p.batch2, split);
   const size_t lds = 2 * (size_t)(BM_ + BN_) * BK * 2;
   static bool attr_set = false;

@@ -535,7 +535,7 @@ int launch_tn_pp(const grove_gemm_tn_params& p, hipStream_t s) {
     sk = tn_skip{p.b_frame_rows / Q_BK, p.b_frames};
   const int nk_eff = sk.fk ? (p.K / Q_BK) / sk.T * (sk.T - 1) : p.K / Q_BK;  // K tiles of the tiles a cut tail holds (the short ones come last)
   int parts = 1, tail = tiles % G;
-  if (tail && (g_tn_split_tail == 2 || (g_tn_split_tail == 1 && GATHER))) {
+  if (tail && !grove_det_on() && (g_tn_split_tail == 2 || (g_tn_split_tail == 1 && GATHER))) {
     double best = 1.0;
     for (int s2 = 2; s2 <= 4; ++s2) {
       if (nk_eff / s2 < 32) break;
@@ -596,6 +596,7 @@ extern "C" int grove_gemm_tn_bf16(const grove_gemm_tn_params* pp, void* stream) 
       if (split < 1) split = 1;
     }
   }
+  if (grove_det_on()) split = 1;  // deterministic mode: whole-K tiles only (no fp32 atomics into C), here and in the pipelined kernel's tail
   // the persistent pipelined kernel: un-split problems with enough 256 x 256 tiles whose column tiles stay inside one tap
   const int g_force = g_tn_pipelined;
   const int n_per_tap = p.N / p.b_taps;

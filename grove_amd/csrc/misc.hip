@@ -60,7 +60,8 @@ __global__ __launch_bounds__(256) void clip_pool_kernel(const bf16_raw* __restri
 // ---------------------------------------------------------------- cross entropy
 // one block per row; fp32 log-sum-exp; writes dlogits = (softmax - onehot) * grad_scale
 __global__ __launch_bounds__(256) void ce_kernel(const bf16_raw* __restrict__ logits, const int32_t* __restrict__ labels, float* __restrict__ loss_sum,
-                                                 bf16_raw* __restrict__ dlogits, const float* __restrict__ grad_scale, int V, int ld) {
+                                                 bf16_raw* __restrict__ dlogits, const float* __restrict__ grad_scale, int V, int ld,
+                                                 unsigned* det) {
   __shared__ float scratch[4];
   const int r = blockIdx.x;
   const bf16_raw* x = logits + (int64_t)r * ld;
@@ -72,7 +73,11 @@ __global__ __launch_bounds__(256) void ce_kernel(const bf16_raw* __restrict__ lo
   s = block_sum<256>(s, scratch);
   const int lab = labels[r];
   const float lse = mx + __logf(s);
-  if (threadIdx.x == 0) atomicAdd(loss_sum, lse - bf2f(x[lab]));
+  if (threadIdx.x == 0) {
+    det_wait(det);
+    atomicAdd(loss_sum, lse - bf2f(x[lab]));
+    det_pass(det);
+  }
   if (dlogits) {
     const float gs = grad_scale ? *grad_scale : 1.f;
     const float inv = 1.f / s;
@@ -469,7 +474,7 @@ __global__ __launch_bounds__(64) void attn_fewk_fwd_kernel(const grove_small_att
   }
 }
 
-__global__ __launch_bounds__(64) void attn_fewk_bwd_kernel(const grove_small_attn_params p) {
+__global__ __launch_bounds__(64) void attn_fewk_bwd_kernel(const grove_small_attn_params p, unsigned* det) {
   const int qblocks = (p.Lq + 63) / 64;
   const int qb = blockIdx.x % qblocks;
   const int ih = blockIdx.x / qblocks;
@@ -527,6 +532,7 @@ __global__ __launch_bounds__(64) void attn_fewk_bwd_kernel(const grove_small_att
   for (int c = 0; c < MAXD; ++c) dqv[c] = 0.f;
   float* dk = (float*)p.dk + (int64_t)inst * p.Lk * HD + h * d;
   float* dv = (float*)p.dv + (int64_t)inst * p.Lk * HD + h * d;
+  det_block_enter(det);
 #pragma unroll
   for (int j = 0; j < MAXK; ++j) {
     if (j < p.Lk) {
@@ -546,6 +552,7 @@ __global__ __launch_bounds__(64) void attn_fewk_bwd_kernel(const grove_small_att
       }
     }
   }
+  det_block_leave(det);
   if (active) {
     float* dqo = (float*)p.dq + ((int64_t)inst * p.Lq + qi) * HD + h * d;
     for (int c = 0; c < d; ++c) dqo[c] = dqv[c];
@@ -596,7 +603,7 @@ __global__ __launch_bounds__(256) void box_head_fwd_kernel(const grove_box_head_
 
 
 // backward of the heads: one block per instance; weight gradients accumulated with f32 atomics.
-__global__ __launch_bounds__(256) void box_head_bwd_kernel(const grove_box_head_bwd_params p) {
+__global__ __launch_bounds__(256) void box_head_bwd_kernel(const grove_box_head_bwd_params p, unsigned* det) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* xs = (float*)smem_raw;  // [D]
   float* hs = xs + p.D;          // [D] hidden (post-relu)
@@ -618,6 +625,7 @@ __global__ __launch_bounds__(256) void box_head_bwd_kernel(const grove_box_head_
   const bf16_raw* W1 = (const bf16_raw*)p.W1;
   const bf16_raw* W2 = (const bf16_raw*)p.W2;
   const bf16_raw* Wo = (const bf16_raw*)p.Wo;
+  det_block_enter(det);  // (each address gets one add per block: the instances take turns)
   // dW2, db2, dh
   for (int c = threadIdx.x; c < D; c += 256) {
     float a = 0.f;
@@ -640,6 +648,7 @@ __global__ __launch_bounds__(256) void box_head_bwd_kernel(const grove_box_head_
     if (g != 0.f)
       for (int c = lane; c < D; c += 64) atomicAdd(&p.dW1[(int64_t)j * D + c], g * xs[c]);
   }
+  det_block_leave(det);
   for (int c = threadIdx.x; c < D; c += 256) {
     float a = p.dobj ? bf2f(Wo[c]) * dobj : 0.f;
     for (int j = 0; j < D; ++j) a += bf2f(W1[(int64_t)j * D + c]) * dh[j];
@@ -692,7 +701,7 @@ __device__ __forceinline__ Dual dscale(Dual a, float s) {
 
 __global__ __launch_bounds__(256) void box_losses_kernel(const float* __restrict__ pb, const float* __restrict__ ol, const float* __restrict__ gb,
                                                          const float* __restrict__ vis, float* __restrict__ sums, float* __restrict__ dbox,
-                                                         float* __restrict__ dobj, int N, float wb, float wo) {
+                                                         float* __restrict__ dobj, int N, float wb, float wo, unsigned* det) {
   __shared__ float scratch[4];
   float giou = 0.f, l1 = 0.f, bce = 0.f;
   const float eps = 1e-7f;
@@ -738,9 +747,11 @@ __global__ __launch_bounds__(256) void box_losses_kernel(const float* __restrict
   l1 = block_sum<256>(l1, scratch);
   bce = block_sum<256>(bce, scratch);
   if (threadIdx.x == 0) {
+    det_wait(det);
     atomicAdd(sums + 0, giou);
     atomicAdd(sums + 1, l1);
     atomicAdd(sums + 2, bce);
+    det_pass(det);
   }
 }
 
@@ -804,12 +815,16 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(float* __restrict__ ma
   }
 }
 
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n) {
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n, unsigned* det) {
   __shared__ float scratch[4];
   float s = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += x[i] * x[i];
   s = block_sum<256>(s, scratch);
-  if (threadIdx.x == 0) atomicAdd(out, s);
+  if (threadIdx.x == 0) {
+    det_wait(det);
+    atomicAdd(out, s);
+    det_pass(det);
+  }
 }
 
 inline dim3 cap_grid(int64_t n) {
@@ -841,7 +856,7 @@ extern "C" int grove_cross_entropy(const void* logits, const int32_t* labels, fl
                                    int32_t V, int32_t ld, void* stream) {
   GROVE_CHECK(R > 0 && V > 0 && ld >= V, GROVE_E_SHAPE, "cross_entropy: bad shape");
   hipLaunchKernelGGL(ce_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, (const bf16_raw*)logits, labels, loss_sum, (bf16_raw*)dlogits, grad_scale, V,
-                     ld);
+                     ld, grove_det_ticket());
   GROVE_LAUNCH_CHECK();
   return GROVE_OK;
 }
@@ -902,7 +917,7 @@ __global__ __launch_bounds__(FK_T) void attn_fewk16_fwd_kernel(const grove_small
   *(u32x4_t*)(op + 8) = u32x4_t{pack2bf(o[8] * inv, o[9] * inv), pack2bf(o[10] * inv, o[11] * inv), pack2bf(o[12] * inv, o[13] * inv), pack2bf(o[14] * inv, o[15] * inv)};
 }
 
-__global__ __launch_bounds__(FK_T) void attn_fewk16_bwd_kernel(const grove_small_attn_params p) {
+__global__ __launch_bounds__(FK_T) void attn_fewk16_bwd_kernel(const grove_small_attn_params p, unsigned* det) {
   __shared__ float ks[MAXK][16], vs[MAXK][16];
   __shared__ float qs[FK_T][17], dos[FK_T][17], dss[FK_T][MAXK + 1], pss[FK_T][MAXK + 1];
   const int qblocks = (p.Lq + FK_T - 1) / FK_T;
@@ -977,6 +992,7 @@ __global__ __launch_bounds__(FK_T) void attn_fewk16_bwd_kernel(const grove_small
   }
   __syncthreads();
   // dK[j][c] = sum_q dS[q][j] q[q][c],  dV[j][c] = sum_q P[q][j] dO[q][c] over this block's queries
+  det_block_enter(det);
   for (int t = tid; t < 2 * p.Lk * 16; t += FK_T) {
     const int which = t / (p.Lk * 16), r = t - which * p.Lk * 16;
     const int j = r >> 4, c = r & 15;
@@ -989,6 +1005,7 @@ __global__ __launch_bounds__(FK_T) void attn_fewk16_bwd_kernel(const grove_small
       atomicAdd((float*)p.dv + ((int64_t)inst * p.Lk + j) * HD + h * 16 + c, a);
     }
   }
+  det_block_leave(det);
 }
 
 
@@ -1091,10 +1108,10 @@ extern "C" int grove_small_attn_bwd(const grove_small_attn_params* p, void* stre
     const bool vec16 = p->d == 16 && p->ld_q % 8 == 0 && p->ld_k % 8 == 0 && p->ld_v % 8 == 0 && p->ld_o % 8 == 0 &&
                        (((uintptr_t)p->q | (uintptr_t)p->k | (uintptr_t)p->v | (uintptr_t)p->d_o | (uintptr_t)p->dq) & 15) == 0;
     if (vec16 && p->Lq >= 64) {
-      hipLaunchKernelGGL(attn_fewk16_bwd_kernel, dim3(p->inst * p->heads * ((p->Lq + FK_T - 1) / FK_T)), dim3(FK_T), 0, s, *p);
+      hipLaunchKernelGGL(attn_fewk16_bwd_kernel, dim3(p->inst * p->heads * ((p->Lq + FK_T - 1) / FK_T)), dim3(FK_T), 0, s, *p, grove_det_ticket());
     } else {
       const int qblocks = (p->Lq + 63) / 64;
-      hipLaunchKernelGGL(attn_fewk_bwd_kernel, dim3(p->inst * p->heads * qblocks), dim3(64), 0, s, *p);
+      hipLaunchKernelGGL(attn_fewk_bwd_kernel, dim3(p->inst * p->heads * qblocks), dim3(64), 0, s, *p, grove_det_ticket());
     }
   } else if (p->d == 16 && p->ld_q % 8 == 0 && p->ld_k % 8 == 0 && p->ld_v % 8 == 0 && (((uintptr_t)p->k | (uintptr_t)p->v) & 15) == 0 &&
              (((uintptr_t)p->dk | (uintptr_t)p->dv) & 15) == 0) {
@@ -1118,7 +1135,7 @@ extern "C" int grove_box_head_fwd(const grove_box_head_params* p, void* stream) 
 extern "C" int grove_box_head_bwd(const grove_box_head_bwd_params* p, void* stream) {
   GROVE_CHECK(p && p->N > 0 && p->D > 0 && p->D <= 4096, GROVE_E_SHAPE, "box_head_bwd: bad shape");
   GROVE_CHECK(p->dW1 && p->db1 && p->dW2 && p->db2 && p->dx && p->hidden && p->box && p->dbox, GROVE_E_SHAPE, "box_head_bwd: missing buffers");
-  hipLaunchKernelGGL(box_head_bwd_kernel, dim3(p->N), dim3(256), (size_t)3 * p->D * sizeof(float), (hipStream_t)stream, *p);
+  hipLaunchKernelGGL(box_head_bwd_kernel, dim3(p->N), dim3(256), (size_t)3 * p->D * sizeof(float), (hipStream_t)stream, *p, grove_det_ticket());
   GROVE_LAUNCH_CHECK();
   return GROVE_OK;
 }
@@ -1127,7 +1144,7 @@ extern "C" int grove_box_losses(const float* pred_box, const float* obj_logit, c
                                 float* dobj, int32_t N, float w_box_over_ngt, float w_obj_over_n, void* stream) {
   GROVE_CHECK(N > 0 && pred_box && gt_box && visible && sums, GROVE_E_SHAPE, "box_losses: bad args");
   hipLaunchKernelGGL(box_losses_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, pred_box, obj_logit, gt_box, visible, sums, dbox, dobj,
-                     N, w_box_over_ngt, w_obj_over_n);
+                     N, w_box_over_ngt, w_obj_over_n, grove_det_ticket());
   GROVE_LAUNCH_CHECK();
   return GROVE_OK;
 }
@@ -1159,7 +1176,7 @@ extern "C" int grove_adamw_step_multi(float* master, const float* grad, float* m
 
 extern "C" int grove_sumsq_f32(const float* x, float* out, int64_t n, void* stream) {
   GROVE_CHECK(n > 0, GROVE_E_SHAPE, "sumsq: bad size");
-  hipLaunchKernelGGL(sumsq_kernel, cap_grid(n), dim3(256), 0, (hipStream_t)stream, x, out, n);
+  hipLaunchKernelGGL(sumsq_kernel, cap_grid(n), dim3(256), 0, (hipStream_t)stream, x, out, n, grove_det_ticket());
   GROVE_LAUNCH_CHECK();
   return GROVE_OK;
 }

@@ -139,7 +139,7 @@ template <bool need_dw>
 constexpr int rows_per_wave() { return need_dw ? 8 : 1; }
 
 template <bool RMS, int MAXCH, bool need_dw>
-__global__ __launch_bounds__(256) void norm_bwd_kernel(const grove_norm_bwd_params p) {
+__global__ __launch_bounds__(256) void norm_bwd_kernel(const grove_norm_bwd_params p, unsigned* det) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* red = (float*)smem_raw;  // [2][C] when dweight requested
   const int lane = threadIdx.x & 63;
@@ -238,22 +238,43 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const grove_norm_bwd_para
     // combine the 4 waves through LDS, then one atomic per channel per block
     for (int c = threadIdx.x; c < 2 * p.C; c += 256) red[c] = 0.f;
     __syncthreads();
+    if (det) {  // deterministic mode: the four waves add to the LDS row one after the other
+      for (int wv_turn = 0; wv_turn < 4; ++wv_turn) {
+        if (wave == wv_turn) {
 #pragma unroll
-    for (int i = 0; i < MAXCH; ++i) {
-      const int ch = lane + i * 64;
-      if (ch < nch) {
+          for (int i = 0; i < MAXCH; ++i) {
+            const int ch = lane + i * 64;
+            if (ch < nch) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          atomicAdd(&red[ch * 8 + e], dw[i][e]);
-          atomicAdd(&red[p.C + ch * 8 + e], db[i][e]);
+              for (int e = 0; e < 8; ++e) {
+                red[ch * 8 + e] += dw[i][e];
+                red[p.C + ch * 8 + e] += db[i][e];
+              }
+            }
+          }
+        }
+        __syncthreads();
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < MAXCH; ++i) {
+        const int ch = lane + i * 64;
+        if (ch < nch) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            atomicAdd(&red[ch * 8 + e], dw[i][e]);
+            atomicAdd(&red[p.C + ch * 8 + e], db[i][e]);
+          }
         }
       }
+      __syncthreads();
     }
-    __syncthreads();
+    det_block_enter(det);
     for (int c = threadIdx.x; c < p.C; c += 256) {
       atomicAdd(&p.dweight[c], red[c]);
       if (p.dbias) atomicAdd(&p.dbias[c], red[p.C + c]);
     }
+    det_block_leave(det);
   }
 }
 
@@ -404,7 +425,8 @@ static int norm_bwd_launch(const grove_norm_bwd_params* p, bool rms, void* strea
   hipStream_t s_ = (hipStream_t)stream;
   const bool dw = p->dweight != nullptr;
   GROVE_CHECK(!(dw && p->C > 2048), GROVE_E_SHAPE, "norm_bwd: dweight supported for C <= 2048 only");
-#define NB(RMS, NCH, DW) hipLaunchKernelGGL((norm_bwd_kernel<RMS, NCH, DW>), grid, dim3(256), lds, s_, *p)
+  unsigned* det = dw ? grove_det_ticket() : nullptr;
+#define NB(RMS, NCH, DW) hipLaunchKernelGGL((norm_bwd_kernel<RMS, NCH, DW>), grid, dim3(256), lds, s_, *p, det)
 #define NB_C(RMS, DW)                 \
   do {                                \
     if (p->C <= 512) NB(RMS, 1, DW);  \

@@ -23,6 +23,8 @@ def _stream():
     current HIP device, so the tensors must live there: one process per GPU calls torch.cuda.set_device(local_rank) once
     (GROVEForCausalLM / GroveEngine do it); a launch whose tensors sit on another device is refused instead of faulting."""
     s = torch.cuda.current_stream()
+    if _det_env:
+        set_deterministic(True)
     if _last_dev[0] == -2:
         raise RuntimeError("grove_amd ops need device tensors (no CPU fallback exists)")
     if _last_dev[0] != s.device_index and _last_dev[0] >= 0:
@@ -97,6 +99,27 @@ def gemm_workspace(plan, image_fn, device):
 # Set by train.GradExchange while gradient buckets are in flight on RCCL (N > 1): called before every persistent-GEMM launch so the
 # exchange can lift its CU reservation as soon as the host sees the collectives complete (None otherwise: no per-launch cost).
 _pre_gemm_hook = None
+
+
+_det_ring = None
+_det_env = os.environ.get("GROVE_DETERMINISTIC", "0") not in ("", "0")
+
+
+def set_deterministic(on: bool, device=None):
+    """Deterministic mode (include/grove_hip.h: grove_set_deterministic; GROVE_DETERMINISTIC=1 turns it on at the first op):
+    fixed-order sums instead of fp32 atomics, for the race tests. The ticket ring is this module's tensor. Returns the previous setting."""
+    global _det_ring, _det_env
+    _det_env = False
+    lib = _lib.lib()
+    prev = bool(lib.grove_deterministic())
+    if on:
+        if _det_ring is None:
+            _det_ring = torch.zeros(4096, dtype=torch.int32, device=device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+            torch.cuda.synchronize()
+        _lib.check(lib.grove_set_deterministic(_p(_det_ring), _det_ring.numel()), "grove_set_deterministic")
+    else:
+        _lib.check(lib.grove_set_deterministic(None, 0), "grove_set_deterministic")
+    return prev
 
 
 def gemm_set_persistent_blocks(n: int):
@@ -455,9 +478,11 @@ def flash_attn_kv(q, k, v, B, H, Lq, Lk, hs, alpha, *, sq, sk, sv, ld_q, ld_k, l
 def rope_table(hd, theta, positions, device):
     """f32 [positions, hd] = cos[hd / 2] | sin[hd / 2] of the rotate-half RoPE angles pos * theta^(-2 i / hd) (HF LlamaRotaryEmbedding:
     inv_freq in fp32, angles in fp32): the table the backward attention kernels un-rotate dq / dk with (grove_flash_attn_params.rope)."""
-    inv_freq = 1.0 / (theta ** (torch.arange(0, hd, 2, dtype=torch.float32, device=device) / hd))
-    ang = torch.arange(positions, dtype=torch.float32, device=device)[:, None] * inv_freq[None]
-    return torch.cat([torch.cos(ang), torch.sin(ang)], 1).contiguous()
+    # evaluated on the HOST, where the reference evaluates it (same fp32 formula, same libm): the table then holds the reference's own
+    # cos / sin bit for bit; made once per sequence-length high-water mark (llama._rope_table), so the upload is not on the step
+    inv_freq = 1.0 / (theta ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
+    ang = torch.arange(positions, dtype=torch.float32)[:, None] * inv_freq[None]
+    return torch.cat([torch.cos(ang), torch.sin(ang)], 1).contiguous().to(device)
 
 
 def flash_attn_bwd(qkv, out, d_out, lse, dqkv, B, L, H, hs, q_off, k_off, v_off, alpha, *, causal=False, kv_len=None, rel=None,

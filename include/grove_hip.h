@@ -53,6 +53,18 @@ enum grove_dtype { GROVE_BF16 = 0, GROVE_F32 = 1 };
 int grove_version(void);
 /* copies the last error message of the calling thread into buf (NUL-terminated) */
 int grove_last_error(char* buf, size_t n);
+/* Deterministic mode (round 4; the Python host turns it on when GROVE_DETERMINISTIC=1): `tickets` = n >= 64 ZEROED 32-bit words of
+ * device memory owned by the caller (the library allocates nothing) that stay valid until the mode is turned off with (NULL, 0);
+ * one ring per process, on the device the caller launches on. Every sum that otherwise meets in global
+ * memory through fp32 atomics gets a fixed order, so two runs of the same program on the same inputs agree bit for bit — the mode the
+ * stream-overlap race tests assert equality in. How: split-K / cut-tail GEMM launches run whole-K tiles (grove_gemm_bf16,
+ * grove_gemm_tn_bf16); the block-level reductions (cross entropy and box-loss sums, norm dweight / dbias, dot, sum of squares, the
+ * few-key attention dK / dV, the box heads' weight gradients) make their blocks add in blockIdx order through a ticket
+ * (csrc/common.h: det_wait / det_pass); scatter_add walks its source rows in order, colsum uses one block per column group.
+ * Slower (the add phases are serialised) and meant for race hunting, not for training runs. Results differ from the default mode's
+ * only in summation order. */
+int grove_set_deterministic(void* tickets, int32_t n);
+int grove_deterministic(void);
 /* sizeof(struct <name>) as compiled into the library (binding self-check), -1 if unknown */
 int grove_sizeof(const char* name);
 
