@@ -106,5 +106,67 @@ assert (r0 - r1).abs().max().item() <= 2e-6 * r0.abs().max().item(), "TN gathere
 screen("TN gathered conv3d wgrad (self)", lambda: tng(1), lambda: tng(1))
 L.grove_gemm_tn_set_pipelined(-1)
 L.grove_gemm_set_stream_k(1)
+# ---- round 4 ----
+# temporal tap skipping (short tiles dealt after the full ones: another work list, another vmcnt tail per block): whole tiles are
+# bit-identical to the un-skipped launch, which is the reference here
+G4, T4, H4, W4, Ci4, Co4 = 4, 8, 32, 32, 128, 256
+M4 = G4 * T4 * H4 * W4
+x4 = torch.randn(M4, Ci4, device=dev).to(bf); w4 = (torch.randn(Co4, 27 * Ci4, device=dev) * 0.03).to(bf); b4 = torch.randn(Co4, device=dev).to(bf)
+idx4 = conv3d_gather_index(G4, T4, H4, W4).to(dev)
+L.grove_gemm_set_stream_k(0)
+def conv4(skip):
+    L.grove_gemm_set_tap_skip(skip)
+    return ops.linear(x4, w4, b4, a_idx=idx4, a_taps=27, M=M4, a_frames=(H4 * W4, T4))
+screen("NT conv3d tap skip vs all taps", lambda: conv4(0), lambda: conv4(1))
+L.grove_gemm_set_stream_k(1)
+L.grove_gemm_set_tap_skip(1)
+dz4 = torch.randn(M4, 512, device=dev).to(bf); xx4 = torch.randn(M4, 256, device=dev).to(bf)
+L.grove_gemm_tn_set_pipelined(1); L.grove_gemm_tn_set_split_tail(0)
+def tn4(skip):
+    L.grove_gemm_tn_set_tap_skip(skip)
+    return ops.wgrad(dz4, xx4, torch.zeros(512, 27 * 256, dtype=torch.float32, device=dev), b_idx=idx4, b_taps=27, b_frames=(H4 * W4, T4))
+screen("TN conv3d wgrad tap skip vs all taps", lambda: tn4(0), lambda: tn4(1))
+L.grove_gemm_tn_set_pipelined(-1); L.grove_gemm_tn_set_split_tail(1); L.grove_gemm_tn_set_tap_skip(1)
+# attention backward with the inverse RoPE in its epilogues, and the tail form (Lq != Lk): self-consistency under churn
+Bq, Hq, hq, Sq = 2, 8, 128, 703
+qkv = (torch.randn(Bq * Sq, 3 * Hq * hq, device=dev) * 0.5).to(bf)
+do_ = (torch.randn(Bq * Sq, Hq * hq, device=dev) * 0.5).to(bf)
+o_, lse_ = ops.flash_attn(qkv, Bq, Sq, Hq, hq, 0, Hq * hq, 2 * Hq * hq, hq ** -0.5, causal=True, want_lse=True)
+tab = ops.rope_table(hq, 10000.0, 1024, dev)
+def fbwd():
+    dqkv = torch.empty_like(qkv)
+    ops.flash_attn_bwd(qkv, o_, do_, lse_, dqkv, Bq, Sq, Hq, hq, 0, Hq * hq, 2 * Hq * hq, hq ** -0.5, causal=True, rope=tab)
+    return dqkv
+screen("flash bwd + fused inverse RoPE (self)", fbwd, fbwd)
+Lq4 = 54
+q_t = (torch.randn(Bq * Lq4, Hq * hq, device=dev) * 0.5).to(bf); kv_ = qkv[:, Hq * hq:].contiguous()
+ot, lset = ops.flash_attn_tail(q_t, kv_, Bq, Lq4, Sq, Hq, hq, hq ** -0.5, want_lse=True)
+dot_ = (torch.randn(Bq * Lq4, Hq * hq, device=dev) * 0.5).to(bf)
+def tbwd():
+    dq, dkv = torch.empty_like(q_t), torch.empty_like(kv_)
+    ops.flash_attn_tail_bwd(q_t, kv_, ot, dot_, lset, dq, dkv, Bq, Lq4, Sq, Hq, hq, hq ** -0.5, rope=tab)
+    return dq, dkv
+screen("tail attention bwd + fused inverse RoPE (self)", tbwd, tbwd)
+# the whole training step in deterministic mode (every overlap on): repeated steps from the same state must agree bit for bit
+ops.set_deterministic(True)
+from grove_amd import train as TR
+from grove_amd.synthetic import TINY, synthetic_batch, synthetic_state_dict
+def three_steps():
+    args = TR.shipped_args(); args.lr, args.steps_per_epoch, args.print_freq = 1e-3, 4, 2
+    eng = TR.GroveEngine(TR.initialize_model(args, dims=TINY, state_dict=synthetic_state_dict(TINY), device=dev), args, total_steps=1000)
+    eng.scheduler.warm = 0
+    ls = []
+    for st in range(3):
+        kw = synthetic_batch(TINY, B=2, T=8, L=48, n_det=2, seed=10 + st, ragged=True).as_kwargs()
+        for k in ("global_enc_images", "grounding_enc_images"):
+            kw[k] = kw[k].to(dev).to(bf)
+        for k in ("input_ids", "labels", "attention_masks", "offset"):
+            kw[k] = kw[k].to(dev)
+        out = eng(**kw); ls.append(out["loss"]); eng.backward(out["loss"]); eng.step()
+    torch.cuda.synchronize()
+    return torch.stack(ls), eng.master.clone()
+REPS = max(REPS // 6, 4)
+screen("3 training steps, deterministic mode (self)", three_steps, three_steps)
+ops.set_deterministic(False)
 print("TOTAL MISMATCHES", bad)
 sys.exit(1 if bad else 0)
