@@ -361,7 +361,7 @@ class WarmupDecayLR:
     """DeepSpeed WarmupDecayLR (train.py:471-474): linear warm-up 0 -> lr over warmup steps, then linear decay to 0."""
 
     def __init__(self, lr, total_steps, warmup_steps=100):
-        self.lr, self.total, self.warm = lr, max(total_steps, 1), warmup_steps
+        self.lr, self.total, self.warm = lr, max(total_steps, 1), max(2, warmup_steps)  # (WarmupLR.__init__: warmup_num_steps = max(2, n))
         self.last = 0.0
 
     def for_update(self, k):
@@ -369,11 +369,11 @@ class WarmupDecayLR:
         last_batch_iteration = -1, which writes warmup_min_lr (0, train.py:472) into the optimizer — the value update 1 uses —
         and the engine steps the scheduler AFTER every optimizer update (iteration 0 after update 1, gamma(0) = 0 for update 2,
         gamma(1) for update 3, ...). So update k runs with gamma(k - 2): the first two updates have lr = 0.
-        UNPINNED: this rests on deepspeed==0.15.1's `WarmupLR.__init__` writing `warmup_min_lr` into the optimizer's
-        param groups when `last_batch_iteration == -1` (deepspeed/runtime/lr_schedules.py, `_format_param` / `update_lr` called from
-        `__init__`) and on `DeepSpeedEngine._take_model_step` calling `lr_scheduler.step()` after `optimizer.step()`. DeepSpeed is not
-        installed offline, so no lr trace of the reference stack could be captured into tests/golden; older DeepSpeed releases left
-        the optimizer's base lr for update 1. `get(step)` is the closed form either way; only the index shift is version dependent."""
+        Pinned (round 4) against oracle/ds_lr_schedule.py — DeepSpeed 0.15.1's `WarmupLR` / `WarmupDecayLR` classes and the engine's
+        optimizer-then-scheduler order restated from the published source and simulated update by update
+        (tests/test_distributed_cpu.py::test_lr_of_every_update_follows_deepspeeds_calling_order). DeepSpeed itself is not installed
+        offline, so no lr trace of the reference STACK exists: the restatement is flagged "parity unpinned" in its header. (Older
+        DeepSpeed releases left the optimizer's base lr for update 1; the pin is the reference's requirements.txt:6.)"""
         return self.get(max(k - 2, 0))
 
     def get(self, step):

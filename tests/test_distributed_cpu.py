@@ -2,6 +2,7 @@
 folded meter all-reduce of grove_amd.train exactly as the RCCL path uses them."""
 import os
 import socket
+import pytest
 
 import torch
 import torch.distributed as dist
@@ -164,6 +165,19 @@ def test_warmup_decay_lr():
     # update k at gamma(k - 2)
     assert s.for_update(1) == 0.0 and s.for_update(2) == 0.0 and abs(s.for_update(3) - 3e-6) < 1e-15
     assert abs(s.for_update(102) - 3e-4) < 1e-12
+
+
+@pytest.mark.parametrize("total,warm", [(250, 100), (5000, 100), (60, 100), (7, 1)])
+def test_lr_of_every_update_follows_deepspeeds_calling_order(total, warm):
+    """`for_update` (which lr the k-th optimizer update runs with) against a step-by-step simulation of DeepSpeed's
+    schedule classes and engine order restated in oracle/ds_lr_schedule.py (deepspeed==0.15.1 is not installed offline: restated from the
+    published source, flagged there) — warm-up, decay, past the end, a total shorter than the warm-up, and warm-up < 2 (clamped to 2)."""
+    from grove_amd.train import WarmupDecayLR
+    from oracle.ds_lr_schedule import lr_of_updates
+    ref = lr_of_updates(3e-4, total, total + 30, warmup_num_steps=warm)
+    s = WarmupDecayLR(3e-4, total, warm)
+    mine = [s.for_update(k) for k in range(1, total + 31)]
+    assert max(abs(a - b) for a, b in zip(ref, mine)) <= 1e-18, [(k + 1, a, b) for k, (a, b) in enumerate(zip(ref, mine)) if abs(a - b) > 1e-18][:5]
 
 
 def _infer_worker(rank, world, port, out):
