@@ -511,7 +511,8 @@ def infer_bench(args, dev, dims, world=1, rank=0):
     from grove_amd.synthetic import synthetic_batch, synthetic_state_dict
     bf = torch.bfloat16
     sd = synthetic_state_dict(dims, device=dev, dtype=bf)
-    model = GROVEForCausalLM(dims=dims, device=dev, state_dict=sd, det_token_idx=dims.det_token_idx, num_frames=8, gemm_dtype=args.dtype)
+    model = GROVEForCausalLM(dims=dims, device=dev, state_dict=sd, det_token_idx=dims.det_token_idx, num_frames=8, gemm_dtype=args.dtype,
+                             fp8_policy=args.fp8_policy)
     del sd
     torch.cuda.empty_cache()
     # N > 1 (config 5 is an 8-GPU job): replicas only — every rank runs its own `--batch` clips (seeded by rank, the
@@ -583,7 +584,7 @@ def infer_bench(args, dev, dims, world=1, rank=0):
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"GROVE inference + SAM mask decoder: {args.batch} clips x T={args.frames} frames ({args.batch * args.frames // 8} windows), "
                                    f"LLaVA-1.5-7B + CLIP ViT-L/14-336 ({args.dtype} linear layers) + SAM ViT-H@512 (bf16) + box / mask decoder, text L={args.text_len}",
-                       "dims": args.dims, "instances": int(out["flat_boxes"].shape[0]), "mask_shape": list(res["masks"].shape),
+                       "dims": args.dims, "fp8_policy": args.fp8_policy if args.dtype == "fp8" else None, "instances": int(out["flat_boxes"].shape[0]), "mask_shape": list(res["masks"].shape),
                        "parallelism": f"dp{world} (replicas only: clips sharded over ranks, end-of-run all_gather_object)", "ranks": world,
                        "ranks_gathered": gathered, "collective_backend": (dist.get_backend() if world > 1 else None),
                        "frames_per_sec_per_gpu": round(frames / dt / world, 3)}}
@@ -615,6 +616,8 @@ def main():
     ap.add_argument("--mode", default="train", choices=["train", "infer"],
                     help="train (default, the headline line: BASELINE config 3) or infer (config 5: inference + SAM masks, use --frames 32 --dtype fp8)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"], help="--mode infer: linear layers of the CLIP tower and the LLaMA stack")
+    ap.add_argument("--fp8_policy", default="det16_kv16", choices=["all", "det16_kv16", "det16_kv16_clip16"],
+                    help="--mode infer --dtype fp8: which GEMMs / rows stay bf16 (DESIGN section 8; _clip16 = the CLIP tower in bf16)")
     ap.add_argument("--exchange", default="allreduce", choices=["allreduce", "rs_ag", "a2a_f32"],
                     help="N > 1: one all-reduce per gradient bucket, reduce-scatter + all-gather per bucket, or all-to-all + fp32 sum + all-gather")
     ap.add_argument("--dense_embed", action="store_true",
@@ -725,7 +728,7 @@ def main():
     all_n, all_f, all_s = (sum(v[i] for v in per_kernel.values()) for i in range(3))
     traffic = None
     try:  # memory-side bytes per launch from the committed PMC passes (profiles/, collected as the microarch guide prescribes)
-        with open(os.path.join(ROOT, "profiles", "r03_pmc_gemm_traffic.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r04_pmc_gemm_traffic.json")) as fh:
             traffic = json.load(fh)["launch_weighted_mean_bytes"].get(dom[dom.index("<"):dom.index(",")] + ">")
     except Exception:
         pass

@@ -749,7 +749,7 @@ __device__ __forceinline__ i32x4_t sload4(const void* p) {  // 4 consecutive int
 //   part 1 + s   STREAM-K: a K range of a tile of the last, partial round; the raw fp32 accumulators go to workspace slot s
 //                and gemm_pp_fixup_kernel (next launch on the stream) sums a tile's slots in K order and runs the epilogue.
 // Stream-K tail (plan_stream_k): tiles = rounds * G + tail with tail <= G / 2 — the tiles of the partial round are cut into 2..4
-// equal K ranges, one block each, so that (nearly) every CU works through the last round instead of `tail` CUs for a whole
+// equal K ranges (up to 8 when the partial round is the only one), one block each, so that (nearly) every CU works through the last round instead of `tail` CUs for a whole
 // tile. The order of the sum is fixed by the list, so results are deterministic.
 struct pp_work {
   const i32x4_t* table;
@@ -1345,10 +1345,14 @@ inline sk_plan plan_stream_k(long tiles, int nk, int G, int mode) {  // mode: 0 
   sk_plan pl;
   pl.rounds = (int)(tiles / G), pl.tail = (int)(tiles % G), pl.S = 0, pl.parts = 1;
   pl.kt_units = (double)((tiles + G - 1) / G) * nk;
-  if (!mode || pl.tail == 0 || pl.rounds == 0) return pl;
-  const int s = std::min(G / pl.tail, 4);
+  if (!mode || pl.tail == 0) return pl;
+  // Round 4: FEWER tiles than CUs (rounds == 0: the few-row GEMMs of LLaMA's last-layer tail, prefill, the decoder's K = 2048 layers) —
+  // the only round is a partial one; with a long K it is cut the same way, into up to 8 ranges (32 tiles x 8 = the whole chip).
+  if (pl.rounds == 0 && nk < 32) return pl;
+  const int s = std::min(G / pl.tail, pl.rounds == 0 ? 8 : 4);
   if (s < 2) return pl;
   const int S = (nk + s - 1) / s;
+  if (pl.rounds == 0 && S < 4) return pl;
   const double pf = (double)(pl.tail * s) / G;  // part blocks / CUs: 5 K tiles for the extra launch + the stores and read-backs (measured: 20 at pf = 1, ~8 at 0.56)
   const double fixed = 5.0 + (SK_FIXED - 5.0) * pf * pf;
   const double t = (double)pl.rounds * nk + S + fixed;
@@ -1831,7 +1835,9 @@ static int gemm_bf16_dispatch(const grove_gemm_params* pp, void* stream) {
     g_gemm_last_variant = cp256 <= cp192 ? GROVE_GEMM_PP256 : GROVE_GEMM_PP192;
     return cp256 <= cp192 ? launch_pp<256, false>(p, s) : launch_pp<192, false>(p, s);
   }
-  if (p256_ok && g_gemm_tile_m == 0 && g_gemm_tile_n == 0 && tp192 >= 48 && (cp256 < c_old || cp192 < c_old))
+  // (under 48 tiles the persistent kernel only pays when the stream-K plan spreads the K range over the idle CUs)
+  const bool few_tiles_cut = tp192 < 48 && bk64 && plan_stream_k(tp192, p.K / 64, 256, g_gemm_stream_k).S > 0;
+  if (p256_ok && g_gemm_tile_m == 0 && g_gemm_tile_n == 0 && (tp192 >= 48 || few_tiles_cut) && (cp256 < c_old || cp192 < c_old))
     {
       g_gemm_last_variant = cp256 <= cp192 ? (p.a_idx ? GROVE_GEMM_PP256_GATHER : GROVE_GEMM_PP256) : (p.a_idx ? GROVE_GEMM_PP192_GATHER : GROVE_GEMM_PP192);
       if (p.a_idx) return cp256 <= cp192 ? launch_pp<256, true>(p, s) : launch_pp<192, true>(p, s);

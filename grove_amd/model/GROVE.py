@@ -269,8 +269,11 @@ class GROVEForCausalLM(torch.nn.Module):
         fp8 = self.gemm_dtype == "fp8"
         if fp8 and tr:
             raise ValueError("gemm_dtype='fp8' is an inference configuration (BASELINE config 5): build the model with train=False")
-        self.clip = ClipTower(sd, d, dev, fp32_stream=f32s, fp8=fp8)
-        self.llama = LlamaStack(sd, d, dev, train=tr, fp32_stream=f32s, fp8=fp8, fp8_policy=self.fp8_policy)
+        # "<policy>_clip16" keeps the CLIP tower's GEMMs in bf16 (round 4: with massive-activation channels in the LLaMA stream the e4m3
+        # error of the VISUAL TOKENS is what reaches the boxes — tools/fp8_policy_study.py --outliers, profiles/r04_fp8_outlier_policy_study_*)
+        clip16 = self.fp8_policy.endswith("_clip16")
+        self.clip = ClipTower(sd, d, dev, fp32_stream=f32s, fp8=fp8 and not clip16)
+        self.llama = LlamaStack(sd, d, dev, train=tr, fp32_stream=f32s, fp8=fp8, fp8_policy=self.fp8_policy[:-7] if clip16 else self.fp8_policy)
         self.sam = SamEncoder(sd, d, dev, train=tr, grads=self._grad, fp32_stream=f32s)
         self.decoder = BoxDecoder(sd, d, dev, grads=self._grad, pe_dtype=self.pe_dtype)
 

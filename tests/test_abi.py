@@ -61,7 +61,11 @@ def test_ops_refuse_cpu_tensors():
     (256, 128, 5, 20, 1),    # the same tiles with K = 1280: the split does not pay, whole tiles
     (256, 128, 5, 20, 2),    # ... forced
     (256, 79, 4, 40, 1),     # one round + 60 tiles -> four parts
-    (192, 15, 16, 64, 1),    # fewer tiles than CUs (LLaMA o-proj): one partial round, never split
+    (192, 15, 16, 64, 1),    # fewer tiles than CUs (LLaMA o-proj, 240 tiles): G / tiles = 1, nothing to cut
+    (192, 2, 16, 344, 1),    # round 4: 32 tiles, long K (the last-layer tail's down-proj, 260 rows): the only round is cut into 8 ranges
+    (192, 2, 16, 64, 1),     # ... K = 4096: 8 ranges of 8 K tiles
+    (192, 4, 16, 64, 1),     # prefill of 615 rows: 64 tiles -> 4 ranges
+    (192, 2, 16, 16, 1),     # short K with few tiles: whole tiles
     (256, 11, 86, 64, 1),    # 946 tiles: tail of 178 > half a round, whole tiles
     (256, 3, 7, 5, 2),       # tiny
     (192, 97, 4, 64, 0),     # stream-K off
@@ -107,17 +111,24 @@ def test_gemm_work_list_covers_every_k_tile_once(lib, bm, tiles_m, tiles_n, nk, 
     if mode == 0 or S.value == 0:
         assert not parts and nf.value == 0
     else:
-        assert nf.value == len(parts) == tiles % G and tiles // G >= 1 and tiles % G <= G // 2
+        assert nf.value == len(parts) == tiles % G and tiles % G <= G // 2
+        cap = 4 if tiles >= G else 8
         for j in range(nf.value):
             m0, n0, s0, np_ = (int(v) for v in fix[j])
             ps = sorted(parts[(m0, n0)])
             assert [p[0] for p in ps] == list(range(s0, s0 + np_)), "consecutive slots in K order"
             assert ps[0][1] == 0 and ps[-1][2] == nk and all(a[2] == b[1] for a, b in zip(ps, ps[1:]))
-            assert max(p[2] - p[1] for p in ps) == S.value and 2 <= np_ <= 4
+            assert max(p[2] - p[1] for p in ps) == S.value and 2 <= np_ <= cap
         assert len({s for v in parts.values() for s, _, _ in v}) == sum(len(v) for v in parts.values()) <= G
     if (bm, tiles_m, tiles_n, nk, mode) == (256, 128, 5, 80, 1):
         assert S.value == 40 and nf.value == 128
     if (bm, tiles_m, tiles_n, nk, mode) == (256, 128, 5, 20, 1):
+        assert S.value == 0
+    if (bm, tiles_m, tiles_n) == (192, 2, 16) and mode == 1:
+        assert (S.value, nf.value) == {344: (43, 32), 64: (8, 32), 16: (0, 0)}[nk]
+    if (bm, tiles_m, tiles_n, nk) == (192, 4, 16, 64):
+        assert (S.value, nf.value) == (16, 64)
+    if (bm, tiles_m, tiles_n, nk) == (192, 15, 16, 64):
         assert S.value == 0
 
 

@@ -441,7 +441,7 @@ def run_fp8_parity(dev, which, policy, outliers=0.0):
            "box_l1_max": (out["flat_boxes"].cpu() - box_o).abs().max().item(),
            "objectness_logit_abs_err": (out["flat_logits"].cpu() - obj_o).abs().max().item(),
            "llama_hidden_rel_rms": rel_rms(out["hidden"], hidden_o), "projected_features_rel_rms": rel_rms(feats_h, feats_o),
-           "bounds": FP8_BOUNDS[(which, policy)], "outliers": outliers, "n_q": n_q}
+           "bounds": FP8_BOUNDS.get((which, policy)), "outliers": outliers, "n_q": n_q}
     with open(os.path.join(ROOT, "gpurun_out", f"full_depth_fp8_parity_{which}_{policy}{tag(outliers)}.json"), "w") as fh:
         json.dump(res, fh, indent=1)
     print(json.dumps(res))

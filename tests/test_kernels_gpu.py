@@ -243,6 +243,37 @@ def test_gemm_stream_k_tail(dev, tile_m, M):
         L.grove_gemm_set_stream_k(1)
 
 
+@pytest.mark.parametrize("M,N,K", [(260, 4096, 22016), (260, 4096, 4096), (12, 4096, 4096), (615, 4096, 4096), (576, 256, 2048), (260, 4096, 1024)])
+def test_gemm_few_tiles_long_k_is_cut_over_the_idle_cus(dev, M, N, K):
+    """Round 4: fewer output tiles than CUs with a long K (the few-row GEMMs of LLaMA's last-layer tail, the 615-row prefill, the
+    decoder's K = 2048 layers): the AUTOMATIC dispatch takes the persistent kernel and cuts the only round into up to 8 K ranges
+    (stream-K parts + the fix-up launch) instead of the two-barrier kernel on a fraction of the chip; K = 1024 stays whole.
+    Against fp32 and against the launch with the cut off; outputs start as NaN."""
+    from grove_amd import _lib, ops
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(M + K)
+    a = (torch.randn(M, K, generator=g) * 0.5).to(bf16).to(dev)
+    b = (torch.randn(N, K, generator=g) * 0.05).to(bf16).to(dev)
+    bias = torch.randn(N, generator=g).to(bf16).to(dev)
+    res = torch.randn(M, N, generator=g).to(bf16).to(dev)
+    outs = []
+    try:
+        for mode in (1, 0):
+            L.grove_gemm_set_stream_k(mode)
+            o = ops.linear(a, b, bias, residual=res, out=torch.full((M, N), float("nan"), dtype=bf16, device=dev))
+            outs.append((o, L.grove_gemm_last_variant(), L.grove_gemm_last_stream_k()))
+    finally:
+        L.grove_gemm_set_stream_k(1)
+    (o1, v1, s1), (o0, v0, s0) = outs
+    if K >= 2048:
+        assert v1 in (4, 5) and s1 >= 4 and (v0 not in (4, 5) or s0 == 0), (v1, s1, v0, s0)  # (last_stream_k is the last PIPELINED launch's)
+    else:
+        assert v1 not in (4, 5) or s1 == 0
+    want = a.float() @ b.float().t() + bias.float() + res.float()
+    close(o1, want, 2 ** -7, "few tiles, cut K vs fp32")
+    close(o1, o0, 2 ** -7, "few tiles, cut K vs whole tiles")
+
+
 def test_gemm_stream_k_gathered_taps(dev):
     """The gathered-A instances under the stream-K tail: a K range that starts inside the tap list (27-tap Conv3d rows, -1 = zero
     row; 2 K tiles per tap, parts of 14 K tiles) with the ReLU + residual + tanh'd scale epilogue the adapters use."""

@@ -7,7 +7,10 @@ Policies (LLaMA; CLIP is `clip8` on/off):
   det16       + the rows of the [DET] positions computed in bf16 (row-selective precision: their q/k/v, o, gate/up, down)
   det16_kv16  + k_proj / v_proj of ALL rows in bf16
   lastN       the last N layers entirely in bf16
-Usage: python tools/fp8_policy_study.py [tiny|deep_narrow]
+  out16       (round 4, with --outliers F) the outlier hidden channels of the norm-following projections (q / k / v / gate / up: their
+              input is the RMSNorm of the residual stream) go through a bf16 side product (K = 3 channels), the e4m3 GEMM sees them zeroed
+  smooth      SmoothQuant: per-input-channel s_j = sqrt(amax|x_j| / amax|W_j|) folded into the norm weight (x / s) and the weight (W s)
+Usage: python tools/fp8_policy_study.py [tiny|deep_narrow] [--outliers F]   (F > 0: synthetic massive activations, grove_amd/synthetic.py)
 """
 import json
 import os
@@ -38,7 +41,8 @@ def r16(x):
 
 
 class Policy:
-    def __init__(self, name, clip8=True, llama8=True, det16=False, kv16=False, last_bf16=0, blk=0, first_bf16=0, o16=False, down16=False, det_from=0):
+    def __init__(self, name, clip8=True, llama8=True, det16=False, kv16=False, last_bf16=0, blk=0, first_bf16=0, o16=False, down16=False, det_from=0,
+                 out16=False, smooth=False):
         self.__dict__.update(locals())
 
 
@@ -52,7 +56,8 @@ def lin16(x, w, b=None):
 
 
 def main():
-    which = sys.argv[1] if len(sys.argv) > 1 else "tiny"
+    which = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "tiny"
+    outl = float(sys.argv[sys.argv.index("--outliers") + 1]) if "--outliers" in sys.argv else 0.0
     from grove_amd.synthetic import TINY, synthetic_batch, synthetic_state_dict
     from oracle import grove_oracle as O
     from tests.test_full_depth_gpu import deep_narrow_dims
@@ -64,7 +69,9 @@ def main():
         d = deep_narrow_dims()
         B, L, n_det, seed = 1, 128, 3, 11
     torch.set_num_threads(os.cpu_count() or 8)
-    sd = {k: v.to(bf).float() for k, v in synthetic_state_dict(d).items()}
+    sd = {k: v.to(bf).float() for k, v in synthetic_state_dict(d, outliers=outl).items()}
+    from grove_amd.synthetic import outlier_channels
+    och = list(outlier_channels(d))
     batch = synthetic_batch(d, B=B, T=8, L=L, n_det=n_det, seed=seed)
     kw = batch.as_kwargs(inference=True)
     gi, si = kw["global_enc_images"].to(bf).float(), kw["grounding_enc_images"].to(bf).float()
@@ -108,10 +115,19 @@ def main():
         def proj(name, h, li, kind):
             w = sd[name + ".weight"]
             full16 = (not pol.llama8) or li >= d.n_layers - pol.last_bf16 or li < pol.first_bf16 or (pol.kv16 and kind in ("k", "v")) \
+                or (pol.first_bf16 < 0 and li < -pol.first_bf16 and kind in ("o", "down")) \
                 or (pol.o16 and kind == "o") or (pol.down16 and kind == "down")
             if full16:
                 return lin16(h, w)
-            y = lin8(h, w, None, pol)
+            if pol.out16 and kind in ("q", "k", "v", "gate", "up"):
+                h0 = h.clone()
+                h0[..., och] = 0.0
+                y = r16(F.linear(q8(r16(h0), pol.blk), q8(w, pol.blk)) + F.linear(r16(h[..., och]), w[:, och]))
+            elif pol.smooth and kind in ("q", "k", "v", "gate", "up"):
+                sj = (r16(h).abs().amax(dim=(0, 1)).clamp_min(1e-5) / w.abs().amax(0).clamp_min(1e-5)).sqrt()
+                y = r16(F.linear(q8(r16(h / sj), pol.blk), q8(w * sj, pol.blk)))
+            else:
+                y = lin8(h, w, None, pol)
             if pol.det16 and li >= pol.det_from:
                 for b in range(Bc):
                     y[b, det_pos[b]] = lin16(h[b, det_pos[b]], w)
@@ -134,7 +150,15 @@ def main():
     def rms(a, b):
         return ((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt()).item()
 
-    pols = [Policy("bf16 (no fp8)", clip8=False, llama8=False),
+    if outl:
+        pols = [Policy("bf16 (no fp8)", clip8=False, llama8=False), Policy("all8"), Policy("all8 + out16", out16=True), Policy("all8 + smooth", smooth=True),
+                Policy("det16_kv16", det16=True, kv16=True), Policy("det16_kv16 + out16", det16=True, kv16=True, out16=True),
+                Policy("det16_kv16 + smooth", det16=True, kv16=True, smooth=True),
+                Policy("all8, first 2 layers bf16", first_bf16=2), Policy("det16_kv16, first 2 layers bf16", det16=True, kv16=True, first_bf16=2),
+                Policy("det16_kv16, o/down of layers 0-1 bf16", det16=True, kv16=True, first_bf16=-2),
+                Policy("det16_kv16 clip16", det16=True, kv16=True, clip8=False), Policy("clip8 llama16", llama8=False)]
+    else:
+      pols = [Policy("bf16 (no fp8)", clip8=False, llama8=False),
             Policy("all8"),
             Policy("all8 blk32", blk=32),
             Policy("clip16 llama8", clip8=False),
@@ -169,7 +193,7 @@ def main():
             rows.append(r)
             print(json.dumps(r), flush=True)
     os.makedirs("gpurun_out", exist_ok=True)
-    with open(f"gpurun_out/fp8_policy_study_{which}.json", "w") as fh:
+    with open(f"gpurun_out/fp8_policy_study_{which}{'_outliers%g' % outl if outl else ''}.json", "w") as fh:
         json.dump(rows, fh, indent=1)
 
 
