@@ -396,7 +396,9 @@ def test_full_width_box_l1_over_seeds(dev):
 # measured (profiles/r03_full_depth_fp8_parity_*.json): deep_narrow all 1.06e-2 / 9.6 %, deep_narrow det16_kv16 6.5e-3 / 8.7 %,
 # full det16_kv16 1.29e-2 / 11.4 % (full "all": 1.65e-2 / 12.2 %, profiles/r03_full_depth_fp8_parity_full_all8.json)
 FP8_BOUNDS = {("deep_narrow", "all"): {"box_l1": 1.6e-2, "hidden_rms": 0.145}, ("deep_narrow", "det16_kv16"): {"box_l1": 1.0e-2, "hidden_rms": 0.13},
-              ("full", "det16_kv16"): {"box_l1": 1.95e-2, "hidden_rms": 0.17}}
+              ("full", "det16_kv16"): {"box_l1": 1.95e-2, "hidden_rms": 0.17},
+              # round 4 (profiles/r04_fp8_clip_policy_deep_narrow.json): CLIP tower in bf16 — 4.6e-3 / 6.2 %; with outliers 9.6e-4 (1.84e-2 with CLIP in e4m3)
+              ("deep_narrow", "det16_kv16_clip16"): {"box_l1": 7e-3, "hidden_rms": 0.095}}
 
 
 def run_fp8_parity(dev, which, policy, outliers=0.0):
@@ -448,7 +450,7 @@ def run_fp8_parity(dev, which, policy, outliers=0.0):
     return res
 
 
-@pytest.mark.parametrize("which,policy", [("deep_narrow", "all"), ("deep_narrow", "det16_kv16"), ("full", "det16_kv16")])
+@pytest.mark.parametrize("which,policy", [("deep_narrow", "all"), ("deep_narrow", "det16_kv16"), ("deep_narrow", "det16_kv16_clip16"), ("full", "det16_kv16")])
 def test_full_depth_fp8_inference_vs_fp32_oracle(dev, which, policy):
     res = run_fp8_parity(dev, which, policy)
     n_q = res["n_q"]
@@ -543,3 +545,7 @@ def test_outlier_stress_deep_narrow(dev):
     assert not bad, bad
     q = run_fp8_parity(dev, "deep_narrow", "det16_kv16", outliers=F)
     assert q["box_l1_vs_oracle"] <= 2.9e-2 and q["llama_hidden_rel_rms"] <= 0.16, q
+    # the excess is the e4m3 CLIP tower (tools/fp8_policy_study.py --outliers: SmoothQuant scaling, bf16 side products for the outlier
+    # channels and bf16 first layers change nothing; CLIP in bf16 does): 9.6e-4 measured (profiles/r04_fp8_clip_policy_deep_narrow.json)
+    q16 = run_fp8_parity(dev, "deep_narrow", "det16_kv16_clip16", outliers=F)
+    assert q16["box_l1_vs_oracle"] <= 1.5e-3 and q16["box_l1_vs_oracle"] < 0.2 * q["box_l1_vs_oracle"], (q16, q)
