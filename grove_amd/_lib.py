@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("GROVE_HIP_LIB") or os.path.join(_HERE, "csrc", "libgr
 
 c_i32, c_i64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
-ACT_NONE, ACT_RELU, ACT_GELU, ACT_QUICKGELU, ACT_SILU, ACT_SIGMOID, ACT_SWIGLU_PAIR = range(7)
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_QUICKGELU, ACT_SILU, ACT_SIGMOID, ACT_SWIGLU_PAIR, ACT_SWIGLU_BWD = range(8)
 BF16, F32 = 0, 1
 
 

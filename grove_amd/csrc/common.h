@@ -83,6 +83,17 @@ __device__ __forceinline__ float fast_erf(float x) {
 // sigmoid-shaped activation of the path goes through it, so fused and unfused forms stay bit-identical to each other.
 __device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 
+// d(gate), d(up) of silu(gate) * up for one element. ONE definition with floating-point contraction OFF: the elementwise kernel
+// (grove_swiglu_bwd), the GEMM epilogue (GROVE_ACT_SWIGLU_BWD) and its stream-K fix-up kernel are three compilation contexts, and
+// hipcc fuses multiply-adds differently in each — with the contraction left to it the three differed in the last bf16 bit.
+__device__ __forceinline__ void swiglu_bwd_elem(const float d, const float g, const float u, float& dg, float& du) {
+#pragma clang fp contract(off)
+  const float s = fast_sigmoid(g);
+  const float gs = g * s;
+  dg = (d * u) * (s + gs * (1.f - s));
+  du = d * gs;
+}
+
 __device__ __forceinline__ float act_apply(int act, float x) {
   switch (act) {
     case GROVE_ACT_RELU: return fmaxf(x, 0.f);

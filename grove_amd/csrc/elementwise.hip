@@ -46,11 +46,7 @@ __global__ __launch_bounds__(EB) void swiglu_bwd_kernel(const bf16_raw* __restri
     unpack8(*(const u32x4_t*)(gu + (int64_t)r * 2 * I + I + c), u);
     unpack8(*(const u32x4_t*)(dy + (int64_t)r * I + c), d);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float s = fast_sigmoid(g[e]);
-      dg[e] = d[e] * u[e] * (s + g[e] * s * (1.f - s));
-      du[e] = d[e] * g[e] * s;
-    }
+    for (int e = 0; e < 8; ++e) swiglu_bwd_elem(d[e], g[e], u[e], dg[e], du[e]);
     *(u32x4_t*)(dgu + (int64_t)r * 2 * I + c) = pack8(dg);
     *(u32x4_t*)(dgu + (int64_t)r * 2 * I + I + c) = pack8(du);
   }

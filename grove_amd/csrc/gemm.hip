@@ -692,6 +692,55 @@ __device__ __forceinline__ void gemm_epilogue_wide(const grove_gemm_params& p, f
   }
 }
 
+// GROVE_ACT_SWIGLU_BWD (round 4): the backward of LlamaMLP's silu(gate) * up in the epilogue of the down-projection's dgrad GEMM. The
+// accumulators are d a (rounded to bf16 first: the value the unfused path stores and reads back, so the outputs are grove_swiglu_bwd's
+// bit for bit); gate | up = the saved pre-activations (p.residual: [M, >= 2N], up at column N + n); C [M, >= 2N] gets d gate at column n
+// and d up at N + n. One function for interior and edge tiles (rows clamped for the loads, stores predicated; N % 8 == 0). Per A half: all
+// four 16-byte loads of a row fragment pair are issued first (they queue behind the previous half's stores once, not once per store),
+// then every (row fragment, column group) is computed and stored straight away — 2 loads + 2 stores per 8 outputs.
+template <int MIH, int BMH>
+__device__ __forceinline__ void gemm_epilogue_swiglu_bwd(const grove_gemm_params& p, f32x4_t (&acc)[2 * MIH][4], const int mw0, const int nw0,
+                                                         const int fr, const int fq) {
+  const bf16_raw* __restrict__ gu = (const bf16_raw*)p.residual;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    u32x4_t gq[MIH][2], uq[MIH][2];
+    const int row0 = mw0 + h * BMH + fr;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int nc8 = min(nw0 + g * 128 + fq * 8, p.N - 8);
+#pragma unroll
+      for (int i = 0; i < MIH; ++i) {
+        const bf16_raw* rp = gu + (int64_t)min(row0 + i * 16, p.M - 1) * p.ldr + nc8;
+        gq[i][g] = *(const u32x4_t*)rp;
+        uq[i][g] = *(const u32x4_t*)(rp + p.N);
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int n = nw0 + g * 128 + fq * 8;
+#pragma unroll
+      for (int i = 0; i < MIH; ++i) {
+        const f32x4_t a0 = acc[h * MIH + i][2 * g], a1 = acc[h * MIH + i][2 * g + 1];
+        const unsigned d01 = pack2bf(a0[0] * p.alpha, a0[1] * p.alpha), d23 = pack2bf(a0[2] * p.alpha, a0[3] * p.alpha);
+        const unsigned d45 = pack2bf(a1[0] * p.alpha, a1[1] * p.alpha), d67 = pack2bf(a1[2] * p.alpha, a1[3] * p.alpha);
+        const float dv[8] = {bf_lo(d01), bf_hi(d01), bf_lo(d23), bf_hi(d23), bf_lo(d45), bf_hi(d45), bf_lo(d67), bf_hi(d67)};
+        const u32x4_t gp = gq[i][g], up = uq[i][g];
+        const float gv[8] = {bf_lo(gp.x), bf_hi(gp.x), bf_lo(gp.y), bf_hi(gp.y), bf_lo(gp.z), bf_hi(gp.z), bf_lo(gp.w), bf_hi(gp.w)};
+        const float uv[8] = {bf_lo(up.x), bf_hi(up.x), bf_lo(up.y), bf_hi(up.y), bf_lo(up.z), bf_hi(up.z), bf_lo(up.w), bf_hi(up.w)};
+        float dg[8], du[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) swiglu_bwd_elem(dv[e], gv[e], uv[e], dg[e], du[e]);
+        if (n < p.N && row0 + i * 16 < p.M) {
+          bf16_raw* c = (bf16_raw*)p.C + (int64_t)(row0 + i * 16) * p.ldc + n;
+          *(u32x4_t*)c = u32x4_t{pack2bf(dg[0], dg[1]), pack2bf(dg[2], dg[3]), pack2bf(dg[4], dg[5]), pack2bf(dg[6], dg[7])};
+          *(u32x4_t*)(c + p.N) = u32x4_t{pack2bf(du[0], du[1]), pack2bf(du[2], du[3]), pack2bf(du[4], du[5]), pack2bf(du[6], du[7])};
+        }
+      }
+    }
+  }
+}
+
 __device__ __forceinline__ void wait_vm_loads(int n) {  // n (even) = vector-memory operations allowed to stay in flight
   if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   else if (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -1058,9 +1107,10 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
       const int mw0 = m0 + wr * WRH, nw0 = n0 + wc * 32;
       const bool interior = fast_addr && m0 + BM <= p.M && n0 + P_BN <= p.N;
       if constexpr (FP8) fp8_scale_acc<MIH, BMH>(p, work, acc, mw0, nw0, fr, fq);
-      if (interior) gemm_epilogue_fast<MIH, BMH, ACT>(p, acc, mw0, nw0, fr, fq, ACT < 0 ? 1.f : scale);
+      if constexpr (ACT == GROVE_ACT_SWIGLU_BWD) gemm_epilogue_swiglu_bwd<MIH, BMH>(p, acc, mw0, nw0, fr, fq);
+      else if (interior) gemm_epilogue_fast<MIH, BMH, ACT>(p, acc, mw0, nw0, fr, fq, ACT < 0 ? 1.f : scale);
       else gemm_epilogue_wide<MIH, BMH, ACT>(p, acc, mw0, nw0, fr, fq, ACT < 0 ? 1.f : scale);
-      relax = interior && !p.aux && !FP8;  // exactly 4 * MIH stores per wave were issued (FP8: the scale loads sit in the queue too)
+      relax = interior && !p.aux && !FP8 && ACT != GROVE_ACT_SWIGLU_BWD;  // exactly 4 * MIH stores per wave were issued (FP8: the scale loads sit in the queue too)
     }
     if constexpr (FP8) {
 #pragma unroll
@@ -1114,7 +1164,8 @@ __global__ __launch_bounds__(64 * FIX_WAVES) void gemm_pp_fixup_kernel(const gro
   const int mw0 = m0 + wr * WRH, nw0 = n0 + wc * 32;
   const bool interior = fast_addr && m0 + BM <= p.M && n0 + P_BN <= p.N;
   if constexpr (FP8) fp8_scale_acc<MIH, BMH>(p, work, acc, mw0, nw0, fr, fq);
-  if (interior) gemm_epilogue_fast<MIH, BMH, ACT>(p, acc, mw0, nw0, fr, fq, ACT < 0 ? 1.f : scale);
+  if constexpr (ACT == GROVE_ACT_SWIGLU_BWD) gemm_epilogue_swiglu_bwd<MIH, BMH>(p, acc, mw0, nw0, fr, fq);
+  else if (interior) gemm_epilogue_fast<MIH, BMH, ACT>(p, acc, mw0, nw0, fr, fq, ACT < 0 ? 1.f : scale);
   else gemm_epilogue_wide<MIH, BMH, ACT>(p, acc, mw0, nw0, fr, fq, ACT < 0 ? 1.f : scale);
 }
 
@@ -1577,7 +1628,8 @@ int launch_pp_act(const grove_gemm_params& p, hipStream_t s, const float* row_sc
 // the gathered instances carry the epilogues their callers use (plain, scaled, ReLU: window (un)partition, Conv3d adapters)
 inline bool pp_act_ok(const grove_gemm_params& p) {
   if (p.a_idx) return p.act == GROVE_ACT_NONE || p.act == GROVE_ACT_RELU;
-  return p.act == GROVE_ACT_NONE || p.act == GROVE_ACT_GELU || p.act == GROVE_ACT_QUICKGELU || p.act == GROVE_ACT_RELU || p.act == GROVE_ACT_SWIGLU_PAIR;
+  return p.act == GROVE_ACT_NONE || p.act == GROVE_ACT_GELU || p.act == GROVE_ACT_QUICKGELU || p.act == GROVE_ACT_RELU || p.act == GROVE_ACT_SWIGLU_PAIR ||
+         p.act == GROVE_ACT_SWIGLU_BWD;
 }
 template <int BM, bool GATHER>
 int launch_pp(const grove_gemm_params& p, hipStream_t s) {
@@ -1590,6 +1642,7 @@ int launch_pp(const grove_gemm_params& p, hipStream_t s) {
     if (p.act == GROVE_ACT_GELU) return launch_pp_act<BM, false, GROVE_ACT_GELU>(p, s);
     if (p.act == GROVE_ACT_QUICKGELU) return launch_pp_act<BM, false, GROVE_ACT_QUICKGELU>(p, s);
     if (p.act == GROVE_ACT_SWIGLU_PAIR) return launch_pp_act<BM, false, GROVE_ACT_SWIGLU_PAIR>(p, s);
+    if (p.act == GROVE_ACT_SWIGLU_BWD) return launch_pp_act<BM, false, GROVE_ACT_SWIGLU_BWD>(p, s);
   }
   GROVE_CHECK(false, GROVE_E_SHAPE, "gemm: no pipelined instance for act %d%s", p.act, GATHER ? " with gathered A" : "");
 }
@@ -1827,6 +1880,14 @@ static int gemm_bf16_dispatch(const grove_gemm_params* pp, void* stream) {
                 GROVE_E_SHAPE, "gemm: n_group/k_group maps need the pipelined kernel (bf16 C, no aux; k map: gathered A with one tap)");
     g_gemm_last_variant = cp256 <= cp192 ? (p.a_idx ? GROVE_GEMM_PP256_GATHER : GROVE_GEMM_PP256) : (p.a_idx ? GROVE_GEMM_PP192_GATHER : GROVE_GEMM_PP192);
     if (p.a_idx) return cp256 <= cp192 ? launch_pp<256, true>(p, s) : launch_pp<192, true>(p, s);
+    return cp256 <= cp192 ? launch_pp<256, false>(p, s) : launch_pp<192, false>(p, s);
+  }
+  if (p.act == GROVE_ACT_SWIGLU_BWD) {  // only the pipelined kernel's epilogue implements it
+    GROVE_CHECK(p256_ok && !p.a_idx && p.residual && !p.bias && !p.aux && !p.c_idx && !p.r_idx && !maps && p.c_dtype == GROVE_BF16 && !p.scale_ptr &&
+                    !p.residual_mul && p.ldc >= 2 * p.N && p.ldr >= 2 * p.N && p.ldc % 8 == 0,
+                GROVE_E_SHAPE, "gemm: act SWIGLU_BWD needs the pipelined kernel (plain un-batched bf16 GEMM, K %% 64 == 0, N %% 8 == 0) with residual = "
+                               "gate | up [M, >= 2N], C [M, >= 2N] and no bias / aux / row maps / scale");
+    g_gemm_last_variant = cp256 <= cp192 ? GROVE_GEMM_PP256 : GROVE_GEMM_PP192;
     return cp256 <= cp192 ? launch_pp<256, false>(p, s) : launch_pp<192, false>(p, s);
   }
   if (p.act == GROVE_ACT_SWIGLU_PAIR) {  // only the pipelined kernel's epilogue implements it

@@ -78,6 +78,14 @@ class LlamaStack:
 
     fuse_rope_bwd = __import__("os").environ.get("GROVE_FUSE_ROPE_BWD", "1") != "0"  # inverse RoPE inside the attention backward kernels (A/B knob)
     rope_from_table = __import__("os").environ.get("GROVE_ROPE_TABLE", "1") != "0"   # forward RoPE reads cos | sin from the table (A/B knob)
+    fuse_swiglu_bwd = __import__("os").environ.get("GROVE_FUSE_SWIGLU_BWD", "1") != "0"  # d(gate | up) in the down-proj dgrad GEMM's epilogue (A/B knob)
+
+    def _mlp_dgu(self, L, dx, gu, I):
+        """d(gate | up) [rows, 2I] from d x2 [rows, H]: the down-projection's dgrad with SwiGLU's backward in its epilogue (round 4:
+        one GEMM instead of GEMM -> [rows, I] -> grove_swiglu_bwd; bit-identical), or the two launches (A/B arm, K % 64 != 0)."""
+        if self.fuse_swiglu_bwd and L["wd_t"].shape[1] % 64 == 0 and I % 8 == 0:
+            return ops.linear(dx, L["wd_t"], act=ops.ACT_SWIGLU_BWD, residual=gu)
+        return ops.swiglu_bwd(gu, ops.linear(dx, L["wd_t"]), I)
 
     def _rope_table(self, S):
         """cos | sin of positions 0 .. S-1 (f32 [>= S, head_dim], ops.rope_table), grown on demand."""
@@ -141,8 +149,7 @@ class LlamaStack:
         n_t = B * Lq
         tail_idx, pos_t = self._tail_index(B, S, s0)
         pos = torch.arange(S, dtype=torch.int32, device=self.dev).repeat(B)
-        da = ops.linear(dx_t, L["wd_t"])
-        dgu = ops.swiglu_bwd(gu, da, I)
+        dgu = self._mlp_dgu(L, dx_t, gu, I)
         dh2 = ops.linear(dgu, L["wgu_t"])
         ops.rmsnorm_bwd(x1_t, L["ln2"], dh2, d.rms_eps, dx=dx_t, accumulate=True)    # dx_t now d x1 (tail rows)
         do = ops.linear(dx_t, L["wo_t"])
@@ -361,9 +368,7 @@ class LlamaStack:
                 continue
             x, qkv, actx, x1, gu = sv
             # x2 = x1 + down(swiglu(gu));  dx is d x2
-            da = ops.linear(dx, L["wd_t"])                      # [B*S, I]
-            dgu = ops.swiglu_bwd(gu, da, I)
-            del da
+            dgu = self._mlp_dgu(L, dx, gu, I)                    # [B*S, 2I]
             dh2 = ops.linear(dgu, L["wgu_t"])                   # [B*S, H]
             del dgu
             ops.rmsnorm_bwd(x1, L["ln2"], dh2, d.rms_eps, dx=dx, accumulate=True)   # dx now d x1

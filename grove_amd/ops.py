@@ -10,7 +10,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import (ACT_GELU, ACT_NONE, ACT_QUICKGELU, ACT_RELU, ACT_SIGMOID, ACT_SILU, ACT_SWIGLU_PAIR, BF16, F32)  # noqa: F401
+from ._lib import (ACT_GELU, ACT_NONE, ACT_QUICKGELU, ACT_RELU, ACT_SIGMOID, ACT_SILU, ACT_SWIGLU_BWD, ACT_SWIGLU_PAIR, BF16, F32)  # noqa: F401
 
 bf16 = torch.bfloat16
 
@@ -181,7 +181,7 @@ def linear(x, w, bias=None, *, act=ACT_NONE, residual=None, out=None, out_dtype=
         assert x2.shape[1] == K, f"linear: x has K={x2.shape[1]}, weight has K={K}"
     if out is None:
         rows = out_rows if out_rows is not None else M
-        cols = out_cols if out_cols is not None else (N // 2 if act == ACT_SWIGLU_PAIR else N)
+        cols = out_cols if out_cols is not None else (N // 2 if act == ACT_SWIGLU_PAIR else 2 * N if act == ACT_SWIGLU_BWD else N)
         out = torch.empty((rows, cols), dtype=out_dtype, device=x.device)
     ldr = residual.stride(0) if residual is not None else 0
     gemm_raw(x2, w, out, M, N, K, x2.stride(0), w.stride(0), out.stride(0), bias=bias, residual=residual, ldr=ldr,

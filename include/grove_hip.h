@@ -43,9 +43,15 @@ enum grove_act {
   GROVE_ACT_QUICKGELU = 3, /* CLIP MLP (modeling_clip.py:336-348) */
   GROVE_ACT_SILU = 4,      /* LLaMA SwiGLU gate */
   GROVE_ACT_SIGMOID = 5,
-  GROVE_ACT_SWIGLU_PAIR = 6 /* LlamaMLP's silu(gate) * up folded into the gate|up GEMM: B rows interleaved [4 gate, 4 up] per 8, C gets
+  GROVE_ACT_SWIGLU_PAIR = 6, /* LlamaMLP's silu(gate) * up folded into the gate|up GEMM: B rows interleaved [4 gate, 4 up] per 8, C gets
                                N / 2 columns (the product), aux (optional, row stride ld_aux) the un-interleaved gate | up pre-activations;
                                pipelined kernel only */
+  GROVE_ACT_SWIGLU_BWD = 7   /* round 4: the BACKWARD of that product folded into the down-projection's dgrad GEMM. With d = the GEMM's own
+                               output (d a = dy . W_down, N = I columns, rounded to bf16 as the unfused path stores it) and the saved
+                               pre-activations gate | up = residual[m, n], residual[m, N + n] (row stride ldr >= 2N):
+                                 C[m, n] = d u (s + g s (1 - s)),  C[m, N + n] = d g s,  s = sigmoid(g)      (C: bf16, ldc >= 2N)
+                               = grove_swiglu_bwd's d(gate | up), bit for bit, without the [M, I] round trip. No bias / aux / c_idx /
+                               n_group; pipelined kernel only */
 };
 
 enum grove_dtype { GROVE_BF16 = 0, GROVE_F32 = 1 };

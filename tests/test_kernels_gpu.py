@@ -274,6 +274,40 @@ def test_gemm_few_tiles_long_k_is_cut_over_the_idle_cus(dev, M, N, K):
     close(o1, o0, 2 ** -7, "few tiles, cut K vs whole tiles")
 
 
+@pytest.mark.parametrize("M,I,K", [(2812, 11008, 4096), (1400, 11008, 4096), (260, 2752, 1024), (703, 1024, 512)])
+def test_swiglu_backward_in_the_dgrad_epilogue(dev, M, I, K):
+    """Round 4: GROVE_ACT_SWIGLU_BWD — d(gate | up) of LlamaMLP's silu(gate) * up computed in the epilogue of the down-projection's dgrad
+    GEMM (C [M, 2I] from d a = dy . W^T [M, I] and the saved gate | up [M, 2I]). BIT-identical to the two launches it replaces (the GEMM to
+    bf16, then grove_swiglu_bwd) — whole tiles, edge rows, the stream-K fix-up path ((1400, 11008): one round + 2 tiles) and the few-tile
+    cut — and against torch autograd of the product in fp32."""
+    from grove_amd import _lib, ops
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(M + I)
+    dy = (torch.randn(M, K, generator=g) * 0.5).to(bf16).to(dev)
+    w = (torch.randn(I, K, generator=g) * 0.05).to(bf16).to(dev)           # W_down^T: [I, H]
+    gu = (torch.randn(M, 2 * I, generator=g) * 1.5).to(bf16).to(dev)
+    try:  # both forms on the SAME kernel and plan (left to itself the plain GEMM of a shape may take another kernel: another fp32 sum order)
+        for tile in (193, 256):
+            L.grove_gemm_set_tile_m(tile)
+            da = ops.linear(dy, w)
+            plan = (L.grove_gemm_last_variant(), L.grove_gemm_last_stream_k())
+            want = ops.swiglu_bwd(gu, da, I)
+            out = ops.linear(dy, w, act=ops.ACT_SWIGLU_BWD, residual=gu, out=torch.full((M, 2 * I), float("nan"), dtype=bf16, device=dev))
+            assert (L.grove_gemm_last_variant(), L.grove_gemm_last_stream_k()) == plan and plan[0] in (4, 5)
+            assert torch.equal(out, want), (tile, (out.float() - want.float()).abs().max().item())
+    finally:
+        L.grove_gemm_set_tile_m(0)
+    out = ops.linear(dy, w, act=ops.ACT_SWIGLU_BWD, residual=gu, out=torch.full((M, 2 * I), float("nan"), dtype=bf16, device=dev))  # automatic dispatch
+    assert L.grove_gemm_last_variant() in (4, 5)
+    close(out, want, 2 ** -6, "automatic dispatch vs the two launches")
+    gate, up = gu[:, :I].float().requires_grad_(), gu[:, I:].float().requires_grad_()
+    (torch.nn.functional.silu(gate) * up).backward(da.float())
+    close(out[:, :I], gate.grad, 2 ** -7, "d gate vs autograd")
+    close(out[:, I:], up.grad, 2 ** -7, "d up vs autograd")
+    with pytest.raises(RuntimeError):
+        ops.linear(dy, w, act=ops.ACT_SWIGLU_BWD)        # no gate | up operand
+
+
 def test_gemm_stream_k_gathered_taps(dev):
     """The gathered-A instances under the stream-K tail: a K range that starts inside the tap list (27-tap Conv3d rows, -1 = zero
     row; 2 K tiles per tap, parts of 14 K tiles) with the ReLU + residual + tanh'd scale epilogue the adapters use."""

@@ -408,7 +408,10 @@ def test_fp8_vit_llama_path_vs_oracle_and_bf16(dev):
     d = dataclasses.replace(TINY, clip_dim=128, clip_heads=2, clip_mlp=256)  # every GEMM K a multiple of the fp8 kernel's 128
     sd = synthetic_state_dict(d)
     sd_r = {k: v.to(bf).float() for k, v in sd.items()}
-    m8 = GROVEForCausalLM(dims=d, device=dev, state_dict=sd, det_token_idx=d.det_token_idx, num_frames=8, pe_dtype=torch.float32, gemm_dtype="fp8")
+    m8 = GROVEForCausalLM(dims=d, device=dev, state_dict=sd, det_token_idx=d.det_token_idx, num_frames=8, pe_dtype=torch.float32, gemm_dtype="fp8",
+                          fp8_policy="det16_kv16")
+    m8c = GROVEForCausalLM(dims=d, device=dev, state_dict=sd, det_token_idx=d.det_token_idx, num_frames=8, pe_dtype=torch.float32, gemm_dtype="fp8")
+    assert m8c.fp8_policy == "det16_kv16_clip16" and not any("w1_q" in L for L in m8c.clip.layers) and all("wq_q" in L for L in m8c.llama.layers)  # round-4 default
     m8a = GROVEForCausalLM(dims=d, device=dev, state_dict=sd, det_token_idx=d.det_token_idx, num_frames=8, pe_dtype=torch.float32, gemm_dtype="fp8",
                            fp8_policy="all")
     assert m8.fp8_policy == "det16_kv16" and all("wq_q" in L and "wkv" in L for L in m8.llama.layers) and not any("wq_q" in L for L in m8a.llama.layers)
@@ -419,7 +422,7 @@ def test_fp8_vit_llama_path_vs_oracle_and_bf16(dev):
     batch = synthetic_batch(d, B=2, T=8, L=40, n_det=3, seed=2)
     kw = to_dev(batch, dev)
     kw["inference"] = True
-    o8, o8a, o16 = m8(**kw), m8a(**kw), m16(**kw)
+    o8, o8a, o16, o8c = m8(**kw), m8a(**kw), m16(**kw), m8c(**kw)
     kwo = batch.as_kwargs(inference=True)
     kwo["global_enc_images"], kwo["grounding_enc_images"] = kwo["global_enc_images"].to(bf).float(), kwo["grounding_enc_images"].to(bf).float()
     with torch.no_grad():
@@ -441,6 +444,9 @@ def test_fp8_vit_llama_path_vs_oracle_and_bf16(dev):
     assert l1_16 < 1e-3 and l1_8 < 9.5e-3 and l1_8a < 1.55e-2, (l1_16, l1_8, l1_8a)  # 1.5 x (6.3e-3, 1.03e-2)
     assert l1_8 < l1_8a, "keeping k/v and the [DET] rows in bf16 must not make the boxes worse"
     assert obj8 < 0.2
+    l1_8c = (o8c["flat_boxes"].cpu() - ref["flat_boxes"]).abs().mean().item()
+    print(f"fp8 default policy (det16_kv16 + CLIP in bf16): box L1 {l1_8c:.3e}")
+    assert l1_8c < 9.5e-3
 
 
 def test_T32_inference_windows_and_masks(dev):
