@@ -167,6 +167,21 @@ def three_steps():
     return torch.stack(ls), eng.master.clone()
 REPS = max(REPS // 6, 4)
 screen("3 training steps, deterministic mode (self)", three_steps, three_steps)
+# ... and at FULL size (the shapes, grids and stream overlaps the bench runs): one engine, the same batch three times from the same
+# weights (gradients and losses compared; no optimizer step), towers overlapped
+if "--no-full" not in sys.argv:
+    from grove_amd.synthetic import FULL
+    args = TR.shipped_args(); args.lr, args.num_frames, args.batch_size = 1e-4, 16, 2
+    eng = TR.GroveEngine(TR.initialize_model(args, dims=FULL, state_dict=synthetic_state_dict(FULL, device=dev, dtype=bf), device=dev), args, total_steps=1000)
+    kwf = synthetic_batch(FULL, B=2, T=16, L=128, n_det=3, seed=3, device=dev, dtype=bf).as_kwargs()
+    def full_step():
+        eng.module.zero_grad()
+        out = eng(**kwf)
+        eng.backward(out["loss"])
+        torch.cuda.synchronize()
+        return torch.stack([out[k].detach().float().reshape(()) for k in sorted(out) if k.endswith("loss")]), eng.module._flat_grad.clone()
+    REPS = 3
+    screen("full-size fwd + bwd (2 clips x T = 16), deterministic mode (self)", full_step, full_step)
 ops.set_deterministic(False)
 print("TOTAL MISMATCHES", bad)
 sys.exit(1 if bad else 0)
