@@ -115,6 +115,14 @@ __device__ __forceinline__ bf16x8_t efrag_key(unsigned kb, int bin0, int KH) {
   for (int jj = 0; jj < 8; ++jj) e[jj] = ((bin0 + jj) == kh || (bin0 + jj) == kwb) ? (short)0x3F80 : (short)0;
   return __builtin_bit_cast(bf16x8_t, e);
 }
+// 8-bin indicator fragment with a 1.0 at position idx (none if idx is outside 0..7)
+__device__ __forceinline__ bf16x8_t onehot8(const int idx) {
+  typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+  s16x8_t e;
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) e[jj] = jj == idx ? (short)0x3F80 : (short)0;
+  return __builtin_bit_cast(bf16x8_t, e);
+}
 // rel'[q][bin0 .. bin0+7] (bf16, already divided by alpha; rows are rel_ld wide, rel_ld % 8 == 0)
 __device__ __forceinline__ bf16x8_t relfrag(const bf16_raw* relrow, int bin0, int rel_ld) {
   if (bin0 < rel_ld) return *(const bf16x8_t*)(relrow + bin0);
@@ -205,12 +213,24 @@ __global__ __launch_bounds__(NTHR, 2) void flash_fwd_kernel(const grove_flash_at
   const bf16_raw* K = (const bf16_raw*)p.k + (int64_t)b * p.sk + h * HS;
   const bf16_raw* V = (const bf16_raw*)p.v + (int64_t)b * p.sv + h * HS;
   constexpr bool REL = NRK > 0;
+  // NRK == 3 (round 4, "register E"): rel_kw == rel_kh == 32, rel_ld == 64 (SAM's global blocks) — two bias k-steps whose indicator
+  // fragments never touch LDS: a 64-key tile starts on a row boundary, so a key's kw bin is ((ni & 1) * 16 + fr) for EVERY tile (two
+  // constant fragments) and its kh bin is kv0 / 32 + (ni >> 1) (two fragments per tile, a compare each). The per-tile build of the
+  // LDS image (integer div / mod, 16 compares and 2 LDS writes per thread, 8 LDS reads per wave: 18 % of this kernel) is gone; the
+  // MFMAs and their operands' VALUES are unchanged, so the results are bit-identical to the NRK = 2 instance.
+  constexpr bool FE = NRK == 3;
+  constexpr int NK = FE ? 2 : NRK;
   const int nrel = REL ? p.rel_ld : 0;
-  constexpr int nrk = NRK;  // 32-bin k-steps of the bias MFMA (compile time: 0 without rel, 1 for rel_ld <= 32, else 2)
+  constexpr int nrk = NK;  // 32-bin k-steps of the bias MFMA (compile time: 0 without rel, 1 for rel_ld <= 32, else 2)
   const float sc = p.alpha * 1.4426950408889634f;  // scores live in the exp2 domain
 
   bf16x8_t qf[2][C::KS];
-  bf16x8_t relf[2][NRK > 0 ? NRK : 1];
+  bf16x8_t relf[2][NK > 0 ? NK : 1];
+  bf16x8_t ew[2];
+  if constexpr (FE) {
+    ew[0] = onehot8(fr - g * 8);
+    ew[1] = onehot8(16 + fr - g * 8);
+  }
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi) {
     const int qi = min(q0 + mi * 16 + fr, p.Lq - 1);
@@ -219,7 +239,7 @@ __global__ __launch_bounds__(NTHR, 2) void flash_fwd_kernel(const grove_flash_at
     if (nrk > 0) {
       const bf16_raw* rrow = (const bf16_raw*)p.rel + ((int64_t)(b * p.H + h) * p.Lq + qi) * nrel;
 #pragma unroll
-      for (int k2 = 0; k2 < NRK; ++k2) relf[mi][k2] = scale_frag(relfrag(rrow, k2 * 32 + g * 8, nrel), sc);
+      for (int k2 = 0; k2 < NK; ++k2) relf[mi][k2] = scale_frag(relfrag(rrow, k2 * 32 + g * 8, nrel), sc);
     }
   }
   f32x4_t oacc[2][C::DT];
@@ -241,7 +261,7 @@ __global__ __launch_bounds__(NTHR, 2) void flash_fwd_kernel(const grove_flash_at
     __syncthreads();
     store_tile<HS>(Ks, kreg, tid);
     store_tile<HS>(Vs, vreg, tid);
-    if (nrk > 0) build_etile(Es, kv0, p.Lk, p.rel_kw, p.rel_kh, nrel, tid);
+    if (nrk > 0 && !FE) build_etile(Es, kv0, p.Lk, p.rel_kw, p.rel_kh, nrel, tid);
     __syncthreads();
     if (kv0 + BKV < kv_lim) {
       load_tile<HS>(kreg, K, p.ld_k, kv0 + BKV, p.Lk, tid);
@@ -271,8 +291,10 @@ __global__ __launch_bounds__(NTHR, 2) void flash_fwd_kernel(const grove_flash_at
           for (int mi = 0; mi < 2; ++mi) s[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[mi][ks], s[mi][ni], 0, 0, 0);
         }
 #pragma unroll
-        for (int k2 = 0; k2 < NRK; ++k2) {
-          const bf16x8_t ef = lds_row_frag(Es, ESB, ni * 16 + fr, k2 * 4 + g);
+        for (int k2 = 0; k2 < NK; ++k2) {
+          bf16x8_t ef;
+          if constexpr (FE) ef = k2 == 0 ? onehot8((kv0 >> 5) + (ni >> 1) - g * 8) : ew[ni & 1];
+          else ef = lds_row_frag(Es, ESB, ni * 16 + fr, k2 * 4 + g);
 #pragma unroll
           for (int mi = 0; mi < 2; ++mi) s[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ef, relf[mi][k2], s[mi][ni], 0, 0, 0);
         }
@@ -800,6 +822,11 @@ bool grove_win_attn_applicable(const grove_flash_attn_params* p);
 int grove_win_attn_fwd_launch(const grove_flash_attn_params* p, hipStream_t s);
 int grove_win_attn_bwd_launch(const grove_flash_attn_params* p, hipStream_t s);
 static int g_win_attn = 1;  // 0 = always the general kernels (A/B arm: grove_flash_attn_set_window_kernels)
+static int g_reg_e = 1;     // 0 = the LDS indicator tile also where the register form applies (A/B arm: grove_flash_attn_set_register_e)
+extern "C" int grove_flash_attn_set_register_e(int32_t on) {
+  g_reg_e = on != 0;
+  return GROVE_OK;
+}
 extern "C" int grove_flash_attn_set_window_kernels(int32_t on) {
   g_win_attn = on != 0;
   return GROVE_OK;
@@ -830,7 +857,9 @@ extern "C" int grove_flash_attn_fwd(const grove_flash_attn_params* p, void* stre
 #define FWD(HS)                                                                                            \
   {                                                                                                        \
     const size_t lds = lds_fwd<HS>(p);                                                                     \
-    if (!p->rel) FWD_L(HS, 0) else if (p->rel_ld <= 32) FWD_L(HS, 1) else FWD_L(HS, 2)                      \
+    if (!p->rel) FWD_L(HS, 0) else if (p->rel_ld <= 32) FWD_L(HS, 1)                                        \
+    else if (HS == 96 && g_reg_e && p->rel_kw == 32 && p->rel_kh == 32 && p->rel_ld == 64) FWD_L(HS == 96 ? 96 : 32, 3) \
+    else FWD_L(HS, 2)                                                                                       \
   }
   DISPATCH_HS(p, FWD)
 #undef FWD

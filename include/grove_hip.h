@@ -408,6 +408,10 @@ int grove_flash_attn_fwd(const grove_flash_attn_params* p, void* stream);
 int grove_flash_attn_bwd(const grove_flash_attn_params* p, void* stream);
 /* 1 (default): problems that fit them run on the window kernels; 0: always the general kernels (A/B arm of tests and tools) */
 int grove_flash_attn_set_window_kernels(int32_t on);
+/* A/B knob (round 4): 0 = the general kernels build their rel-pos indicator tile in LDS for every key tile also where the register
+ * form applies (rel_kw == rel_kh == 32, rel_ld == 64, head dim 96: SAM's global blocks); 1 (default) = indicator fragments in registers.
+ * Same MFMAs on the same operand values: bit-identical results. */
+int grove_flash_attn_set_register_e(int32_t on);
 int grove_flash_attn_window_kernels_on(void);
 
 /* Decomposed relative-position terms of SAM attention (image_encoder.py:420-458):

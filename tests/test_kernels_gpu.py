@@ -770,6 +770,35 @@ def test_gemm_split_k_atomics(dev):
         close(out, ref, 3e-5, f"split_k={split}")
 
 
+@pytest.mark.parametrize("L", [1024, 1000, 130])
+def test_rel_pos_indicator_in_registers_is_bit_identical(dev, L):
+    """Round 4: SAM's global blocks (rel_kw = rel_kh = 32, rel_ld = 64, head dim 96) take kernel instances whose rel-pos indicator
+    fragments are made in registers instead of an LDS tile rebuilt per key tile — the same MFMAs on the same operand values: the forward (the
+    only kernel that gained from it; the backward runs with both settings here too) is bit-identical to the LDS form; ragged last tiles included."""
+    from grove_amd import _lib, ops
+    Lb = _lib.lib()
+    B, H, hs, hd = 2, 3, 96, 80
+    g = torch.Generator().manual_seed(L)
+    qkv = torch.zeros(B * L, 3 * H * hs)
+    qkv.view(B * L, 3, H, hs)[..., :hd] = torch.randn(B * L, 3, H, hd, generator=g)
+    qkv = qkv.to(bf16).to(dev)
+    do = (torch.randn(B * L, H * hs, generator=g)).to(bf16).to(dev)
+    rel = (torch.randn(B * H, L, 64, generator=g) / hd ** -0.5).to(bf16).to(dev)
+    res = []
+    try:
+        for on in (0, 1):
+            Lb.grove_flash_attn_set_register_e(on)
+            out, lse = ops.flash_attn(qkv, B, L, H, hs, 0, H * hs, 2 * H * hs, hd ** -0.5, rel=rel, rel_hw=(32, 32), want_lse=True, hs_valid=hd)
+            dqkv = torch.full_like(qkv, float("nan"))
+            drel = ops.flash_attn_bwd(qkv, out, do, lse, dqkv, B, L, H, hs, 0, H * hs, 2 * H * hs, hd ** -0.5, rel=rel, rel_hw=(32, 32), want_drel=True,
+                                      hs_valid=hd)
+            res.append((out, lse, dqkv, drel))
+    finally:
+        Lb.grove_flash_attn_set_register_e(1)
+    for a, b, name in zip(res[0], res[1], ("o", "lse", "dqkv", "drel")):
+        assert torch.equal(a, b), name
+
+
 @pytest.mark.parametrize("B,H,L,hs,hd,causal,use_len,rel_hw", [
     (2, 3, 77, 64, 64, False, False, None),
     (2, 2, 200, 128, 128, True, True, None),
