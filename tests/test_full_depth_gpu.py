@@ -233,8 +233,10 @@ def test_full_depth_training_vs_oracle_autograd(dev, which):
     # training models keep the reference's bf16 streams and the bf16 decoder: their boxes sit above the inference
     # models' figure, and ONE seed of it is a noisy sample — any change of a rounding pattern anywhere in the 32 layers redraws it:
     # deep-narrow over 5 batch seeds x 2 builds (profiles/r04_training_box_l1_seeds.json) 0.94e-3 .. 2.35e-3, mean 1.4-1.9e-3; full
-    # width 2.56e-3 (round 3) and 1.26e-3 (round 4) on the same seed. The bound is 1.5x the largest seen; the losses above are the gate.
-    assert res["box_l1_train_mode_vs_oracle"] <= (4e-3 if which == "full" else 3.5e-3), res["box_l1_train_mode_vs_oracle"]
+    # width 2.56e-3 (round 3) and 1.26e-3 (round 4) on the same seed, 2.78e-3 / 1.82e-3 / 3.20e-3 on seeds 12-14
+    # (profiles/r04_full_width_training_parity_seeds.json; losses <= 0.5 %, every gradient group's cosine >= 0.985 there). The bound is
+    # 1.5x the largest seen; the losses above are the gate.
+    assert res["box_l1_train_mode_vs_oracle"] <= (4.8e-3 if which == "full" else 3.5e-3), res["box_l1_train_mode_vs_oracle"]
 
 
 def test_full_size_greedy_ids_vs_oracle(dev):

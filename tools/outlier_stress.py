@@ -22,29 +22,31 @@ def main():
     ap.add_argument("--factor", type=float, default=1000.0)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "outlier_stress.json"))
     ap.add_argument("--cases", default="inference,training,fp8_all,fp8_det16_kv16")
+    ap.add_argument("--which", default="deep_narrow", choices=["deep_narrow", "full"], help="full = FULL dims (inference / fp8 cases: minutes of CPU oracle each)")
     args = ap.parse_args()
     import torch
     spec = importlib.util.spec_from_file_location("full_depth", os.path.join(ROOT, "tests", "test_full_depth_gpu.py"))
     FD = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(FD)
     dev = torch.device("cuda:0")
-    out = {"factor": args.factor, "model": "deep narrow (LLaMA 32 x 1024, CLIP 24 x 256, SAM 32 x 320), B=1, T=8, L=128, n_det=3"}
+    W = args.which
+    out = {"factor": args.factor, "model": ("deep narrow (LLaMA 32 x 1024, CLIP 24 x 256, SAM 32 x 320)" if W == "deep_narrow" else "FULL dims") + ", B=1, T=8, L=128, n_det=3"}
     for F in (0.0, args.factor):
         key = "outliers" if F else "baseline"
         rec = {}
         cases = args.cases.split(",")
         if "inference" in cases:
-            r = FD.run_inference_parity(dev, "deep_narrow", outliers=F)
+            r = FD.run_inference_parity(dev, W, outliers=F)
             rec["inference"] = {k: r[k] for k in ("box_l1_vs_oracle_full", "box_l1_max_full", "objectness_logit_abs_err", "llama_hidden_rel_rms",
                                                   "llama_hidden_rel_max", "llama_stream_abs_max_oracle")}
         if "training" in cases:
-            r = FD.run_training_parity(dev, "deep_narrow", outliers=F)
+            r = FD.run_training_parity(dev, W, outliers=F)
             rec["training"] = {"loss_terms_rel_err": r["loss_terms_rel_err"], "whole_gradient": r["whole_gradient"],
                                "gradient_groups": {g: {"cos": round(v["cos"], 5), "norm_ratio": round(v["norm_ratio"], 4)} for g, v in r["gradient_groups"].items()},
                                "box_l1_train_mode_vs_oracle": r["box_l1_train_mode_vs_oracle"]}
-        for pol in ("all", "det16_kv16"):
+        for pol in ("all", "det16_kv16", "det16_kv16_clip16"):
             if "fp8_" + pol in cases:
-                r = FD.run_fp8_parity(dev, "deep_narrow", pol, outliers=F)
+                r = FD.run_fp8_parity(dev, W, pol, outliers=F)
                 rec["fp8_" + pol] = {k: r[k] for k in ("box_l1_vs_oracle", "box_l1_max", "objectness_logit_abs_err", "llama_hidden_rel_rms")}
         out[key] = rec
         with open(args.out, "w") as fh:
