@@ -400,7 +400,10 @@ def test_full_width_box_l1_over_seeds(dev):
 FP8_BOUNDS = {("deep_narrow", "all"): {"box_l1": 1.6e-2, "hidden_rms": 0.145}, ("deep_narrow", "det16_kv16"): {"box_l1": 1.0e-2, "hidden_rms": 0.13},
               ("full", "det16_kv16"): {"box_l1": 1.95e-2, "hidden_rms": 0.17},
               # round 4 (profiles/r04_fp8_clip_policy_deep_narrow.json): CLIP tower in bf16 — 4.6e-3 / 6.2 %; with outliers 9.6e-4 (1.84e-2 with CLIP in e4m3)
-              ("deep_narrow", "det16_kv16_clip16"): {"box_l1": 7e-3, "hidden_rms": 0.095}}
+              ("deep_narrow", "det16_kv16_clip16"): {"box_l1": 7e-3, "hidden_rms": 0.095},
+              # FULL dims, the default policy since round 4 (profiles/r04_outlier_stress_full_dims.json): 5.98e-3 / 7.7 % (det16_kv16 there: 1.34e-2);
+              # with massive-activation channels 5.0e-4 (det16_kv16: 7.9e-3)
+              ("full", "det16_kv16_clip16"): {"box_l1": 9e-3, "hidden_rms": 0.115}}
 
 
 def run_fp8_parity(dev, which, policy, outliers=0.0):
@@ -452,7 +455,7 @@ def run_fp8_parity(dev, which, policy, outliers=0.0):
     return res
 
 
-@pytest.mark.parametrize("which,policy", [("deep_narrow", "all"), ("deep_narrow", "det16_kv16"), ("deep_narrow", "det16_kv16_clip16"), ("full", "det16_kv16")])
+@pytest.mark.parametrize("which,policy", [("deep_narrow", "all"), ("deep_narrow", "det16_kv16"), ("deep_narrow", "det16_kv16_clip16"), ("full", "det16_kv16_clip16")])
 def test_full_depth_fp8_inference_vs_fp32_oracle(dev, which, policy):
     res = run_fp8_parity(dev, which, policy)
     n_q = res["n_q"]
