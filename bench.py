@@ -783,13 +783,13 @@ def main():
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is a rank-0, N = 1 figure (other N: GPU numbers only)
             try:  # recorded by the last `pytest -m gpu` run of tests/test_full_depth_gpu.py (committed under profiles/): not measured in this run
                 rec = {}
-                for key, fn, field in (("box_l1_vs_oracle_full", "r03_full_depth_parity_full.json", "box_l1_vs_oracle_full"),
+                for key, fn, field in (("box_l1_vs_oracle_full", "r04_full_depth_parity_full.json", "box_l1_vs_oracle_full"),
                                        ("box_l1_deep_narrow_mean_4_seeds", "r03_full_depth_box_l1_seeds.json", "mean"),
-                                       ("train_mode_loss_rel_err_deep_narrow", "r03_full_depth_training_parity_deep_narrow.json", "loss_terms_rel_err"),
-                                       ("train_mode_whole_gradient_deep_narrow", "r03_full_depth_training_parity_deep_narrow.json", "whole_gradient"),
+                                       ("train_mode_loss_rel_err_deep_narrow", "r04_full_depth_training_parity_deep_narrow.json", "loss_terms_rel_err"),
+                                       ("train_mode_whole_gradient_deep_narrow", "r04_full_depth_training_parity_deep_narrow.json", "whole_gradient"),
                                        ("greedy_ids_equal_full_size", "r03_full_size_greedy_parity.json", "ids_equal"),
                                        ("box_l1_from_generated_rows_deep_narrow", "r03_decode_rows_precision_deep_narrow.json", "box_l1_from_f32_decode_rows"),
-                                       ("fp8_box_l1_full_det16_kv16", "r03_full_depth_fp8_parity_full_det16_kv16.json", "box_l1_vs_oracle")):
+                                       ("fp8_box_l1_full_default_policy_det16_kv16_clip16", "r04_full_depth_fp8_parity_full_det16_kv16_clip16.json", "box_l1_vs_oracle")):
                     with open(os.path.join(ROOT, "profiles", fn)) as fh:
                         rec[key] = json.load(fh)[field]
                 res["full_depth_parity_recorded"] = rec
