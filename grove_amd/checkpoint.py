@@ -162,7 +162,7 @@ def init_missing_trainable(model, missing):
     from .model.GROVE import trainable_names
     from .synthetic import det_uniform01, param_shapes
     shapes = param_shapes(model.dims)
-    train = set(trainable_names(model.dims))
+    train = set(model.trainable) if getattr(model, "trainable", None) is not None else set(trainable_names(model.dims))
     out = {}
     for n in missing:
         if n not in train:
@@ -199,6 +199,10 @@ def load_grove_weights(model, path, strict=False, sd=None, log=None):
         sd = dict(sd)
         sd.update(init)
     rep = model.load_state_dict(sd, strict=strict)
+    # tensors the checkpoint carries for modules that are not on this path (the never-executed region encoder, the prompt encoder's
+    # point / mask tables — DESIGN section 8): kept on the host and written back by consolidated_state_dict, so that a checkpoint
+    # saved here has the reference model's FULL key set again (infer_anet.py:556 loads with strict=True)
+    model._passthrough = {k: v.detach().cpu() for k, v in sd.items() if k not in want}
     rep.missing_keys = missing
     rep.resized = resized
     rep.initialised = sorted(init)
@@ -227,6 +231,10 @@ def consolidated_state_dict(model, engine=None, dtype=torch.float32):
                 co, ci = ref_shape[0], ref_shape[1]
                 t = t.view(co, 27, ci).permute(0, 2, 1).reshape(ref_shape)
             out[name] = t.reshape(ref_shape).to(dtype).clone()
+    obj = "model.grounding_encoder.mask_decoder.temporal_objectness_head."
+    for k, v in (getattr(model, "_passthrough", None) or {}).items():
+        if k not in out and not (k.startswith(obj) and not getattr(getattr(model, "config", None), "use_temp_objectness", True)):
+            out[k] = v.to(dtype)
     return out
 
 

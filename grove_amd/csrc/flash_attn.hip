@@ -821,6 +821,9 @@ size_t lds_fwd(const grove_flash_attn_params* p) { return 2 * Cfg<HS>::TILEB + (
 bool grove_win_attn_applicable(const grove_flash_attn_params* p);
 int grove_win_attn_fwd_launch(const grove_flash_attn_params* p, hipStream_t s);
 int grove_win_attn_bwd_launch(const grove_flash_attn_params* p, hipStream_t s);
+// flash_attn2.hip: the round-5 eight-wave kernels
+bool grove_flash2_fwd_applicable(const grove_flash_attn_params* p);
+int grove_flash2_fwd_launch(const grove_flash_attn_params* p, hipStream_t s);
 static int g_win_attn = 1;  // 0 = always the general kernels (A/B arm: grove_flash_attn_set_window_kernels)
 static int g_reg_e = 1;     // 0 = the LDS indicator tile also where the register form applies (A/B arm: grove_flash_attn_set_register_e)
 extern "C" int grove_flash_attn_set_register_e(int32_t on) {
@@ -845,6 +848,11 @@ extern "C" int grove_flash_attn_fwd(const grove_flash_attn_params* p, void* stre
               "flash_attn_fwd: q_valid / pad_k / pad_v are window-kernel features, but this problem does not take the window kernels");
   if (g_win_attn && grove_win_attn_applicable(p)) {
     grove_win_attn_fwd_launch(p, s);
+    GROVE_LAUNCH_CHECK();
+    return GROVE_OK;
+  }
+  if (grove_flash2_fwd_applicable(p)) {
+    grove_flash2_fwd_launch(p, s);
     GROVE_LAUNCH_CHECK();
     return GROVE_OK;
   }

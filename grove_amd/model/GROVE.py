@@ -27,15 +27,22 @@ from .tape import Param, Tape, Var
 bf = torch.bfloat16
 
 
-def trainable_names(d: GroveDims, train_mask_decoder=True):
+OBJ_HEAD = DEC_PREFIX + "temporal_objectness_head."
+
+
+def trainable_names(d: GroveDims, train_mask_decoder=True, use_temp_objectness=True):
     """The parameters that receive gradients under the shipped freeze policy
     (train.py::prepare_model_for_training :234-333 with --lora_r 0 --pretrained --train_mask_decoder).
     CLIP adapters are flagged trainable there too but the tower runs under no_grad (clip_encoder.py:55),
     so they never get a gradient and are excluded. Without --train_mask_decoder (train.py:280-283 not taken)
-    only the box head and the temporal-objectness head of the decoder train (train.py:284-288)."""
+    only the box head and the temporal-objectness head of the decoder train (train.py:284-288). Without use_temp_objectness
+    (ANet / VidSTG, train.py:203) the reference's decoder HAS no objectness head (mask_decoder.py:83-87): not trainable, not in any
+    state dict."""
     names = []
-    heads = (DEC_PREFIX + "bbox_prediction_head.", DEC_PREFIX + "temporal_objectness_head.")
+    heads = (DEC_PREFIX + "bbox_prediction_head.", OBJ_HEAD)
     for n in param_shapes(d):
+        if n.startswith(OBJ_HEAD) and not use_temp_objectness:
+            continue
         if is_mask_branch(n):  # flagged trainable by --train_mask_decoder, but no gradient reaches them on the box ("query") path
             continue
         if n.startswith(DEC_PREFIX) and not train_mask_decoder and not n.startswith(heads):
@@ -219,7 +226,7 @@ class GROVEForCausalLM(torch.nn.Module):
                     t.copy_(src.to(self.dev))
                 self._sd[name] = t
         if self._train_mode:
-            names = trainable_names(d, self.config.train_mask_decoder)
+            names = trainable_names(d, self.config.train_mask_decoder, self.config.use_temp_objectness)
             # every parameter starts on a 16-byte boundary of the flat fp32 buffer (vector / atomic epilogues)
             offs, off = {}, 0
             slot = lambda n: (ops.pad_to(self._sd[n].shape[0], 8) * self._sd[n].shape[1] if n == "lm_head.weight" else self._sd[n].numel())
@@ -240,27 +247,33 @@ class GROVEForCausalLM(torch.nn.Module):
                 self._lm_head_grad_full = self._flat_grad[offs[n]:offs[n] + slot(n)].view(-1, self._sd[n].shape[1])
             self.trainable = names
 
+    def _visible(self, n):
+        """The reference model built with use_temp_objectness=False has no `temporal_objectness_head` (mask_decoder.py:83-87). The
+        fused box-head kernel still takes the head's pointers, so the (zero) storage stays in `_sd`, but it is no parameter of the
+        model: not in state_dict() / named_parameters() / a consolidated checkpoint (infer_anet.py:556 loads with strict=True)."""
+        return self.config.use_temp_objectness or not n.startswith(OBJ_HEAD)
+
     def state_dict(self, *a, **k):
         self.wait_weights()
-        return dict(self._sd)
+        return {n: v for n, v in self._sd.items() if self._visible(n)}
 
     def load_state_dict(self, sd, strict=False, **k):
-        missing = [n for n in self._sd if n not in sd]
-        unexpected = [n for n in sd if n not in self._sd]
+        missing = [n for n in self._sd if n not in sd and self._visible(n)]
+        unexpected = [n for n in sd if n not in self._sd or not self._visible(n)]
         if strict and (missing or unexpected):
             raise RuntimeError(f"missing {missing[:3]} unexpected {unexpected[:3]}")
         self.wait_weights()
         for n, v in sd.items():
-            if n in self._sd:
+            if n in self._sd and self._visible(n):
                 self._sd[n].copy_(v.to(self.dev))
         self._build_engines()
         return SimpleNamespace(missing_keys=missing, unexpected_keys=unexpected)
 
     def named_parameters(self, *a, **k):
-        return iter(self._sd.items())
+        return iter((n, v) for n, v in self._sd.items() if self._visible(n))
 
     def parameters(self, *a, **k):
-        return iter(self._sd.values())
+        return iter(v for n, v in self._sd.items() if self._visible(n))
 
     def _build_engines(self):
         d, sd, dev, tr = self.dims, self._sd, self.dev, self._train_mode

@@ -258,7 +258,8 @@ class BoxDecoder:
         hp = M_ + "bbox_prediction_head."
         t = M_ + "transformer."
         grads = {"dW1": G[hp + "0.weight"], "db1": G[hp + "0.bias"], "dW2": G[hp + "2.weight"], "db2": G[hp + "2.bias"],
-                 "dWo": G[M_ + "temporal_objectness_head.weight"].view(-1), "dbo": G[M_ + "temporal_objectness_head.bias"]}
+                 "dWo": G[M_ + "temporal_objectness_head.weight"].view(-1) if M_ + "temporal_objectness_head.weight" in G else None,
+                 "dbo": G.get(M_ + "temporal_objectness_head.bias")}  # (no objectness head without use_temp_objectness: mask_decoder.py:83-87)
         dhs = ops.box_head_bwd(state["hs"], self.sd[hp + "0.weight"], self.sd[hp + "2.weight"],
                                self.sd[M_ + "temporal_objectness_head.weight"], state["hidden"], state["box"], dbox, dobj, grads)
         # (without --train_mask_decoder only the two heads train: the transformer's tensors have no gradient views)

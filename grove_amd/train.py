@@ -354,7 +354,8 @@ def prepare_model_for_training(model, tokenizer=None, args=None):
     if tokenizer is not None and len(tokenizer) != model.dims.vocab and getattr(args, "dims", "full") == "full":
         raise RuntimeError(f"len(tokenizer) = {len(tokenizer)} but the model's embedding tables have {model.dims.vocab} rows: build it with "
                            "initialize_model(args, tokenizer)")
-    return list(model.trainable) if getattr(model, "trainable", None) is not None else trainable_names(model.dims, model.config.train_mask_decoder)
+    return list(model.trainable) if getattr(model, "trainable", None) is not None else trainable_names(
+        model.dims, model.config.train_mask_decoder, model.config.use_temp_objectness)
 
 
 class WarmupDecayLR:
@@ -473,8 +474,10 @@ class GradExchange:
         self._kmax = None
         self._inflight = []   # what the CU reservation waits for: Work handles / events of the buckets handed to RCCL
         self._user_blocks = None
-        self.reserve_cus = self.RESERVED_CUS if (flat.is_cuda and os.environ.get("GROVE_RCCL_RESERVED_CUS") is None) else \
-            int(os.environ.get("GROVE_RCCL_RESERVED_CUS", "0"))
+        # OPT-IN (round 5): no 8-GPU A/B exists for this rule, so the default is 0 (the GEMMs keep every CU). Ask for it with
+        # GROVE_RCCL_RESERVED_CUS=16 or `engine.exchange.reserve_cus = 16`; `bench.py --gpus N` measures both settings in its
+        # calibration pass before the timed region and runs the faster one (the line prints every arm).
+        self.reserve_cus = int(os.environ.get("GROVE_RCCL_RESERVED_CUS", "0")) if flat.is_cuda else 0
         self.reserved_launch_polls = 0  # (diagnostic: how many GEMM launches ran under the cap in the last step)
 
     # ---- CU reservation for the collectives in flight
@@ -690,6 +693,57 @@ class GradExchange:
         return done
 
 
+EXCHANGE_ARMS = [(m, r) for m in ("allreduce", "rs_ag", "a2a_f32") for r in (0, GradExchange.RESERVED_CUS)]
+
+
+def calibrate_exchange(engine, step_fn, steps=3, arms=None, barrier=None):
+    """The first N > 1 run on real hardware is ONE shot with default arguments, so that run measures its own
+    choices: every arm {exchange mode} x {CUs reserved for RCCL while buckets are in flight} is driven for `steps` steps of the real
+    workload (`step_fn` = engine(**batch) / backward / step) between two barriers, timed by the wall clock (max over ranks) with the
+    exposed-communication events of its last step. Returns (table, best) — `table` one dict per arm in the order run, `best` the arm
+    with the smallest ms/step — and leaves the engine on `best` unless `GROVE_EXCHANGE_KEEP=1`. Every rank runs the same arms in the
+    same order (the collectives of an arm must match across ranks); the decision is taken on the all-reduced maxima, so every rank
+    decides alike. RCCL's channel count is NOT an arm: NCCL_MAX_NCHANNELS is read once when the communicator is created."""
+    import time as _time
+    ex = engine.exchange
+    if ex is None:
+        return [], None
+    arms = list(arms if arms is not None else EXCHANGE_ARMS)
+    dev = engine.dev
+    on_gpu = torch.device(dev).type == "cuda"
+    sync = (lambda: torch.cuda.synchronize(dev)) if on_gpu else (lambda: None)
+    bar = barrier if barrier is not None else (dist.barrier if (dist.is_initialized() and dist.get_world_size() > 1) else (lambda: None))
+    start = (ex.mode, ex.reserve_cus)
+    table = []
+    for mode, reserve in arms:
+        if mode == "a2a_f32" and ex.wire is None:  # (fp32 wire: the all-to-all arm is defined for a bf16 wire only)
+            continue
+        ex.mode, ex.reserve_cus = mode, (reserve if on_gpu else 0)
+        step_fn()  # one untimed step per arm: RCCL builds its plan for a new collective / message size on first use
+        sync()
+        bar()
+        t0 = _time.perf_counter()
+        for _ in range(steps):
+            step_fn()
+        sync()
+        bar()
+        dt = (_time.perf_counter() - t0) / steps * 1e3
+        exposed = engine.exposed_comm_ms() if on_gpu else None
+        vals = torch.tensor([dt, exposed if exposed is not None else 0.0], dtype=torch.float64, device=dev if on_gpu else "cpu")
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(vals, op=dist.ReduceOp.MAX)
+        table.append({"exchange": mode, "reserved_cus": ex.reserve_cus, "ms_per_step": round(float(vals[0]), 3),
+                      "exposed_comm_ms": (round(float(vals[1]), 3) if exposed is not None else None),
+                      "gemm_launches_under_cap": ex.reserved_launch_polls})
+        ex.reserved_launch_polls = 0
+    best = min(table, key=lambda a: a["ms_per_step"]) if table else None
+    if best is not None and os.environ.get("GROVE_EXCHANGE_KEEP") != "1":
+        ex.mode, ex.reserve_cus = best["exchange"], best["reserved_cus"]
+    else:
+        ex.mode, ex.reserve_cus = start
+    return table, best
+
+
 def shard_clips(n_clips, rank, world):
     """DistributedSampler partition of train.py:453 (no shuffle, padded by wrap-around): clip indices of `rank`."""
     per = (n_clips + world - 1) // world
@@ -792,6 +846,12 @@ class GroveEngine:
         self.module._grad_ready_cb = self.exchange.ready if (self.exchange is not None and self.overlap and last_micro) else None
         try:
             self.module.backward(loss)
+        except BaseException:
+            # a backward that raises never reaches step(): without this the persistent-GEMM grid cap and the pre-launch poll hook that
+            # GradExchange installed for the buckets already in flight would stay on for the rest of the process
+            if self.exchange is not None:
+                self.exchange._release()
+            raise
         finally:
             self.module._grad_ready_cb = None
         self.micro += 1
@@ -982,19 +1042,48 @@ def train(data_loader, model, epoch, *rest, log=None):
     trackers = {k: AverageMeter(k) for k in LOSS_KEYS}
     batch_time = AverageMeter("Time")
     engine.train()
+    # Loss terms are read back ONE micro-step late (round 5): the reference's `loss.item()`-style update of the
+    # meters right after the forward (train.py:733-742) is a stream sync BETWEEN forward and backward — the host would queue the
+    # backward's ~900 launches onto an idle GPU. Here the terms of micro-step k are copied into a pinned slot behind the forward
+    # (async D2H + an event) and folded into the meters while micro-step k + 1 runs; the slots still pending are drained before the
+    # meters are printed / all-reduced, so every logged average covers exactly the steps the reference's would.
+    on_gpu = torch.device(engine.dev).type == "cuda"
+    ring = [torch.empty(len(LOSS_KEYS), dtype=torch.float32, pin_memory=True) for _ in range(2)] if on_gpu else None
+    pending = []  # (slot tensor, event, keys present)
+
+    def drain(keep=0):
+        while len(pending) > keep:
+            slot, ev, keys = pending.pop(0)
+            if ev is not None:
+                ev.synchronize()
+            for k, v in zip(keys, slot[:len(keys)].tolist()):
+                trackers[k].update(v, 1)
+
+    micro = 0
     end = time.time()
     for global_step in range(args.steps_per_epoch):
         for _ in range(args.grad_accumulation_steps):
             batch, dataset_iter = next_input(dataset_iter)
             out = engine(**_to_device_batch(batch, engine.dev))
-            vals = torch.stack([out[k].float() for k in trackers if k in out]).cpu()  # one D2H copy per micro-step
-            for (k, tr), v in zip([(k, t) for k, t in trackers.items() if k in out], vals.tolist()):
-                tr.update(v, 1)
+            keys = [k for k in trackers if k in out]
+            vals = torch.stack([out[k].float() for k in keys])
+            if on_gpu:
+                drain(keep=1)  # the slot about to be reused belongs to micro-step k - 2: long finished
+                slot = ring[micro % 2]
+                slot[:len(keys)].copy_(vals, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                pending.append((slot, ev, keys))
+            else:
+                pending.append((vals.cpu(), None, keys))
+            micro += 1
             engine.backward(out["loss"])
             engine.step()
+            drain(keep=1 if on_gpu else 0)  # micro-step k - 1's terms: their event completed during this micro-step's forward
         batch_time.update(time.time() - end)
         end = time.time()
         if global_step % args.print_freq == 0:
+            drain()
             if engine.world > 1:
                 t = torch.tensor([x for tr in trackers.values() for x in (tr.sum, tr.count)], dtype=torch.float32, device=engine.dev)
                 dist.all_reduce(t)
@@ -1013,6 +1102,7 @@ def train(data_loader, model, epoch, *rest, log=None):
                 tr.reset()
         if global_step != 0 and writer is not None and engine.rank == 0:
             writer.add_scalar("train/lr", scheduler.get_last_lr()[0], global_step)
+    drain()
     return dataset_iter
 
 
@@ -1129,13 +1219,14 @@ def resume_training_from_checkpoint(engine, args, log=print):
 def init_distributed(local_rank, timeout_s=1800, backend=None):
     """deepspeed.init_distributed() (train.py:932): one process per GPU, RCCL ("nccl" IS RCCL on ROCm) bound to this rank's device,
     with a FINITE timeout so that a wedged collective ends the job with RCCL's own report of the stuck operation instead of hanging
-    it (the reference's inference scripts pass 2-4 h, infer_iground.py:495). RCCL gets at most 16 channels (NCCL_MAX_NCHANNELS,
-    overridable): its kernels then occupy at most the 16 CUs GradExchange leaves free while a bucket is in flight."""
+    it (the reference's inference scripts pass 2-4 h, infer_iground.py:495). RCCL's channel count is left to RCCL (round 5: the
+    cap of 16 that rounds 3-4 set by default could throttle an 8-GPU xGMI all-reduce and was never measured; the variable is read
+    once at communicator creation, so it cannot be an arm of a calibration inside one run — set NCCL_MAX_NCHANNELS=16 in the
+    environment, together with GROVE_RCCL_RESERVED_CUS=16, to get the rounds 3-4 behaviour)."""
     import datetime
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        os.environ.setdefault("NCCL_MAX_NCHANNELS", str(GradExchange.RESERVED_CUS))
         backend = backend or os.environ.get("GROVE_BACKEND", "nccl")  # gloo only for one-GPU rehearsals
         kw = {"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}
         dist.init_process_group(backend, timeout=datetime.timedelta(seconds=timeout_s), **kw)

@@ -128,3 +128,42 @@ def test_missing_trainable_keys_get_constructor_init_not_zeros():
     # deterministic per name: every rank builds the same tensors
     rep2 = ck.init_missing_trainable(FakeModel(), drop)
     assert all(torch.equal(rep2[n], loaded[n]) for n in rep2)
+
+
+@pytest.mark.parametrize("use_obj", [True, False])
+def test_consolidated_key_set_equals_the_reference_models(use_obj):
+    """a model built with use_temp_objectness=False (ANet / VidSTG, train.py:203) has NO temporal_objectness_head
+    in the reference (mask_decoder.py:83-87), and infer_anet.py:556 loads `pytorch_model.bin` with strict=True — so the consolidated
+    checkpoint written here must carry exactly the reference model's key set in either mode: without the head when it is off, and
+    WITH the tensors of modules that are not on this path (region encoder, the prompt encoder's point / mask tables) passed through
+    from the checkpoint the run started from. Key sets: tests/golden/state_dict_keys.json, made from the reference's own
+    `state_dict()` by oracle/refgen/make_keys_golden.py."""
+    from types import SimpleNamespace
+    from grove_amd.model.GROVE import OBJ_HEAD, trainable_names
+    from grove_amd.synthetic import TINY, param_shapes
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "state_dict_keys.json")))
+    ref_keys = set(gold["with_objectness" if use_obj else "without_objectness"])
+    d = TINY
+    shapes = param_shapes(d)
+    visible = {n: s for n, s in shapes.items() if use_obj or not n.startswith(OBJ_HEAD)}
+    names = trainable_names(d, True, use_obj)
+    assert all(not n.startswith(OBJ_HEAD) for n in names) or use_obj
+    assert set(names) <= set(visible)
+
+    class FakeModel:  # the host-side surface of GROVEForCausalLM that checkpoint.py uses (the real model needs a GPU)
+        dims = d
+        trainable = names
+        config = SimpleNamespace(use_temp_objectness=use_obj)
+
+        def state_dict(self):
+            return {n: torch.zeros(s) for n, s in visible.items()}
+
+        def load_state_dict(self, sd, strict=False):
+            return SimpleNamespace(missing_keys=[], unexpected_keys=[n for n in sd if n not in visible])
+
+    # the checkpoint a run starts from: the reference model's full key set of the OTHER run type too (a HowToGround pre-train carries the head)
+    src = {k: torch.zeros(shapes[k]) if k in shapes else torch.zeros(3) for k in gold["with_objectness"]}
+    m = FakeModel()
+    ck.load_grove_weights(m, "<memory>", sd=src, log=lambda _m: None)
+    out = ck.consolidated_state_dict(m)
+    assert set(out) == ref_keys, (sorted(set(out) - ref_keys)[:3], sorted(ref_keys - set(out))[:3])
