@@ -525,10 +525,14 @@ __global__ __launch_bounds__(NTHR, (HS <= 96 ? 2 : 1)) void flash_bwd_dkv_kernel
       if (p.causal && qt0 + s2 * 32 + 31 + (p.Lk - p.Lq) < k0) continue;  // every query of this half is above the diagonal
       // S[q][key] and dP[q][key] for q tiles 2*s2, 2*s2+1 and this wave's 2 key tiles
       f32x4_t sacc[2][2], pacc[2][2];
+      const f32x4_t zero4 = f32x4_t{0.f, 0.f, 0.f, 0.f};  // (round 5: the chains start on the MFMA's zero operand — instances without rel-pos)
+      constexpr bool TRIM0 = NRK == 0;
+      if constexpr (!TRIM0) {
 #pragma unroll
-      for (int qi_ = 0; qi_ < 2; ++qi_)
+        for (int qi_ = 0; qi_ < 2; ++qi_)
 #pragma unroll
-        for (int nj = 0; nj < 2; ++nj) { sacc[qi_][nj] = f32x4_t{0.f, 0.f, 0.f, 0.f}; pacc[qi_][nj] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+          for (int nj = 0; nj < 2; ++nj) { sacc[qi_][nj] = zero4; pacc[qi_][nj] = zero4; }
+      }
 #pragma unroll
       for (int qi_ = 0; qi_ < 2; ++qi_)
 #pragma unroll
@@ -538,8 +542,8 @@ __global__ __launch_bounds__(NTHR, (HS <= 96 ? 2 : 1)) void flash_bwd_dkv_kernel
           const bf16x8_t da = lds_row_frag(dOs, C::ROWB, row, ks * 4 + g);
 #pragma unroll
           for (int nj = 0; nj < 2; ++nj) {
-            sacc[qi_][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[nj][ks], sacc[qi_][nj], 0, 0, 0);
-            pacc[qi_][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[nj][ks], pacc[qi_][nj], 0, 0, 0);
+            sacc[qi_][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[nj][ks], (TRIM0 && ks == 0) ? zero4 : sacc[qi_][nj], 0, 0, 0);
+            pacc[qi_][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[nj][ks], (TRIM0 && ks == 0) ? zero4 : pacc[qi_][nj], 0, 0, 0);
           }
         }
 #pragma unroll
@@ -560,26 +564,44 @@ __global__ __launch_bounds__(NTHR, (HS <= 96 ? 2 : 1)) void flash_bwd_dkv_kernel
       const int qlo = qt0 + s2 * 32;
       const bool need_mask = (qlo + 31 >= p.Lq) || (k0 + 31 >= kv_end) || (p.causal && k0 + 31 > qlo + (p.Lk - p.Lq));
       bf16x8_t pfr[2], dsfr[2];
+      // (round 5: the mask is ONE wave-uniform branch around two straight-line bodies; inside the element loops hipcc had turned it
+      // into a scalar branch per score — 180 SALU instructions and 32 branches per tile)
+      constexpr bool TRIM = NRK == 0;  // (rel-pos instances: at the register limit, the single body spills less — see the dQ kernel)
+      if (!TRIM || need_mask) {
 #pragma unroll
-      for (int nj = 0; nj < 2; ++nj) {
-        const int j = k0 + nj * 16 + fr;
-        f32x4_t pp[2], dd[2];
+        for (int nj = 0; nj < 2; ++nj) {
+          const int j = k0 + nj * 16 + fr;
+          f32x4_t pp[2], dd[2];
 #pragma unroll
-        for (int qi_ = 0; qi_ < 2; ++qi_)
+          for (int qi_ = 0; qi_ < 2; ++qi_)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float pr = fast_exp2(sacc[qi_][nj][r] - lse4[qi_][r]);
-            if (need_mask) {
+            for (int r = 0; r < 4; ++r) {
               const int qi = qlo + qi_ * 16 + g * 4 + r;
               int lim = kv_end;
               if (p.causal) lim = min(lim, qi + (p.Lk - p.Lq) + 1);
-              if (!((j < lim) && (qi < p.Lq))) pr = 0.f;
+              float pr = fast_exp2(sacc[qi_][nj][r] - lse4[qi_][r]);
+              if (need_mask && !((j < lim) && (qi < p.Lq))) pr = 0.f;
+              pp[qi_][r] = pr;
+              dd[qi_][r] = pr * (pacc[qi_][nj][r] - del4[qi_][r]) * p.alpha;
             }
-            pp[qi_][r] = pr;
-            dd[qi_][r] = pr * (pacc[qi_][nj][r] - del4[qi_][r]) * p.alpha;
-          }
-        pfr[nj] = pack_frag(pp[0], pp[1]);
-        dsfr[nj] = pack_frag(dd[0], dd[1]);
+          pfr[nj] = pack_frag(pp[0], pp[1]);
+          dsfr[nj] = pack_frag(dd[0], dd[1]);
+        }
+      } else {
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj) {
+          f32x4_t pp[2], dd[2];
+#pragma unroll
+          for (int qi_ = 0; qi_ < 2; ++qi_)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float pr = fast_exp2(sacc[qi_][nj][r] - lse4[qi_][r]);
+              pp[qi_][r] = pr;
+              dd[qi_][r] = pr * (pacc[qi_][nj][r] - del4[qi_][r]) * p.alpha;
+            }
+          pfr[nj] = pack_frag(pp[0], pp[1]);
+          dsfr[nj] = pack_frag(dd[0], dd[1]);
+        }
       }
       // dV[key][d] += sum_q P[q][key] dO[q][d];  dK[key][d] += sum_q dS[q][key] Q[q][d]
 #pragma unroll
@@ -715,20 +737,34 @@ __global__ __launch_bounds__(NTHR, 2) void flash_bwd_dq_kernel(const grove_flash
     if (p.causal) lim_hi = min(lim_hi, q0 + 31 + (p.Lk - p.Lq) + 1);
     if (q0 >= p.Lq || kv0 >= lim_hi) continue;  // wave-uniform: dead query wave / nothing visible in this key tile
     const int nv = min(4, (lim_hi - kv0 + 15) >> 4);
+    // round 5: (i) the S / dP chains start on the MFMA's zero operand (the 64 v_mov per tile that cleared the accumulators are gone);
+    // (ii) the key mask runs on edge tiles only (wave-uniform test; interior tiles: no compare / select per score). Same arithmetic.
+    int lim_lo = kv_end;
+    if (p.causal) lim_lo = min(lim_lo, q0 + (p.Lk - p.Lq) + 1);
+    // (the rel-pos instances sit at the 256-register limit: there the two-path form spills more than it saves — measured 1.74 -> 1.85 ms
+    // on SAM's global backward — so they keep the single masked body)
+    constexpr bool TRIM = NRK == 0;
+    const bool edge = !TRIM || kv0 + BKV > lim_lo;
+    const f32x4_t zero4 = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
       f32x4_t s[4], dp[4];
+      if constexpr (!TRIM) {
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) { s[ni] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dp[ni] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+        for (int ni = 0; ni < 4; ++ni) { s[ni] = zero4; dp[ni] = zero4; }
+      }
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) {
-        if (ni >= nv) continue;
+        if (ni >= nv) {
+          if constexpr (TRIM) { s[ni] = zero4; dp[ni] = zero4; }
+          continue;
+        }
 #pragma unroll
         for (int ks = 0; ks < C::KS; ++ks) {
           const bf16x8_t ka = lds_row_frag(Ks, C::ROWB, ni * 16 + fr, ks * 4 + g);
           const bf16x8_t va = lds_row_frag(Vs, C::ROWB, ni * 16 + fr, ks * 4 + g);
-          s[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[mi][ks], s[ni], 0, 0, 0);
-          dp[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, dof[mi][ks], dp[ni], 0, 0, 0);
+          s[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[mi][ks], (TRIM && ks == 0) ? zero4 : s[ni], 0, 0, 0);
+          dp[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, dof[mi][ks], (TRIM && ks == 0) ? zero4 : dp[ni], 0, 0, 0);
         }
 #pragma unroll
         for (int k2 = 0; k2 < NRK; ++k2) {
@@ -736,17 +772,24 @@ __global__ __launch_bounds__(NTHR, 2) void flash_bwd_dq_kernel(const grove_flash
           s[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ef, relf[mi][k2], s[ni], 0, 0, 0);
         }
       }
-      const int qi = q0 + mi * 16 + fr;
-      int lim = kv_end;
-      if (p.causal) lim = min(lim, qi + (p.Lk - p.Lq) + 1);
+      if (edge) {
+        const int qi = q0 + mi * 16 + fr;
+        int lim = kv_end;
+        if (p.causal) lim = min(lim, qi + (p.Lk - p.Lq) + 1);
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
+        for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int j = kv0 + ni * 16 + g * 4 + r;
-          const float pr = j < lim ? fast_exp2(s[ni][r] - lse2[mi]) : 0.f;
-          s[ni][r] = pr * (dp[ni][r] - del[mi]) * p.alpha;
-        }
+          for (int r = 0; r < 4; ++r) {
+            const int j = kv0 + ni * 16 + g * 4 + r;
+            const float pr = j < lim ? fast_exp2(s[ni][r] - lse2[mi]) : 0.f;
+            s[ni][r] = pr * (dp[ni][r] - del[mi]) * p.alpha;
+          }
+      } else {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[ni][r] = fast_exp2(s[ni][r] - lse2[mi]) * (dp[ni][r] - del[mi]) * p.alpha;
+      }
       const bf16x8_t dsf0 = pack_frag(s[0], s[1]), dsf1 = pack_frag(s[2], s[3]);
       // dQ^T[d][q] += sum_key K^T[d][key] dS^T[key][q];   d rel'^T[bin][q] += sum_key E^T[bin][key] dS^T[key][q]
 #pragma unroll

@@ -11,30 +11,12 @@
 namespace {
 constexpr int GV_THREADS = 256;
 
-template <int MX, int GV_RW>  // GV_RW: output rows per wave (4; 2 when N is too small to fill the chip with 4)
-__global__ __launch_bounds__(GV_THREADS) void gemv_kernel(const grove_gemv_params p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16_raw* xs = (bf16_raw*)smem;  // [MX][K]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// x -> LDS as bf16 rows of XS elements (XS >= K): plain copy, the folded RMSNorm (bf16 or fp32 stream input) or the SwiGLU of a fused
+// gate|up row — the prologue shared by the VALU kernel (1-2 sequences) and the matrix-core kernel (3-8 sequences)
+template <int MX>
+__device__ __forceinline__ void gemv_stage_x(const grove_gemv_params& p, bf16_raw* xs, const int XS, float* red, const int tid) {
   const int K = p.K;
   const bf16_raw* __restrict__ X = (const bf16_raw*)p.x;
-  __shared__ float red[GV_THREADS / 64];
-  // The weight stream starts BEFORE the x prologue (round 3): the first trip of this wave's rows (4 chunks x GV_RW rows = 16 / 8
-  // loads of 16 B per lane) does not depend on x, and the prologue — x into LDS, the folded RMSNorm's block reduction or the SwiGLU —
-  // is 2-3 us during which the HBM pipe of this CU would otherwise sit idle (129 such kernels per generated token).
-  const int n0 = (blockIdx.x * (GV_THREADS / 64) + wave) * GV_RW;
-  const bf16_raw* __restrict__ W = (const bf16_raw*)p.W;
-  const bf16_raw* wrow[GV_RW];
-#pragma unroll
-  for (int r = 0; r < GV_RW; ++r) wrow[r] = W + (int64_t)min(n0 + r, p.N - 1) * p.ldw;
-  const bool prefetched = K >= 2048;
-  u32x4_t pre[4][GV_RW];
-  if (prefetched) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int r = 0; r < GV_RW; ++r) pre[q][r] = __builtin_nontemporal_load((const u32x4_t*)(wrow[r] + lane * 8 + q * 512));
-  }
   if (p.x_mode == GROVE_GEMV_X_SWIGLU) {
     // x' = silu(gate) * up of a fused [M, 2K] gate|up row (HF LlamaMLP), rounded to bf16 like grove_swiglu_fwd
     for (int c = tid; c < MX * (K >> 3); c += GV_THREADS) {
@@ -46,7 +28,7 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_kernel(const grove_gemv_param
       float o[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = g[e] * fast_sigmoid(g[e]) * u[e];
-      *(u32x4_t*)(xs + b * K + kc * 8) = u32x4_t{pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
+      *(u32x4_t*)(xs + b * XS + kc * 8) = u32x4_t{pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
     }
     __syncthreads();
   } else if (p.x_f32) {
@@ -82,7 +64,7 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_kernel(const grove_gemv_param
             const u32x2_t w2 = *(const u32x2_t*)(nw + q * 4);
             o[0] *= rstd * bf_lo(w2.x), o[1] *= rstd * bf_hi(w2.x), o[2] *= rstd * bf_lo(w2.y), o[3] *= rstd * bf_hi(w2.y);
           }
-          *(u32x2_t*)(xs + b * K + q * 4) = u32x2_t{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+          *(u32x2_t*)(xs + b * XS + q * 4) = u32x2_t{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
         }
       } else {  // long rows: two passes over global memory
         float rstd = 1.f;
@@ -101,7 +83,7 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_kernel(const grove_gemv_param
             const u32x2_t w2 = *(const u32x2_t*)(nw + q * 4);
             o[0] *= rstd * bf_lo(w2.x), o[1] *= rstd * bf_hi(w2.x), o[2] *= rstd * bf_lo(w2.y), o[3] *= rstd * bf_hi(w2.y);
           }
-          *(u32x2_t*)(xs + b * K + q * 4) = u32x2_t{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+          *(u32x2_t*)(xs + b * XS + q * 4) = u32x2_t{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
         }
       }
     }
@@ -109,7 +91,7 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_kernel(const grove_gemv_param
   } else {
     for (int c = tid; c < MX * (K >> 3); c += GV_THREADS) {
       const int b = c / (K >> 3), kc = c - b * (K >> 3);
-      *(u32x4_t*)(xs + b * K + kc * 8) = *(const u32x4_t*)(X + (int64_t)b * p.ldx + kc * 8);
+      *(u32x4_t*)(xs + b * XS + kc * 8) = *(const u32x4_t*)(X + (int64_t)b * p.ldx + kc * 8);
     }
     __syncthreads();
     if (p.x_mode == GROVE_GEMV_X_RMSNORM) {
@@ -118,15 +100,42 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_kernel(const grove_gemv_param
       for (int b = 0; b < MX; ++b) {
         float ss = 0.f;
         for (int k = tid; k < K; k += GV_THREADS) {
-          const float v = bf2f(xs[b * K + k]);
+          const float v = bf2f(xs[b * XS + k]);
           ss += v * v;
         }
         const float rstd = rsqrtf(block_sum<GV_THREADS>(ss, red) / (float)K + p.eps);
-        for (int k = tid; k < K; k += GV_THREADS) xs[b * K + k] = f2bf(bf2f(xs[b * K + k]) * rstd * bf2f(nw[k]));
+        for (int k = tid; k < K; k += GV_THREADS) xs[b * XS + k] = f2bf(bf2f(xs[b * XS + k]) * rstd * bf2f(nw[k]));
         __syncthreads();
       }
     }
   }
+}
+
+template <int MX, int GV_RW>  // GV_RW: output rows per wave (4; 2 when N is too small to fill the chip with 4)
+__global__ __launch_bounds__(GV_THREADS) void gemv_kernel(const grove_gemv_params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_raw* xs = (bf16_raw*)smem;  // [MX][K]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = p.K;
+  const bf16_raw* __restrict__ X = (const bf16_raw*)p.x;
+  __shared__ float red[GV_THREADS / 64];
+  // The weight stream starts BEFORE the x prologue (round 3): the first trip of this wave's rows (4 chunks x GV_RW rows = 16 / 8
+  // loads of 16 B per lane) does not depend on x, and the prologue — x into LDS, the folded RMSNorm's block reduction or the SwiGLU —
+  // is 2-3 us during which the HBM pipe of this CU would otherwise sit idle (129 such kernels per generated token).
+  const int n0 = (blockIdx.x * (GV_THREADS / 64) + wave) * GV_RW;
+  const bf16_raw* __restrict__ W = (const bf16_raw*)p.W;
+  const bf16_raw* wrow[GV_RW];
+#pragma unroll
+  for (int r = 0; r < GV_RW; ++r) wrow[r] = W + (int64_t)min(n0 + r, p.N - 1) * p.ldw;
+  const bool prefetched = K >= 2048;
+  u32x4_t pre[4][GV_RW];
+  if (prefetched) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int r = 0; r < GV_RW; ++r) pre[q][r] = __builtin_nontemporal_load((const u32x4_t*)(wrow[r] + lane * 8 + q * 512));
+  }
+  gemv_stage_x<MX>(p, xs, K, red, tid);
   if (n0 >= p.N) return;
   float acc[GV_RW][MX];
 #pragma unroll
@@ -224,6 +233,85 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_kernel(const grove_gemv_param
   }
 }
 
+// ---- 3..8 sequences (round 5: the clip-batched decode of infer_iground): the same weight stream on the MATRIX cores.
+// The VALU kernel above does MX fused multiply-adds per weight element: at MX = 8 it is compute-bound (11.4 ms per token step at
+// LLaMA-7B size against 3.1 ms for the 13.2 GB weight stream). Here a workgroup owns 16 output rows and its four waves a quarter of K
+// each; per 32-deep k-step a wave issues ONE v_mfma_f32_16x16x32_bf16 with A = x (rows = sequences, 8..13 of the 16 rows are zero
+// padding: the matrix pipe is idle otherwise) and B = the weight rows loaded straight from HBM in fragment form (lane = weight row
+// n0 + (lane & 15), 16 bytes at k + 8 (lane >> 4): no LDS staging of W, 8 k-steps = 8 independent 16-byte loads in flight per lane).
+// x comes from LDS (staged by gemv_stage_x: folded RMSNorm / SwiGLU / fp32 stream input; rows XS = K + 32 elements apart) or, in
+// plain mode, straight from global memory (8 x 11008 bf16 = 176 KB would not fit; it is L2-resident). The four partial 16 x 16
+// tiles meet in LDS; thread (m, n) of the workgroup runs the epilogue of element (sequence m, row n0 + n).
+template <bool X_LDS, int MXS>  // MXS: rows of x staged in LDS (the caller pads x to 4 or 8 rows)
+__global__ __launch_bounds__(GV_THREADS) void gemv_mfma_kernel(const grove_gemv_params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_raw* xs = (bf16_raw*)smem;
+  __shared__ float red[GV_THREADS / 64];
+  __shared__ float part[GV_THREADS / 64][16][17];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = p.K, XS = K + 32;
+  const int fr = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * 16;
+  const int kw = K >> 2;                 // this wave's K range (K % 128 == 0)
+  const int k_lo = wave * kw;
+  const bf16_raw* __restrict__ wrow = (const bf16_raw*)p.W + (int64_t)min(n0 + fr, p.N - 1) * p.ldw + k_lo + g * 8;
+  constexpr int U = 8;
+  // the first trip of the weight stream starts before the x prologue (it does not depend on x)
+  u32x4_t wv[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) wv[u] = (u * 32 < kw) ? __builtin_nontemporal_load((const u32x4_t*)(wrow + u * 32)) : u32x4_t{0u, 0u, 0u, 0u};
+  if constexpr (X_LDS) gemv_stage_x<MXS>(p, xs, XS, red, tid);
+  const bool row_ok = fr < p.M;
+  const bf16_raw* __restrict__ xg = (const bf16_raw*)p.x + (int64_t)min(fr, p.M - 1) * p.ldx + k_lo + g * 8;
+  const bf16_raw* xl = xs + min(fr, MXS - 1) * XS + k_lo + g * 8;
+  f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const u32x4_t z4 = u32x4_t{0u, 0u, 0u, 0u};
+  for (int k = 0; k < kw; k += 32 * U) {
+    u32x4_t xv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool in = k + u * 32 < kw;
+      if constexpr (X_LDS) xv[u] = (in && row_ok) ? *(const u32x4_t*)(xl + k + u * 32) : z4;
+      else xv[u] = (in && row_ok) ? *(const u32x4_t*)(xg + k + u * 32) : z4;
+    }
+    u32x4_t wn[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      wn[u] = (k + 32 * U + u * 32 < kw) ? __builtin_nontemporal_load((const u32x4_t*)(wrow + k + 32 * U + u * 32)) : z4;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, xv[u]), __builtin_bit_cast(bf16x8_t, wv[u]), acc, 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) wv[u] = wn[u];
+  }
+  // acc[r] = partial y[sequence 4 g + r][row n0 + fr]
+#pragma unroll
+  for (int r = 0; r < 4; ++r) part[wave][4 * g + r][fr] = acc[r];
+  __syncthreads();
+  const int m = tid >> 4, n = tid & 15;
+  if (m >= p.M || n0 + n >= p.N) return;
+  float v = (part[0][m][n] + part[1][m][n]) + (part[2][m][n] + part[3][m][n]);
+  if (p.act == GROVE_ACT_SWIGLU_PAIR) {
+    // W rows interleaved [4 gate, 4 up] per 8 (ops.swiglu_interleave): row n (n & 4 == 0) is a gate row, row n + 4 its up row
+    if (n & 4) return;
+    const float u_ = (part[0][m][n + 4] + part[1][m][n + 4]) + (part[2][m][n + 4] + part[3][m][n + 4]);
+    const float gt = bf2f(f2bf(v)), up = bf2f(f2bf(u_));
+    const float o = gt * fast_sigmoid(gt) * up;
+    const int col = ((n0 + n) >> 3) * 4 + (n & 3);
+    if (p.y_dtype == GROVE_BF16) ((bf16_raw*)p.y)[(int64_t)m * p.ldy + col] = f2bf(o);
+    else ((float*)p.y)[(int64_t)m * p.ldy + col] = o;
+    return;
+  }
+  const int nn = n0 + n;
+  if (p.bias) v += bf2f(((const bf16_raw*)p.bias)[nn]);
+  v = act_apply(p.act, v);
+  if (p.residual) v += p.res_f32 ? ((const float*)p.residual)[(int64_t)m * p.ldr + nn] : bf2f(((const bf16_raw*)p.residual)[(int64_t)m * p.ldr + nn]);
+  if (p.y_dtype == GROVE_BF16) ((bf16_raw*)p.y)[(int64_t)m * p.ldy + nn] = f2bf(v);
+  else ((float*)p.y)[(int64_t)m * p.ldy + nn] = v;
+}
+
+static int g_gemv_mfma = 1;  // 0 = the VALU kernel for every M (A/B arm: grove_gemv_set_mfma)
+
 template <int MX, int RW>
 int launch_gemv_rw(const grove_gemv_params& p, hipStream_t s) {
   const size_t lds = (size_t)MX * p.K * 2;
@@ -245,12 +333,21 @@ int launch_gemv(const grove_gemv_params& p, hipStream_t s) {
 }
 }  // namespace
 
+extern "C" int grove_gemv_set_mfma(int32_t on) {
+  g_gemv_mfma = on != 0;
+  return GROVE_OK;
+}
+
 extern "C" int grove_gemv_bf16(const grove_gemv_params* pp, void* stream) {
   GROVE_CHECK(pp != nullptr, GROVE_E_SHAPE, "gemv: null params");
   const grove_gemv_params& p = *pp;
   GROVE_CHECK(p.M >= 1 && p.M <= 8, GROVE_E_SHAPE, "gemv: M=%d must be 1..8 (use grove_gemm_bf16 beyond)", p.M);
   GROVE_CHECK(p.N > 0 && p.K > 0 && p.K % 8 == 0, GROVE_E_SHAPE, "gemv: N=%d K=%d (K must be a multiple of 8)", p.N, p.K);
-  GROVE_CHECK((size_t)(p.M <= 2 ? p.M : p.M <= 4 ? 4 : 8) * p.K * 2 <= 159 * 1024, GROVE_E_SHAPE, "gemv: M*K=%d*%d does not fit the LDS", p.M, p.K);
+  // 3..8 sequences: the matrix-core kernel (x in LDS for the folded prologues, straight from global memory in plain mode)
+  const bool plain_x = p.x_mode == GROVE_GEMV_X_PLAIN && !p.x_f32;
+  const bool mfma = g_gemv_mfma && p.M >= 3 && p.K % 128 == 0 && (p.act != GROVE_ACT_SWIGLU_PAIR || p.N % 16 == 0) &&
+                    (plain_x || (size_t)8 * (p.K + 32) * 2 <= 150 * 1024);
+  GROVE_CHECK(mfma || (size_t)(p.M <= 2 ? p.M : p.M <= 4 ? 4 : 8) * p.K * 2 <= 159 * 1024, GROVE_E_SHAPE, "gemv: M*K=%d*%d does not fit the LDS", p.M, p.K);
   GROVE_CHECK(p.ldx % 8 == 0 && p.ldw % 8 == 0, GROVE_E_ALIGN, "gemv: ldx=%d ldw=%d must be multiples of 8", p.ldx, p.ldw);
   GROVE_CHECK(!p.x_f32 || p.x_mode != GROVE_GEMV_X_SWIGLU, GROVE_E_DTYPE, "gemv: x_mode swiglu reads a bf16 gate|up row");
   GROVE_CHECK(!p.x_f32 || (p.ldx % 4 == 0 && ((uintptr_t)p.x & 15) == 0), GROVE_E_ALIGN, "gemv: fp32 x rows must be 16-byte aligned");
@@ -261,6 +358,23 @@ extern "C" int grove_gemv_bf16(const grove_gemv_params* pp, void* stream) {
   GROVE_CHECK(p.act != GROVE_ACT_SWIGLU_PAIR || (p.N % 16 == 0 && !p.bias && !p.residual), GROVE_E_SHAPE,
               "gemv: act SWIGLU_PAIR needs N %% 16 == 0 (whole wave pairs), no bias, no residual");
   hipStream_t s = (hipStream_t)stream;
+  if (mfma) {
+    const dim3 grid((p.N + 15) / 16);
+    if (plain_x) {
+      hipLaunchKernelGGL((gemv_mfma_kernel<false, 8>), grid, dim3(GV_THREADS), 0, s, p);
+    } else {
+      static bool attr_set = false;
+      if (!attr_set) {
+        hipFuncSetAttribute((const void*)gemv_mfma_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        hipFuncSetAttribute((const void*)gemv_mfma_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr_set = true;
+      }
+      if (p.M <= 4) hipLaunchKernelGGL((gemv_mfma_kernel<true, 4>), grid, dim3(GV_THREADS), (size_t)4 * (p.K + 32) * 2, s, p);
+      else hipLaunchKernelGGL((gemv_mfma_kernel<true, 8>), grid, dim3(GV_THREADS), (size_t)8 * (p.K + 32) * 2, s, p);
+    }
+    GROVE_LAUNCH_CHECK();
+    return GROVE_OK;
+  }
   switch (p.M) {
     case 1: return launch_gemv<1>(p, s);
     case 2: return launch_gemv<2>(p, s);

@@ -393,6 +393,19 @@ def gemv(x, w, bias=None, *, act=ACT_NONE, residual=None, out_dtype=bf16, out=No
     assert x.shape[1] == (2 * K if swiglu else K) and x.stride(1) == 1 and w.stride(1) == 1
     assert x.dtype in (bf16, torch.float32) and (residual is None or residual.dtype in (bf16, torch.float32))
     mx = 1 if M == 1 else 2 if M == 2 else 4 if M <= 4 else 8
+    plain = rms_weight is None and not swiglu and x.dtype == bf16
+    mfma = M >= 3 and K % 128 == 0 and (act != ACT_SWIGLU_PAIR or N % 16 == 0) and (plain or 8 * (K + 32) * 2 <= 150 * 1024)
+    if mx * K * 2 > 159 * 1024 and M > 4 and not mfma:  # (the matrix-core kernel of 3..8 sequences reads a plain x straight from global memory)
+        # the kernel keeps its mx rows of x in LDS (bf16): 8 rows of LLaMA-7B's down-projection input (K = 11008) are 176 KB. Two
+        # launches of <= 4 rows each (88 KB): the weight matrix is streamed twice for the 5..8 sequences instead of once — still one
+        # stream per FOUR sequences (round 5: the clip-batched decode of infer_iground runs through here at B = 8)
+        if out is None:
+            out = torch.empty((M, N // 2 if act == ACT_SWIGLU_PAIR else N), dtype=out_dtype, device=x.device)
+        for lo in range(0, M, 4):
+            hi = min(M, lo + 4)
+            gemv(x[lo:hi], w, bias, act=act, residual=(residual[lo:hi] if residual is not None else None), out_dtype=out_dtype,
+                 out=out[lo:hi], rms_weight=rms_weight, eps=eps, swiglu=swiglu)
+        return out
     if mx != M:  # the kernel reads mx rows
         xp = torch.zeros((mx, x.shape[1]), dtype=x.dtype, device=x.device)
         xp[:M] = x

@@ -503,6 +503,10 @@ typedef struct grove_gemv_params {
   int32_t x_f32, res_f32;
 } grove_gemv_params;
 int grove_gemv_bf16(const grove_gemv_params* p, void* stream);
+/* A/B knob (round 5): 1 (default) = 3..8 sequences with K % 128 == 0 run on the matrix-core kernel (one weight stream feeds one
+ * v_mfma_f32_16x16x32_bf16 per 32-deep k-step: HBM-bound at 8 sequences, where the VALU kernel is compute-bound); 0 = the VALU
+ * kernel for every M. fp32 sum order differs between the two (both accumulate in fp32). */
+int grove_gemv_set_mfma(int32_t on);
 
 /* One cached decode step of causal self-attention for ONE new token per sequence (HF LlamaAttention with a KV cache):
  * rotates q and k of the new token in place (rotate-half RoPE at position pos[b], fp32), appends k | v to the cache row

@@ -47,44 +47,24 @@ def deep_narrow_dims():
                                clip_mlp=1024, sam_dim=320, sam_heads=4)
 
 
-def run_inference_parity(dev, which, outliers=0.0):
-    from grove_amd import GROVEForCausalLM
-    from grove_amd.model.decoder import BoxDecoder
-    from grove_amd.synthetic import FULL, synthetic_batch, synthetic_state_dict
+_ORACLE = {}
+
+
+def oracle_inference(dev, which, outliers=0.0):
+    """The fp32 CPU oracle's inference forward on the seed-11 input (B=1, T=8, L=128, n_det=3), ONCE per (dims, outliers) and process:
+    the bf16 parity case, the fp8 case and the seeds test all compare against the same pass (round 5, VERDICT r4 next #9a: the full-width
+    pass costs ~45 s of host time each and the suite sat at 632 s of the driver's 1200 s)."""
+    key = (which, outliers)
+    if key in _ORACLE:
+        return _ORACLE[key]
+    from grove_amd.synthetic import FULL, synthetic_batch
     from oracle import grove_oracle as O
     d = FULL if which == "full" else deep_narrow_dims()
-    t0 = time.time()
-    sd_dev = synthetic_state_dict(d, device=dev, dtype=bf, outliers=outliers)
-    model = GROVEForCausalLM(dims=d, device=dev, state_dict=sd_dev, det_token_idx=d.det_token_idx, num_frames=8)  # pe_dtype: bf16 default
-    del sd_dev
-    torch.cuda.empty_cache()
-    batch = synthetic_batch(d, B=1, T=8, L=128, n_det=3, seed=11)
-    kw = batch.as_kwargs(inference=True)
-    kd = dict(kw)
-    for k in ("global_enc_images", "grounding_enc_images"):
-        kd[k] = kw[k].to(dev).to(bf)
-    for k in ("input_ids", "labels", "attention_masks", "offset"):
-        kd[k] = kw[k].to(dev)
-    out_bf = model(**kd)                                   # product default: dense PE in bf16 (quirk Q10)
-    model.decoder = BoxDecoder(model._sd, d, dev, grads=model._grad, pe_dtype=torch.float32)
-    out = model(**kd)                                      # fp32 PE: the arithmetic-parity configuration of the other tests
-    feats_h, clip_h = model(mode="encode_images", images=kd["global_enc_images"])
-    torch.cuda.synchronize()
-    t_gpu = time.time() - t0
-
-    sd = LazyRoundedWeights(d, gen_device=dev, outliers=outliers)
-    torch.set_num_threads(min(os.cpu_count() or 1, 64))
-    gi, si = kw["global_enc_images"].to(bf).float(), kw["grounding_enc_images"].to(bf).float()
-    t0 = time.time()
-    with torch.no_grad():
-        emb_o = O.sam_image_encoder(sd, d, si)
-        feats_o, hs_o = O.encode_images(sd, d, gi)
-        embeds, _, _ = O.splice(sd, kw["input_ids"], None, None, feats_o)
-        hidden_o = O.llama_forward(sd, d, embeds, None)
-        pemb = O.pred_embeddings(sd, d, hidden_o, O.det_token_mask(d, kw["input_ids"]))
-        _, _, box_o, obj_o = O.decode_boxes(sd, d, pemb, emb_o, kw["original_size_list"], O.dense_pe(sd, d), True)
-        _, _, box_ob, obj_ob = O.decode_boxes(sd, d, pemb, emb_o, kw["original_size_list"], O.dense_pe(sd, d, dtype=bf).float(), True)
-    t_cpu = time.time() - t0
+    kw = synthetic_batch(d, B=1, T=8, L=128, n_det=3, seed=11).as_kwargs(inference=True)
+    orc = oracle_inference(dev, which, outliers)
+    emb_o, feats_o, hidden_o, box_o, obj_o, box_ob, obj_ob = (orc[k] for k in ("emb_o", "feats_o", "hidden_o", "box_o", "obj_o", "box_ob", "obj_ob"))
+    hs_o = [orc["hs_m2"]]
+    t_cpu = orc["seconds"]
 
     g = d.sam_grid
     emb_h = out["image_embeddings"].float().cpu().view(8, g, g, -1).permute(0, 3, 1, 2)
@@ -366,7 +346,7 @@ def test_full_width_box_l1_over_seeds(dev):
     sd = LazyRoundedWeights(d, gen_device=dev)
     torch.set_num_threads(min(os.cpu_count() or 1, 64))
     vals, maxs, objs, secs = [], [], [], []
-    for seed in (21, 22, 23):
+    for seed in (11, 21, 22):  # (seed 11's oracle pass is the cached one of the parity case above: two fresh ~45 s passes instead of three)
         batch = synthetic_batch(d, B=1, T=8, L=128, n_det=3, seed=seed)
         kw = batch.as_kwargs(inference=True)
         kd = dict(kw)
@@ -377,14 +357,18 @@ def test_full_width_box_l1_over_seeds(dev):
             kd[k] = kw[k].to(dev)
         out = model(**kd)
         t0 = time.time()
-        with torch.no_grad():
-            ref = O.model_forward(sd, d, **kw)
+        if seed == 11:
+            orc = oracle_inference(dev, "full")
+            ref = {"flat_boxes": orc["box_o"], "flat_logits": orc["obj_o"]}
+        else:
+            with torch.no_grad():
+                ref = O.model_forward(sd, d, **kw)
         secs.append(round(time.time() - t0, 1))
         e = (out["flat_boxes"].cpu() - ref["flat_boxes"]).abs()
         vals.append(e.mean().item())
         maxs.append(e.max().item())
         objs.append((out["flat_logits"].cpu() - ref["flat_logits"]).abs().max().item())
-    res = {"config": "FULL dims (LLaMA 32x4096, CLIP 24x1024, SAM 32x1280), inference model (fp32 streams, fp32 box path), B=1, T=8, L=128, n_det=3, seeds 21-23",
+    res = {"config": "FULL dims (LLaMA 32x4096, CLIP 24x1024, SAM 32x1280), inference model (fp32 streams, fp32 box path), B=1, T=8, L=128, n_det=3, seeds 11, 21, 22",
            "box_l1": vals, "box_l1_max": maxs, "objectness_logit_abs_err": objs, "mean": sum(vals) / len(vals), "oracle_seconds": secs,
            "seed_11_recorded": "profiles/r03_full_depth_parity_full.json: 7.9e-4 mean / 2.1e-3 max"}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
@@ -432,16 +416,8 @@ def run_fp8_parity(dev, which, policy, outliers=0.0):
     out = model(**kd)
     feats_h, _ = model(mode="encode_images", images=kd["global_enc_images"])
     torch.cuda.synchronize()
-    sd = LazyRoundedWeights(d, gen_device=dev, outliers=outliers)
-    torch.set_num_threads(min(os.cpu_count() or 1, 64))
-    gi, si = kw["global_enc_images"].to(bf).float(), kw["grounding_enc_images"].to(bf).float()
-    with torch.no_grad():
-        emb_o = O.sam_image_encoder(sd, d, si)
-        feats_o, _ = O.encode_images(sd, d, gi)
-        embeds, _, _ = O.splice(sd, kw["input_ids"], None, None, feats_o)
-        hidden_o = O.llama_forward(sd, d, embeds, None)
-        pemb = O.pred_embeddings(sd, d, hidden_o, O.det_token_mask(d, kw["input_ids"]))
-        _, _, box_o, obj_o = O.decode_boxes(sd, d, pemb, emb_o, kw["original_size_list"], O.dense_pe(sd, d), True)
+    orc = oracle_inference(dev, which, outliers)  # the same seed-11 pass the bf16 case compares against
+    feats_o, hidden_o, box_o, obj_o = orc["feats_o"], orc["hidden_o"], orc["box_o"], orc["obj_o"]
     res = {"config": ("FULL dims" if which == "full" else "full depth at quarter width") + ", gemm_dtype=fp8 (CLIP + LLaMA linear layers, e4m3, per-row / "
            "per-output-channel scales), B=1, T=8, L=128, n_det=3, inference forward vs fp32 oracle",
            "fp8_policy": policy, "llama_projections_quantised": n_q, "box_l1_vs_oracle": (out["flat_boxes"].cpu() - box_o).abs().mean().item(),
@@ -554,3 +530,63 @@ def test_outlier_stress_deep_narrow(dev):
     # channels and bf16 first layers change nothing; CLIP in bf16 does): 9.6e-4 measured (profiles/r04_fp8_clip_policy_deep_narrow.json)
     q16 = run_fp8_parity(dev, "deep_narrow", "det16_kv16_clip16", outliers=F)
     assert q16["box_l1_vs_oracle"] <= 1.5e-3 and q16["box_l1_vs_oracle"] < 0.2 * q["box_l1_vs_oracle"], (q16, q)
+
+
+def test_bench_shape_step_equals_its_windows_full_dims(dev):
+    """Round 5 (VERDICT r4 next #9e): the shape the headline bench times — B = 2 clips x T = 16 frames = four 8-frame windows, GEMMs at
+    M = 2812 / 32768 with their stream-K cuts, temporal tap skipping and the last-layer tail — is otherwise covered only by the
+    bit-repeat race screen; every oracle comparison at full dims runs B = 1, T = 8 (M = 703 / 8192: other tile plans). Here the two
+    meet on the SAME model: a batch whose four windows are identical (both clips equal, frames 8..15 = frames 0..7) must give the
+    loss terms of the one-window step (every normaliser — labelled tokens, ground-truth boxes, instances — scales with the window
+    count) and the same gradient (mean over four equal windows), up to fp32 sum order: five loss terms to 1e-3, the whole 481 M-element
+    gradient and every parameter group at cosine >= 0.999 with norm ratio within 1 %."""
+    from grove_amd import GROVEForCausalLM
+    from grove_amd.synthetic import FULL, synthetic_batch, synthetic_state_dict
+    d = FULL
+    sd_dev = synthetic_state_dict(d, device=dev, dtype=bf)
+    model = GROVEForCausalLM(dims=d, device=dev, state_dict=sd_dev, det_token_idx=d.det_token_idx, num_frames=8, train=True)
+    del sd_dev
+    torch.cuda.empty_cache()
+    b1 = synthetic_batch(d, B=1, T=8, L=128, n_det=3, seed=11)
+    k1 = b1.as_kwargs()
+    one = dict(k1)
+    for k in ("global_enc_images", "grounding_enc_images"):
+        one[k] = k1[k].to(dev).to(bf)
+    for k in ("input_ids", "labels", "attention_masks", "offset"):
+        one[k] = k1[k].to(dev)
+    four = dict(one)
+    for k in ("global_enc_images", "grounding_enc_images"):
+        four[k] = torch.cat([one[k], one[k]], 2).repeat(2, 1, 1, 1, 1).contiguous()      # [2, 3, 16, H, W]
+    for k in ("input_ids", "labels", "attention_masks"):
+        four[k] = one[k].repeat(2, 1)
+    four["bboxes_list"] = [list(k1["bboxes_list"][0]) * 2 for _ in range(2)]
+    four["temp_objectness_labels_list"] = [list(k1["temp_objectness_labels_list"][0]) * 2 for _ in range(2)]
+    four["original_size_list"] = [k1["original_size_list"][0]] * 2
+    four["offset"] = torch.arange(3, device=dev)
+    keys = ("ce_loss", "giou_loss", "l1_loss", "temp_objectness_loss", "loss")
+    res = {}
+    for name, kw in (("one_window", one), ("bench_shape", four)):
+        model.zero_grad()
+        out = model(**kw)
+        model.backward(out["loss"])
+        torch.cuda.synchronize()
+        res[name] = ({k: float(out[k]) for k in keys}, model._flat_grad.clone())
+    (l1, g1), (l4, g4) = res["one_window"], res["bench_shape"]
+    rec = {"losses_one_window": l1, "losses_bench_shape": l4, "groups": {}}
+    cos = torch.nn.functional.cosine_similarity(g1, g4, dim=0).item()
+    rec["whole_gradient"] = {"cosine": cos, "norm_ratio": (g4.norm() / g1.norm()).item(), "elements": g1.numel()}
+    for gname, pre in GROUPS:
+        names = [n for n in model.trainable if n.startswith(pre)]
+        lo = min(model._grad_off[n] for n in names)
+        hi = max(model._grad_off[n] + model._grad_slot[n] for n in names)
+        a, c = g1[lo:hi], g4[lo:hi]
+        rec["groups"][gname] = {"cosine": torch.nn.functional.cosine_similarity(a, c, dim=0).item(), "norm_ratio": (c.norm() / a.norm().clamp_min(1e-30)).item()}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "bench_shape_consistency_full.json"), "w") as fh:
+        json.dump(rec, fh, indent=1)
+    print(json.dumps(rec))
+    for k in keys:
+        assert abs(l4[k] - l1[k]) <= 1e-3 * max(1.0, abs(l1[k])), (k, l1[k], l4[k])
+    assert cos >= 0.999 and abs(rec["whole_gradient"]["norm_ratio"] - 1.0) <= 0.01, rec["whole_gradient"]
+    for gname, v in rec["groups"].items():
+        assert v["cosine"] >= 0.999 and abs(v["norm_ratio"] - 1.0) <= 0.01, (gname, v)

@@ -999,6 +999,60 @@ def test_gemv_fused_rmsnorm_and_swiglu(dev):
     close(yp, xc.to(bf16).float() @ w.float().cpu().t(), 2 ** -10, "gemv with plain fp32 x")
 
 
+@pytest.mark.parametrize("M", [3, 4, 5, 8])
+def test_gemv_matrix_core_kernel_for_batched_decode(dev, M):
+    """Round 5: 3..8 sequences (the clip-batched decode) run the weight stream through v_mfma_f32_16x16x32_bf16 (gemv_mfma_kernel):
+    every prologue (plain x from global memory incl. LLaMA's K = 11008 that does not fit the LDS at 8 rows, folded RMSNorm on a bf16
+    and on an fp32 stream, fused SwiGLU input) and epilogue (bias + activation + residual, fp32 output, the SwiGLU pair) against
+    the VALU kernel of the same library (grove_gemv_set_mfma(0); one row at a time where 8 rows of K do not fit its LDS) and fp32."""
+    from grove_amd import _lib, ops
+    Lb = _lib.lib()
+
+    def both(fn):
+        Lb.grove_gemv_set_mfma(1)
+        a = fn()
+        Lb.grove_gemv_set_mfma(0)
+        try:
+            b = fn()
+        finally:
+            Lb.grove_gemv_set_mfma(1)
+        return a, b
+    # plain x, long K (the down projection), ragged N
+    K, N = 11008, 200
+    x, w = rnd(M, K, seed=1).to(dev), rnd(N, K, seed=2, scale=0.05).to(dev)
+    bias, res = rnd(N, seed=3).to(dev), rnd(M, N, seed=4).to(dev)
+    y = ops.gemv(x, w, bias, act=ops.ACT_RELU, residual=res)
+    ref = F.relu(x.float().cpu() @ w.float().cpu().t() + bias.float().cpu()) + res.float().cpu()
+    close(y, ref, 2 ** -7, "mfma gemv plain K=11008 vs fp32")
+    Lb.grove_gemv_set_mfma(0)
+    try:
+        y1 = torch.cat([ops.gemv(x[i:i + 1], w, bias, act=ops.ACT_RELU, residual=res[i:i + 1]) for i in range(M)], 0)
+    finally:
+        Lb.grove_gemv_set_mfma(1)
+    close(y, y1.float().cpu(), 2 ** -7, "mfma gemv vs VALU kernel row by row")
+    # folded RMSNorm (bf16 x), K = 4096; fp32 output
+    K, N = 4096, 528
+    x, w, nw = rnd(M, K, seed=5).to(dev), rnd(N, K, seed=6, scale=0.05).to(dev), rnd(K, seed=7).to(dev)
+    a, b = both(lambda: ops.gemv(x, w, rms_weight=nw, eps=1e-5, out_dtype=torch.float32))
+    close(a, b.cpu(), 2 ** -9, "mfma gemv rmsnorm-folded vs VALU kernel")
+    # fp32 stream input with the norm folded + fp32 residual (the inference model's decode step)
+    xf = (x.float() * 1.001).contiguous()
+    r32 = rnd(M, N, seed=8).to(dev).float() * 1.003
+    a, b = both(lambda: ops.gemv(xf, w, rms_weight=nw, eps=1e-5, residual=r32, out_dtype=torch.float32))
+    close(a, b.cpu(), 2 ** -9, "mfma gemv fp32-stream vs VALU kernel")
+    # fused SwiGLU input (gate | up row)
+    K2 = 1024
+    gu, w2 = rnd(M, 2 * K2, seed=9).to(dev), rnd(N, K2, seed=10, scale=0.05).to(dev)
+    a, b = both(lambda: ops.gemv(gu, w2, swiglu=True))
+    close(a, b.float().cpu(), 2 ** -7, "mfma gemv swiglu-input vs VALU kernel")
+    # the SwiGLU pair epilogue of the gate|up projection (rows interleaved 4 gate / 4 up)
+    I, Kx = 96, 2304
+    wgu, xs2, nw2 = rnd(2 * I, Kx, seed=21, scale=0.1).to(dev), rnd(M, Kx, seed=22).to(dev), rnd(Kx, seed=23).to(dev)
+    a, b = both(lambda: ops.gemv(xs2, ops.swiglu_interleave(wgu), rms_weight=nw2, eps=1e-5, act=ops.ACT_SWIGLU_PAIR))
+    assert a.shape == (M, I)
+    close(a, b.float().cpu(), 2 ** -7, "mfma gemv swiglu-pair epilogue vs VALU kernel")
+
+
 @pytest.mark.parametrize("B,H,hd,t,Smax", [(2, 4, 32, 36, 64), (1, 8, 128, 699, 768), (3, 2, 64, 0, 16), (2, 32, 128, 1500, 2048)])
 def test_decode_attention_fused(dev, B, H, hd, t, Smax):
     """grove_decode_attn = rope(q, k) + cache append + one-query attention, vs the unfused kernels and fp32."""

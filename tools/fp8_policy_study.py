@@ -11,6 +11,8 @@ Policies (LLaMA; CLIP is `clip8` on/off):
               input is the RMSNorm of the residual stream) go through a bf16 side product (K = 3 channels), the e4m3 GEMM sees them zeroed
   smooth      SmoothQuant: per-input-channel s_j = sqrt(amax|x_j| / amax|W_j|) folded into the norm weight (x / s) and the weight (W s)
 Usage: python tools/fp8_policy_study.py [tiny|deep_narrow] [--outliers F]   (F > 0: synthetic massive activations, grove_amd/synthetic.py)
+       python tools/fp8_policy_study.py deep_narrow --sam   (round 5, VERDICT r4 next #10: the SAM arm — e4m3 for the SAM tower's
+       mlp.lin1 / lin2 (two thirds of its GEMM FLOPs), then qkv / proj as well, on top of the bf16 path and of the default LLaMA policy)
 """
 import json
 import os
@@ -150,6 +152,47 @@ def main():
     def rms(a, b):
         return ((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt()).item()
 
+    sam_arm = "--sam" in sys.argv
+
+    def sam_embs(which_layers):
+        """SAM tower with the named linear layers of every block fake-quantised to e4m3 (per-row activations, per-channel weights)."""
+        if not which_layers:
+            return emb_o
+        orig = O._lin
+        pol0 = Policy("sam")
+
+        def lin(sd_, name, x):
+            if name.startswith(O.S + "blocks.") and name.rsplit(".", 2)[-2] + "." + name.rsplit(".", 2)[-1] in which_layers or \
+                    (name.startswith(O.S + "blocks.") and name.rsplit(".", 1)[-1] in which_layers):
+                return lin8(x, sd_[name + ".weight"], sd_.get(name + ".bias"), pol0)
+            return orig(sd_, name, x)
+        O._lin = lin
+        try:
+            return O.sam_image_encoder(sd, d, si)
+        finally:
+            O._lin = orig
+
+    if sam_arm:
+        rows = []
+        with torch.no_grad():
+            base = Policy("bf16 (no fp8)", clip8=False, llama8=False)
+            dflt = Policy("det16_kv16 clip16", det16=True, kv16=True, clip8=False)
+            feats = clip_feats(base)
+            embeds, _, _ = O.splice(sd, ids, None, None, feats)
+            hid = {"bf16": llama(base, embeds), "det16_kv16_clip16": llama(dflt, embeds)}
+            for sam_name, layers in (("SAM bf16", ()), ("SAM mlp.lin1 + mlp.lin2 e4m3", ("mlp.lin1", "mlp.lin2")),
+                                     ("SAM mlp + qkv + proj e4m3", ("mlp.lin1", "mlp.lin2", "qkv", "proj"))):
+                emb = sam_embs(layers)
+                for hname, hidden in hid.items():
+                    _, _, box, obj = O.decode_boxes(sd, d, O.pred_embeddings(sd, d, hidden, mask), emb, kw["original_size_list"], pe, True)
+                    r = {"sam": sam_name, "llama_clip": hname, "sam_emb_rms": rms(emb, emb_o), "box_l1": (box - box_o).abs().mean().item(),
+                         "box_max": (box - box_o).abs().max().item(), "obj_abs": (obj - obj_o).abs().max().item()}
+                    rows.append(r)
+                    print(json.dumps(r), flush=True)
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open(f"gpurun_out/fp8_policy_study_{which}_sam.json", "w") as fh:
+            json.dump(rows, fh, indent=1)
+        return
     if outl:
         pols = [Policy("bf16 (no fp8)", clip8=False, llama8=False), Policy("all8"), Policy("all8 + out16", out16=True), Policy("all8 + smooth", smooth=True),
                 Policy("det16_kv16", det16=True, kv16=True), Policy("det16_kv16 + out16", det16=True, kv16=True, out16=True),
