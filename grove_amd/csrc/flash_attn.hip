@@ -867,6 +867,10 @@ int grove_win_attn_bwd_launch(const grove_flash_attn_params* p, hipStream_t s);
 // flash_attn2.hip: the round-5 eight-wave kernels
 bool grove_flash2_fwd_applicable(const grove_flash_attn_params* p);
 int grove_flash2_fwd_launch(const grove_flash_attn_params* p, hipStream_t s);
+bool grove_flash2_bwd_dq_applicable(const grove_flash_attn_params* p);
+int grove_flash2_bwd_dq_launch(const grove_flash_attn_params* p, int make_delta, hipStream_t s);
+bool grove_flash2_bwd_dkv_applicable(const grove_flash_attn_params* p);
+int grove_flash2_bwd_dkv_launch(const grove_flash_attn_params* p, hipStream_t s);
 static int g_win_attn = 1;  // 0 = always the general kernels (A/B arm: grove_flash_attn_set_window_kernels)
 static int g_reg_e = 1;     // 0 = the LDS indicator tile also where the register form applies (A/B arm: grove_flash_attn_set_register_e)
 extern "C" int grove_flash_attn_set_register_e(int32_t on) {
@@ -946,12 +950,16 @@ extern "C" int grove_flash_attn_bwd(const grove_flash_attn_params* p, void* stre
   if (!vec16) hipLaunchKernelGGL(flash_delta_kernel<false>, dim3((unsigned)((nrows + 15) / 16)), dim3(NTHR), 0, s, *p);
   const int nrel = p->rel ? p->rel_ld : 0;
   dim3 gk((p->Lk + 127) / 128, p->H, p->B), gq((p->Lq + 127) / 128, p->H, p->B);
+  // round 5: the dQ (+ delta, + d rel') kernel in the eight-wave form where it applies; dK / dV stays the four-wave kernel
+  const bool dq2 = make_delta && grove_flash2_bwd_dq_applicable(p);
+  if (dq2) grove_flash2_bwd_dq_launch(p, make_delta, s);
+  const bool dkv2 = grove_flash2_bwd_dkv_applicable(p);  // (delta is in p.delta by now: made by the dQ kernel or by flash_delta_kernel, same stream)
 #define BWD_L(HS, NRK)                                                                                     \
   {                                                                                                        \
     hipFuncSetAttribute((const void*)flash_bwd_dkv_kernel<HS, NRK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1); \
     hipFuncSetAttribute((const void*)flash_bwd_dq_kernel<HS, NRK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);  \
-    hipLaunchKernelGGL((flash_bwd_dq_kernel<HS, NRK>), gq, dim3(NTHR), l2, s, *p, make_delta);              \
-    hipLaunchKernelGGL((flash_bwd_dkv_kernel<HS, NRK>), gk, dim3(NTHR), l1, s, *p);                         \
+    if (!dq2) hipLaunchKernelGGL((flash_bwd_dq_kernel<HS, NRK>), gq, dim3(NTHR), l2, s, *p, make_delta);    \
+    if (!dkv2) hipLaunchKernelGGL((flash_bwd_dkv_kernel<HS, NRK>), gk, dim3(NTHR), l1, s, *p);              \
   }
 #define BWD(HS)                                                                                            \
   {                                                                                                        \
@@ -962,6 +970,7 @@ extern "C" int grove_flash_attn_bwd(const grove_flash_attn_params* p, void* stre
   DISPATCH_HS(p, BWD)
 #undef BWD
 #undef BWD_L
+  if (dkv2) grove_flash2_bwd_dkv_launch(p, s);
   GROVE_LAUNCH_CHECK();
   return GROVE_OK;
 }
