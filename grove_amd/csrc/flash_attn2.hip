@@ -894,6 +894,7 @@ __global__ __launch_bounds__(NT2, 2) void flash2_bwd_dq_kernel(const grove_flash
   __builtin_amdgcn_s_barrier();                                   \
   __builtin_amdgcn_sched_barrier(0);
 
+  f32x4_t rope_c[C::DT / 2 > 0 ? C::DT / 2 : 1][4], rope_s[C::DT / 2 > 0 ? C::DT / 2 : 1][4];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (nsub > 0) {  // (workgroup-uniform)
@@ -925,6 +926,19 @@ __global__ __launch_bounds__(NT2, 2) void flash2_bwd_dq_kernel(const grove_flash
       SEG_END2();
       slot = nslot;
     }
+    // the cos | sin rows of the fused inverse RoPE are fetched HERE, under the last two segments (Q and dO fragments are dead: their
+    // registers take them): fetched in the epilogue, the sixteen dependent-on-nothing but late loads cost 9 us of a 53 us launch
+    if (p.rope && wave_live) {
+      const float* cs = p.rope + (int64_t)(qi + coff) * HS;
+#pragma unroll
+      for (int dt = 0; dt < (C::DT / 2 > 0 ? C::DT / 2 : 1); ++dt)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const int d0 = dt * 32 + 8 * r4 + 4 * hi;
+          rope_c[dt][r4] = *(const f32x4_t*)(cs + d0);
+          rope_s[dt][r4] = *(const f32x4_t*)(cs + HS / 2 + d0);
+        }
+    }
     DS(nsub - 1);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -937,15 +951,13 @@ __global__ __launch_bounds__(NT2, 2) void flash2_bwd_dq_kernel(const grove_flash
 #undef SEG_END2
 
   // ---- epilogue: dQ^T[d][q] (inverse RoPE in place) -> wave-private LDS rows [q][d] -> 16-byte coalesced stores; d rel'
-  if (p.rope && wave_live) {
+  if (p.rope && wave_live && nsub > 0) {
     // query i sits at position i + Lk - Lq; the lane holds both halves (d tiles dt and dt + DT / 2) of its rotation pairs
-    const float* cs = p.rope + (int64_t)(qi + coff) * HS;
 #pragma unroll
     for (int dt = 0; dt < C::DT / 2; ++dt)
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
-        const int d0 = dt * 32 + 8 * r4 + 4 * hi;
-        const f32x4_t c = *(const f32x4_t*)(cs + d0), sn = *(const f32x4_t*)(cs + HS / 2 + d0);
+        const f32x4_t c = rope_c[dt][r4], sn = rope_s[dt][r4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const float y1 = dqacc[dt][r4 * 4 + i], y2 = dqacc[dt + C::DT / 2][r4 * 4 + i];
@@ -1004,7 +1016,13 @@ __global__ __launch_bounds__(NT2, 2) void flash2_bwd_dq_kernel(const grove_flash
 // non-zero entries carry the softmax scale in bf16).
 // Register budget at head dim 96: dK, dV 96 + K, V 48 + S, dP 32 + P, dS 16 + read buffers 20-28 + indicator 16: two waves per SIMD. Head
 // dim 128 does not fit (128 + 64 before any score tile) and keeps the four-wave kernel of flash_attn.hip.
-template <int HS, int REL>
+// SPLIT (head dim 128): dK^T and dV^T of 32 keys are 128 registers, K and V fragments 64 more — a wave cannot hold both products. The
+// two waves of a SIMD then share ONE group of 32 keys and split the products: the leading half (waves 0-3) runs S, dP, dS and dK^T,
+// the lagging half (waves 4-7) runs S, P and dV^T (S is computed twice: 40 MFMAs per sub-step and key group instead of 32, but in the
+// two-waves-per-SIMD form). A workgroup then owns 128 keys. The role is a wave-uniform branch around two instantiations of the body:
+// their register sets are disjoint live ranges.
+enum { ROLE_BOTH = 0, ROLE_DK = 1, ROLE_DV = 2 };
+template <int HS, int REL, bool SPLIT>
 __global__ __launch_bounds__(NT2, 2) void flash2_bwd_dkv_kernel(const grove_flash_attn_params p) {
   using C = C2<HS>;
   using CR = C2<64>;  // the rel' tile: 64 bins = 128-byte rows
@@ -1021,8 +1039,8 @@ __global__ __launch_bounds__(NT2, 2) void flash2_bwd_dkv_kernel(const grove_flas
   const int l31 = lane & 31, hi = lane >> 5;
   int bx, h, b;
   causal_order2(p.causal != 0, false, bx, h, b);
-  const int kblk = bx * BQ2;
-  const int k0 = kblk + wave * 32;
+  const int kblk = bx * (SPLIT ? BQ2 / 2 : BQ2);
+  const int k0 = kblk + (SPLIT ? (wave & 3) : wave) * 32;
   const bf16_raw* Kp = (const bf16_raw*)p.k + (int64_t)b * p.sk + h * HS;
   const bf16_raw* Vp = (const bf16_raw*)p.v + (int64_t)b * p.sv + h * HS;
   const char* Q = (const char*)((const bf16_raw*)p.q + (int64_t)b * p.sq + h * HS);
@@ -1063,13 +1081,16 @@ __global__ __launch_bounds__(NT2, 2) void flash2_bwd_dkv_kernel(const grove_flas
       del_s[i] = i < p.Lq ? DEL[i] * p.alpha : 0.f;
     }
   }
+  auto body = [&](auto role_tag) {
+  constexpr int ROLE = decltype(role_tag)::value;
   // K, V fragments of this wave's keys: B[k = d][col = key]
   const int kj = min(k0 + l31, p.Lk - 1);
-  bf16x8_t kf[C::KS], vf[C::KS];
+  constexpr bool DK_ = ROLE != ROLE_DV, DV_ = ROLE != ROLE_DK;  // which products this wave runs
+  bf16x8_t kf[C::KS], vf[DK_ ? C::KS : 1];
 #pragma unroll
   for (int ks = 0; ks < C::KS; ++ks) {
     kf[ks] = scale8(*(const bf16x8_t*)(Kp + (int64_t)kj * p.ld_k + ks * 16 + hi * 8), sc);
-    vf[ks] = *(const bf16x8_t*)(Vp + (int64_t)kj * p.ld_v + ks * 16 + hi * 8);
+    if constexpr (DK_) vf[ks] = *(const bf16x8_t*)(Vp + (int64_t)kj * p.ld_v + ks * 16 + hi * 8);
   }
   // indicator column of key k0 + l31: bins kh = key / 32 and 32 + key % 32 (rel_kw == rel_kh == 32). A wave's 32 keys share kh, so of the two
   // 16-bin k-steps of the h bins only the one that holds kh is run (its index is wave-uniform: it picks the A operand's chunk); the w bins
@@ -1093,11 +1114,14 @@ __global__ __launch_bounds__(NT2, 2) void flash2_bwd_dkv_kernel(const grove_flas
     }
     return __builtin_bit_cast(bf16x8_t, e);
   };
-  f32x16_t dk[C::DT], dv[C::DT];
+  f32x16_t dk[DK_ ? C::DT : 1], dv[DV_ ? C::DT : 1];
 #pragma unroll
   for (int dt = 0; dt < C::DT; ++dt)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dk[dt][r] = 0.f, dv[dt][r] = 0.f;
+    for (int r = 0; r < 16; ++r) {
+      if constexpr (DK_) dk[dt][r] = 0.f;
+      if constexpr (DV_) dv[dt][r] = 0.f;
+    }
   f32x16_t s, dp;
   bf16x8_t pfr[2], dsf[2];
 
@@ -1107,7 +1131,8 @@ __global__ __launch_bounds__(NT2, 2) void flash2_bwd_dkv_kernel(const grove_flas
   // X segment: slots [0, 2 DT) dV, [2 DT, 4 DT) dK (two transposed reads each), then [4 bias,] S / dP alternating (one row read each)
   auto XSEG = [&](auto do_g, auto do_s, int pslot, int psub, int cslot, int csub) {
     constexpr bool DO_G = decltype(do_g)::value, DO_S = decltype(do_s)::value;
-    constexpr int NG = DO_G ? 4 * C::DT : 0, NB = (DO_S && REL) ? 3 : 0, NS = DO_S ? 2 * C::KS : 0, NM = NG + NB + NS;
+    constexpr int NGV = (DO_G && DV_) ? 2 * C::DT : 0, NGK = (DO_G && DK_) ? 2 * C::DT : 0, NG = NGV + NGK;  // dV slots first, then dK
+    constexpr int NB = (DO_S && REL) ? 3 : 0, NS = DO_S ? (DK_ ? 2 : 1) * C::KS : 0, NM = NG + NB + NS;
     // per-lane LDS read offsets, re-derived from the lane id HERE (laundered: not hoisted), so that they do not occupy seven registers
     // through the vector segment, which is this kernel's register peak
     int ln = lane;
@@ -1142,8 +1167,8 @@ __global__ __launch_bounds__(NT2, 2) void flash2_bwd_dkv_kernel(const grove_flas
       if constexpr (m < NM) {
         constexpr int bq = m % (LOOK + 1);
         if constexpr (m < NG) {
-          constexpr int mm = m % (2 * C::DT), dt = mm / 2, kk = mm % 2;
-          const unsigned a0 = (m < 2 * C::DT ? dt_ : qt_) + ((dt << 6) ^ vx);
+          constexpr int mm = m < NGV ? m : m - NGV, dt = mm / 2, kk = mm % 2;
+          const unsigned a0 = (m < NGV ? dt_ : qt_) + ((dt << 6) ^ vx);
           fr[bq][0] = ds_tr16_o<kk * 16 * C::ROWB>(a0);
           fr[bq][1] = ds_tr16_o<kk * 16 * C::ROWB>(a0 + vd1);
         } else if constexpr (m < NG + NB) {
@@ -1151,7 +1176,7 @@ __global__ __launch_bounds__(NT2, 2) void flash2_bwd_dkv_kernel(const grove_flas
           const int ks = e3 == 0 ? ksh : e3 + 1;
           ds_read128<0>(rr_ + ((ks << 5) ^ rx), fr[bq][0], fr[bq][1]);
         } else {
-          constexpr int ks = (m - NG - NB) / 2, which = (m - NG - NB) % 2;
+          constexpr int ks = DK_ ? (m - NG - NB) / 2 : (m - NG - NB), which = DK_ ? (m - NG - NB) % 2 : 0;
           ds_read128<0>((which ? dr_ : qr_) + ((ks << 5) ^ kx), fr[bq][0], fr[bq][1]);
         }
       }
@@ -1171,21 +1196,21 @@ __global__ __launch_bounds__(NT2, 2) void flash2_bwd_dkv_kernel(const grove_flas
       }
       const f32x16_t z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       if constexpr (m < NG) {
-        constexpr int mm = m % (2 * C::DT), dt = mm / 2, kk = mm % 2;
-        if constexpr (m < 2 * C::DT) dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(fr[bq][0], fr[bq][1]), pfr[kk], dv[dt], 0, 0, 0);
-        else dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(fr[bq][0], fr[bq][1]), dsf[kk], dk[dt], 0, 0, 0);
+        constexpr int mm = m < NGV ? m : m - NGV, dt = mm / 2, kk = mm % 2;
+        if constexpr (m < NGV) dv[DV_ ? dt : 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(fr[bq][0], fr[bq][1]), pfr[kk], dv[DV_ ? dt : 0], 0, 0, 0);
+        else dk[DK_ ? dt : 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(fr[bq][0], fr[bq][1]), dsf[kk], dk[DK_ ? dt : 0], 0, 0, 0);
       } else if constexpr (m < NG + NB) {
         constexpr int e3 = m - NG;
         if constexpr (e3 == 0) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(fr[bq][0], fr[bq][1]), efrag(e3), z, 0, 0, 0);
         else s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(fr[bq][0], fr[bq][1]), efrag(e3), s, 0, 0, 0);
       } else {
-        constexpr int ks = (m - NG - NB) / 2, which = (m - NG - NB) % 2;
+        constexpr int ks = DK_ ? (m - NG - NB) / 2 : (m - NG - NB), which = DK_ ? (m - NG - NB) % 2 : 0;
         if constexpr (which == 0) {
           if constexpr (ks == 0 && !REL) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(fr[bq][0], fr[bq][1]), kf[ks], z, 0, 0, 0);
           else s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(fr[bq][0], fr[bq][1]), kf[ks], s, 0, 0, 0);
         } else {
-          if constexpr (ks == 0) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(fr[bq][0], fr[bq][1]), vf[ks], z, 0, 0, 0);
-          else dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(fr[bq][0], fr[bq][1]), vf[ks], dp, 0, 0, 0);
+          if constexpr (ks == 0) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(fr[bq][0], fr[bq][1]), vf[DK_ ? ks : 0], z, 0, 0, 0);
+          else dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(fr[bq][0], fr[bq][1]), vf[DK_ ? ks : 0], dp, 0, 0, 0);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -1197,7 +1222,7 @@ __global__ __launch_bounds__(NT2, 2) void flash2_bwd_dkv_kernel(const grove_flas
   const int key = k0 + l31;
   auto PDS = [&](int u) {
     const int qs = u * 32;
-    float seed = fmaxf(s[0], dp[0]);  // compiler-visible first read of both MFMA results (hazard padding is hipcc's here)
+    float seed = DK_ ? fmaxf(s[0], dp[0]) : s[0] + 0.f;  // compiler-visible first read of the MFMA results (hazard padding is hipcc's here)
     LAUNDER(seed);
     const bool edge = (qs + 32 > p.Lq) || (k0 + 32 > kv_end) || (p.causal && k0 + 31 > qs + coff);  // wave-uniform
     if (edge) {
@@ -1220,13 +1245,13 @@ __global__ __launch_bounds__(NT2, 2) void flash2_bwd_dkv_kernel(const grove_flas
         for (int i = 0; i < 4; ++i) {
           const float pv = exp2_fast(s[r4 * 4 + i] - l4[i]);
           pr[q4 * 4 + i] = pv;
-          ds_[q4 * 4 + i] = pv * fmaf(dp[r4 * 4 + i], p.alpha, -d4[i]);
+          ds_[q4 * 4 + i] = DK_ ? pv * fmaf(dp[r4 * 4 + i], p.alpha, -d4[i]) : 0.f;
         }
       }
       const u32x4_t a = u32x4_t{pack2bf(pr[0], pr[1]), pack2bf(pr[2], pr[3]), pack2bf(pr[4], pr[5]), pack2bf(pr[6], pr[7])};
       const u32x4_t c = u32x4_t{pack2bf(ds_[0], ds_[1]), pack2bf(ds_[2], ds_[3]), pack2bf(ds_[4], ds_[5]), pack2bf(ds_[6], ds_[7])};
-      pfr[s2] = __builtin_bit_cast(bf16x8_t, a);
-      dsf[s2] = __builtin_bit_cast(bf16x8_t, c);
+      if constexpr (DV_) pfr[s2] = __builtin_bit_cast(bf16x8_t, a);
+      if constexpr (DK_) dsf[s2] = __builtin_bit_cast(bf16x8_t, c);
     }
     (void)seed;
   };
@@ -1236,6 +1261,7 @@ __global__ __launch_bounds__(NT2, 2) void flash2_bwd_dkv_kernel(const grove_flas
   __builtin_amdgcn_s_barrier();                                   \
   __builtin_amdgcn_sched_barrier(0);
 
+  f32x4_t rope_c[C::DT / 2 > 0 ? C::DT / 2 : 1][4], rope_s[C::DT / 2 > 0 ? C::DT / 2 : 1][4];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (nsub > 0) {  // (workgroup-uniform)
@@ -1260,6 +1286,19 @@ __global__ __launch_bounds__(NT2, 2) void flash2_bwd_dkv_kernel(const grove_flas
       SEG_END3();
       slot = nslot;
     }
+    if constexpr (DK_) {
+      if (p.rope) {  // the cos | sin row of the lane's key, fetched under the last two segments (see the dQ kernel)
+        const float* cs = p.rope + (int64_t)kj * HS;
+#pragma unroll
+        for (int dt = 0; dt < (C::DT / 2 > 0 ? C::DT / 2 : 1); ++dt)
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            const int d0 = dt * 32 + 8 * r4 + 4 * hi;
+            rope_c[dt][r4] = *(const f32x4_t*)(cs + d0);
+            rope_s[dt][r4] = *(const f32x4_t*)(cs + HS / 2 + d0);
+          }
+      }
+    }
     PDS(u1 - 1);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -1275,13 +1314,29 @@ __global__ __launch_bounds__(NT2, 2) void flash2_bwd_dkv_kernel(const grove_flas
   bf16_raw* DK = (bf16_raw*)p.dk + (int64_t)b * p.sdk + h * HS;
   bf16_raw* DV = (bf16_raw*)p.dv + (int64_t)b * p.sdv + h * HS;
   char* osc = smem + wave * (32 * C::OSTR);
+  if constexpr (DK_) {
+    if (p.rope && nsub > 0) {  // key j sits at position j; the lane holds both halves (d tiles dt and dt + DT / 2) of its rotation pairs (HS % 64 == 0)
 #pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
+      for (int dt = 0; dt < C::DT / 2; ++dt)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const f32x4_t c = rope_c[dt][r4], sn = rope_s[dt][r4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float y1 = dk[dt][r4 * 4 + i], y2 = dk[dt + C::DT / 2][r4 * 4 + i];
+            dk[dt][r4 * 4 + i] = y1 * c[i] + y2 * sn[i];
+            dk[dt + C::DT / 2][r4 * 4 + i] = y2 * c[i] - y1 * sn[i];
+          }
+        }
+    }
+  }
+#pragma unroll
+  for (int pass = (DK_ ? 0 : 1); pass < (DV_ ? 2 : 1); ++pass) {
 #pragma unroll
     for (int dt = 0; dt < C::DT; ++dt)
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
-        const f32x16_t& a = pass ? dv[dt] : dk[dt];
+        const f32x16_t& a = pass ? dv[DV_ ? dt : 0] : dk[DK_ ? dt : 0];
         const u32x2_t u = u32x2_t{pack2bf(a[r4 * 4], a[r4 * 4 + 1]), pack2bf(a[r4 * 4 + 2], a[r4 * 4 + 3])};
         *(u32x2_t*)(osc + l31 * C::OSTR + (dt * 32 + 8 * r4 + 4 * hi) * 2) = u;
       }
@@ -1296,6 +1351,13 @@ __global__ __launch_bounds__(NT2, 2) void flash2_bwd_dkv_kernel(const grove_flas
       if (k0 + r < p.Lk) *(u32x4_t*)(D + (int64_t)(k0 + r) * ldd + c * 8) = v;
     }
   }
+  };
+  if constexpr (!SPLIT) {
+    body(std::integral_constant<int, ROLE_BOTH>{});
+  } else {
+    if (half == 0) body(std::integral_constant<int, ROLE_DK>{});
+    else body(std::integral_constant<int, ROLE_DV>{});
+  }
 }
 
 template <int HS>
@@ -1303,7 +1365,7 @@ size_t lds2_fwd(bool rel) { return 6 * (size_t)C2<HS>::TILEB + (rel ? 8 * 32 * 6
 
 }  // namespace
 
-static int g_flash2 = 7;  // bit 0 forward, bit 1 dQ, bit 2 dK / dV (A/B arm: grove_flash_attn_set_v2)
+static int g_flash2 = 15;  // bit 0 forward, bit 1 dQ, bit 2 dK / dV, bit 3 the split dK / dV of head dim 128 (A/B arm: grove_flash_attn_set_v2)
 extern "C" int grove_flash_attn_set_v2(int32_t on) {
   g_flash2 = on;
   return GROVE_OK;
@@ -1321,7 +1383,10 @@ bool grove_flash2_fwd_applicable(const grove_flash_attn_params* p) {
 // true when the round-5 dQ kernel takes this backward problem (flash_attn.hip asks before its own dispatch)
 bool grove_flash2_bwd_dq_applicable(const grove_flash_attn_params* p) {
   if (!(g_flash2 & 2)) return false;
-  if (!(p->hs == 64 || p->hs == 96 || p->hs == 128)) return false;
+  // head dim 128 (LLaMA: 3 query blocks of 4 / 8 / 11 key tiles per head — launches dominated by their fixed cost): measured in pairs
+  // with the dK / dV kernel and the fused inverse RoPE, the four-wave dQ kernel is the faster one (131.4 vs 137.2 us per backward,
+  // tools/dev/bench_llama_bwd.py), so the eight-wave dQ takes head dim 128 only when bit 4 of the mask asks for it
+  if (!(p->hs == 64 || p->hs == 96 || (p->hs == 128 && (g_flash2 & 16)))) return false;
   if (p->rel && !(p->rel_kw == 32 && p->rel_kh == 32 && p->rel_ld == 64 && p->hs == 96)) return false;
   if (p->ld_dq % 8 != 0 || ((uintptr_t)p->dq & 15) != 0 || (p->sdq % 8) != 0) return false;
   if (p->ld_do % 8 != 0 || ((uintptr_t)p->d_o & 15) != 0 || (p->sdo % 8) != 0) return false;
@@ -1347,13 +1412,13 @@ int grove_flash2_bwd_dq_launch(const grove_flash_attn_params* p, int make_delta,
   return GROVE_OK;
 }
 
-// true when the round-5 dK / dV kernel takes this backward problem: head dim 96 (128 does not fit two waves per SIMD; at 64 the
-// four-wave kernel is the faster one — 142 against 177 us on the CLIP shape — so it keeps that)
+// true when the round-5 dK / dV kernel takes this backward problem: head dim 96 (one wave = both products) and 128 (the two waves of a
+// SIMD split dK and dV: SPLIT); at 64 the four-wave kernel is the faster one — 142 against 177 us on the CLIP shape — so it keeps that
 bool grove_flash2_bwd_dkv_applicable(const grove_flash_attn_params* p) {
   if (!(g_flash2 & 4)) return false;
-  if (p->hs != 96) return false;
+  if (!(p->hs == 96 || (p->hs == 128 && (g_flash2 & 8)))) return false;
   if (p->rel && !(p->rel_kw == 32 && p->rel_kh == 32 && p->rel_ld == 64 && p->hs == 96)) return false;
-  if (p->rope) return false;
+  if (p->rope && (p->hs % 64 != 0 || ((uintptr_t)p->rope & 15) != 0)) return false;
   if (p->Lq > 4096) return false;  // lse / delta stash of the whole (batch, head) in LDS
   if (p->ld_dk % 8 != 0 || p->ld_dv % 8 != 0 || (((uintptr_t)p->dk | (uintptr_t)p->dv) & 15) != 0 || (p->sdk % 8) != 0 || (p->sdv % 8) != 0) return false;
   if (p->ld_do % 8 != 0 || ((uintptr_t)p->d_o & 15) != 0 || (p->sdo % 8) != 0) return false;
@@ -1362,17 +1427,18 @@ bool grove_flash2_bwd_dkv_applicable(const grove_flash_attn_params* p) {
 }
 
 int grove_flash2_bwd_dkv_launch(const grove_flash_attn_params* p, hipStream_t s) {
-  dim3 grid((p->Lk + BQ2 - 1) / BQ2, p->H, p->B);
+  const int keys = p->hs == 128 ? BQ2 / 2 : BQ2;
+  dim3 grid((p->Lk + keys - 1) / keys, p->H, p->B);
   const size_t stash = (size_t)((p->Lq + 63) & ~63) * 8;
-#define K2(HS, REL)                                                                                                              \
-  {                                                                                                                              \
-    const size_t lds = 6 * (size_t)C2<HS>::TILEB + (REL ? 3 * (size_t)C2<64>::TILEB : 0) + stash;                                 \
-    hipFuncSetAttribute((const void*)flash2_bwd_dkv_kernel<HS, REL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
-    hipLaunchKernelGGL((flash2_bwd_dkv_kernel<HS, REL>), grid, dim3(NT2), lds, s, *p);                                            \
+#define K2(HS, REL, SPLIT)                                                                                                         \
+  {                                                                                                                                \
+    const size_t lds = 6 * (size_t)C2<HS>::TILEB + (REL ? 3 * (size_t)C2<64>::TILEB : 0) + stash;                                   \
+    hipFuncSetAttribute((const void*)flash2_bwd_dkv_kernel<HS, REL, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+    hipLaunchKernelGGL((flash2_bwd_dkv_kernel<HS, REL, SPLIT>), grid, dim3(NT2), lds, s, *p);                                       \
   }
-  if (p->hs == 64) K2(64, 0)
-  else if (p->rel) K2(96, 1)
-  else K2(96, 0)
+  if (p->hs == 128) K2(128, 0, true)
+  else if (p->rel) K2(96, 1, false)
+  else K2(96, 0, false)
 #undef K2
   return GROVE_OK;
 }

@@ -412,10 +412,11 @@ int grove_flash_attn_set_window_kernels(int32_t on);
  * form applies (rel_kw == rel_kh == 32, rel_ld == 64, head dim 96: SAM's global blocks); 1 (default) = indicator fragments in registers.
  * Same MFMAs on the same operand values: bit-identical results. */
 int grove_flash_attn_set_register_e(int32_t on);
-/* A/B knob (round 5): bit 0 = forward, bit 1 = backward dQ, bit 2 = backward dK / dV of the eight-wave ping-pong kernels
- * (flash_attn2.hip: 512-thread workgroups, LDS-DMA rings, 32x32x16 MFMAs, rel-pos bias as the score accumulators' initial
- * value) for head dims 64 / 96 / 128 without rel-pos or with SAM's 32 x 32 global form; 0 = the round-2 four-wave kernels
- * everywhere. Default 7. Results agree to fp32 sum order (different tile shapes), not bit for bit. */
+/* A/B knob (round 5): bit 0 = forward, bit 1 = backward dQ, bit 2 = backward dK / dV (head dim 96), bit 3 = the role-split
+ * dK / dV of head dim 128, bit 4 = the dQ kernel at head dim 128 too (off by default: slower there) — the eight-wave ping-pong kernels (flash_attn2.hip: 512-thread workgroups, LDS-DMA rings, 32x32x16
+ * MFMAs, rel-pos bias on the score accumulators / the matrix pipe) for head dims 64 / 96 / 128 without rel-pos or with SAM's
+ * 32 x 32 global form; 0 = the round-2 four-wave kernels everywhere. Default 15. Results agree to fp32 sum order (different
+ * tile shapes), not bit for bit. */
 int grove_flash_attn_set_v2(int32_t mask);
 int grove_flash_attn_window_kernels_on(void);
 

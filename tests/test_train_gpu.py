@@ -193,6 +193,35 @@ def test_engine_step_through_real_rccl_world1(dev, rccl_world1, mode, wire, spar
     engine.step()
     torch.cuda.synchronize()
     assert engine.global_step == 2 and not torch.equal(engine.master, w0) and bool(torch.isfinite(engine.master).all())
+
+
+def test_exchange_calibration_table_through_real_rccl_world1(dev, rccl_world1):
+    """Round 5: the pass `bench.py --gpus N` runs before its timed region — every exchange arm {allreduce, rs_ag,
+    a2a_f32} x {0, 16 CUs reserved for RCCL} driven for a few steps of the real step function through real RCCL (one rank: the
+    collectives are identities), one table row per arm with ms/step, the exposed-communication time and the number of GEMM launches
+    that ran under the CU cap; the engine is left on the fastest arm, with the cap and the pre-launch poll hook released."""
+    from grove_amd import _lib, ops, train as T
+    from grove_amd.synthetic import TINY, synthetic_state_dict
+    args = T.shipped_args()
+    args.lr = 1e-3
+    model = T.initialize_model(args, dims=TINY, state_dict=synthetic_state_dict(TINY), device=dev)
+    engine = T.GroveEngine(model, args, total_steps=1000, bucket_bytes=96 << 10, force_exchange=True)
+    assert engine.exchange is not None and engine.exchange.reserve_cus == 0   # the reservation is opt-in since round 5
+    batch = _batch(TINY, dev, 21)
+
+    def step():
+        out = engine(**batch)
+        engine.backward(out["loss"])
+        engine.step()
+    table, best = T.calibrate_exchange(engine, step, steps=2)
+    assert [(a["exchange"], a["reserved_cus"]) for a in table] == T.EXCHANGE_ARMS and len(table) == 6
+    for a in table:
+        assert a["ms_per_step"] > 0 and a["exposed_comm_ms"] is not None and a["exposed_comm_ms"] >= 0
+        assert (a["gemm_launches_under_cap"] > 0) == (a["reserved_cus"] > 0), a   # the cap is active exactly in the arms that ask for it
+    assert best in table and (engine.exchange.mode, engine.exchange.reserve_cus) == (best["exchange"], best["reserved_cus"])
+    torch.cuda.synchronize()
+    assert _lib.lib().grove_gemm_persistent_blocks() == 0 and ops._pre_gemm_hook is None
+    assert bool(torch.isfinite(engine.master).all())
     assert _lib.lib().grove_gemm_persistent_blocks() == 0
 
 
@@ -387,6 +416,12 @@ def test_bench_self_launches_ranks(tmp_path):
     # reduce-scatter + all-gather form
     losses = [res["config"]["last_loss"]]
     assert res["config"]["exposed_comm_ms"] is not None and "touched rows" in res["config"]["gradient_exchange"]
+    # round 5: the one-shot run explains itself — the calibration pass timed every exchange arm before the timed region
+    cal = res["config"]["exchange_calibration"]
+    assert cal is not None and len(cal["arms"]) == 6 and cal["chosen"] in cal["arms"]
+    assert {(a["exchange"], a["reserved_cus"]) for a in cal["arms"]} == {(m, r) for m in ("allreduce", "rs_ag", "a2a_f32") for r in (0, 16)}
+    assert all(a["ms_per_step"] > 0 and a["exposed_comm_ms"] is not None for a in cal["arms"])
+    assert res["config"]["gradient_exchange"].startswith(cal["chosen"]["exchange"])
     for extra in (["--no_comm_overlap"], ["--exchange", "rs_ag"], ["--exchange", "a2a_f32"], ["--dense_embed"]):
         q = run(extra)
         assert q.returncode == 0, q.stderr[-2000:]
