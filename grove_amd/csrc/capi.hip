@@ -21,9 +21,10 @@ static std::atomic<unsigned*> g_det_ring{nullptr};
 static std::atomic<unsigned> g_det_n{0}, g_det_next{0};
 bool grove_det_on() { return g_det_ring.load(std::memory_order_relaxed) != nullptr; }
 unsigned* grove_det_ticket() {
-  unsigned* ring = g_det_ring.load(std::memory_order_relaxed);
-  if (!ring) return nullptr;
-  return ring + g_det_next.fetch_add(1, std::memory_order_relaxed) % g_det_n.load(std::memory_order_relaxed);
+  const unsigned n = g_det_n.load(std::memory_order_acquire);  // n before the ring: a concurrent switch-off must not leave n == 0 behind a live ring
+  unsigned* ring = g_det_ring.load(std::memory_order_acquire);
+  if (!ring || n == 0) return nullptr;
+  return ring + g_det_next.fetch_add(1, std::memory_order_relaxed) % n;
 }
 extern "C" int grove_set_deterministic(void* tickets, int32_t n) {
   GROVE_CHECK(!tickets || n >= 64, GROVE_E_SHAPE, "set_deterministic: the ticket ring needs at least 64 zeroed words");

@@ -169,6 +169,10 @@ __device__ __forceinline__ void act_apply_grad(int act, float x, float& y, float
 // on (the last block puts the 0 back). Blocks are dispatched in linear-id order — per XCD in order too — so the lowest block that
 // has not passed yet is always resident or next to be dispatched: the wait cannot deadlock, and only the add phase is serialised.
 // With the ticket null (the default) each helper is a single uniform branch.
+// A TEST / DEBUG mode, not a production one: (i) the no-deadlock argument rests on the dispatcher handing out workgroups in linear-id
+// order, which gfx950 does and no specification promises; (ii) a ticketed kernel must reach det_pass / det_block_leave in EVERY block —
+// no early return before it (none has one; keep it so); (iii) the mode must not be switched while launches are in flight. Kernels that
+// do not add to shared global memory take no ticket (e.g. norm_bwd_stream_kernel, the frozen norms' backward: no dweight, no atomics).
 __device__ __forceinline__ unsigned det_block_id() { return (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x; }
 __device__ __forceinline__ unsigned det_block_count() { return gridDim.x * gridDim.y * gridDim.z; }
 // one thread of the block does all of its adds

@@ -1897,7 +1897,7 @@ static int gemm_bf16_dispatch(const grove_gemm_params* pp, void* stream) {
     return cp256 <= cp192 ? launch_pp<256, false>(p, s) : launch_pp<192, false>(p, s);
   }
   // (under 48 tiles the persistent kernel only pays when the stream-K plan spreads the K range over the idle CUs)
-  const bool few_tiles_cut = tp192 < 48 && bk64 && plan_stream_k(tp192, p.K / 64, 256, g_gemm_stream_k).S > 0;
+  const bool few_tiles_cut = tp192 < 48 && bk64 && plan_stream_k(tp192, p.K / 64, num_cus(), g_gemm_stream_k).S > 0;
   if (p256_ok && g_gemm_tile_m == 0 && g_gemm_tile_n == 0 && (tp192 >= 48 || few_tiles_cut) && (cp256 < c_old || cp192 < c_old))
     {
       g_gemm_last_variant = cp256 <= cp192 ? (p.a_idx ? GROVE_GEMM_PP256_GATHER : GROVE_GEMM_PP256) : (p.a_idx ? GROVE_GEMM_PP192_GATHER : GROVE_GEMM_PP192);

@@ -100,6 +100,8 @@ class LlamaStack:
         if getattr(self, "_tail_cache", None) is None:
             self._tail_cache = {}
         if key not in self._tail_cache:
+            if len(self._tail_cache) >= 64:  # real data: (S, s0) differs per batch — keep the most recent geometries only
+                self._tail_cache.pop(next(iter(self._tail_cache)))
             j = torch.arange(s0, S, dtype=torch.int32)
             idx = (torch.arange(B, dtype=torch.int32)[:, None] * S + j[None]).reshape(-1)
             self._tail_cache[key] = (idx.to(self.dev), j.repeat(B).to(self.dev))

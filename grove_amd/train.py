@@ -1254,8 +1254,12 @@ def main(args, dims=None, log=print):
         from .checkpoint import dims_from_checkpoint, load_grove_weights, read_state_dict
         sd = read_state_dict(args.grove_weights)
         dims = dims_from_checkpoint(args.grove_weights, sd, base=dims)
-        if not tiny:
-            args.det_token_idx = min(args.det_token_idx, dims.vocab - 1)
+        if not tiny and args.det_token_idx >= dims.vocab:
+            # the reference resizes the embeddings to len(tokenizer) before it loads (train.py:330), so a GROVE checkpoint always holds a
+            # row for [DET]; a table too small for the tokenizer's [DET] id is not such a checkpoint — aliasing another token's row would
+            # train silently on the wrong embedding
+            raise ValueError(f"--grove_weights {args.grove_weights}: its embedding table has {dims.vocab} rows but the tokenizer places [DET] at id "
+                             f"{args.det_token_idx}; the checkpoint was not written after the tokenizer's special tokens were added (train.py:330)")
         model = GROVEForCausalLM(dims=dims, device=device, state_dict=None, train=True, det_token_idx=args.det_token_idx,
                                  num_frames=args.num_frames, out_dim=args.out_dim, ce_loss_weight=args.ce_loss_weight,
                                  giou_loss_weight=args.giou_loss_weight, temp_objectness_loss_weight=args.temp_objectness_loss_weight,

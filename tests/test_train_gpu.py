@@ -414,7 +414,7 @@ def test_bench_self_launches_ranks(tmp_path):
     assert res["value"] > 0 and res["steps"] == 2 and res["scaling"] == "weak"
     # the exchange variants reach the same loss: group-by-group from inside the backward (default), after the backward, and the
     # reduce-scatter + all-gather form
-    losses = [res["config"]["last_loss"]]
+    losses = []  # (the calibrated run has taken 24 more optimizer steps by its last loss: it is not part of this comparison)
     assert res["config"]["exposed_comm_ms"] is not None and "touched rows" in res["config"]["gradient_exchange"]
     # round 5: the one-shot run explains itself — the calibration pass timed every exchange arm before the timed region
     cal = res["config"]["exchange_calibration"]
@@ -422,8 +422,8 @@ def test_bench_self_launches_ranks(tmp_path):
     assert {(a["exchange"], a["reserved_cus"]) for a in cal["arms"]} == {(m, r) for m in ("allreduce", "rs_ag", "a2a_f32") for r in (0, 16)}
     assert all(a["ms_per_step"] > 0 and a["exposed_comm_ms"] is not None for a in cal["arms"])
     assert res["config"]["gradient_exchange"].startswith(cal["chosen"]["exchange"])
-    for extra in (["--no_comm_overlap"], ["--exchange", "rs_ag"], ["--exchange", "a2a_f32"], ["--dense_embed"]):
-        q = run(extra)
+    for extra in ([], ["--no_comm_overlap"], ["--exchange", "rs_ag"], ["--exchange", "a2a_f32"], ["--dense_embed"]):
+        q = run(extra + ["--no_calibration"])
         assert q.returncode == 0, q.stderr[-2000:]
         losses.append(json.loads([ln for ln in q.stdout.splitlines() if ln.strip()][0])["config"]["last_loss"])
     assert max(losses) - min(losses) <= 2e-3 * max(1.0, abs(losses[0])), losses
