@@ -906,7 +906,8 @@ def main():
     all_n, all_f, all_s = (sum(v[i] for v in per_kernel.values()) for i in range(3))
     traffic = None
     try:  # memory-side bytes per launch from the committed PMC passes (profiles/, collected as the microarch guide prescribes)
-        with open(os.path.join(ROOT, "profiles", "r04_pmc_gemm_traffic.json")) as fh:
+        rec = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_gemm_traffic.json"))[-1]  # the latest round's
+        with open(os.path.join(ROOT, "profiles", rec)) as fh:
             traffic = json.load(fh)["launch_weighted_mean_bytes"].get(dom[dom.index("<"):dom.index(",")] + ">")
     except Exception:
         pass
