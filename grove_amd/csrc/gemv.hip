@@ -14,6 +14,7 @@ constexpr int GV_THREADS = 256;
 // x -> LDS as bf16 rows of XS elements (XS >= K): plain copy, the folded RMSNorm (bf16 or fp32 stream input) or the SwiGLU of a fused
 // gate|up row — the prologue shared by the VALU kernel (1-2 sequences) and the matrix-core kernel (3-8 sequences)
 template <int MX>
+// (rows M .. MX - 1 of the LDS image repeat row M - 1: x has M rows, the instances 1 / 2 / 4 / 8; their results are never stored)
 __device__ __forceinline__ void gemv_stage_x(const grove_gemv_params& p, bf16_raw* xs, const int XS, float* red, const int tid) {
   const int K = p.K;
   const bf16_raw* __restrict__ X = (const bf16_raw*)p.x;
@@ -21,8 +22,8 @@ __device__ __forceinline__ void gemv_stage_x(const grove_gemv_params& p, bf16_ra
     // x' = silu(gate) * up of a fused [M, 2K] gate|up row (HF LlamaMLP), rounded to bf16 like grove_swiglu_fwd
     for (int c = tid; c < MX * (K >> 3); c += GV_THREADS) {
       const int b = c / (K >> 3), kc = c - b * (K >> 3);
-      const u32x4_t gv = *(const u32x4_t*)(X + (int64_t)b * p.ldx + kc * 8);
-      const u32x4_t uv = *(const u32x4_t*)(X + (int64_t)b * p.ldx + K + kc * 8);
+      const u32x4_t gv = *(const u32x4_t*)(X + (int64_t)min(b, p.M - 1) * p.ldx + kc * 8);
+      const u32x4_t uv = *(const u32x4_t*)(X + (int64_t)min(b, p.M - 1) * p.ldx + K + kc * 8);
       const float g[8] = {bf_lo(gv.x), bf_hi(gv.x), bf_lo(gv.y), bf_hi(gv.y), bf_lo(gv.z), bf_hi(gv.z), bf_lo(gv.w), bf_hi(gv.w)};
       const float u[8] = {bf_lo(uv.x), bf_hi(uv.x), bf_lo(uv.y), bf_hi(uv.y), bf_lo(uv.z), bf_hi(uv.z), bf_lo(uv.w), bf_hi(uv.w)};
       float o[8];
@@ -40,7 +41,7 @@ __device__ __forceinline__ void gemv_stage_x(const grove_gemv_params& p, bf16_ra
     constexpr int XV = 4;  // float4 chunks a thread keeps: K <= 256 * 4 * XV = 4096 (the 7B hidden size) in ONE pass over global memory (16-byte loads)
     const int nq = K >> 2;  // (K % 8 == 0)
     for (int b = 0; b < MX; ++b) {
-      const f32x4_t* xr = (const f32x4_t*)(XF + (int64_t)b * p.ldx);
+      const f32x4_t* xr = (const f32x4_t*)(XF + (int64_t)min(b, p.M - 1) * p.ldx);
       if (nq <= GV_THREADS * XV) {
         f32x4_t v[XV];
 #pragma unroll
@@ -91,7 +92,7 @@ __device__ __forceinline__ void gemv_stage_x(const grove_gemv_params& p, bf16_ra
   } else {
     for (int c = tid; c < MX * (K >> 3); c += GV_THREADS) {
       const int b = c / (K >> 3), kc = c - b * (K >> 3);
-      *(u32x4_t*)(xs + b * XS + kc * 8) = *(const u32x4_t*)(X + (int64_t)b * p.ldx + kc * 8);
+      *(u32x4_t*)(xs + b * XS + kc * 8) = *(const u32x4_t*)(X + (int64_t)min(b, p.M - 1) * p.ldx + kc * 8);
     }
     __syncthreads();
     if (p.x_mode == GROVE_GEMV_X_RMSNORM) {
@@ -205,6 +206,7 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_kernel(const grove_gemv_param
         const int col = (n >> 3) * 4 + (n & 3);
 #pragma unroll
         for (int b = 0; b < MX; ++b) {
+          if (b >= p.M) continue;  // (x is padded to MX rows by the caller; y and the residual have M)
           const float gt = bf2f(f2bf(pair_s[wave][r][b])), up = bf2f(f2bf(pair_s[wave + 1][r][b]));
           const float v = gt * fast_sigmoid(gt) * up;
           if (p.y_dtype == GROVE_BF16) ((bf16_raw*)p.y)[(int64_t)b * p.ldy + col] = f2bf(v);
@@ -222,6 +224,7 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_kernel(const grove_gemv_param
       if (n >= p.N) continue;
 #pragma unroll
       for (int b = 0; b < MX; ++b) {
+        if (b >= p.M) continue;  // y and the residual have M rows (3, 5, 6, 7 sequences run the 4- / 8-row instance on a padded x)
         float v = acc[r][b];
         if (bias) v += bf2f(bias[n]);
         v = act_apply(p.act, v);

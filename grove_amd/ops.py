@@ -383,6 +383,9 @@ def flash_attn(qkv, B, L, H, hs, q_off, k_off, v_off, alpha, *, causal=False, kv
 
 
 
+_GEMV_SPLIT_NORM = os.environ.get("GROVE_GEMV_SPLIT_NORM", "1") != "0"  # A/B arm of the batched decode step
+
+
 def gemv(x, w, bias=None, *, act=ACT_NONE, residual=None, out_dtype=bf16, out=None, rms_weight=None, eps=0.0, swiglu=False):
     """y = act(x' @ w.T + bias) + residual for 1..8 rows of x (the cached decode step): the weight-streaming kernel.
     x' = x, or rmsnorm(x) * rms_weight (rms_weight given), or silu(gate) * up of a fused [M, 2K] row (swiglu=True).
@@ -395,6 +398,14 @@ def gemv(x, w, bias=None, *, act=ACT_NONE, residual=None, out_dtype=bf16, out=No
     mx = 1 if M == 1 else 2 if M == 2 else 4 if M <= 4 else 8
     plain = rms_weight is None and not swiglu and x.dtype == bf16
     mfma = M >= 3 and K % 128 == 0 and (act != ACT_SWIGLU_PAIR or N % 16 == 0) and (plain or 8 * (K + 32) * 2 <= 150 * 1024)
+    if mfma and rms_weight is not None and not swiglu and _GEMV_SPLIT_NORM:
+        # 3..8 sequences on the matrix-core kernel: a block owns 16 output rows — 128 KB of weights at K = 4096 — and a folded RMSNorm
+        # makes every one of its N / 16 blocks re-read and re-normalise the M x K fp32 rows (another 128 KB, plus the block reductions)
+        # before its first product: in the batched decode step the folded form ran 57 us per launch against 24-44 us for the same
+        # GEMV on a plain x (round 5, profile of bench.py --mode infer_iground). So the rows are normalised ONCE, by the norm kernel,
+        # into M x K bf16 — the rounding the kernel's LDS staging applies anyway — and the GEMV reads them from L2.
+        xn = rmsnorm(None, rms_weight, eps, res=x) if x.dtype == torch.float32 else rmsnorm(x, rms_weight, eps)
+        return gemv(xn, w, bias, act=act, residual=residual, out_dtype=out_dtype, out=out)
     if mx * K * 2 > 159 * 1024 and M > 4 and not mfma:  # (the matrix-core kernel of 3..8 sequences reads a plain x straight from global memory)
         # the kernel keeps its mx rows of x in LDS (bf16): 8 rows of LLaMA-7B's down-projection input (K = 11008) are 176 KB. Two
         # launches of <= 4 rows each (88 KB): the weight matrix is streamed twice for the 5..8 sequences instead of once — still one
@@ -406,10 +417,6 @@ def gemv(x, w, bias=None, *, act=ACT_NONE, residual=None, out_dtype=bf16, out=No
             gemv(x[lo:hi], w, bias, act=act, residual=(residual[lo:hi] if residual is not None else None), out_dtype=out_dtype,
                  out=out[lo:hi], rms_weight=rms_weight, eps=eps, swiglu=swiglu)
         return out
-    if mx != M:  # the kernel reads mx rows
-        xp = torch.zeros((mx, x.shape[1]), dtype=x.dtype, device=x.device)
-        xp[:M] = x
-        x = xp
     if out is None:  # ACT_SWIGLU_PAIR: w rows interleaved [4 gate, 4 up] (swiglu_interleave), the result is silu(gate) * up: N / 2 columns
         out = torch.empty((M, N // 2 if act == ACT_SWIGLU_PAIR else N), dtype=out_dtype, device=x.device)
     p = _lib.GemvParams()

@@ -476,8 +476,8 @@ int grove_rope_inplace(const grove_rope_params* p, void* stream);
  * token per sequence after step 0: llava_llama.py:144-180, GROVE.py:418-422).
  *   y[b, n] = act( sum_k x[b, k] * W[n, k] + bias[n] ) + residual[b, n],  1 <= M <= 8 rows
  * x: bf16 [M, ldx]; W: bf16 [N, ldw] (nn.Linear layout); y: bf16 or f32 [M, ldy]. HBM-bound: every
- * weight byte is read once. For M of 3 (5..7) the kernel reads 4 (8) x rows: x must have that many
- * addressable rows (the wrapper pads).
+ * weight byte is read once. x, residual and y have exactly M rows: for M of 3 (5..7) the 4- (8-)row
+ * instance runs on row M - 1 repeated and stores M rows (round 5; earlier builds read and wrote the padding rows).
  * act GROVE_ACT_SWIGLU_PAIR (HF LlamaMLP's silu(gate) * up in the gate|up projection's epilogue): W rows interleaved
  * [4 gate, 4 up] per 8 as for grove_gemm_bf16, N % 16 == 0, no bias / residual; y gets N / 2 columns.
  * ------------------------------------------------------------------------------------------ */

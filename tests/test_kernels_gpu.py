@@ -930,6 +930,26 @@ def test_gemm_tile_variants(dev, M, N, K, tile_n, tile_m):
         _lib.lib().grove_gemm_set_tile_m(0)
 
 
+@pytest.mark.parametrize("M", [3, 5, 6, 7])
+def test_gemv_touches_only_its_m_rows(dev, M):
+    """3, 5, 6 and 7 sequences run the 4- / 8-row instances of the VALU kernel (K % 128 != 0 keeps them off the matrix-core one): x,
+    the residual and y have M rows, not 4 / 8. Round 5 found the epilogue storing (and reading the residual of) all MX rows — past the
+    end of y, a fault only when y ends a mapped segment. x, residual and y are the LAST rows of larger buffers here: the rows behind
+    them must keep their guard values, and the result must not depend on them."""
+    from grove_amd import ops
+    N, K = 520, 1096
+    w = rnd(N, K, seed=2, scale=0.05).to(dev)
+    xb = torch.full((M + 8, K), float("nan"), dtype=bf16, device=dev)
+    rb = torch.full((M + 8, N), float("nan"), dtype=bf16, device=dev)
+    yb = torch.full((M + 8, N), 7.0, dtype=bf16, device=dev)
+    x, res = rnd(M, K, seed=1), rnd(M, N, seed=4)
+    xb[:M], rb[:M] = x.to(dev), res.to(dev)
+    ops.gemv(xb[:M], w, residual=rb[:M], out=yb[:M])
+    torch.cuda.synchronize()
+    assert torch.equal(yb[M:], torch.full((8, N), 7.0, dtype=bf16, device=dev)), "rows behind y were written"
+    close(yb[:M], x.float() @ w.float().cpu().t() + res.float(), 2 ** -7, "gemv M rows")
+
+
 @pytest.mark.parametrize("M,N,K", [(1, 300, 512), (2, 4096, 4096), (3, 1000, 1096), (4, 515, 11008), (7, 64, 256), (8, 320, 128)])
 def test_gemv_decode(dev, M, N, K):
     """grove_gemv_bf16 (cached decode step) vs fp32 reference, with bias / activation / residual / fp32 output."""

@@ -4,7 +4,7 @@ import torch
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from grove_amd import ops
 dev = torch.device("cuda:0")
-for M in (1, 2):
+for M in ([int(a) for a in sys.argv[1:]] or (1, 2)):
     for N, K in [(12288, 4096), (4096, 4096), (22016, 4096), (4096, 11008), (32008, 4096)]:
         ws = [(torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16) for _ in range(6)]  # rotate: defeat the 256 MB MALL
         x = torch.randn(M, K, device=dev).to(torch.bfloat16)
