@@ -1,0 +1,176 @@
+"""Out-of-bounds WRITE screen for the kernels whose tiles overhang their problem (round 5: the GEMV's padded-row stores were found by a
+fault that only happened when `y` ended a mapped segment — no GPU sanitizer exists on this pool). Every tensor a wrapper allocates during
+the call is carved out of a larger buffer whose margins hold a byte pattern; after the call the margins must be intact. Results are
+checked elsewhere (tests/test_kernels_gpu.py); here only that nothing outside the tensors was touched."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+bf16 = torch.bfloat16
+PAT = 0xA5
+MARGIN = 8192  # bytes on each side (a 64-row tile of 128 bf16 columns overhanging by a few rows lands inside it)
+
+
+class GuardedAllocs:
+    """Replaces torch.empty / torch.zeros for CUDA tensors while active."""
+
+    def __init__(self):
+        self.bufs = []
+        self._empty, self._zeros = torch.empty, torch.zeros
+
+    def carve(self, shape, dtype, device, zero=False):
+        n = int(math.prod(shape))
+        es = torch.empty((), dtype=dtype).element_size()
+        m = MARGIN // es
+        raw = self._empty(n + 2 * m, dtype=dtype, device=device)
+        raw.view(torch.uint8).fill_(PAT)
+        t = raw[m:m + n]
+        if zero:
+            t.zero_()
+        self.bufs.append((raw, m, n))
+        return t.view(shape)
+
+    def _wrap(self, zero):
+        def fn(*size, dtype=None, device=None, **kw):
+            shape = tuple(size[0]) if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)) else tuple(size)
+            dev = torch.device(device) if device is not None else None
+            if dev is None or dev.type != "cuda" or kw:
+                return (self._zeros if zero else self._empty)(*size, dtype=dtype, device=device, **kw)
+            return self.carve(shape, dtype or torch.float32, dev, zero)
+        return fn
+
+    def __enter__(self):
+        torch.empty, torch.zeros = self._wrap(False), self._wrap(True)
+        return self
+
+    def __exit__(self, *a):
+        torch.empty, torch.zeros = self._empty, self._zeros
+
+    def check(self, what):
+        torch.cuda.synchronize()
+        for i, (raw, m, n) in enumerate(self.bufs):
+            b = raw.view(torch.uint8)
+            es = raw.element_size()
+            head, tail = b[:m * es], b[(m + n) * es:]
+            assert bool((head == PAT).all()), f"{what}: allocation {i} ({n} elements): bytes BEFORE it were written"
+            assert bool((tail == PAT).all()), f"{what}: allocation {i} ({n} elements): bytes AFTER it were written"
+
+
+@pytest.fixture()
+def dev():
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("B,H,L,hs,hd,causal,rel_hw,rope", [
+    (2, 3, 77, 64, 64, False, None, False),
+    (1, 3, 577, 64, 64, False, None, False),       # CLIP's shape: eight-wave forward / dQ, four-wave dK / dV
+    (2, 2, 130, 96, 80, False, None, False),
+    (1, 2, 1000, 96, 80, False, None, False),      # eight-wave forward, dQ, dK / dV; last key tile 40 rows
+    (1, 2, 1024, 96, 80, False, (32, 32), False),  # SAM global: rel-pos instances
+    (1, 3, 703, 128, 128, True, None, False),      # LLaMA: eight-wave forward, role-split dK / dV
+    (2, 2, 703, 128, 128, True, None, True),       # + the fused inverse RoPE epilogues
+    (1, 2, 200, 128, 128, True, None, True),
+    (3, 2, 196, 96, 80, False, (14, 14), False),   # window kernels
+])
+def test_attention_kernels_write_inside_their_tensors(dev, B, H, L, hs, hd, causal, rel_hw, rope):
+    from grove_amd import ops
+    g = torch.Generator().manual_seed(5)
+    alpha = hd ** -0.5
+    with GuardedAllocs() as ga:
+        qkv = ga.carve((B * L, 3 * H * hs), bf16, dev, zero=True)
+        qkv.view(B * L, 3, H, hs)[..., :hd] = torch.randn(B * L, 3, H, hd, generator=g).to(bf16).to(dev)
+        do = ga.carve((B * L, H * hs), bf16, dev, zero=True)
+        do.view(B * L, H, hs)[..., :hd] = torch.randn(B * L, H, hd, generator=g).to(bf16).to(dev)
+        dqkv = ga.carve((B * L, 3 * H * hs), bf16, dev)
+        rel, rel_arg = None, (0, 0)
+        if rel_hw is not None:
+            kh, kw = rel_hw
+            khp = (kh + 15) // 16 * 16
+            rel = ga.carve((B * H, L, khp + (kw + 15) // 16 * 16), bf16, dev, zero=True)
+            rel[..., :kh] = (torch.randn(B * H, L, kh, generator=g) / alpha).to(bf16).to(dev)
+            rel[..., khp:khp + kw] = (torch.randn(B * H, L, kw, generator=g) / alpha).to(bf16).to(dev)
+            rel_arg = (khp, kw)
+        hv = hd if hd < hs else 0
+        out, lse = ops.flash_attn(qkv, B, L, H, hs, 0, H * hs, 2 * H * hs, alpha, causal=causal, rel=rel, rel_hw=rel_arg, want_lse=True, hs_valid=hv)
+        ga.check("forward")
+        kw_b = {}
+        if rope:
+            kw_b["rope"] = ops.rope_table(hs, 10000.0, L + 5, dev)
+        ops.flash_attn_bwd(qkv, out, do, lse, dqkv, B, L, H, hs, 0, H * hs, 2 * H * hs, alpha, causal=causal, rel=rel, rel_hw=rel_arg,
+                           want_drel=rel is not None, hs_valid=hv, **kw_b)
+        ga.check("backward")
+    assert torch.isfinite(dqkv.float()).all() and torch.isfinite(out.float()).all()
+
+
+@pytest.mark.parametrize("M", [1, 2, 3, 4, 5, 7, 8])
+@pytest.mark.parametrize("N,K,fold", [(520, 1096, False), (1000, 1024, False), (2064, 4096, True), (515, 11008, False)])
+def test_gemv_kernels_write_inside_their_tensors(dev, M, N, K, fold):
+    """VALU instances (K % 128 != 0 or M <= 2) and the matrix-core kernel (3..8 rows), plain and with the folded RMSNorm on an fp32 stream."""
+    from grove_amd import ops
+    g = torch.Generator().manual_seed(6)
+    with GuardedAllocs() as ga:
+        w = ga.carve((N, K), bf16, dev)
+        w.copy_((torch.randn(N, K, generator=g) * 0.05).to(bf16))
+        x = ga.carve((M, K), torch.float32 if fold else bf16, dev)
+        x.copy_(torch.randn(M, K, generator=g).to(x.dtype))
+        res = ga.carve((M, N), torch.float32 if fold else bf16, dev)
+        res.copy_(torch.randn(M, N, generator=g).to(res.dtype))
+        nw = ga.carve((K,), bf16, dev)
+        nw.copy_(torch.ones(K).to(bf16))
+        y = ops.gemv(x, w, residual=res, rms_weight=nw if fold else None, eps=1e-5, out_dtype=res.dtype)
+        ga.check(f"gemv M={M}")
+    assert y.shape == (M, N) and torch.isfinite(y.float()).all()
+
+
+@pytest.mark.parametrize("M,N,K,act", [
+    (300, 200, 96, "gelu"), (2812, 520, 128, "none"), (130, 64, 64, "none"),
+    (2812, 1288, 4096, "none"),     # persistent 192- / 256-row tiles with a ragged last row and column tile
+    (4100, 1280, 1280, "gelu"),     # partial last round: stream-K parts + fix-up launch (workspace slots)
+    (260, 4096, 8192, "none"),      # few tiles, long K: the only round cut into K ranges
+    (703, 4096, 11008, "none"),
+])
+def test_gemm_kernels_write_inside_their_tensors(dev, M, N, K, act):
+    """NT GEMM family: ragged edges, stream-K workspace, fix-up launch — C, the workspace and every other allocation keep their margins."""
+    from grove_amd import ops
+    g = torch.Generator().manual_seed(7)
+    with GuardedAllocs() as ga:
+        a = ga.carve((M, K), bf16, dev)
+        a.copy_(torch.randn(M, K, generator=g).to(bf16))
+        b = ga.carve((N, K), bf16, dev)
+        b.copy_((torch.randn(N, K, generator=g) * 0.05).to(bf16))
+        bias = ga.carve((N,), bf16, dev)
+        bias.copy_(torch.randn(N, generator=g).to(bf16))
+        res = ga.carve((M, N), bf16, dev)
+        res.copy_(torch.randn(M, N, generator=g).to(bf16))
+        y = ops.linear(a, b, bias, act=ops.ACT_GELU if act == "gelu" else ops.ACT_NONE, residual=res)
+        ga.check("nt gemm")
+        gw = ga.carve((N, K), torch.float32, dev, zero=True)
+        dy = ga.carve((M, N), bf16, dev)
+        dy.copy_(torch.randn(M, N, generator=g).to(bf16))
+        ops.wgrad(dy, a, gw)   # gw[N, K] += dy^T a
+        ga.check("tn gemm")
+    assert torch.isfinite(y.float()).all() and torch.isfinite(gw).all()
+
+
+@pytest.mark.parametrize("rows,C,rms", [(703, 4096, True), (2812, 1024, True), (1000, 1280, False), (577, 1024, False), (37, 320, False)])
+def test_norm_kernels_write_inside_their_tensors(dev, rows, C, rms):
+    from grove_amd import ops
+    g = torch.Generator().manual_seed(8)
+    with GuardedAllocs() as ga:
+        x = ga.carve((rows, C), bf16, dev)
+        x.copy_(torch.randn(rows, C, generator=g).to(bf16))
+        w = ga.carve((C,), bf16, dev)
+        w.copy_(torch.randn(C, generator=g).to(bf16))
+        bvec = ga.carve((C,), bf16, dev, zero=True)
+        dy = ga.carve((rows, C), bf16, dev)
+        dy.copy_(torch.randn(rows, C, generator=g).to(bf16))
+        if rms:
+            y = ops.rmsnorm(x, w, 1e-5)
+            dx = ops.rmsnorm_bwd(x, w, dy, 1e-5)
+        else:
+            y, mean, rstd = ops.layernorm(x, w, bvec, 1e-5, save_stats=True)
+            dx = ops.layernorm_bwd(x, w, dy, mean, rstd)
+        ga.check("norm")
+    assert torch.isfinite(y.float()).all() and torch.isfinite(dx.float()).all()
