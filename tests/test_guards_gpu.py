@@ -174,3 +174,38 @@ def test_norm_kernels_write_inside_their_tensors(dev, rows, C, rms):
             dx = ops.layernorm_bwd(x, w, dy, mean, rstd)
         ga.check("norm")
     assert torch.isfinite(y.float()).all() and torch.isfinite(dx.float()).all()
+
+
+@pytest.mark.parametrize("mode", ["train", "infer_generate"])
+def test_whole_model_writes_inside_its_tensors(dev, mode):
+    """Every kernel of the path in one go: a tiny-dims training step (forward + backward: towers, window / global / causal attention,
+    Conv3d adapters, decoder, losses) and an inference pass with cached greedy decoding at B = 3 (the padded-row GEMV instances), with
+    every torch.empty / torch.zeros of the product code carved out of patterned buffers."""
+    from grove_amd import GROVEForCausalLM
+    from grove_amd.synthetic import TINY, synthetic_batch, synthetic_state_dict
+    d = TINY
+    sd = synthetic_state_dict(d)
+    train = mode == "train"
+    model = GROVEForCausalLM(dims=d, device=dev, state_dict=sd, det_token_idx=d.det_token_idx, num_frames=8, train=train)
+    batch = synthetic_batch(d, B=2 if train else 3, T=8, L=48, n_det=2, seed=7, ragged=True)
+    kw = batch.as_kwargs()
+    for k in ("global_enc_images", "grounding_enc_images"):
+        kw[k] = kw[k].to(dev).to(bf16)
+    for k in ("input_ids", "labels", "attention_masks", "offset"):
+        kw[k] = kw[k].to(dev)
+    if train:
+        model.zero_grad()
+    with GuardedAllocs() as ga:
+        if train:
+            out = model(**kw)
+            model.backward(out["loss"])
+            ga.check("training step")
+            assert torch.isfinite(out["loss"]).all() and torch.isfinite(model._flat_grad).all()
+        else:
+            feats, _ = model(mode="encode_images", images=kw["global_enc_images"])
+            prompt = kw["input_ids"][:, :20].contiguous()
+            gen = model.generate(input_ids=prompt, image_features=feats, max_new_tokens=5, eos_token_id=-1, output_hidden_states=True,
+                                 return_dict_in_generate=True)
+            ga.check("generate B=3")
+            assert gen.sequences.shape[0] == 3
+    assert len(ga.bufs) > 50
