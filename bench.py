@@ -692,7 +692,7 @@ def infer_iground_bench(args, dev, dims, world=1, rank=0):
                        "stage_seconds_per_step_batched": {k: round(v, 4) for k, v in stages.items()},
                        "stage_note": "encode = CLIP + SAM towers of the centre windows; evaluate = prefill + greedy decode + box decoder; windows = the other windows' "
                                      "forward (all clips of a batch in one launch sequence); measured in one extra pass with device syncs around the stages"},
-            "roofline": {"bound": "hbm", "kernel": f"gemv_kernel<{nb}, .> (grove_gemv_bf16: the cached decode step's weight stream, {nb} sequences per launch)",
+            "roofline": {"bound": "hbm", "kernel": (f"gemv_mfma_kernel<., 8>" if nb >= 3 else f"gemv_kernel<{nb}, .>") + f" (grove_gemv_bf16: the cached decode step's weight stream, {nb} sequences per launch)",
                          "achieved": round(wbytes / per_tok / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(wbytes / per_tok / 8e12, 4), "traffic": None,
                          "ms_per_token": round(per_tok * 1e3, 3), "sequences_per_token_step": nb, "weight_bytes_per_token_step": wbytes,
                          "prefill_ms": round(prefill_s * 1e3, 2), "decode_share_of_step": round(min(1.0, (N / nb) * new * per_tok / per_step), 3)}}
