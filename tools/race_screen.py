@@ -147,6 +147,44 @@ def tbwd():
     ops.flash_attn_tail_bwd(q_t, kv_, ot, dot_, lset, dq, dkv, Bq, Lq4, Sq, Hq, hq, hq ** -0.5, rope=tab)
     return dq, dkv
 screen("tail attention bwd + fused inverse RoPE (self)", tbwd, tbwd)
+# round 5: the eight-wave attention kernels (LDS-DMA rings, counted waits, two wave halves half a step apart) on the step's three
+# shapes, forward and backward, repeated under churn: self-consistency bit for bit, and the forward against the four-wave kernels'
+# result within bf16 rounding of the different summation order
+def attn_case(name, B, H, Lc, hs, hd, causal, rel_hw):
+    g = torch.Generator(device="cpu").manual_seed(3)
+    q3 = torch.zeros(B * Lc, 3, H, hs)
+    q3[..., :hd] = torch.randn(B * Lc, 3, H, hd, generator=g) * 0.7
+    qkv_c = q3.view(B * Lc, 3 * H * hs).to(bf).to(dev)
+    d3 = torch.zeros(B * Lc, H, hs)
+    d3[..., :hd] = torch.randn(B * Lc, H, hd, generator=g)
+    do_c = d3.view(B * Lc, H * hs).to(bf).to(dev)
+    al = hd ** -0.5
+    rel_c, ra = None, (0, 0)
+    if rel_hw:
+        kh, kw = rel_hw
+        rel_c = torch.zeros(B * H, Lc, kh + kw)
+        rel_c[..., :kh + kw] = torch.randn(B * H, Lc, kh + kw, generator=g) / al
+        rel_c, ra = rel_c.to(bf).to(dev), (kh, kw)
+    hv = hd if hd < hs else 0
+    def fwd():
+        return ops.flash_attn(qkv_c, B, Lc, H, hs, 0, H * hs, 2 * H * hs, al, causal=causal, rel=rel_c, rel_hw=ra, want_lse=True, hs_valid=hv)
+    screen(name + " eight-wave fwd (self)", fwd, fwd)
+    o_c, lse_c = fwd()
+    def bwd():
+        dq_c = torch.zeros_like(qkv_c)
+        dr = ops.flash_attn_bwd(qkv_c, o_c, do_c, lse_c, dq_c, B, Lc, H, hs, 0, H * hs, 2 * H * hs, al, causal=causal, rel=rel_c, rel_hw=ra,
+                                want_drel=rel_c is not None, hs_valid=hv, rope=(tab if causal else None))
+        return (dq_c, dr) if dr is not None else dq_c
+    screen(name + " eight-wave bwd (self)", bwd, bwd)
+    L.grove_flash_attn_set_v2(0)
+    o4, _ = fwd()
+    L.grove_flash_attn_set_v2(15)
+    err = (o_c.float() - o4.float()).abs().max().item()
+    print(f"{name + ' eight-wave vs four-wave forward':55s} max |diff| {err:.4g}", flush=True)
+    assert err < 2e-2
+attn_case("SAM global <96, rel>", 4, 16, 1024, 96, 80, False, (32, 32))
+attn_case("LLaMA <128> causal", 4, 32, 703, 128, 128, True, None)
+attn_case("CLIP <64>", 8, 16, 577, 64, 64, False, None)
 # the whole training step in deterministic mode (every overlap on): repeated steps from the same state must agree bit for bit
 ops.set_deterministic(True)
 from grove_amd import train as TR
