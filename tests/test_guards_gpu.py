@@ -209,3 +209,30 @@ def test_whole_model_writes_inside_its_tensors(dev, mode):
             ga.check("generate B=3")
             assert gen.sequences.shape[0] == 3
     assert len(ga.bufs) > 50
+
+
+def test_full_dims_bench_step_writes_inside_its_tensors(dev):
+    """The headline step itself (full dims, B = 2 clips x T = 16: the persistent GEMMs' stream-K cuts and fix-up slots at M = 2812 / 32768,
+    temporal tap skipping, the last-layer tail, the eight-wave attention kernels on their real shapes, window kernels with real-token
+    lists) under the same screen: the tiny-dims step above takes other tile plans."""
+    from grove_amd import GROVEForCausalLM
+    from grove_amd.synthetic import FULL, synthetic_batch, synthetic_state_dict
+    d = FULL
+    sd = synthetic_state_dict(d, device=dev, dtype=bf16)
+    model = GROVEForCausalLM(dims=d, device=dev, state_dict=sd, det_token_idx=d.det_token_idx, num_frames=8, train=True)
+    del sd
+    torch.cuda.empty_cache()
+    kw = synthetic_batch(d, B=2, T=16, L=128, n_det=3, seed=11).as_kwargs()
+    for k in ("global_enc_images", "grounding_enc_images"):
+        kw[k] = kw[k].to(dev).to(bf16)
+    for k in ("input_ids", "labels", "attention_masks", "offset"):
+        kw[k] = kw[k].to(dev)
+    model.zero_grad()
+    out = model(**kw)                      # warm: plans, workspaces, tables
+    model.backward(out["loss"])
+    model.zero_grad()
+    with GuardedAllocs() as ga:
+        out = model(**kw)
+        model.backward(out["loss"])
+        ga.check("full-dims training step")
+    assert torch.isfinite(out["loss"]).all() and len(ga.bufs) > 200
