@@ -726,7 +726,8 @@ def main():
                     help="--mode infer --dtype fp8: which GEMMs / rows stay bf16 (DESIGN section 8; _clip16 = the CLIP tower in bf16)")
     ap.add_argument("--exchange", default="auto", choices=["auto", "allreduce", "rs_ag", "a2a_f32"],
                     help="N > 1: one all-reduce per gradient bucket, reduce-scatter + all-gather per bucket, or all-to-all + fp32 sum + all-gather; "
-                         "auto (default) = the fastest arm of the calibration pass that precedes the timed region (the line prints every arm)")
+                         "auto (default) = all-reduce for the line's timed region; the calibration pass that FOLLOWS it times every arm, prints the table, and re-times "
+                         "the line on an arm that beats all-reduce by more than 1 % (a stalled calibration cannot lose the line)")
     ap.add_argument("--no_calibration", action="store_true", help="N > 1: skip the exchange-arm calibration pass (then --exchange auto = allreduce)")
     ap.add_argument("--calibration_steps", type=int, default=3)
     ap.add_argument("--via_train_loop", action="store_true",
@@ -823,20 +824,8 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    calibration = None
-    if engine.exchange is not None and not args.no_calibration:
-        # the first multi-GPU run is one shot: it measures every exchange arm itself, then times the best (or the one asked for)
-        from grove_amd.train import EXCHANGE_ARMS, calibrate_exchange
-        prog.stage(f"exchange calibration ({len(EXCHANGE_ARMS)} arms x {args.calibration_steps + 1} steps)",
-                   args.stage_timeout + len(EXCHANGE_ARMS) * (args.calibration_steps + 1) * 10)
-        table, best = calibrate_exchange(engine, step, steps=args.calibration_steps)
-        if args.exchange != "auto":  # an explicit arm wins over the calibration's choice (its reservation: the faster of the two measured)
-            mine = [a for a in table if a["exchange"] == args.exchange]
-            best = min(mine, key=lambda a: a["ms_per_step"]) if mine else best
-            engine.exchange.mode, engine.exchange.reserve_cus = best["exchange"], best["reserved_cus"]
-        calibration = {"arms": table, "chosen": best, "steps_per_arm": args.calibration_steps,
-                       "note": "ms/step = wall clock between barriers, max over ranks; NCCL_MAX_NCHANNELS is read at communicator creation and "
-                               "cannot be an arm (left to RCCL unless set in the environment)"}
+    calibration = None  # (N > 1: filled AFTER the line is complete, see the epilogue at the end of main)
+    args.exchange_asked = args.exchange
     if engine.exchange is not None:
         args.exchange = engine.exchange.mode
     prog.stage("barrier before the timed region", args.stage_timeout)
@@ -983,12 +972,96 @@ def main():
                 res["cpu_baseline"] = cpu_baseline(args, dev)
             except Exception as e:  # the baseline is informational; never lose the measured line
                 res["cpu_baseline"] = {"error": repr(e)}
-        prog.done()
-        os.write(real_stdout, (json.dumps(res) + "\n").encode())
+    if rank != 0:
+        res = None
+    if engine.exchange is not None and not args.no_calibration:
+        exchange_epilogue(args, engine, step, res, prog, world, rank, dev, real_stdout, frames_per_step=world * args.batch * args.frames)
     prog.done()
+    if rank == 0:
+        os.write(real_stdout, (json.dumps(res) + "\n").encode())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def exchange_epilogue(args, engine, step, res, prog, world, rank, dev, real_stdout, frames_per_step):
+    """N > 1 only, AFTER the line is complete (timed on the start arm: all-reduce without a CU reservation, or the arm asked for): the
+    first multi-GPU run is one shot with default arguments, so it measures every exchange arm itself — and it must
+    not be able to lose the number it already has. A heartbeat thread watches the calibration: if no step completes for 90 s (a wedged
+    collective; RCCL's own watchdog would abort the process at 120 s) rank 0 prints the line as it stands, marked, and every rank leaves
+    with exit code 0. If an arm beats the start arm by more than 1 % and no arm was asked for explicitly, the K steps are timed again on
+    it and THAT becomes `value` (the start arm's figure stays in the table)."""
+    import threading
+    from grove_amd.train import EXCHANGE_ARMS, calibrate_exchange
+    prog.stage(f"exchange calibration ({len(EXCHANGE_ARMS)} arms x {args.calibration_steps + 1} steps), the line is already safe", limit_s=0)
+    beat = [time.time(), "start"]
+    done = threading.Event()
+    stall_s = float(os.environ.get("GROVE_BENCH_STALL_S", "90"))               # (tests shorten it)
+    test_stall_arm = int(os.environ.get("GROVE_BENCH_TEST_STALL_ARM", "-1"))   # (tests: arm number that never returns)
+
+    def watch():
+        while not done.wait(5.0):
+            if time.time() - beat[0] > stall_s:
+                if rank == 0 and res is not None:
+                    res["config"]["exchange_calibration"] = {"status": f"STALLED in '{beat[1]}' (no step for {stall_s:.0f} s): this line is the start arm's, measured before the "
+                                                                       f"calibration; arms finished: {beat[2:] }"}
+                    os.write(real_stdout, (json.dumps(res) + "\n").encode())
+                else:
+                    time.sleep(3.0)  # let rank 0 print first
+                print(f"[bench rank {rank}] exchange calibration stalled in '{beat[1]}': leaving with the line measured before it", file=sys.stderr, flush=True)
+                os._exit(0)
+    th = threading.Thread(target=watch, daemon=True)
+    th.start()
+    ex = engine.exchange
+    start_arm = (ex.mode, ex.reserve_cus)
+
+    def beating_step():
+        out = step()
+        beat[0] = time.time()
+        return out
+
+    def on_arm(mode, reserve):
+        beat[1] = f"{mode}, {reserve} CUs reserved"
+        if len(beat) - 2 == test_stall_arm:
+            time.sleep(1e6)
+    table, best = calibrate_exchange(engine, beating_step, steps=args.calibration_steps, on_arm=on_arm, done_arms=beat)
+    mine = [a for a in table if (a["exchange"], a["reserved_cus"]) == start_arm]
+    start_row = mine[0] if mine else None
+    calibration = {"arms": table, "fastest": best, "steps_per_arm": args.calibration_steps, "line_timed_on": {"exchange": start_arm[0], "reserved_cus": start_arm[1]},
+                   "note": "ms/step = wall clock between barriers, max over ranks, run AFTER the line's own timed region; NCCL_MAX_NCHANNELS is read at "
+                           "communicator creation and cannot be an arm (left to RCCL unless set in the environment)"}
+    retime = (args.exchange_asked == "auto" and best is not None and start_row is not None and (best["exchange"], best["reserved_cus"]) != start_arm
+              and best["ms_per_step"] < 0.99 * start_row["ms_per_step"])
+    if retime:
+        beat[1] = f"re-timing on {best['exchange']}, {best['reserved_cus']} CUs reserved"
+        ex.mode, ex.reserve_cus = best["exchange"], best["reserved_cus"]
+        beating_step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            beating_step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt2 = float(t[0])
+        exposed2 = engine.exposed_comm_ms()
+        if rank == 0:
+            calibration["start_arm_line"] = {"value": res["value"], "ms_per_step": res["ms_per_step"], "exposed_comm_ms": res["config"]["exposed_comm_ms"]}
+            res["value"] = round(frames_per_step * args.steps / dt2, 3)
+            res["ms_per_step"] = round(dt2 / args.steps * 1e3, 2)
+            res["config"]["frames_per_sec_per_gpu"] = round(res["value"] / world, 3)
+            res["config"]["exposed_comm_ms"] = None if exposed2 is None else round(exposed2, 3)
+            res["config"]["gradient_exchange"] = res["config"]["gradient_exchange"].replace(start_arm[0], best["exchange"], 1) + \
+                f" (re-timed on the calibration's fastest arm, {best['reserved_cus']} CUs reserved)"
+            calibration["line_timed_on"] = {"exchange": best["exchange"], "reserved_cus": best["reserved_cus"]}
+    else:
+        ex.mode, ex.reserve_cus = start_arm
+    if rank == 0:
+        res["config"]["exchange_calibration"] = calibration
+    done.set()
 
 
 if __name__ == "__main__":

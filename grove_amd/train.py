@@ -696,14 +696,16 @@ class GradExchange:
 EXCHANGE_ARMS = [(m, r) for m in ("allreduce", "rs_ag", "a2a_f32") for r in (0, GradExchange.RESERVED_CUS)]
 
 
-def calibrate_exchange(engine, step_fn, steps=3, arms=None, barrier=None):
+def calibrate_exchange(engine, step_fn, steps=3, arms=None, barrier=None, on_arm=None, done_arms=None):
     """The first N > 1 run on real hardware is ONE shot with default arguments, so that run measures its own
     choices: every arm {exchange mode} x {CUs reserved for RCCL while buckets are in flight} is driven for `steps` steps of the real
     workload (`step_fn` = engine(**batch) / backward / step) between two barriers, timed by the wall clock (max over ranks) with the
     exposed-communication events of its last step. Returns (table, best) — `table` one dict per arm in the order run, `best` the arm
     with the smallest ms/step — and leaves the engine on `best` unless `GROVE_EXCHANGE_KEEP=1`. Every rank runs the same arms in the
     same order (the collectives of an arm must match across ranks); the decision is taken on the all-reduced maxima, so every rank
-    decides alike. RCCL's channel count is NOT an arm: NCCL_MAX_NCHANNELS is read once when the communicator is created."""
+    decides alike. RCCL's channel count is NOT an arm: NCCL_MAX_NCHANNELS is read once when the communicator is created.
+    `on_arm(mode, reserve)` is called before an arm starts and finished arms are appended to the list `done_arms` (bench.py's stall
+    watchdog reports where a wedged run stood)."""
     import time as _time
     ex = engine.exchange
     if ex is None:
@@ -719,6 +721,8 @@ def calibrate_exchange(engine, step_fn, steps=3, arms=None, barrier=None):
         if mode == "a2a_f32" and ex.wire is None:  # (fp32 wire: the all-to-all arm is defined for a bf16 wire only)
             continue
         ex.mode, ex.reserve_cus = mode, (reserve if on_gpu else 0)
+        if on_arm is not None:
+            on_arm(mode, reserve)
         step_fn()  # one untimed step per arm: RCCL builds its plan for a new collective / message size on first use
         sync()
         bar()
@@ -736,6 +740,8 @@ def calibrate_exchange(engine, step_fn, steps=3, arms=None, barrier=None):
                       "exposed_comm_ms": (round(float(vals[1]), 3) if exposed is not None else None),
                       "gemm_launches_under_cap": ex.reserved_launch_polls})
         ex.reserved_launch_polls = 0
+        if done_arms is not None:
+            done_arms.append(f"{mode}/{ex.reserve_cus}: {table[-1]['ms_per_step']} ms")
     best = min(table, key=lambda a: a["ms_per_step"]) if table else None
     if best is not None and os.environ.get("GROVE_EXCHANGE_KEEP") != "1":
         ex.mode, ex.reserve_cus = best["exchange"], best["reserved_cus"]

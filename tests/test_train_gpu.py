@@ -418,10 +418,21 @@ def test_bench_self_launches_ranks(tmp_path):
     assert res["config"]["exposed_comm_ms"] is not None and "touched rows" in res["config"]["gradient_exchange"]
     # round 5: the one-shot run explains itself — the calibration pass timed every exchange arm before the timed region
     cal = res["config"]["exchange_calibration"]
-    assert cal is not None and len(cal["arms"]) == 6 and cal["chosen"] in cal["arms"]
+    assert cal is not None and len(cal["arms"]) == 6 and cal["fastest"] in cal["arms"]
     assert {(a["exchange"], a["reserved_cus"]) for a in cal["arms"]} == {(m, r) for m in ("allreduce", "rs_ag", "a2a_f32") for r in (0, 16)}
     assert all(a["ms_per_step"] > 0 and a["exposed_comm_ms"] is not None for a in cal["arms"])
-    assert res["config"]["gradient_exchange"].startswith(cal["chosen"]["exchange"])
+    # the line was timed BEFORE the calibration on all-reduce, or re-timed on an arm that beat it by more than 1 %
+    assert res["config"]["gradient_exchange"].startswith(cal["line_timed_on"]["exchange"])
+    assert cal["line_timed_on"]["exchange"] == "allreduce" or "start_arm_line" in cal
+    # a wedged collective inside the calibration cannot lose the line: arm 3 never returns, nothing moves for 6 s -> rank 0 prints the
+    # line it measured before the calibration, marked, and every rank leaves with exit code 0
+    st = _run_rehearsal(base, dict(env, GROVE_BENCH_STALL_S="6", GROVE_BENCH_TEST_STALL_ARM="3"))
+    assert st.returncode == 0, st.stderr[-2000:]
+    sl = [ln for ln in st.stdout.splitlines() if ln.strip()]
+    assert len(sl) == 1, st.stdout
+    sres = json.loads(sl[0])
+    assert sres["value"] > 0 and sres["n_gpus"] == 2
+    assert sres["config"]["exchange_calibration"]["status"].startswith("STALLED in 'rs_ag, 16 CUs reserved'"), sres["config"]["exchange_calibration"]
     for extra in ([], ["--no_comm_overlap"], ["--exchange", "rs_ag"], ["--exchange", "a2a_f32"], ["--dense_embed"]):
         q = run(extra + ["--no_calibration"])
         assert q.returncode == 0, q.stderr[-2000:]
