@@ -1111,6 +1111,17 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
       else if (interior) gemm_epilogue_fast<MIH, BMH, ACT>(p, acc, mw0, nw0, fr, fq, ACT < 0 ? 1.f : scale);
       else gemm_epilogue_wide<MIH, BMH, ACT>(p, acc, mw0, nw0, fr, fq, ACT < 0 ? 1.f : scale);
       relax = interior && !p.aux && !FP8 && ACT != GROVE_ACT_SWIGLU_BWD;  // exactly 4 * MIH stores per wave were issued (FP8: the scale loads sit in the queue too)
+      // Round 5: in the 256-row GELU instance (SAM's fc1: 32 launches, 15 ms per step) hipcc's register allocation leaves epilogue
+      // vector-memory operations pending on the back edge into the K loop and guards the loop's first fragment read with
+      // `s_waitcnt vmcnt(0)` — at the LOOP HEADER, so the staging queue drained once per K tile, 20 times per output tile
+      // (tools/isa_loop_waits.py finds such waits; tools/isa_kloop.py counted 8 instead of the 4 explicit ones). A wait the compiler
+      // can SEE, once per output tile, clears its scoreboard: one store round trip per tile (what RELAX otherwise hides) against
+      // twenty drains — 507 -> 474 us for (32768, 5120, 1280) + GELU + aux, same box (tools/dev/pp_drain_ab.py). The other instances
+      // are clean or (QuickGELU at K = 1024: +2.6 %) lose more to the round trip than they gain: they keep RELAX.
+      if constexpr (!FP8 && BM == 256 && !GATHER && ACT == GROVE_ACT_GELU) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) expcnt(7) lgkmcnt(15)
+        relax = false;
+      }
     }
     if constexpr (FP8) {
 #pragma unroll

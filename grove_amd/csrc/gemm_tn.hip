@@ -198,7 +198,11 @@ typedef __attribute__((ext_vector_type(8))) short q_s16x8_t;
 template <int OFF>
 __device__ __forceinline__ q_s16x4_t ds_tr16(unsigned addr) {
   q_s16x4_t v;
+#if defined(TN_ABL) && TN_ABL == 1
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));  // ablation: the same bytes without the transpose
+#else
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+#endif
   return v;
 }
 struct TrFrag {
@@ -384,13 +388,23 @@ __global__ __launch_bounds__(Q_NT) void gemm_tn_pp_kernel(const grove_gemm_tn_pa
 #pragma unroll
   for (int j = 0; j < 2; ++j) b_adr[j] = lds0 + ((wc * 4 + 2 * j) ^ R2) * 16;
   TrFrag af[4][2], b0[2][2], b1[2][2];
+#if defined(TN_ABL) && (TN_ABL == 3 || TN_ABL == 4)
+#define TN_RD (T == 0)   /* ablation: fragments read for the first K tile only */
+#else
+#define TN_RD true
+#endif
+#if defined(TN_ABL) && (TN_ABL == 2 || TN_ABL == 4)
+#define TN_DMA(Q) ((Q) < 4)  /* ablation: no LDS-DMA after the first K tile */
+#else
+#define TN_DMA(Q) true
+#endif
 #define QQ_READ_A(X)                                                              \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                \
+  if (TN_RD) _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                \
     af[i][0] = tr_pair<(X) * Q_HALF>(a_adr[i] + st_off);                         \
     af[i][1] = tr_pair<(X) * Q_HALF + 32 * Q_ROWB>(a_adr[i] + st_off);           \
   }
 #define QQ_READ_B(X, BB)                                                          \
-  _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                \
+  if (TN_RD) _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                \
     BB[j][0] = tr_pair<(X) * Q_HALF>(b_adr[j] + st_off);                         \
     BB[j][1] = tr_pair<(X) * Q_HALF + 32 * Q_ROWB>(b_adr[j] + st_off);           \
   }
@@ -404,7 +418,7 @@ __global__ __launch_bounds__(Q_NT) void gemm_tn_pp_kernel(const grove_gemm_tn_pa
   __builtin_amdgcn_sched_barrier(0);
 #define QQ_MEM_END(Q, X, TOFF, WAIT)                                                                                      \
   if ((Q) + 6 < NH) {                                                                                                     \
-    issue(X, T + TOFF);                                                                                                   \
+    if (TN_DMA(Q)) issue(X, T + TOFF);                                                                                                   \
     if (WAIT) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                            \
   } else if (WAIT) {                                                                                                      \
     wait_vm_even(2 * max(NH - 3 - (Q), 0));                                                                               \
@@ -494,6 +508,14 @@ __global__ __launch_bounds__(Q_NT) void gemm_tn_pp_kernel(const grove_gemm_tn_pa
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
       c_u += G;
       if (c_u < units) unit_of(c_u, c_L, c_k, c_kb);
+#ifndef TN_NO_EPI_DRAIN
+      // The epilogue's stores (and atomics) are still outstanding here, and hipcc guards their DATA registers against the next K tile's
+      // fragment reads: with the loop's LDS-DMA pieces in the same counter it can only do that with `s_waitcnt vmcnt(0)` — which it
+      // placed at the LOOP HEADER, i.e. in every K tile, for a path taken once per 512: the staging queue drained once per K tile, a
+      // quarter of the kernel's time (round 5: tools/dev/tn_ablate.py, 2855 us with the pieces, 2126 without). A wait the compiler
+      // can see, here, once per output tile, clears its scoreboard before the back edge.
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) expcnt(7) lgkmcnt(15)
+#endif
     }
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();
