@@ -180,6 +180,15 @@ __device__ __forceinline__ i32x4s_t sload4(const int* p) {
   asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
   return v;
 }
+__device__ __forceinline__ void wait_vm_even12(int n) {  // exact even counts up to 12 (the rebalanced staging schedule's tail)
+  if (n >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if (n == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else if (n == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
 __device__ __forceinline__ void wait_vm_even(int n) {
   if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   else if (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -225,6 +234,14 @@ __device__ __forceinline__ bf16x8_t tr_join(const TrFrag& f) {
 // +0.0 and are left out. A tile of tap group 0 / 2 walks `run` = (T - 1) fk valid K tiles per T fk (LOGICAL K tiles; the physical one
 // adds the skipped frames back), and the tiles are dealt full ones (tap group 1) first, so that rounds and the cut tail hold tiles of
 // one length. Whole tiles stay bit-identical to the un-skipped launch.
+#ifndef TN_SCHED
+// 1 = two pieces per phase (rounds 2-5, shipped); 2 = the rebalanced 0 / 2 / 2 / 4 schedule (round 5 experiment, -DTN_SCHED=2: correct —
+// the TN tests and the guard screen pass — and 3 % faster on the plain (1280, 34560, 32768) launch, nothing on the gathered Conv3d
+// launches the step runs (2696 / 2720 against 2717 / 2717 us): the K loop is bound by the latency of its pieces at 64-80 KiB in flight
+// per CU — tools/micro/dma_gemm_emul.hip streams the same operands without any arithmetic in 1.09 us per K tile, the MFMAs alone
+// need 1.15 — not by where in the K tile the pieces are issued)
+#define TN_SCHED 1
+#endif
 struct tn_skip {
   int fk, T;  // K tiles per frame, frames per group
 };
@@ -435,6 +452,26 @@ __global__ __launch_bounds__(Q_NT) void gemm_tn_pp_kernel(const grove_gemm_tn_pa
     take_rows();
     prefetch_rows(next_rows_base());
   }
+#if TN_SCHED == 2
+  // Rebalanced staging schedule (round 5). A K tile's fragment reads fall 24 / 8 / 16 / 0 on its four phases; with two LDS-DMA pieces
+  // in every phase the memory segments of phases 1 and 3 outlast the partner group's MFMA segment. Here the pieces of K tile T + 2 are
+  // issued 0 / 2 / 2 / 4 (regions A_lo, B_lo, then B_hi + A_hi) into the slots tile T frees as it goes — regions 0 and 1 are read in
+  // phase 1, region 2 in phase 2, region 3 in phase 3 — so a piece is in flight for 6-7 phases instead of 5-6 and up to 16 pieces
+  // per wave instead of 10. Waits (vmcnt retires in issue order; n1 / n2 = tile T + 1 / T + 2 exists):
+  //   phase 1 retires region 2 of T (younger: region 3 of T, all of T + 1):                 2 + 8 n1
+  //   phase 2 retires region 3 of T (younger: T + 1, region 0 of T + 2 just issued):        8 n1 + 2 n2
+  //   phase 4 retires regions 0, 1 of T + 1 (younger: regions 2, 3 of T + 1, T + 2):        4 + 8 n2
+  // WAR: region 0 of T + 2 is issued in phase 2 of T by a wave whose partner group read region 0 of T before the barrier both have
+  // passed; the reads were queued at the LDS before that barrier, the piece lands hundreds of cycles after its issue.
+  issue(0, 0); issue(1, 0); issue(2, 0); issue(3, 0);
+  if (NT > 1) {
+    advance_issue();
+    issue(0, 1); issue(1, 1); issue(2, 1); issue(3, 1);
+  }
+  wait_vm_even12(4 + (NT > 1 ? 8 : 0));
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();
+#else
   issue(0, 0); issue(1, 0); issue(2, 0); issue(3, 0);
   if (NT > 1) {
     advance_issue();
@@ -443,12 +480,58 @@ __global__ __launch_bounds__(Q_NT) void gemm_tn_pp_kernel(const grove_gemm_tn_pa
   wait_vm_even(2 * (min(5, NH - 1) - 1));
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();
+#endif
 
   int c_u = wgid, c_L, c_k, c_kb;
   unit_of(c_u, c_L, c_k, c_kb);
   for (int T = 0; T < NT; ++T) {
     const unsigned st_off = (T & 1) * Q_STAGE;
     const int q = 4 * T;
+#if TN_SCHED == 2
+    const bool n1 = T + 1 < NT, n2 = T + 2 < NT;
+    (void)q;
+    // phase 1: 24 reads, no piece
+    QQ_READ_B(1, b0)
+    QQ_READ_A(0)
+    if (n1) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    QQ_MMA(0, 0, b0)
+    __builtin_amdgcn_s_barrier();
+    // phase 2: 8 reads, region 0 (A_lo) of T + 2
+    if (n2) advance_issue();  // before this phase's reads: its (already satisfied) lgkmcnt wait must not cover them
+    QQ_READ_B(2, b1)
+    if (n2) {
+      issue(0, T);
+      asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    } else {
+      wait_vm_even12(n1 ? 8 : 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    QQ_MMA(0, 2, b1)
+    __builtin_amdgcn_s_barrier();
+    // phase 3: 16 reads, region 1 (B_lo) of T + 2; nothing to retire (phase 4 reads nothing)
+    QQ_READ_A(3)
+    if (n2) issue(1, T);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    QQ_MMA(4, 2, b1)
+    __builtin_amdgcn_s_barrier();
+    // phase 4: no reads, regions 2 and 3 (B_hi, A_hi) of T + 2
+    if (n2) {
+      issue(2, T);
+      issue(3, T);
+      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    } else if (n1) {
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    QQ_MMA(4, 0, b0)
+    __builtin_amdgcn_s_barrier();
+#else
     QQ_READ_B(1, b0)
     QQ_READ_A(0)
     QQ_MEM_END(q, 2, 1, true)
@@ -466,6 +549,7 @@ __global__ __launch_bounds__(Q_NT) void gemm_tn_pp_kernel(const grove_gemm_tn_pa
     QQ_MEM_END(q + 3, 1, 2, true)
     QQ_MMA(4, 0, b0)
     __builtin_amdgcn_s_barrier();
+#endif
     if (++c_k == c_kb) {
       // acc[i][j] holds D[n = 4 g + e][m = fr] of A fragment i (m) and B fragment j (n): C += scale * D, 16 bytes per lane
       const int tm = c_L % tiles_m, tn = c_L / tiles_m;
