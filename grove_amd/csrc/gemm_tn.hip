@@ -237,9 +237,7 @@ __device__ __forceinline__ bf16x8_t tr_join(const TrFrag& f) {
 #ifndef TN_SCHED
 // 1 = two pieces per phase (rounds 2-5, shipped); 2 = the rebalanced 0 / 2 / 2 / 4 schedule (round 5 experiment, -DTN_SCHED=2: correct —
 // the TN tests and the guard screen pass — and 3 % faster on the plain (1280, 34560, 32768) launch, nothing on the gathered Conv3d
-// launches the step runs (2696 / 2720 against 2717 / 2717 us): the K loop is bound by the latency of its pieces at 64-80 KiB in flight
-// per CU — tools/micro/dma_gemm_emul.hip streams the same operands without any arithmetic in 1.09 us per K tile, the MFMAs alone
-// need 1.15 — not by where in the K tile the pieces are issued)
+// launches the step runs (2696 / 2720 against 2717 / 2717 us): where in the K tile the pieces are issued is not what they cost)
 #define TN_SCHED 1
 #endif
 struct tn_skip {
