@@ -1118,10 +1118,12 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
       // can SEE, once per output tile, clears its scoreboard: one store round trip per tile (what RELAX otherwise hides) against
       // twenty drains — 507 -> 474 us for (32768, 5120, 1280) + GELU + aux, same box (tools/dev/pp_drain_ab.py). The other instances
       // are clean or (QuickGELU at K = 1024: +2.6 %) lose more to the round trip than they gain: they keep RELAX.
+#ifndef PP_NO_EPI_DRAIN  // (-DPP_NO_EPI_DRAIN: the A/B arm of tools/dev/step_ab.sh)
       if constexpr (!FP8 && BM == 256 && !GATHER && ACT == GROVE_ACT_GELU) {
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) expcnt(7) lgkmcnt(15)
         relax = false;
       }
+#endif
     }
     if constexpr (FP8) {
 #pragma unroll
