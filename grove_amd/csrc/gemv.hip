@@ -245,29 +245,35 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_kernel(const grove_gemv_param
 // x comes from LDS (staged by gemv_stage_x: folded RMSNorm / SwiGLU / fp32 stream input; rows XS = K + 32 elements apart) or, in
 // plain mode, straight from global memory (8 x 11008 bf16 = 176 KB would not fit; it is L2-resident). The four partial 16 x 16
 // tiles meet in LDS; thread (m, n) of the workgroup runs the epilogue of element (sequence m, row n0 + n).
-template <bool X_LDS, int MXS>  // MXS: rows of x staged in LDS (the caller pads x to 4 or 8 rows)
+template <bool X_LDS, int MXS, int NG = 1>  // MXS: rows of x staged in LDS; NG: groups of 16 output rows per workgroup (2: the x fragments feed two MFMAs — half the x traffic per weight byte)
 __global__ __launch_bounds__(GV_THREADS) void gemv_mfma_kernel(const grove_gemv_params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_raw* xs = (bf16_raw*)smem;
   __shared__ float red[GV_THREADS / 64];
-  __shared__ float part[GV_THREADS / 64][16][17];
+  __shared__ float part[NG][GV_THREADS / 64][16][17];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = p.K, XS = K + 32;
   const int fr = lane & 15, g = lane >> 4;
-  const int n0 = blockIdx.x * 16;
+  const int n0 = blockIdx.x * (16 * NG);
   const int kw = K >> 2;                 // this wave's K range (K % 128 == 0)
   const int k_lo = wave * kw;
-  const bf16_raw* __restrict__ wrow = (const bf16_raw*)p.W + (int64_t)min(n0 + fr, p.N - 1) * p.ldw + k_lo + g * 8;
-  constexpr int U = 8;
-  // the first trip of the weight stream starts before the x prologue (it does not depend on x)
-  u32x4_t wv[U];
+  const bf16_raw* __restrict__ wrow[NG];
 #pragma unroll
-  for (int u = 0; u < U; ++u) wv[u] = (u * 32 < kw) ? __builtin_nontemporal_load((const u32x4_t*)(wrow + u * 32)) : u32x4_t{0u, 0u, 0u, 0u};
+  for (int q = 0; q < NG; ++q) wrow[q] = (const bf16_raw*)p.W + (int64_t)min(n0 + 16 * q + fr, p.N - 1) * p.ldw + k_lo + g * 8;
+  constexpr int U = NG == 1 ? 8 : 4;     // k-steps per trip: NG * U = 8 independent 16-byte weight loads in flight per lane beside the next trip's 8
+  // the first trip of the weight stream starts before the x prologue (it does not depend on x)
+  u32x4_t wv[NG][U];
+#pragma unroll
+  for (int q = 0; q < NG; ++q)
+#pragma unroll
+    for (int u = 0; u < U; ++u) wv[q][u] = (u * 32 < kw) ? __builtin_nontemporal_load((const u32x4_t*)(wrow[q] + u * 32)) : u32x4_t{0u, 0u, 0u, 0u};
   if constexpr (X_LDS) gemv_stage_x<MXS>(p, xs, XS, red, tid);
   const bool row_ok = fr < p.M;
   const bf16_raw* __restrict__ xg = (const bf16_raw*)p.x + (int64_t)min(fr, p.M - 1) * p.ldx + k_lo + g * 8;
   const bf16_raw* xl = xs + min(fr, MXS - 1) * XS + k_lo + g * 8;
-  f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  f32x4_t acc[NG];
+#pragma unroll
+  for (int q = 0; q < NG; ++q) acc[q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   const u32x4_t z4 = u32x4_t{0u, 0u, 0u, 0u};
   for (int k = 0; k < kw; k += 32 * U) {
     u32x4_t xv[U];
@@ -277,43 +283,56 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_mfma_kernel(const grove_gemv_
       if constexpr (X_LDS) xv[u] = (in && row_ok) ? *(const u32x4_t*)(xl + k + u * 32) : z4;
       else xv[u] = (in && row_ok) ? *(const u32x4_t*)(xg + k + u * 32) : z4;
     }
-    u32x4_t wn[U];
+    u32x4_t wn[NG][U];
+#pragma unroll
+    for (int q = 0; q < NG; ++q)
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        wn[q][u] = (k + 32 * U + u * 32 < kw) ? __builtin_nontemporal_load((const u32x4_t*)(wrow[q] + k + 32 * U + u * 32)) : z4;
 #pragma unroll
     for (int u = 0; u < U; ++u)
-      wn[u] = (k + 32 * U + u * 32 < kw) ? __builtin_nontemporal_load((const u32x4_t*)(wrow + k + 32 * U + u * 32)) : z4;
 #pragma unroll
-    for (int u = 0; u < U; ++u)
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, xv[u]), __builtin_bit_cast(bf16x8_t, wv[u]), acc, 0, 0, 0);
+      for (int q = 0; q < NG; ++q)
+        acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, xv[u]), __builtin_bit_cast(bf16x8_t, wv[q][u]), acc[q], 0, 0, 0);
 #pragma unroll
-    for (int u = 0; u < U; ++u) wv[u] = wn[u];
+    for (int q = 0; q < NG; ++q)
+#pragma unroll
+      for (int u = 0; u < U; ++u) wv[q][u] = wn[q][u];
   }
-  // acc[r] = partial y[sequence 4 g + r][row n0 + fr]
+  // acc[q][r] = partial y[sequence 4 g + r][row n0 + 16 q + fr]
 #pragma unroll
-  for (int r = 0; r < 4; ++r) part[wave][4 * g + r][fr] = acc[r];
+  for (int q = 0; q < NG; ++q)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[q][wave][4 * g + r][fr] = acc[q][r];
   __syncthreads();
   const int m = tid >> 4, n = tid & 15;
-  if (m >= p.M || n0 + n >= p.N) return;
-  float v = (part[0][m][n] + part[1][m][n]) + (part[2][m][n] + part[3][m][n]);
-  if (p.act == GROVE_ACT_SWIGLU_PAIR) {
-    // W rows interleaved [4 gate, 4 up] per 8 (ops.swiglu_interleave): row n (n & 4 == 0) is a gate row, row n + 4 its up row
-    if (n & 4) return;
-    const float u_ = (part[0][m][n + 4] + part[1][m][n + 4]) + (part[2][m][n + 4] + part[3][m][n + 4]);
-    const float gt = bf2f(f2bf(v)), up = bf2f(f2bf(u_));
-    const float o = gt * fast_sigmoid(gt) * up;
-    const int col = ((n0 + n) >> 3) * 4 + (n & 3);
-    if (p.y_dtype == GROVE_BF16) ((bf16_raw*)p.y)[(int64_t)m * p.ldy + col] = f2bf(o);
-    else ((float*)p.y)[(int64_t)m * p.ldy + col] = o;
-    return;
+  if (m >= p.M) return;
+#pragma unroll
+  for (int q = 0; q < NG; ++q) {
+    const int nn = n0 + 16 * q + n;
+    if (nn >= p.N) continue;
+    float v = (part[q][0][m][n] + part[q][1][m][n]) + (part[q][2][m][n] + part[q][3][m][n]);
+    if (p.act == GROVE_ACT_SWIGLU_PAIR) {
+      // W rows interleaved [4 gate, 4 up] per 8 (ops.swiglu_interleave): row n (n & 4 == 0) is a gate row, row n + 4 its up row
+      if (n & 4) continue;
+      const float u_ = (part[q][0][m][n + 4] + part[q][1][m][n + 4]) + (part[q][2][m][n + 4] + part[q][3][m][n + 4]);
+      const float gt = bf2f(f2bf(v)), up = bf2f(f2bf(u_));
+      const float o = gt * fast_sigmoid(gt) * up;
+      const int col = (nn >> 3) * 4 + (n & 3);
+      if (p.y_dtype == GROVE_BF16) ((bf16_raw*)p.y)[(int64_t)m * p.ldy + col] = f2bf(o);
+      else ((float*)p.y)[(int64_t)m * p.ldy + col] = o;
+      continue;
+    }
+    if (p.bias) v += bf2f(((const bf16_raw*)p.bias)[nn]);
+    v = act_apply(p.act, v);
+    if (p.residual) v += p.res_f32 ? ((const float*)p.residual)[(int64_t)m * p.ldr + nn] : bf2f(((const bf16_raw*)p.residual)[(int64_t)m * p.ldr + nn]);
+    if (p.y_dtype == GROVE_BF16) ((bf16_raw*)p.y)[(int64_t)m * p.ldy + nn] = f2bf(v);
+    else ((float*)p.y)[(int64_t)m * p.ldy + nn] = v;
   }
-  const int nn = n0 + n;
-  if (p.bias) v += bf2f(((const bf16_raw*)p.bias)[nn]);
-  v = act_apply(p.act, v);
-  if (p.residual) v += p.res_f32 ? ((const float*)p.residual)[(int64_t)m * p.ldr + nn] : bf2f(((const bf16_raw*)p.residual)[(int64_t)m * p.ldr + nn]);
-  if (p.y_dtype == GROVE_BF16) ((bf16_raw*)p.y)[(int64_t)m * p.ldy + nn] = f2bf(v);
-  else ((float*)p.y)[(int64_t)m * p.ldy + nn] = v;
 }
 
-static int g_gemv_mfma = 1;  // 0 = the VALU kernel for every M (A/B arm: grove_gemv_set_mfma)
+static int g_gemv_mfma = 1;
+static int g_gemv_rows32 = 1;  // (grove_gemv_set_mfma bit 1 clears it: 16-row workgroups everywhere, the A/B arm)  // 0 = the VALU kernel for every M (A/B arm: grove_gemv_set_mfma)
 
 template <int MX, int RW>
 int launch_gemv_rw(const grove_gemv_params& p, hipStream_t s) {
@@ -338,6 +357,7 @@ int launch_gemv(const grove_gemv_params& p, hipStream_t s) {
 
 extern "C" int grove_gemv_set_mfma(int32_t on) {
   g_gemv_mfma = on != 0;
+  g_gemv_rows32 = (on & 2) == 0;
   return GROVE_OK;
 }
 
@@ -363,7 +383,11 @@ extern "C" int grove_gemv_bf16(const grove_gemv_params* pp, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (mfma) {
     const dim3 grid((p.N + 15) / 16);
-    if (plain_x) {
+    // the widest projections (gate | up, lm_head: >= 2.7 workgroups of 32 rows per CU): two row groups per workgroup share the x fragments
+    // (M = 8, tools/bench_gemv.py 8: N = 22016 44.3 -> 41.2 us, N = 32008 59.9 -> 54.1; N = 12288 = 1.5 workgroups per CU: 24.1 -> 27.9, so not there)
+    if (plain_x && g_gemv_rows32 && p.N >= 16384) {
+      hipLaunchKernelGGL((gemv_mfma_kernel<false, 8, 2>), dim3((p.N + 31) / 32), dim3(GV_THREADS), 0, s, p);
+    } else if (plain_x) {
       hipLaunchKernelGGL((gemv_mfma_kernel<false, 8>), grid, dim3(GV_THREADS), 0, s, p);
     } else {
       static bool attr_set = false;

@@ -105,7 +105,7 @@ def test_attention_kernels_write_inside_their_tensors(dev, B, H, L, hs, hd, caus
 
 
 @pytest.mark.parametrize("M", [1, 2, 3, 4, 5, 7, 8])
-@pytest.mark.parametrize("N,K,fold", [(520, 1096, False), (1000, 1024, False), (2064, 4096, True), (515, 11008, False)])
+@pytest.mark.parametrize("N,K,fold", [(520, 1096, False), (1000, 1024, False), (2064, 4096, True), (515, 11008, False), (16400, 256, False), (16400, 256, True)])
 def test_gemv_kernels_write_inside_their_tensors(dev, M, N, K, fold):
     """VALU instances (K % 128 != 0 or M <= 2) and the matrix-core kernel (3..8 rows), plain and with the folded RMSNorm on an fp32 stream."""
     from grove_amd import ops

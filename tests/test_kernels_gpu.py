@@ -1050,6 +1050,19 @@ def test_gemv_matrix_core_kernel_for_batched_decode(dev, M):
     finally:
         Lb.grove_gemv_set_mfma(1)
     close(y, y1.float().cpu(), 2 ** -7, "mfma gemv vs VALU kernel row by row")
+    # wide projection (N >= 16384): two 16-row groups per workgroup share the x fragments; ragged N (last workgroup: one group, 8 rows);
+    # bit-identical to the 16-row form (grove_gemv_set_mfma(3)): same products, same sum order per output
+    K, N = 256, 16400
+    xw, ww = rnd(M, K, seed=11).to(dev), rnd(N, K, seed=12, scale=0.05).to(dev)
+    bw, rw = rnd(N, seed=13).to(dev), rnd(M, N, seed=14).to(dev)
+    y32 = ops.gemv(xw, ww, bw, act=ops.ACT_RELU, residual=rw)
+    Lb.grove_gemv_set_mfma(3)
+    try:
+        y16 = ops.gemv(xw, ww, bw, act=ops.ACT_RELU, residual=rw)
+    finally:
+        Lb.grove_gemv_set_mfma(1)
+    assert torch.equal(y32, y16)
+    close(y32, F.relu(xw.float().cpu() @ ww.float().cpu().t() + bw.float().cpu()) + rw.float().cpu(), 2 ** -7, "mfma gemv 32-row workgroups vs fp32")
     # folded RMSNorm (bf16 x), K = 4096; fp32 output
     K, N = 4096, 528
     x, w, nw = rnd(M, K, seed=5).to(dev), rnd(N, K, seed=6, scale=0.05).to(dev), rnd(K, seed=7).to(dev)
