@@ -741,6 +741,9 @@ __device__ __forceinline__ void gemm_epilogue_swiglu_bwd(const grove_gemm_params
   }
 }
 
+#ifndef PP_SCHED
+#define PP_SCHED 1
+#endif
 __device__ __forceinline__ void wait_vm_loads(int n) {  // n (even) = vector-memory operations allowed to stay in flight
   if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   else if (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -1043,6 +1046,55 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
     const f32x4_t zero4 = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const char* st = smem + (T & 1) * P_STAGE;
     const int q = 4 * T;
+#if PP_SCHED == 2
+    // Staging schedule 2 (round 5 experiment, -DPP_SCHED=2; correct: the GEMM tests, the guard screen and the ABI tests pass on it;
+    // measured same-box against schedule 1, tools/dev/pp_drain_ab.py product _s2: long-K launches 2-3 % faster — the gathered Conv3d
+    // forward / dgrad 1993 -> 1940 / 1973 -> 1917 us, LLaMA o_proj 85.5 -> 83.1 — the K <= 5120 SAM launches 1-2.5 % SLOWER — fc2 +
+    // residual 341.5 -> 349.6, fc2 dgrad 336.7 -> 346.3, fc1 + GELU + aux 466 -> 471-484: a wash over the step, so schedule 1 ships):
+    // every piece one phase later, phase 4 issues two half-tiles — the pieces
+    // fall 0 / 2 / 2 / 4 on the phases whose fragment reads fall 12 / 4 / 8 / 0 (2 / 2 / 2 / 2 in schedule 1). Half-tile q + 6 is
+    // issued in phase 2, q + 7 in phase 3, q + 8 and q + 9 in phase 4; phase 1 retires q + 2 (younger: q + 3 .. q + 5), phase 2
+    // retires q + 3 (younger: q + 4 .. q + 6), phase 4 retires q + 5 (younger: q + 6 .. q + 9). Slots are refilled three phases or
+    // more after their last read. The prologue (half-tiles 0 .. 5) is the same.
+    auto tail_wait = [&](int needed, int last) { wait_vm_loads(2 * max(min(last, NH - 1) - needed, 0)); };
+    // ph1: 12 reads, no piece
+    read_b(st, 1, b0);
+    read_a(st, 0);
+    if (STEADY) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + RELAX) : "memory");
+    else tail_wait(q + 2, q + 5);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    PP_MMA(0, 0, b0)
+    __builtin_amdgcn_s_barrier();
+    // ph2: 4 reads, B_hi of the next K tile
+    read_b(st, 2, b1);
+    if (STEADY || q + 6 < NH) issue(2, T + 1);
+    if (STEADY) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + RELAX) : "memory");
+    else tail_wait(q + 3, q + 6);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    PP_MMA(0, 2, b1)
+    __builtin_amdgcn_s_barrier();
+    // ph3: 8 reads, A_hi of the next K tile; nothing to retire (phase 4 reads nothing)
+    read_a(st, 3);
+    if (STEADY || q + 7 < NH) issue(3, T + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    PP_MMA(MIH, 2, b1)
+    __builtin_amdgcn_s_barrier();
+    // ph4: no reads, A_lo and B_lo of the K tile after the next
+    if (STEADY || q + 8 < NH) {
+      advance_issue();
+      issue(0, T + 2);
+    }
+    if (STEADY || q + 9 < NH) issue(1, T + 2);
+    if (STEADY) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + RELAX) : "memory");
+    else tail_wait(q + 5, q + 9);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    PP_MMA(MIH, 0, b0)
+    __builtin_amdgcn_s_barrier();
+#else
     // ph1
     read_b(st, 1, b0);
     read_a(st, 0);
@@ -1063,6 +1115,7 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
     PP_MEM_END(STEADY, q + 3, 1, 2, true)
     PP_MMA(MIH, 0, b0)
     __builtin_amdgcn_s_barrier();
+#endif
   };
   const bool fast_addr = p.c_dtype == GROVE_BF16 && !p.c_idx && !p.r_idx && !p.n_group;  // gemm_epilogue_fast's case
   // my output tiles in turn: their K tiles (STEADY while the stream still has a half-tile to issue six phases ahead, i.e. all

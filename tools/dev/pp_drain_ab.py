@@ -36,8 +36,10 @@ print("%%-26s (%%5d, %%5d, %%5d): %%7.1f us %%7.1f TF" %% ("adapter fwd <gather,
 us = t(lambda: ops.linear(x, w, a_idx=idx, a_taps=27, M=M, residual=x, scale_ptr=alpha, scale_tanh=True, a_frames=(H * W, T), out=out))
 print("%%-26s (%%5d, %%5d, %%5d): %%7.1f us %%7.1f TF" %% ("adapter dgrad <gather, 0>", M, C, 27 * C, us, 2.0 * M * C * 27 * C / us / 1e6))
 ''' % ROOT
+names = sys.argv[1:] or ["", "_drainall", "_drainsel"]
 for rnd in range(2):
-    for name in ["", "_drainall", "_drainsel"]:
+    for name in names:
+        name = "" if name == "product" else name
         lib = os.path.join(ROOT, "grove_amd", "csrc", "libgrove_hip%s.so" % name)
         print("==", name or "product", flush=True)
         subprocess.run([sys.executable, "-c", CODE], env=dict(os.environ, GROVE_HIP_LIB=lib))
