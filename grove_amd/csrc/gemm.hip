@@ -1039,6 +1039,9 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
   // loads as vmcnt(8) does elsewhere and lets the stores drain behind the MFMAs instead of stalling the first phase (~1500
   // clocks per output tile). From the next K tile on, vmcnt(8) covers only loads issued after the stores.
   // FIRST: a segment's first K tile starts its accumulators from the zero operand of the MFMA (no 128-register clear per tile)
+  // schedule 2 ships in the two instances that only ever run the Conv3d adapters' 27-tap launches (K = 34560: -2 ... -3 %); -DPP_SCHED=2
+  // puts every instance on it (the A/B build)
+  constexpr bool SCHED2 = PP_SCHED == 2 || (!FP8 && GATHER && BM == 256 && (ACT == GROVE_ACT_NONE || ACT == GROVE_ACT_RELU));
   auto k_tile = [&](auto steady, auto relax_stores, auto first, int T) {
     constexpr bool STEADY = decltype(steady)::value;
     constexpr int RELAX = decltype(relax_stores)::value;
@@ -1046,11 +1049,11 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
     const f32x4_t zero4 = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const char* st = smem + (T & 1) * P_STAGE;
     const int q = 4 * T;
-#if PP_SCHED == 2
+    if constexpr (SCHED2) {
     // Staging schedule 2 (round 5 experiment, -DPP_SCHED=2; correct: the GEMM tests, the guard screen and the ABI tests pass on it;
     // measured same-box against schedule 1, tools/dev/pp_drain_ab.py product _s2: long-K launches 2-3 % faster — the gathered Conv3d
     // forward / dgrad 1993 -> 1940 / 1973 -> 1917 us, LLaMA o_proj 85.5 -> 83.1 — the K <= 5120 SAM launches 1-2.5 % SLOWER — fc2 +
-    // residual 341.5 -> 349.6, fc2 dgrad 336.7 -> 346.3, fc1 + GELU + aux 466 -> 471-484: a wash over the step, so schedule 1 ships):
+    // residual 341.5 -> 349.6, fc2 dgrad 336.7 -> 346.3, fc1 + GELU + aux 466 -> 471-484: a wash over the step, so schedule 1 ships everywhere but in the two adapter-only instances):
     // every piece one phase later, phase 4 issues two half-tiles — the pieces
     // fall 0 / 2 / 2 / 4 on the phases whose fragment reads fall 12 / 4 / 8 / 0 (2 / 2 / 2 / 2 in schedule 1). Half-tile q + 6 is
     // issued in phase 2, q + 7 in phase 3, q + 8 and q + 9 in phase 4; phase 1 retires q + 2 (younger: q + 3 .. q + 5), phase 2
@@ -1094,7 +1097,7 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
     __builtin_amdgcn_s_barrier();
     PP_MMA(MIH, 0, b0)
     __builtin_amdgcn_s_barrier();
-#else
+    } else {
     // ph1
     read_b(st, 1, b0);
     read_a(st, 0);
@@ -1115,7 +1118,7 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
     PP_MEM_END(STEADY, q + 3, 1, 2, true)
     PP_MMA(MIH, 0, b0)
     __builtin_amdgcn_s_barrier();
-#endif
+    }
   };
   const bool fast_addr = p.c_dtype == GROVE_BF16 && !p.c_idx && !p.r_idx && !p.n_group;  // gemm_epilogue_fast's case
   // my output tiles in turn: their K tiles (STEADY while the stream still has a half-tile to issue six phases ahead, i.e. all
