@@ -1041,7 +1041,10 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
   // FIRST: a segment's first K tile starts its accumulators from the zero operand of the MFMA (no 128-register clear per tile)
   // schedule 2 ships in the two instances that only ever run the Conv3d adapters' 27-tap launches (K = 34560: -2 ... -3 %); -DPP_SCHED=2
   // puts every instance on it (the A/B build)
-  constexpr bool SCHED2 = PP_SCHED == 2 || (!FP8 && GATHER && BM == 256 && (ACT == GROVE_ACT_NONE || ACT == GROVE_ACT_RELU));
+  // and in the plain 192-row instance (LLaMA's 2812-row launches: down 193 -> 189 us, o_proj 80 -> 78, qkv dgrad 235 -> 230, the others
+  // and CLIP's within +-1 %: tools/dev/pp_shapes_ab.py)
+  constexpr bool SCHED2 = PP_SCHED == 2 || (!FP8 && GATHER && BM == 256 && (ACT == GROVE_ACT_NONE || ACT == GROVE_ACT_RELU)) ||
+                          (!FP8 && !GATHER && BM == 192 && ACT < 0);
   auto k_tile = [&](auto steady, auto relax_stores, auto first, int T) {
     constexpr bool STEADY = decltype(steady)::value;
     constexpr int RELAX = decltype(relax_stores)::value;
