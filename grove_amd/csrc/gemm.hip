@@ -744,6 +744,9 @@ __device__ __forceinline__ void gemm_epilogue_swiglu_bwd(const grove_gemm_params
 #ifndef PP_SCHED
 #define PP_SCHED 1
 #endif
+#ifndef PP_SCHED2_EXTRA
+#define PP_SCHED2_EXTRA false   // (A/B builds: an expression over BM / GATHER / ACT that puts more instances on schedule 2)
+#endif
 __device__ __forceinline__ void wait_vm_loads(int n) {  // n (even) = vector-memory operations allowed to stay in flight
   if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   else if (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -1044,7 +1047,9 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
   // and in the plain 192-row instance (LLaMA's 2812-row launches: down 193 -> 189 us, o_proj 80 -> 78, qkv dgrad 235 -> 230, the others
   // and CLIP's within +-1 %: tools/dev/pp_shapes_ab.py)
   constexpr bool SCHED2 = PP_SCHED == 2 || (!FP8 && GATHER && BM == 256 && (ACT == GROVE_ACT_NONE || ACT == GROVE_ACT_RELU)) ||
-                          (!FP8 && !GATHER && BM == 192 && ACT < 0);
+                          (!FP8 && !GATHER && BM == 192 && ACT < 0) ||
+                          (!FP8 && !GATHER && (ACT == GROVE_ACT_SWIGLU_PAIR || ACT == GROVE_ACT_SWIGLU_BWD)) ||  // LLaMA's MLP: 431-439 -> 422-425 us, 236-242 -> 234
+                          PP_SCHED2_EXTRA;
   auto k_tile = [&](auto steady, auto relax_stores, auto first, int T) {
     constexpr bool STEADY = decltype(steady)::value;
     constexpr int RELAX = decltype(relax_stores)::value;

@@ -20,6 +20,15 @@ for name, M, N, K in [("LLaMA qkv", 2812, 12288, 4096), ("LLaMA qkv dgrad", 2812
     x = torch.randn(M, K, device=dev).to(bf); w = (torch.randn(N, K, device=dev) * 0.03).to(bf); out = torch.empty(M, N, device=dev, dtype=bf)
     us = t(lambda: ops.linear(x, w, out=out))
     print("%%-22s (%%5d, %%5d, %%5d): %%7.1f us %%7.1f TF" %% (name, M, N, K, us, 2.0 * M * N * K / us / 1e6))
+# LLaMA MLP: gate|up with the SwiGLU pair epilogue (+ aux = gate|up saved), and the down-projection dgrad with the SwiGLU backward epilogue
+M, H, I = 2812, 4096, 11008
+h = torch.randn(M, H, device=dev).to(bf); wgu = ops.swiglu_interleave((torch.randn(2 * I, H, device=dev) * 0.03).to(bf))
+gu = torch.empty(M, 2 * I, device=dev, dtype=bf); a = torch.empty(M, I, device=dev, dtype=bf)
+us = t(lambda: ops.linear(h, wgu, act=ops.ACT_SWIGLU_PAIR, aux=gu, ld_aux=2 * I, out=a))
+print("%%-22s (%%5d, %%5d, %%5d): %%7.1f us %%7.1f TF" %% ("LLaMA gate|up SwiGLU", M, 2 * I, H, us, 2.0 * M * 2 * I * H / us / 1e6))
+dx = torch.randn(M, H, device=dev).to(bf); wdt = (torch.randn(I, H, device=dev) * 0.03).to(bf); dgu = torch.empty(M, 2 * I, device=dev, dtype=bf)
+us = t(lambda: ops.linear(dx, wdt, act=ops.ACT_SWIGLU_BWD, residual=gu, out=dgu))
+print("%%-22s (%%5d, %%5d, %%5d): %%7.1f us %%7.1f TF" %% ("LLaMA down dgrad SwiGLU'", M, I, H, us, 2.0 * M * I * H / us / 1e6))
 ''' % ROOT
 names = sys.argv[1:] or ["product", "_s2"]
 for rnd in range(2):
