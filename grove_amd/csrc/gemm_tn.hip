@@ -529,6 +529,45 @@ __global__ __launch_bounds__(Q_NT) void gemm_tn_pp_kernel(const grove_gemm_tn_pa
     __builtin_amdgcn_s_barrier();
     QQ_MMA(4, 0, b0)
     __builtin_amdgcn_s_barrier();
+#elif TN_SCHED == 3
+    // the NT kernel's schedule 2: every piece one phase later, both half-tiles of the K tile after next in phase 4 (pieces 0 / 2 / 2 / 4);
+    // half-tile h = 4 T + region in issue order; phase 1 retires h = q + 2 (younger: q + 3 .. q + 5), phase 2 q + 3 (.. q + 6), phase 4
+    // q + 5 (.. q + 9); same prologue as schedule 1
+    auto tail_wait = [&](int needed, int last) { wait_vm_even(2 * max(min(last, NH - 1) - needed, 0)); };
+    const bool steady = q + 9 < NH;
+    QQ_READ_B(1, b0)
+    QQ_READ_A(0)
+    if (steady) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else tail_wait(q + 2, q + 5);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    QQ_MMA(0, 0, b0)
+    __builtin_amdgcn_s_barrier();
+    QQ_READ_B(2, b1)
+    if (q + 6 < NH) issue(2, T + 1);
+    if (steady) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else tail_wait(q + 3, q + 6);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    QQ_MMA(0, 2, b1)
+    __builtin_amdgcn_s_barrier();
+    QQ_READ_A(3)
+    if (q + 7 < NH) issue(3, T + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    QQ_MMA(4, 2, b1)
+    __builtin_amdgcn_s_barrier();
+    if (q + 8 < NH) {
+      advance_issue();
+      issue(0, T + 2);
+    }
+    if (q + 9 < NH) issue(1, T + 2);
+    if (steady) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else tail_wait(q + 5, q + 9);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    QQ_MMA(4, 0, b0)
+    __builtin_amdgcn_s_barrier();
 #else
     QQ_READ_B(1, b0)
     QQ_READ_A(0)
