@@ -237,7 +237,9 @@ __device__ __forceinline__ bf16x8_t tr_join(const TrFrag& f) {
 #ifndef TN_SCHED
 // 1 = two pieces per phase (rounds 2-5, shipped); 2 = the rebalanced 0 / 2 / 2 / 4 schedule (round 5 experiment, -DTN_SCHED=2: correct —
 // the TN tests and the guard screen pass — and 3 % faster on the plain (1280, 34560, 32768) launch, nothing on the gathered Conv3d
-// launches the step runs (2696 / 2720 against 2717 / 2717 us): where in the K tile the pieces are issued is not what they cost)
+// launches the step runs (2696 / 2720 against 2717 / 2717 us): where in the K tile the pieces are issued is not what they cost);
+// 3 = the NT kernel's schedule 2 (every piece one phase later, 0 / 2 / 2 / 4): plain launch -3 % (2736 -> 2655 us), the gathered
+// Conv3d launches 10 % SLOWER (2762 -> 3063: the row-index hand-over lands in the phase that now issues four pieces)
 #define TN_SCHED 1
 #endif
 struct tn_skip {
