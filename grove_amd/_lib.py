@@ -206,6 +206,8 @@ def lib():
             _lib.grove_gemm_set_persistent_blocks(int(os.environ["GROVE_GEMM_BLOCKS"]))
         if os.environ.get("GROVE_GEMM_STREAM_K") is not None:  # A/B runs of whole programs: 0 = whole tiles only (grove_hip.h)
             _lib.grove_gemm_set_stream_k(int(os.environ["GROVE_GEMM_STREAM_K"]))
+        if os.environ.get("GROVE_FLASH_V2") is not None:       # A/B runs of whole programs: which attention launches take the eight-wave kernels
+            _lib.grove_flash_attn_set_v2(int(os.environ["GROVE_FLASH_V2"]))
     return _lib
 
 
