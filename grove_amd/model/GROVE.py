@@ -14,6 +14,8 @@ feature row b).
 import math
 from types import SimpleNamespace
 
+import os
+
 import torch
 
 from .. import ops
@@ -587,7 +589,9 @@ class GROVEForCausalLM(torch.nn.Module):
         # (same-box A/B: -11 ms per step, forward and backward). `tower_overlap = False` serialises them.
         if self.tower_overlap:
             if self._sam_stream is None:
-                self._sam_stream = torch.cuda.Stream(device=self.dev)
+                # (GROVE_SAM_STREAM_PRIORITY: A/B knob — -1 = high, 0 = default; the persistent GEMMs of both towers want every CU, the
+                # priority decides whose workgroups are dispatched first when both have some pending)
+                self._sam_stream = torch.cuda.Stream(device=self.dev, priority=int(os.environ.get("GROVE_SAM_STREAM_PRIORITY", "0")))
             self._sam_stream.wait_event(start)
             with torch.cuda.stream(self._sam_stream):
                 emb_rows, sam_ctx = self.sam.forward(simg.to(bf), save=train, before_adapters=self.wait_weights)
