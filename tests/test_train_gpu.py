@@ -424,15 +424,15 @@ def test_bench_self_launches_ranks(tmp_path):
     # the line was timed BEFORE the calibration on all-reduce, or re-timed on an arm that beat it by more than 1 %
     assert res["config"]["gradient_exchange"].startswith(cal["line_timed_on"]["exchange"])
     assert cal["line_timed_on"]["exchange"] == "allreduce" or "start_arm_line" in cal
-    # a wedged collective inside the calibration cannot lose the line: arm 3 never returns, nothing moves for 6 s -> rank 0 prints the
+    # a wedged collective inside the calibration cannot lose the line: arm 1 never returns, nothing moves for 4 s -> rank 0 prints the
     # line it measured before the calibration, marked, and every rank leaves with exit code 0
-    st = _run_rehearsal(base, dict(env, GROVE_BENCH_STALL_S="6", GROVE_BENCH_TEST_STALL_ARM="3"))
+    st = _run_rehearsal(base, dict(env, GROVE_BENCH_STALL_S="4", GROVE_BENCH_TEST_STALL_ARM="1"))
     assert st.returncode == 0, st.stderr[-2000:]
     sl = [ln for ln in st.stdout.splitlines() if ln.strip()]
     assert len(sl) == 1, st.stdout
     sres = json.loads(sl[0])
     assert sres["value"] > 0 and sres["n_gpus"] == 2
-    assert sres["config"]["exchange_calibration"]["status"].startswith("STALLED in 'rs_ag, 16 CUs reserved'"), sres["config"]["exchange_calibration"]
+    assert sres["config"]["exchange_calibration"]["status"].startswith("STALLED in 'allreduce, 16 CUs reserved'"), sres["config"]["exchange_calibration"]
     for extra in ([], ["--no_comm_overlap"], ["--exchange", "rs_ag"], ["--exchange", "a2a_f32"], ["--dense_embed"]):
         q = run(extra + ["--no_calibration"])
         assert q.returncode == 0, q.stderr[-2000:]
