@@ -1024,7 +1024,16 @@ def exchange_epilogue(args, engine, step, res, prog, world, rank, dev, real_stdo
         beat[1] = f"{mode}, {reserve} CUs reserved"
         if len(beat) - 2 == test_stall_arm:
             time.sleep(1e6)
-    table, best = calibrate_exchange(engine, beating_step, steps=args.calibration_steps, on_arm=on_arm, done_arms=beat)
+    try:
+        table, best = calibrate_exchange(engine, beating_step, steps=args.calibration_steps, on_arm=on_arm, done_arms=beat)
+    except Exception as e:  # an arm that raises (an RCCL error, an out-of-memory plan) must not take the measured line with it
+        print(f"[bench rank {rank}] exchange calibration failed in '{beat[1]}': {e!r}", file=sys.stderr, flush=True)
+        if rank == 0 and res is not None:
+            res["config"]["exchange_calibration"] = {"status": f"FAILED in '{beat[1]}': {e!r}; this line is the start arm's, measured before the calibration; "
+                                                               f"arms finished: {beat[2:]}"}
+        ex.mode, ex.reserve_cus = start_arm
+        done.set()
+        return
     mine = [a for a in table if (a["exchange"], a["reserved_cus"]) == start_arm]
     start_row = mine[0] if mine else None
     calibration = {"arms": table, "fastest": best, "steps_per_arm": args.calibration_steps, "line_timed_on": {"exchange": start_arm[0], "reserved_cus": start_arm[1]},
