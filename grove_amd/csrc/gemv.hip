@@ -331,6 +331,7 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_mfma_kernel(const grove_gemv_
   }
 }
 
+static int g_gemv_rw1 = 1;  // one output row per wave for N <= 4096 at M = 1 (o_proj 10.9 -> 10.5 us, down 20.4 -> 19.5; bit 2 of grove_gemv_set_mfma clears it)
 static int g_gemv_mfma = 1;
 static int g_gemv_rows32 = 1;  // (grove_gemv_set_mfma bit 1 clears it: 16-row workgroups everywhere, the A/B arm)  // 0 = the VALU kernel for every M (A/B arm: grove_gemv_set_mfma)
 
@@ -351,6 +352,7 @@ template <int MX>
 int launch_gemv(const grove_gemv_params& p, hipStream_t s) {
   // 4 rows per wave amortise the x reads; below ~3 blocks per CU take 2 rows per wave for more loads in flight
   if (p.act == GROVE_ACT_SWIGLU_PAIR) return launch_gemv_rw<MX, 4>(p, s);  // (the pairing is laid out for 4 rows per wave)
+  if (MX == 1 && p.N <= 4096 && g_gemv_rw1) return launch_gemv_rw<MX, 1>(p, s);  // one row per wave for the narrow projections: twice the workgroups
   return p.N >= 12288 ? launch_gemv_rw<MX, 4>(p, s) : launch_gemv_rw<MX, 2>(p, s);
 }
 }  // namespace
@@ -358,6 +360,7 @@ int launch_gemv(const grove_gemv_params& p, hipStream_t s) {
 extern "C" int grove_gemv_set_mfma(int32_t on) {
   g_gemv_mfma = on != 0;
   g_gemv_rows32 = (on & 2) == 0;
+  g_gemv_rw1 = (on & 4) == 0;
   return GROVE_OK;
 }
 

@@ -507,7 +507,8 @@ int grove_gemv_bf16(const grove_gemv_params* p, void* stream);
 /* A/B knob (round 5): 1 (default) = 3..8 sequences with K % 128 == 0 run on the matrix-core kernel (one weight stream feeds one
  * v_mfma_f32_16x16x32_bf16 per 32-deep k-step: HBM-bound at 8 sequences, where the VALU kernel is compute-bound); 0 = the VALU
  * kernel for every M. fp32 sum order differs between the two (both accumulate in fp32). Bit 1 (on = 3): the matrix-core kernel
- * with 16-row workgroups for every N (default: 32-row workgroups when N >= 16384 and x is plain — the same results bit for bit). */
+ * with 16-row workgroups for every N (default: 32-row workgroups when N >= 16384 and x is plain — the same results bit for bit);
+ * bit 2 (on = 5): the VALU kernel at M = 1 with two rows per wave for N <= 4096 (default: one — the same results). */
 int grove_gemv_set_mfma(int32_t on);
 
 /* One cached decode step of causal self-attention for ONE new token per sequence (HF LlamaAttention with a KV cache):
