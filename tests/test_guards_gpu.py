@@ -16,8 +16,11 @@ MARGIN = 8192  # bytes on each side (a 64-row tile of 128 bf16 columns overhangi
 class GuardedAllocs:
     """Replaces torch.empty / torch.zeros for CUDA tensors while active."""
 
-    def __init__(self):
+    def __init__(self, poison=False):
+        # poison: the INSIDE of every torch.empty tensor starts as all-ones bytes (NaN as bf16 / fp16 / fp32, -1 as an integer), so an
+        # element a kernel never writes but a later one reads turns the results non-finite instead of passing on whatever was there
         self.bufs = []
+        self.poison = poison
         self._empty, self._zeros = torch.empty, torch.zeros
 
     def carve(self, shape, dtype, device, zero=False):
@@ -29,6 +32,8 @@ class GuardedAllocs:
         t = raw[m:m + n]
         if zero:
             t.zero_()
+        elif self.poison and n:
+            t.view(torch.uint8).fill_(0xFF)
         self.bufs.append((raw, m, n))
         return t.view(shape)
 
@@ -195,7 +200,7 @@ def test_whole_model_writes_inside_its_tensors(dev, mode):
         kw[k] = kw[k].to(dev)
     if train:
         model.zero_grad()
-    with GuardedAllocs() as ga:
+    with GuardedAllocs(poison=True) as ga:
         if train:
             out = model(**kw)
             model.backward(out["loss"])
@@ -208,6 +213,7 @@ def test_whole_model_writes_inside_its_tensors(dev, mode):
                                  return_dict_in_generate=True)
             ga.check("generate B=3")
             assert gen.sequences.shape[0] == 3
+            assert all(torch.isfinite(h.float()).all() for h in gen.hidden_states), "a generated hidden state read an element nobody wrote"
     assert len(ga.bufs) > 50
 
 
@@ -231,7 +237,7 @@ def test_full_dims_bench_step_writes_inside_its_tensors(dev):
     out = model(**kw)                      # warm: plans, workspaces, tables
     model.backward(out["loss"])
     model.zero_grad()
-    with GuardedAllocs() as ga:
+    with GuardedAllocs(poison=True) as ga:
         out = model(**kw)
         model.backward(out["loss"])
         ga.check("full-dims training step")
