@@ -1,7 +1,9 @@
 """Out-of-bounds WRITE screen for the kernels whose tiles overhang their problem (round 5: the GEMV's padded-row stores were found by a
 fault that only happened when `y` ended a mapped segment — no GPU sanitizer exists on this pool). Every tensor a wrapper allocates during
-the call is carved out of a larger buffer whose margins hold a byte pattern; after the call the margins must be intact. Results are
-checked elsewhere (tests/test_kernels_gpu.py); here only that nothing outside the tensors was touched."""
+the call is carved out of a larger buffer whose margins hold a byte pattern; after the call the margins must be intact; the inside of
+every `torch.empty` tensor starts as NaN (-1 for integers), so an element that is read without ever having been written shows up as a
+non-finite result. Values are checked elsewhere (tests/test_kernels_gpu.py); here only that nothing outside the tensors was touched
+and nothing inside them was consumed unwritten."""
 import math
 
 import pytest
@@ -83,7 +85,7 @@ def test_attention_kernels_write_inside_their_tensors(dev, B, H, L, hs, hd, caus
     from grove_amd import ops
     g = torch.Generator().manual_seed(5)
     alpha = hd ** -0.5
-    with GuardedAllocs() as ga:
+    with GuardedAllocs(poison=True) as ga:
         qkv = ga.carve((B * L, 3 * H * hs), bf16, dev, zero=True)
         qkv.view(B * L, 3, H, hs)[..., :hd] = torch.randn(B * L, 3, H, hd, generator=g).to(bf16).to(dev)
         do = ga.carve((B * L, H * hs), bf16, dev, zero=True)
@@ -115,7 +117,7 @@ def test_gemv_kernels_write_inside_their_tensors(dev, M, N, K, fold):
     """VALU instances (K % 128 != 0 or M <= 2) and the matrix-core kernel (3..8 rows), plain and with the folded RMSNorm on an fp32 stream."""
     from grove_amd import ops
     g = torch.Generator().manual_seed(6)
-    with GuardedAllocs() as ga:
+    with GuardedAllocs(poison=True) as ga:
         w = ga.carve((N, K), bf16, dev)
         w.copy_((torch.randn(N, K, generator=g) * 0.05).to(bf16))
         x = ga.carve((M, K), torch.float32 if fold else bf16, dev)
@@ -140,7 +142,7 @@ def test_gemm_kernels_write_inside_their_tensors(dev, M, N, K, act):
     """NT GEMM family: ragged edges, stream-K workspace, fix-up launch — C, the workspace and every other allocation keep their margins."""
     from grove_amd import ops
     g = torch.Generator().manual_seed(7)
-    with GuardedAllocs() as ga:
+    with GuardedAllocs(poison=True) as ga:
         a = ga.carve((M, K), bf16, dev)
         a.copy_(torch.randn(M, K, generator=g).to(bf16))
         b = ga.carve((N, K), bf16, dev)
@@ -163,7 +165,7 @@ def test_gemm_kernels_write_inside_their_tensors(dev, M, N, K, act):
 def test_norm_kernels_write_inside_their_tensors(dev, rows, C, rms):
     from grove_amd import ops
     g = torch.Generator().manual_seed(8)
-    with GuardedAllocs() as ga:
+    with GuardedAllocs(poison=True) as ga:
         x = ga.carve((rows, C), bf16, dev)
         x.copy_(torch.randn(rows, C, generator=g).to(bf16))
         w = ga.carve((C,), bf16, dev)
