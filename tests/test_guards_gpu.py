@@ -183,7 +183,7 @@ def test_norm_kernels_write_inside_their_tensors(dev, rows, C, rms):
     assert torch.isfinite(y.float()).all() and torch.isfinite(dx.float()).all()
 
 
-@pytest.mark.parametrize("mode", ["train", "infer_generate"])
+@pytest.mark.parametrize("mode", ["train", "infer_generate", "infer_masks"])
 def test_whole_model_writes_inside_its_tensors(dev, mode):
     """Every kernel of the path in one go: a tiny-dims training step (forward + backward: towers, window / global / causal attention,
     Conv3d adapters, decoder, losses) and an inference pass with cached greedy decoding at B = 3 (the padded-row GEMV instances), with
@@ -208,6 +208,14 @@ def test_whole_model_writes_inside_its_tensors(dev, mode):
             model.backward(out["loss"])
             ga.check("training step")
             assert torch.isfinite(out["loss"]).all() and torch.isfinite(model._flat_grad).all()
+        elif mode == "infer_masks":  # config 5's path: teacher-forced inference forward + the SAM mask branch with its post-processing
+            out = model(**dict(kw, inference=True))
+            n_inst = int(out["flat_boxes"].shape[0]) // 8
+            text = torch.randn(max(n_inst, 1), d.out_dim, device=dev) * 0.1
+            inst_frame = torch.zeros(max(n_inst, 1), dtype=torch.int32, device=dev)
+            res = model.predict_masks(out["image_embeddings"], text, inst_frame, input_size=(384, 512), original_size=(360, 640))
+            ga.check("inference forward + masks")
+            assert torch.isfinite(out["flat_boxes"]).all() and torch.isfinite(res["masks"]).all() and torch.isfinite(res["iou_predictions"]).all()
         else:
             feats, _ = model(mode="encode_images", images=kw["global_enc_images"])
             prompt = kw["input_ids"][:, :20].contiguous()
