@@ -183,7 +183,7 @@ def test_norm_kernels_write_inside_their_tensors(dev, rows, C, rms):
     assert torch.isfinite(y.float()).all() and torch.isfinite(dx.float()).all()
 
 
-@pytest.mark.parametrize("mode", ["train", "infer_generate", "infer_masks"])
+@pytest.mark.parametrize("mode", ["train", "infer_generate", "infer_masks", "infer_fp8"])
 def test_whole_model_writes_inside_its_tensors(dev, mode):
     """Every kernel of the path in one go: a tiny-dims training step (forward + backward: towers, window / global / causal attention,
     Conv3d adapters, decoder, losses) and an inference pass with cached greedy decoding at B = 3 (the padded-row GEMV instances), with
@@ -193,7 +193,8 @@ def test_whole_model_writes_inside_its_tensors(dev, mode):
     d = TINY
     sd = synthetic_state_dict(d)
     train = mode == "train"
-    model = GROVEForCausalLM(dims=d, device=dev, state_dict=sd, det_token_idx=d.det_token_idx, num_frames=8, train=train)
+    extra = dict(gemm_dtype="fp8", fp8_policy="det16_kv16") if mode == "infer_fp8" else {}  # (CLIP in e4m3 too: every fp8 kernel of config 5)
+    model = GROVEForCausalLM(dims=d, device=dev, state_dict=sd, det_token_idx=d.det_token_idx, num_frames=8, train=train, **extra)
     batch = synthetic_batch(d, B=2 if train else 3, T=8, L=48, n_det=2, seed=7, ragged=True)
     kw = batch.as_kwargs()
     for k in ("global_enc_images", "grounding_enc_images"):
@@ -208,6 +209,10 @@ def test_whole_model_writes_inside_its_tensors(dev, mode):
             model.backward(out["loss"])
             ga.check("training step")
             assert torch.isfinite(out["loss"]).all() and torch.isfinite(model._flat_grad).all()
+        elif mode == "infer_fp8":
+            out = model(**dict(kw, inference=True))
+            ga.check("fp8 inference forward")
+            assert torch.isfinite(out["flat_boxes"]).all() and torch.isfinite(out["hidden"].float()).all()
         elif mode == "infer_masks":  # config 5's path: teacher-forced inference forward + the SAM mask branch with its post-processing
             out = model(**dict(kw, inference=True))
             n_inst = int(out["flat_boxes"].shape[0]) // 8
