@@ -460,6 +460,14 @@ def test_bench_infer_mode_runs_on_two_ranks(tmp_path):
         res = json.loads(lines[0])
         assert res["n_gpus"] == 2 and res["config"]["ranks"] == 2 and res["config"]["ranks_gathered"] == 2
         assert res["config"]["collective_backend"] == "gloo" and res["value"] > 0 and res["dtype"] == dtype
+    # config 2 (round 5): the infer_iground flow — clip-batched centre `evaluate` + the other windows — as replicas on two ranks
+    p = _run_rehearsal([sys.executable, os.path.join(root, "bench.py"), "--mode", "infer_iground", "--gpus", "2", "--dims", "tiny", "--steps", "1", "--warmup", "1",
+                        "--frames", "24", "--clips", "2", "--clips_per_batch", "2", "--max_new_tokens", "4", "--no_cpu_baseline"], env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["value"] > 0 and res["config"]["clips_per_batch"] == 2 and res["config"]["speedup_over_batch1"] > 0
 
 
 def _three_steps(dev, overlap=True):
