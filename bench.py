@@ -727,7 +727,7 @@ def main():
     ap.add_argument("--exchange", default="auto", choices=["auto", "allreduce", "rs_ag", "a2a_f32"],
                     help="N > 1: one all-reduce per gradient bucket, reduce-scatter + all-gather per bucket, or all-to-all + fp32 sum + all-gather; "
                          "auto (default) = all-reduce for the line's timed region; the calibration pass that FOLLOWS it times every arm, prints the table, and re-times "
-                         "the line on an arm that beats all-reduce by more than 1 % (a stalled calibration cannot lose the line)")
+                         "the line on an arm that beats all-reduce by more than 1 %% (a stalled calibration cannot lose the line)")
     ap.add_argument("--no_calibration", action="store_true", help="N > 1: skip the exchange-arm calibration pass (then --exchange auto = allreduce)")
     ap.add_argument("--calibration_steps", type=int, default=3)
     ap.add_argument("--via_train_loop", action="store_true",

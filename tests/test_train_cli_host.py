@@ -103,3 +103,13 @@ def test_trainable_set_follows_train_mask_decoder():
     assert dec and all(n.startswith((M_ + "bbox_prediction_head.", M_ + "temporal_objectness_head.")) for n in dec)
     assert any(n.startswith(M_ + "transformer.") for n in full)
     assert [n for n in full if not n.startswith(M_)] == [n for n in heads if not n.startswith(M_)]
+
+
+def test_bench_and_train_help_render():
+    """argparse expands `%` in help strings: a literal per-cent sign in one of them breaks `--help` (round 5 had one)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for cmd in ([sys.executable, os.path.join(root, "bench.py"), "--help"], [sys.executable, "-m", "grove_amd.train", "--help"]):
+        p = subprocess.run(cmd, cwd=root, capture_output=True, text=True)
+        assert p.returncode == 0 and "usage:" in p.stdout, p.stderr[-500:]
