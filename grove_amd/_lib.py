@@ -25,7 +25,7 @@ class GemmParams(C.Structure):
                 ("batch1", c_i32), ("batch2", c_i32), ("a_taps", c_i32), ("act", c_i32),
                 ("c_dtype", c_i32), ("accumulate", c_i32), ("scale_tanh", c_i32), ("alpha", c_f32), ("split_k", c_i32), ("ld_aux", c_i32),
                 ("n_group", c_i32), ("n_pad", c_i32), ("k_group", c_i32), ("k_pad", c_i32), ("aux_grad", c_i32), ("residual_mul", c_i32),
-                ("a_frame_rows", c_i32), ("a_frames", c_i32)]
+                ("a_frame_rows", c_i32), ("a_frames", c_i32), ("b_group_rows", c_i32), ("reserved0", c_i32), ("sB_group", c_i64)]
 
 
 class TransposeParams(C.Structure):
@@ -103,7 +103,7 @@ class GemmTnParams(C.Structure):
     _fields_ = [("A", c_vp), ("B", c_vp), ("C", c_vp), ("scale_ptr", c_vp), ("b_idx", c_vp),
                 ("M", c_i32), ("N", c_i32), ("K", c_i32), ("lda", c_i32), ("ldb", c_i32), ("ldc", c_i32),
                 ("b_taps", c_i32), ("scale_tanh", c_i32), ("split_k", c_i32), ("alpha", c_f32),
-                ("b_frame_rows", c_i32), ("b_frames", c_i32)]
+                ("b_frame_rows", c_i32), ("b_frames", c_i32), ("k_batches", c_i32), ("overwrite", c_i32), ("sC_batch", c_i64)]
 
 
 class FlashAttnParams(C.Structure):
@@ -153,6 +153,13 @@ class GreedyPickParams(C.Structure):
                 ("B", c_i32), ("V", c_i32), ("H", c_i32), ("eos", c_i32), ("pad", c_i32), ("pos0", c_i32), ("max_steps", c_i32)]
 
 
+class Wino3dParams(C.Structure):
+    _fields_ = [("src", c_vp), ("dst", c_vp), ("bias", c_vp), ("residual", c_vp), ("aux", c_vp), ("scale_ptr", c_vp),
+                ("groups", c_i32), ("T", c_i32), ("H", c_i32), ("W", c_i32), ("C", c_i32), ("rows", c_i32),
+                ("ld_src", c_i32), ("ld_dst", c_i32), ("ld_res", c_i32), ("ld_aux", c_i32), ("mode", c_i32), ("act", c_i32), ("scale_tanh", c_i32),
+                ("alpha", c_f32)]
+
+
 class GemmWorkspace(C.Structure):
     _fields_ = [("image", c_vp), ("image_bytes", C.c_size_t), ("scratch", c_vp), ("scratch_bytes", C.c_size_t)]
 
@@ -171,6 +178,7 @@ STRUCTS = {
     "grove_gemm_tn_params": GemmTnParams, "grove_gemv_params": GemvParams, "grove_decode_attn_params": DecodeAttnParams, "grove_resample_params": ResampleParams,
     "grove_normalize_params": NormalizeParams, "grove_gemm_f32_params": GemmF32Params, "grove_gemm_fp8_params": GemmFp8Params,
     "grove_gemm_workspace": GemmWorkspace, "grove_gemm_plan": GemmPlan, "grove_greedy_pick_params": GreedyPickParams,
+    "grove_wino3d_params": Wino3dParams,
 }
 
 # every symbol include/grove_hip.h declares (tests/test_abi.py checks the header against this list)
@@ -182,6 +190,7 @@ SYMBOLS = [
     "grove_copy_rows", "grove_dot_bf16", "grove_axpy_f32", "grove_scatter_add_f32", "grove_scatter_add_rows_f32", "grove_colsum_f32", "grove_cast_f32_to_bf16", "grove_cast_bf16_to_f32",
     "grove_im2col_patch", "grove_clip_pool", "grove_cross_entropy", "grove_small_attn_fwd", "grove_small_attn_bwd", "grove_gemm_f32", "grove_gemm_fp8", "grove_gemm_fp8_set_pipelined", "grove_quant_fp8_rows",
     "grove_box_head_fwd", "grove_box_head_bwd", "grove_box_losses", "grove_adamw_step", "grove_adamw_step_multi", "grove_sumsq_f32",
+    "grove_wino3d_transform_tokens", "grove_wino3d_transform_weight", "grove_wino3d_output", "grove_wino3d_wgrad_output",
 ]
 
 _lib = None

@@ -71,6 +71,7 @@ extern "C" int grove_sizeof(const char* name) {
   SZ(grove_greedy_pick_params);
   SZ(grove_gemm_workspace);
   SZ(grove_gemm_plan);
+  SZ(grove_wino3d_params);
 #undef SZ
   return -1;
 }

@@ -848,7 +848,9 @@ __device__ __forceinline__ void fp8_scale_acc(const grove_gemm_params& p, const 
 // 128 codes instead of 64 bf16) and a phase's MFMAs are v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales — one per
 // (row fragment, column fragment) on the SAME two 16-byte reads per operand that feed the two bf16 k-steps: a lane's 32 bytes are
 // chunks fq and fq + 4 of the row for A and B alike, and which k a byte is does not matter as long as both operands agree.
-template <int BM, bool GATHER, int ACT, bool FP8 = false>
+// GROUPED (round 6; grove_gemm_params.b_group_rows — the Winograd form of the Conv3d adapters, 64 transform points in one launch):
+// the rows of A are groups of b_group_rows rows (whole tiles) and group g multiplies its own B matrix at B + g * sB_group.
+template <int BM, bool GATHER, int ACT, bool FP8 = false, bool GROUPED = false>
 __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_params p, const pp_work work) {
   constexpr int BMH = BM / 2;    // rows of an A half-tile: 128 or 96
   constexpr int WRH = BMH / 2;   // ... of which one wave group owns 64 or 48
@@ -911,6 +913,8 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
   };
   auto set_src = [&](int m0, int n0, int k0) {
     if constexpr (GATHER) set_src_a(m0, k0 ? __builtin_amdgcn_readfirstlane(k0 / kt_per_tap) : 0);  // (a stream-K part starts inside the K range)
+    const bf16_raw* Bg = B;
+    if constexpr (GROUPED) Bg = B + (int64_t)(m0 / p.b_group_rows) * p.sB_group;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int r = st_r + 64 * i;
@@ -922,8 +926,8 @@ __global__ __launch_bounds__(P_NT) void gemm_nt_pp_kernel(const grove_gemm_param
       // LDS row R of a B half holds column pn(R): fragment j, operand row r of a wave's 32-column group lands on column
       // 8 * (r >> 2) + 4 * j + (r & 3), so a lane's accumulators for (j = 0, 1) are 8 consecutive columns -> 16-byte stores
       const int pn = (r & ~31) | (((r & 15) >> 2) * 8 + ((r >> 4) & 1) * 4 + (r & 3));
-      src[1][i] = B + (int64_t)min(n0 + pn, p.N - 1) * p.ldb + c;
-      src[2][i] = B + (int64_t)min(n0 + 128 + pn, p.N - 1) * p.ldb + c;
+      src[1][i] = Bg + (int64_t)min(n0 + pn, p.N - 1) * p.ldb + c;
+      src[2][i] = Bg + (int64_t)min(n0 + 128 + pn, p.N - 1) * p.ldb + c;
     }
   };
   int is_seg = 0, is_k, is_kend;  // segment and K tile of the half-tile being issued
@@ -1626,7 +1630,7 @@ inline void build_work_list(const pp_table_key& key, const sk_plan& pl, std::vec
   (void)nk;
 }
 
-template <int BM, bool GATHER, int ACT, bool FP8 = false>
+template <int BM, bool GATHER, int ACT, bool FP8 = false, bool GROUPED = false>
 int launch_pp_act(const grove_gemm_params& p, hipStream_t s, const float* row_scale = nullptr, const float* col_scale = nullptr) {
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + P_BN - 1) / P_BN;
   const size_t lds = 2 * (size_t)P_STAGE;
@@ -1672,7 +1676,7 @@ int launch_pp_act(const grove_gemm_params& p, hipStream_t s, const float* row_sc
               "gemm: this launch cuts %d tiles into stream-K parts and needs %zu bytes of scratch (got %zu)", n_fix, scratch_bytes, t_call.scratch_bytes);
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<BM, GATHER, ACT, FP8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<BM, GATHER, ACT, FP8, GROUPED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   g_gemm_last_epilogue = ACT;
@@ -1693,7 +1697,7 @@ int launch_pp_act(const grove_gemm_params& p, hipStream_t s, const float* row_sc
     }
   }
 #endif
-  if (!w4) hipLaunchKernelGGL((gemm_nt_pp_kernel<BM, GATHER, ACT, FP8>), dim3(grid, 1, 1), dim3(P_NT), lds, s, p, work);
+  if (!w4) hipLaunchKernelGGL((gemm_nt_pp_kernel<BM, GATHER, ACT, FP8, GROUPED>), dim3(grid, 1, 1), dim3(P_NT), lds, s, p, work);
   GROVE_LAUNCH_CHECK();
   if (td.n_fixups) {
     hipLaunchKernelGGL((gemm_pp_fixup_kernel<BM, ACT, FP8>), dim3(td.n_fixups * (8 / FIX_WAVES), 1, 1), dim3(64 * FIX_WAVES), 0, s, p, td.fixups,
@@ -1946,6 +1950,14 @@ static int gemm_bf16_dispatch(const grove_gemm_params* pp, void* stream) {
   const double cp256 = pp_cost(tp256, 1.5, 3.0 + 3.0 * out_scale);
   const double cp192 = pp_cost(tp192, 1.17, 0.8 * (3.0 + 3.0 * out_scale));
   const double c_old = c128 < c192 ? c128 : c192;
+  if (p.b_group_rows) {  // grouped B: the plain 256-row pipelined instance only
+    GROVE_CHECK(p256_ok && !p.a_idx && !maps && p.act == GROVE_ACT_NONE && p.alpha == 1.f && !p.scale_ptr && p.c_dtype == GROVE_BF16 && !p.aux && !p.c_idx && !p.r_idx &&
+                    !p.residual && p.b_group_rows > 0 && p.b_group_rows % 256 == 0 && p.M % p.b_group_rows == 0 && p.sB_group % 8 == 0,
+                GROVE_E_SHAPE, "gemm: b_group_rows needs the plain pipelined kernel (bf16 C, no epilogue operands beyond bias, no row maps), groups of whole 256-row "
+                               "tiles (b_group_rows = %d, M = %d) and a 16-byte aligned group stride", p.b_group_rows, p.M);
+    g_gemm_last_variant = GROVE_GEMM_PP256;
+    return launch_pp_act<256, false, -1, false, true>(p, s);
+  }
   if (p256_ok && (g_gemm_tile_m == 193 || g_gemm_tile_m == 256)) {
     g_gemm_last_variant = g_gemm_tile_m == 256 ? (p.a_idx ? GROVE_GEMM_PP256_GATHER : GROVE_GEMM_PP256) : (p.a_idx ? GROVE_GEMM_PP192_GATHER : GROVE_GEMM_PP192);
     if (p.a_idx) return g_gemm_tile_m == 256 ? launch_pp<256, true>(p, s) : launch_pp<192, true>(p, s);

@@ -245,7 +245,10 @@ __device__ __forceinline__ bf16x8_t tr_join(const TrFrag& f) {
 struct tn_skip {
   int fk, T;  // K tiles per frame, frames per group
 };
-template <bool GATHER, bool TSKIP = false>
+// KBATCH (round 6; grove_gemm_tn_params.k_batches — the Winograd weight gradient, 64 transform points in one launch): the operands are
+// k_batches stacked K ranges and the tile index carries the batch: L = batch * (tiles_m * tiles_n) + tile; batch b reads rows
+// [b K, (b + 1) K) of A and B and accumulates into C + b * sC_batch. Everything else (units, rounds, the cut tail) is unchanged.
+template <bool GATHER, bool TSKIP = false, bool KBATCH = false>
 __global__ __launch_bounds__(Q_NT) void gemm_tn_pp_kernel(const grove_gemm_tn_params p, const int tiles_m, const int tiles_n, const int tiles_whole,
                                                           const int parts, const tn_skip sk = tn_skip{0, 0}) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -261,7 +264,8 @@ __global__ __launch_bounds__(Q_NT) void gemm_tn_pp_kernel(const grove_gemm_tn_pa
   // Work units, dealt round-robin (unit u = wgid + G r): the first tiles_whole tiles whole, then the tiles of the partial last
   // round cut into `parts` equal K ranges, part-major (all first parts, then all second parts: the blocks of a round walk the same
   // K range, as they do in a round of whole tiles). A partial range is added to C with fp32 atomics (launch_tn_pp picks parts).
-  const int tiles = tiles_m * tiles_n;
+  const int tiles1 = tiles_m * tiles_n;
+  const int tiles = KBATCH ? tiles1 * p.k_batches : tiles1;
   const int tail_tiles = tiles - tiles_whole;
   const int units = tiles_whole + tail_tiles * parts;
   const int nk = p.K / Q_BK;
@@ -310,6 +314,7 @@ __global__ __launch_bounds__(Q_NT) void gemm_tn_pp_kernel(const grove_gemm_tn_pa
   const bf16_raw* pa[2];     // A_lo / A_hi column bases (row 0)
   int colb[2];               // B_lo / B_hi column offsets inside a (gathered) row
   const bf16_raw* pbrow[2];  // GATHER: my two B rows of the K tile being issued (nullptr = zero row)
+  const bf16_raw* Bt = B;    // KBATCH: row 0 of the tile's batch
   const int32_t* bidx = nullptr;
   int is_u = wgid, is_k = 0, is_kb = 0;
   int is_kp = 0, is_left = 0x7fffffff, is_grp = 1;  // physical K tile being issued, valid tiles left in its run, tap group (TSKIP)
@@ -318,12 +323,15 @@ __global__ __launch_bounds__(Q_NT) void gemm_tn_pp_kernel(const grove_gemm_tn_pa
     unit_of(u, L, is_k, is_kb);
     is_grp = grp_of(L);
     is_kp = phys_of(is_k, is_grp, is_left);
-    const int tm = L % tiles_m, tn = L / tiles_m;
+    const int bt = KBATCH ? L / tiles1 : 0, Lt = KBATCH ? L - bt * tiles1 : L;
+    const int tm = Lt % tiles_m, tn = Lt / tiles_m;
     const int m0 = tm * 256, n0 = tn * 256;
     const int tap = n0 / n_per_tap, nb0 = n0 - tap * n_per_tap;
+    const bf16_raw* At = A;
+    if constexpr (KBATCH) At = A + (int64_t)bt * p.K * p.lda, Bt = B + (int64_t)bt * p.K * p.ldb;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      pa[h] = A + min(m0 + 128 * h + lc * 8, p.M - 8);
+      pa[h] = At + min(m0 + 128 * h + lc * 8, p.M - 8);
       colb[h] = min(nb0 + 128 * h + lc * 8, n_per_tap - 8);
     }
     if (GATHER) bidx = p.b_idx + (int64_t)tap * p.K;
@@ -369,7 +377,7 @@ __global__ __launch_bounds__(Q_NT) void gemm_tn_pp_kernel(const grove_gemm_tn_pa
       } else if (GATHER) {
         src = pbrow[i] ? pbrow[i] + colb[x == 2] : (const bf16_raw*)g_tn_zero_page;
       } else {
-        src = B + (int64_t)(is_kp * Q_BK + 32 * i + st_k) * p.ldb + colb[x == 2];
+        src = Bt + (int64_t)(is_kp * Q_BK + 32 * i + st_k) * p.ldb + colb[x == 2];
       }
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(dst + i * (Q_NT * 16)), 16, 0, 0);
@@ -591,8 +599,10 @@ __global__ __launch_bounds__(Q_NT) void gemm_tn_pp_kernel(const grove_gemm_tn_pa
 #endif
     if (++c_k == c_kb) {
       // acc[i][j] holds D[n = 4 g + e][m = fr] of A fragment i (m) and B fragment j (n): C += scale * D, 16 bytes per lane
-      const int tm = c_L % tiles_m, tn = c_L / tiles_m;
+      const int cbt = KBATCH ? c_L / tiles1 : 0, cLt = KBATCH ? c_L - cbt * tiles1 : c_L;
+      const int tm = cLt % tiles_m, tn = cLt / tiles_m;
       const int m0 = tm * 256 + wr * 64 + fr, n0 = tn * 256 + wc * 32 + 4 * g;
+      float* const Cb = KBATCH ? p.C + (int64_t)cbt * p.sC_batch : p.C;
       if (__builtin_expect(c_u >= tiles_whole && parts > 1, 0)) {  // one K range of a cut tile
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -602,7 +612,7 @@ __global__ __launch_bounds__(Q_NT) void gemm_tn_pp_kernel(const grove_gemm_tn_pa
           for (int i = 0; i < 8; ++i) {
             const int m = m0 + (i >> 2) * 128 + (i & 3) * 16;
             if (m < p.M) {
-              float* c = p.C + (int64_t)m * p.ldc + n;
+              float* c = Cb + (int64_t)m * p.ldc + n;
 #pragma unroll
               for (int e = 0; e < 4; ++e) unsafeAtomicAdd(c + e, acc[i][j][e] * scale);
             }
@@ -617,12 +627,12 @@ __global__ __launch_bounds__(Q_NT) void gemm_tn_pp_kernel(const grove_gemm_tn_pa
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const int m = min(m0 + (i >> 2) * 128 + (i & 3) * 16, p.M - 1);
-          old[i] = *(const f32x4_t*)(p.C + (int64_t)m * p.ldc + n);
+          old[i] = (KBATCH && p.overwrite) ? f32x4_t{0.f, 0.f, 0.f, 0.f} : *(const f32x4_t*)(Cb + (int64_t)m * p.ldc + n);
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const int m = m0 + (i >> 2) * 128 + (i & 3) * 16;
-          if (m < p.M) *(f32x4_t*)(p.C + (int64_t)m * p.ldc + n) = old[i] + acc[i][j] * scale;
+          if (m < p.M) *(f32x4_t*)(Cb + (int64_t)m * p.ldc + n) = old[i] + acc[i][j] * scale;
         }
       }
 #pragma unroll
@@ -664,7 +674,8 @@ int launch_tn_pp(const grove_gemm_tn_params& p, hipStream_t s) {
     if (num_cus <= 0) num_cus = 256;
     attr_set = true;
   }
-  const int tiles = tiles_m * tiles_n;
+  const int kb = (!GATHER && p.k_batches > 1) ? p.k_batches : 1;
+  const int tiles = tiles_m * tiles_n * kb;
   const int cap = grove_gemm_persistent_blocks();  // the resident-block cap of the persistent kernels (N > 1: CUs left to RCCL)
   const int cus = cap > 0 && cap < num_cus ? cap : num_cus;
   const int G = tiles < cus ? tiles : cus;
@@ -680,7 +691,7 @@ int launch_tn_pp(const grove_gemm_tn_params& p, hipStream_t s) {
     sk = tn_skip{p.b_frame_rows / Q_BK, p.b_frames};
   const int nk_eff = sk.fk ? (p.K / Q_BK) / sk.T * (sk.T - 1) : p.K / Q_BK;  // K tiles of the tiles a cut tail holds (the short ones come last)
   int parts = 1, tail = tiles % G;
-  if (tail && !grove_det_on() && (g_tn_split_tail == 2 || (g_tn_split_tail == 1 && GATHER))) {
+  if (tail && !grove_det_on() && !(kb > 1 && p.overwrite) && (g_tn_split_tail == 2 || (g_tn_split_tail == 1 && GATHER))) {
     double best = 1.0;
     for (int s2 = 2; s2 <= 4; ++s2) {
       if (nk_eff / s2 < 32) break;
@@ -693,6 +704,18 @@ int launch_tn_pp(const grove_gemm_tn_params& p, hipStream_t s) {
   if constexpr (GATHER) {
     if (sk.fk) {
       hipLaunchKernelGGL((gemm_tn_pp_kernel<true, true>), dim3(G), dim3(Q_NT), lds, s, p, tiles_m, tiles_n, parts > 1 ? tiles - tail : tiles, parts, sk);
+      GROVE_LAUNCH_CHECK();
+      return GROVE_OK;
+    }
+  }
+  if constexpr (!GATHER) {
+    if (kb > 1) {
+      static bool attr_kb = false;
+      if (!attr_kb) {
+        hipFuncSetAttribute((const void*)gemm_tn_pp_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_kb = true;
+      }
+      hipLaunchKernelGGL((gemm_tn_pp_kernel<false, false, true>), dim3(G), dim3(Q_NT), lds, s, p, tiles_m, tiles_n, parts > 1 ? tiles - tail : tiles, parts, sk);
       GROVE_LAUNCH_CHECK();
       return GROVE_OK;
     }
@@ -740,6 +763,12 @@ extern "C" int grove_gemm_tn_bf16(const grove_gemm_tn_params* pp, void* stream) 
       if (split > 256) split = 256;
       if (split < 1) split = 1;
     }
+  }
+  if (p.k_batches > 1) {  // the K-batched form exists in the pipelined kernel only
+    GROVE_CHECK(!p.b_idx && p.b_taps == 1 && p.K % 64 == 0 && p.split_k <= 1 && p.ldc % 4 == 0 && p.M >= 8 && p.N >= 8 && p.sC_batch % 4 == 0 &&
+                    (long)p.k_batches * p.K < (1L << 31),
+                GROVE_E_SHAPE, "gemm_tn: k_batches needs plain operands (no b_idx / taps / split_k), K %% 64 == 0 and 16-byte aligned batch strides");
+    return launch_tn_pp<false>(p, (hipStream_t)stream);
   }
   if (grove_det_on()) split = 1;  // deterministic mode: whole-K tiles only (no fp32 atomics into C), here and in the pipelined kernel's tail
   // the persistent pipelined kernel: un-split problems with enough 256 x 256 tiles whose column tiles stay inside one tap

@@ -109,6 +109,11 @@ class SamEncoder:
         # the Conv3d adapters' row-gather table (conv3d_gather_index(F // 8, 8, g, g)) has no temporal neighbour before a group's first
         # and after its last frame: the promise that lets the GEMM planner skip those tap groups (grove_gemm_params.a_frame_rows)
         self.conv_frames = (d.sam_grid * d.sam_grid, 8)
+        # Round 6: the Conv3d adapters in Winograd F(2x2x2, 3x3x3) form (64 products per 2x2x2 output tile instead of 216: csrc/winograd.hip,
+        # DESIGN section 7d) — which of forward / dgrad / wgrad take it (GROVE_SAM_WINOGRAD = comma list, "0" = the 27-tap implicit GEMMs)
+        w = os.environ.get("GROVE_SAM_WINOGRAD", "fwd,dgrad,wgrad")
+        self.wino = set() if w in ("0", "") else set(w.split(","))
+        assert self.wino <= {"fwd", "dgrad", "wgrad"}, self.wino
 
     @property
     def _zero_row(self):
@@ -120,6 +125,7 @@ class SamEncoder:
         """alpha is read on device by the GEMM epilogue (fp32 scalar)."""
         for A in self.adapters:
             A["alpha_f32"] = A["alpha"].float().contiguous()
+            A.pop("U", None)  # (the cached Winograd transform of the weights follows them)
 
     def _indices(self, F):
         if not hasattr(self, "_pad"):
@@ -236,22 +242,40 @@ class SamEncoder:
             ctx = dict(x=x, mean=mean, rstd=rstd, qkv=qkv, actx=actx, x1=x1, mean2=mean2, rstd2=rstd2, pre=pre, nb=nb, L=L, qhw=qhw)
         return t2, ctx
 
+    def _wino_geom(self, rows, C):
+        """(groups, T, H, W) of the token tensor when the Winograd kernels take it (even T / H / W, whole 256-row GEMM tiles per transform
+        point, K tiles of 64 for both GEMMs), else None."""
+        g = self.d.sam_grid
+        if not self.wino or g % 2 or rows % (8 * g * g) or C % 64:
+            return None
+        geom = (rows // (8 * g * g), 8, g, g)
+        return geom if ops.wino3d_tiles(geom) % 256 == 0 else None
+
     def _adapter(self, A, res, t, conv_idx, save):
         """tanh(alpha) * relu(Conv3d(x) + b) + x (image_encoder.py:48-59) on the FP32 stream: the Conv3d reads the stream itself
         (gathered rows of the implicit GEMM), so its bf16 rounding x = bf16(res + t) is materialised; the adapter's own
-        contribution becomes the next pending branch output (its `+ x` is the stream)."""
-        if res.dtype != torch.float32:  # bf16 stream: `res` is x, the adapter's `+ x` rides in the GEMM epilogue
+        contribution becomes the next pending branch output (its `+ x` is the stream). Returns (y, (x, pre-activation, transformed input))."""
+        f32 = res.dtype == torch.float32
+        if f32:
+            x = torch.empty((res.shape[0], res.shape[1]), dtype=torch.bfloat16, device=self.dev)
+            ops.stream_add(res, t, res_bf16=x)
+        else:  # bf16 stream: `res` is x, the adapter's `+ x` rides in the epilogue
             x = res
-            pre = torch.empty_like(x) if save else None
-            y = ops.linear(x, A["w"], A["b"], act=ops.ACT_RELU, scale_ptr=A["alpha_f32"], scale_tanh=True, a_idx=conv_idx, a_taps=27,
-                           M=x.shape[0], residual=x, aux=pre, a_frames=self.conv_frames)
-            return y, (x, pre)
-        x = torch.empty((res.shape[0], res.shape[1]), dtype=torch.bfloat16, device=self.dev)
-        ops.stream_add(res, t, res_bf16=x)
         pre = torch.empty_like(x) if save else None
+        geom = self._wino_geom(x.shape[0], x.shape[1])
+        if geom is not None and "fwd" in self.wino:
+            U = A.get("U") if not self.train else None  # (inference: the weights are constants)
+            if U is None:
+                U = ops.wino3d_transform_weight(A["w"])
+                if not self.train:
+                    A["U"] = U
+            y = torch.empty_like(x)
+            _, V = ops.wino3d_conv(x, U, geom, y, bias=A["b"], act=ops.ACT_RELU, scale_ptr=A["alpha_f32"], scale_tanh=True,
+                                   residual=None if f32 else x, aux=pre, keep_V=save and "wgrad" in self.wino)
+            return y, (x, pre, V)
         y = ops.linear(x, A["w"], A["b"], act=ops.ACT_RELU, scale_ptr=A["alpha_f32"], scale_tanh=True, a_idx=conv_idx, a_taps=27,
-                       M=x.shape[0], aux=pre, a_frames=self.conv_frames)
-        return y, (x, pre)
+                       M=x.shape[0], residual=None if f32 else x, aux=pre, a_frames=self.conv_frames)
+        return y, (x, pre, None)
 
     def forward(self, images, save=False, upto=None, before_adapters=None):
         """images bf16 [B, 3, T, 512, 512] -> channels-last embeddings [F, g*g, 256] (the reference returns
@@ -377,8 +401,9 @@ class SamEncoder:
 
     def _adapter_bwd(self, A, actx, dy, conv_idx, need_dx):
         """y = tanh(alpha) * relu(conv(x) + b) + x. Accumulates dW (tap-major), db, dalpha; returns dx."""
-        x, pre = actx
+        x, pre, V = actx
         C = self.d.sam_dim
+        geom = self._wino_geom(x.shape[0], C)
         M = x.shape[0]
         g = self.grads
         name = A["name"]
@@ -393,7 +418,13 @@ class SamEncoder:
         # weight grad, tap-major: dW[co, tap, ci] = tanh(alpha) * sum_m (dy relu')[m, co] * x[gather(tap, m), ci]
         # one TN GEMM over the K-major operands with the per-tap row gather on x (no im2col, no transposes)
         gw = g[name + "conv3d.weight"].view(C, 27 * C)
-        if C % 128 == 0:
+        if geom is not None and "wgrad" in self.wino:
+            # Winograd form: per transform point dU = dM^T V (one K-batched TN GEMM over the 64 points, K = tiles), dW = G^T-transform of dU
+            if V is None:
+                V = ops.wino3d_transform_tokens(x, geom, 0)
+            ops.wino3d_wgrad(prod, V, geom, gw, scale_ptr=a, scale_tanh=True)
+            del V
+        elif C % 128 == 0:
             ops.wgrad(prod, x, gw, b_idx=conv_idx, b_taps=27, scale_ptr=a, scale_tanh=True, K=M, b_frames=self.conv_frames)
         else:  # tiny test dims: a 128-wide tile would straddle taps -> one launch per tap
             for tap in range(27):
@@ -408,6 +439,10 @@ class SamEncoder:
                 if wd is None or wd.shape != (C, 27 * C):
                     wd = A["w_d"] = torch.empty((C, 27 * C), dtype=torch.bfloat16, device=A["w"].device)
                 ops.transpose(A["w"], C, C, 27 * C, wd[:, 26 * C:], 27 * C, batch=(27, 1), s_in=(C, 0), s_out=(-C, 0))
-            dx = ops.linear(prod, A["w_d"], a_idx=conv_idx, a_taps=27, M=M, residual=dy, scale_ptr=a, scale_tanh=True,
-                            a_frames=self.conv_frames)  # (flipped taps: the first / last tap GROUP still pairs with the first / last frame)
+            if geom is not None and "dgrad" in self.wino:
+                dx = torch.empty_like(dy)
+                ops.wino3d_conv(prod, ops.wino3d_transform_weight(A["w_d"]), geom, dx, scale_ptr=a, scale_tanh=True, residual=dy)
+            else:
+                dx = ops.linear(prod, A["w_d"], a_idx=conv_idx, a_taps=27, M=M, residual=dy, scale_ptr=a, scale_tanh=True,
+                                a_frames=self.conv_frames)  # (flipped taps: the first / last tap GROUP still pairs with the first / last frame)
         return dx

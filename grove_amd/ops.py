@@ -133,9 +133,10 @@ def gemm_set_persistent_blocks(n: int):
 def gemm_raw(A, B, Cout, M, N, K, lda, ldb, ldc, *, bias=None, residual=None, ldr=0, aux=None, scale_ptr=None,
              scale_tanh=False, a_idx=None, a_taps=1, c_idx=None, r_idx=None, batch=(1, 1), sA=(0, 0), sB=(0, 0),
              sC=(0, 0), sR=(0, 0), act=ACT_NONE, accumulate=False, alpha=1.0, split_k=0, ld_aux=0, n_map=(0, 0), k_map=(0, 0),
-             aux_grad=False, residual_mul=False, a_frames=(0, 0)):
+             aux_grad=False, residual_mul=False, a_frames=(0, 0), b_group=(0, 0)):
     """Direct call of grove_gemm_bf16; A/B/Cout are tensors whose storage the pointers refer to.
-    a_frames = (rows per frame, frames per group): the temporal-padding promise about a_idx (grove_gemm_params.a_frame_rows)."""
+    a_frames = (rows per frame, frames per group): the temporal-padding promise about a_idx (grove_gemm_params.a_frame_rows).
+    b_group = (rows per group, elements between the groups' B matrices): grouped B (grove_gemm_params.b_group_rows)."""
     _chk_dev(A, B, Cout)
     if _pre_gemm_hook is not None:
         _pre_gemm_hook()
@@ -158,6 +159,7 @@ def gemm_raw(A, B, Cout, M, N, K, lda, ldb, ldc, *, bias=None, residual=None, ld
     p.n_group, p.n_pad = n_map
     p.k_group, p.k_pad = k_map
     p.a_frame_rows, p.a_frames = a_frames
+    p.b_group_rows, p.sB_group = b_group
     lib = _lib.lib()
     st = _stream()
     plan = _lib.GemmPlan()
@@ -191,21 +193,119 @@ def linear(x, w, bias=None, *, act=ACT_NONE, residual=None, out=None, out_dtype=
     return out
 
 
-def wgrad(dy, x, grad, *, b_idx=None, b_taps=1, scale_ptr=None, scale_tanh=False, alpha=1.0, split_k=0, K=None, b_frames=(0, 0)):
+def wgrad(dy, x, grad, *, b_idx=None, b_taps=1, scale_ptr=None, scale_tanh=False, alpha=1.0, split_k=0, K=None, b_frames=(0, 0),
+          k_batches=0, sC_batch=0, overwrite=False, M=None, N=None):
     """grad[M, N] (fp32) += alpha * dy[K, M]^T @ x[K, N]  (x rows optionally gathered per tap).
-    b_frames = (rows per frame, frames per group): the temporal-padding promise about b_idx (grove_gemm_tn_params.b_frame_rows)."""
+    b_frames = (rows per frame, frames per group): the temporal-padding promise about b_idx (grove_gemm_tn_params.b_frame_rows).
+    k_batches > 1: dy / x are k_batches stacked operands of K rows, batch b lands in grad + b * sC_batch elements (= instead of += with
+    `overwrite`); M / N then name one product's shape (grove_gemm_tn_params.k_batches)."""
     _chk_dev(dy, x, grad)
     if _pre_gemm_hook is not None:
         _pre_gemm_hook()
     p = _lib.GemmTnParams()
     p.A, p.B, p.C, p.scale_ptr, p.b_idx = _p(dy), _p(x), _p(grad), _p(scale_ptr), _p(b_idx)
-    p.M, p.N = grad.shape[0], grad.shape[1]
+    p.M, p.N = (grad.shape[0] if M is None else M), (grad.shape[1] if N is None else N)
     p.K = K if K is not None else dy.shape[0]
-    p.lda, p.ldb, p.ldc = dy.stride(0), x.stride(0), grad.stride(0)
+    p.k_batches, p.sC_batch, p.overwrite = int(k_batches), int(sC_batch), int(overwrite)
+    p.lda, p.ldb, p.ldc = dy.stride(-2), x.stride(-2), grad.stride(-2)
     p.b_taps, p.scale_tanh, p.split_k, p.alpha = b_taps, int(scale_tanh), split_k, float(alpha)
     p.b_frame_rows, p.b_frames = b_frames
     _lib.check(_lib.lib().grove_gemm_tn_bf16(C.byref(p), _stream()), "grove_gemm_tn_bf16")
     return grad
+
+
+# ---- Winograd F(2x2x2, 3x3x3) form of the Conv3d adapters (grove_hip.h "grove_wino3d_*"; image_encoder.py:43-59)
+def _wino_params(src, dst, geom, Cc):
+    p = _lib.Wino3dParams()
+    p.src, p.dst = _p(src), _p(dst)
+    p.groups, p.T, p.H, p.W = geom
+    p.C = Cc
+    p.alpha = 1.0
+    return p
+
+
+def wino3d_tiles(geom):
+    g, T, H, W = geom
+    return g * (T // 2) * (H // 2) * (W // 2)
+
+
+def wino3d_transform_tokens(x, geom, mode, out=None):
+    """x bf16 tokens [groups*T*H*W, C] -> bf16 [64, tiles, C]: mode 0 = input tiles (B^T), mode 1 = output-gradient tiles (A)."""
+    _chk_dev(x)
+    Cc = x.shape[1]
+    tiles = wino3d_tiles(geom)
+    assert x.shape[0] == geom[0] * geom[1] * geom[2] * geom[3] and x.dtype == bf16 and x.stride(1) == 1
+    if out is None:
+        out = torch.empty((64, tiles, Cc), dtype=bf16, device=x.device)
+    assert out.is_contiguous() and out.shape == (64, tiles, Cc)
+    p = _wino_params(x, out, geom, Cc)
+    p.ld_src, p.ld_dst, p.mode = x.stride(0), Cc, mode
+    _lib.check(_lib.lib().grove_wino3d_transform_tokens(C.byref(p), _stream()), "grove_wino3d_transform_tokens")
+    return out
+
+
+def wino3d_transform_weight(w, out=None):
+    """w bf16 [Co, 27 * Ci] (tap-major packed Conv3d weight) -> bf16 [64, Co, Ci]."""
+    _chk_dev(w)
+    Co, Ci = w.shape[0], w.shape[1] // 27
+    assert w.shape[1] == 27 * Ci and w.dtype == bf16 and w.stride(1) == 1
+    if out is None:
+        out = torch.empty((64, Co, Ci), dtype=bf16, device=w.device)
+    p = _wino_params(w, out, (0, 0, 0, 0), Ci)
+    p.rows, p.ld_src, p.ld_dst = Co, w.stride(0), Ci
+    _lib.check(_lib.lib().grove_wino3d_transform_weight(C.byref(p), _stream()), "grove_wino3d_transform_weight")
+    return out
+
+
+def wino3d_output(Mh, geom, out, *, bias=None, act=ACT_NONE, scale_ptr=None, scale_tanh=False, residual=None, aux=None):
+    """Mh bf16 [64, tiles, C] -> out tokens: act((A^T..) Mh + bias) * scale + residual; aux = the pre-activation."""
+    _chk_dev(Mh, out)
+    Cc = Mh.shape[2]
+    assert Mh.is_contiguous() and Mh.shape[:2] == (64, wino3d_tiles(geom)) and out.shape == (geom[0] * geom[1] * geom[2] * geom[3], Cc)
+    p = _wino_params(Mh, out, geom, Cc)
+    p.bias, p.residual, p.aux, p.scale_ptr = _p(bias), _p(residual), _p(aux), _p(scale_ptr)
+    p.ld_src, p.ld_dst = Cc, out.stride(0)
+    p.ld_res = residual.stride(0) if residual is not None else 0
+    p.ld_aux = aux.stride(0) if aux is not None else 0
+    p.act, p.scale_tanh = act, int(scale_tanh)
+    _lib.check(_lib.lib().grove_wino3d_output(C.byref(p), _stream()), "grove_wino3d_output")
+    return out
+
+
+def wino3d_wgrad_output(dU, gw, *, scale_ptr=None, scale_tanh=False):
+    """gw f32 [Co, 27 * Ci] += scale * (G^T..) dU, dU f32 [64, Co, Ci]."""
+    _chk_dev(dU, gw)
+    _, Co, Ci = dU.shape
+    assert dU.is_contiguous() and dU.dtype == torch.float32 and gw.dtype == torch.float32 and gw.shape == (Co, 27 * Ci) and gw.stride(1) == 1
+    p = _wino_params(dU, gw, (0, 0, 0, 0), Ci)
+    p.scale_ptr, p.scale_tanh = _p(scale_ptr), int(scale_tanh)
+    p.rows, p.ld_src, p.ld_dst = Co, Ci, gw.stride(0)
+    _lib.check(_lib.lib().grove_wino3d_wgrad_output(C.byref(p), _stream()), "grove_wino3d_wgrad_output")
+    return gw
+
+
+def wino3d_conv(x, U, geom, out, *, bias=None, act=ACT_NONE, scale_ptr=None, scale_tanh=False, residual=None, aux=None, V=None, keep_V=False):
+    """out = epilogue(Conv3d 3x3x3 'same' of the token tensor x with the TRANSFORMED weights U [64, Co, Ci]) — transform, ONE grouped GEMM
+    over the 64 transform points, output transform. Returns (out, V) with V the transformed input when keep_V (the weight gradient reads it)."""
+    tiles = wino3d_tiles(geom)
+    Co, Ci = U.shape[1], U.shape[2]
+    if V is None:
+        V = wino3d_transform_tokens(x, geom, 0)
+    Mh = torch.empty((64, tiles, Co), dtype=bf16, device=x.device)
+    gemm_raw(V, U, Mh, 64 * tiles, Co, Ci, Ci, Ci, Co, b_group=(tiles, Co * Ci))
+    wino3d_output(Mh, geom, out, bias=bias, act=act, scale_ptr=scale_ptr, scale_tanh=scale_tanh, residual=residual, aux=aux)
+    return out, (V if keep_V else None)
+
+
+def wino3d_wgrad(dz, V, geom, gw, *, scale_ptr=None, scale_tanh=False):
+    """gw f32 [Co, 27 Ci] += scale * dW of the Conv3d, from the output gradient dz (tokens [rows, Co]) and the transformed input V [64, tiles, Ci]:
+    per transform point dU = dM^T V as ONE K-batched TN GEMM, then the G^T transform."""
+    tiles = wino3d_tiles(geom)
+    Co, Ci = dz.shape[1], V.shape[2]
+    dM = wino3d_transform_tokens(dz, geom, 1)
+    dU = torch.empty((64, Co, Ci), dtype=torch.float32, device=dz.device)
+    wgrad(dM, V, dU, K=tiles, k_batches=64, sC_batch=Co * Ci, overwrite=True, M=Co, N=Ci)
+    return wino3d_wgrad_output(dU, gw, scale_ptr=scale_ptr, scale_tanh=scale_tanh)
 
 
 def gemm_set_tile_n(n: int):

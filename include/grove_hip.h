@@ -133,6 +133,12 @@ typedef struct grove_gemm_params {
    * the temporal zero padding). Those tiles then run 2/3 of the K range; whole tiles stay bit-identical (the skipped products only
    * ever added +0.0), a stream-K tail is cut at other K tiles (deterministic, different fp32 sum order). 0 / 0 = no promise. */
   int32_t a_frame_rows, a_frames;
+  /* Grouped B (round 6; the plain pipelined kernel with 256-row tiles only — the Winograd form of the Conv3d adapters, see
+   * grove_wino3d_*): the M rows are groups of b_group_rows rows (a multiple of 256) and group g multiplies its own weight matrix
+   * B + g * sB_group (elements; [N, ldb] each). One launch for the 64 independent [tiles, C] x [C, C] products of the 64
+   * transform points. 0 = off. Needs a_idx NULL, no batch, no split, bf16 C. */
+  int32_t b_group_rows, reserved0;
+  int64_t sB_group;
 } grove_gemm_params;
 
 /* Workspaces of the persistent GEMMs (`grove_<op>_workspace_bytes` + `workspace, ws_bytes` arguments).
@@ -241,6 +247,14 @@ typedef struct grove_gemm_tn_params {
    * the last group when k lies in the last frame. Those K tiles are skipped (1 / b_frames of the K range of two thirds of the output
    * tiles) and the full tiles are dealt first. Whole tiles stay bit-identical. 0 / 0 = no promise. */
   int32_t b_frame_rows, b_frames;
+  /* K-batched form (round 6; the pipelined kernel only — the Winograd weight gradient, see grove_wino3d_*): A and B are k_batches
+   * stacked operands of K rows each ([k_batches * K, ld]) and batch b accumulates its own product into C + b * sC_batch
+   * (elements; [M, ldc] each): sum_k A[b K + k, m] * B[b K + k, n]. One launch for the 64 transform points (64 x the output
+   * tiles of one product fill the chip where one product's 25 tiles cannot). 0 / 1 = off. Needs b_idx NULL, K % 64 == 0.
+   * overwrite (K-batched form only): C = f * product instead of C += (every tile whole: no cut tail, fixed sum order) — the
+   * transform-point sums are temporaries, and zero-filling 64 x [M, N] fp32 first would cost a pass of its own. */
+  int32_t k_batches, overwrite;
+  int64_t sC_batch;
 } grove_gemm_tn_params;
 int grove_gemm_tn_bf16(const grove_gemm_tn_params* p, void* stream);
 /* kernel choice of grove_gemm_tn_bf16: -1 = auto (default), 0 = the 128 x 128 kernel always, 1 = the persistent pipelined
@@ -710,6 +724,43 @@ int grove_gemm_fp8(const grove_gemm_fp8_params* p, const grove_gemm_workspace* w
 int grove_gemm_fp8_set_pipelined(int on);
 /* x bf16 [rows, ld_x] -> q e4m3 [rows, ld_q] with one scale per row: scale = amax / 448 (1 for a zero row), q = x / scale */
 int grove_quant_fp8_rows(const void* x, void* q, float* scale, int32_t rows, int32_t K, int32_t ld_x, int32_t ld_q, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Winograd F(2 x 2 x 2, 3 x 3 x 3) form of the Conv3d adapters (round 6): the memory-bound transforms either side of the grouped
+ * / K-batched GEMMs (grove_gemm_params.b_group_rows, grove_gemm_tn_params.k_batches). Replaces the 27-tap implicit GEMMs of
+ * SpatioTemporalConvAdapter (image_encoder.py:43-59: nn.Conv3d(C, C, 3, padding = 1) on '(b t) h w c -> b c t h w', t = 8) with
+ * 64 products per 2 x 2 x 2 output tile instead of 216. fp32 arithmetic; transformed operands are rounded to bf16 once.
+ *   tokens: bf16 rows [(g, t, y, x)][ld] = ((g T + t) H + y) W + x, groups of T frames of H x W positions; T, H, W even.
+ *   tile (g, tt, ty, tx) = outputs (2 tt + {0, 1}, 2 ty + {0, 1}, 2 tx + {0, 1}); tile id = ((g T/2 + tt) H/2 + ty) W/2 + tx.
+ *   transformed tensors: POINT-MAJOR [64][tiles or rows][ld], point = (a 4 + b) 4 + c over (t, y, x).
+ * grove_wino3d_transform_tokens  mode 0: dst bf16 [64][tiles][ld_dst] = (B^T (x) B^T (x) B^T) of the zero-padded 4 x 4 x 4 input
+ *                                tiles of src (tokens); mode 1: = (A (x) A (x) A) of the 2 x 2 x 2 tiles of src (the output gradient).
+ * grove_wino3d_transform_weight  src bf16 [rows = Co][27 taps][C = Ci] (tap = (kt 3 + kh) 3 + kw, ld_src >= 27 C) ->
+ *                                dst bf16 [64][rows][ld_dst] = (G (x) G (x) G) per (co, ci).
+ * grove_wino3d_output            src bf16 [64][tiles][ld_src] (the products) -> dst tokens: v = (A^T (x) A^T (x) A^T) src + bias;
+ *                                aux = bf16(v) (optional pre-activation copy); dst = act(v) * f + residual, act NONE / RELU,
+ *                                f = alpha * (scale_ptr ? (scale_tanh ? tanh(*scale_ptr) : *scale_ptr) : 1).
+ * grove_wino3d_wgrad_output      src f32 [64][rows = Co][ld_src] (sum over tiles of dM (.) V per point) ->
+ *                                dst f32 [rows][27][C] += f * (G^T (x) G^T (x) G^T) src.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct grove_wino3d_params {
+  const void* src;
+  void* dst;
+  const void* bias;        /* bf16 [C] or NULL (output) */
+  const void* residual;    /* bf16 tokens [*, ld_res] or NULL (output) */
+  void* aux;               /* bf16 tokens [*, ld_aux] or NULL (output) */
+  const float* scale_ptr;  /* device scalar or NULL (output, wgrad_output) */
+  int32_t groups, T, H, W; /* token geometry (transform_tokens, output) */
+  int32_t C;               /* channels per row (even) */
+  int32_t rows;            /* weight rows = output channels (transform_weight, wgrad_output) */
+  int32_t ld_src, ld_dst, ld_res, ld_aux; /* row strides in elements (even) */
+  int32_t mode, act, scale_tanh;
+  float alpha;             /* 0 is NOT special: pass 1 for "no scale" */
+} grove_wino3d_params;
+int grove_wino3d_transform_tokens(const grove_wino3d_params* p, void* stream);
+int grove_wino3d_transform_weight(const grove_wino3d_params* p, void* stream);
+int grove_wino3d_output(const grove_wino3d_params* p, void* stream);
+int grove_wino3d_wgrad_output(const grove_wino3d_params* p, void* stream);
 
 /* Box + temporal-objectness heads in fp32 (mask_decoder.py:80-84,198-203): x f32 [N, D];
  * box = sigmoid(W2 relu(W1 x + b1) + b2) [N,4]; obj = Wo x + bo [N]. Weights bf16.

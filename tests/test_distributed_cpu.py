@@ -156,6 +156,91 @@ def test_three_rank_sparse_rows_sum_in_rank_order_on_every_replica():
         assert torch.equal(out[r]["a2a"], out[0]["a2a"])
 
 
+def _worker8(rank, world, port, out):
+    """World 8 = the size of the one run that matters (train_scripts/train_howtoground.sh:20-28: 8 ranks per node; train.py:453,
+    466-486). Every exchange arm on both wires over a flat buffer whose length is NOT a multiple of world x bucket, groups handed
+    over out of order, the touched-row path with row counts uneven over the ranks (two ranks touch nothing), shard_clips."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from grove_amd.train import GradExchange, allreduce_buckets, shard_clips
+    res = {}
+    n = 3 * 8 * 96 + 517  # three whole rounds of 8-rank buckets + a ragged remainder that is odd (all-reduce fallback of the tail)
+    mult = sum(r + 1 for r in range(world))
+    g = torch.arange(n, dtype=torch.float32) * (rank + 1)
+    allreduce_buckets(g, 96)
+    res["plain"] = bool(torch.equal(g, torch.arange(n, dtype=torch.float32) * mult))
+    for mode in ("allreduce", "rs_ag", "a2a_f32"):
+        for wire in (torch.bfloat16, torch.float32):
+            base = torch.randn(n, generator=torch.Generator().manual_seed(23))
+            flat = base * (rank + 1)
+            ex = GradExchange(flat, world, 96 * 8, comm_dtype=wire, mode=mode)
+            assert ex.bucket % world == 0
+            ex.ready(2000, n)     # ragged tail first (the "decoder" group)
+            ex.ready(301, 1203)   # neither end on a bucket boundary
+            done = ex.finish()
+            assert sorted(done) == [(0, 301), (301, 1203), (1203, 2000), (2000, n)], done
+            if wire == torch.float32:
+                ok = torch.allclose(flat, base * mult, rtol=2e-6, atol=0)
+            else:  # a sum of 8 bf16-rounded contributions, running sums rounded to bf16 by the ring forms: <= 8 half-ulps of the result
+                want = sum((base * (r + 1)).to(torch.bfloat16).float() for r in range(world))
+                ok = (flat - want).abs().max().item() <= want.abs().max().item() * 8 * 2 ** -8
+            res[f"{mode}/{wire}"] = (bool(ok), flat.clone())
+    # fp32 accumulation of the bf16 wire is EXACT: the sum of the 8 rounded contributions in fp32, rounded once
+    base = torch.randn(8 * 96 * 2, generator=torch.Generator().manual_seed(29))
+    flat = base * (rank + 1)
+    ex = GradExchange(flat, world, 96 * 8, comm_dtype=torch.bfloat16, mode="a2a_f32")
+    ex.finish()
+    want = sum((base * (r + 1)).to(torch.bfloat16).float() for r in range(world)).to(torch.bfloat16).float()
+    res["a2a_exact"] = bool(torch.equal(flat, want))
+    # touched rows: rank r touches r % 4 rows (ranks 0 and 4: none) of a [40, 4] table, ids overlapping between ranks
+    H, V = 4, 40
+    for wire in (torch.float32, torch.bfloat16):
+        flat = torch.zeros(8 + V * H + 8)
+        flat[:8] = 1.0
+        flat[8 + V * H:] = float(rank)
+        ex = GradExchange(flat, world, 64, comm_dtype=wire, mode="allreduce")
+        my_ids = torch.tensor([(5 * rank + 3 * j) % V for j in range(rank % 4)], dtype=torch.int32)
+        ex.sparse_begin(my_ids.numel())
+        K = ex.sparse_kmax()
+        assert K == 3
+        rows = torch.zeros(K, H)
+        rows[:my_ids.numel()] = float(rank + 1)
+        ids = torch.full((K,), -1, dtype=torch.int32)
+        ids[:my_ids.numel()] = my_ids
+        ex.sparse_rows(ids, rows, 8, 8 + V * H, H)
+        ex.finish()
+        want = torch.zeros(V, H)
+        for r in range(world):
+            for j in range(r % 4):
+                want[(5 * r + 3 * j) % V] += float(r + 1)
+        res[f"rows/{wire}"] = (bool(torch.equal(flat[8:8 + V * H].view(V, H), want) and torch.equal(flat[:8], torch.full((8,), float(world)))
+                                    and torch.equal(flat[8 + V * H:], torch.full((8,), float(sum(range(world)))))), flat.clone())
+    res["shards"] = {n_: shard_clips(n_, rank, world) for n_ in (7, 8, 9, 64)}
+    out[rank] = res
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_rank_gradient_exchange_rows_and_sharding():
+    world, port = 8, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker8, args=(world, port, out), nprocs=world, join=True)
+    for r in range(world):
+        res = out[r]
+        assert res["plain"] and res["a2a_exact"], r
+        for k, v in res.items():
+            if isinstance(v, tuple):
+                assert v[0], (r, k)
+                assert torch.equal(v[1], out[0][k][1]), (r, k)  # every replica holds the same bits
+    for n_ in (7, 8, 9, 64):
+        parts = [out[r]["shards"][n_] for r in range(world)]
+        per = (n_ + world - 1) // world
+        assert all(len(p) == per for p in parts)
+        flat = sorted(i for p in parts for i in p)
+        assert set(flat) == set(range(n_)) and len(flat) == per * world  # every clip at least once, padding by wrap-around
+
+
 def test_warmup_decay_lr():
     from grove_amd.train import WarmupDecayLR
     s = WarmupDecayLR(3e-4, 1000, 100)
