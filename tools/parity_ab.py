@@ -1,5 +1,6 @@
-"""Which of the round-4 LLaMA changes moves the deep-narrow training parity figures, and by how much?  (one subprocess per arm: the
-switches are read at import)   python tools/parity_ab.py [--outliers 1000] -> gpurun_out/parity_ab.json"""
+"""Which of the round-4 LLaMA changes (round 6: which form of the SAM Conv3d adapters) moves the deep-narrow training parity figures, and by
+how much?  (one subprocess per arm: the switches are read at import)   python tools/parity_ab.py [--outliers 1000] [--arms ...] [--seeds ...]
+[--out name] -> gpurun_out/<name>.json"""
 import argparse
 import json
 import os
@@ -11,7 +12,9 @@ ARMS = {"all_off": dict(GROVE_LLAMA_TAIL="0", GROVE_ROPE_TABLE="0", GROVE_FUSE_R
         "tail": dict(GROVE_LLAMA_TAIL="1", GROVE_ROPE_TABLE="0", GROVE_FUSE_ROPE_BWD="0"),
         "table": dict(GROVE_LLAMA_TAIL="0", GROVE_ROPE_TABLE="1", GROVE_FUSE_ROPE_BWD="0"),
         "fuse": dict(GROVE_LLAMA_TAIL="0", GROVE_ROPE_TABLE="0", GROVE_FUSE_ROPE_BWD="1"),
-        "all_on": dict(GROVE_LLAMA_TAIL="1", GROVE_ROPE_TABLE="1", GROVE_FUSE_ROPE_BWD="1")}
+        "all_on": dict(GROVE_LLAMA_TAIL="1", GROVE_ROPE_TABLE="1", GROVE_FUSE_ROPE_BWD="1"),
+        # round 6: the SAM Conv3d adapters as 27-tap implicit GEMMs / in Winograd F(2x2x2, 3x3x3) form, everything else at its default
+        "conv_direct": dict(GROVE_SAM_WINOGRAD="0"), "conv_wino_wgrad": dict(GROVE_SAM_WINOGRAD="wgrad"), "conv_winograd": dict(GROVE_SAM_WINOGRAD="fwd,dgrad,wgrad")}
 
 CHILD = r"""
 import json, sys, torch
@@ -28,6 +31,7 @@ def main():
     ap.add_argument("--outliers", type=float, nargs="*", default=[0.0, 1000.0])
     ap.add_argument("--arms", nargs="*", default=list(ARMS))
     ap.add_argument("--seeds", type=int, nargs="*", default=[11])
+    ap.add_argument("--out", default="parity_ab")
     a = ap.parse_args()
     out = {}
     for o in a.outliers:
@@ -40,7 +44,7 @@ def main():
             out[key] = json.loads(line[0][7:]) if line else {"error": p.stderr[-800:]}
             print(key, json.dumps(out[key])[:300], flush=True)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "parity_ab.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", a.out + ".json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
