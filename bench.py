@@ -73,7 +73,7 @@ def instrumented_gemm_pass(engine, batch):
         r = orig(A, B, C, M, N, K, *a, **k)
         e1.record()
         b = k.get("batch", (1, 1))
-        grouped = bool(k.get("b_group", (0, 0))[0])
+        grouped = bool(k.get("b_group", 0))
         recs.append((e0, e1, 2.0 * M * N * K * b[0] * b[1], (M, N, K, b[0] * b[1], k.get("a_taps", 1)),
                      kernel_name(grouped)))
         if grouped:
@@ -728,7 +728,7 @@ def main():
     ap.add_argument("--clips_per_batch", type=int, default=8, help="--mode infer_iground: clips decoded together (1 = the reference's batch-1 form)")
     ap.add_argument("--max_new_tokens", type=int, default=64, help="--mode infer_iground: greedy tokens per clip (infer_iground.py:192)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"], help="--mode infer: linear layers of the CLIP tower and the LLaMA stack")
-    ap.add_argument("--fp8_policy", default="det16_kv16_clip16", choices=["all", "det16_kv16", "det16_kv16_clip16"],
+    ap.add_argument("--fp8_policy", default="sam_mlp", choices=["sam_mlp", "all", "det16_kv16", "det16_kv16_clip16"],
                     help="--mode infer --dtype fp8: which GEMMs / rows stay bf16 (DESIGN section 8; _clip16 = the CLIP tower in bf16)")
     ap.add_argument("--exchange", default="auto", choices=["auto", "allreduce", "rs_ag", "a2a_f32"],
                     help="N > 1: one all-reduce per gradient bucket, reduce-scatter + all-gather per bucket, or all-to-all + fp32 sum + all-gather; "

@@ -25,7 +25,7 @@ class GemmParams(C.Structure):
                 ("batch1", c_i32), ("batch2", c_i32), ("a_taps", c_i32), ("act", c_i32),
                 ("c_dtype", c_i32), ("accumulate", c_i32), ("scale_tanh", c_i32), ("alpha", c_f32), ("split_k", c_i32), ("ld_aux", c_i32),
                 ("n_group", c_i32), ("n_pad", c_i32), ("k_group", c_i32), ("k_pad", c_i32), ("aux_grad", c_i32), ("residual_mul", c_i32),
-                ("a_frame_rows", c_i32), ("a_frames", c_i32), ("b_group_rows", c_i32), ("reserved0", c_i32), ("sB_group", c_i64)]
+                ("a_frame_rows", c_i32), ("a_frames", c_i32), ("b_group_rows", c_i32)]
 
 
 class TransposeParams(C.Structure):

@@ -138,9 +138,11 @@ class GROVEForCausalLM(torch.nn.Module):
         self.stream_dtype = kwargs.get("stream_dtype", None)  # None: fp32 for inference models, bf16 for training models
         # "bf16" (default) or "fp8": the linear layers of the CLIP tower and the LLaMA stack on the e4m3 MFMA GEMM (config 5; inference)
         self.gemm_dtype = kwargs.get("gemm_dtype", "bf16")
-        # which GEMMs / rows stay bf16 under gemm_dtype="fp8": [DET] rows + k / v projections of LLaMA, and (round 4, default) the CLIP tower —
-        # 0.5 % of config 5's frames/s for 6.3e-3 -> 4.6e-3 box L1, and 1.8e-2 -> 9.6e-4 when the stream carries massive activations
-        self.fp8_policy = kwargs.get("fp8_policy", "det16_kv16_clip16")
+        # which GEMMs run in e4m3 under gemm_dtype="fp8". Default (round 6): "sam_mlp" — the SAM tower's mlp.lin1 / lin2 only (the policy
+        # that keeps the boxes inside 1e-3; see _build_engines). The LLaMA policies ("all", "det16_kv16": [DET] rows + k / v projections in
+        # bf16, "..._clip16": the CLIP tower in bf16 too) carry their own 5e-3 .. 1e-2 tolerance and stay as fenced options.
+        self.fp8_policy = kwargs.get("fp8_policy", "sam_mlp")
+        assert self.fp8_policy in ("sam_mlp", "all", "det16_kv16", "all_clip16", "det16_kv16_clip16"), self.fp8_policy
         self.dev = torch.device(device)
         if self.dev.type != "cuda":
             raise RuntimeError("grove_amd runs on MI355X only: there is no CPU path (use oracle/ for a CPU check)")
@@ -288,10 +290,14 @@ class GROVEForCausalLM(torch.nn.Module):
             raise ValueError("gemm_dtype='fp8' is an inference configuration (BASELINE config 5): build the model with train=False")
         # "<policy>_clip16" keeps the CLIP tower's GEMMs in bf16 (round 4: with massive-activation channels in the LLaMA stream the e4m3
         # error of the VISUAL TOKENS is what reaches the boxes — tools/fp8_policy_study.py --outliers, profiles/r04_fp8_outlier_policy_study_*)
+        # "sam_mlp" (round 6; the fp8 DEFAULT): only the SAM tower's mlp.lin1 / lin2 in e4m3, CLIP and LLaMA in bf16 — the one policy whose
+        # boxes stay inside the bf16 path's 1e-3 (tools/fp8_policy_study.py --sam: 9.0e-4 against 7.1e-4 for bf16)
+        sam_mlp = fp8 and self.fp8_policy == "sam_mlp"
         clip16 = self.fp8_policy.endswith("_clip16")
-        self.clip = ClipTower(sd, d, dev, fp32_stream=f32s, fp8=fp8 and not clip16)
-        self.llama = LlamaStack(sd, d, dev, train=tr, fp32_stream=f32s, fp8=fp8, fp8_policy=self.fp8_policy[:-7] if clip16 else self.fp8_policy)
-        self.sam = SamEncoder(sd, d, dev, train=tr, grads=self._grad, fp32_stream=f32s)
+        self.clip = ClipTower(sd, d, dev, fp32_stream=f32s, fp8=fp8 and not clip16 and not sam_mlp)
+        self.llama = LlamaStack(sd, d, dev, train=tr, fp32_stream=f32s, fp8=fp8 and not sam_mlp,
+                                fp8_policy="det16_kv16" if sam_mlp else (self.fp8_policy[:-7] if clip16 else self.fp8_policy))
+        self.sam = SamEncoder(sd, d, dev, train=tr, grads=self._grad, fp32_stream=f32s, fp8_mlp=sam_mlp)
         self.decoder = BoxDecoder(sd, d, dev, grads=self._grad, pe_dtype=self.pe_dtype)
 
     def P(self, name):
@@ -490,7 +496,7 @@ class GROVEForCausalLM(torch.nn.Module):
             # the tail is at most half the sequence, LlamaStack runs its last layer's queries / MLP on positions >= s0 only and returns
             # the compact [B * (S - s0), H] rows; the row tables below index that layout.
             hp.tail_start = 0
-            if self.llama_tail and not self.llama.fp32_stream and self.gemm_dtype != "fp8" and (int(ti.numel()) or int(det_rows.numel())):
+            if self.llama_tail and not self.llama.fp32_stream and not self.llama.fp8 and (int(ti.numel()) or int(det_rows.numel())):
                 cand = ([int(ti.min())] if int(ti.numel()) else []) + ([int((det_rows % S).min())] if int(det_rows.numel()) else [])
                 s0 = min(cand)
                 if s0 > 0 and (S - s0) * 2 <= S:
@@ -579,7 +585,7 @@ class GROVEForCausalLM(torch.nn.Module):
         self.wait_weights()
         x = self._embed(plan, feats.data)
         hidden, llama_ctx = self.llama.forward(x, plan.B, plan.S, kv_len=plan.kv_len, save=train,
-                                               precise_rows=det_rows if self.gemm_dtype == "fp8" else None,
+                                               precise_rows=det_rows if self.llama.fp8 else None,
                                                tail_start=hp.tail_start or None)
         tail = hidden.shape[0] != plan.B * plan.S  # the last layer ran on the tail rows only: `hidden` is [B * (S - s0), H]
         assert tail == bool(hp.tail_start), (tail, hp.tail_start)

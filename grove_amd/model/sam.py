@@ -43,7 +43,12 @@ def _rcat_tables(size, rel_pos_h, rel_pos_w, hd, hp, alpha):
 
 
 class SamEncoder:
-    def __init__(self, sd, d, device, train=False, grads=None, fp32_stream=None):
+    def __init__(self, sd, d, device, train=False, grads=None, fp32_stream=None, fp8_mlp=False):
+        """fp8_mlp (round 6, fp8_policy "sam_mlp": BASELINE config 5): mlp.lin1 (+ GELU) and mlp.lin2 of every block — two thirds of the tower's
+        GEMM FLOPs, plain token-order [rows, 1280 <-> 5120] products — on the e4m3 MFMA GEMM (per-output-channel weight scales made here,
+        per-row activation scales on the fly); qkv / proj and everything else stay bf16. Inference only."""
+        assert not (fp8_mlp and train), "the fp8 path is inference-only"
+        self.fp8_mlp = fp8_mlp
         self.d, self.dev, self.train = d, device, train
         self.fp32_stream = (not train) if fp32_stream is None else fp32_stream
         self.grads = grads  # name -> f32 gradient accumulator (trainable adapters)
@@ -84,6 +89,10 @@ class SamEncoder:
                 Bk["wproj_c"] = sd[p + "attn.proj.weight"].to(bf).contiguous()
             Bk["Rcat"], Bk["RcatT"], Bk["khp"], Bk["rel_ld"] = _rcat_tables(size, sd[p + "attn.rel_pos_h"], sd[p + "attn.rel_pos_w"],
                                                                              hd, hp, hd ** -0.5)
+            if fp8_mlp:
+                for k in ("w1", "w2"):
+                    if Bk[k].shape[1] % 128 == 0:  # (the fp8 GEMM's 128-byte K tile)
+                        Bk[k + "_q"] = ops.quant_fp8_rows(Bk[k].contiguous())
             if train and i >= self.first_bwd_block:
                 for k in ("wqkv", "wproj", "w1", "w2") + (("wqkv_c", "wproj_c") if Bk["maps"] else ()):
                     Bk[k + "_t"] = ops.transpose2d(Bk[k])
@@ -236,8 +245,14 @@ class SamEncoder:
         pre = torch.empty((rows, 4 * C), dtype=torch.bfloat16, device=self.dev) if save else None
         # backward needs only gelu'(lin1(.)) (the block's weights are frozen: no weight gradient reads the pre-activation), so the
         # GEMM stores the derivative and the backward's lin2 dgrad multiplies by it in its epilogue — no elementwise pass
-        f = ops.linear(h2, Bk["w1"], Bk["b1"], act=ops.ACT_GELU, aux=pre, aux_grad=True)
-        t2 = ops.linear(f, Bk["w2"], Bk["b2"], residual=None if f32 else x1)  # bf16 stream: t2 is the new stream x2
+        if "w1_q" in Bk and not save:
+            f = ops.linear_fp8(h2, Bk["w1_q"][0], Bk["w1_q"][1], Bk["b1"], act=ops.ACT_GELU)
+        else:
+            f = ops.linear(h2, Bk["w1"], Bk["b1"], act=ops.ACT_GELU, aux=pre, aux_grad=True)
+        if "w2_q" in Bk and not save:
+            t2 = ops.linear_fp8(f, Bk["w2_q"][0], Bk["w2_q"][1], Bk["b2"], residual=None if f32 else x1)
+        else:
+            t2 = ops.linear(f, Bk["w2"], Bk["b2"], residual=None if f32 else x1)  # bf16 stream: t2 is the new stream x2
         if save:
             ctx = dict(x=x, mean=mean, rstd=rstd, qkv=qkv, actx=actx, x1=x1, mean2=mean2, rstd2=rstd2, pre=pre, nb=nb, L=L, qhw=qhw)
         return t2, ctx

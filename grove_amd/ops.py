@@ -133,10 +133,10 @@ def gemm_set_persistent_blocks(n: int):
 def gemm_raw(A, B, Cout, M, N, K, lda, ldb, ldc, *, bias=None, residual=None, ldr=0, aux=None, scale_ptr=None,
              scale_tanh=False, a_idx=None, a_taps=1, c_idx=None, r_idx=None, batch=(1, 1), sA=(0, 0), sB=(0, 0),
              sC=(0, 0), sR=(0, 0), act=ACT_NONE, accumulate=False, alpha=1.0, split_k=0, ld_aux=0, n_map=(0, 0), k_map=(0, 0),
-             aux_grad=False, residual_mul=False, a_frames=(0, 0), b_group=(0, 0)):
+             aux_grad=False, residual_mul=False, a_frames=(0, 0), b_group=0):
     """Direct call of grove_gemm_bf16; A/B/Cout are tensors whose storage the pointers refer to.
     a_frames = (rows per frame, frames per group): the temporal-padding promise about a_idx (grove_gemm_params.a_frame_rows).
-    b_group = (rows per group, elements between the groups' B matrices): grouped B (grove_gemm_params.b_group_rows)."""
+    b_group = rows per group: grouped B, the groups' [N, ldb] matrices stacked in B (grove_gemm_params.b_group_rows)."""
     _chk_dev(A, B, Cout)
     if _pre_gemm_hook is not None:
         _pre_gemm_hook()
@@ -159,7 +159,7 @@ def gemm_raw(A, B, Cout, M, N, K, lda, ldb, ldc, *, bias=None, residual=None, ld
     p.n_group, p.n_pad = n_map
     p.k_group, p.k_pad = k_map
     p.a_frame_rows, p.a_frames = a_frames
-    p.b_group_rows, p.sB_group = b_group
+    p.b_group_rows = int(b_group)
     lib = _lib.lib()
     st = _stream()
     plan = _lib.GemmPlan()
@@ -292,7 +292,7 @@ def wino3d_conv(x, U, geom, out, *, bias=None, act=ACT_NONE, scale_ptr=None, sca
     if V is None:
         V = wino3d_transform_tokens(x, geom, 0)
     Mh = torch.empty((64, tiles, Co), dtype=bf16, device=x.device)
-    gemm_raw(V, U, Mh, 64 * tiles, Co, Ci, Ci, Ci, Co, b_group=(tiles, Co * Ci))
+    gemm_raw(V, U, Mh, 64 * tiles, Co, Ci, Ci, Ci, Co, b_group=tiles)
     wino3d_output(Mh, geom, out, bias=bias, act=act, scale_ptr=scale_ptr, scale_tanh=scale_tanh, residual=residual, aux=aux)
     return out, (V if keep_V else None)
 

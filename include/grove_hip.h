@@ -134,11 +134,11 @@ typedef struct grove_gemm_params {
    * ever added +0.0), a stream-K tail is cut at other K tiles (deterministic, different fp32 sum order). 0 / 0 = no promise. */
   int32_t a_frame_rows, a_frames;
   /* Grouped B (round 6; the plain pipelined kernel with 256-row tiles only — the Winograd form of the Conv3d adapters, see
-   * grove_wino3d_*): the M rows are groups of b_group_rows rows (a multiple of 256) and group g multiplies its own weight matrix
-   * B + g * sB_group (elements; [N, ldb] each). One launch for the 64 independent [tiles, C] x [C, C] products of the 64
-   * transform points. 0 = off. Needs a_idx NULL, no batch, no split, bf16 C. */
-  int32_t b_group_rows, reserved0;
-  int64_t sB_group;
+   * grove_wino3d_*): the M rows are groups of b_group_rows rows (a multiple of 256) and group g multiplies its own weight matrix,
+   * the g-th of M / b_group_rows matrices [N, ldb] stacked in B (group g at B + g * N * ldb elements). One launch for the 64
+   * independent [tiles, C] x [C, C] products of the 64 transform points. 0 = off. Needs a_idx NULL, no batch, no split, bf16 C.
+   * (One int32 in what was the struct's tail padding: sizeof(grove_gemm_params) is what it was in round 5.) */
+  int32_t b_group_rows;
 } grove_gemm_params;
 
 /* Workspaces of the persistent GEMMs (`grove_<op>_workspace_bytes` + `workspace, ws_bytes` arguments).
@@ -719,7 +719,7 @@ typedef struct grove_gemm_fp8_params {
 int grove_gemm_fp8_make_plan(const grove_gemm_fp8_params* p, grove_gemm_plan* out);
 int grove_gemm_fp8_plan_image(const grove_gemm_fp8_params* p, void* host_image, size_t bytes);
 int grove_gemm_fp8(const grove_gemm_fp8_params* p, const grove_gemm_workspace* ws, void* stream);
-/* 1 (default): problems that fit them (K % 128 == 0, N % 8 == 0, 16-byte aligned operands, act NONE / QUICKGELU) run on the FP8
+/* 1 (default): problems that fit them (K % 128 == 0, N % 8 == 0, 16-byte aligned operands, act NONE / QUICKGELU / GELU) run on the FP8
  * instances of the persistent pipelined kernel; 0: always the two-barrier kernel (A/B arm of tests and tools) */
 int grove_gemm_fp8_set_pipelined(int on);
 /* x bf16 [rows, ld_x] -> q e4m3 [rows, ld_q] with one scale per row: scale = amax / 448 (1 for a zero row), q = x / scale */

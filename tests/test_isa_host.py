@@ -19,7 +19,7 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 # instances that are known to carry such a wait and keep it, with the measurement that says why (tools/dev/pp_drain_ab.py):
 #   <256, *, 0, *> (plain + scale: the gathered Conv3d dgrad, K = 34560 — nothing measurable) and <256, false, 3, *> (QuickGELU, CLIP
 #   fc1 at K = 1024: the cure, a compiler-visible drain per output tile, costs 2.6 % there); the FP8 instances (config 5 only)
-ACCEPTED = ("gemm_nt_pp_kernelILi256ELb0ELi0E", "gemm_nt_pp_kernelILi256ELb1ELi0E", "gemm_nt_pp_kernelILi256ELb0ELi3E", "ELb1EEEv17grove_gemm_params")
+ACCEPTED = ("gemm_nt_pp_kernelILi256ELb0ELi0E", "gemm_nt_pp_kernelILi256ELb1ELi0E", "gemm_nt_pp_kernelILi256ELb0ELi3E", "ELb1ELb0EEEv17grove_gemm_params")
 
 
 def to_asm(name, out_dir):

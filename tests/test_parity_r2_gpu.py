@@ -410,8 +410,12 @@ def test_fp8_vit_llama_path_vs_oracle_and_bf16(dev):
     sd_r = {k: v.to(bf).float() for k, v in sd.items()}
     m8 = GROVEForCausalLM(dims=d, device=dev, state_dict=sd, det_token_idx=d.det_token_idx, num_frames=8, pe_dtype=torch.float32, gemm_dtype="fp8",
                           fp8_policy="det16_kv16")
-    m8c = GROVEForCausalLM(dims=d, device=dev, state_dict=sd, det_token_idx=d.det_token_idx, num_frames=8, pe_dtype=torch.float32, gemm_dtype="fp8")
-    assert m8c.fp8_policy == "det16_kv16_clip16" and not any("w1_q" in L for L in m8c.clip.layers) and all("wq_q" in L for L in m8c.llama.layers)  # round-4 default
+    m8c = GROVEForCausalLM(dims=d, device=dev, state_dict=sd, det_token_idx=d.det_token_idx, num_frames=8, pe_dtype=torch.float32, gemm_dtype="fp8",
+                           fp8_policy="det16_kv16_clip16")
+    assert not any("w1_q" in L for L in m8c.clip.layers) and all("wq_q" in L for L in m8c.llama.layers)  # round-4 default, a fenced option since round 6
+    # round 6: the default policy quantises the SAM tower's MLPs and nothing else (TINY's lin2 has K = 256, its lin1 K = 64: only lin2 fits the 128-byte K tile)
+    m8s = GROVEForCausalLM(dims=d, device=dev, state_dict=sd, det_token_idx=d.det_token_idx, num_frames=8, pe_dtype=torch.float32, gemm_dtype="fp8")
+    assert m8s.fp8_policy == "sam_mlp" and not m8s.llama.fp8 and not any("w1_q" in L for L in m8s.clip.layers) and all("w2_q" in B for B in m8s.sam.blocks)
     m8a = GROVEForCausalLM(dims=d, device=dev, state_dict=sd, det_token_idx=d.det_token_idx, num_frames=8, pe_dtype=torch.float32, gemm_dtype="fp8",
                            fp8_policy="all")
     assert m8.fp8_policy == "det16_kv16" and all("wq_q" in L and "wkv" in L for L in m8.llama.layers) and not any("wq_q" in L for L in m8a.llama.layers)

@@ -95,11 +95,11 @@ def test_grouped_b_gemm(dev, groups, rows, N, K):
     a = rnd(groups * rows, K, seed=11)
     b = rnd(groups, N, K, seed=12, scale=0.1)
     out = torch.empty(groups * rows, N, dtype=bf16, device=dev)
-    ops.gemm_raw(a.to(dev), b.to(dev), out, groups * rows, N, K, K, K, N, b_group=(rows, N * K))
+    ops.gemm_raw(a.to(dev), b.to(dev), out, groups * rows, N, K, K, K, N, b_group=rows)
     ref = torch.einsum("grk,gnk->grn", a.float().reshape(groups, rows, K), b.float()).reshape(groups * rows, N)
     close(out, ref, 6e-3, "grouped B")
     with pytest.raises(RuntimeError):  # groups must be whole 256-row tiles
-        ops.gemm_raw(a.to(dev), b.to(dev), out, groups * rows, N, K, K, K, N, b_group=(rows - 64, N * K))
+        ops.gemm_raw(a.to(dev), b.to(dev), out, groups * rows, N, K, K, K, N, b_group=rows - 64)
 
 
 @pytest.mark.parametrize("batches,K,M,N,overwrite", [(3, 128, 64, 72, True), (64, 256, 320, 320, True), (5, 192, 264, 136, False)])

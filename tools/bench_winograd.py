@@ -50,7 +50,7 @@ dU = torch.empty(64, C, C, dtype=torch.float32, device=dev)
 rep["wino input transform"] = timeit(lambda: ops.wino3d_transform_tokens(x, geom, 0, out=V))
 rep["wino grad transform"] = timeit(lambda: ops.wino3d_transform_tokens(dz, geom, 1, out=dM))
 rep["wino weight transform"] = timeit(lambda: ops.wino3d_transform_weight(w, out=U))
-rep["wino grouped NT gemm"] = timeit(lambda: ops.gemm_raw(V, U, Mh, 64 * tiles, C, C, C, C, C, b_group=(tiles, C * C)))
+rep["wino grouped NT gemm"] = timeit(lambda: ops.gemm_raw(V, U, Mh, 64 * tiles, C, C, C, C, C, b_group=tiles))
 rep["wino output transform"] = timeit(lambda: ops.wino3d_output(Mh, geom, y, bias=b, act=ops.ACT_RELU, scale_ptr=a, scale_tanh=True, residual=x, aux=pre))
 rep["wino k-batched TN gemm"] = timeit(lambda: ops.wgrad(dM, V, dU, K=tiles, k_batches=64, sC_batch=C * C, overwrite=True, M=C, N=C))
 rep["wino wgrad output"] = timeit(lambda: ops.wino3d_wgrad_output(dU, gw, scale_ptr=a, scale_tanh=True))
