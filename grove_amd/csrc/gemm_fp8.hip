@@ -165,6 +165,55 @@ __global__ __launch_bounds__(256) void quant_fp8_rows_kernel(const bf16_raw* __r
   }
 }
 
+// The same with an activation in front: q = e4m3(act(x) / scale), scale = amax(act(x)) / 448 — SAM's mlp.lin1 -> GELU -> lin2 under fp8_policy
+// "sam_mlp" (image_encoder.py:243-259, common.py:21-26). At the fp8 rate a K = 1280 output tile's matrix work is 10 K tiles, and a GELU in
+// that GEMM's epilogue costs more than half of it again (measured 381 vs 243 us for the launch: nothing hides the epilogue of a persistent
+// block); this pass is memory-bound and reads every element anyway. One wave per row; the row, rounded to bf16 after the activation (the
+// value the unfused path would have stored and re-read), stays in registers between the amax sweep and the conversion: one read, one write.
+template <int CH>  // 512-element chunks per row held in registers (K <= 512 CH)
+__global__ __launch_bounds__(256) void quant_fp8_rows_act_kernel(const bf16_raw* __restrict__ x, unsigned char* __restrict__ q, float* __restrict__ scale,
+                                                                 int rows, int K, int ld_x, int ld_q, int act) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const bf16_raw* xr = x + (int64_t)row * ld_x;
+  u32x4_t keep[CH];
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    const int c = lane * 8 + i * 512;
+    u32x4_t u = u32x4_t{0u, 0u, 0u, 0u};
+    if (c < K) {
+      u = *(const u32x4_t*)(xr + c);
+      u.x = pack2bf(act_apply(act, bf_lo(u.x)), act_apply(act, bf_hi(u.x)));
+      u.y = pack2bf(act_apply(act, bf_lo(u.y)), act_apply(act, bf_hi(u.y)));
+      u.z = pack2bf(act_apply(act, bf_lo(u.z)), act_apply(act, bf_hi(u.z)));
+      u.w = pack2bf(act_apply(act, bf_lo(u.w)), act_apply(act, bf_hi(u.w)));
+      amax = fmaxf(amax, fmaxf(fmaxf(fabsf(bf_lo(u.x)), fabsf(bf_hi(u.x))), fmaxf(fabsf(bf_lo(u.y)), fabsf(bf_hi(u.y)))));
+      amax = fmaxf(amax, fmaxf(fmaxf(fabsf(bf_lo(u.z)), fabsf(bf_hi(u.z))), fmaxf(fabsf(bf_lo(u.w)), fabsf(bf_hi(u.w)))));
+    }
+    keep[i] = u;
+  }
+  amax = wave_max(amax);
+  const float sc = amax > 0.f ? amax * (1.f / 448.f) : 1.f;
+  const float inv = 1.f / sc;
+  if (lane == 0) scale[row] = sc;
+  unsigned char* qr = q + (int64_t)row * ld_q;
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    const int c = lane * 8 + i * 512;
+    if (c >= K) continue;
+    const u32x4_t u = keep[i];
+    auto cl = [inv](float v) { return fminf(fmaxf(v * inv, -448.f), 448.f); };
+    int w0 = 0, w1 = 0;
+    w0 = __builtin_amdgcn_cvt_pk_fp8_f32(cl(bf_lo(u.x)), cl(bf_hi(u.x)), w0, false);
+    w0 = __builtin_amdgcn_cvt_pk_fp8_f32(cl(bf_lo(u.y)), cl(bf_hi(u.y)), w0, true);
+    w1 = __builtin_amdgcn_cvt_pk_fp8_f32(cl(bf_lo(u.z)), cl(bf_hi(u.z)), w1, false);
+    w1 = __builtin_amdgcn_cvt_pk_fp8_f32(cl(bf_lo(u.w)), cl(bf_hi(u.w)), w1, true);
+    *(u32x2_t*)(qr + c) = u32x2_t{(unsigned)w0, (unsigned)w1};
+  }
+}
+
 }  // namespace
 
 int grove_gemm_fp8_pipelined(const grove_gemm_fp8_params* q, hipStream_t s);  // gemm.hip
@@ -224,6 +273,23 @@ extern "C" int grove_quant_fp8_rows(const void* x, void* q, float* scale, int32_
               "quant_fp8_rows: K and the leading dims must be multiples of 8");
   hipLaunchKernelGGL(quant_fp8_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_raw*)x, (unsigned char*)q, scale, rows, K,
                      ld_x, ld_q);
+  GROVE_LAUNCH_CHECK();
+  return GROVE_OK;
+}
+
+extern "C" int grove_quant_fp8_rows_act(const void* x, void* q, float* scale, int32_t rows, int32_t K, int32_t ld_x, int32_t ld_q, int32_t act, void* stream) {
+  GROVE_CHECK(x && q && scale && rows > 0 && K > 0, GROVE_E_SHAPE, "quant_fp8_rows_act: bad arguments");
+  GROVE_CHECK(K % 8 == 0 && ld_x % 8 == 0 && ld_q % 8 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)q & 7) == 0, GROVE_E_ALIGN,
+              "quant_fp8_rows_act: K and the leading dims must be multiples of 8");
+  GROVE_CHECK(K <= 8192, GROVE_E_SHAPE, "quant_fp8_rows_act: K=%d > 8192 (the row is held in registers)", K);
+  GROVE_CHECK(act >= GROVE_ACT_NONE && act <= GROVE_ACT_SIGMOID, GROVE_E_SHAPE, "quant_fp8_rows_act: act %d", act);
+  const dim3 grid((rows + 3) / 4), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  const bf16_raw* xs = (const bf16_raw*)x;
+  unsigned char* qs = (unsigned char*)q;
+  if (K <= 2048) hipLaunchKernelGGL(quant_fp8_rows_act_kernel<4>, grid, block, 0, s, xs, qs, scale, rows, K, ld_x, ld_q, act);
+  else if (K <= 5120) hipLaunchKernelGGL(quant_fp8_rows_act_kernel<10>, grid, block, 0, s, xs, qs, scale, rows, K, ld_x, ld_q, act);
+  else hipLaunchKernelGGL(quant_fp8_rows_act_kernel<16>, grid, block, 0, s, xs, qs, scale, rows, K, ld_x, ld_q, act);
   GROVE_LAUNCH_CHECK();
   return GROVE_OK;
 }

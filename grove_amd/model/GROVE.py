@@ -296,7 +296,7 @@ class GROVEForCausalLM(torch.nn.Module):
         clip16 = self.fp8_policy.endswith("_clip16")
         self.clip = ClipTower(sd, d, dev, fp32_stream=f32s, fp8=fp8 and not clip16 and not sam_mlp)
         self.llama = LlamaStack(sd, d, dev, train=tr, fp32_stream=f32s, fp8=fp8 and not sam_mlp,
-                                fp8_policy="det16_kv16" if sam_mlp else (self.fp8_policy[:-7] if clip16 else self.fp8_policy))
+                                fp8_policy="det16_kv16" if (sam_mlp or not fp8) else (self.fp8_policy[:-7] if clip16 else self.fp8_policy))
         self.sam = SamEncoder(sd, d, dev, train=tr, grads=self._grad, fp32_stream=f32s, fp8_mlp=sam_mlp)
         self.decoder = BoxDecoder(sd, d, dev, grads=self._grad, pe_dtype=self.pe_dtype)
 

@@ -245,12 +245,19 @@ class SamEncoder:
         pre = torch.empty((rows, 4 * C), dtype=torch.bfloat16, device=self.dev) if save else None
         # backward needs only gelu'(lin1(.)) (the block's weights are frozen: no weight gradient reads the pre-activation), so the
         # GEMM stores the derivative and the backward's lin2 dgrad multiplies by it in its epilogue — no elementwise pass
+        fq = None
         if "w1_q" in Bk and not save:
-            f = ops.linear_fp8(h2, Bk["w1_q"][0], Bk["w1_q"][1], Bk["b1"], act=ops.ACT_GELU)
+            if "w2_q" in Bk and Bk["w2"].shape[1] <= 8192:
+                # e4m3 MLP: the GELU rides in the quantisation pass of lin2's input (a K = 1280 tile at the fp8 rate is too short to hide a
+                # GELU epilogue behind: 381 vs 243 us per launch, tools/dev/bench_sam_mlp_fp8.py), lin1 leaves the pre-activation
+                f = ops.linear_fp8(h2, Bk["w1_q"][0], Bk["w1_q"][1], Bk["b1"])
+                fq = ops.quant_fp8_rows(f, act=ops.ACT_GELU)
+            else:
+                f = ops.linear_fp8(h2, Bk["w1_q"][0], Bk["w1_q"][1], Bk["b1"], act=ops.ACT_GELU)
         else:
             f = ops.linear(h2, Bk["w1"], Bk["b1"], act=ops.ACT_GELU, aux=pre, aux_grad=True)
         if "w2_q" in Bk and not save:
-            t2 = ops.linear_fp8(f, Bk["w2_q"][0], Bk["w2_q"][1], Bk["b2"], residual=None if f32 else x1)
+            t2 = ops.linear_fp8(f, Bk["w2_q"][0], Bk["w2_q"][1], Bk["b2"], residual=None if f32 else x1, xq=fq)
         else:
             t2 = ops.linear(f, Bk["w2"], Bk["b2"], residual=None if f32 else x1)  # bf16 stream: t2 is the new stream x2
         if save:

@@ -932,14 +932,17 @@ def linear_f32(x, w, bias=None, *, act=ACT_NONE, residual=None, out=None, out_bf
     return out
 
 
-def quant_fp8_rows(x):
-    """bf16 [rows, K] -> (e4m3 codes uint8 [rows, K], fp32 scale [rows]): per-row amax / 448 scaling (grove_quant_fp8_rows)."""
+def quant_fp8_rows(x, act=ACT_NONE):
+    """bf16 [rows, K] -> (e4m3 codes uint8 [rows, K], fp32 scale [rows]): per-row amax / 448 scaling (grove_quant_fp8_rows) of act(x)."""
     _chk_dev(x)
     rows, K = x.shape
     assert x.dtype == bf16 and x.stride(1) == 1
     q = torch.empty((rows, K), dtype=torch.uint8, device=x.device)
     sc = torch.empty(rows, dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().grove_quant_fp8_rows(_p(x), _p(q), _p(sc), rows, K, x.stride(0), q.stride(0), _stream()), "grove_quant_fp8_rows")
+    if act != ACT_NONE:
+        _lib.check(_lib.lib().grove_quant_fp8_rows_act(_p(x), _p(q), _p(sc), rows, K, x.stride(0), q.stride(0), act, _stream()), "grove_quant_fp8_rows_act")
+    else:
+        _lib.check(_lib.lib().grove_quant_fp8_rows(_p(x), _p(q), _p(sc), rows, K, x.stride(0), q.stride(0), _stream()), "grove_quant_fp8_rows")
     return q, sc
 
 

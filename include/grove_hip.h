@@ -724,6 +724,10 @@ int grove_gemm_fp8(const grove_gemm_fp8_params* p, const grove_gemm_workspace* w
 int grove_gemm_fp8_set_pipelined(int on);
 /* x bf16 [rows, ld_x] -> q e4m3 [rows, ld_q] with one scale per row: scale = amax / 448 (1 for a zero row), q = x / scale */
 int grove_quant_fp8_rows(const void* x, void* q, float* scale, int32_t rows, int32_t K, int32_t ld_x, int32_t ld_q, void* stream);
+/* the same on act(x) (enum grove_act NONE .. SIGMOID; the activation's result is rounded to bf16 first, as a stored activation would be):
+ * MLPBlock's lin1 -> GELU -> lin2 (common.py:21-26) with the GELU in the quantisation pass of lin2's input instead of lin1's epilogue.
+ * K <= 8192 (the row stays in registers between the amax sweep and the conversion). */
+int grove_quant_fp8_rows_act(const void* x, void* q, float* scale, int32_t rows, int32_t K, int32_t ld_x, int32_t ld_q, int32_t act, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Winograd F(2 x 2 x 2, 3 x 3 x 3) form of the Conv3d adapters (round 6): the memory-bound transforms either side of the grouped

@@ -1334,7 +1334,7 @@ def test_fp8_linear_quantised(dev, M, N, K, act):
     assert same > 0.999, same  # (ties of the device's division vs torch's can differ in the last bit on a handful of elements)
     ws_ref = w.float().abs().amax(1) / 448
     w_model = _e4m3(w.float() / ws_ref[:, None])
-    a = {0: ops.ACT_NONE, 1: ops.ACT_GELU, 2: ops.ACT_QUICKGELU}[act]  # (GELU: no pipelined instance -> gemm_fp8.hip's own kernel)
+    a = {0: ops.ACT_NONE, 1: ops.ACT_GELU, 2: ops.ACT_QUICKGELU}[act]  # (round 6: GELU has its pipelined FP8 instances too — SAM's mlp.lin1)
     fact = {0: lambda v: v, 1: torch.nn.functional.gelu, 2: lambda v: v * torch.sigmoid(1.702 * v)}[act]
     y = ops.linear_fp8(x.to(dev), wq, ws, bias.to(dev), act=a, residual=res.to(dev))
     pre = (x_model @ w_model.t()) * xs_ref[:, None] * ws_ref[None, :] + bias.float()
@@ -1343,7 +1343,7 @@ def test_fp8_linear_quantised(dev, M, N, K, act):
     assert rms < 6e-3, f"fp8 gemm vs its own quantisation model: rms {rms}"  # bf16 output rounding + last-bit ties of the device division (measured 3.0-3.4e-3)
     close(y, ref, 2e-2, "fp8 gemm vs its own quantisation model")
     full = fact(x.float() @ w.float().t() + bias.float()) + res.float()
-    if act != 1:  # both kernels: same products, different fp32 sum order
+    if True:  # both kernels: same products, different fp32 sum order
         from grove_amd import _lib
         try:
             _lib.lib().grove_gemm_fp8_set_pipelined(0)
@@ -1353,6 +1353,25 @@ def test_fp8_linear_quantised(dev, M, N, K, act):
         close(y, y0, 2 ** -7, "pipelined FP8 instance vs the two-barrier fp8 kernel")
     err = ((y.float().cpu() - full).pow(2).mean().sqrt() / full.pow(2).mean().sqrt()).item()
     assert err < 6e-2, f"fp8 quantisation error {err}"
+
+
+@pytest.mark.parametrize("rows,K,ld", [(37, 5120, 5120), (9, 520, 528), (5, 8192, 8192), (130, 1280, 1280)])
+def test_fp8_quantisation_with_gelu_in_front(dev, rows, K, ld):
+    """grove_quant_fp8_rows_act: e4m3(gelu(x) / scale) with the per-row scale of gelu(x) — equal to quantising the stored bf16 GELU output
+    (what the unfused path does), up to last-bit differences of the erf approximation at bf16 rounding boundaries."""
+    from grove_amd import ops
+    x = rnd(rows, ld, seed=7, scale=2.0)[:, :K]
+    xd = x.to(dev)
+    q, sc = ops.quant_fp8_rows(xd, act=ops.ACT_GELU)
+    f16 = torch.nn.functional.gelu(x.float()).to(bf16)
+    q0, sc0 = ops.quant_fp8_rows(f16.to(dev).contiguous())
+    assert torch.allclose(sc.cpu(), sc0.cpu(), rtol=2 ** -7)
+    a, b = q.cpu().view(torch.float8_e4m3fn).float() * sc.cpu()[:, None], q0.cpu().view(torch.float8_e4m3fn).float() * sc0.cpu()[:, None]
+    assert (q.cpu() == q0.cpu()).float().mean().item() > 0.995
+    close(a, b, 2 ** -3 * 1.01, "gelu + quantise vs quantise of the stored gelu")  # (a flipped bf16 bit can move a code by one e4m3 step)
+    close(a, torch.nn.functional.gelu(x.float()), 2 ** -4 * 1.1, "e4m3 rounding of gelu(x)")
+    with pytest.raises(RuntimeError):
+        ops.quant_fp8_rows(rnd(2, 8704, seed=1).to(dev), act=ops.ACT_GELU)  # K > 8192: the row does not fit the registers
 
 
 @pytest.mark.parametrize("nb,nh,size,hd,hp", [(18, 16, 14, 80, 96), (3, 16, 32, 80, 96), (5, 4, 6, 32, 32), (7, 12, 14, 64, 64)])
