@@ -35,6 +35,8 @@ def build(dims, dev, args):
     targs = T.shipped_args()  # --lora_r 0 --pretrained --train_mask_decoder: every shipped launch line (train_scripts/*.sh)
     targs.num_frames = args.frames
     targs.batch_size = args.batch
+    if getattr(args, "stream", "default") != "default":
+        targs.stream_dtype = args.stream
     sd = synthetic_state_dict(dims, device=dev, dtype=torch.bfloat16)
     model = T.initialize_model(targs, dims=dims, state_dict=sd, device=dev)
     del sd
@@ -745,6 +747,8 @@ def main():
                     help="N > 1: exchange all gradients after the backward instead of group by group from inside it (exposed-communication A/B)")
     ap.add_argument("--gemm_blocks", type=int, default=0,
                     help="N > 1 A/B: resident blocks of the persistent GEMMs (0 = one per CU); fewer leaves CUs to the overlapped RCCL kernels")
+    ap.add_argument("--stream", default="default", choices=["default", "fp32", "bf16"],
+                    help="--mode train: residual streams of the three towers (default = bf16, what the reference stores; fp32 = the inference models' form)")
     ap.add_argument("--serial_towers", action="store_true",
                     help="run the SAM tower on the main stream as well (no kernel overlap): how profiles/*_kernel_stats are collected")
     args = ap.parse_args()

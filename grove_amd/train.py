@@ -328,6 +328,8 @@ def initialize_model(args, tokenizer=None, dims=None, state_dict=None, device=No
               temp_objectness_loss_weight=args.temp_objectness_loss_weight, train_mask_decoder=args.train_mask_decoder,
               use_temp_objectness=getattr(args, "dataset", "HowToGround") == "HowToGround",   # train.py:203
               bbox_token_idx=getattr(args, "bbox_token_idx", None))
+    if getattr(args, "stream_dtype", None) is not None:  # (this build's addition: the residual streams of a training model, bf16 unless asked)
+        kw["stream_dtype"] = {"fp32": torch.float32, "bf16": torch.bfloat16}.get(args.stream_dtype, args.stream_dtype)
     if state_dict is None and os.path.isdir(str(getattr(args, "version", ""))):
         model = GROVEForCausalLM.from_pretrained(args.version, torch_dtype=torch.bfloat16, low_cpu_mem_usage=True, dims=dims, **kw)
         initialize_custom_layers_in_model(model)

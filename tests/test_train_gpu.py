@@ -388,6 +388,31 @@ def _run_rehearsal(cmd, env):
         warnings.warn(f"two-rank rehearsal failed once (rc {proc.returncode}) and is retried; diagnostics in {path}: {err[-1500:]!r}")
 
 
+def test_bench_self_launches_eight_ranks(tmp_path):
+    """the driver's one shot at `bench.py --gpus 8` is the first time eight ranks ever run this code — so they run
+    here first: eight processes on this box's one GPU (tiny dims; gloo, because RCCL refuses two ranks on one device), the self-launch,
+    per-rank batches, the world-8 bucket / chunk arithmetic of every exchange arm in the calibration table, the barrier + MAX timing and
+    the single JSON line (train_scripts/train_howtoground.sh:20-28: 8 ranks per node)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GROVE_BENCH_BACKEND="gloo", GROVE_BENCH_ONE_GPU="1", GLOO_SOCKET_IFNAME="lo", OMP_NUM_THREADS="2")
+    env.pop("WORLD_SIZE", None)
+    p = _run_rehearsal([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--dims", "tiny", "--steps", "2", "--warmup", "1", "--frames", "8",
+                        "--text_len", "48", "--no_cpu_baseline", "--calibration_steps", "1"], env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 8 and res["config"]["ranks"] == 8 and res["config"]["global_batch_clips"] == 16 and res["config"]["collective_backend"] == "gloo"
+    assert res["value"] > 0 and res["scaling"] == "weak" and res["config"]["exposed_comm_ms"] is not None
+    cal = res["config"]["exchange_calibration"]
+    assert cal is not None and len(cal["arms"]) == 6 and all(a["ms_per_step"] > 0 for a in cal["arms"])
+    print(json.dumps({"ms_per_step": res["ms_per_step"], "arms": [(a["exchange"], a["reserved_cus"], a["ms_per_step"]) for a in cal["arms"]]}))
+
+
 def test_bench_self_launches_ranks(tmp_path):
     """`python bench.py --gpus 2` with no launcher around it (the shape of the driver's command) spawns its own two ranks before
     touching the GPU and prints ONE JSON line with n_gpus = 2. On this one-GPU box both ranks share cuda:0 and the collectives go
