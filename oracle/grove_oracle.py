@@ -224,6 +224,40 @@ def llama_forward(sd, d, embeds, attention_mask=None):
     return rms_norm(x, sd["model.norm.weight"], d.rms_eps)
 
 
+def llama_forward_cached(sd, d, embeds_new, cache):
+    """The same stack on NEW positions only, against a key / value cache of the earlier ones (HF `use_cache=True`, the form
+    `GenerationMixin.generate` drives: GROVE.py:418-422, llava_llama.py:144-180): embeds_new [B, n, H] are positions P .. P + n - 1
+    where P = the cache length; cache = list over layers of (K, V) [B, heads, P, hd] (RoPE already applied to K), [] before the
+    prefill. No padding (quirk Q9: every caller feeds un-padded, equal-length prompts). Returns the post-norm hidden states of the new
+    positions; the cache is extended in place. Cached and uncached streams agree (tests/test_oracle_golden.py)."""
+    B, n, H = embeds_new.shape
+    nh, hd = d.n_heads, d.head_dim
+    P = cache[0][0].shape[2] if cache else 0
+    cos, sin = _rope_cos_sin(d, torch.arange(P, P + n))
+    neg = torch.finfo(torch.float32).min
+    add = torch.cat([torch.zeros(n, P), torch.full((n, n), neg).triu(1)], 1)[None, None]  # everything cached + causal inside the new block
+    x = embeds_new
+    for i in range(d.n_layers):
+        p = f"model.layers.{i}."
+        h = rms_norm(x, sd[p + "input_layernorm.weight"], d.rms_eps)
+        sh = lambda t: t.view(B, n, nh, hd).transpose(1, 2)  # noqa: E731
+        q, k, v = (sh(_lin(sd, p + f"self_attn.{m}_proj", h)) for m in "qkv")
+        q = q * cos + _rotate_half(q) * sin
+        k = k * cos + _rotate_half(k) * sin
+        if len(cache) > i:
+            k, v = torch.cat([cache[i][0], k], 2), torch.cat([cache[i][1], v], 2)
+            cache[i] = (k, v)
+        else:
+            cache.append((k, v))
+        att = torch.softmax((q @ k.transpose(-1, -2) * hd ** -0.5 + add).float(), -1).to(q.dtype)
+        o = (att @ v).transpose(1, 2).reshape(B, n, H)
+        x = x + _lin(sd, p + "self_attn.o_proj", o)
+        h = rms_norm(x, sd[p + "post_attention_layernorm.weight"], d.rms_eps)
+        h = F.silu(_lin(sd, p + "mlp.gate_proj", h)) * _lin(sd, p + "mlp.up_proj", h)
+        x = x + _lin(sd, p + "mlp.down_proj", h)
+    return rms_norm(x, sd["model.norm.weight"], d.rms_eps)
+
+
 def lm_loss(sd, hidden, labels):
     """lm_head + shifted CrossEntropyLoss (mean over labels != -100), llava_llama.py:111-125."""
     logits = F.linear(hidden, sd["lm_head.weight"])

@@ -13,9 +13,14 @@ import torch
 class LazyRoundedWeights(dict):
     """{name: fp32 tensor of the bf16-rounded synthetic weight}, generated on access."""
 
-    def __init__(self, d, gen_device="cpu", outliers=0.0):
+    def __init__(self, d, gen_device="cpu", outliers=0.0, scale=None, keep_prefix=None):
+        """scale: {name: factor} applied to the generated tensor before its bf16 rounding (a test that wants, say, louder token embeddings
+        applies the same factor to the device model's copy). keep_prefix: names starting with it are kept on the host as bf16 after their
+        first use (a decode loop touches every LLaMA weight once per token: 13.5 GB held instead of 7.6e9 values regenerated per step)."""
         super().__init__()
         self.outliers = outliers
+        self.scale = scale or {}
+        self.keep_prefix, self._kept = keep_prefix, {}
         from grove_amd.synthetic import param_shapes
         self.d, self.shapes = d, param_shapes(d)
         self._last = (None, None)
@@ -30,7 +35,16 @@ class LazyRoundedWeights(dict):
         if self._last[0] == k:
             return self._last[1]
         t0 = time.perf_counter()
-        t = synthetic_param(k, self.shapes[k], self.d, self.gen_device, self.outliers).to(torch.bfloat16).float().cpu()
+        if k in self._kept:
+            t = self._kept[k].float()
+        else:
+            t = synthetic_param(k, self.shapes[k], self.d, self.gen_device, self.outliers)
+            if k in self.scale:
+                t = t * self.scale[k]
+            t16 = t.to(torch.bfloat16).cpu()
+            if self.keep_prefix is not None and k.startswith(self.keep_prefix):
+                self._kept[k] = t16
+            t = t16.float()
         self._last = (k, t)
         self.fetch_seconds += time.perf_counter() - t0
         return t

@@ -85,6 +85,33 @@ def test_greedy_evaluate(sd):
     near(flat(boxes) / 640, g["pred_bboxes"] / 640, what="forced-DET boxes")
 
 
+def test_cached_decode_equals_uncached_and_the_reference_ids(sd):
+    """oracle.llama_forward_cached (prefill + one-token steps against a K / V cache: what HF generate drives, GROVE.py:418-422) against the
+    uncached llama_forward on the same prefixes, and its greedy ids against the reference's golden ids (row 0 of the golden runs to the
+    end without an eos, so plain argmax reproduces it). The full-size caption-id test decodes with this form."""
+    import torch.nn.functional as Fn
+    g = np.load(os.path.join(G, "tiny_evaluate_B2_T8_seed3.npz"))
+    batch = synthetic_batch(TINY, B=2, T=8, L=24, n_det=1, seed=3)
+    P = int(g["prompt_len"])
+    prompt = batch.input_ids[:1, :P].clone()
+    with torch.no_grad():
+        feats, _ = O.encode_images(sd, TINY, batch.global_enc_images)
+        feats = feats[:1]
+        cache, ids = [], prompt.clone()
+        x = O.splice(sd, ids, None, None, feats)[0]
+        hid = [O.llama_forward_cached(sd, TINY, x, cache)]
+        for t in range(8):
+            nxt = Fn.linear(hid[-1][:, -1], sd["lm_head.weight"]).argmax(-1)
+            ids = torch.cat([ids, nxt[:, None]], 1)
+            hid.append(O.llama_forward_cached(sd, TINY, sd["model.embed_tokens.weight"][nxt][:, None], cache))
+        full = O.llama_forward(sd, TINY, O.splice(sd, ids, None, None, feats)[0], None)
+    near(torch.cat(hid, 1), full, tol=2e-5, what="cached vs uncached hidden states")
+    assert cache[0][0].shape[2] == full.shape[1]
+    want = torch.from_numpy(g["greedy_ids"])[:1, :ids.shape[1]]
+    n = want.shape[1]
+    assert torch.equal(ids[:, :n], want), (ids, want)
+
+
 def test_literal_T16_row_indexing(sd):
     """Quirk Q1: at T=16 the reference feeds sample b the b-th 8-frame group of the pooled features."""
     from dataclasses import replace
