@@ -231,6 +231,48 @@ def cpu_layer_samples(args):
     return fwd, bwd, measured, S
 
 
+def cpu_config1_leg(sd, d, fwd_fp32_s, cores, new_tokens=64, budget_s=150.0):
+    """SURVEY.md section 8(d)'s config-1 CPU baseline (BASELINE config 1: one clip x 8 frames @336 px, greedy decode — the reference's own
+    CPU-runnable case, grove_transformers / infer_iground.py:185-196): B = 1, T = 8 forward + `new_tokens` greedy tokens, on the oracle
+    with its own K / V cache (oracle.llama_forward_cached). fp32: the window forward measured by the caller (the same towers + prefill) +
+    the decode loop timed here. bf16: the LLaMA prefill + decode loop with bf16 weights and activations (torch CPU bf16 kernels) — the
+    decode-dominated part; the towers are reported in fp32 only. Bounded: a leg that would pass `budget_s` stops early and is scaled."""
+    import torch.nn.functional as Fn
+    from grove_amd.synthetic import synthetic_batch
+    from oracle import grove_oracle as O
+    batch = synthetic_batch(d, B=1, T=8, L=64, n_det=1, seed=5)
+    prompt = batch.input_ids[:, :40].contiguous()
+    out = {"what": f"B=1, T=8 forward + {new_tokens}-token greedy decode (KV-cached oracle), {cores} threads", "new_tokens": new_tokens}
+    t_all = time.perf_counter()
+    with torch.no_grad():
+        feats = torch.zeros(1, 576, d.hidden)  # (timing only: the visual tokens' values do not change the work)
+        for name, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+            # the LLaMA side of the state dict in the leg's dtype, converted ONCE, outside the timed regions (13.5 GB more for bf16)
+            v = {k: t.detach().to(dt) for k, t in sd.items() if k.startswith("model.layers.") or k in ("model.embed_tokens.weight", "model.norm.weight", "lm_head.weight")}
+            emb_table, lm_head = v["model.embed_tokens.weight"], v["lm_head.weight"]
+            cache = []
+            t0 = time.perf_counter()
+            embeds, _, _ = O.splice(v, prompt, None, None, feats.to(emb_table.dtype))
+            hidden = O.llama_forward_cached(v, d, embeds, cache)
+            t_prefill = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            done = 0
+            for _ in range(new_tokens):
+                tok = Fn.linear(hidden[:, -1], lm_head).argmax(-1)
+                hidden = O.llama_forward_cached(v, d, emb_table[tok][:, None], cache)
+                done += 1
+                if time.perf_counter() - t_all > budget_s * (0.5 if name == "fp32" else 1.0):
+                    break
+            t_dec = (time.perf_counter() - t0) * new_tokens / max(done, 1)
+            out[name] = {"llama_prefill_s": round(t_prefill, 2), "decode_s": round(t_dec, 2), "decode_tokens_measured": done,
+                         "s_per_token": round(t_dec / new_tokens, 3)}
+    total32 = fwd_fp32_s + out["fp32"]["decode_s"]
+    out["fp32"]["forward_window_s"] = round(fwd_fp32_s, 1)
+    out["fp32"]["clip_seconds"] = round(total32, 1)
+    out["fp32"]["frames_per_s"] = round(8.0 / total32, 4)
+    return out
+
+
 def cpu_baseline(args, dev=None):
     """The CPU oracle (a port, oracle/grove_oracle.py) on the host cores, on a bounded sample of the bench workload: ONE of the
     step's 8-frame windows at FULL dimensions.
@@ -277,8 +319,14 @@ def cpu_baseline(args, dev=None):
         out["loss"].backward()
         t2 = time.perf_counter()
         total = t2 - t0
+        c1 = None
+        try:  # SURVEY section 8(d)'s other CPU figure: config 1 (forward + 64-token greedy decode), beside the fwd + bwd window
+            del out
+            c1 = cpu_config1_leg(sd, d, t1 - t0, cores)
+        except Exception as e:
+            c1 = {"error": repr(e)}
         return {"value": round(8.0 / total, 4), "unit": "frames/s", "cores": cores, "cpu_model": cpu, "kind": "port", "measured": True, "seconds_per_window": round(total, 1),
-                "forward_seconds_measured": round(t1 - t0, 1), "backward_seconds_measured": round(t2 - t1, 1),
+                "forward_seconds_measured": round(t1 - t0, 1), "backward_seconds_measured": round(t2 - t1, 1), "config1_infer_greedy64": c1,
                 "sample": (f"oracle fp32 at full dims, ONE whole 8-frame window of the step (B=1, T=8, L={args.text_len}), forward {t1 - t0:.1f} s + "
                            f"backward through torch autograd {t2 - t1:.1f} s, timed end to end on {cores} threads")}
     sd = LazyRoundedWeights(d, gen_device=dev if dev is not None else "cpu")

@@ -233,7 +233,7 @@ def llama_forward_cached(sd, d, embeds_new, cache):
     B, n, H = embeds_new.shape
     nh, hd = d.n_heads, d.head_dim
     P = cache[0][0].shape[2] if cache else 0
-    cos, sin = _rope_cos_sin(d, torch.arange(P, P + n))
+    cos, sin = (t.to(embeds_new.dtype) for t in _rope_cos_sin(d, torch.arange(P, P + n)))  # (computed in fp32, cast to the activation dtype: HF :113-127)
     neg = torch.finfo(torch.float32).min
     add = torch.cat([torch.zeros(n, P), torch.full((n, n), neg).triu(1)], 1)[None, None]  # everything cached + causal inside the new block
     x = embeds_new
