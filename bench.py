@@ -1104,8 +1104,15 @@ def exchange_epilogue(args, engine, step, res, prog, world, rank, dev, real_stdo
             res["config"]["exchange_calibration"] = {"status": f"FAILED in '{beat[1]}': {e!r}; this line is the start arm's, measured before the calibration; "
                                                                f"arms finished: {beat[2:]}"}
         ex.mode, ex.reserve_cus = start_arm
+        # a rank that raised must not walk into main()'s final barrier — the ranks still inside the arm's collective leave through
+        # the heartbeat's os._exit(0) after `stall_s`, and this one would then wait for them until --launch_timeout and turn the run's exit
+        # code into 124 although the line was printed. So: the line goes out here, and this rank leaves now with the promised exit code 0
+        # (an exit, never a re-exec; the process group is torn down by the exit).
+        if rank == 0 and res is not None:
+            os.write(real_stdout, (json.dumps(res) + "\n").encode())
+        sys.stderr.flush()
         done.set()
-        return
+        os._exit(0)
     mine = [a for a in table if (a["exchange"], a["reserved_cus"]) == start_arm]
     start_row = mine[0] if mine else None
     calibration = {"arms": table, "fastest": best, "steps_per_arm": args.calibration_steps, "line_timed_on": {"exchange": start_arm[0], "reserved_cus": start_arm[1]},

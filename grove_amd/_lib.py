@@ -183,7 +183,7 @@ STRUCTS = {
 
 # every symbol include/grove_hip.h declares (tests/test_abi.py checks the header against this list)
 SYMBOLS = [
-    "grove_version", "grove_last_error", "grove_set_deterministic", "grove_deterministic", "grove_sizeof", "grove_gemm_bf16", "grove_gemm_make_plan", "grove_gemm_plan_image", "grove_gemm_workspace_bytes", "grove_gemm_fp8_make_plan", "grove_gemm_fp8_plan_image", "grove_gemm_last_variant", "grove_gemm_last_epilogue", "grove_gemm_set_staging", "grove_gemm_set_stream_k", "grove_gemm_set_persistent_blocks", "grove_gemm_persistent_blocks", "grove_gemm_set_tap_skip", "grove_gemm_work_list", "grove_gemm_last_stream_k", "grove_gemm_set_tile_n", "grove_gemm_set_tile_m", "grove_gemm_set_bk", "grove_gemm_tn_bf16", "grove_gemm_tn_set_pipelined", "grove_gemm_tn_set_split_tail", "grove_gemm_tn_last_parts", "grove_gemm_tn_set_tap_skip", "grove_gemm_tn_last_skip", "grove_gemv_bf16", "grove_gemv_set_mfma", "grove_decode_attn", "grove_greedy_pick", "grove_resample_u8", "grove_normalize_pack",
+    "grove_version", "grove_last_error", "grove_set_deterministic", "grove_deterministic", "grove_sizeof", "grove_gemm_bf16", "grove_gemm_make_plan", "grove_gemm_plan_image", "grove_gemm_workspace_bytes", "grove_gemm_fp8_make_plan", "grove_gemm_fp8_plan_image", "grove_gemm_last_variant", "grove_gemm_last_epilogue", "grove_gemm_set_staging", "grove_gemm_set_stream_k", "grove_gemm_set_persistent_blocks", "grove_gemm_persistent_blocks", "grove_gemm_set_tap_skip", "grove_gemm_work_list", "grove_gemm_last_stream_k", "grove_gemm_set_tile_n", "grove_gemm_set_tile_m", "grove_gemm_set_bk", "grove_gemm_tn_bf16", "grove_gemm_tn_set_pipelined", "grove_gemm_tn_set_split_tail", "grove_gemm_tn_last_parts", "grove_gemm_tn_set_tap_skip", "grove_gemm_tn_last_skip", "grove_gemv_bf16", "grove_gemv_set_mfma", "grove_gemv_uses_mfma", "grove_decode_attn", "grove_greedy_pick", "grove_resample_u8", "grove_normalize_pack",
     "grove_transpose_bf16", "grove_layernorm_fwd", "grove_rmsnorm_fwd", "grove_layernorm_bwd", "grove_rmsnorm_bwd",
     "grove_flash_attn_fwd", "grove_flash_attn_bwd", "grove_flash_attn_set_window_kernels", "grove_flash_attn_set_register_e", "grove_flash_attn_set_v2", "grove_flash_attn_window_kernels_on", "grove_softmax_fwd", "grove_softmax_bwd", "grove_relpos_fwd", "grove_relpos_bwd", "grove_rel_bias_fwd", "grove_rel_bias_bwd", "grove_rope_inplace",
     "grove_swiglu_fwd", "grove_swiglu_bwd", "grove_act_bwd", "grove_act_fwd", "grove_resize_bilinear_f32", "grove_add_bf16", "grove_add_bcast_rows",

@@ -234,7 +234,7 @@ def consolidated_state_dict(model, engine=None, dtype=torch.float32):
     obj = "model.grounding_encoder.mask_decoder.temporal_objectness_head."
     for k, v in (getattr(model, "_passthrough", None) or {}).items():
         if k not in out and not (k.startswith(obj) and not getattr(getattr(model, "config", None), "use_temp_objectness", True)):
-            out[k] = v.to(dtype)
+            out[k] = v.to(dtype) if v.is_floating_point() else v  # (an integer buffer — older HF CLIP's position_ids — keeps its dtype: ADVICE r5)
     return out
 
 

@@ -1371,9 +1371,15 @@ extern "C" int grove_flash_attn_set_v2(int32_t on) {
   return GROVE_OK;
 }
 
+// dma_tile forms its per-lane LDS-DMA source offsets (row * ld + column, in bytes) in 32-bit arithmetic: every operand a kernel stages
+// that way must span less than 4 GiB per (batch, head) base, or the offsets wrap silently. Longer / wider problems go to
+// the four-wave kernels, whose row offsets are 64-bit.
+static bool spans32(int64_t rows, int64_t ld) { return rows * ld * 2 < (1ll << 32); }
+
 // true when the round-5 forward kernel takes this problem (flash_attn.hip asks before its own dispatch)
 bool grove_flash2_fwd_applicable(const grove_flash_attn_params* p) {
   if (!(g_flash2 & 1)) return false;
+  if (!spans32(p->Lk, p->ld_k) || !spans32(p->Lk, p->ld_v) || !spans32(p->Lq, p->ld_q)) return false;
   if (!(p->hs == 64 || p->hs == 96 || p->hs == 128)) return false;
   if (p->rel && !(p->rel_kw == 32 && p->rel_kh == 32 && p->rel_ld == 64 && p->hs == 96)) return false;
   if (p->ld_o % 8 != 0 || ((uintptr_t)p->o & 15) != 0 || (p->so % 8) != 0) return false;
@@ -1383,6 +1389,7 @@ bool grove_flash2_fwd_applicable(const grove_flash_attn_params* p) {
 // true when the round-5 dQ kernel takes this backward problem (flash_attn.hip asks before its own dispatch)
 bool grove_flash2_bwd_dq_applicable(const grove_flash_attn_params* p) {
   if (!(g_flash2 & 2)) return false;
+  if (!spans32(p->Lk, p->ld_k) || !spans32(p->Lk, p->ld_v) || !spans32(p->Lq, p->ld_q) || !spans32(p->Lq, p->ld_do)) return false;
   // head dim 128 (LLaMA: 3 query blocks of 4 / 8 / 11 key tiles per head — launches dominated by their fixed cost): measured in pairs
   // with the dK / dV kernel and the fused inverse RoPE, the four-wave dQ kernel is the faster one (131.4 vs 137.2 us per backward,
   // tools/dev/bench_llama_bwd.py), so the eight-wave dQ takes head dim 128 only when bit 4 of the mask asks for it
@@ -1416,6 +1423,7 @@ int grove_flash2_bwd_dq_launch(const grove_flash_attn_params* p, int make_delta,
 // SIMD split dK and dV: SPLIT); at 64 the four-wave kernel is the faster one — 142 against 177 us on the CLIP shape — so it keeps that
 bool grove_flash2_bwd_dkv_applicable(const grove_flash_attn_params* p) {
   if (!(g_flash2 & 4)) return false;
+  if (!spans32(p->Lk, p->ld_k) || !spans32(p->Lk, p->ld_v) || !spans32(p->Lq, p->ld_q) || !spans32(p->Lq, p->ld_do)) return false;
   if (!(p->hs == 96 || (p->hs == 128 && (g_flash2 & 8)))) return false;
   if (p->rel && !(p->rel_kw == 32 && p->rel_kh == 32 && p->rel_ld == 64 && p->hs == 96)) return false;
   if (p->rope && (p->hs % 64 != 0 || ((uintptr_t)p->rope & 15) != 0)) return false;

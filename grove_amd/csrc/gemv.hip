@@ -364,15 +364,22 @@ extern "C" int grove_gemv_set_mfma(int32_t on) {
   return GROVE_OK;
 }
 
+// 3..8 sequences: the matrix-core kernel (x in LDS for the folded prologues — MXS = 4 rows for M <= 4, else 8 — straight from global
+// memory in plain mode). ONE predicate for the dispatcher and for callers that plan around it (grove_gemv_uses_mfma).
+static bool gemv_takes_mfma(const grove_gemv_params& p) {
+  const bool plain_x = p.x_mode == GROVE_GEMV_X_PLAIN && !p.x_f32;
+  const size_t mxs = p.M <= 4 ? 4 : 8;
+  return g_gemv_mfma && p.M >= 3 && p.K % 128 == 0 && (p.act != GROVE_ACT_SWIGLU_PAIR || p.N % 16 == 0) && (plain_x || mxs * (p.K + 32) * 2 <= 150 * 1024);
+}
+extern "C" int grove_gemv_uses_mfma(const grove_gemv_params* pp) { return pp && gemv_takes_mfma(*pp) ? 1 : 0; }
+
 extern "C" int grove_gemv_bf16(const grove_gemv_params* pp, void* stream) {
   GROVE_CHECK(pp != nullptr, GROVE_E_SHAPE, "gemv: null params");
   const grove_gemv_params& p = *pp;
   GROVE_CHECK(p.M >= 1 && p.M <= 8, GROVE_E_SHAPE, "gemv: M=%d must be 1..8 (use grove_gemm_bf16 beyond)", p.M);
   GROVE_CHECK(p.N > 0 && p.K > 0 && p.K % 8 == 0, GROVE_E_SHAPE, "gemv: N=%d K=%d (K must be a multiple of 8)", p.N, p.K);
-  // 3..8 sequences: the matrix-core kernel (x in LDS for the folded prologues, straight from global memory in plain mode)
   const bool plain_x = p.x_mode == GROVE_GEMV_X_PLAIN && !p.x_f32;
-  const bool mfma = g_gemv_mfma && p.M >= 3 && p.K % 128 == 0 && (p.act != GROVE_ACT_SWIGLU_PAIR || p.N % 16 == 0) &&
-                    (plain_x || (size_t)8 * (p.K + 32) * 2 <= 150 * 1024);
+  const bool mfma = gemv_takes_mfma(p);
   GROVE_CHECK(mfma || (size_t)(p.M <= 2 ? p.M : p.M <= 4 ? 4 : 8) * p.K * 2 <= 159 * 1024, GROVE_E_SHAPE, "gemv: M*K=%d*%d does not fit the LDS", p.M, p.K);
   GROVE_CHECK(p.ldx % 8 == 0 && p.ldw % 8 == 0, GROVE_E_ALIGN, "gemv: ldx=%d ldw=%d must be multiples of 8", p.ldx, p.ldw);
   GROVE_CHECK(!p.x_f32 || p.x_mode != GROVE_GEMV_X_SWIGLU, GROVE_E_DTYPE, "gemv: x_mode swiglu reads a bf16 gate|up row");

@@ -496,8 +496,12 @@ def gemv(x, w, bias=None, *, act=ACT_NONE, residual=None, out_dtype=bf16, out=No
     assert x.shape[1] == (2 * K if swiglu else K) and x.stride(1) == 1 and w.stride(1) == 1
     assert x.dtype in (bf16, torch.float32) and (residual is None or residual.dtype in (bf16, torch.float32))
     mx = 1 if M == 1 else 2 if M == 2 else 4 if M <= 4 else 8
-    plain = rms_weight is None and not swiglu and x.dtype == bf16
-    mfma = M >= 3 and K % 128 == 0 and (act != ACT_SWIGLU_PAIR or N % 16 == 0) and (plain or 8 * (K + 32) * 2 <= 150 * 1024)
+    # which kernel the library will run is the LIBRARY's decision (its knob, its LDS bound): asked, not re-derived
+    q = _lib.GemvParams()
+    q.M, q.N, q.K, q.act = M, N, K, act
+    q.x_mode = 2 if swiglu else 1 if rms_weight is not None else 0
+    q.x_f32 = int(x.dtype == torch.float32)
+    mfma = bool(_lib.lib().grove_gemv_uses_mfma(C.byref(q)))
     if mfma and rms_weight is not None and not swiglu and _GEMV_SPLIT_NORM:
         # 3..8 sequences on the matrix-core kernel: a block owns 16 output rows — 128 KB of weights at K = 4096 — and a folded RMSNorm
         # makes every one of its N / 16 blocks re-read and re-normalise the M x K fp32 rows (another 128 KB, plus the block reductions)

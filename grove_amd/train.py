@@ -930,7 +930,10 @@ class GroveEngine:
             tag = tag or f"global_step{self.global_step}"
             torch.save({"module": {k: v.cpu() for k, v in self.module.state_dict().items()}, "master": self.master.cpu(),
                         "exp_avg": self.m.cpu(), "exp_avg_sq": self.v.cpu(), "global_step": self.global_step,
-                        "trainable": list(self.names), "world": self.world},
+                        "trainable": list(self.names), "world": self.world,
+                        # tensors of the reference checkpoint for modules off this path (checkpoint.load_grove_weights keeps them on the model):
+                        # saved with the engine state so that a RESUMED run still writes the reference's full key set
+                        "passthrough": dict(getattr(self.module, "_passthrough", None) or {})},
                        os.path.join(save_dir, tag + ".pt"))
             if consolidated:
                 from .checkpoint import save_grove_weights
@@ -955,6 +958,8 @@ class GroveEngine:
         self.m.copy_(ck["exp_avg"])
         self.v.copy_(ck["exp_avg_sq"])
         self.global_step = int(ck["global_step"])
+        if ck.get("passthrough") and not getattr(self.module, "_passthrough", None):
+            self.module._passthrough = dict(ck["passthrough"])
         self.broadcast_parameters()
         if dist.is_initialized():
             dist.barrier()

@@ -524,6 +524,9 @@ int grove_gemv_bf16(const grove_gemv_params* p, void* stream);
  * with 16-row workgroups for every N (default: 32-row workgroups when N >= 16384 and x is plain — the same results bit for bit);
  * bit 2 (on = 5): the VALU kernel at M = 1 with two rows per wave for N <= 4096 (default: one — the same results). */
 int grove_gemv_set_mfma(int32_t on);
+/* 1 when grove_gemv_bf16 would run `p` on the matrix-core kernel under the current knob (host only; the dispatcher's own predicate, so a
+ * caller that splits rows or un-folds a norm around it cannot disagree with the library). */
+int grove_gemv_uses_mfma(const grove_gemv_params* p);
 
 /* One cached decode step of causal self-attention for ONE new token per sequence (HF LlamaAttention with a KV cache):
  * rotates q and k of the new token in place (rotate-half RoPE at position pos[b], fp32), appends k | v to the cache row
