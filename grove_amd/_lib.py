@@ -157,7 +157,7 @@ class Wino3dParams(C.Structure):
     _fields_ = [("src", c_vp), ("dst", c_vp), ("bias", c_vp), ("residual", c_vp), ("aux", c_vp), ("scale_ptr", c_vp),
                 ("groups", c_i32), ("T", c_i32), ("H", c_i32), ("W", c_i32), ("C", c_i32), ("rows", c_i32),
                 ("ld_src", c_i32), ("ld_dst", c_i32), ("ld_res", c_i32), ("ld_aux", c_i32), ("mode", c_i32), ("act", c_i32), ("scale_tanh", c_i32),
-                ("alpha", c_f32)]
+                ("alpha", c_f32), ("frame_rows", c_i32), ("row_offset", c_i32), ("tiles_ld", c_i32)]
 
 
 class GemmWorkspace(C.Structure):

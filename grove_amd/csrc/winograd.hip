@@ -39,6 +39,12 @@ __device__ __forceinline__ tile_pos tile_of(int tile, int T2, int H2, int W2) {
   return r;
 }
 
+// row of token (g, t, y, x): dense frames of H W rows, or frames of frame_rows rows whose tokens start at row_offset (CLIP's CLS row)
+__device__ __forceinline__ int64_t token_row(const grove_wino3d_params& p, int g, int t, int y, int x) {
+  const int fr = p.frame_rows ? p.frame_rows : p.H * p.W;
+  return (int64_t)(g * p.T + t) * fr + p.row_offset + y * p.W + x;
+}
+
 // one 1-D transform of a line of 4 (in place)
 __device__ __forceinline__ void bt4(float& d0, float& d1, float& d2, float& d3) {
   const float a = d0 - d2, b = d1 + d2, c = d2 - d1, e = d1 - d3;
@@ -71,7 +77,7 @@ __global__ __launch_bounds__(320) void wino3d_tokens_kernel(const grove_wino3d_p
           const int x = 2 * tp.tx - 1 + k;
           unsigned u = 0;  // (the tests are block-uniform: scalar branches)
           if ((unsigned)t < (unsigned)p.T && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W)
-            u = src[(int64_t)(((tp.g * p.T + t) * p.H + y) * p.W + x) * lds];
+            u = src[token_row(p, tp.g, t, y, x) * lds];
           v[i][j][k][0] = bf_lo(u), v[i][j][k][1] = bf_hi(u);
         }
       }
@@ -99,7 +105,7 @@ __global__ __launch_bounds__(320) void wino3d_tokens_kernel(const grove_wino3d_p
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-          const unsigned u = src[(int64_t)(((tp.g * p.T + 2 * tp.tt + i) * p.H + 2 * tp.ty + j) * p.W + 2 * tp.tx + k) * lds];
+          const unsigned u = src[token_row(p, tp.g, 2 * tp.tt + i, 2 * tp.ty + j, 2 * tp.tx + k) * lds];
           d[i][j][k][0] = bf_lo(u), d[i][j][k][1] = bf_hi(u);
         }
     // A = [1 0; 1 1; 1 -1; 0 -1] along x, then y, then t
@@ -130,7 +136,7 @@ __global__ __launch_bounds__(320) void wino3d_tokens_kernel(const grove_wino3d_p
     }
   }
   unsigned* __restrict__ dst = (unsigned*)p.dst + (int64_t)tile * (p.ld_dst >> 1) + cp;
-  const int64_t ps = (int64_t)tiles * (p.ld_dst >> 1);  // dwords per transform point
+  const int64_t ps = (int64_t)(p.tiles_ld ? p.tiles_ld : tiles) * (p.ld_dst >> 1);  // dwords per transform point
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -204,7 +210,7 @@ __global__ __launch_bounds__(320) void wino3d_output_kernel(const grove_wino3d_p
   if (tile >= tiles) return;
   const tile_pos tp = tile_of(tile, T2, H2, W2);
   const unsigned* __restrict__ src = (const unsigned*)p.src + (int64_t)tile * (p.ld_src >> 1) + cp;
-  const int64_t ps = (int64_t)tiles * (p.ld_src >> 1);
+  const int64_t ps = (int64_t)(p.tiles_ld ? p.tiles_ld : tiles) * (p.ld_src >> 1);
   float m[4][4][4][2];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -254,7 +260,7 @@ __global__ __launch_bounds__(320) void wino3d_output_kernel(const grove_wino3d_p
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
-        const int64_t row = ((tp.g * p.T + 2 * tp.tt + i) * p.H + 2 * tp.ty + j) * p.W + 2 * tp.tx + k;
+        const int64_t row = token_row(p, tp.g, 2 * tp.tt + i, 2 * tp.ty + j, 2 * tp.tx + k);
         float v0 = y[i][j][k][0] + b0, v1 = y[i][j][k][1] + b1;
         if (p.aux) ((unsigned*)p.aux)[row * (p.ld_aux >> 1) + cp] = pack2bf(v0, v1);
         v0 = act_apply(p.act, v0) * scale, v1 = act_apply(p.act, v1) * scale;
@@ -345,7 +351,11 @@ inline int check_geometry(const grove_wino3d_params* p, const char* who, long* t
   GROVE_CHECK(p->groups > 0 && p->T > 0 && p->H > 0 && p->W > 0 && p->T % 2 == 0 && p->H % 2 == 0 && p->W % 2 == 0, GROVE_E_SHAPE,
               "%s: groups=%d and even T, H, W needed (got %d, %d, %d)", who, p->groups, p->T, p->H, p->W);
   *tiles = (long)p->groups * (p->T / 2) * (p->H / 2) * (p->W / 2);
-  GROVE_CHECK((long)p->groups * p->T * p->H * p->W < (1L << 31) && *tiles * 64 < (1L << 31), GROVE_E_SHAPE, "%s: too many rows", who);
+  GROVE_CHECK(p->frame_rows == 0 || (p->frame_rows >= p->row_offset + p->H * p->W && p->row_offset >= 0), GROVE_E_SHAPE,
+              "%s: frame_rows=%d must hold row_offset=%d + H W tokens", who, p->frame_rows, p->row_offset);
+  GROVE_CHECK(p->tiles_ld == 0 || p->tiles_ld >= *tiles, GROVE_E_SHAPE, "%s: tiles_ld=%d < %ld tiles", who, p->tiles_ld, *tiles);
+  const long fr = p->frame_rows ? p->frame_rows : (long)p->H * p->W, tl = p->tiles_ld ? p->tiles_ld : *tiles;
+  GROVE_CHECK((long)p->groups * p->T * fr < (1L << 31) && tl * 64 < (1L << 31), GROVE_E_SHAPE, "%s: too many rows", who);
   return GROVE_OK;
 }
 inline dim3 tile_grid(int C, int block, long tiles) {

@@ -59,6 +59,10 @@ class ClipTower:
                 A["w"] = sd[p + "conv3d.weight"].permute(0, 2, 3, 4, 1).reshape(C, 27 * C).contiguous()
                 A["b"] = sd[p + "conv3d.bias"]
             self.adapters.append(A)
+        # round 6: active adapters (alpha != 0: trained checkpoints) in Winograd F(2x2x2, 3x3x3) form like SAM's (csrc/winograd.hip): the
+        # 16 x 36 grid of a frame's 576 patch rows behind its CLS row, groups of 8 frames; the tower is frozen, so the transformed weights
+        # are made once. GROVE_CLIP_WINOGRAD=0: the 27-tap implicit GEMM.
+        self.wino = os.environ.get("GROVE_CLIP_WINOGRAD", "1") != "0" and C % 64 == 0 and (d.clip_tokens - 1) % 32 == 0
         self._idx = {}
 
     def _indices(self, F):
@@ -123,8 +127,11 @@ class ClipTower:
                     # the adapter's own contribution tanh(alpha) * relu(conv + b) becomes the next pending branch output (CLS rows: 0)
                     ops.stream_add(res, t, res_bf16=x)
                     t = torch.zeros_like(x)
-                    ops.linear(x, A["w"], A["b"], act=ops.ACT_RELU, scale_ptr=A["alpha"], scale_tanh=True, a_idx=conv_idx,
-                               a_taps=27, M=F * n, c_idx=patch_rows, out=t)
+                    if self.wino:
+                        self._adapter_wino(A, x, t, F, n, None)
+                    else:
+                        ops.linear(x, A["w"], A["b"], act=ops.ACT_RELU, scale_ptr=A["alpha"], scale_tanh=True, a_idx=conv_idx,
+                                   a_taps=27, M=F * n, c_idx=patch_rows, out=t)
             if taps is not None and (i + 1) in taps:
                 ops.stream_add(res, t, res_bf16=x)
                 t = None
@@ -134,6 +141,14 @@ class ClipTower:
         else:
             ops.stream_add(res, None, res_bf16=x)
         return x
+
+    def _adapter_wino(self, A, x, out, F, n, residual):
+        """tanh(alpha) relu(Conv3d(x) + b) (+ residual) on the patch rows of `out` (modeling_clip.py:599-611: CLS split off,
+        '(b t) (h w) c -> b c t h w' with t = 8, h = 16, w = n / 16); the CLS rows of `out` are left as they are."""
+        if "U" not in A:
+            A["U"] = ops.wino3d_transform_weight(A["w"])
+        ops.wino3d_conv(x, A["U"], (F // 8, 8, 16, n // 16), out, bias=A["b"], act=ops.ACT_RELU, scale_ptr=A["alpha"], scale_tanh=True,
+                        residual=residual, frames=(n + 1, 1))
 
     def _hidden_states_bf16_stream(self, x, F, upto, taps):
         """The same layers with the residual stream in bf16 (what the reference stores): the residual add rides in the epilogue of the
@@ -159,8 +174,11 @@ class ClipTower:
                 A = self.adapters[i // 3]
                 if A["active"]:
                     y = torch.empty_like(x)
-                    ops.linear(x, A["w"], A["b"], act=ops.ACT_RELU, scale_ptr=A["alpha"], scale_tanh=True, a_idx=conv_idx,
-                               a_taps=27, M=F * n, c_idx=patch_rows, residual=x, out=y)
+                    if self.wino:
+                        self._adapter_wino(A, x, y, F, n, x)
+                    else:
+                        ops.linear(x, A["w"], A["b"], act=ops.ACT_RELU, scale_ptr=A["alpha"], scale_tanh=True, a_idx=conv_idx,
+                                   a_taps=27, M=F * n, c_idx=patch_rows, residual=x, out=y)
                     ops.copy_rows(x, y, F, C, idx_src=cls_dst, idx_dst=cls_dst)
                     x = y
             if taps is not None and (i + 1) in taps:

@@ -215,13 +215,19 @@ def wgrad(dy, x, grad, *, b_idx=None, b_taps=1, scale_ptr=None, scale_tanh=False
 
 
 # ---- Winograd F(2x2x2, 3x3x3) form of the Conv3d adapters (grove_hip.h "grove_wino3d_*"; image_encoder.py:43-59)
-def _wino_params(src, dst, geom, Cc):
+def _wino_params(src, dst, geom, Cc, frames=(0, 0), tiles_ld=0):
     p = _lib.Wino3dParams()
     p.src, p.dst = _p(src), _p(dst)
     p.groups, p.T, p.H, p.W = geom
     p.C = Cc
     p.alpha = 1.0
+    p.frame_rows, p.row_offset = frames
+    p.tiles_ld = tiles_ld
     return p
+
+
+def _wino_rows(geom, frames):
+    return geom[0] * geom[1] * (frames[0] if frames[0] else geom[2] * geom[3])
 
 
 def wino3d_tiles(geom):
@@ -229,16 +235,19 @@ def wino3d_tiles(geom):
     return g * (T // 2) * (H // 2) * (W // 2)
 
 
-def wino3d_transform_tokens(x, geom, mode, out=None):
-    """x bf16 tokens [groups*T*H*W, C] -> bf16 [64, tiles, C]: mode 0 = input tiles (B^T), mode 1 = output-gradient tiles (A)."""
+def wino3d_transform_tokens(x, geom, mode, out=None, frames=(0, 0), tiles_ld=0):
+    """x bf16 tokens [groups*T*H*W, C] -> bf16 [64, tiles, C]: mode 0 = input tiles (B^T), mode 1 = output-gradient tiles (A).
+    frames = (rows per frame, row of a frame's first token): token tensors with extra rows per frame (CLIP's CLS); tiles_ld: rows per
+    transform point of the output (>= tiles: padded so that a point is whole GEMM tiles; the pad rows are left as they are)."""
     _chk_dev(x)
     Cc = x.shape[1]
     tiles = wino3d_tiles(geom)
-    assert x.shape[0] == geom[0] * geom[1] * geom[2] * geom[3] and x.dtype == bf16 and x.stride(1) == 1
+    tl = tiles_ld or tiles
+    assert x.shape[0] == _wino_rows(geom, frames) and x.dtype == bf16 and x.stride(1) == 1
     if out is None:
-        out = torch.empty((64, tiles, Cc), dtype=bf16, device=x.device)
-    assert out.is_contiguous() and out.shape == (64, tiles, Cc)
-    p = _wino_params(x, out, geom, Cc)
+        out = torch.empty((64, tl, Cc), dtype=bf16, device=x.device)
+    assert out.is_contiguous() and out.shape == (64, tl, Cc)
+    p = _wino_params(x, out, geom, Cc, frames, tiles_ld)
     p.ld_src, p.ld_dst, p.mode = x.stride(0), Cc, mode
     _lib.check(_lib.lib().grove_wino3d_transform_tokens(C.byref(p), _stream()), "grove_wino3d_transform_tokens")
     return out
@@ -257,12 +266,13 @@ def wino3d_transform_weight(w, out=None):
     return out
 
 
-def wino3d_output(Mh, geom, out, *, bias=None, act=ACT_NONE, scale_ptr=None, scale_tanh=False, residual=None, aux=None):
-    """Mh bf16 [64, tiles, C] -> out tokens: act((A^T..) Mh + bias) * scale + residual; aux = the pre-activation."""
+def wino3d_output(Mh, geom, out, *, bias=None, act=ACT_NONE, scale_ptr=None, scale_tanh=False, residual=None, aux=None, frames=(0, 0)):
+    """Mh bf16 [64, tiles_ld, C] -> out tokens: act((A^T..) Mh + bias) * scale + residual; aux = the pre-activation. Rows of `out` that
+    are not tokens (frames = (rows per frame, first token row): CLIP's CLS rows) are not touched."""
     _chk_dev(Mh, out)
     Cc = Mh.shape[2]
-    assert Mh.is_contiguous() and Mh.shape[:2] == (64, wino3d_tiles(geom)) and out.shape == (geom[0] * geom[1] * geom[2] * geom[3], Cc)
-    p = _wino_params(Mh, out, geom, Cc)
+    assert Mh.is_contiguous() and Mh.shape[0] == 64 and Mh.shape[1] >= wino3d_tiles(geom) and out.shape == (_wino_rows(geom, frames), Cc)
+    p = _wino_params(Mh, out, geom, Cc, frames, Mh.shape[1] if Mh.shape[1] != wino3d_tiles(geom) else 0)
     p.bias, p.residual, p.aux, p.scale_ptr = _p(bias), _p(residual), _p(aux), _p(scale_ptr)
     p.ld_src, p.ld_dst = Cc, out.stride(0)
     p.ld_res = residual.stride(0) if residual is not None else 0
@@ -284,16 +294,20 @@ def wino3d_wgrad_output(dU, gw, *, scale_ptr=None, scale_tanh=False):
     return gw
 
 
-def wino3d_conv(x, U, geom, out, *, bias=None, act=ACT_NONE, scale_ptr=None, scale_tanh=False, residual=None, aux=None, V=None, keep_V=False):
+def wino3d_conv(x, U, geom, out, *, bias=None, act=ACT_NONE, scale_ptr=None, scale_tanh=False, residual=None, aux=None, V=None, keep_V=False,
+                frames=(0, 0)):
     """out = epilogue(Conv3d 3x3x3 'same' of the token tensor x with the TRANSFORMED weights U [64, Co, Ci]) — transform, ONE grouped GEMM
-    over the 64 transform points, output transform. Returns (out, V) with V the transformed input when keep_V (the weight gradient reads it)."""
+    over the 64 transform points, output transform. Returns (out, V) with V the transformed input when keep_V (the weight gradient reads it).
+    A tile count that is not a multiple of 256 is padded per point (the grouped GEMM's groups are whole 256-row tiles): the pad rows of V
+    are whatever the allocator left — rows of a GEMM do not mix, and the output transform never reads theirs."""
     tiles = wino3d_tiles(geom)
+    tl = pad_to(tiles, 256)
     Co, Ci = U.shape[1], U.shape[2]
     if V is None:
-        V = wino3d_transform_tokens(x, geom, 0)
-    Mh = torch.empty((64, tiles, Co), dtype=bf16, device=x.device)
-    gemm_raw(V, U, Mh, 64 * tiles, Co, Ci, Ci, Ci, Co, b_group=tiles)
-    wino3d_output(Mh, geom, out, bias=bias, act=act, scale_ptr=scale_ptr, scale_tanh=scale_tanh, residual=residual, aux=aux)
+        V = wino3d_transform_tokens(x, geom, 0, frames=frames, tiles_ld=tl if tl != tiles else 0)
+    Mh = torch.empty((64, tl, Co), dtype=bf16, device=x.device)
+    gemm_raw(V, U, Mh, 64 * tl, Co, Ci, Ci, Ci, Co, b_group=tl)
+    wino3d_output(Mh, geom, out, bias=bias, act=act, scale_ptr=scale_ptr, scale_tanh=scale_tanh, residual=residual, aux=aux, frames=frames)
     return out, (V if keep_V else None)
 
 

@@ -763,6 +763,13 @@ typedef struct grove_wino3d_params {
   int32_t ld_src, ld_dst, ld_res, ld_aux; /* row strides in elements (even) */
   int32_t mode, act, scale_tanh;
   float alpha;             /* 0 is NOT special: pass 1 for "no scale" */
+  /* Token tensors whose frames carry extra rows (CLIP: [frames, 1 CLS + 576 patches, C], modeling_clip.py:599-611 splits the CLS row off
+   * and treats the 24 x 24 grid as 16 x 36): token (g, t, y, x) is row (g T + t) * frame_rows + row_offset + y W + x of the token
+   * operands (src of transform_tokens; dst / residual / aux of output). 0 / 0 = dense frames of H W rows. */
+  int32_t frame_rows, row_offset;
+  /* Rows per transform point of the point-major tensor (dst of transform_tokens, src of output): >= tiles, 0 = tiles. A caller pads it to
+   * a multiple of 256 so that every point is whole tiles of the grouped GEMM; the pad rows are never written and never read here. */
+  int32_t tiles_ld;
 } grove_wino3d_params;
 int grove_wino3d_transform_tokens(const grove_wino3d_params* p, void* stream);
 int grove_wino3d_transform_weight(const grove_wino3d_params* p, void* stream);

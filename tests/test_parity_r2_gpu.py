@@ -156,7 +156,7 @@ def test_clip_adapter_alpha_nonzero_full_width(dev):
     sd[k1] = torch.full_like(sd[k1], -0.2)
     sd_dev = {k: v.to(dev).to(bf) for k, v in sd.items()}
     tower = ClipTower(sd_dev, d, dev)
-    assert tower.adapters[0]["active"] and tower.adapters[1]["active"]
+    assert tower.adapters[0]["active"] and tower.adapters[1]["active"] and tower.wino  # (round 6: the Winograd form, 576 tiles padded to 768 per point)
     batch = synthetic_batch(d, B=1, T=8, L=24, n_det=1, seed=8)
     gi = batch.global_enc_images.to(bf)
     pooled, hs = tower.forward(gi.to(dev))
@@ -166,6 +166,9 @@ def test_clip_adapter_alpha_nonzero_full_width(dev):
         pooled_o, hs_o = O.clip_vision_tower(sd_r, d, gi.float())
     assert rel(hs, hs_o[-1]) < 2e-2, "clip hidden[-2]"
     assert rel(pooled, pooled_o) < 2e-2, "pooled features"
+    tower.wino = False  # the 27-tap implicit GEMM it replaces: the same function to a bf16 rounding
+    pooled_d, hs_d = tower.forward(gi.to(dev))
+    assert rel(hs, hs_d) < 1.5e-2 and rel(pooled, pooled_d) < 1.5e-2
 
 
 def test_dense_pe_bf16_default(dev):

@@ -49,6 +49,31 @@ def test_token_transforms_match_the_restatement(dev, geom, C):
         assert rel_rms(out.float(), R.r16(want)) < 2e-3
 
 
+def test_framed_tokens_and_padded_points(dev):
+    """CLIP's layout: frames of 1 CLS row + H W patch rows (frame_rows, row_offset) and a tile count that is not a multiple of the grouped
+    GEMM's 256-row tiles (tiles_ld): the whole convolution against F.conv3d, the CLS rows of the output untouched."""
+    from grove_amd import ops
+    from oracle import winograd_ref as R
+    geom, C = (1, 8, 6, 12), 128          # 4 * 3 * 6 = 72 tiles -> padded to 256 per point
+    g, T, H, W = geom
+    fr = H * W + 1
+    x = rnd(g * T * fr, C, seed=41)
+    w = rnd(C, C, 3, 3, 3, seed=42, scale=0.05)
+    bias = rnd(C, seed=43)
+    wp = w.permute(0, 2, 3, 4, 1).reshape(C, 27 * C).contiguous()
+    patches = x.float().reshape(g * T, fr, C)[:, 1:].reshape(g * T * H * W, C)
+    ref = F.conv3d(R.tokens_to_5d(patches, geom), w.float(), bias.float(), padding=1).permute(0, 2, 3, 4, 1).reshape(g * T, H * W, C)
+    want = x.float().reshape(g * T, fr, C).clone()
+    want[:, 1:] = torch.relu(ref) * math.tanh(0.3) + want[:, 1:]
+    V = ops.wino3d_transform_tokens(x.to(dev), geom, 0, frames=(fr, 1), tiles_ld=256)
+    close(V[:, :72], R.to_point_major(R.input_transform(R.tokens_to_5d(patches, geom))), 2.0 ** -8, "framed input transform")
+    out = x.to(dev).clone()
+    ops.wino3d_conv(x.to(dev), ops.wino3d_transform_weight(wp.to(dev)), geom, out, bias=bias.to(dev), act=ops.ACT_RELU,
+                    scale_ptr=torch.tensor([0.3]).to(dev), scale_tanh=True, residual=x.to(dev), frames=(fr, 1))
+    close(out, want.reshape(-1, C), 1.2e-2, "framed winograd adapter vs conv3d")
+    assert torch.equal(out.cpu().reshape(g * T, fr, C)[:, 0], x.reshape(g * T, fr, C)[:, 0])
+
+
 def test_weight_transform_and_its_adjoint(dev):
     from grove_amd import ops
     from oracle import winograd_ref as R

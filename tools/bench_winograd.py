@@ -9,6 +9,35 @@ from grove_amd.model.indexing import conv3d_gather_index
 dev = torch.device("cuda:0")
 C = int(sys.argv[1]) if len(sys.argv) > 1 else 1280
 geom = (4, 8, 32, 32)
+if len(sys.argv) > 2 and sys.argv[2] == "clip":
+    # the CLIP tower's adapter (modeling_clip.py:599-611) at the bench's 32 frames: forward only, CLS row per frame
+    C, geom, fr = 1024, (4, 8, 16, 36), 577
+    rows = 32 * fr
+    x = torch.randn(rows, C, device=dev).to(torch.bfloat16)
+    w = (torch.randn(C, 27 * C, device=dev) * 0.02).to(torch.bfloat16)
+    b = torch.randn(C, device=dev).to(torch.bfloat16)
+    a = torch.tensor([0.1], device=dev)
+    idx = conv3d_gather_index(4, 8, 16, 36, frame_rows=fr, row_offset=1).to(dev)
+    from grove_amd.model.indexing import frame_rows_index
+    patch_rows = frame_rows_index(32, 576, fr, 1).to(dev)
+    y = torch.zeros_like(x)
+    U = ops.wino3d_transform_weight(w)
+
+    def t_(fn, n=3):
+        best = 1e9
+        for _ in range(3):
+            fn(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) / n * 1e3)
+        return best
+    d_ = t_(lambda: ops.linear(x, w, b, act=ops.ACT_RELU, scale_ptr=a, scale_tanh=True, a_idx=idx, a_taps=27, M=32 * 576, c_idx=patch_rows, out=y))
+    w_ = t_(lambda: ops.wino3d_conv(x, U, geom, y, bias=b, act=ops.ACT_RELU, scale_ptr=a, scale_tanh=True, frames=(fr, 1)))
+    print(f"CLIP adapter, 32 frames x (1 + 16 x 36) rows, C = 1024: direct {d_:.1f} us, winograd {w_:.1f} us")
+    sys.exit(0)
 rows = geom[0] * geom[1] * geom[2] * geom[3]
 tiles = ops.wino3d_tiles(geom)
 bf = torch.bfloat16

@@ -13,3 +13,10 @@ python3 $R/tools/pmc_gemm_traffic.py $O/pmc_fetch $O/pmc_write > $O/pmc_gemm_tra
 timeout 600 python3 $R/tools/bench_flash.py > $O/flash_bench.txt 2>&1; echo flash_rc=$?
 timeout 600 python3 $R/tools/bench_decode.py > $O/decode_bench.json 2> $O/decode.err; echo decode_rc=$?
 ls -la $O | head -30; du -sh $O
+# round 6 additions: config 5 (bf16 / fp8 default policy, alternated), config 2, the Winograd stage bench, the fp8 MLP microbench
+for i in 1 2; do for dt in bf16 fp8; do timeout 600 python3 $R/bench.py --mode infer --frames 32 --dtype $dt --steps 5 --warmup 2 --no_cpu_baseline 2>/dev/null | tail -1 > $O/bench_infer_${dt}_$i.json; done; done; echo infer_rc=$?
+timeout 900 python3 $R/bench.py --mode infer_iground --no_cpu_baseline 2>/dev/null | tail -1 > $O/bench_infer_iground.json; echo iground_rc=$?
+timeout 300 python3 $R/tools/bench_winograd.py > $O/winograd_bench.txt 2>&1; echo wino_rc=$?
+timeout 300 python3 $R/tools/dev/bench_sam_mlp_fp8.py > $O/sam_mlp_fp8_bench.txt 2>&1; echo mlp8_rc=$?
+timeout 600 python3 $R/tools/bench_decode.py 8 > $O/decode_bench_b8.json 2>> $O/decode.err; echo decode8_rc=$?
+ls -la $O | head -40
