@@ -38,6 +38,10 @@ def build(dims, dev, args):
     if getattr(args, "stream", "default") != "default":
         targs.stream_dtype = args.stream
     sd = synthetic_state_dict(dims, device=dev, dtype=torch.bfloat16)
+    if getattr(args, "clip_alpha", 0.0):  # a TRAINED checkpoint's CLIP adapters are active (SURVEY's synthetic weights: alpha = 0, the conv is skipped)
+        for k in sd:
+            if "vision_tower" in k and k.endswith(".alpha"):
+                sd[k] = torch.full_like(sd[k], args.clip_alpha)
     model = T.initialize_model(targs, dims=dims, state_dict=sd, device=dev)
     del sd
     torch.cuda.empty_cache()
@@ -795,6 +799,9 @@ def main():
                     help="N > 1: exchange all gradients after the backward instead of group by group from inside it (exposed-communication A/B)")
     ap.add_argument("--gemm_blocks", type=int, default=0,
                     help="N > 1 A/B: resident blocks of the persistent GEMMs (0 = one per CU); fewer leaves CUs to the overlapped RCCL kernels")
+    ap.add_argument("--clip_alpha", type=float, default=0.0,
+                    help="--mode train: alpha of the CLIP tower's 8 Conv3d adapters (default 0 = SURVEY section 8(d)'s synthetic weights, whose adapters are "
+                         "skipped; a trained checkpoint has them active — NOT the headline configuration, an A/B aid)")
     ap.add_argument("--stream", default="default", choices=["default", "fp32", "bf16"],
                     help="--mode train: residual streams of the three towers (default = bf16, what the reference stores; fp32 = the inference models' form)")
     ap.add_argument("--serial_towers", action="store_true",
