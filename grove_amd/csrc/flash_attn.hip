@@ -933,6 +933,9 @@ extern "C" int grove_flash_attn_bwd(const grove_flash_attn_params* p, void* stre
   hipStream_t s = (hipStream_t)stream;
   GROVE_CHECK(!p->o_map || (g_win_attn && grove_win_attn_applicable(p) && p->q_valid && p->ld_do % 8 == 0), GROVE_E_SHAPE,
               "flash_attn_bwd: o_map (token-order o / d_o) is a window-kernel feature and needs q_valid");
+  GROVE_CHECK(!p->g_tok || (p->o_map && p->pad_k && p->pad_v && p->o_hs > 0 && p->o_hs % 4 == 0), GROVE_E_SHAPE,
+              "flash_attn_bwd: g_tok (token-order dq / dk / dv) needs o_map, o_hs (compact head stride, a multiple of 4) and pad_k / pad_v (gradients of "
+              "padded positions have no row)");
   const bool win = g_win_attn && !p->rope && grove_win_attn_applicable(p) && p->ld_do % 8 == 0 && p->ld_dq % 4 == 0 && p->ld_dk % 4 == 0 && p->ld_dv % 4 == 0 &&
                    ((uintptr_t)p->d_o & 15) == 0 && ((uintptr_t)p->o & 15) == 0;
   GROVE_CHECK(!(p->q_valid || p->pad_k || p->pad_v) || win, GROVE_E_SHAPE,

@@ -105,8 +105,11 @@ __global__ __launch_bounds__(RB_THREADS) void rel_bias_bwd_kernel(const grove_re
   const bool head_ok = fr < p.nh;
   const int hq = min(fr, p.nh - 1);
   const bf16_raw* D = (const bf16_raw*)p.rel + ((int64_t)hq * p.L + q) * p.rel_ld + 8 * g;
-  bf16_raw* DQ = (bf16_raw*)p.dq + (int64_t)q * p.ld_dq + hq * p.hp;
+  // dq rows: (window, position) in the layout of q, or token order through dq_map (compact heads of dq_hs columns)
+  const int32_t* __restrict__ dmap = p.dq_map ? p.dq_map + q : nullptr;
+  bf16_raw* DQ = (bf16_raw*)p.dq + (dmap ? (int64_t)hq * p.dq_hs : (int64_t)q * p.ld_dq + hq * p.hp);
   const int64_t d_step = (int64_t)p.nh * p.L * p.rel_ld, q_step = (int64_t)p.L * p.ld_dq;
+  auto dq_off = [&](int w) -> int64_t { return dmap ? (int64_t)dmap[(int64_t)w * p.L] * p.ld_dq : w * q_step; };
   const unsigned long long live = valid_windows(p, q, w0, w1, lane);
   constexpr int U = 2;  // windows in flight per wave
   for (int w = w0; w < w1; w += U) {
@@ -114,14 +117,16 @@ __global__ __launch_bounds__(RB_THREADS) void rel_bias_bwd_kernel(const grove_re
     bf16x8_t df[U][KB];
     u32x4_t old[U][NP];
     u32x2_t old1[U];
+    int64_t qoff[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int wu = ((live >> (w - w0 + u)) & 1) ? min(w + u, w1 - 1) : w0 + __builtin_ctzll(live);  // (a dead window reads a live one's rows: finite, L2-hot, never stored)
+      qoff[u] = dq_off(wu);
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) df[u][kb] = ld_frag(D + wu * d_step + 32 * kb);
 #pragma unroll
-      for (int s = 0; s < NP; ++s) old[u][s] = *(const u32x4_t*)(DQ + wu * q_step + 32 * s + 8 * g);
-      if (NS) old1[u] = *(const u32x2_t*)(DQ + wu * q_step + 32 * NP + 4 * g);
+      for (int s = 0; s < NP; ++s) old[u][s] = *(const u32x4_t*)(DQ + qoff[u] + 32 * s + 8 * g);
+      if (NS) old1[u] = *(const u32x2_t*)(DQ + qoff[u] + 32 * NP + 4 * g);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -137,7 +142,7 @@ __global__ __launch_bounds__(RB_THREADS) void rel_bias_bwd_kernel(const grove_re
         const u32x4_t o = old[u][s];
         const u32x4_t r = u32x4_t{pack2bf(a0[0] + bf_lo(o.x), a0[1] + bf_hi(o.x)), pack2bf(a0[2] + bf_lo(o.y), a0[3] + bf_hi(o.y)),
                                   pack2bf(a1[0] + bf_lo(o.z), a1[1] + bf_hi(o.z)), pack2bf(a1[2] + bf_lo(o.w), a1[3] + bf_hi(o.w))};
-        if (ok) *(u32x4_t*)(DQ + (w + u) * q_step + 32 * s + 8 * g) = r;
+        if (ok) *(u32x4_t*)(DQ + qoff[u] + 32 * s + 8 * g) = r;
       }
       if (NS) {
         f32x4_t a = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(RB_THREADS) void rel_bias_bwd_kernel(const grove_re
         for (int kb = 0; kb < KB; ++kb) a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rt[2 * NP][kb], df[u][kb], a, 0, 0, 0);
         const u32x2_t o = old1[u];
         const u32x2_t r = u32x2_t{pack2bf(a[0] + bf_lo(o.x), a[1] + bf_hi(o.x)), pack2bf(a[2] + bf_lo(o.y), a[3] + bf_hi(o.y))};
-        if (ok) *(u32x2_t*)(DQ + (w + u) * q_step + 32 * NP + 4 * g) = r;
+        if (ok) *(u32x2_t*)(DQ + qoff[u] + 32 * NP + 4 * g) = r;
       }
     }
   }
@@ -158,6 +163,8 @@ int check(const grove_rel_bias_params* p, const char* name, bool bwd) {
               "%s: hp=%d must be a multiple of 32 up to 128, rel_ld=%d must be 32 or 64", name, p->hp, p->rel_ld);
   GROVE_CHECK(p->hd > 0 && p->hd <= p->hp, GROVE_E_SHAPE, "%s: hd=%d outside (0, hp]", name, p->hd);
   GROVE_CHECK(!p->q_valid || (p->kw > 0 && p->L % p->kw == 0), GROVE_E_SHAPE, "%s: q_valid needs kw (window width) dividing L", name);
+  GROVE_CHECK(!p->dq_map || (bwd && p->q_valid && p->dq_hs >= p->hd && p->dq_hs % 8 == 0 && p->hd % 16 == 0), GROVE_E_SHAPE,
+              "%s: dq_map (token-order dq) needs the backward, q_valid, and compact heads of dq_hs = %d >= hd columns in whole 16-byte pieces", name, p->dq_hs);
   GROVE_CHECK(p->table && p->rel && (bwd ? p->dq != nullptr : p->q != nullptr), GROVE_E_SHAPE, "%s: null operand", name);
   GROVE_CHECK((bwd ? p->ld_dq : p->ld_q) % 8 == 0, GROVE_E_ALIGN, "%s: leading dims must be multiples of 8", name);
   GROVE_CHECK((((uintptr_t)p->table | (uintptr_t)p->rel | (uintptr_t)(bwd ? p->dq : p->q)) & 15) == 0, GROVE_E_ALIGN, "%s: operands must be 16-byte aligned", name);

@@ -415,6 +415,13 @@ __device__ __forceinline__ void store_t(bf16_raw* __restrict__ dst, int ld, int 
   *(u32x2_t*)(r + 80 + g * 4) = u32x2_t{0u, 0u};
 }
 
+// token-order gradient rows (grove_flash_attn_params.g_tok): compact heads, no pad columns
+__device__ __forceinline__ void store_tok(bf16_raw* __restrict__ dst, int ld, int64_t row, const f32x4_t (&acc)[5], int g) {
+  bf16_raw* r = dst + row * ld;
+#pragma unroll
+  for (int dt = 0; dt < 5; ++dt) *(u32x2_t*)(r + dt * 16 + g * 4) = u32x2_t{pack2bf(acc[dt][0], acc[dt][1]), pack2bf(acc[dt][2], acc[dt][3])};
+}
+
 // phase A for NTILE (1 or 2) key tiles kt0, kt0 + 4 of this wave
 template <int NTILE>
 __device__ __forceinline__ void load_kv(KVFrag (&kv)[NTILE], int kt0, const bf16_raw* __restrict__ K, int ld_k, const bf16_raw* __restrict__ V,
@@ -443,7 +450,7 @@ template <int NTILE>
 __device__ __forceinline__ void bwd_keys(const KVFrag (&kv)[NTILE], int kt0,
                                          const char* Qs, const char* dOs, const char* Rs, const float* lse_s, const float* del_s, int L, int nq,
                                          float alpha, int lane, bf16_raw* __restrict__ DK, int ld_dk, bf16_raw* __restrict__ DV, int ld_dv,
-                                         const QList& ql, bool drop_padded) {
+                                         const QList& ql, bool drop_padded, const int32_t* __restrict__ gmap) {
   const int fr = lane & 15, g = lane >> 4;
   const int esw = e_swz(fr);
   constexpr int ntile = NTILE;
@@ -570,8 +577,14 @@ __device__ __forceinline__ void bwd_keys(const KVFrag (&kv)[NTILE], int kt0,
   for (int nj = 0; nj < NTILE; ++nj) {
     const int key = (kt0 + 4 * nj) * 16 + fr;
     if (nj < ntile && key < L && !(drop_padded && !ql.real(key))) {  // (nobody reads dk / dv of a padded position)
-      store_t(DK, ld_dk, key, dk[nj], g);
-      store_t(DV, ld_dv, key, dv[nj], g);
+      if (gmap) {  // token order: the row of this (real) position
+        const int64_t row = gmap[key];
+        store_tok(DK, ld_dk, row, dk[nj], g);
+        store_tok(DV, ld_dv, row, dv[nj], g);
+      } else {
+        store_t(DK, ld_dk, key, dk[nj], g);
+        store_t(DV, ld_dv, key, dv[nj], g);
+      }
     }
   }
 }
@@ -584,7 +597,7 @@ struct QDPair {         // B operands of one pair of 16-query tiles (phase B)
 };
 
 __device__ __forceinline__ void bwd_queries(const QDPair& x, const char* Ks, const char* Vs, const char* Es, int q0, int L, const QList& ql, float alpha,
-                                            int lane, bf16_raw* __restrict__ DQ, int ld_dq, bf16_raw* __restrict__ DR) {
+                                            int lane, bf16_raw* __restrict__ DQ, int ld_dq, bf16_raw* __restrict__ DR, const int32_t* __restrict__ gmap) {
   const int fr = lane & 15, g = lane >> 4;
   const int esw = e_swz(fr);
   const f32x4_t z4 = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -691,7 +704,8 @@ __device__ __forceinline__ void bwd_queries(const QDPair& x, const char* Ks, con
   for (int mi = 0; mi < 2; ++mi) {
     if (q0 + mi * 16 + fr >= ql.nq) continue;
     const int qi = ql.pos(q0 + mi * 16 + fr);
-    store_t(DQ, ld_dq, qi, dq[mi], g);
+    if (gmap) store_tok(DQ, ld_dq, gmap[qi], dq[mi], g);
+    else store_t(DQ, ld_dq, qi, dq[mi], g);
     if (DR) {
       bf16_raw* r = DR + (int64_t)qi * 32;
 #pragma unroll
@@ -764,17 +778,19 @@ __global__ __launch_bounds__(WTHR, 2) void win_attn_bwd_kernel(const grove_flash
   }
   __syncthreads();
   // ---- phase A: dK, dV of this wave's key tiles {w, w+4} and {w+8, w+12}
-  bf16_raw* DK = (bf16_raw*)p.dk + (int64_t)b * p.sdk + h * p.hs;
-  bf16_raw* DV = (bf16_raw*)p.dv + (int64_t)b * p.sdv + h * p.hs;
-  bwd_keys<2>(kv0, wave, Xs, Ys, Rs, lse_s, del_s, L, ql.nq, p.alpha, lane, DK, p.ld_dk, DV, p.ld_dv, ql, PK != nullptr);
+  // g_tok: dq / dk / dv in token order through o_map (compact heads of o_hs columns), like o and d_o
+  const int32_t* gmap = (p.g_tok && omap) ? omap : nullptr;
+  bf16_raw* DK = (bf16_raw*)p.dk + (gmap ? (int64_t)h * ohs : (int64_t)b * p.sdk + h * p.hs);
+  bf16_raw* DV = (bf16_raw*)p.dv + (gmap ? (int64_t)h * ohs : (int64_t)b * p.sdv + h * p.hs);
+  bwd_keys<2>(kv0, wave, Xs, Ys, Rs, lse_s, del_s, L, ql.nq, p.alpha, lane, DK, p.ld_dk, DV, p.ld_dv, ql, PK != nullptr, gmap);
   if (wave == 0) {  // key tiles {8, 12}
     KVFrag kv1[2];
     load_kv<2>(kv1, 8, K, p.ld_k, V, p.ld_v, L, sc, p.rel_kw, p.rel_kh, lane, PK, PV, ql);
-    bwd_keys<2>(kv1, 8, Xs, Ys, Rs, lse_s, del_s, L, ql.nq, p.alpha, lane, DK, p.ld_dk, DV, p.ld_dv, ql, PK != nullptr);
+    bwd_keys<2>(kv1, 8, Xs, Ys, Rs, lse_s, del_s, L, ql.nq, p.alpha, lane, DK, p.ld_dk, DV, p.ld_dv, ql, PK != nullptr, gmap);
   } else {          // key tile 8 + wave
     KVFrag kv1[1];
     load_kv<1>(kv1, 8 + wave, K, p.ld_k, V, p.ld_v, L, sc, p.rel_kw, p.rel_kh, lane, PK, PV, ql);
-    bwd_keys<1>(kv1, 8 + wave, Xs, Ys, Rs, lse_s, del_s, L, ql.nq, p.alpha, lane, DK, p.ld_dk, DV, p.ld_dv, ql, PK != nullptr);
+    bwd_keys<1>(kv1, 8 + wave, Xs, Ys, Rs, lse_s, del_s, L, ql.nq, p.alpha, lane, DK, p.ld_dk, DV, p.ld_dv, ql, PK != nullptr, gmap);
   }
   __syncthreads();
   // ---- phase B: K, V, E replace Q, dO, rel' in LDS; dQ and d rel' of this wave's query-tile pairs
@@ -787,7 +803,7 @@ __global__ __launch_bounds__(WTHR, 2) void win_attn_bwd_kernel(const grove_flash
   dma_image_k(Xs, K, p.ld_k, L, PK, ql, wave, lane);
   dma_image_k(Ys, V, p.ld_v, L, PV, ql, wave, lane);
   build_e(Rs, L, p.rel_kw, p.rel_kh, tid);
-  bf16_raw* DQ = (bf16_raw*)p.dq + (int64_t)b * p.sdq + h * p.hs;
+  bf16_raw* DQ = (bf16_raw*)p.dq + (gmap ? (int64_t)h * ohs : (int64_t)b * p.sdq + h * p.hs);
   bf16_raw* DR = p.drel ? (bf16_raw*)p.drel + bh * 32 : nullptr;
   auto load_x = [&](QDPair& x, int q0, const int* tk) {
     load_qpair(x.q, Q, p.ld_q, REL, q0, ql, sc, fr, g);
@@ -810,7 +826,7 @@ __global__ __launch_bounds__(WTHR, 2) void win_attn_bwd_kernel(const grove_flash
   __syncthreads();
 #pragma nounroll
   for (int q0 = wave * 32; q0 < ql.nq; q0 += 128) {
-    bwd_queries(x, Xs, Ys, Rs, q0, L, ql, p.alpha, lane, DQ, p.ld_dq, DR);
+    bwd_queries(x, Xs, Ys, Rs, q0, L, ql, p.alpha, lane, DQ, p.ld_dq, DR, gmap);
     if (q0 + 128 < ql.nq) load_x(x, q0 + 128, nullptr);
   }
 }

@@ -64,7 +64,7 @@ def attention_fwd(qkv, B, L, H, hs, q_off, k_off, v_off, alpha, *, causal=False,
     return out, ctx
 
 
-def attention_bwd(ctx, qkv, d_out, dqkv, want_drel=False, rope=None):
+def attention_bwd(ctx, qkv, d_out, dqkv, want_drel=False, rope=None, grads_tok=False):
     """d_out: bf16 [B*L, H*hs]. Writes dq/dk/dv into the matching column blocks of dqkv (bf16, same
     layout as qkv; every column of the three blocks is overwritten). Returns drel (f32) if asked.
     rope (ops.rope_table; fused kernels only — the caller checks ctx.flash): dq / dk are un-rotated inside the two backward kernels;
@@ -73,7 +73,7 @@ def attention_bwd(ctx, qkv, d_out, dqkv, want_drel=False, rope=None):
     if ctx.flash:
         return ops.flash_attn_bwd(qkv, ctx.out, d_out, ctx.lse, dqkv, ctx.B, ctx.L, ctx.H, ctx.hs, ctx.q_off, ctx.k_off, ctx.v_off,
                                   ctx.alpha, causal=ctx.causal, kv_len=ctx.kv_len, rel=ctx.rel, rel_hw=ctx.rel_hw, want_drel=want_drel,
-                                  hs_valid=ctx.hs_valid, q_valid=ctx.q_valid, pad_row=ctx.pad_row, o_map=ctx.o_map, rope=ctx_rope)
+                                  hs_valid=ctx.hs_valid, q_valid=ctx.q_valid, pad_row=ctx.pad_row, o_map=ctx.o_map, rope=ctx_rope, grads_tok=grads_tok)
     B, H, L, hs, ld, ld_p = ctx.B, ctx.H, ctx.L, ctx.hs, ctx.ld, ctx.ld_p
     dev = qkv.device
     bf = torch.bfloat16

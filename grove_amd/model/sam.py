@@ -399,17 +399,24 @@ class SamEncoder:
             else:
                 do = ops.linear(dx, Bk["wproj_t"])
             qkv = c["qkv"]
-            dqkv = torch.empty_like(qkv)
-            drel = attention_bwd(c["actx"], qkv, do, dqkv, want_drel=True)
+            # window kernels with token-order o (o_map): dq / dk / dv come back in TOKEN order with compact heads too (round 6), so the qkv
+            # dgrad below is a plain GEMM over the tokens — no gathered rows, no padded-head column map, 58 % of the rows and 5 / 6 of the columns
+            g_tok = (ws > 0 and c["actx"].o_map is not None and c["actx"].pad_row is not None and Bk["maps"] and hd % 16 == 0 and
+                     ops.rel_bias_applicable(nh, hp, Bk["rel_ld"]) and os.environ.get("GROVE_SAM_G_TOKEN", "1") != "0")
+            dqkv = torch.empty((dx.shape[0], 3 * nh * hd), dtype=torch.bfloat16, device=self.dev) if g_tok else torch.empty_like(qkv)
+            drel = attention_bwd(c["actx"], qkv, do, dqkv, want_drel=True, grads_tok=g_tok)
             # dq[(b q), h, :] += d rel'[(b h), q, :] . R_cat[q]  (one GEMM batched over q, accumulating in place)
             L, rel_ld, ldd = c["L"], Bk["rel_ld"], dqkv.stride(0)
             if ops.rel_bias_applicable(nh, hp, rel_ld):
-                ops.rel_bias_bwd(drel, Bk["RcatT"], dqkv, c["nb"], nh, L, hp, self.hd, q_valid=c["actx"].q_valid, kw=Bk["window"])
+                ops.rel_bias_bwd(drel, Bk["RcatT"], dqkv, c["nb"], nh, L, hp, self.hd, q_valid=c["actx"].q_valid, kw=Bk["window"],
+                                 dq_map=c["actx"].o_map if g_tok else None)
             else:
                 hrow = self._head_rows(c["nb"], L)
                 ops.gemm_raw(drel, Bk["RcatT"], dqkv, c["nb"] * nh, hp, rel_ld, L * rel_ld, rel_ld, hp, c_idx=hrow, residual=dqkv, ldr=hp,
                              batch=(L, 1), sA=(rel_ld, 0), sB=(hp * rel_ld, 0), sC=(ldd, 0), sR=(ldd, 0))
-            if ws > 0:  # only the real tokens' rows of d qkv feed norm1
+            if g_tok:
+                dh = ops.linear(dqkv, Bk["wqkv_c_t"])
+            elif ws > 0:  # only the real tokens' rows of d qkv feed norm1
                 if Bk["maps"]:
                     dh = ops.linear(dqkv, Bk["wqkv_c_t"], a_idx=tok2win, a_taps=1, M=dx.shape[0], k_map=(hd, hp - hd))
                 else:

@@ -624,14 +624,21 @@ def rope_table(hd, theta, positions, device):
 
 
 def flash_attn_bwd(qkv, out, d_out, lse, dqkv, B, L, H, hs, q_off, k_off, v_off, alpha, *, causal=False, kv_len=None, rel=None,
-                   rel_hw=(0, 0), want_drel=False, hs_valid=0, q_valid=None, pad_row=None, o_map=None, rope=None):
+                   rel_hw=(0, 0), want_drel=False, hs_valid=0, q_valid=None, pad_row=None, o_map=None, rope=None, grads_tok=False):
+    """grads_tok (window kernels with o_map): dqkv is in TOKEN order with compact heads — [tokens, 3 * H * hs_valid], q | k | v blocks of
+    H * hs_valid columns — instead of the layout of qkv (grove_flash_attn_params.g_tok)."""
     dev = qkv.device
     ld, ldd = qkv.stride(0), dqkv.stride(0)
     delta = torch.empty((B * H, L), dtype=torch.float32, device=dev)
     drel = torch.empty_like(rel) if want_drel else None
     p = _lib.FlashAttnParams()
     p.q, p.k, p.v, p.o, p.d_o = _p(qkv[:, q_off:]), _p(qkv[:, k_off:]), _p(qkv[:, v_off:]), _p(out), _p(d_out)
-    p.dq, p.dk, p.dv = _p(dqkv[:, q_off:]), _p(dqkv[:, k_off:]), _p(dqkv[:, v_off:])
+    if grads_tok:
+        assert o_map is not None and pad_row is not None and hs_valid and dqkv.shape[1] == 3 * H * hs_valid
+        p.dq, p.dk, p.dv = _p(dqkv), _p(dqkv[:, H * hs_valid:]), _p(dqkv[:, 2 * H * hs_valid:])
+        p.g_tok = 1
+    else:
+        p.dq, p.dk, p.dv = _p(dqkv[:, q_off:]), _p(dqkv[:, k_off:]), _p(dqkv[:, v_off:])
     p.lse, p.delta, p.kv_len, p.rel, p.drel = _p(lse), _p(delta), _p(kv_len), _p(rel), _p(drel)
     p.sq = p.sk = p.sv = L * ld
     p.so, p.sdo = L * out.stride(0), L * d_out.stride(0)
@@ -720,8 +727,9 @@ def rel_bias_fwd(q, rcat, nb, nh, L, hp, hd, *, out=None, q_valid=None, kw=0):
     return out
 
 
-def rel_bias_bwd(drel, rcat_t, dq, nb, nh, L, hp, hd, *, q_valid=None, kw=0):
-    """dq[(b q), h, :] += d rel'[(b h), q, :] . rcat[q] in place: rcat_t bf16 [L, hp, rel_ld], dq bf16 [nb*L, ld]."""
+def rel_bias_bwd(drel, rcat_t, dq, nb, nh, L, hp, hd, *, q_valid=None, kw=0, dq_map=None):
+    """dq[(b q), h, :] += d rel'[(b h), q, :] . rcat[q] in place: rcat_t bf16 [L, hp, rel_ld], dq bf16 [nb*L, ld] — or, with dq_map
+    (int32 [nb * L]: (window, position) -> token row), dq in token order with compact heads of hd columns."""
     _chk_dev(drel, rcat_t, dq)
     rel_ld = rcat_t.shape[2]
     assert rcat_t.shape == (L, hp, rel_ld) and rcat_t.is_contiguous() and drel.is_contiguous() and dq.stride(1) == 1
@@ -730,6 +738,9 @@ def rel_bias_bwd(drel, rcat_t, dq, nb, nh, L, hp, hd, *, q_valid=None, kw=0):
     p.q, p.table, p.rel, p.dq = None, _p(rcat_t), _p(drel), _p(dq)
     p.nb, p.nh, p.L, p.hp, p.hd, p.rel_ld, p.ld_q, p.ld_dq = nb, nh, L, hp, hd, rel_ld, 0, dq.stride(0)
     p.q_valid, p.kw = _p(q_valid), kw
+    if dq_map is not None:
+        assert q_valid is not None and dq_map.numel() == nb * L and dq_map.dtype == torch.int32
+        p.dq_map, p.dq_hs = _p(dq_map), hd
     _lib.check(_lib.lib().grove_rel_bias_bwd(C.byref(p), _stream()), "grove_rel_bias_bwd")
     return dq
 

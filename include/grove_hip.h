@@ -408,6 +408,10 @@ typedef struct grove_flash_attn_params {
                        column h * o_hs (o_hs = 0: hs; SAM: 80 — compact heads), row strides ld_o / ld_do, so / sdo unused. window_unpartition
                        (image_encoder.py:356-384) and its backward then need no gather: the projection reads / writes plain matrices */
   int32_t o_hs;
+  int32_t g_tok;  /* backward, window kernels with o_map only (round 6; fills the padding after o_hs): 1 = dq / dk / dv are in TOKEN order too —
+                     the row of (batch b, position i) is o_map[b * Lq + i], head h at column h * o_hs, row strides ld_dq / ld_dk / ld_dv (sdq /
+                     sdk / sdv unused), no pad columns; rows of padded positions do not exist. The qkv dgrad is then a plain GEMM over the
+                     tokens instead of a gathered one over the windowed rows (image_encoder.py:329-353 window_partition's backward). */
   const void* pad_k; const void* pad_v; /* with q_valid, window kernels only: bf16 rows [H*hs] = k / v of a padded position (a zero token's
                        projection = the bias), or NULL. Given, the k / v rows at padded positions are NOT read (the caller need not
                        fill them) and dk / dv there are NOT written */
@@ -465,6 +469,9 @@ typedef struct grove_rel_bias_params {
   const int32_t* q_valid; /* int32 [nb][2] = {vy, vx} or NULL: grove_flash_attn_params.q_valid's rule — positions outside the top-left
                              vy x vx block of window b get no rel row (fwd) and no dq contribution (bwd; their rel rows are not read) */
   int32_t kw;             /* window width (positions per window row); with q_valid only */
+  int32_t dq_hs;          /* bwd with dq_map: column stride between heads of dq (compact heads: hd) */
+  const int32_t* dq_map;  /* bwd (round 6): int32 [nb * L] or NULL. Given, dq is in TOKEN order (grove_flash_attn_params.g_tok): the row of
+                             (window b, position q) is dq_map[b * L + q] (valid wherever q_valid keeps the position), head h at column h * dq_hs */
 } grove_rel_bias_params;
 int grove_rel_bias_fwd(const grove_rel_bias_params* p, void* stream);
 int grove_rel_bias_bwd(const grove_rel_bias_params* p, void* stream);

@@ -1514,6 +1514,15 @@ def test_window_attention_valid_queries(dev, valid):
     dr_t = ops.flash_attn_bwd(holes.to(dev), o_t, do_t, lse_t, dq_t, B, L, H, hs, 0, H * hs, 2 * H * hs, alpha, rel=relp.to(dev),
                               rel_hw=(16, ws), want_drel=True, hs_valid=hd, q_valid=qv, pad_row=pad_row.to(dev), o_map=omap)
     assert torch.equal(dq_t[rd], dq_p[rd]) and torch.equal(dr_t[hm.to(dev)], dr_p[hm.to(dev)]), "backward from token-order o / d_o"
+    # g_tok (round 6): dq / dk / dv in token order with compact heads too — [tokens, q | k | v blocks of H * hd columns] — the same numbers
+    # as the windowed-layout run at the mapped rows, every element of the tensor written (a torch.empty buffer is enough)
+    dg = torch.full((ntok, 3 * H * hd), float("nan"), dtype=bf16, device=dev)
+    dr_g = ops.flash_attn_bwd(holes.to(dev), o_t, do_t, lse_t, dg, B, L, H, hs, 0, H * hs, 2 * H * hs, alpha, rel=relp.to(dev),
+                              rel_hw=(16, ws), want_drel=True, hs_valid=hd, q_valid=qv, pad_row=pad_row.to(dev), o_map=omap, grads_tok=True)
+    assert torch.equal(dr_g[hm.to(dev)], dr_p[hm.to(dev)])
+    assert not torch.isnan(dg.float()).any(), "every element of the token-order gradient must be written"
+    want = dq_p[rd].view(ntok, 3, H, hs)[..., :hd]
+    assert torch.equal(dg[sel].view(ntok, 3, H, hd), want), "token-order dq / dk / dv"
 
 
 def test_rel_bias_streams_skip_padded_positions(dev):
@@ -1552,6 +1561,18 @@ def test_rel_bias_streams_skip_padded_positions(dev):
     want = dq0.float().view(nb, L, 3 * nh, hp).clone()
     want[:, :, :nh] += add * mask[:, :, None, None]
     close(dq, want.view(nb * L, ld), 2 ** -7, "dq += d rel' . Rcat at the real positions, untouched elsewhere")
+    # dq_map (round 6): the same accumulation into a TOKEN-order dq with compact heads (row dq_map[(b, q)], head h at column h * hd)
+    ntok = int(mask.sum())
+    tok_of = torch.full((nb * L,), -1, dtype=torch.int32)
+    tok_of[mask.view(-1)] = torch.randperm(ntok, generator=g).to(torch.int32)
+    dt0 = (torch.randn(ntok, 3 * nh * hd, generator=g) * 0.5).to(bf16)
+    dt = dt0.clone().to(dev)
+    ops.rel_bias_bwd(drel.to(dev), rcat_t, dt, nb, nh, L, hp, hd, q_valid=valid.to(dev), kw=size, dq_map=tok_of.to(dev))
+    want_t = dt0.float().clone().view(ntok, 3 * nh, hd)
+    sel = tok_of[mask.view(-1)].long()
+    want_t[sel, :nh] += add.reshape(nb * L, nh, hp)[mask.view(-1)][..., :hd]
+    close(dt, want_t.view(ntok, 3 * nh * hd), 2 ** -7, "token-order dq += d rel' . Rcat")
+    assert torch.equal(dt.cpu().view(ntok, 3 * nh, hd)[:, nh:], dt0.view(ntok, 3 * nh, hd)[:, nh:]), "the k / v blocks are not touched"
 
 
 def test_gemm_stream_k_shape_inside_a_stream_capture(dev):
