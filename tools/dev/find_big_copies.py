@@ -7,12 +7,18 @@ import bench
 from torch.utils._python_dispatch import TorchDispatchMode
 
 
+MIN_MB = int(__import__("os").environ.get("MIN_MB", "32"))
+
+
 class Log(TorchDispatchMode):
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         out = func(*args, **(kwargs or {}))
         outs = out if isinstance(out, (tuple, list)) else (out,)
         for o in outs:
-            if isinstance(o, torch.Tensor) and o.is_cuda and o.numel() * o.element_size() >= (32 << 20) and "empty" not in str(func) and "view" not in str(func) \
+            big = isinstance(o, torch.Tensor) and o.is_cuda and o.numel() * o.element_size() >= (MIN_MB << 20)
+            if "cat" in str(func) and isinstance(o, torch.Tensor) and o.is_cuda:
+                big = True
+            if big and "empty" not in str(func) and "view" not in str(func) \
                     and "as_strided" not in str(func) and "slice" not in str(func) and "select" not in str(func) and "reshape" not in str(func) and "alias" not in str(func) \
                     and "detach" not in str(func) and "unsqueeze" not in str(func) and "permute" not in str(func) and "transpose" not in str(func) and "t.default" not in str(func):
                 fr = [f for f in traceback.extract_stack() if "grove_amd" in f.filename or "bench.py" in f.filename][-3:]
