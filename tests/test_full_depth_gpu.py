@@ -147,6 +147,53 @@ def run_inference_parity(dev, which, outliers=0.0):
     return res
 
 
+def test_full_depth_with_active_clip_adapters(dev):
+    """A TRAINED checkpoint's CLIP adapters are active (alpha != 0; SURVEY's synthetic weights have them at 0 and the conv is skipped):
+    full depth at quarter width with all eight at alpha = 0.1 — 23 layers, 8 Conv3d adapters on the 16 x 36 grid behind the CLS row —
+    against the fp32 oracle, through the Winograd form (round 6: 576 tiles per 8-frame group padded to 768 per transform point) and
+    through the 27-tap implicit GEMM: the visual tokens, the LLaMA state they feed and the boxes."""
+    from grove_amd import GROVEForCausalLM
+    from grove_amd.synthetic import synthetic_batch, synthetic_state_dict
+    from oracle import grove_oracle as O
+    d = deep_narrow_dims()
+    sd_dev = synthetic_state_dict(d, device=dev, dtype=bf)
+    names = [k for k in sd_dev if "vision_tower" in k and k.endswith(".alpha")]
+    assert len(names) == d.clip_layers // 3
+    for k in names:
+        sd_dev[k] = torch.full_like(sd_dev[k], 0.1)
+    sd = {k: v.float().cpu() for k, v in sd_dev.items()}
+    batch = synthetic_batch(d, B=1, T=8, L=128, n_det=3, seed=11)
+    kw = batch.as_kwargs(inference=True)
+    kd = dict(kw)
+    for k in ("global_enc_images", "grounding_enc_images"):
+        kd[k] = kw[k].to(dev).to(bf)
+        kw[k] = kw[k].to(bf).float()
+    for k in ("input_ids", "labels", "attention_masks", "offset"):
+        kd[k] = kw[k].to(dev)
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    with torch.no_grad():
+        ref = O.model_forward(sd, d, **kw)
+        feats_o, _ = O.encode_images(sd, d, kw["global_enc_images"])
+        feats_0, _ = O.encode_images({**sd, **{k: torch.zeros_like(sd[k]) for k in names}}, d, kw["global_enc_images"])
+    assert rel_rms(feats_0, feats_o) > 2e-2, "the adapters must move the visual tokens far beyond the tolerance"
+    res = {}
+    for form in ("winograd", "direct"):
+        model = GROVEForCausalLM(dims=d, device=dev, state_dict=sd_dev, det_token_idx=d.det_token_idx, num_frames=8, pe_dtype=torch.float32)
+        assert all(A["active"] for A in model.clip.adapters) and model.clip.wino
+        model.clip.wino = form == "winograd"
+        out = model(**kd)
+        feats_h, _ = model(mode="encode_images", images=kd["global_enc_images"])
+        res[form] = {"box_l1": (out["flat_boxes"].cpu() - ref["flat_boxes"]).abs().mean().item(), "features_rel_rms": rel_rms(feats_h, feats_o),
+                     "hidden_rel_rms": rel_rms(out["hidden"], ref["hidden"])}
+        del model
+    with open(os.path.join(ROOT, "gpurun_out", "full_depth_active_clip_adapters_deep_narrow.json"), "w") as fh:
+        json.dump(res, fh, indent=1)
+    print(json.dumps(res))
+    for form, r in res.items():
+        assert r["features_rel_rms"] < 1e-2 and r["hidden_rel_rms"] < 1.5e-2 and r["box_l1"] < 1.5e-3, (form, r)
+    assert res["winograd"]["features_rel_rms"] < 1.5 * res["direct"]["features_rel_rms"] + 1e-3, res
+
+
 @pytest.mark.parametrize("which", ["deep_narrow", "full"])
 def test_full_depth_inference_vs_fp32_oracle(dev, which):
     res = run_inference_parity(dev, which)
