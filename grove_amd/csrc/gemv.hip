@@ -245,7 +245,21 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_kernel(const grove_gemv_param
 // x comes from LDS (staged by gemv_stage_x: folded RMSNorm / SwiGLU / fp32 stream input; rows XS = K + 32 elements apart) or, in
 // plain mode, straight from global memory (8 x 11008 bf16 = 176 KB would not fit; it is L2-resident). The four partial 16 x 16
 // tiles meet in LDS; thread (m, n) of the workgroup runs the epilogue of element (sequence m, row n0 + n).
-template <bool X_LDS, int MXS, int NG = 1>  // MXS: rows of x staged in LDS; NG: groups of 16 output rows per workgroup (2: the x fragments feed two MFMAs — half the x traffic per weight byte)
+// PAIR (round 6): the REQUEST SHAPE of the weight loads. The MFMA B operand wants lane (n = lane & 15, g = lane >> 4) to hold row n, k = 8 g .. 8 g + 7
+// of a 32-deep k-step: loaded that way a wave instruction asks for 64 contiguous bytes of each of 16 rows. A stream of such requests
+// runs at 4.4 TB/s where 128 contiguous bytes per row per instruction run at 5.3-5.4 (tools/micro/row_request_shape.hip, the down_proj
+// matrix; lanes of a row need not be neighbours). So a PAIR of k-steps is loaded as two instructions of 8 rows x 128 bytes — lane
+// (g, b = (lane >> 3) & 1, r = lane & 7) takes chunk 4 b + g of row r (R0) and of row 8 + r (R1) — and one exchange between lanes l and
+// l ^ 8 (DPP row_ror:8, no LDS) puts them into operand order: k-step 0 = b ? partner's R1 : R0, k-step 1 = b ? R1 : partner's R0.
+__device__ __forceinline__ unsigned swap8(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false); }
+__device__ __forceinline__ void pair_to_operands(u32x4_t& r0, u32x4_t& r1, bool b) {
+  const u32x4_t send = b ? r0 : r1;
+  const u32x4_t got = u32x4_t{swap8(send.x), swap8(send.y), swap8(send.z), swap8(send.w)};
+  const u32x4_t s0 = b ? got : r0, s1 = b ? r1 : got;
+  r0 = s0, r1 = s1;
+}
+
+template <bool X_LDS, int MXS, int NG = 1, bool PAIR = false>  // MXS: rows of x staged in LDS; NG: groups of 16 output rows per workgroup (2: the x fragments feed two MFMAs — half the x traffic per weight byte)
 __global__ __launch_bounds__(GV_THREADS) void gemv_mfma_kernel(const grove_gemv_params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_raw* xs = (bf16_raw*)smem;
@@ -258,15 +272,34 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_mfma_kernel(const grove_gemv_
   const int kw = K >> 2;                 // this wave's K range (K % 128 == 0)
   const int k_lo = wave * kw;
   const bf16_raw* __restrict__ wrow[NG];
+  const bf16_raw* __restrict__ wrow8[NG];  // PAIR: rows 8 + r
+  const bool pb = (lane >> 3) & 1;
 #pragma unroll
-  for (int q = 0; q < NG; ++q) wrow[q] = (const bf16_raw*)p.W + (int64_t)min(n0 + 16 * q + fr, p.N - 1) * p.ldw + k_lo + g * 8;
+  for (int q = 0; q < NG; ++q) {
+    if constexpr (PAIR) {
+      wrow[q] = (const bf16_raw*)p.W + (int64_t)min(n0 + 16 * q + (lane & 7), p.N - 1) * p.ldw + k_lo + (4 * (int)pb + g) * 8;
+      wrow8[q] = (const bf16_raw*)p.W + (int64_t)min(n0 + 16 * q + 8 + (lane & 7), p.N - 1) * p.ldw + k_lo + (4 * (int)pb + g) * 8;
+    } else {
+      wrow[q] = (const bf16_raw*)p.W + (int64_t)min(n0 + 16 * q + fr, p.N - 1) * p.ldw + k_lo + g * 8;
+      wrow8[q] = wrow[q];
+    }
+  }
   constexpr int U = NG == 1 ? 8 : 4;     // k-steps per trip: NG * U = 8 independent 16-byte weight loads in flight per lane beside the next trip's 8
+  // weight load u of a trip starting at k (PAIR: loads 2 j and 2 j + 1 are the two 8-row halves of k-steps 2 j, 2 j + 1)
+  auto wload = [&](int q, int k, int u) -> u32x4_t {
+    if constexpr (PAIR) {
+      const int ko = k + 64 * (u >> 1);
+      return ko < kw ? __builtin_nontemporal_load((const u32x4_t*)(((u & 1) ? wrow8[q] : wrow[q]) + ko)) : u32x4_t{0u, 0u, 0u, 0u};
+    } else {
+      return (k + u * 32 < kw) ? __builtin_nontemporal_load((const u32x4_t*)(wrow[q] + k + u * 32)) : u32x4_t{0u, 0u, 0u, 0u};
+    }
+  };
   // the first trip of the weight stream starts before the x prologue (it does not depend on x)
   u32x4_t wv[NG][U];
 #pragma unroll
   for (int q = 0; q < NG; ++q)
 #pragma unroll
-    for (int u = 0; u < U; ++u) wv[q][u] = (u * 32 < kw) ? __builtin_nontemporal_load((const u32x4_t*)(wrow[q] + u * 32)) : u32x4_t{0u, 0u, 0u, 0u};
+    for (int u = 0; u < U; ++u) wv[q][u] = wload(q, 0, u);
   if constexpr (X_LDS) gemv_stage_x<MXS>(p, xs, XS, red, tid);
   const bool row_ok = fr < p.M;
   const bf16_raw* __restrict__ xg = (const bf16_raw*)p.x + (int64_t)min(fr, p.M - 1) * p.ldx + k_lo + g * 8;
@@ -287,8 +320,13 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_mfma_kernel(const grove_gemv_
 #pragma unroll
     for (int q = 0; q < NG; ++q)
 #pragma unroll
-      for (int u = 0; u < U; ++u)
-        wn[q][u] = (k + 32 * U + u * 32 < kw) ? __builtin_nontemporal_load((const u32x4_t*)(wrow[q] + k + 32 * U + u * 32)) : z4;
+      for (int u = 0; u < U; ++u) wn[q][u] = wload(q, k + 32 * U, u);
+    if constexpr (PAIR) {
+#pragma unroll
+      for (int q = 0; q < NG; ++q)
+#pragma unroll
+        for (int j = 0; j < U / 2; ++j) pair_to_operands(wv[q][2 * j], wv[q][2 * j + 1], pb);
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -333,6 +371,7 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_mfma_kernel(const grove_gemv_
 
 static int g_gemv_rw1 = 1;  // one output row per wave for N <= 4096 at M = 1 (o_proj 10.9 -> 10.5 us, down 20.4 -> 19.5; bit 2 of grove_gemv_set_mfma clears it)
 static int g_gemv_mfma = 1;
+static int g_gemv_pair = 1;    // 128-byte-per-row weight requests + lane-pair exchange in the plain-x matrix-core launches (grove_gemv_set_mfma bit 3 clears it: the A/B arm; same results bit for bit)
 static int g_gemv_rows32 = 1;  // (grove_gemv_set_mfma bit 1 clears it: 16-row workgroups everywhere, the A/B arm)  // 0 = the VALU kernel for every M (A/B arm: grove_gemv_set_mfma)
 
 template <int MX, int RW>
@@ -361,6 +400,7 @@ extern "C" int grove_gemv_set_mfma(int32_t on) {
   g_gemv_mfma = on != 0;
   g_gemv_rows32 = (on & 2) == 0;
   g_gemv_rw1 = (on & 4) == 0;
+  g_gemv_pair = (on & 8) == 0;
   return GROVE_OK;
 }
 
@@ -395,10 +435,13 @@ extern "C" int grove_gemv_bf16(const grove_gemv_params* pp, void* stream) {
     const dim3 grid((p.N + 15) / 16);
     // the widest projections (gate | up, lm_head: >= 2.7 workgroups of 32 rows per CU): two row groups per workgroup share the x fragments
     // (M = 8, tools/bench_gemv.py 8: N = 22016 44.3 -> 41.2 us, N = 32008 59.9 -> 54.1; N = 12288 = 1.5 workgroups per CU: 24.1 -> 27.9, so not there)
+    const bool pair = plain_x && g_gemv_pair && p.K % 256 == 0;  // (a wave's quarter of K in whole pairs of k-steps)
     if (plain_x && g_gemv_rows32 && p.N >= 16384) {
-      hipLaunchKernelGGL((gemv_mfma_kernel<false, 8, 2>), dim3((p.N + 31) / 32), dim3(GV_THREADS), 0, s, p);
+      if (pair) hipLaunchKernelGGL((gemv_mfma_kernel<false, 8, 2, true>), dim3((p.N + 31) / 32), dim3(GV_THREADS), 0, s, p);
+      else hipLaunchKernelGGL((gemv_mfma_kernel<false, 8, 2>), dim3((p.N + 31) / 32), dim3(GV_THREADS), 0, s, p);
     } else if (plain_x) {
-      hipLaunchKernelGGL((gemv_mfma_kernel<false, 8>), grid, dim3(GV_THREADS), 0, s, p);
+      if (pair) hipLaunchKernelGGL((gemv_mfma_kernel<false, 8, 1, true>), grid, dim3(GV_THREADS), 0, s, p);
+      else hipLaunchKernelGGL((gemv_mfma_kernel<false, 8>), grid, dim3(GV_THREADS), 0, s, p);
     } else {
       static bool attr_set = false;
       if (!attr_set) {

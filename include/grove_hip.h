@@ -529,7 +529,9 @@ int grove_gemv_bf16(const grove_gemv_params* p, void* stream);
  * v_mfma_f32_16x16x32_bf16 per 32-deep k-step: HBM-bound at 8 sequences, where the VALU kernel is compute-bound); 0 = the VALU
  * kernel for every M. fp32 sum order differs between the two (both accumulate in fp32). Bit 1 (on = 3): the matrix-core kernel
  * with 16-row workgroups for every N (default: 32-row workgroups when N >= 16384 and x is plain — the same results bit for bit);
- * bit 2 (on = 5): the VALU kernel at M = 1 with two rows per wave for N <= 4096 (default: one — the same results). */
+ * bit 2 (on = 5): the VALU kernel at M = 1 with two rows per wave for N <= 4096 (default: one — the same results);
+ * bit 3 (on = 9, round 6): the matrix-core kernel's weight loads in MFMA operand shape (64 contiguous bytes per row per instruction; default:
+ * 128 bytes per row per instruction + a lane-pair exchange, the same results bit for bit, 15-20 % more bytes per second). */
 int grove_gemv_set_mfma(int32_t on);
 /* 1 when grove_gemv_bf16 would run `p` on the matrix-core kernel under the current knob (host only; the dispatcher's own predicate, so a
  * caller that splits rows or un-folds a norm around it cannot disagree with the library). */
