@@ -409,7 +409,7 @@ extern "C" int grove_gemv_set_mfma(int32_t on) {
 static bool gemv_takes_mfma(const grove_gemv_params& p) {
   const bool plain_x = p.x_mode == GROVE_GEMV_X_PLAIN && !p.x_f32;
   const size_t mxs = p.M <= 4 ? 4 : 8;
-  return g_gemv_mfma && p.M >= 3 && p.K % 128 == 0 && (p.act != GROVE_ACT_SWIGLU_PAIR || p.N % 16 == 0) && (plain_x || mxs * (p.K + 32) * 2 <= 150 * 1024);
+  return g_gemv_mfma && p.M >= (p.force_mfma ? 1 : 3) && p.K % 128 == 0 && (p.act != GROVE_ACT_SWIGLU_PAIR || p.N % 16 == 0) && (plain_x || mxs * (p.K + 32) * 2 <= 150 * 1024);
 }
 extern "C" int grove_gemv_uses_mfma(const grove_gemv_params* pp) { return pp && gemv_takes_mfma(*pp) ? 1 : 0; }
 

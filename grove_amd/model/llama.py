@@ -8,6 +8,8 @@ so the backward is dgrad only and uses pre-transposed weight copies (HBM is 288 
 W^T buys NT-form GEMMs for every dgrad). Activations of all layers are kept (no recompute).
 Layout: hidden [B*S, H] bf16 row-major, sequence b at rows b*S .. b*S+S-1, right padded.
 """
+import os
+
 import torch
 
 from .. import ops
@@ -28,6 +30,7 @@ class LlamaStack:
         assert not (fp8 and train), "the fp8 path is inference-only"
         assert fp8_policy in ("all", "det16_kv16")
         self.fp8, self.fp8_policy = fp8, fp8_policy
+        self.batch_invariant = os.environ.get("GROVE_DECODE_BATCH_INVARIANT", "0") == "1"  # (set per call by GROVEForCausalLM.generate(batch_invariant=...))
         self.layers = []
         for i in range(d.n_layers):
             p = f"model.layers.{i}."
@@ -265,23 +268,28 @@ class LlamaStack:
         sdt = torch.float32 if f32 else torch.bfloat16
         if f32 and x.dtype != torch.float32:
             x = ops.to_f32(x)
+        # batch-invariant arithmetic (round 6, `self.batch_invariant`: the clip-batched decode of infer_iground): every GEMV on the
+        # matrix-core kernel whatever the number of sequences, and a fixed number of cache splits per head — a sequence's bits do not
+        # depend on which (or how many) other sequences share its step, so batched ids equal the one-at-a-time ids BY CONSTRUCTION
+        bi = self.batch_invariant
+        ns = 8 if bi else None
         for L, kv in zip(self.layers, kv_cache):
-            qkv = ops.gemv(x, L["wqkv"], rms_weight=L["ln1"], eps=d.rms_eps)
-            o = ops.decode_attn(qkv, kv, pos, nh, hd, d.rope_theta, hd ** -0.5)
-            x1 = ops.gemv(o, L["wo"], residual=x, out_dtype=sdt)
+            qkv = ops.gemv(x, L["wqkv"], rms_weight=L["ln1"], eps=d.rms_eps, batch_invariant=bi)
+            o = ops.decode_attn(qkv, kv, pos, nh, hd, d.rope_theta, hd ** -0.5, n_split=ns)
+            x1 = ops.gemv(o, L["wo"], residual=x, out_dtype=sdt, batch_invariant=bi)
             if "wgu_sw" in L and (2 * d.mlp) % 16 == 0:  # SwiGLU in the gate|up GEMV's epilogue (rows interleaved 4 gate / 4 up)
-                a = ops.gemv(x1, L["wgu_sw"], rms_weight=L["ln2"], eps=d.rms_eps, act=ops.ACT_SWIGLU_PAIR)
-                x = ops.gemv(a, L["wd"], residual=x1, out_dtype=sdt)
+                a = ops.gemv(x1, L["wgu_sw"], rms_weight=L["ln2"], eps=d.rms_eps, act=ops.ACT_SWIGLU_PAIR, batch_invariant=bi)
+                x = ops.gemv(a, L["wd"], residual=x1, out_dtype=sdt, batch_invariant=bi)
             else:
-                gu = ops.gemv(x1, L["wgu"], rms_weight=L["ln2"], eps=d.rms_eps)
-                x = ops.gemv(gu, L["wd"], residual=x1, swiglu=True, out_dtype=sdt)
+                gu = ops.gemv(x1, L["wgu"], rms_weight=L["ln2"], eps=d.rms_eps, batch_invariant=bi)
+                x = ops.gemv(gu, L["wd"], residual=x1, swiglu=True, out_dtype=sdt, batch_invariant=bi)
         if f32:
             out = ops.rmsnorm(None, self.norm, d.rms_eps, res=x)
             self.last_decode_hidden_f32 = ops.rmsnorm(None, self.norm, d.rms_eps, res=x, out_dtype=torch.float32)  # the box path's rows
         else:
             out = ops.rmsnorm(x, self.norm, d.rms_eps)
             self.last_decode_hidden_f32 = None
-        logits = ops.gemv(x, lm_head, out_dtype=torch.float32, rms_weight=self.norm, eps=d.rms_eps) if lm_head is not None else None
+        logits = ops.gemv(x, lm_head, out_dtype=torch.float32, rms_weight=self.norm, eps=d.rms_eps, batch_invariant=bi) if lm_head is not None else None
         return out, logits
 
     def decode_step(self, x, t, kv_cache, lm_head=None):

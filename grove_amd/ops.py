@@ -122,6 +122,17 @@ def set_deterministic(on: bool, device=None):
     return prev
 
 
+_stream_k_mode = [int(os.environ.get("GROVE_GEMM_STREAM_K", "1"))]  # what grove_gemm_set_stream_k was last given (the library has no getter)
+
+
+def gemm_set_stream_k(mode: int):
+    """Stream-K tail of the persistent GEMMs: 0 never / 1 where it pays / 2 wherever it applies; returns the previous setting."""
+    prev = _stream_k_mode[0]
+    _lib.check(_lib.lib().grove_gemm_set_stream_k(int(mode)), "grove_gemm_set_stream_k")
+    _stream_k_mode[0] = int(mode)
+    return prev
+
+
 def gemm_set_persistent_blocks(n: int):
     """Resident blocks of the persistent GEMMs (0 = one per CU); returns the previous setting."""
     lib = _lib.lib()
@@ -500,10 +511,12 @@ def flash_attn(qkv, B, L, H, hs, q_off, k_off, v_off, alpha, *, causal=False, kv
 _GEMV_SPLIT_NORM = os.environ.get("GROVE_GEMV_SPLIT_NORM", "1") != "0"  # A/B arm of the batched decode step
 
 
-def gemv(x, w, bias=None, *, act=ACT_NONE, residual=None, out_dtype=bf16, out=None, rms_weight=None, eps=0.0, swiglu=False):
+def gemv(x, w, bias=None, *, act=ACT_NONE, residual=None, out_dtype=bf16, out=None, rms_weight=None, eps=0.0, swiglu=False, batch_invariant=False):
     """y = act(x' @ w.T + bias) + residual for 1..8 rows of x (the cached decode step): the weight-streaming kernel.
     x' = x, or rmsnorm(x) * rms_weight (rms_weight given), or silu(gate) * up of a fused [M, 2K] row (swiglu=True).
-    x and residual may be fp32 (the decode step's fp32 residual stream): norm statistics then run on the fp32 values."""
+    x and residual may be fp32 (the decode step's fp32 residual stream): norm statistics then run on the fp32 values.
+    batch_invariant: the matrix-core kernel for every M (grove_gemv_params.force_mfma): a row's bits do not depend on how many other
+    sequences share the launch."""
     _chk_dev(x, w)
     M = x.shape[0]
     N, K = w.shape
@@ -515,6 +528,7 @@ def gemv(x, w, bias=None, *, act=ACT_NONE, residual=None, out_dtype=bf16, out=No
     q.M, q.N, q.K, q.act = M, N, K, act
     q.x_mode = 2 if swiglu else 1 if rms_weight is not None else 0
     q.x_f32 = int(x.dtype == torch.float32)
+    q.force_mfma = int(batch_invariant)
     mfma = bool(_lib.lib().grove_gemv_uses_mfma(C.byref(q)))
     if mfma and rms_weight is not None and not swiglu and _GEMV_SPLIT_NORM:
         # 3..8 sequences on the matrix-core kernel: a block owns 16 output rows — 128 KB of weights at K = 4096 — and a folded RMSNorm
@@ -523,7 +537,7 @@ def gemv(x, w, bias=None, *, act=ACT_NONE, residual=None, out_dtype=bf16, out=No
         # GEMV on a plain x (round 5, profile of bench.py --mode infer_iground). So the rows are normalised ONCE, by the norm kernel,
         # into M x K bf16 — the rounding the kernel's LDS staging applies anyway — and the GEMV reads them from L2.
         xn = rmsnorm(None, rms_weight, eps, res=x) if x.dtype == torch.float32 else rmsnorm(x, rms_weight, eps)
-        return gemv(xn, w, bias, act=act, residual=residual, out_dtype=out_dtype, out=out)
+        return gemv(xn, w, bias, act=act, residual=residual, out_dtype=out_dtype, out=out, batch_invariant=batch_invariant)
     if mx * K * 2 > 159 * 1024 and M > 4 and not mfma:  # (the matrix-core kernel of 3..8 sequences reads a plain x straight from global memory)
         # the kernel keeps its mx rows of x in LDS (bf16): 8 rows of LLaMA-7B's down-projection input (K = 11008) are 176 KB. Two
         # launches of <= 4 rows each (88 KB): the weight matrix is streamed twice for the 5..8 sequences instead of once — still one
@@ -533,7 +547,7 @@ def gemv(x, w, bias=None, *, act=ACT_NONE, residual=None, out_dtype=bf16, out=No
         for lo in range(0, M, 4):
             hi = min(M, lo + 4)
             gemv(x[lo:hi], w, bias, act=act, residual=(residual[lo:hi] if residual is not None else None), out_dtype=out_dtype,
-                 out=out[lo:hi], rms_weight=rms_weight, eps=eps, swiglu=swiglu)
+                 out=out[lo:hi], rms_weight=rms_weight, eps=eps, swiglu=swiglu, batch_invariant=batch_invariant)
         return out
     if out is None:  # ACT_SWIGLU_PAIR: w rows interleaved [4 gate, 4 up] (swiglu_interleave), the result is silu(gate) * up: N / 2 columns
         out = torch.empty((M, N // 2 if act == ACT_SWIGLU_PAIR else N), dtype=out_dtype, device=x.device)
@@ -548,6 +562,7 @@ def gemv(x, w, bias=None, *, act=ACT_NONE, residual=None, out_dtype=bf16, out=No
     p.x_mode = 2 if swiglu else 1 if rms_weight is not None else 0
     p.x_f32 = int(x.dtype == torch.float32)
     p.res_f32 = int(residual is not None and residual.dtype == torch.float32)
+    p.force_mfma = int(batch_invariant)
     _lib.check(_lib.lib().grove_gemv_bf16(C.byref(p), _stream()), "grove_gemv_bf16")
     return out
 

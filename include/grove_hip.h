@@ -523,6 +523,10 @@ typedef struct grove_gemv_params {
   /* the decode step's residual stream in FP32 (inference models): x is f32 [M, ldx] (x_mode PLAIN / RMSNORM: statistics and
    * normalisation on the fp32 values), residual is f32 [M, ldr]; combine with y_dtype F32 for the stream's next value */
   int32_t x_f32, res_f32;
+  /* 1 = the matrix-core kernel for EVERY M it can take (default: from 3 sequences up; 1 and 2 run the VALU kernel, whose fp32 sum order
+   * is different). A row's result is then the same bits whichever other sequences share its launch: batch-invariant decode (round 6;
+   * one int32 in what was the struct's tail padding). */
+  int32_t force_mfma;
 } grove_gemv_params;
 int grove_gemv_bf16(const grove_gemv_params* p, void* stream);
 /* A/B knob (round 5): 1 (default) = 3..8 sequences with K % 128 == 0 run on the matrix-core kernel (one weight stream feeds one

@@ -147,6 +147,46 @@ def run_inference_parity(dev, which, outliers=0.0):
     return res
 
 
+def test_batched_clips_are_batch_invariant_full_width(dev):
+    """the clip-batched `infer_clips_batched` must return a clip's ids BY CONSTRUCTION, not by luck of the margins.
+    FULL WIDTH (LLaMA 4096 x 2 layers, CLIP 1024 x 3, SAM 1280 x 4 blocks with a global one — the GEMM shapes, tile plans and GEMV
+    kernels of the real model; depth only repeats them): three different clips decoded together, the same clips one at a time, and
+    regrouped — under `model.batch_invariant_mode()` (whole-tile GEMM plans, the matrix-core GEMV and eight K / V splits for every
+    number of sequences) every clip's greedy ids, its generated rows' boxes and its objectness logits are the SAME BITS in all three runs."""
+    import dataclasses
+    from grove_amd import GROVEForCausalLM
+    from grove_amd.infer import infer_clips_batched
+    from grove_amd.synthetic import FULL, synthetic_batch, synthetic_state_dict
+    d = dataclasses.replace(FULL, n_layers=2, clip_layers=4, sam_depth=4, sam_global=(1, 3))
+    sd_dev = synthetic_state_dict(d, device=dev, dtype=bf)
+    sd_dev["model.embed_tokens.weight"] = sd_dev["model.embed_tokens.weight"] * 64.0  # (a stream that walks: see test_full_size_greedy_ids_vs_oracle)
+    model = GROVEForCausalLM(dims=d, device=dev, state_dict=sd_dev, det_token_idx=d.det_token_idx, num_frames=8)
+    del sd_dev
+    clips = []
+    for seed in (31, 32, 33):
+        b = synthetic_batch(d, B=1, T=16, L=24, n_det=2, seed=seed)
+        clips.append((b.global_enc_images.to(bf), b.grounding_enc_images.to(bf), b.original_size_list[0]))
+    prompt = synthetic_batch(d, B=1, T=16, L=24, n_det=2, seed=31).input_ids[0, :20].clone()
+    new = 12
+    together = infer_clips_batched(model, clips, prompt, max_tokens_new=new)
+    alone = [infer_clips_batched(model, [c], prompt, max_tokens_new=new)[0] for c in clips]
+    regrouped = infer_clips_batched(model, [clips[2], clips[0]], prompt, max_tokens_new=new)
+    ids = [r["output_ids"] for r in together]
+    assert len({tuple(i.tolist()) for i in ids}) == 3 and all(len(set(i.tolist()[-new:])) >= 4 for i in ids), ids  # three different walks
+    for n, (a, b_) in enumerate(list(zip(together, alone)) + [(together[2], regrouped[0]), (together[0], regrouped[1])]):
+        assert torch.equal(a["output_ids"], b_["output_ids"]), (n, a["output_ids"], b_["output_ids"])
+        for f in range(len(a["pred_bboxes"])):
+            assert torch.equal(a["pred_bboxes"][f].cpu(), b_["pred_bboxes"][f].cpu()), (n, f)
+            la, lb = a["logits_temp_objectness"][f], b_["logits_temp_objectness"][f]
+            assert (la is None and lb is None) or torch.equal(la.cpu(), lb.cpu()), (n, f)
+    # without the mode the same call is allowed to differ in the last bits (other tile plans, other GEMV kernel) — it must still agree closely
+    loose = infer_clips_batched(model, clips, prompt, max_tokens_new=new, batch_invariant=False)
+    for a, b_ in zip(together, loose):
+        for f in range(len(a["pred_bboxes"])):
+            if a["pred_bboxes"][f].shape == b_["pred_bboxes"][f].shape and a["pred_bboxes"][f].numel():
+                assert (a["pred_bboxes"][f].float().cpu() - b_["pred_bboxes"][f].float().cpu()).abs().max().item() / 640 < 5e-3
+
+
 def test_full_depth_with_active_clip_adapters(dev):
     """A TRAINED checkpoint's CLIP adapters are active (alpha != 0; SURVEY's synthetic weights have them at 0 and the conv is skipped):
     full depth at quarter width with all eight at alpha = 0.1 — 23 layers, 8 Conv3d adapters on the 16 x 36 grid behind the CLS row —
