@@ -718,6 +718,11 @@ def infer_iground_bench(args, dev, dims, world=1, rank=0):
         for x, y in zip(a["pred_bboxes"], b_["pred_bboxes"]):
             if x.shape == y.shape and x.numel():
                 box_diff = max(box_diff, float((x.float().cpu() - y.float().cpu()).abs().max()) / max(sz))
+    # by construction (round 6): the batched run is batch-invariant (infer_clips_batched's default, model.batch_invariant_mode) — every clip
+    # alone, as a batch of ONE under the same mode, must return the same ids and the same boxes bit for bit
+    ones = [infer_clips_batched(model, [c], prompt, max_tokens_new=new)[0] for c in clips[:min(N, 3)]]
+    invariant = all(torch.equal(a["output_ids"], b_["output_ids"]) and
+                    all(torch.equal(x.cpu(), y.cpu()) for x, y in zip(a["pred_bboxes"], b_["pred_bboxes"])) for a, b_ in zip(res_b, ones))
     stages = {}
     run_batched(stages)  # one extra pass with a device sync around every stage: the breakdown (not part of the timed region)
     # decode alone at the batch the job decodes at: per-token time and the weight stream's share of the HBM peak
@@ -749,6 +754,7 @@ def infer_iground_bench(args, dev, dims, world=1, rank=0):
                        "parallelism": f"dp{world} (replicas only: clips sharded over ranks)", "ranks": world,
                        "clips_per_s": round(world * N * args.steps / dt_b, 3), "clips_per_s_batch1_reference_form": round(world * N * args.steps / dt_1, 3),
                        "speedup_over_batch1": round(dt_1 / dt_b, 3), "ids_equal_to_batch1": bool(same_ids), "max_box_diff_vs_batch1_normalised": box_diff,
+                       "batch_invariant": True, "bit_identical_to_one_clip_batches": bool(invariant),
                        "stage_seconds_per_step_batched": {k: round(v, 4) for k, v in stages.items()},
                        "stage_note": "encode = CLIP + SAM towers of the centre windows; evaluate = prefill + greedy decode + box decoder; windows = the other windows' "
                                      "forward (all clips of a batch in one launch sequence); measured in one extra pass with device syncs around the stages"},
