@@ -222,7 +222,7 @@ def _to_host(x):
 
 @torch.no_grad()
 def infer_dataset(model, clips, prompt_ids, *, rank=None, world=None, max_tokens_new=64, answer_ids_fn=None, token_embeddings=None,
-                  num_segments=8, gather=True, on_clip=None, clips_per_batch=1):
+                  num_segments=8, gather=True, on_clip=None, clips_per_batch=None):
     """The multi-rank inference job of infer_iground.py:150-293, 538-551: `clips` is an indexable dataset whose item i is
     (clip_id, global_enc_images_all [1, 3, F, 336, 336], grounding_enc_images_all [1, 3, F, 512, 512], original_size) — or a callable
     `clips.load(i)` style object with `__len__` / `__getitem__`; every rank takes the clip indices `shard_clips(len(clips), rank, world)`
@@ -231,7 +231,12 @@ def infer_dataset(model, clips, prompt_ids, *, rank=None, world=None, max_tokens
     there is no data-path collective, the gather moves the (host) results once at the end. Without an initialised process group
     (or world == 1) it is the plain loop. Returns the merged dict (every rank holds it; the reference pickles rank 0's).
     clips_per_batch > 1 (<= 8): this rank's clips go through `infer_clips_batched` in groups of that many with equal frame counts —
-    the MI355X-first form of the job (one weight stream per generated token for the whole group)."""
+    the MI355X-first form of the job (one weight stream per generated token for the whole group). Default (None, round 6): 8 for a
+    GROVEForCausalLM — the batched form is batch-invariant (`model.batch_invariant_mode`): a clip's ids and boxes do not depend on its
+    group, so the grouping is a throughput choice, not a numerical one — and 1 (the reference's per-clip form, `infer_clip`) for any other
+    model object."""
+    if clips_per_batch is None:
+        clips_per_batch = 8 if hasattr(model, "batch_invariant_mode") else 1
     import torch.distributed as dist
     from .train import shard_clips
     if world is None:

@@ -276,8 +276,17 @@ def test_inference_job_over_a_clip_list_matches_per_clip_driver(setup, dev):
         clips.append((f"vid{seed}", b.global_enc_images.to(bf), b.grounding_enc_images.to(bf), b.original_size_list[0]))
     prompt = synthetic_batch(d, B=1, T=16, L=24, n_det=2, seed=11).input_ids[0, :20].clone()
     seen = []
-    res = infer_dataset(model, clips, prompt, max_tokens_new=3, on_clip=lambda cid, r: seen.append(cid))
+    res = infer_dataset(model, clips, prompt, max_tokens_new=3, on_clip=lambda cid, r: seen.append(cid), clips_per_batch=1)  # the reference's per-clip form
     assert sorted(res) == ["vid11", "vid12"] and seen == ["vid11", "vid12"]
+    # the DEFAULT since round 6: groups of up to 8 clips under model.batch_invariant_mode — a clip's result is the same bits as from a batch of one
+    from grove_amd.infer import infer_clips_batched
+    res8 = infer_dataset(model, clips, prompt, max_tokens_new=3)
+    for cid, g_all, s_all, size in clips:
+        alone = infer_clips_batched(model, [(g_all, s_all, size)], prompt, max_tokens_new=3)[0]
+        assert torch.equal(res8[cid]["output_ids"], alone["output_ids"].cpu())
+        for f in range(16):
+            assert torch.equal(res8[cid]["pred_bboxes"][f], alone["pred_bboxes"][f].cpu()) and \
+                torch.equal(res8[cid]["logits_temp_objectness"][f], alone["logits_temp_objectness"][f].cpu())
     for cid, g_all, s_all, size in clips:
         one = infer_clip(model, g_all.to(dev), s_all.to(dev), prompt, size, max_tokens_new=3)
         r = res[cid]
