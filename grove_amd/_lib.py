@@ -119,7 +119,8 @@ class FlashAttnParams(C.Structure):
 class GemvParams(C.Structure):
     _fields_ = [("x", c_vp), ("W", c_vp), ("y", c_vp), ("bias", c_vp), ("residual", c_vp), ("norm_weight", c_vp),
                 ("M", c_i32), ("N", c_i32), ("K", c_i32), ("ldx", c_i32), ("ldw", c_i32), ("ldy", c_i32), ("ldr", c_i32),
-                ("act", c_i32), ("y_dtype", c_i32), ("x_mode", c_i32), ("eps", c_f32), ("x_f32", c_i32), ("res_f32", c_i32), ("force_mfma", c_i32)]
+                ("act", c_i32), ("y_dtype", c_i32), ("x_mode", c_i32), ("eps", c_f32), ("x_f32", c_i32), ("res_f32", c_i32), ("force_mfma", c_i32),
+                ("xs_out", c_vp), ("xs_weight", c_vp), ("ssq_out", c_vp), ("ssq_in", c_vp), ("ssq_in_blocks", c_i32), ("ld_xs", c_i32)]
 
 
 class DecodeAttnParams(C.Structure):

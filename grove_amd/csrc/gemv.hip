@@ -345,15 +345,26 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_mfma_kernel(const grove_gemv_
   __syncthreads();
   const int m = tid >> 4, n = tid & 15;
   if (m >= p.M) return;
+  // DEFERRED RMSNorm (round 6, plain x only): x is bf16(stream * norm weight) written by the producer launch (xs_out below) and the
+  // row's rsqrt(mean(stream^2) + eps) multiplies the PRODUCT here: rstd = rsqrt(sum of the producer's per-workgroup partial sums / K + eps),
+  // summed in a fixed order (16 lanes x blocks / 16 terms each, then the 16 lanes) — the 64 norm launches of a decode step are gone.
+  float rstd = 1.f;
+  if (!X_LDS && p.ssq_in) {
+    float sacc = 0.f;
+    for (int b = n; b < p.ssq_in_blocks; b += 16) sacc += p.ssq_in[(int64_t)b * 8 + m];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o, 16);
+    rstd = rsqrtf(sacc / (float)p.K + p.eps);
+  }
 #pragma unroll
   for (int q = 0; q < NG; ++q) {
     const int nn = n0 + 16 * q + n;
-    if (nn >= p.N) continue;
-    float v = (part[q][0][m][n] + part[q][1][m][n]) + (part[q][2][m][n] + part[q][3][m][n]);
+    const bool live = nn < p.N;
+    float v = live ? ((part[q][0][m][n] + part[q][1][m][n]) + (part[q][2][m][n] + part[q][3][m][n])) * rstd : 0.f;
     if (p.act == GROVE_ACT_SWIGLU_PAIR) {
       // W rows interleaved [4 gate, 4 up] per 8 (ops.swiglu_interleave): row n (n & 4 == 0) is a gate row, row n + 4 its up row
-      if (n & 4) continue;
-      const float u_ = (part[q][0][m][n + 4] + part[q][1][m][n + 4]) + (part[q][2][m][n + 4] + part[q][3][m][n + 4]);
+      if (!live || (n & 4)) continue;
+      const float u_ = ((part[q][0][m][n + 4] + part[q][1][m][n + 4]) + (part[q][2][m][n + 4] + part[q][3][m][n + 4])) * rstd;
       const float gt = bf2f(f2bf(v)), up = bf2f(f2bf(u_));
       const float o = gt * fast_sigmoid(gt) * up;
       const int col = (nn >> 3) * 4 + (n & 3);
@@ -361,11 +372,22 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_mfma_kernel(const grove_gemv_
       else ((float*)p.y)[(int64_t)m * p.ldy + col] = o;
       continue;
     }
-    if (p.bias) v += bf2f(((const bf16_raw*)p.bias)[nn]);
-    v = act_apply(p.act, v);
-    if (p.residual) v += p.res_f32 ? ((const float*)p.residual)[(int64_t)m * p.ldr + nn] : bf2f(((const bf16_raw*)p.residual)[(int64_t)m * p.ldr + nn]);
-    if (p.y_dtype == GROVE_BF16) ((bf16_raw*)p.y)[(int64_t)m * p.ldy + nn] = f2bf(v);
-    else ((float*)p.y)[(int64_t)m * p.ldy + nn] = v;
+    if (live) {
+      if (p.bias) v += bf2f(((const bf16_raw*)p.bias)[nn]);
+      v = act_apply(p.act, v);
+      if (p.residual) v += p.res_f32 ? ((const float*)p.residual)[(int64_t)m * p.ldr + nn] : bf2f(((const bf16_raw*)p.residual)[(int64_t)m * p.ldr + nn]);
+      if (p.y_dtype == GROVE_BF16) ((bf16_raw*)p.y)[(int64_t)m * p.ldy + nn] = f2bf(v);
+      else ((float*)p.y)[(int64_t)m * p.ldy + nn] = v;
+    }
+    if (!X_LDS && p.ssq_out) {
+      // the producer side of the deferred norm: the NEXT norm's input is the value just stored (the residual stream); its weighted bf16
+      // rounding goes to xs_out, and this workgroup's sum of squares over its 16 columns of row m to ssq_out[16-row group][m]
+      if (live && p.xs_out) ((bf16_raw*)p.xs_out)[(int64_t)m * p.ld_xs + nn] = f2bf(v * bf2f(((const bf16_raw*)p.xs_weight)[nn]));
+      float sq = live ? v * v : 0.f;
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 16);
+      if (n == 0) p.ssq_out[(int64_t)((n0 >> 4) + q) * 8 + m] = sq;
+    }
   }
 }
 
@@ -420,6 +442,11 @@ extern "C" int grove_gemv_bf16(const grove_gemv_params* pp, void* stream) {
   GROVE_CHECK(p.N > 0 && p.K > 0 && p.K % 8 == 0, GROVE_E_SHAPE, "gemv: N=%d K=%d (K must be a multiple of 8)", p.N, p.K);
   const bool plain_x = p.x_mode == GROVE_GEMV_X_PLAIN && !p.x_f32;
   const bool mfma = gemv_takes_mfma(p);
+  GROVE_CHECK(!(p.ssq_in || p.ssq_out) || (mfma && plain_x), GROVE_E_SHAPE,
+              "gemv: the deferred RMSNorm (ssq_in / ssq_out) exists in the matrix-core kernel with a plain bf16 x only (K %% 128 == 0, M >= 3 or force_mfma)");
+  GROVE_CHECK(!p.ssq_out || (p.act != GROVE_ACT_SWIGLU_PAIR && (!p.xs_out || (p.xs_weight && p.ld_xs >= p.N))), GROVE_E_SHAPE,
+              "gemv: ssq_out / xs_out describe the value stored to y (no SWIGLU_PAIR); xs_out needs xs_weight and ld_xs >= N");
+  GROVE_CHECK(!p.ssq_in || p.ssq_in_blocks > 0, GROVE_E_SHAPE, "gemv: ssq_in needs ssq_in_blocks (the producer's N / 16, rounded up)");
   GROVE_CHECK(mfma || (size_t)(p.M <= 2 ? p.M : p.M <= 4 ? 4 : 8) * p.K * 2 <= 159 * 1024, GROVE_E_SHAPE, "gemv: M*K=%d*%d does not fit the LDS", p.M, p.K);
   GROVE_CHECK(p.ldx % 8 == 0 && p.ldw % 8 == 0, GROVE_E_ALIGN, "gemv: ldx=%d ldw=%d must be multiples of 8", p.ldx, p.ldw);
   GROVE_CHECK(!p.x_f32 || p.x_mode != GROVE_GEMV_X_SWIGLU, GROVE_E_DTYPE, "gemv: x_mode swiglu reads a bf16 gate|up row");

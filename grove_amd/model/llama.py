@@ -30,6 +30,7 @@ class LlamaStack:
         assert not (fp8 and train), "the fp8 path is inference-only"
         assert fp8_policy in ("all", "det16_kv16")
         self.fp8, self.fp8_policy = fp8, fp8_policy
+        self.defer_norm = os.environ.get("GROVE_DECODE_DEFER_NORM", "1") != "0"  # A/B knob of the deferred RMSNorm in the batched decode step
         self.batch_invariant = os.environ.get("GROVE_DECODE_BATCH_INVARIANT", "0") == "1"  # (set per call by GROVEForCausalLM.generate(batch_invariant=...))
         self.layers = []
         for i in range(d.n_layers):
@@ -273,6 +274,28 @@ class LlamaStack:
         # depend on which (or how many) other sequences share its step, so batched ids equal the one-at-a-time ids BY CONSTRUCTION
         bi = self.batch_invariant
         ns = 8 if bi else None
+        B = x.shape[0]
+        # Deferred RMSNorm (round 6): when every GEMV of the step runs on the matrix-core kernel (3..8 sequences, or any number in the
+        # batch-invariant mode), o_proj / down_proj leave bf16(stream * next norm weight) and their per-workgroup sums of squares, and the
+        # q|k|v / gate|up / lm_head launches scale their product by the row's rstd: 64 of the step's 67 norm launches disappear
+        # (grove_gemv_params.xs_out / ssq_in; the step keeps one norm for the first layer's input and the two that PRODUCE the final hidden rows)
+        deferred = (f32 and (bi or B >= 3) and self.defer_norm and d.hidden % 128 == 0 and d.mlp % 128 == 0 and (2 * d.mlp) % 16 == 0 and
+                    all("wgu_sw" in L for L in self.layers))
+        if deferred:
+            nl = len(self.layers)
+            xs = ops.rmsnorm(None, self.layers[0]["ln1"], d.rms_eps, res=x)  # layer 0's input: the one norm launch of the layers
+            ssq = None
+            for i, (L, kv) in enumerate(zip(self.layers, kv_cache)):
+                qkv = ops.gemv(xs, L["wqkv"], batch_invariant=bi, norm_in=(ssq, d.rms_eps) if ssq is not None else None)
+                o = ops.decode_attn(qkv, kv, pos, nh, hd, d.rope_theta, hd ** -0.5, n_split=ns)
+                x1, xs2, ssq2 = ops.gemv(o, L["wo"], residual=x, out_dtype=sdt, batch_invariant=bi, norm_out=L["ln2"])
+                a = ops.gemv(xs2, L["wgu_sw"], act=ops.ACT_SWIGLU_PAIR, batch_invariant=bi, norm_in=(ssq2, d.rms_eps))
+                nxt = self.layers[i + 1]["ln1"] if i + 1 < nl else self.norm
+                x, xs, ssq = ops.gemv(a, L["wd"], residual=x1, out_dtype=sdt, batch_invariant=bi, norm_out=nxt)
+            out = ops.rmsnorm(None, self.norm, d.rms_eps, res=x)
+            self.last_decode_hidden_f32 = ops.rmsnorm(None, self.norm, d.rms_eps, res=x, out_dtype=torch.float32)  # the box path's rows
+            logits = ops.gemv(xs, lm_head, out_dtype=torch.float32, batch_invariant=bi, norm_in=(ssq, d.rms_eps)) if lm_head is not None else None
+            return out, logits
         for L, kv in zip(self.layers, kv_cache):
             qkv = ops.gemv(x, L["wqkv"], rms_weight=L["ln1"], eps=d.rms_eps, batch_invariant=bi)
             o = ops.decode_attn(qkv, kv, pos, nh, hd, d.rope_theta, hd ** -0.5, n_split=ns)

@@ -511,12 +511,16 @@ def flash_attn(qkv, B, L, H, hs, q_off, k_off, v_off, alpha, *, causal=False, kv
 _GEMV_SPLIT_NORM = os.environ.get("GROVE_GEMV_SPLIT_NORM", "1") != "0"  # A/B arm of the batched decode step
 
 
-def gemv(x, w, bias=None, *, act=ACT_NONE, residual=None, out_dtype=bf16, out=None, rms_weight=None, eps=0.0, swiglu=False, batch_invariant=False):
+def gemv(x, w, bias=None, *, act=ACT_NONE, residual=None, out_dtype=bf16, out=None, rms_weight=None, eps=0.0, swiglu=False, batch_invariant=False,
+         norm_out=None, norm_in=None):
     """y = act(x' @ w.T + bias) + residual for 1..8 rows of x (the cached decode step): the weight-streaming kernel.
     x' = x, or rmsnorm(x) * rms_weight (rms_weight given), or silu(gate) * up of a fused [M, 2K] row (swiglu=True).
     x and residual may be fp32 (the decode step's fp32 residual stream): norm statistics then run on the fp32 values.
     batch_invariant: the matrix-core kernel for every M (grove_gemv_params.force_mfma): a row's bits do not depend on how many other
-    sequences share the launch."""
+    sequences share the launch.
+    Deferred RMSNorm (grove_gemv_params.xs_out / ssq_out / ssq_in; matrix-core kernel, plain x): norm_out = (next norm's weight [N]) makes this
+    launch also return (xs bf16 [M, N] = bf16(y * weight), ssq f32 [ceil(N / 16), 8]) — `out` becomes (y, xs, ssq); norm_in = (ssq, eps) of the
+    producer makes this launch multiply row m of its product by rsqrt(sum(ssq[:, m]) / K + eps): x must then be the producer's xs."""
     _chk_dev(x, w)
     M = x.shape[0]
     N, K = w.shape
@@ -563,8 +567,16 @@ def gemv(x, w, bias=None, *, act=ACT_NONE, residual=None, out_dtype=bf16, out=No
     p.x_f32 = int(x.dtype == torch.float32)
     p.res_f32 = int(residual is not None and residual.dtype == torch.float32)
     p.force_mfma = int(batch_invariant)
+    xs = ssq = None
+    if norm_out is not None:
+        xs = torch.empty((M, N), dtype=bf16, device=x.device)
+        ssq = torch.empty(((N + 15) // 16, 8), dtype=torch.float32, device=x.device)
+        p.xs_out, p.xs_weight, p.ssq_out, p.ld_xs = _p(xs), _p(norm_out), _p(ssq), xs.stride(0)
+    if norm_in is not None:
+        assert rms_weight is None and not swiglu
+        p.ssq_in, p.ssq_in_blocks, p.eps = _p(norm_in[0]), norm_in[0].shape[0], float(norm_in[1])
     _lib.check(_lib.lib().grove_gemv_bf16(C.byref(p), _stream()), "grove_gemv_bf16")
-    return out
+    return (out, xs, ssq) if norm_out is not None else out
 
 
 def greedy_pick(logits, V, finished, tok, pos, ids_out, eos, pad, pos0, hidden=None, hid_out=None, hidden_f32=None, hid_out_f32=None):

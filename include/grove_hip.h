@@ -527,6 +527,18 @@ typedef struct grove_gemv_params {
    * is different). A row's result is then the same bits whichever other sequences share its launch: batch-invariant decode (round 6;
    * one int32 in what was the struct's tail padding). */
   int32_t force_mfma;
+  /* DEFERRED RMSNorm between two launches of the decode step (round 6; matrix-core kernel, plain bf16 x): HF LlamaDecoderLayer's
+   * `hidden = residual + proj(...)` followed by the next `*_layernorm` and projection, without a norm launch in between.
+   *   producer (o_proj / down_proj, y = the fp32 residual stream v): xs_out bf16 [M, ld_xs] = bf16(v * xs_weight[n]) (NULL: not wanted),
+   *     ssq_out f32 [ceil(N / 16)][8] = this launch's sums of v^2 over each group of 16 output columns, per row (every entry written);
+   *   consumer (q|k|v / gate|up / lm_head, x = that xs_out): ssq_in = the producer's ssq_out, ssq_in_blocks = its entry count — row m of
+   *     the product is multiplied by rsqrt(sum_b ssq_in[b][m] / K + eps) (fixed summation order) before bias / activation.
+   * Same function as x_mode RMSNORM up to where the bf16 rounding of the normalised input falls (before instead of after the rstd). */
+  void* xs_out;
+  const void* xs_weight;
+  float* ssq_out;
+  const float* ssq_in;
+  int32_t ssq_in_blocks, ld_xs;
 } grove_gemv_params;
 int grove_gemv_bf16(const grove_gemv_params* p, void* stream);
 /* A/B knob (round 5): 1 (default) = 3..8 sequences with K % 128 == 0 run on the matrix-core kernel (one weight stream feeds one

@@ -930,6 +930,44 @@ def test_gemm_tile_variants(dev, M, N, K, tile_n, tile_m):
         _lib.lib().grove_gemm_set_tile_m(0)
 
 
+@pytest.mark.parametrize("M,N1,K1,N2", [(8, 4096, 4096, 22016), (3, 512, 11008, 1536), (1, 4096, 4096, 32008)])
+def test_gemv_deferred_rmsnorm(dev, M, N1, K1, N2):
+    """The deferred RMSNorm of the batched decode step (grove_gemv_params.xs_out / ssq_out / ssq_in): a producer GEMV (o_proj / down_proj
+    shape: fp32 residual in, fp32 stream out) that also leaves bf16(stream * next norm weight) and its per-16-column sums of squares, and
+    a consumer GEMV (gate | up with the SwiGLU epilogue, or lm_head) that scales its product by the row's rstd — against
+    rmsnorm(stream) * weight -> GEMV in fp32, and bit-identical between M sequences and the same rows one at a time (force_mfma)."""
+    from grove_amd import ops
+    g = torch.Generator().manual_seed(21)
+    o = (torch.randn(M, K1, generator=g) * 0.5).to(bf16)
+    w1 = (torch.randn(N1, K1, generator=g) * 0.02).to(bf16)
+    res = torch.randn(M, N1, generator=g)
+    nw = (1.0 + 0.1 * torch.randn(N1, generator=g)).to(bf16)
+    swiglu = N2 % 16 == 0 and N2 != 32008
+    w2 = (torch.randn(N2, N1, generator=g) * 0.02).to(bf16)
+    y, xs, ssq = ops.gemv(o.to(dev), w1.to(dev), residual=res.to(dev), out_dtype=torch.float32, batch_invariant=True, norm_out=nw.to(dev))
+    y_ref = o.float() @ w1.float().t() + res
+    close(y, y_ref, 2e-5, "producer: the stream")
+    close(xs, y.float().cpu() * nw.float(), 2 ** -8, "producer: bf16(stream * weight)")
+    assert ssq.shape == ((N1 + 15) // 16, 8)
+    close(ssq.cpu().sum(0)[:M], y.float().cpu().pow(2).sum(1), 1e-5, "producer: sums of squares")
+    eps = 1e-5
+    act = ops.ACT_SWIGLU_PAIR if swiglu else ops.ACT_NONE
+    out = ops.gemv(xs, w2.to(dev), act=act, out_dtype=torch.float32 if not swiglu else bf16, batch_invariant=True, norm_in=(ssq, eps))
+    yn = y.float().cpu()
+    xn = (yn * torch.rsqrt(yn.pow(2).mean(1, keepdim=True) + eps) * nw.float())
+    z = xn @ w2.float().t()
+    if swiglu:  # rows interleaved 4 gate / 4 up per 8
+        z8 = z.view(M, N2 // 8, 2, 4)
+        want = (torch.nn.functional.silu(z8[:, :, 0]) * z8[:, :, 1]).reshape(M, N2 // 2)
+        close(out, want, 1.5e-2, "consumer: SwiGLU of the normalised product")
+    else:
+        close(out, z, 6e-3, "consumer: the normalised product")
+    # batch invariance of the pair: row 0 alone gives the same bits
+    y1, xs1, ssq1 = ops.gemv(o[:1].to(dev), w1.to(dev), residual=res[:1].to(dev), out_dtype=torch.float32, batch_invariant=True, norm_out=nw.to(dev))
+    out1 = ops.gemv(xs1, w2.to(dev), act=act, out_dtype=out.dtype, batch_invariant=True, norm_in=(ssq1, eps))
+    assert torch.equal(y1[0], y[0]) and torch.equal(xs1[0], xs[0]) and torch.equal(ssq1[:, 0], ssq[:, 0]) and torch.equal(out1[0], out[0])
+
+
 @pytest.mark.parametrize("M", [3, 5, 6, 7])
 def test_gemv_touches_only_its_m_rows(dev, M):
     """3, 5, 6 and 7 sequences run the 4- / 8-row instances of the VALU kernel (K % 128 != 0 keeps them off the matrix-core one): x,
