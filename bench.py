@@ -698,8 +698,10 @@ def infer_iground_bench(args, dev, dims, world=1, rank=0):
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        marks = []
         for _ in range(args.steps):
             res = fn()
+            marks.append(time.perf_counter() - t0)  # (host time: the results of a step are read back inside it, so this is the step's end)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -709,8 +711,10 @@ def infer_iground_bench(args, dev, dims, world=1, rank=0):
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t[0])
+        timed.steps_s = [round(b_ - a, 4) for a, b_ in zip([0.0] + marks[:-1], marks)]
         return dt, res
     dt_b, res_b = timed(run_batched)
+    steps_batched_s = timed.steps_s
     dt_1, res_1 = timed(run_b1)
     same_ids = all(torch.equal(a["output_ids"], b_["output_ids"]) for a, b_ in zip(res_b, res_1))
     box_diff = 0.0
@@ -754,7 +758,7 @@ def infer_iground_bench(args, dev, dims, world=1, rank=0):
                        "parallelism": f"dp{world} (replicas only: clips sharded over ranks)", "ranks": world,
                        "clips_per_s": round(world * N * args.steps / dt_b, 3), "clips_per_s_batch1_reference_form": round(world * N * args.steps / dt_1, 3),
                        "speedup_over_batch1": round(dt_1 / dt_b, 3), "ids_equal_to_batch1": bool(same_ids), "max_box_diff_vs_batch1_normalised": box_diff,
-                       "batch_invariant": True, "bit_identical_to_one_clip_batches": bool(invariant),
+                       "batch_invariant": True, "bit_identical_to_one_clip_batches": bool(invariant), "seconds_of_each_timed_step": steps_batched_s,
                        "stage_seconds_per_step_batched": {k: round(v, 4) for k, v in stages.items()},
                        "stage_note": "encode = CLIP + SAM towers of the centre windows; evaluate = prefill + greedy decode + box decoder; windows = the other windows' "
                                      "forward (all clips of a batch in one launch sequence); measured in one extra pass with device syncs around the stages"},

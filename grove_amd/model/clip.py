@@ -147,8 +147,15 @@ class ClipTower:
         '(b t) (h w) c -> b c t h w' with t = 8, h = 16, w = n / 16); the CLS rows of `out` are left as they are."""
         if "U" not in A:
             A["U"] = ops.wino3d_transform_weight(A["w"])
-        ops.wino3d_conv(x, A["U"], (F // 8, 8, 16, n // 16), out, bias=A["b"], act=ops.ACT_RELU, scale_ptr=A["alpha"], scale_tanh=True,
-                        residual=residual, frames=(n + 1, 1))
+        if not hasattr(self, "_wino_ws"):
+            self._wino_ws = {}
+        # groups of 8 frames are independent: chunks of 8 groups on one persistent pair of temporaries (see SamEncoder._adapter)
+        fr = 8 * (n + 1)
+        for g0 in range(0, F // 8, 8):
+            gc = min(8, F // 8 - g0)
+            r0, r1 = g0 * fr, (g0 + gc) * fr
+            ops.wino3d_conv(x[r0:r1], A["U"], (gc, 8, 16, n // 16), out[r0:r1], bias=A["b"], act=ops.ACT_RELU, scale_ptr=A["alpha"], scale_tanh=True,
+                            residual=residual[r0:r1] if residual is not None else None, frames=(n + 1, 1), ws=self._wino_ws)
 
     def _hidden_states_bf16_stream(self, x, F, upto, taps):
         """The same layers with the residual stream in bf16 (what the reference stores): the residual add rides in the epilogue of the

@@ -43,6 +43,8 @@ def _rcat_tables(size, rel_pos_h, rel_pos_w, hd, hp, alpha):
 
 
 class SamEncoder:
+    WINO_CHUNK = 8  # groups of 8 frames per Winograd launch sequence at inference
+
     def __init__(self, sd, d, device, train=False, grads=None, fp32_stream=None, fp8_mlp=False):
         """fp8_mlp (round 6, fp8_policy "sam_mlp": BASELINE config 5): mlp.lin1 (+ GELU) and mlp.lin2 of every block — two thirds of the tower's
         GEMM FLOPs, plain token-order [rows, 1280 <-> 5120] products — on the e4m3 MFMA GEMM (per-output-channel weight scales made here,
@@ -123,6 +125,7 @@ class SamEncoder:
         w = os.environ.get("GROVE_SAM_WINOGRAD", "fwd,dgrad,wgrad")
         self.wino = set() if w in ("0", "") else set(w.split(","))
         assert self.wino <= {"fwd", "dgrad", "wgrad"}, self.wino
+        self._wino_ws = {}  # persistent temporaries of the Winograd pipeline (ops._ws_tensor)
 
     @property
     def _zero_row(self):
@@ -292,9 +295,20 @@ class SamEncoder:
                 if not self.train:
                     A["U"] = U
             y = torch.empty_like(x)
-            _, V = ops.wino3d_conv(x, U, geom, y, bias=A["b"], act=ops.ACT_RELU, scale_ptr=A["alpha_f32"], scale_tanh=True,
-                                   residual=None if f32 else x, aux=pre, keep_V=save and "wgrad" in self.wino)
-            return y, (x, pre, V)
+            if save:
+                _, V = ops.wino3d_conv(x, U, geom, y, bias=A["b"], act=ops.ACT_RELU, scale_ptr=A["alpha_f32"], scale_tanh=True,
+                                       residual=None if f32 else x, aux=pre, keep_V="wgrad" in self.wino, ws=self._wino_ws)
+                return y, (x, pre, V)
+            # inference: groups of 8 frames are independent (a tile never crosses a group), so a long batch of windows goes through in
+            # chunks of WINO_CHUNK groups on ONE persistent pair of temporaries (2 x 1.3 GB at 8 groups) instead of two fresh
+            # [64, tiles, C] tensors per adapter call (2 x 6.7 GB at infer_iground's 320 frames: see ops._ws_tensor)
+            gg = 8 * self.d.sam_grid ** 2
+            for g0 in range(0, geom[0], self.WINO_CHUNK):
+                gc = min(self.WINO_CHUNK, geom[0] - g0)
+                r0, r1 = g0 * gg, (g0 + gc) * gg
+                ops.wino3d_conv(x[r0:r1], U, (gc,) + geom[1:], y[r0:r1], bias=A["b"], act=ops.ACT_RELU, scale_ptr=A["alpha_f32"], scale_tanh=True,
+                                residual=None if f32 else x[r0:r1], ws=self._wino_ws)
+            return y, (x, pre, None)
         y = ops.linear(x, A["w"], A["b"], act=ops.ACT_RELU, scale_ptr=A["alpha_f32"], scale_tanh=True, a_idx=conv_idx, a_taps=27,
                        M=x.shape[0], residual=None if f32 else x, aux=pre, a_frames=self.conv_frames)
         return y, (x, pre, None)
@@ -470,7 +484,7 @@ class SamEncoder:
                 ops.transpose(A["w"], C, C, 27 * C, wd[:, 26 * C:], 27 * C, batch=(27, 1), s_in=(C, 0), s_out=(-C, 0))
             if geom is not None and "dgrad" in self.wino:
                 dx = torch.empty_like(dy)
-                ops.wino3d_conv(prod, ops.wino3d_transform_weight(A["w_d"]), geom, dx, scale_ptr=a, scale_tanh=True, residual=dy)
+                ops.wino3d_conv(prod, ops.wino3d_transform_weight(A["w_d"]), geom, dx, scale_ptr=a, scale_tanh=True, residual=dy, ws=self._wino_ws)
             else:
                 dx = ops.linear(prod, A["w_d"], a_idx=conv_idx, a_taps=27, M=M, residual=dy, scale_ptr=a, scale_tanh=True,
                                 a_frames=self.conv_frames)  # (flipped taps: the first / last tap GROUP still pairs with the first / last frame)

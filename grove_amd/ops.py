@@ -305,18 +305,33 @@ def wino3d_wgrad_output(dU, gw, *, scale_ptr=None, scale_tanh=False):
     return gw
 
 
+def _ws_tensor(ws, key, shape, dtype, device):
+    """A [shape] view of the caller's persistent workspace buffer `key` (grown when too small): big temporaries that come back every call
+    are allocated once — a fresh multi-GB block from the allocator is mapped page by page under the first kernel that writes it (measured:
+    +0.35 s on a step whose two 6.7 GB Winograd temporaries were fresh, against 1.40 s when the allocator happened to hand back mapped ones)."""
+    n = 1
+    for d_ in shape:
+        n *= int(d_)
+    buf = ws.get(key)
+    if buf is None or buf.numel() < n or buf.dtype != dtype or buf.device != device:
+        buf = ws[key] = torch.empty(n, dtype=dtype, device=device)
+    return buf[:n].view(*shape)
+
+
 def wino3d_conv(x, U, geom, out, *, bias=None, act=ACT_NONE, scale_ptr=None, scale_tanh=False, residual=None, aux=None, V=None, keep_V=False,
-                frames=(0, 0)):
+                frames=(0, 0), ws=None):
     """out = epilogue(Conv3d 3x3x3 'same' of the token tensor x with the TRANSFORMED weights U [64, Co, Ci]) — transform, ONE grouped GEMM
     over the 64 transform points, output transform. Returns (out, V) with V the transformed input when keep_V (the weight gradient reads it).
+    ws (dict or None): the caller's persistent workspace for the two [64, tiles, C] temporaries (inference: the same sizes every call).
     A tile count that is not a multiple of 256 is padded per point (the grouped GEMM's groups are whole 256-row tiles): the pad rows of V
     are whatever the allocator left — rows of a GEMM do not mix, and the output transform never reads theirs."""
     tiles = wino3d_tiles(geom)
     tl = pad_to(tiles, 256)
     Co, Ci = U.shape[1], U.shape[2]
     if V is None:
-        V = wino3d_transform_tokens(x, geom, 0, frames=frames, tiles_ld=tl if tl != tiles else 0)
-    Mh = torch.empty((64, tl, Co), dtype=bf16, device=x.device)
+        Vb = _ws_tensor(ws, "V", (64, tl, Ci), bf16, x.device) if (ws is not None and not keep_V) else None
+        V = wino3d_transform_tokens(x, geom, 0, out=Vb, frames=frames, tiles_ld=tl if tl != tiles else 0)
+    Mh = _ws_tensor(ws, "M", (64, tl, Co), bf16, x.device) if ws is not None else torch.empty((64, tl, Co), dtype=bf16, device=x.device)
     gemm_raw(V, U, Mh, 64 * tl, Co, Ci, Ci, Ci, Co, b_group=tl)
     wino3d_output(Mh, geom, out, bias=bias, act=act, scale_ptr=scale_ptr, scale_tanh=scale_tanh, residual=residual, aux=aux, frames=frames)
     return out, (V if keep_V else None)
