@@ -221,5 +221,61 @@ if "--no-full" not in sys.argv:
     REPS = 3
     screen("full-size fwd + bwd (2 clips x T = 16), deterministic mode (self)", full_step, full_step)
 ops.set_deterministic(False)
+# ---- round 6: the Winograd pipeline's two GEMM modes, its transforms, and the request-shape loads of the matrix-core GEMV
+L.grove_gemm_set_stream_k(0)
+L.grove_gemm_set_tile_m(256)
+for groups, rows, N, K in ((64, 512, 1280, 1280), (12, 256, 320, 192)):
+    ga = torch.randn(groups * rows, K, device=dev).to(bf); gb = (torch.randn(groups, N, K, device=dev) * 0.1).to(bf)
+
+    def grouped():
+        o = torch.empty(groups * rows, N, device=dev, dtype=bf)
+        ops.gemm_raw(ga, gb, o, groups * rows, N, K, K, K, N, b_group=rows)
+        return o
+
+    def per_group():
+        return torch.cat([ops.linear(ga[g_ * rows:(g_ + 1) * rows], gb[g_]) for g_ in range(groups)], 0)
+    screen(f"NT grouped B {groups} x [{rows}, {K}] x [{N}, {K}] vs per-group launches", per_group, grouped)
+L.grove_gemm_set_tile_m(0)
+L.grove_gemm_set_stream_k(1)
+L.grove_gemm_tn_set_pipelined(1)
+L.grove_gemm_tn_set_split_tail(0)
+for batches, K, M, N in ((64, 1024, 1280, 1280), (7, 192, 264, 136)):
+    ta = torch.randn(batches * K, M, device=dev).to(bf); tb = torch.randn(batches * K, N, device=dev).to(bf)
+
+    def kbatched():
+        o = torch.empty(batches, M, N, device=dev)
+        ops.wgrad(ta, tb, o, K=K, k_batches=batches, sC_batch=M * N, overwrite=True, M=M, N=N)
+        return o
+
+    def per_batch():
+        o = torch.zeros(batches, M, N, device=dev)
+        for b_ in range(batches):
+            ops.wgrad(ta[b_ * K:(b_ + 1) * K], tb[b_ * K:(b_ + 1) * K], o[b_])
+        return o
+    screen(f"TN K-batched {batches} x [{K}, {M}]^T [{K}, {N}] vs per-batch launches", per_batch, kbatched)
+L.grove_gemm_tn_set_pipelined(-1)
+L.grove_gemm_tn_set_split_tail(1)
+wgeom, wC = (2, 8, 16, 16), 320
+wx = torch.randn(wgeom[0] * wgeom[1] * wgeom[2] * wgeom[3], wC, device=dev).to(bf)
+ww = (torch.randn(wC, 27 * wC, device=dev) * 0.05).to(bf)
+wa = torch.tensor([0.2], device=dev)
+
+
+def wino_all():
+    y, pre = torch.empty_like(wx), torch.empty_like(wx)
+    _, V = ops.wino3d_conv(wx, ops.wino3d_transform_weight(ww), wgeom, y, act=ops.ACT_RELU, scale_ptr=wa, scale_tanh=True, residual=wx, aux=pre, keep_V=True)
+    gw = torch.zeros(wC, 27 * wC, device=dev)
+    ops.wino3d_wgrad(pre, V, wgeom, gw, scale_ptr=wa, scale_tanh=True)
+    return y, pre, gw
+screen("Winograd adapter forward + wgrad (self)", wino_all, wino_all)
+for N, K in ((4096, 4096), (22016, 4096), (4096, 11008)):
+    vw = (torch.randn(N, K, device=dev) * 0.02).to(bf); vx = torch.randn(8, K, device=dev).to(bf)
+
+    def gv(knob):
+        L.grove_gemv_set_mfma(knob)
+        o = ops.gemv(vx, vw)
+        L.grove_gemv_set_mfma(1)
+        return o
+    screen(f"GEMV 8 x [{N}, {K}]: 128 B / row loads + lane exchange vs operand-shape loads", lambda: gv(9), lambda: gv(1))
 print("TOTAL MISMATCHES", bad)
 sys.exit(1 if bad else 0)
