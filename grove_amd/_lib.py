@@ -113,7 +113,7 @@ class FlashAttnParams(C.Structure):
                 ("B", c_i32), ("H", c_i32), ("Lq", c_i32), ("Lk", c_i32), ("hs", c_i32),
                 ("ld_q", c_i32), ("ld_k", c_i32), ("ld_v", c_i32), ("ld_o", c_i32), ("ld_do", c_i32), ("ld_dq", c_i32),
                 ("ld_dk", c_i32), ("ld_dv", c_i32), ("causal", c_i32), ("rel_kh", c_i32), ("rel_kw", c_i32), ("rel_ld", c_i32), ("alpha", c_f32),
-                ("hs_valid", c_i32), ("q_valid", c_vp), ("o_map", c_vp), ("o_hs", c_i32), ("g_tok", c_i32), ("pad_k", c_vp), ("pad_v", c_vp), ("rope", c_vp)]
+                ("hs_valid", c_i32), ("q_valid", c_vp), ("o_map", c_vp), ("o_hs", c_i32), ("g_tok", c_i32), ("pad_k", c_vp), ("pad_v", c_vp), ("rope", c_vp), ("rel_table", c_vp)]
 
 
 class GemvParams(C.Structure):

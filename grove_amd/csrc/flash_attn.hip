@@ -893,6 +893,9 @@ extern "C" int grove_flash_attn_fwd(const grove_flash_attn_params* p, void* stre
   // q_valid / pad_k / pad_v exist only in the window kernels: the general ones below would read the (uninitialised) pad rows instead
   GROVE_CHECK(!(p->q_valid || p->pad_k || p->pad_v) || (g_win_attn && grove_win_attn_applicable(p)), GROVE_E_SHAPE,
               "flash_attn_fwd: q_valid / pad_k / pad_v are window-kernel features, but this problem does not take the window kernels");
+  GROVE_CHECK(!p->rel_table || (g_win_attn && grove_win_attn_applicable(p)), GROVE_E_SHAPE,
+              "flash_attn_fwd: rel_table (rel-pos terms made inside the kernel) is a window-kernel feature: 14 x 14-like windows, hs_valid 80, rel_ld 32, "
+              "at most 64 table rows, 16-byte aligned table / rel");
   if (g_win_attn && grove_win_attn_applicable(p)) {
     grove_win_attn_fwd_launch(p, s);
     GROVE_LAUNCH_CHECK();
@@ -941,6 +944,8 @@ extern "C" int grove_flash_attn_bwd(const grove_flash_attn_params* p, void* stre
   GROVE_CHECK(!(p->q_valid || p->pad_k || p->pad_v) || win, GROVE_E_SHAPE,
               "flash_attn_bwd: q_valid / pad_k / pad_v are window-kernel features, but this problem does not take the window kernels "
               "(shape, alignment of o / d_o / dq / dk / dv, or grove_flash_attn_set_window_kernels(0))");
+  GROVE_CHECK(!p->rel_table || (win && p->rel && !p->drel), GROVE_E_SHAPE,
+              "flash_attn_bwd: rel_table is a window-kernel feature; it needs rel (the operand the forward left) and no drel (dq leaves complete)");
   if (win) {
     grove_win_attn_bwd_launch(p, s);  // one kernel: delta, dK / dV, then dQ / d rel (win_attn.hip)
     GROVE_LAUNCH_CHECK();

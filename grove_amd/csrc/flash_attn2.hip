@@ -183,11 +183,24 @@ __device__ __forceinline__ float half_sum(float v) {
   return __uint_as_float(a[0]) + __uint_as_float(a[1]);
 }
 
-__device__ __forceinline__ void causal_order2(const bool causal, const bool reverse, int& bx, int& h, int& b) {
+__device__ __forceinline__ void causal_order2(const bool causal, const bool reverse, int& bx, int& h, int& b, const int xcd_groups) {
   bx = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-  if (!causal) return;
   const int id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
   const int nbh = gridDim.y * gridDim.z;
+  if (!causal) {
+    // Workgroups are dealt to the 8 XCDs round-robin by linear id, so the gridDim.x blocks of one (batch, head) — which all stream
+    // that head's whole K / V (forward, dQ) or Q / dO (dK / dV) — would land on gridDim.x DIFFERENT L2s and every L2 would fetch
+    // every head: SAM's global blocks at 320 frames ran 2.4x slower per frame than at 32 (where the Infinity Cache hid it). Deal
+    // whole (batch, head) groups to an XCD instead: XCD x's s-th block is tile s % gridDim.x of group (s / gridDim.x) * 8 + x.
+    if ((nbh & 7) == 0 && xcd_groups) {
+      const int x = id & 7, s = id >> 3;
+      const int grp = (s / (int)gridDim.x) * 8 + x;
+      bx = s % (int)gridDim.x;
+      h = grp % (int)gridDim.y;
+      b = grp / (int)gridDim.y;
+    }
+    return;
+  }
   const int qi = id / nbh, bh = id - qi * nbh;
   bx = reverse ? (int)gridDim.x - 1 - qi : qi;
   h = bh % (int)gridDim.y;
@@ -258,7 +271,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 // REL: 0 none; 1 = SAM global form (rel_kw == rel_kh == 32, rel_ld == 64).
 template <int HS, int REL>
-__global__ __launch_bounds__(NT2, 2) void flash2_fwd_kernel(const grove_flash_attn_params p) {
+__global__ __launch_bounds__(NT2, 2) void flash2_fwd_kernel(const grove_flash_attn_params p, const int xcd_groups) {
   using C = C2<HS>;
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   char* Kring = smem;
@@ -270,7 +283,7 @@ __global__ __launch_bounds__(NT2, 2) void flash2_fwd_kernel(const grove_flash_at
   const int half = wave >> 2;  // 0: waves 0-3 (lead), 1: waves 4-7 (half a tile behind)
   const int l31 = lane & 31, hi = lane >> 5;
   int bx, h, b;
-  causal_order2(p.causal != 0, true, bx, h, b);
+  causal_order2(p.causal != 0, true, bx, h, b, xcd_groups);
   const int qblk = bx * BQ2;
   const int q0 = qblk + wave * 32;
   const bf16_raw* Q = (const bf16_raw*)p.q + (int64_t)b * p.sq + h * HS;
@@ -681,7 +694,7 @@ __global__ __launch_bounds__(NT2, 2) void flash2_fwd_kernel(const grove_flash_at
 // issued in Y(2t + 1), drained (vmcnt(0)) at the end of the issuing wave's next X, first read in X(2t + 4); the slot it overwrites held
 // tile t - 1, last read in X(2t) by the lagging half — one barrier before the first issue.
 template <int HS, int REL>
-__global__ __launch_bounds__(NT2, 2) void flash2_bwd_dq_kernel(const grove_flash_attn_params p, const int make_delta) {
+__global__ __launch_bounds__(NT2, 2) void flash2_bwd_dq_kernel(const grove_flash_attn_params p, const int make_delta, const int xcd_groups) {
   using C = C2<HS>;
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   char* Kring = smem;
@@ -695,7 +708,7 @@ __global__ __launch_bounds__(NT2, 2) void flash2_bwd_dq_kernel(const grove_flash
   const int half = wave >> 2;
   const int l31 = lane & 31, hi = lane >> 5;
   int bx, h, b;
-  causal_order2(p.causal != 0, true, bx, h, b);
+  causal_order2(p.causal != 0, true, bx, h, b, xcd_groups);
   const int qblk = bx * BQ2;
   const int q0 = qblk + wave * 32;
   const bf16_raw* Q = (const bf16_raw*)p.q + (int64_t)b * p.sq + h * HS;
@@ -1023,7 +1036,7 @@ __global__ __launch_bounds__(NT2, 2) void flash2_bwd_dq_kernel(const grove_flash
 // their register sets are disjoint live ranges.
 enum { ROLE_BOTH = 0, ROLE_DK = 1, ROLE_DV = 2 };
 template <int HS, int REL, bool SPLIT>
-__global__ __launch_bounds__(NT2, 2) void flash2_bwd_dkv_kernel(const grove_flash_attn_params p) {
+__global__ __launch_bounds__(NT2, 2) void flash2_bwd_dkv_kernel(const grove_flash_attn_params p, const int xcd_groups) {
   using C = C2<HS>;
   using CR = C2<64>;  // the rel' tile: 64 bins = 128-byte rows
   extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -1038,7 +1051,7 @@ __global__ __launch_bounds__(NT2, 2) void flash2_bwd_dkv_kernel(const grove_flas
   const int half = wave >> 2;
   const int l31 = lane & 31, hi = lane >> 5;
   int bx, h, b;
-  causal_order2(p.causal != 0, false, bx, h, b);
+  causal_order2(p.causal != 0, false, bx, h, b, xcd_groups);
   const int kblk = bx * (SPLIT ? BQ2 / 2 : BQ2);
   const int k0 = kblk + (SPLIT ? (wave & 3) : wave) * 32;
   const bf16_raw* Kp = (const bf16_raw*)p.k + (int64_t)b * p.sk + h * HS;
@@ -1365,7 +1378,8 @@ size_t lds2_fwd(bool rel) { return 6 * (size_t)C2<HS>::TILEB + (rel ? 8 * 32 * 6
 
 }  // namespace
 
-static int g_flash2 = 15;  // bit 0 forward, bit 1 dQ, bit 2 dK / dV, bit 3 the split dK / dV of head dim 128 (A/B arm: grove_flash_attn_set_v2)
+#define XCDG ((g_flash2 & 32) ? 1 : 0)
+static int g_flash2 = 15 + 32;  // bit 0 forward, bit 1 dQ, bit 2 dK / dV, bit 3 the split dK / dV of head dim 128 (A/B arm: grove_flash_attn_set_v2)
 extern "C" int grove_flash_attn_set_v2(int32_t on) {
   g_flash2 = on;
   return GROVE_OK;
@@ -1409,7 +1423,7 @@ int grove_flash2_bwd_dq_launch(const grove_flash_attn_params* p, int make_delta,
   {                                                                                                                              \
     const size_t lds = 6 * (size_t)C2<HS>::TILEB + (REL ? 8 * 32 * 68 + 8 * 32 * 33 * 4 : 0);                                     \
     hipFuncSetAttribute((const void*)flash2_bwd_dq_kernel<HS, REL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
-    hipLaunchKernelGGL((flash2_bwd_dq_kernel<HS, REL>), grid, dim3(NT2), lds, s, *p, make_delta);                                 \
+    hipLaunchKernelGGL((flash2_bwd_dq_kernel<HS, REL>), grid, dim3(NT2), lds, s, *p, make_delta, XCDG);                              \
   }
   if (p->hs == 64) Q2(64, 0)
   else if (p->hs == 128) Q2(128, 0)
@@ -1442,7 +1456,7 @@ int grove_flash2_bwd_dkv_launch(const grove_flash_attn_params* p, hipStream_t s)
   {                                                                                                                                \
     const size_t lds = 6 * (size_t)C2<HS>::TILEB + (REL ? 3 * (size_t)C2<64>::TILEB : 0) + stash;                                   \
     hipFuncSetAttribute((const void*)flash2_bwd_dkv_kernel<HS, REL, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
-    hipLaunchKernelGGL((flash2_bwd_dkv_kernel<HS, REL, SPLIT>), grid, dim3(NT2), lds, s, *p);                                       \
+    hipLaunchKernelGGL((flash2_bwd_dkv_kernel<HS, REL, SPLIT>), grid, dim3(NT2), lds, s, *p, XCDG);                                 \
   }
   if (p->hs == 128) K2(128, 0, true)
   else if (p->rel) K2(96, 1, false)
@@ -1457,7 +1471,7 @@ int grove_flash2_fwd_launch(const grove_flash_attn_params* p, hipStream_t s) {
   {                                                                                                                            \
     const size_t lds = lds2_fwd<HS>(REL);                                                                                      \
     hipFuncSetAttribute((const void*)flash2_fwd_kernel<HS, REL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
-    hipLaunchKernelGGL((flash2_fwd_kernel<HS, REL>), grid, dim3(NT2), lds, s, *p);                                              \
+    hipLaunchKernelGGL((flash2_fwd_kernel<HS, REL>), grid, dim3(NT2), lds, s, *p, XCDG);                                        \
   }
   if (p->hs == 64) F2(64, 0)
   else if (p->hs == 128) F2(128, 0)

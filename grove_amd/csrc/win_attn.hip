@@ -227,6 +227,9 @@ struct QPair {          // B operands of one pair of 16-query tiles, pre-scaled 
   bf16x8_t rel[2];      // rel'[q][32 bins]
 };
 
+// REL_MODE 0: rel' = q . Rcat / alpha from HBM, scaled here; 1: the score-domain operand itself from HBM (written by the forward of the
+// rel_table form); 2: not loaded (the caller makes it: rel_from_table)
+template <int REL_MODE = 0>
 __device__ __forceinline__ void load_qpair(QPair& q, const bf16_raw* __restrict__ Q, int ld_q, const bf16_raw* __restrict__ REL, int q0,
                                            const QList& ql, float sc, int fr, int g) {
 #pragma unroll
@@ -236,8 +239,72 @@ __device__ __forceinline__ void load_qpair(QPair& q, const bf16_raw* __restrict_
     q.f[mi][0] = wscale(*(const bf16x8_t*)(row + g * 8), sc);
     q.f[mi][1] = wscale(*(const bf16x8_t*)(row + 32 + g * 8), sc);
     q.t[mi] = wscale4(*(const u32x2_t*)(row + 64 + g * 4), sc);
-    q.rel[mi] = wscale(*(const bf16x8_t*)(REL + (int64_t)qi * 32 + g * 8), sc);
+    if (REL_MODE == 0) q.rel[mi] = wscale(*(const bf16x8_t*)(REL + (int64_t)qi * 32 + g * 8), sc);
+    if (REL_MODE == 1) q.rel[mi] = *(const bf16x8_t*)(REL + (int64_t)qi * 32 + g * 8);
   }
+}
+
+// ================================================================================ rel-pos inside the kernels
+// grove_flash_attn_params.rel_table: the bias operand rel'[q][32 bins] of a query is 14 + 14 of the 27 + 27 products q . T[row] — which
+// 14 depends on the query's own (row, column) in the window: bin b of the h part is T[(n - 1) - q_row + b] (the table is stored in
+// key-minus-query order, so the bins of one query are CONSECUTIVE rows). The products of 16 queries with all 64 table rows are
+// 12 MFMAs on the Q fragments the score chain holds anyway (G^T = T Q^T: lane (fr = query, g) gets table rows 16t + 4g + r); the
+// per-query shift is a trip through a wave-private LDS scratch [16 queries][72] bf16 (4 x 8-byte writes, 8 two-byte reads per
+// lane and tile). MEASURED (tools/bench_flash.py, 32 frames): forward 143 -> 171 us (182 with the operand kept for the backward) against
+// the 27 us rel_bias_fwd stream it replaces; backward 402 -> 455 us against the 46 us rel_bias_bwd stream; config 2 end to end
+// 1.4129 -> 1.4102 s. The extra work sits in the prologue of a latency-bound kernel (dependent MFMA chains and LDS round trips before
+// the first score tile, one more barrier) — a wash, so sam.py keeps the two streams by default (GROVE_SAM_REL_IN_KERNEL=1 turns this on).
+constexpr int WSCRB = 144;  // scratch row stride in bytes (72 bf16: rows 16-byte aligned, 36 banks apart)
+struct RelTable {           // A operands: four tiles of 16 table rows
+  bf16x8_t f[4][2];
+  s16x4_t t[4];
+};
+__device__ __forceinline__ void load_rel_table(RelTable& rt, const bf16_raw* __restrict__ T, int fr, int g) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const bf16_raw* row = T + (16 * t + fr) * 80;
+    rt.f[t][0] = *(const bf16x8_t*)(row + g * 8);
+    rt.f[t][1] = *(const bf16x8_t*)(row + 32 + g * 8);
+    rt.t[t] = __builtin_bit_cast(s16x4_t, *(const u32x2_t*)(row + 64 + g * 4));
+  }
+}
+// where bin b of the query at window position qi lives among the 64 table rows (-1: a pad bin)
+struct RelShift {
+  int hb, wb, nkh, KH, kw;
+  __device__ __forceinline__ int col(int b) const {
+    const bool h = b < nkh, w = b >= KH && b < KH + kw;
+    return h ? hb + b : w ? wb + b : -1;
+  }
+};
+__device__ __forceinline__ RelShift make_shift(int qi, int nkh, int KH, const QList& ql) {
+  const int qy = (qi * ql.mkw) >> 16, qx = qi - qy * ql.kw;
+  RelShift s;
+  s.nkh = nkh, s.KH = KH, s.kw = ql.kw;
+  s.hb = nkh - 1 - qy;
+  s.wb = (2 * nkh - 1) + (ql.kw - 1) - qx - KH;
+  return s;
+}
+// qf / qt: the pre-scaled Q fragments of 16 queries (lane: query fr, dims 8g.. of each k-step); returns their bias operand
+__device__ __forceinline__ bf16x8_t rel_from_table(const RelTable& rt, const bf16x8_t (&qf)[2], s16x4_t qt, char* scr, const RelShift& sh, int fr, int g) {
+  const f32x4_t z4 = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    f32x4_t a = mfma32(rt.f[t][0], qf[0], z4);
+    a = mfma32(rt.f[t][1], qf[1], a);
+    a = mfma16(rt.t[t], qt, a);
+    *(u32x2_t*)(scr + fr * WSCRB + 32 * t + 8 * g) = u32x2_t{pack2bf(a[0], a[1]), pack2bf(a[2], a[3])};
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the wave's own LDS traffic is in order; this is the compiler's fence)
+  const unsigned short* row = (const unsigned short*)(scr + fr * WSCRB);
+  unsigned v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = sh.col(8 * g + j);
+    v[j] = c >= 0 ? (unsigned)row[max(c, 0)] : 0u;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const u32x4_t u = u32x4_t{v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16)};
+  return __builtin_bit_cast(bf16x8_t, u);
 }
 
 // ================================================================================ forward
@@ -333,6 +400,7 @@ __device__ __forceinline__ void fwd_pair(const QPair& q, const char* Ks, const c
   }
 }
 
+template <bool TABLE>
 __global__ __launch_bounds__(WTHR, 2) void win_attn_fwd_kernel(const grove_flash_attn_params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;
@@ -346,7 +414,6 @@ __global__ __launch_bounds__(WTHR, 2) void win_attn_fwd_kernel(const grove_flash
   const bf16_raw* Q = (const bf16_raw*)p.q + (int64_t)b * p.sq + h * p.hs;
   const bf16_raw* K = (const bf16_raw*)p.k + (int64_t)b * p.sk + h * p.hs;
   const bf16_raw* V = (const bf16_raw*)p.v + (int64_t)b * p.sv + h * p.hs;
-  const bf16_raw* REL = (const bf16_raw*)p.rel + (int64_t)(b * p.H + h) * L * 32;
   // o in token order (o_map: row of (b, position), head h at column h * o_hs) or in the layout of q
   const int ohs = p.o_map && p.o_hs ? p.o_hs : p.hs;
   const int32_t* omap = p.o_map ? p.o_map + (int64_t)b * L : nullptr;
@@ -356,20 +423,60 @@ __global__ __launch_bounds__(WTHR, 2) void win_attn_fwd_kernel(const grove_flash
   const QList ql = make_qlist(p, b);
   const bf16_raw* PK = p.pad_k ? (const bf16_raw*)p.pad_k + h * p.hs : nullptr;
   const bf16_raw* PV = p.pad_v ? (const bf16_raw*)p.pad_v + h * p.hs : nullptr;
-  dma_image_k(Ks, K, p.ld_k, L, PK, ql, wave, lane);
-  dma_image_k(Vs, V, p.ld_v, L, PV, ql, wave, lane);
-  build_e(Es, L, p.rel_kw, p.rel_kh, tid);
-  QPair q;
-  load_qpair(q, Q, p.ld_q, REL, wave * 32, ql, sc, fr, g);  // in flight together with the DMA
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  if constexpr (TABLE) {
+    // a wave owns at most two pairs of query tiles (nq <= 208): both pairs' Q fragments now, their bias operands from the table
+    // through the wave's scratch — which lives where the indicator image goes afterwards. The table and Q loads are issued BEFORE
+    // the image DMAs: vmcnt retires in order, so the products below start when these have landed, under the DMAs' flight
+    QPair qs[2];
+    RelTable rt;
+    load_rel_table(rt, (const bf16_raw*)p.rel_table, fr, g);
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi)
+      if (wave * 32 + 128 * pi < ql.nq) load_qpair<2>(qs[pi], Q, p.ld_q, nullptr, wave * 32 + 128 * pi, ql, sc, fr, g);
+    asm volatile("" ::: "memory");
+    dma_image_k(Ks, K, p.ld_k, L, PK, ql, wave, lane);
+    dma_image_k(Vs, V, p.ld_v, L, PV, ql, wave, lane);
+    bf16_raw* RO = p.rel ? (bf16_raw*)p.rel + (int64_t)(b * p.H + h) * L * 32 : nullptr;
+    char* scr = Es + wave * (16 * WSCRB);
+    const int nkh = L / p.rel_kw;
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi) {
+      const int q0 = wave * 32 + 128 * pi;
+      if (q0 < ql.nq) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          const int qc = q0 + mi * 16 + fr;
+          const int qi = ql.pos(min(qc, ql.nq - 1));
+          qs[pi].rel[mi] = rel_from_table(rt, qs[pi].f[mi], qs[pi].t[mi], scr, make_shift(qi, nkh, p.rel_kh, ql), fr, g);
+          if (RO && qc < ql.nq) *(bf16x8_t*)(RO + (int64_t)qi * 32 + g * 8) = qs[pi].rel[mi];  // kept for the backward
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every wave has read its scratch back: the indicator image may overwrite it
+    asm volatile("" ::: "memory");
+    build_e(Es, L, p.rel_kw, p.rel_kh, tid);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (wave * 32 < ql.nq) fwd_pair(qs[0], Ks, Vs, Es, wave * 32, L, ql, lane, O, p.ld_o, LSE, omap, ohs >= 96);
+    if (wave * 32 + 128 < ql.nq) fwd_pair(qs[1], Ks, Vs, Es, wave * 32 + 128, L, ql, lane, O, p.ld_o, LSE, omap, ohs >= 96);
+  } else {
+    dma_image_k(Ks, K, p.ld_k, L, PK, ql, wave, lane);
+    dma_image_k(Vs, V, p.ld_v, L, PV, ql, wave, lane);
+    const bf16_raw* REL = (const bf16_raw*)p.rel + (int64_t)(b * p.H + h) * L * 32;
+    build_e(Es, L, p.rel_kw, p.rel_kh, tid);
+    QPair q;
+    load_qpair(q, Q, p.ld_q, REL, wave * 32, ql, sc, fr, g);  // in flight together with the DMA
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 #pragma nounroll
-  for (int q0 = wave * 32; q0 < ql.nq; q0 += 128) {
-    QPair qn;
-    const bool more = q0 + 128 < ql.nq;
-    if (more) load_qpair(qn, Q, p.ld_q, REL, q0 + 128, ql, sc, fr, g);  // lands under this pair's MFMAs
-    fwd_pair(q, Ks, Vs, Es, q0, L, ql, lane, O, p.ld_o, LSE, omap, ohs >= 96);
-    if (more) q = qn;
+    for (int q0 = wave * 32; q0 < ql.nq; q0 += 128) {
+      QPair qn;
+      const bool more = q0 + 128 < ql.nq;
+      if (more) load_qpair(qn, Q, p.ld_q, REL, q0 + 128, ql, sc, fr, g);  // lands under this pair's MFMAs
+      fwd_pair(q, Ks, Vs, Es, q0, L, ql, lane, O, p.ld_o, LSE, omap, ohs >= 96);
+      if (more) q = qn;
+    }
   }
 }
 
@@ -596,8 +703,10 @@ struct QDPair {         // B operands of one pair of 16-query tiles (phase B)
   float lse2[2], del[2];
 };
 
+// drp (or NULL): the pair's d rel' rows stay in registers as bf16 — [mi][bt] = bins 16 bt + 4g .. + 3 of query fr — for rel_tail
 __device__ __forceinline__ void bwd_queries(const QDPair& x, const char* Ks, const char* Vs, const char* Es, int q0, int L, const QList& ql, float alpha,
-                                            int lane, bf16_raw* __restrict__ DQ, int ld_dq, bf16_raw* __restrict__ DR, const int32_t* __restrict__ gmap) {
+                                            int lane, bf16_raw* __restrict__ DQ, int ld_dq, bf16_raw* __restrict__ DR, const int32_t* __restrict__ gmap,
+                                            u32x2_t (*drp)[2] = nullptr) {
   const int fr = lane & 15, g = lane >> 4;
   const int esw = e_swz(fr);
   const f32x4_t z4 = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -706,6 +815,10 @@ __device__ __forceinline__ void bwd_queries(const QDPair& x, const char* Ks, con
     const int qi = ql.pos(q0 + mi * 16 + fr);
     if (gmap) store_tok(DQ, ld_dq, gmap[qi], dq[mi], g);
     else store_t(DQ, ld_dq, qi, dq[mi], g);
+    if (drp) {
+#pragma unroll
+      for (int bt = 0; bt < 2; ++bt) drp[mi][bt] = u32x2_t{pack2bf(drl[mi][bt][0], drl[mi][bt][1]), pack2bf(drl[mi][bt][2], drl[mi][bt][3])};
+    }
     if (DR) {
       bf16_raw* r = DR + (int64_t)qi * 32;
 #pragma unroll
@@ -715,6 +828,52 @@ __device__ __forceinline__ void bwd_queries(const QDPair& x, const char* Ks, con
   }
 }
 
+// The rel-pos term of dq with grove_flash_attn_params.rel_table: dq[q][d] += sum_bin d rel'[q][bin] T[row of (q, bin)][d]. The wave
+// scatters the d rel' rows of 16 queries to their table rows in a private scratch dG[16 queries][64 rows] (the inverse of
+// rel_from_table's shift), and dq^T += T^T dG^T is ten MFMAs whose accumulators land on the lanes that stored dq[q][d] (a lane adds
+// to its own stores: bf16 + bf16, the two roundings the grove_rel_bias_bwd stream had). Runs after the last pair of every wave:
+// the scratch takes the place of the K image.
+struct RelTableT { bf16x8_t f[5][2]; };  // A operands: T^T rows d = 16 dt + fr, table rows 32 ks + 8g ..
+__device__ __forceinline__ void load_rel_table_t(RelTableT& tt, const bf16_raw* __restrict__ TT, int fr, int g) {
+#pragma unroll
+  for (int dt = 0; dt < 5; ++dt)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) tt.f[dt][ks] = *(const bf16x8_t*)(TT + (16 * dt + fr) * 64 + 32 * ks + 8 * g);
+}
+__device__ __forceinline__ void rel_tail(const RelTableT& tt, const u32x2_t (&drp)[2], char* scr, const RelShift& sh, bf16_raw* __restrict__ dq_row, bool live,
+                                         int lane) {
+  const int fr = lane & 15, g = lane >> 4;
+  const u32x4_t z = u32x4_t{0u, 0u, 0u, 0u};
+  *(u32x4_t*)(scr + lane * 16) = z;  // 16 rows x 144 bytes = 144 chunks of 16
+  *(u32x4_t*)(scr + 1024 + lane * 16) = z;
+  if (lane < 16) *(u32x4_t*)(scr + 2048 + lane * 16) = z;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  unsigned short* row = (unsigned short*)(scr + fr * WSCRB);
+#pragma unroll
+  for (int bt = 0; bt < 2; ++bt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = sh.col(16 * bt + 4 * g + r);
+      const unsigned w = r < 2 ? drp[bt].x : drp[bt].y;
+      if (c >= 0) row[c] = (unsigned short)((r & 1) ? (w >> 16) : (w & 0xffffu));
+    }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const bf16x8_t d0 = *(const bf16x8_t*)(scr + fr * WSCRB + g * 16), d1 = *(const bf16x8_t*)(scr + fr * WSCRB + 64 + g * 16);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const f32x4_t z4 = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int dt = 0; dt < 5; ++dt) {
+    f32x4_t a = mfma32(tt.f[dt][0], d0, z4);
+    a = mfma32(tt.f[dt][1], d1, a);
+    if (live) {
+      u32x2_t* at = (u32x2_t*)(dq_row + dt * 16 + g * 4);
+      const u32x2_t o = *at;
+      *at = u32x2_t{pack2bf(a[0] + bf_lo(o.x), a[1] + bf_hi(o.x)), pack2bf(a[2] + bf_lo(o.y), a[3] + bf_hi(o.y))};
+    }
+  }
+}
+
+template <bool TABLE>
 __global__ __launch_bounds__(WTHR, 2) void win_attn_bwd_kernel(const grove_flash_attn_params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Xs = smem;                  // Q, then K
@@ -752,7 +911,8 @@ __global__ __launch_bounds__(WTHR, 2) void win_attn_bwd_kernel(const grove_flash
     const int row = c >> 2, ch = c & 3;
     u32x4_t v = u32x4_t{0u, 0u, 0u, 0u};
     if (row < ql.nq) v = *(const u32x4_t*)(REL + (int64_t)ql.pos(row) * 32 + ch * 8);
-    *(bf16x8_t*)(Rs + row * 64 + ((ch ^ e_swz(row)) << 4)) = wscale(__builtin_bit_cast(bf16x8_t, v), sc);
+    // (rel_table: the forward left the score-domain operand itself)
+    *(bf16x8_t*)(Rs + row * 64 + ((ch ^ e_swz(row)) << 4)) = TABLE ? __builtin_bit_cast(bf16x8_t, v) : wscale(__builtin_bit_cast(bf16x8_t, v), sc);
   }
   dma_image_rows(Ys, dO, p.ld_do, do_rows, wave, lane);
   u32x4_t orow[10];
@@ -806,7 +966,7 @@ __global__ __launch_bounds__(WTHR, 2) void win_attn_bwd_kernel(const grove_flash
   bf16_raw* DQ = (bf16_raw*)p.dq + (gmap ? (int64_t)h * ohs : (int64_t)b * p.sdq + h * p.hs);
   bf16_raw* DR = p.drel ? (bf16_raw*)p.drel + bh * 32 : nullptr;
   auto load_x = [&](QDPair& x, int q0, const int* tk) {
-    load_qpair(x.q, Q, p.ld_q, REL, q0, ql, sc, fr, g);
+    load_qpair<TABLE ? 1 : 0>(x.q, Q, p.ld_q, REL, q0, ql, sc, fr, g);
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
       const int qc = min(q0 + mi * 16 + fr, ql.nq - 1);  // compact index: lse_s / del_s; position: the global rows
@@ -824,10 +984,37 @@ __global__ __launch_bounds__(WTHR, 2) void win_attn_bwd_kernel(const grove_flash
   load_x(x, wave * 32, tok);  // in flight with the DMA
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  if constexpr (TABLE) {
+    u32x2_t drp[2][2][2];  // [pair][mi][bt]
+    if (wave * 32 < ql.nq) bwd_queries(x, Xs, Ys, Rs, wave * 32, L, ql, p.alpha, lane, DQ, p.ld_dq, nullptr, gmap, drp[0]);
+    if (wave * 32 + 128 < ql.nq) {
+      load_x(x, wave * 32 + 128, nullptr);
+      bwd_queries(x, Xs, Ys, Rs, wave * 32 + 128, L, ql, p.alpha, lane, DQ, p.ld_dq, nullptr, gmap, drp[1]);
+    }
+    RelTableT tt;
+    load_rel_table_t(tt, (const bf16_raw*)p.rel_table + 64 * 80, fr, g);
+    __syncthreads();  // every wave is through with the K image (and its dq stores are ordered before the adds below)
+    char* scr = Xs + wave * (16 * WSCRB);
+    const int nkh = L / p.rel_kw;
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi) {
+      const int q0 = wave * 32 + 128 * pi;
+      if (q0 < ql.nq) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          const int qc = q0 + mi * 16 + fr;
+          const int qi = ql.pos(min(qc, ql.nq - 1));
+          bf16_raw* dq_row = DQ + (gmap ? (int64_t)gmap[qi] : (int64_t)qi) * p.ld_dq;
+          rel_tail(tt, drp[pi][mi], scr, make_shift(qi, nkh, p.rel_kh, ql), dq_row, qc < ql.nq, lane);
+        }
+      }
+    }
+  } else {
 #pragma nounroll
-  for (int q0 = wave * 32; q0 < ql.nq; q0 += 128) {
-    bwd_queries(x, Xs, Ys, Rs, q0, L, ql, p.alpha, lane, DQ, p.ld_dq, DR, gmap);
-    if (q0 + 128 < ql.nq) load_x(x, q0 + 128, nullptr);
+    for (int q0 = wave * 32; q0 < ql.nq; q0 += 128) {
+      bwd_queries(x, Xs, Ys, Rs, q0, L, ql, p.alpha, lane, DQ, p.ld_dq, DR, gmap);
+      if (q0 + 128 < ql.nq) load_x(x, q0 + 128, nullptr);
+    }
   }
 }
 
@@ -835,20 +1022,33 @@ __global__ __launch_bounds__(WTHR, 2) void win_attn_bwd_kernel(const grove_flash
 
 // Does this problem fit the window kernels? (192 < L <= 208 tokens, head dim 80 in a 96-wide slot, 32 rel bins, no masks)
 bool grove_win_attn_applicable(const grove_flash_attn_params* p) {
-  return p->hs == 96 && p->hs_valid == 80 && p->Lq == p->Lk && p->Lk > (WNT - 1) * 16 && p->Lk <= WNT * 16 && p->rel && p->rel_ld == 32 &&
+  if (p->rel_table && !(p->rel_kw > 0 && p->Lq % p->rel_kw == 0 && 2 * (p->Lq / p->rel_kw) + 2 * p->rel_kw - 2 <= 64 && p->Lq / p->rel_kw <= p->rel_kh &&
+                        p->rel_kh + p->rel_kw <= 32 && ((uintptr_t)p->rel_table & 15) == 0 && ((uintptr_t)p->rel & 15) == 0))
+    return false;
+  return p->hs == 96 && p->hs_valid == 80 && p->Lq == p->Lk && p->Lk > (WNT - 1) * 16 && p->Lk <= WNT * 16 && (p->rel || p->rel_table) && p->rel_ld == 32 &&
          !p->causal && !p->kv_len && p->ld_q % 8 == 0 && p->ld_k % 8 == 0 && p->ld_v % 8 == 0 && p->ld_o % 8 == 0;
 }
 
 int grove_win_attn_bwd_launch(const grove_flash_attn_params* p, hipStream_t s) {
   const size_t lds = 2 * WIMGB + WEB + 2 * WNT * 16 * sizeof(float);
-  hipFuncSetAttribute((const void*)win_attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(win_attn_bwd_kernel, dim3((unsigned)(p->B * p->H)), dim3(WTHR), lds, s, *p);
+  if (p->rel_table) {
+    hipFuncSetAttribute((const void*)win_attn_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(win_attn_bwd_kernel<true>, dim3((unsigned)(p->B * p->H)), dim3(WTHR), lds, s, *p);
+  } else {
+    hipFuncSetAttribute((const void*)win_attn_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(win_attn_bwd_kernel<false>, dim3((unsigned)(p->B * p->H)), dim3(WTHR), lds, s, *p);
+  }
   return 0;
 }
 
 int grove_win_attn_fwd_launch(const grove_flash_attn_params* p, hipStream_t s) {
   const size_t lds = 2 * WIMGB + WEB;
-  hipFuncSetAttribute((const void*)win_attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(win_attn_fwd_kernel, dim3((unsigned)(p->B * p->H)), dim3(WTHR), lds, s, *p);
+  if (p->rel_table) {
+    hipFuncSetAttribute((const void*)win_attn_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(win_attn_fwd_kernel<true>, dim3((unsigned)(p->B * p->H)), dim3(WTHR), lds, s, *p);
+  } else {
+    hipFuncSetAttribute((const void*)win_attn_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(win_attn_fwd_kernel<false>, dim3((unsigned)(p->B * p->H)), dim3(WTHR), lds, s, *p);
+  }
   return 0;
 }

@@ -19,22 +19,26 @@ MODE = os.environ.get("GROVE_ATTN", "flash")
 
 class AttnCtx:
     __slots__ = ("probs", "B", "H", "L", "hs", "ld", "q_off", "k_off", "v_off", "alpha", "ld_p", "rel", "rel_hw",
-                 "out", "lse", "causal", "kv_len", "flash", "hs_valid", "q_valid", "pad_row", "o_map")
+                 "out", "lse", "causal", "kv_len", "flash", "hs_valid", "q_valid", "pad_row", "o_map", "rel_table")
 
 
 def attention_fwd(qkv, B, L, H, hs, q_off, k_off, v_off, alpha, *, causal=False, kv_len=None, rel=None, rel_hw=(0, 0),
-                  out=None, save=False, hs_valid=0, q_valid=None, pad_row=None, o_map=None, o_rows=0):
+                  out=None, save=False, hs_valid=0, q_valid=None, pad_row=None, o_map=None, o_rows=0, rel_table=None):
     """qkv: bf16 [B*L, ld]; head h of q/k/v lives at columns off + h*hs (hs = padded head dim, the pad
-    columns are exact zeros). Returns (out [B*L, H*hs], ctx or None)."""
+    columns are exact zeros). Returns (out [B*L, H*hs], ctx or None).
+    rel_table (ops.rel_table_images; window kernels): the rel-pos terms are made inside the attention kernels, rel must be None."""
     dev = qkv.device
     ld = qkv.stride(0)
-    if MODE == "flash" or rel is not None:  # the rel-pos bias exists only in the fused kernels
-        out, lse = ops.flash_attn(qkv, B, L, H, hs, q_off, k_off, v_off, alpha, causal=causal, kv_len=kv_len, rel=rel,
+    if MODE == "flash" or rel is not None or rel_table is not None:  # the rel-pos bias exists only in the fused kernels
+        if rel_table is not None and save:  # the operand the backward reads (written by the forward kernel)
+            rel = torch.empty((B * H, L, 32), dtype=torch.bfloat16, device=dev)
+        out, lse = ops.flash_attn(qkv, B, L, H, hs, q_off, k_off, v_off, alpha, causal=causal, kv_len=kv_len, rel=None if rel_table is not None else rel,
                                   rel_hw=rel_hw, out=out, want_lse=save, hs_valid=hs_valid, q_valid=q_valid, pad_row=pad_row, o_map=o_map,
-                                  o_rows=o_rows)
+                                  o_rows=o_rows, rel_table=rel_table, rel_out=rel if rel_table is not None else None)
         ctx = None
         if save:
             ctx = AttnCtx()
+            ctx.rel_table = rel_table
             ctx.hs_valid, ctx.q_valid, ctx.pad_row, ctx.o_map = hs_valid, q_valid, pad_row, o_map
             ctx.flash, ctx.out, ctx.lse, ctx.B, ctx.H, ctx.L, ctx.hs, ctx.ld = True, out, lse, B, H, L, hs, ld
             ctx.q_off, ctx.k_off, ctx.v_off, ctx.alpha = q_off, k_off, v_off, alpha
@@ -57,7 +61,7 @@ def attention_fwd(qkv, B, L, H, hs, q_off, k_off, v_off, alpha, *, causal=False,
     ctx = None
     if save:
         ctx = AttnCtx()
-        ctx.flash = False
+        ctx.flash, ctx.rel_table = False, None
         ctx.probs, ctx.B, ctx.H, ctx.L, ctx.hs, ctx.ld = probs, B, H, L, hs, ld
         ctx.q_off, ctx.k_off, ctx.v_off, ctx.alpha, ctx.ld_p = q_off, k_off, v_off, alpha, ld_p
         ctx.rel, ctx.rel_hw = rel, rel_hw
@@ -73,7 +77,8 @@ def attention_bwd(ctx, qkv, d_out, dqkv, want_drel=False, rope=None, grads_tok=F
     if ctx.flash:
         return ops.flash_attn_bwd(qkv, ctx.out, d_out, ctx.lse, dqkv, ctx.B, ctx.L, ctx.H, ctx.hs, ctx.q_off, ctx.k_off, ctx.v_off,
                                   ctx.alpha, causal=ctx.causal, kv_len=ctx.kv_len, rel=ctx.rel, rel_hw=ctx.rel_hw, want_drel=want_drel,
-                                  hs_valid=ctx.hs_valid, q_valid=ctx.q_valid, pad_row=ctx.pad_row, o_map=ctx.o_map, rope=ctx_rope, grads_tok=grads_tok)
+                                  hs_valid=ctx.hs_valid, q_valid=ctx.q_valid, pad_row=ctx.pad_row, o_map=ctx.o_map, rope=ctx_rope, grads_tok=grads_tok,
+                                  rel_table=ctx.rel_table)
     B, H, L, hs, ld, ld_p = ctx.B, ctx.H, ctx.L, ctx.hs, ctx.ld, ctx.ld_p
     dev = qkv.device
     bf = torch.bfloat16

@@ -492,9 +492,14 @@ def window_kernels_take(L, hs, hs_valid, rel_ld):
 
 
 def flash_attn(qkv, B, L, H, hs, q_off, k_off, v_off, alpha, *, causal=False, kv_len=None, rel=None, rel_hw=(0, 0), out=None,
-               want_lse=False, hs_valid=0, q_valid=None, pad_row=None, o_map=None, o_rows=0):
+               want_lse=False, hs_valid=0, q_valid=None, pad_row=None, o_map=None, o_rows=0, rel_table=None, rel_out=None):
     """Fused attention over a fused qkv activation [B*L, ld]; returns (out [B*L, H*hs], lse or None).
-    o_map (window kernels, with q_valid): out is [o_rows, H*hs_valid] in TOKEN order, row o_map[b*L + i] for position i of batch b."""
+    o_map (window kernels, with q_valid): out is [o_rows, H*hs_valid] in TOKEN order, row o_map[b*L + i] for position i of batch b.
+    rel_table (window kernels; grove_flash_attn_params.rel_table, see rel_table_images): the rel-pos terms are made inside the kernel; rel_out
+    (bf16 [B*H, L, 32], optional) receives the score-domain operand the backward needs."""
+    if rel_table is not None:
+        assert rel is None and rel_table.dtype == bf16 and rel_table.numel() == 2 * 64 * 80 and rel_table.is_contiguous()
+        assert rel_out is None or (rel_out.dtype == bf16 and rel_out.shape == (B * H, L, 32) and rel_out.is_contiguous())
     dev = qkv.device
     ld = qkv.stride(0)
     if out is None:
@@ -510,6 +515,8 @@ def flash_attn(qkv, B, L, H, hs, q_off, k_off, v_off, alpha, *, causal=False, kv
     p.ld_o = out.stride(0)
     p.causal, p.rel_kh, p.rel_kw, p.alpha = int(causal), rel_hw[0], rel_hw[1], alpha
     p.rel_ld = rel.shape[-1] if rel is not None else 0
+    if rel_table is not None:
+        p.rel_table, p.rel, p.rel_ld = _p(rel_table), _p(rel_out), 32
     p.hs_valid = hs_valid
     p.q_valid = _p(q_valid)
     if o_map is not None:
@@ -666,12 +673,14 @@ def rope_table(hd, theta, positions, device):
 
 
 def flash_attn_bwd(qkv, out, d_out, lse, dqkv, B, L, H, hs, q_off, k_off, v_off, alpha, *, causal=False, kv_len=None, rel=None,
-                   rel_hw=(0, 0), want_drel=False, hs_valid=0, q_valid=None, pad_row=None, o_map=None, rope=None, grads_tok=False):
+                   rel_hw=(0, 0), want_drel=False, hs_valid=0, q_valid=None, pad_row=None, o_map=None, rope=None, grads_tok=False, rel_table=None):
     """grads_tok (window kernels with o_map): dqkv is in TOKEN order with compact heads — [tokens, 3 * H * hs_valid], q | k | v blocks of
-    H * hs_valid columns — instead of the layout of qkv (grove_flash_attn_params.g_tok)."""
+    H * hs_valid columns — instead of the layout of qkv (grove_flash_attn_params.g_tok).
+    rel_table (window kernels): rel is the operand tensor the forward left (rel_out); dq leaves complete, no drel."""
     dev = qkv.device
     ld, ldd = qkv.stride(0), dqkv.stride(0)
     delta = torch.empty((B * H, L), dtype=torch.float32, device=dev)
+    assert rel_table is None or (rel is not None and not want_drel)
     drel = torch.empty_like(rel) if want_drel else None
     p = _lib.FlashAttnParams()
     p.q, p.k, p.v, p.o, p.d_o = _p(qkv[:, q_off:]), _p(qkv[:, k_off:]), _p(qkv[:, v_off:]), _p(out), _p(d_out)
@@ -702,8 +711,21 @@ def flash_attn_bwd(qkv, out, d_out, lse, dqkv, B, L, H, hs, q_off, k_off, v_off,
     if rope is not None:  # fused inverse RoPE of dq / dk: f32 [>= L, hs]
         assert rope.dtype == torch.float32 and rope.shape[1] == hs and rope.shape[0] >= L and rope.is_contiguous()
         p.rope = _p(rope)
+    p.rel_table = _p(rel_table)
     _lib.check(_lib.lib().grove_flash_attn_bwd(C.byref(p), _stream()), "grove_flash_attn_bwd")
     return drel
+
+
+def rel_table_images(rel_pos_h, rel_pos_w, size, alpha):
+    """grove_flash_attn_params.rel_table for size x size windows: T [64, 80] = [rel_pos_h reversed ; rel_pos_w reversed ; 0] / alpha (row r of a
+    part = the embedding of key - query = r - (size - 1): image_encoder.py:387-417 get_rel_pos with q_size == k_size, :420-458) followed by
+    T^T [80, 64], one bf16 buffer [2 * 5120]. Init-time only."""
+    n = 2 * size - 1
+    assert rel_pos_h.shape == (n, 80) and rel_pos_w.shape == (n, 80) and 2 * n <= 64
+    T = torch.zeros((64, 80), dtype=torch.float32, device=rel_pos_h.device)
+    T[:n] = rel_pos_h.float().flip(0) / alpha
+    T[n:2 * n] = rel_pos_w.float().flip(0) / alpha
+    return torch.cat([T.to(bf16).reshape(-1), T.to(bf16).t().contiguous().reshape(-1)]).contiguous()
 
 
 def flash_attn_tail(q, kv, B, Lq, Lk, H, hs, alpha, *, kv_len=None, want_lse=False):

@@ -421,6 +421,15 @@ typedef struct grove_flash_attn_params {
                        the halves of every head, in the epilogues of the two backward kernels (a lane holds both halves of its dims) — the
                        separate inverse-RoPE pass over dq | dk (46 MB read + written per LLaMA layer) is gone. Query i sits at position
                        i + Lk - Lq (the causal mask's alignment), key j at position j. */
+  const void* rel_table; /* window kernels only (round 6b): bf16 [2][64 * 80] or NULL — the decomposed rel-pos terms are then computed INSIDE the
+                       kernels from the relative-position embeddings themselves (image_encoder.py:420-458 add_decomposed_rel_pos + :387-417
+                       get_rel_pos with q_size == k_size), no grove_rel_bias_fwd / _bwd launch and no rel / d rel stream through HBM. First image
+                       T [64 rows][80 dims]: with n = Lq / rel_kw window rows, row r < 2n - 1 = rel_pos_h[2n - 2 - r] / alpha (the embedding of
+                       key row - query row = r - (n - 1)), row 2n - 1 + r (r < 2 rel_kw - 1) = rel_pos_w[2 rel_kw - 2 - r] / alpha, zero rows
+                       after; second image T^T [80][64]. Needs hs_valid = 80 and 2n + 2 rel_kw - 2 <= 64; rel_kh / rel_kw / rel_ld = 32 as with rel.
+                       fwd: rel, if given, is an OUTPUT — bf16 [B*H, Lq, 32], the score-domain (x alpha log2 e) bias operand of every valid
+                       query, kept for the backward; bwd: rel = that tensor, drel must be NULL, and dq already contains
+                       sum_bin d rel[q][bin] * T[bin's row for q] (what grove_rel_bias_bwd added). */
 } grove_flash_attn_params;
 int grove_flash_attn_fwd(const grove_flash_attn_params* p, void* stream);
 int grove_flash_attn_bwd(const grove_flash_attn_params* p, void* stream);
@@ -433,8 +442,10 @@ int grove_flash_attn_set_register_e(int32_t on);
 /* A/B knob (round 5): bit 0 = forward, bit 1 = backward dQ, bit 2 = backward dK / dV (head dim 96), bit 3 = the role-split
  * dK / dV of head dim 128, bit 4 = the dQ kernel at head dim 128 too (off by default: slower there) — the eight-wave ping-pong kernels (flash_attn2.hip: 512-thread workgroups, LDS-DMA rings, 32x32x16
  * MFMAs, rel-pos bias on the score accumulators / the matrix pipe) for head dims 64 / 96 / 128 without rel-pos or with SAM's
- * 32 x 32 global form; 0 = the round-2 four-wave kernels everywhere. Default 15. Results agree to fp32 sum order (different
- * tile shapes), not bit for bit. */
+ * 32 x 32 global form; 0 = the round-2 four-wave kernels everywhere. Bit 5 (round 6b): the non-causal launches of those kernels deal
+ * whole (batch, head) groups to an XCD — the blocks that stream one head's K / V (or Q / dO) share one L2 instead of eight; bit-identical
+ * results, a launch-order change only. Default 47. Results of the kernel families agree to fp32 sum order (different tile shapes), not
+ * bit for bit. */
 int grove_flash_attn_set_v2(int32_t mask);
 int grove_flash_attn_window_kernels_on(void);
 

@@ -1563,6 +1563,116 @@ def test_window_attention_valid_queries(dev, valid):
     assert torch.equal(dg[sel].view(ntok, 3, H, hd), want), "token-order dq / dk / dv"
 
 
+@pytest.mark.parametrize("valid", [[(14, 14), (4, 14), (14, 4), (4, 4)], [(1, 1), (3, 7), (14, 1), (9, 14)]])
+def test_window_attention_rel_pos_in_kernel(dev, valid):
+    """grove_flash_attn_params.rel_table (round 6b): the decomposed rel-pos terms made INSIDE the window kernels from the 27 + 27
+    embeddings (image_encoder.py:387-458) — against fp32 attention with add_decomposed_rel_pos written out, and against the two-stream
+    form (grove_rel_bias_fwd -> kernel -> grove_rel_bias_bwd) on the same inputs: o, lse, the operand tensor the forward leaves, dq
+    (with its rel-pos term), dk, dv; padded queries skipped, k / v of padded positions from pad_row, windowed and token-order layouts."""
+    from grove_amd import ops
+    from grove_amd.model.sam import _rcat_tables
+    B, H, L, hs, hd, ws = 4, 16, 196, 96, 80, 14
+    g = torch.Generator().manual_seed(123)
+    alpha = hd ** -0.5
+    rel_h = (torch.randn(2 * ws - 1, hd, generator=g) * 0.2).to(bf16)
+    rel_w = (torch.randn(2 * ws - 1, hd, generator=g) * 0.2).to(bf16)
+    T = ops.rel_table_images(rel_h.to(dev), rel_w.to(dev), ws, alpha)
+    rcat, rcat_t, khp, rel_ld = _rcat_tables(ws, rel_h.to(dev), rel_w.to(dev), hd, hs, alpha)
+    assert khp == 16 and rel_ld == 32
+    qkv = torch.zeros(B * L, 3, H, hs)
+    qkv[..., :hd] = torch.randn(B * L, 3, H, hd, generator=g) * 0.7
+    qkv = qkv.view(B * L, 3 * H * hs).to(bf16)
+    do = torch.zeros(B * L, H, hs)
+    do[..., :hd] = torch.randn(B * L, H, hd, generator=g) * 0.5
+    do = do.view(B * L, H * hs).to(bf16)
+    qmask = torch.zeros(B, ws, ws, dtype=torch.bool)
+    for b, (vy, vx) in enumerate(valid):
+        qmask[b, :vy, :vx] = True
+    qmask = qmask.view(B, L)
+    rows = qmask.view(-1)
+    pad_row = torch.zeros(3, H, hs)
+    pad_row[..., :hd] = torch.randn(3, H, hd, generator=g) * 0.7
+    pad_row = pad_row.view(-1).to(bf16)
+    filled = qkv.clone()
+    filled[~rows] = pad_row
+    # fp32 reference: add_decomposed_rel_pos written out
+    t = filled.float().view(B, L, 3, H, hs).requires_grad_(True)
+    q, k, v = t[:, :, 0].transpose(1, 2), t[:, :, 1].transpose(1, 2), t[:, :, 2].transpose(1, 2)   # [B, H, L, hs]
+    c = torch.arange(ws)
+    Rh = rel_h.float()[(c[:, None] - c[None, :]) + (ws - 1)]   # [qy, ky, hd]
+    Rw = rel_w.float()[(c[:, None] - c[None, :]) + (ws - 1)]
+    r_q = q[..., :hd].reshape(B, H, ws, ws, hd)
+    relh = torch.einsum("bnhwc,hkc->bnhwk", r_q, Rh)
+    relw = torch.einsum("bnhwc,wkc->bnhwk", r_q, Rw)
+    s = (q @ k.transpose(-1, -2) * alpha).view(B, H, ws, ws, ws, ws) + relh[..., :, None] + relw[..., None, :]
+    s = s.view(B, H, L, L)
+    o_ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B * L, H * hs)
+    o_ref.backward(do.float() * rows.view(-1, 1))
+    lse_ref = torch.logsumexp(s, -1).reshape(B * H, L)
+    gref = t.grad.reshape(B * L, 3 * H * hs)
+    qv = torch.tensor(valid, dtype=torch.int32).to(dev)
+    hm = qmask[:, None, :].expand(B, H, L).reshape(B * H, L)
+    holes = qkv.clone()
+    holes[~rows] = float("nan")
+    do_dev = do.clone()
+    do_dev[~rows] = float("nan")
+    # the two-stream form
+    rel_s = ops.rel_bias_fwd(holes.to(dev), rcat, B, H, L, hs, hd, q_valid=qv, kw=ws)
+    o_s, lse_s = ops.flash_attn(holes.to(dev), B, L, H, hs, 0, H * hs, 2 * H * hs, alpha, rel=rel_s, rel_hw=(16, ws), want_lse=True,
+                                hs_valid=hd, q_valid=qv, pad_row=pad_row.to(dev))
+    dq_s = torch.full((B * L, 3 * H * hs), float("nan"), dtype=bf16, device=dev)
+    dr_s = ops.flash_attn_bwd(holes.to(dev), o_s, do_dev.to(dev), lse_s, dq_s, B, L, H, hs, 0, H * hs, 2 * H * hs, alpha, rel=rel_s,
+                              rel_hw=(16, ws), want_drel=True, hs_valid=hd, q_valid=qv, pad_row=pad_row.to(dev))
+    ops.rel_bias_bwd(dr_s, rcat_t, dq_s, B, H, L, hs, hd, q_valid=qv, kw=ws)
+    # in the kernels
+    rel_o = torch.full((B * H, L, 32), float("nan"), dtype=bf16, device=dev)
+    o_k = torch.full((B * L, H * hs), float("nan"), dtype=bf16, device=dev)
+    o_k, lse_k = ops.flash_attn(holes.to(dev), B, L, H, hs, 0, H * hs, 2 * H * hs, alpha, rel_hw=(16, ws), want_lse=True, hs_valid=hd, q_valid=qv,
+                                pad_row=pad_row.to(dev), rel_table=T, rel_out=rel_o, out=o_k)
+    rd = rows.to(dev)
+
+    def err(a, b_):
+        return (a.float().cpu() - b_.float().cpu()).abs().max().item()
+    # both forms round the bias operand to bf16 once more than the fp32 reference: the in-kernel form must be as close to it as the streams
+    e_k, e_s = err(o_k[rd], o_ref[rows]), err(o_s[rd], o_ref[rows])
+    assert e_k <= max(1.5 * e_s, 1e-2 * o_ref.abs().max().item()), f"o vs fp32: in kernel {e_k:.4g}, two streams {e_s:.4g}"
+    close(o_k[rd], o_s[rd], 2e-2, "o vs the two-stream form")
+    assert torch.isnan(o_k[~rd].float()).all(), "rows of o at padded positions must not be written"
+    close(lse_k[hm.to(dev)], lse_ref[hm], 2e-3, "lse vs fp32")
+    sc = alpha * 1.4426950408889634
+    close(rel_o[hm.to(dev)], rel_s[hm.to(dev)].float() * sc, 2e-2, "the operand tensor = rel' x alpha log2 e")
+    assert torch.isnan(rel_o[(~hm).to(dev)].float()).all(), "operand rows at padded positions must not be written"
+    no_table = ops.flash_attn(holes.to(dev), B, L, H, hs, 0, H * hs, 2 * H * hs, alpha, rel_hw=(16, ws), hs_valid=hd, q_valid=qv,
+                              pad_row=pad_row.to(dev), rel_table=T)[0]   # inference: nothing kept
+    assert torch.equal(no_table[rd], o_k[rd])
+    dq_k = torch.full((B * L, 3 * H * hs), float("nan"), dtype=bf16, device=dev)
+    ops.flash_attn_bwd(holes.to(dev), o_k, do_dev.to(dev), lse_k, dq_k, B, L, H, hs, 0, H * hs, 2 * H * hs, alpha, rel=rel_o, rel_hw=(16, ws),
+                       hs_valid=hd, q_valid=qv, pad_row=pad_row.to(dev), rel_table=T)
+    for name, lo in (("dq", 0), ("dk", H * hs), ("dv", 2 * H * hs)):
+        want = gref[rows, lo:lo + H * hs]
+        e_k, e_s = err(dq_k[rd, lo:lo + H * hs], want), err(dq_s[rd, lo:lo + H * hs], want)
+        assert e_k <= max(1.5 * e_s, 2e-2 * want.abs().max().item()), f"{name} vs fp32: in kernel {e_k:.4g}, two streams {e_s:.4g}"
+        close(dq_k[rd, lo:lo + H * hs], dq_s[rd, lo:lo + H * hs], 3e-2, name + " vs the two-stream form")
+    assert torch.isnan(dq_k[~rd].float()).all(), "dq / dk / dv rows at padded positions must not be written"
+    # token order (o_map, g_tok): the same numbers at the mapped rows
+    ntok = int(rows.sum())
+    tok_of = torch.full((B * L,), -1, dtype=torch.int32)
+    tok_of[rows] = torch.randperm(ntok, generator=g).to(torch.int32)
+    omap = tok_of.to(dev)
+    sel = tok_of[rows].long().to(dev)
+    rel_t = torch.empty((B * H, L, 32), dtype=bf16, device=dev)
+    o_t, lse_t = ops.flash_attn(holes.to(dev), B, L, H, hs, 0, H * hs, 2 * H * hs, alpha, rel_hw=(16, ws), want_lse=True, hs_valid=hd, q_valid=qv,
+                                pad_row=pad_row.to(dev), o_map=omap, o_rows=ntok, rel_table=T, rel_out=rel_t)
+    assert torch.equal(o_t[sel].view(ntok, H, hd), o_k[rd].view(ntok, H, hs)[..., :hd]), "token-order o"
+    do_t = torch.zeros(ntok, H * hd, dtype=bf16, device=dev)
+    do_t[sel] = do_dev.to(dev)[rd].view(ntok, H, hs)[..., :hd].reshape(ntok, H * hd)
+    dg = torch.full((ntok, 3 * H * hd), float("nan"), dtype=bf16, device=dev)
+    ops.flash_attn_bwd(holes.to(dev), o_t, do_t, lse_t, dg, B, L, H, hs, 0, H * hs, 2 * H * hs, alpha, rel=rel_t, rel_hw=(16, ws), hs_valid=hd,
+                       q_valid=qv, pad_row=pad_row.to(dev), o_map=omap, grads_tok=True, rel_table=T)
+    assert not torch.isnan(dg.float()).any(), "every element of the token-order gradient must be written"
+    assert torch.equal(dg[sel].view(ntok, 3, H, hd), dq_k[rd].view(ntok, 3, H, hs)[..., :hd]), "token-order dq / dk / dv"
+
+
 def test_rel_bias_streams_skip_padded_positions(dev):
     """q_valid of the rel-pos streams: positions outside a window's top-left vy x vx block get no rel' row (the output starts as NaN
     and must stay NaN there), their d rel' rows are not read (NaN there) and their dq rows are not touched."""

@@ -82,3 +82,37 @@ for name, tokens in (("win real", False), ("win real tok", True)):
         e1.record(); torch.cuda.synchronize()
         res.append(e0.elapsed_time(e1) / 10)
     print(f"{name:12s} F={F} windows={B} H={H} (q_valid, pad_row{', o_map' if tokens else ''}): fwd {res[0]:.3f} ms | bwd {res[1]:.3f} ms", flush=True)
+
+# round 6b: the rel-pos terms made inside the window kernels (grove_flash_attn_params.rel_table) against the two streams they replace
+from grove_amd.model.sam import _rcat_tables
+rel_h = (torch.randn(2 * ws - 1, hd, device=dev) * 0.5).to(bf)
+rel_w = (torch.randn(2 * ws - 1, hd, device=dev) * 0.5).to(bf)
+T = ops.rel_table_images(rel_h, rel_w, ws, alpha)
+rcat, rcat_t, _, _ = _rcat_tables(ws, rel_h, rel_w, hd, hs, alpha)
+do = torch.randn(ntok, H * hd, device=dev).to(bf)
+dg = torch.empty((ntok, 3 * H * hd), dtype=bf, device=dev)
+rel_o = torch.empty((B * H, L, 32), dtype=bf, device=dev)
+out, lse = ops.flash_attn(qkv, B, L, H, hs, 0, H * hs, 2 * H * hs, alpha, rel_hw=(16, ws), want_lse=True, hs_valid=hd, q_valid=qv, pad_row=pad_row,
+                          o_map=omap, o_rows=ntok, rel_table=T, rel_out=rel_o)
+cases = {
+    "rel_bias_fwd stream": lambda: ops.rel_bias_fwd(qkv, rcat, B, H, L, hs, hd, out=rel_o, q_valid=qv, kw=ws),
+    "rel_bias_bwd stream": lambda: ops.rel_bias_bwd(rel_o, rcat_t, dg, B, H, L, hs, hd, q_valid=qv, kw=ws, dq_map=omap),
+    "fwd two-stream form (tok)": lambda: ops.flash_attn(qkv, B, L, H, hs, 0, H * hs, 2 * H * hs, alpha, rel=rel, rel_hw=(16, ws), want_lse=True, hs_valid=hd,
+                                                        q_valid=qv, pad_row=pad_row, o_map=omap, o_rows=ntok, out=out),
+    "fwd rel in kernel, operand kept": lambda: ops.flash_attn(qkv, B, L, H, hs, 0, H * hs, 2 * H * hs, alpha, rel_hw=(16, ws), want_lse=True, hs_valid=hd, q_valid=qv,
+                                                              pad_row=pad_row, o_map=omap, o_rows=ntok, rel_table=T, rel_out=rel_o, out=out),
+    "fwd rel in kernel, inference": lambda: ops.flash_attn(qkv, B, L, H, hs, 0, H * hs, 2 * H * hs, alpha, rel_hw=(16, ws), hs_valid=hd, q_valid=qv,
+                                                           pad_row=pad_row, o_map=omap, o_rows=ntok, rel_table=T, out=out),
+    "bwd two-stream form (g_tok)": lambda: ops.flash_attn_bwd(qkv, out, do, lse, dg, B, L, H, hs, 0, H * hs, 2 * H * hs, alpha, rel=rel, rel_hw=(16, ws), want_drel=True,
+                                                              hs_valid=hd, q_valid=qv, pad_row=pad_row, o_map=omap, grads_tok=True),
+    "bwd rel in kernel (g_tok)": lambda: ops.flash_attn_bwd(qkv, out, do, lse, dg, B, L, H, hs, 0, H * hs, 2 * H * hs, alpha, rel=rel_o, rel_hw=(16, ws), hs_valid=hd,
+                                                            q_valid=qv, pad_row=pad_row, o_map=omap, grads_tok=True, rel_table=T),
+}
+for name, fn in cases.items():
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    print(f"  {name:34s} {e0.elapsed_time(e1) / 10 * 1e3:7.1f} us", flush=True)

@@ -178,7 +178,7 @@ def attn_case(name, B, H, Lc, hs, hd, causal, rel_hw):
     screen(name + " eight-wave bwd (self)", bwd, bwd)
     L.grove_flash_attn_set_v2(0)
     o4, _ = fwd()
-    L.grove_flash_attn_set_v2(15)
+    L.grove_flash_attn_set_v2(47)
     err = (o_c.float() - o4.float()).abs().max().item()
     print(f"{name + ' eight-wave vs four-wave forward':55s} max |diff| {err:.4g}", flush=True)
     assert err < 2e-2
