@@ -301,6 +301,10 @@ class GROVEForCausalLM(torch.nn.Module):
                                 fp8_policy="det16_kv16" if (sam_mlp or not fp8) else (self.fp8_policy[:-7] if clip16 else self.fp8_policy))
         self.sam = SamEncoder(sd, d, dev, train=tr, grads=self._grad, fp32_stream=f32s, fp8_mlp=sam_mlp)
         self.decoder = BoxDecoder(sd, d, dev, grads=self._grad, pe_dtype=self.pe_dtype)
+        # round 6b: the box decoder's ~40 weight gradients and ~40 bias column sums (small, latency-bound launches: 3.6 ms of a serial
+        # chain in front of the SAM backward) leave the critical path — a side stream, joined before the group is handed to the exchange /
+        # the optimizer (GROVE_DEC_WGRAD_STREAM=0: in line, the A/B arm)
+        self.decoder.wgrad_stream = (torch.cuda.Stream(device=self.dev) if (tr and os.environ.get("GROVE_DEC_WGRAD_STREAM", "1") != "0") else None)
 
     def P(self, name):
         return Param(self._sd[name], self._grad.get(name))
@@ -756,7 +760,17 @@ class GROVEForCausalLM(torch.nn.Module):
             dte = torch.zeros((n_det, d.out_dim), dtype=torch.float32, device=self.dev)
             ops.scatter_add_f32(c.dec_state["text"].grad, dte, inst_det_t, c.N, d.out_dim)
             te.grad = ops.to_bf16(dte)
-        self._grads_final([DEC_PREFIX])  # box decoder + heads: first group to finish
+        dec_side = getattr(self.decoder, "wgrad_stream", None)
+        dec_side_done = None
+        if dec_side is not None and c.dec_state is not None:
+            # the decoder's weight / bias gradients ride a side stream (tape.py): the group is final when that stream has seen both its own
+            # launches and the norm / head gradients written on this one
+            dec_side.wait_stream(torch.cuda.current_stream(self.dev))
+            dec_side_done = torch.cuda.Event()
+            dec_side_done.record(dec_side)
+            self._grads_final([DEC_PREFIX], event=dec_side_done)
+        else:
+            self._grads_final([DEC_PREFIX])  # box decoder + heads: first group to finish
         # SAM (adapters' weight gradients, dgrad through blocks 31..8) needs d_emb only: it runs on the SAM stream beside the
         # lm_head / LLaMA / projector backward (disjoint slices of the flat gradient buffer), queued AFTER that longer chain
         main = torch.cuda.current_stream(self.dev)
@@ -845,6 +859,8 @@ class GROVEForCausalLM(torch.nn.Module):
         else:
             self.sam.backward(c.sam_ctx, ops.to_bf16(d_emb), on_adapter_done=lambda j: adapter_done(j, None))
             last_group()
+        if dec_side_done is not None:
+            main.wait_event(dec_side_done)  # (the optimizer reads the decoder's gradient views on this stream)
         self._ctx = None
 
     # ------------------------------------------------------------------ generation (GROVE.py:412-451, llava_llama.py:57-180)

@@ -192,7 +192,7 @@ class BoxDecoder:
         d = self.d
         D, g2 = d.dec_dim, d.sam_grid ** 2
         N = text_embeds.data.shape[0]
-        tp = Tape(enabled=train)
+        tp = Tape(enabled=train, side=getattr(self, "wgrad_stream", None) if train else None)
         # tokens = [iou | 4 mask | text]  (mask_decoder.py:166-173)
         out_tok = torch.cat([self.sd[M_ + "iou_token.weight"], self.sd[M_ + "mask_tokens.weight"]], 0)  # [5, D] (tiny concat of weights)
         tokens_data = torch.empty((N * 6, D), dtype=bf, device=self.dev)

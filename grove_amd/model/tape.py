@@ -31,8 +31,12 @@ class Param:
 
 
 class Tape:
-    def __init__(self, enabled=True):
+    def __init__(self, enabled=True, side=None):
+        """side (a torch.cuda.Stream or None): weight and bias gradients of `linear` are launched on that stream, gated on an event of
+        the launching stream — they feed nothing but the optimizer, so they leave the dgrad chain's critical path (the caller joins the
+        side stream before anything reads the gradient views)."""
         self.enabled = enabled
+        self.side = side
         self.fns = []
 
     def push(self, fn):
@@ -67,16 +71,30 @@ class Tape:
             dy = y.grad
             if dy is None:
                 return
+            side = self.side if (W.g is not None or (b is not None and b.g is not None)) else None
             if residual is not None:
-                Tape.acc(residual, dy if act == ops.ACT_NONE else dy.clone())
+                # (side stream: the residual branch may accumulate INTO the tensor it is handed while the weight gradient still reads dy)
+                Tape.acc(residual, dy if (act == ops.ACT_NONE and side is None) else dy.clone())
             dz = ops.act_bwd(pre, dy, act) if act != ops.ACT_NONE else dy
             if residual is not None and act == ops.ACT_NONE:
                 dz = dy  # shared with the residual branch: treated read-only below
             N, K = W.w.shape
-            if W.g is not None:
-                ops.wgrad(dz, x.data, W.g, K=M)  # dW[N, K] += dz^T x on the K-major operands as they lie in HBM
-            if b is not None and b.g is not None:
-                ops.colsum(dz, out=b.g, accumulate=True)
+
+            def param_grads():
+                if W.g is not None:
+                    ops.wgrad(dz, x.data, W.g, K=M)  # dW[N, K] += dz^T x on the K-major operands as they lie in HBM
+                if b is not None and b.g is not None:
+                    ops.colsum(dz, out=b.g, accumulate=True)
+            if side is None:
+                param_grads()
+            else:
+                ready = torch.cuda.Event()
+                ready.record()
+                with torch.cuda.stream(side):
+                    side.wait_event(ready)
+                    param_grads()
+                dz.record_stream(side)
+                x.data.record_stream(side)
             if x.needs_grad:
                 assert N % 32 == 0, "tape.linear dgrad needs out_features % 32 == 0"
                 wT = ops.transpose2d(W.w)  # [K, N]

@@ -311,6 +311,37 @@ def test_tower_overlap_changes_nothing_but_time(dev, det):
     assert g_off.abs().max().item() > 0 and torch.equal(g_on, g_off) and torch.equal(g_on2, g_off), (g_on - g_off).abs().max().item()
 
 
+def test_decoder_wgrad_side_stream_changes_nothing_but_time(dev, det):
+    """Round 6b: the box decoder's weight / bias gradients ride a side stream (tape.py, `decoder.wgrad_stream`), gated on events of the
+    dgrad chain and joined before the group is final. Scheduling only: in deterministic mode losses and the whole flat gradient are
+    BIT-equal to the in-line order's, with another stream keeping the memory system busy so that the two orders really interleave."""
+    T, args, d, engine = _engine(dev)
+    model = engine.module
+    side = model.decoder.wgrad_stream
+    assert side is not None, "the training model must own the decoder's side stream by default"
+    names = [n for n in model.trainable if "mask_decoder.transformer" in n and n.endswith("weight")]
+    assert names, "the decoder's transformer must be trainable here (its linears are what moves to the side stream)"
+    batch = _batch(d, dev, 4)
+    noise = torch.randn(16 << 20, device=dev)
+    churn = torch.cuda.Stream()
+    res = {}
+    for on in (True, False, True, True):
+        model.decoder.wgrad_stream = side if on else None
+        model.zero_grad()
+        out = engine(**batch)
+        with torch.cuda.stream(churn):
+            noise.mul_(1.0001)
+        engine.backward(out["loss"])
+        torch.cuda.synchronize()
+        res.setdefault(on, []).append(model._flat_grad.clone())
+    model.decoder.wgrad_stream = side
+    g_off = res[False][0]
+    lo = min(model._grad_off[n] for n in names)
+    assert g_off[lo:lo + 64].abs().max().item() > 0
+    for g_on in res[True]:
+        assert torch.equal(g_on, g_off), (g_on - g_off).abs().max().item()
+
+
 def test_tower_overlap_default_mode_agrees_to_accumulation_noise(dev):
     """The same comparison with the atomics on (the mode training runs in): agreement to accumulation-order noise."""
     T, args, d, engine = _engine(dev)
