@@ -761,6 +761,14 @@ extern "C" int grove_gemm_tn_bf16(const grove_gemm_tn_params* pp, void* stream) 
       split = (768 + tiles - 1) / tiles;
       if (split > nkt / 2) split = nkt / 2;
       if (split > 256) split = 256;
+      // a few output tiles under a very long K (the box decoder's key-side weight gradients: 128 x 256 from K = 98,304): every K range adds
+      // its whole tile with fp32 atomics onto the SAME addresses, and that serialises — measured time ~ 1.05 us x (k tiles per range) +
+      // 0.28 us x tiles x ranges (tools/dev/tn_split_sweep.py: 256 ranges 145-215 us, 32-64 ranges 63-87 us), minimal at the root below
+      if (tiles <= 8) {
+        int best = 1;
+        while ((long)(best + 1) * (best + 1) * tiles * 4 <= 15L * nkt) ++best;  // best = floor(sqrt(3.75 nkt / tiles))
+        if (split > best) split = best;
+      }
       if (split < 1) split = 1;
     }
   }

@@ -629,6 +629,8 @@ class GROVEForCausalLM(torch.nn.Module):
         F = emb_rows.shape[0]
         emb_rows2 = emb_rows.view(F * d.sam_grid ** 2, -1)
         if self.tower_overlap:
+            # (joining later — the CE head and the [DET] rows' text_hidden_fcs do not read the embeddings — was measured: +0.45 ms, same box,
+            # GROVE_LATE_JOIN arm of round 6b: those launches then share the device with the SAM tower's last GEMMs and slow them)
             main.wait_stream(self._sam_stream)
             emb_rows.record_stream(main)  # allocated under the SAM stream, read by the decoder on this one
         H = d.hidden

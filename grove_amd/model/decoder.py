@@ -181,7 +181,21 @@ class BoxDecoder:
         m = ops.resize_bilinear(masks.contiguous(), S, S)
         return ops.resize_bilinear(m, int(original_size[0]), int(original_size[1]), crop=(int(input_size[0]), int(input_size[1])))
 
-    def forward(self, image_emb_rows, text_embeds, frame_of_instance, train=False):
+    def prepare(self, frame_of_instance, N):
+        """The index tensors of one forward (and its backward) and the learned token rows — nothing here reads a tower's output, so the
+        caller can issue these ~20 tiny launches BEFORE it joins the SAM stream instead of on the serial stretch behind the join."""
+        d = self.d
+        g2 = d.sam_grid ** 2
+        t_idx = torch.arange(N * 6, device=self.dev, dtype=torch.int32)
+        neg = torch.full_like(t_idx, -1)
+        src5 = torch.where(t_idx % 6 < 5, t_idx % 6, neg)
+        dst5 = torch.where(t_idx % 6 < 5, t_idx, neg)
+        text_dst = (torch.arange(N, device=self.dev, dtype=torch.int32) * 6 + 5)
+        key_src = (frame_of_instance.to(torch.int64)[:, None] * g2 + torch.arange(g2, device=self.dev)[None]).reshape(-1).to(torch.int32)
+        out_tok = torch.cat([self.sd[M_ + "iou_token.weight"], self.sd[M_ + "mask_tokens.weight"]], 0)  # [5, D] (tiny concat of weights)
+        return dict(N=N, src5=src5, dst5=dst5, text_dst=text_dst, key_src=key_src, out_tok=out_tok)
+
+    def forward(self, image_emb_rows, text_embeds, frame_of_instance, train=False, prep=None):
         """image_emb_rows: bf16 [F*g*g, 256] channels-last SAM embeddings; text_embeds: Var bf16 [N, 256]
         ([DET] embeddings, one per (frame, DET) instance; fp32 allowed when not training); frame_of_instance: int32 [N] frame index.
         Returns (box f32 [N,4], obj f32 [N], state for backward). Without a backward to serve (train=False) the token side runs
@@ -194,17 +208,14 @@ class BoxDecoder:
         N = text_embeds.data.shape[0]
         tp = Tape(enabled=train, side=getattr(self, "wgrad_stream", None) if train else None)
         # tokens = [iou | 4 mask | text]  (mask_decoder.py:166-173)
-        out_tok = torch.cat([self.sd[M_ + "iou_token.weight"], self.sd[M_ + "mask_tokens.weight"]], 0)  # [5, D] (tiny concat of weights)
+        if prep is None or prep["N"] != N:
+            prep = self.prepare(frame_of_instance, N)
+        out_tok, src5, dst5, text_dst, key_src = prep["out_tok"], prep["src5"], prep["dst5"], prep["text_dst"], prep["key_src"]
         tokens_data = torch.empty((N * 6, D), dtype=bf, device=self.dev)
-        t_idx = torch.arange(N * 6, device=self.dev, dtype=torch.int32)
-        src5 = torch.where(t_idx % 6 < 5, t_idx % 6, torch.full_like(t_idx, -1))
-        dst5 = torch.where(t_idx % 6 < 5, t_idx, torch.full_like(t_idx, -1))
         ops.copy_rows(out_tok, tokens_data, N * 6, D, idx_src=src5, idx_dst=dst5)
-        text_dst = (torch.arange(N, device=self.dev, dtype=torch.int32) * 6 + 5)
         ops.copy_rows(text_embeds.data, tokens_data, N, D, idx_dst=text_dst)
         tokens = Var(tokens_data)
         # keys = image_embeddings[idx] + no_mask_embed  (:181-186; prompt_encoder.py:182-184)
-        key_src = (frame_of_instance.to(torch.int64)[:, None] * g2 + torch.arange(g2, device=self.dev)[None]).reshape(-1).to(torch.int32)
         keys0 = torch.empty((N * g2, D), dtype=bf, device=self.dev)
         ops.copy_rows(image_emb_rows, keys0, N * g2, D, idx_src=key_src)
         ops.add_bcast_rows(keys0, self.sd[PE_ + "no_mask_embed.weight"], 1, out=keys0)
@@ -245,7 +256,7 @@ class BoxDecoder:
         state = None
         if train:
             state = dict(tp=tp, queries=queries, q5=q5, hs=hs, mean=mean, rstd=rstd, hidden=hidden, box=box, text_dst=text_dst,
-                         tokens=tokens, keys_init=keys_init, key_src=key_src, N=N, text=text_embeds)
+                         tokens=tokens, keys_init=keys_init, key_src=key_src, N=N, text=text_embeds, src5=src5)
         return box, obj, state
 
     def backward(self, state, dbox, dobj, d_image_emb_rows):
@@ -278,8 +289,7 @@ class BoxDecoder:
         ops.copy_rows(tg, dtext, N, D, idx_src=state["text_dst"])
         state["text"].grad = dtext
         if G.get(M_ + "iou_token.weight") is not None:
-            t_idx = torch.arange(N * 6, device=self.dev, dtype=torch.int32)
-            tok_of_row = torch.where(t_idx % 6 < 5, t_idx % 6, torch.full_like(t_idx, -1))
+            tok_of_row = state["src5"]  # row -> learned token 0..4, -1 for the text rows
             tokg = torch.zeros((5, D), dtype=torch.float32, device=self.dev)
             ops.scatter_add_f32(tg, tokg, tok_of_row, N * 6, D)
             ops.axpy(G[M_ + "iou_token.weight"].view(-1), tokg[0])
