@@ -393,6 +393,41 @@ extern "C" int grove_scatter_add_f32(const void* src, float* dst, const int32_t*
   GROVE_LAUNCH_CHECK();
   return GROVE_OK;
 }
+// dst[(s * R + r), :] += sum over the segment's members i in [ptr[s], ptr[s + 1]) of src[(i * R + r), :]: a scatter-add whose index is
+// "member i belongs to segment s, members of a segment are consecutive" turned around — every output element has ONE owner, no atomics
+__global__ __launch_bounds__(EB) void segment_sum_rows_kernel(const bf16_raw* __restrict__ src, float* __restrict__ dst, const int32_t* __restrict__ ptr,
+                                                              int nseg, int R, int C8, int ld_src, int ld_dst) {
+  const int64_t total = (int64_t)nseg * R * C8;
+  for (int64_t t = (int64_t)blockIdx.x * EB + threadIdx.x; t < total; t += (int64_t)gridDim.x * EB) {
+    const int ch = (int)(t % C8);
+    const int64_t row = t / C8;          // s * R + r
+    const int sgm = (int)(row / R), r = (int)(row - (int64_t)sgm * R);
+    const int lo = ptr[sgm], hi = ptr[sgm + 1];
+    if (lo >= hi) continue;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int i = lo; i < hi; ++i) {
+      const u32x4_t u = *(const u32x4_t*)(src + ((int64_t)i * R + r) * ld_src + ch * 8);
+      acc[0] += bf_lo(u.x); acc[1] += bf_hi(u.x); acc[2] += bf_lo(u.y); acc[3] += bf_hi(u.y);
+      acc[4] += bf_lo(u.z); acc[5] += bf_hi(u.z); acc[6] += bf_lo(u.w); acc[7] += bf_hi(u.w);
+    }
+    float* d = dst + row * ld_dst + ch * 8;
+    f32x4_t a = *(const f32x4_t*)d, b = *(const f32x4_t*)(d + 4);
+    a[0] += acc[0]; a[1] += acc[1]; a[2] += acc[2]; a[3] += acc[3];
+    b[0] += acc[4]; b[1] += acc[5]; b[2] += acc[6]; b[3] += acc[7];
+    *(f32x4_t*)d = a;
+    *(f32x4_t*)(d + 4) = b;
+  }
+}
+extern "C" int grove_segment_sum_rows(const void* src, float* dst, const int32_t* seg_ptr, int32_t nseg, int32_t rows_per_seg, int32_t C, int32_t ld_src,
+                                      int32_t ld_dst, void* stream) {
+  GROVE_CHECK(src && dst && seg_ptr && nseg > 0 && rows_per_seg > 0 && C > 0, GROVE_E_SHAPE, "segment_sum_rows: bad shape");
+  GROVE_CHECK(C % 8 == 0 && ld_src % 8 == 0 && ld_dst % 4 == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, GROVE_E_ALIGN,
+              "segment_sum_rows: C / ld_src multiples of 8, ld_dst of 4, 16-byte aligned operands");
+  hipLaunchKernelGGL(segment_sum_rows_kernel, grid_for((int64_t)nseg * rows_per_seg * (C / 8)), dim3(EB), 0, (hipStream_t)stream, (const bf16_raw*)src, dst,
+                     seg_ptr, nseg, rows_per_seg, C / 8, ld_src, ld_dst);
+  GROVE_LAUNCH_CHECK();
+  return GROVE_OK;
+}
 extern "C" int grove_scatter_add_rows_f32(const float* src, float* dst, const int32_t* idx, int32_t rows, int32_t C, int32_t ld_src, int32_t ld_dst,
                                           void* stream) {
   GROVE_CHECK(rows > 0 && C > 0, GROVE_E_SHAPE, "scatter_add_rows_f32: bad shape");

@@ -259,6 +259,32 @@ constexpr int MAXK = 8;
 // loads: 0.5-0.7 ms per launch for 0.3 GFLOP); all Lq queries are evaluated against a key while it sits in registers, with a
 // per-thread online softmax that is merged across the block at the end.
 constexpr int FQ_T = 256;
+// wave-wide sum / max on the VALU alone (DPP quad permutes and row mirrors, then the two cross-row swaps of gfx950): the merges below
+// reduce ~100 values per thread, and __shfl_xor's ds_bpermute put 600 LDS-pipe instructions per wave in front of every store
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum_v(float v) {
+  v += dpp_f<0xB1>(v);    // quad_perm [1, 0, 3, 2]
+  v += dpp_f<0x4E>(v);    // quad_perm [2, 3, 0, 1]
+  v += dpp_f<0x141>(v);   // row_half_mirror: lanes i <-> 7 - i
+  v += dpp_f<0x140>(v);   // row_mirror: lanes i <-> 15 - i
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+__device__ __forceinline__ float wave_max_v(float v) {
+  v = fmaxf(v, dpp_f<0xB1>(v));
+  v = fmaxf(v, dpp_f<0x4E>(v));
+  v = fmaxf(v, dpp_f<0x141>(v));
+  v = fmaxf(v, dpp_f<0x140>(v));
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
 __device__ __forceinline__ void load_row16(const bf16_raw* p, float (&x)[16]) {
   const u32x4_t a = *(const u32x4_t*)p, b = *(const u32x4_t*)(p + 8);
   x[0] = bf_lo(a.x); x[1] = bf_hi(a.x); x[2] = bf_lo(a.y); x[3] = bf_hi(a.y); x[4] = bf_lo(a.z); x[5] = bf_hi(a.z); x[6] = bf_lo(a.w); x[7] = bf_hi(a.w);
@@ -268,7 +294,7 @@ __device__ __forceinline__ void load_row16(const bf16_raw* p, float (&x)[16]) {
 template <int NQ>  // compile-time bound on Lq (6 on the path, 8 = MAXQ otherwise): sizes the per-thread accumulators
 __global__ __launch_bounds__(FQ_T) void attn_fewq16_fwd_kernel(const grove_small_attn_params p) {
   __shared__ float qs[MAXQ][16];
-  __shared__ float red[FQ_T / 64];
+  __shared__ float wm[FQ_T / 64][MAXQ], wred[FQ_T / 64][MAXQ][17];
   const int inst = blockIdx.x / p.heads, h = blockIdx.x - inst * p.heads;
   const int tid = threadIdx.x;
   const bf16_raw* q = (const bf16_raw*)p.q + (int64_t)inst * p.Lq * p.ld_q + h * 16;
@@ -303,27 +329,46 @@ __global__ __launch_bounds__(FQ_T) void attn_fewq16_fwd_kernel(const grove_small
       }
     }
   }
+  // merge of the 256 per-thread softmax states: the wave reductions of ALL values first, then one trip through LDS per stage (two barriers
+  // in all — one block_max / block_sum per value was 108 reductions x 2 barriers, most of this launch's 93 us).
   bf16_raw* o = (bf16_raw*)p.o + (int64_t)inst * p.Lq * p.ld_o + h * 16;
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int qi = 0; qi < NQ; ++qi) {
+    const float mw = wave_max_v(m[qi]);
+    if (lane == 0) wm[wave][qi] = mw;
+  }
+  __syncthreads();
 #pragma unroll
   for (int qi = 0; qi < NQ; ++qi) {
     if (qi < p.Lq) {
-      const float M = block_max<FQ_T>(m[qi], red);
+      float M = wm[0][qi];
+#pragma unroll
+      for (int i = 1; i < FQ_T / 64; ++i) M = fmaxf(M, wm[i][qi]);
       const float w = m[qi] == -INFINITY ? 0.f : __expf(m[qi] - M);
-      const float L = block_sum<FQ_T>(l[qi] * w, red);
-      const float inv = 1.f / L;
+      const float lw = wave_sum_v(l[qi] * w);
+      if (lane == 0) wred[wave][qi][16] = lw;
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
-        const float r = block_sum<FQ_T>(acc[qi][c] * w, red);
-        if (tid == 0) o[(int64_t)qi * p.ld_o + c] = f2bf(r * inv);
+        const float r = wave_sum_v(acc[qi][c] * w);
+        if (lane == 0) wred[wave][qi][c] = r;
       }
     }
+  }
+  __syncthreads();
+  if (tid < p.Lq * 16) {
+    const int qi = tid >> 4, c = tid & 15;
+    float L = 0.f, r = 0.f;
+#pragma unroll
+    for (int i = 0; i < FQ_T / 64; ++i) { L += wred[i][qi][16]; r += wred[i][qi][c]; }
+    o[(int64_t)qi * p.ld_o + c] = f2bf(r * (1.f / L));
   }
 }
 
 template <int NQ>
 __global__ __launch_bounds__(FQ_T) void attn_fewq16_bwd_kernel(const grove_small_attn_params p) {
   __shared__ float qs[MAXQ][16], dos[MAXQ][16], Ms[MAXQ], Ls[MAXQ], deltas[MAXQ];
-  __shared__ float red[FQ_T / 64];
+  __shared__ float wm[FQ_T / 64][MAXQ], wred[FQ_T / 64][MAXQ][17];
   const int inst = blockIdx.x / p.heads, h = blockIdx.x - inst * p.heads;
   const int tid = threadIdx.x;
   const int HD = p.heads * 16;
@@ -363,13 +408,31 @@ __global__ __launch_bounds__(FQ_T) void attn_fewq16_bwd_kernel(const grove_small
       }
     }
   }
+  // (block-wide merges batched as in the forward: wave reductions of every value, then one LDS stage)
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int qi = 0; qi < NQ; ++qi) {
+    const float mw = wave_max_v(m[qi]);
+    if (lane == 0) wm[wave][qi] = mw;
+  }
+  __syncthreads();
 #pragma unroll
   for (int qi = 0; qi < NQ; ++qi) {
     if (qi < p.Lq) {
-      const float M = block_max<FQ_T>(m[qi], red);
-      const float L = block_sum<FQ_T>(m[qi] == -INFINITY ? 0.f : l[qi] * __expf(m[qi] - M), red);
-      if (tid == 0) { Ms[qi] = M; Ls[qi] = L; }
+      float M = wm[0][qi];
+#pragma unroll
+      for (int i = 1; i < FQ_T / 64; ++i) M = fmaxf(M, wm[i][qi]);
+      const float lw = wave_sum_v(m[qi] == -INFINITY ? 0.f : l[qi] * __expf(m[qi] - M));
+      if (lane == 0) wred[wave][qi][16] = lw;
+      if (tid == 0) Ms[qi] = M;
     }
+  }
+  __syncthreads();
+  if (tid < p.Lq) {
+    float L = 0.f;
+#pragma unroll
+    for (int i = 0; i < FQ_T / 64; ++i) L += wred[i][tid][16];
+    Ls[tid] = L;
   }
   __syncthreads();
   // pass 2 (K re-read: an L2 hit): dK, dV rows of my keys (written once, 16-byte stores), dQ partials reduced over the block at the end
@@ -419,11 +482,178 @@ __global__ __launch_bounds__(FQ_T) void attn_fewq16_bwd_kernel(const grove_small
     if (qi < p.Lq) {
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
-        const float r = block_sum<FQ_T>(dq[qi][c], red);
-        if (tid == 0) dqo[(int64_t)qi * HD + c] = r;
+        const float r = wave_sum_v(dq[qi][c]);
+        if (lane == 0) wred[wave][qi][c] = r;
       }
     }
   }
+  __syncthreads();
+  if (tid < p.Lq * 16) {
+    const int qi = tid >> 4, c = tid & 15;
+    float r = 0.f;
+#pragma unroll
+    for (int i = 0; i < FQ_T / 64; ++i) r += wred[i][qi][c];
+    dqo[(int64_t)qi * HD + c] = r;
+  }
+}
+
+// ---- "tiny" attention: Lq, Lk <= 8 at head dim 32 — the self attention of the box decoder's 6 tokens per instance (transformer.py:
+// 153-160; 8 heads x 32). The generic few-keys kernels gave it a 64-thread block per (instance, head) with 6 live lanes and 2-byte loads:
+// 55 us forward, 159 us backward (two memsets, a wave reduction + two atomics per gradient element) for 0.3 MFLOP per instance. Here a
+// lane is (pair, role): eight (instance, head) pairs per wave, role = the query (forward, dq) and then the key (dk, dv: plain stores,
+// every element written once — no atomics, no memset, nothing run-to-run); rows travel as 16-byte loads.
+__device__ __forceinline__ void load_row32(const bf16_raw* p, float (&x)[32]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const u32x4_t a = *(const u32x4_t*)(p + 8 * i);
+    x[8 * i + 0] = bf_lo(a.x); x[8 * i + 1] = bf_hi(a.x); x[8 * i + 2] = bf_lo(a.y); x[8 * i + 3] = bf_hi(a.y);
+    x[8 * i + 4] = bf_lo(a.z); x[8 * i + 5] = bf_hi(a.z); x[8 * i + 6] = bf_lo(a.w); x[8 * i + 7] = bf_hi(a.w);
+  }
+}
+__device__ __forceinline__ float dot32(const float (&a)[32], const float (&b)[32]) {
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < 32; ++c) s = fmaf(a[c], b[c], s);
+  return s;
+}
+
+__global__ __launch_bounds__(64) void attn_tiny32_fwd_kernel(const grove_small_attn_params p) {
+  const int pair = blockIdx.x * 8 + (threadIdx.x >> 3), role = threadIdx.x & 7;
+  if (pair >= p.inst * p.heads || role >= p.Lq) return;
+  const int inst = pair / p.heads, h = pair - inst * p.heads;
+  const float scale = rsqrtf(32.f);
+  float qv[32], row[32], s[MAXK];
+  load_row32((const bf16_raw*)p.q + ((int64_t)inst * p.Lq + role) * p.ld_q + h * 32, qv);
+  const bf16_raw* k = (const bf16_raw*)p.k + (int64_t)inst * p.Lk * p.ld_k + h * 32;
+  const bf16_raw* v = (const bf16_raw*)p.v + (int64_t)inst * p.Lk * p.ld_v + h * 32;
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < MAXK; ++j) {
+    s[j] = -INFINITY;
+    if (j < p.Lk) {
+      load_row32(k + (int64_t)j * p.ld_k, row);
+      s[j] = dot32(qv, row) * scale;
+      mx = fmaxf(mx, s[j]);
+    }
+  }
+  float l = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXK; ++j) {
+    s[j] = j < p.Lk ? __expf(s[j] - mx) : 0.f;
+    l += s[j];
+  }
+  const float inv = 1.f / l;
+  float o[32];
+#pragma unroll
+  for (int c = 0; c < 32; ++c) o[c] = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXK; ++j) {
+    if (j < p.Lk) {
+      load_row32(v + (int64_t)j * p.ld_v, row);
+#pragma unroll
+      for (int c = 0; c < 32; ++c) o[c] = fmaf(s[j], row[c], o[c]);
+    }
+  }
+  bf16_raw* orow = (bf16_raw*)p.o + ((int64_t)inst * p.Lq + role) * p.ld_o + h * 32;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    *(u32x4_t*)(orow + 8 * i) = u32x4_t{pack2bf(o[8 * i] * inv, o[8 * i + 1] * inv), pack2bf(o[8 * i + 2] * inv, o[8 * i + 3] * inv),
+                                        pack2bf(o[8 * i + 4] * inv, o[8 * i + 5] * inv), pack2bf(o[8 * i + 6] * inv, o[8 * i + 7] * inv)};
+}
+
+__global__ __launch_bounds__(64) void attn_tiny32_bwd_kernel(const grove_small_attn_params p) {
+  __shared__ float Ps[8][MAXQ][MAXK + 1], dSs[8][MAXQ][MAXK + 1];
+  const int pl = threadIdx.x >> 3, role = threadIdx.x & 7;
+  const int pair = blockIdx.x * 8 + pl;
+  const bool live = pair < p.inst * p.heads;
+  const int inst = live ? pair / p.heads : 0, h = live ? pair - inst * p.heads : 0;
+  const int HD = p.heads * 32;
+  const float scale = rsqrtf(32.f);
+  const bf16_raw* q = (const bf16_raw*)p.q + (int64_t)inst * p.Lq * p.ld_q + h * 32;
+  const bf16_raw* dO = (const bf16_raw*)p.d_o + (int64_t)inst * p.Lq * p.ld_o + h * 32;
+  const bf16_raw* k = (const bf16_raw*)p.k + (int64_t)inst * p.Lk * p.ld_k + h * 32;
+  const bf16_raw* v = (const bf16_raw*)p.v + (int64_t)inst * p.Lk * p.ld_v + h * 32;
+  if (live && role < p.Lq) {  // this lane as QUERY `role`: P, dS of its row, dq
+    float qv[32], dov[32], row[32], s[MAXK], dp[MAXK];
+    load_row32(q + (int64_t)role * p.ld_q, qv);
+    load_row32(dO + (int64_t)role * p.ld_o, dov);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < MAXK; ++j) {
+      s[j] = -INFINITY;
+      dp[j] = 0.f;
+      if (j < p.Lk) {
+        load_row32(k + (int64_t)j * p.ld_k, row);
+        s[j] = dot32(qv, row) * scale;
+        mx = fmaxf(mx, s[j]);
+        load_row32(v + (int64_t)j * p.ld_v, row);
+        dp[j] = dot32(dov, row);
+      }
+    }
+    float l = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXK; ++j) {
+      s[j] = j < p.Lk ? __expf(s[j] - mx) : 0.f;
+      l += s[j];
+    }
+    float delta = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXK; ++j) {
+      s[j] /= l;
+      delta += s[j] * dp[j];
+    }
+    float dq[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) dq[c] = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXK; ++j) {
+      if (j < p.Lk) {
+        const float ds = s[j] * (dp[j] - delta) * scale;
+        Ps[pl][role][j] = s[j];
+        dSs[pl][role][j] = ds;
+        load_row32(k + (int64_t)j * p.ld_k, row);
+#pragma unroll
+        for (int c = 0; c < 32; ++c) dq[c] = fmaf(ds, row[c], dq[c]);
+      }
+    }
+    float* dqo = (float*)p.dq + ((int64_t)inst * p.Lq + role) * HD + h * 32;
+#pragma unroll
+    for (int c = 0; c < 32; c += 4) *(f32x4_t*)(dqo + c) = f32x4_t{dq[c], dq[c + 1], dq[c + 2], dq[c + 3]};
+  }
+  __syncthreads();
+  if (live && role < p.Lk) {  // this lane as KEY `role`: dk = sum_q dS[q][role] q_q, dv = sum_q P[q][role] dO_q
+    float dk[32], dv[32], row[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) { dk[c] = 0.f; dv[c] = 0.f; }
+#pragma unroll
+    for (int qi = 0; qi < MAXQ; ++qi) {
+      if (qi < p.Lq) {
+        const float a = dSs[pl][qi][role], b = Ps[pl][qi][role];
+        load_row32(q + (int64_t)qi * p.ld_q, row);
+#pragma unroll
+        for (int c = 0; c < 32; ++c) dk[c] = fmaf(a, row[c], dk[c]);
+        load_row32(dO + (int64_t)qi * p.ld_o, row);
+#pragma unroll
+        for (int c = 0; c < 32; ++c) dv[c] = fmaf(b, row[c], dv[c]);
+      }
+    }
+    float* dko = (float*)p.dk + ((int64_t)inst * p.Lk + role) * HD + h * 32;
+    float* dvo = (float*)p.dv + ((int64_t)inst * p.Lk + role) * HD + h * 32;
+#pragma unroll
+    for (int c = 0; c < 32; c += 4) {
+      *(f32x4_t*)(dko + c) = f32x4_t{dk[c], dk[c + 1], dk[c + 2], dk[c + 3]};
+      *(f32x4_t*)(dvo + c) = f32x4_t{dv[c], dv[c + 1], dv[c + 2], dv[c + 3]};
+    }
+  }
+}
+
+// does the tiny kernel pair take this problem? (bf16 everywhere, Lq, Lk <= 8, head dim 32, 16-byte rows)
+static bool tiny32_applicable(const grove_small_attn_params* p, bool bwd) {
+  if (p->q_f32 || p->kv_f32 || p->o_f32 || p->d != 32 || p->Lq > MAXQ || p->Lk > MAXK) return false;
+  if (p->ld_q % 8 || p->ld_k % 8 || p->ld_v % 8 || p->ld_o % 8) return false;
+  uintptr_t a = (uintptr_t)p->q | (uintptr_t)p->k | (uintptr_t)p->v | (uintptr_t)p->o;
+  if (bwd) a |= (uintptr_t)p->d_o | (uintptr_t)p->dq | (uintptr_t)p->dk | (uintptr_t)p->dv;
+  return (a & 15) == 0;
 }
 
 __global__ __launch_bounds__(64) void attn_fewk_fwd_kernel(const grove_small_attn_params p) {
@@ -572,14 +802,49 @@ __global__ __launch_bounds__(256) void box_head_fwd_kernel(const grove_box_head_
   __syncthreads();
   const bf16_raw* W1 = (const bf16_raw*)p.W1;
   const bf16_raw* b1 = (const bf16_raw*)p.b1;
-  for (int j = wave; j < D; j += 4) {
-    float a = 0.f;
-    for (int c = lane; c < D; c += 64) a += bf2f(W1[(int64_t)j * D + c]) * xs[c];
-    a = wave_sum(a) + bf2f(b1[j]);
-    a = fmaxf(a, 0.f);
-    if (lane == 0) {
-      hs[j] = a;
-      if (p.hidden) p.hidden[(int64_t)n * D + j] = a;
+  if (D == 256 && (((uintptr_t)W1) & 15) == 0) {
+    // the path's size (transformer_dim 256): a row of W1 is 32 lanes x 16 bytes, so a wave takes two rows per load and four loads per trip
+    // (eight rows in flight), reduced over the half wave on the VALU — the loop below did one row per wave per trip with 2-byte loads and a
+    // six-step ds_bpermute reduction: 64 serial trips, 110 us for 96 instances
+    const int half = lane >> 5, l5 = lane & 31;
+    float xv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) xv[e] = xs[l5 * 8 + e];
+    for (int j0 = wave * 64; j0 < wave * 64 + 64; j0 += 8) {
+      float a[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const u32x4_t w = *(const u32x4_t*)(W1 + (int64_t)(j0 + 2 * u + half) * 256 + l5 * 8);
+        a[u] = bf_lo(w.x) * xv[0] + bf_hi(w.x) * xv[1] + bf_lo(w.y) * xv[2] + bf_hi(w.y) * xv[3] + bf_lo(w.z) * xv[4] + bf_hi(w.z) * xv[5] +
+               bf_lo(w.w) * xv[6] + bf_hi(w.w) * xv[7];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float v = a[u];
+        v += dpp_f<0xB1>(v);
+        v += dpp_f<0x4E>(v);
+        v += dpp_f<0x141>(v);
+        v += dpp_f<0x140>(v);
+        auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);  // the sum over this lane's 32-lane half
+        const int j = j0 + 2 * u + half;
+        v = fmaxf(v + bf2f(b1[j]), 0.f);
+        if (l5 == 0) {
+          hs[j] = v;
+          if (p.hidden) p.hidden[(int64_t)n * D + j] = v;
+        }
+      }
+    }
+  } else {
+    for (int j = wave; j < D; j += 4) {
+      float a = 0.f;
+      for (int c = lane; c < D; c += 64) a += bf2f(W1[(int64_t)j * D + c]) * xs[c];
+      a = wave_sum(a) + bf2f(b1[j]);
+      a = fmaxf(a, 0.f);
+      if (lane == 0) {
+        hs[j] = a;
+        if (p.hidden) p.hidden[(int64_t)n * D + j] = a;
+      }
     }
   }
   __syncthreads();
@@ -1049,6 +1314,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const grove_gemm_f32_para
   }
 }
 
+static int g_small_attn_tiny = 1;  // 0: the generic few-keys kernels also for the 6 x 6 self attention (A/B arm and second implementation for the tests)
+extern "C" int grove_small_attn_set_tiny(int32_t on) {
+  g_small_attn_tiny = on != 0;
+  return GROVE_OK;
+}
+
 static int small_attn_check(const grove_small_attn_params* p, const char* name) {
   GROVE_CHECK(p && p->inst > 0 && p->heads > 0 && p->Lq > 0 && p->Lk > 0, GROVE_E_SHAPE, "%s: bad shape", name);
   GROVE_CHECK(p->d > 0 && p->d <= MAXD, GROVE_E_SHAPE, "%s: head dim %d > %d", name, p->d, MAXD);
@@ -1076,6 +1347,11 @@ extern "C" int grove_small_attn_fwd(const grove_small_attn_params* p, void* stre
     GROVE_LAUNCH_CHECK();
     return GROVE_OK;
   }
+  if (tiny32_applicable(p, false) && g_small_attn_tiny) {
+    hipLaunchKernelGGL(attn_tiny32_fwd_kernel, dim3((p->inst * p->heads + 7) / 8), dim3(64), 0, s, *p);
+    GROVE_LAUNCH_CHECK();
+    return GROVE_OK;
+  }
   const bool vec16 = p->d == 16 && p->ld_q % 8 == 0 && p->ld_k % 8 == 0 && p->ld_v % 8 == 0 && p->ld_o % 8 == 0 &&
                      (((uintptr_t)p->q | (uintptr_t)p->k | (uintptr_t)p->v | (uintptr_t)p->o) & 15) == 0;
   if (p->Lk <= MAXK && vec16 && p->Lq >= 64) {
@@ -1099,6 +1375,11 @@ extern "C" int grove_small_attn_bwd(const grove_small_attn_params* p, void* stre
   GROVE_CHECK(p->d_o && p->dq && p->dk && p->dv && p->o, GROVE_E_SHAPE, "small_attn_bwd: d_o/dq/dk/dv/o required");
   GROVE_CHECK(!(p->q_f32 || p->kv_f32 || p->o_f32), GROVE_E_DTYPE, "small_attn_bwd: bf16 operands only (the fp32 token path is inference-only)");
   hipStream_t s = (hipStream_t)stream;
+  if (tiny32_applicable(p, true) && g_small_attn_tiny) {
+    hipLaunchKernelGGL(attn_tiny32_bwd_kernel, dim3((p->inst * p->heads + 7) / 8), dim3(64), 0, s, *p);
+    GROVE_LAUNCH_CHECK();
+    return GROVE_OK;
+  }
   if (p->Lk <= MAXK) {
     // dk/dv accumulate with atomics -> zero them first
     const size_t bytes = (size_t)p->inst * p->Lk * p->heads * p->d * sizeof(float);

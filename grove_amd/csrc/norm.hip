@@ -139,7 +139,7 @@ template <bool need_dw>
 constexpr int rows_per_wave() { return need_dw ? 8 : 1; }
 
 template <bool RMS, int MAXCH, bool need_dw>
-__global__ __launch_bounds__(256) void norm_bwd_kernel(const grove_norm_bwd_params p, unsigned* det) {
+__global__ __launch_bounds__(256) void norm_bwd_kernel(const grove_norm_bwd_params p, unsigned* det, const int rows_per_wave_rt) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* red = (float*)smem_raw;  // [2][C] when dweight requested
   const int lane = threadIdx.x & 63;
@@ -165,7 +165,9 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const grove_norm_bwd_para
 #pragma unroll
     for (int e = 0; e < 8; ++e) { dw[i][e] = 0.f; db[i][e] = 0.f; }
 
-  constexpr int ROWS_PER_WAVE = rows_per_wave<need_dw>();
+  // (need_dw: 8 rows per wave, more on long inputs — every block ends in one global atomic per channel and parameter, and 3,072 blocks
+  // adding onto the same 512 addresses were most of the 111 us of the box decoder's key-side norms, 98,304 rows of 256)
+  const int ROWS_PER_WAVE = rows_per_wave_rt;
   const int row_base = (blockIdx.x * 4 + wave) * ROWS_PER_WAVE;
   for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
     const int row = row_base + rr;
@@ -419,14 +421,21 @@ static int norm_bwd_launch(const grove_norm_bwd_params* p, bool rms, void* strea
   GROVE_CHECK(p->C % 8 == 0 && p->C <= MAXCH_ALL * 512, GROVE_E_SHAPE, "norm_bwd: C=%d unsupported", p->C);
   GROVE_CHECK(p->ld_x % 8 == 0 && p->ld_dy % 8 == 0 && p->ld_dx % 8 == 0, GROVE_E_ALIGN, "norm_bwd: leading dims must be multiples of 8");
   GROVE_CHECK(rms || (p->mean && p->rstd), GROVE_E_SHAPE, "layernorm_bwd: saved mean/rstd required");
-  const int rows_per_block = 4 * (p->dweight ? rows_per_wave<true>() : rows_per_wave<false>());
+  int rpw = p->dweight ? rows_per_wave<true>() : rows_per_wave<false>();
+  if (p->dweight) {  // about 768 blocks on long inputs (at most 64 rows per wave); short ones (the decoder's 576 token rows: 8 rows per wave were
+                     // 18 blocks of eight serial rows, 54 us) spread over up to 256 blocks first
+    const int want = (p->rows + 4 * 768 - 1) / (4 * 768);
+    const int few = p->rows / 1024;
+    rpw = want > 64 ? 64 : want > rpw ? want : few < 1 ? 1 : few < rpw ? few : rpw;
+  }
+  const int rows_per_block = 4 * rpw;
   const size_t lds = p->dweight ? (size_t)2 * p->C * sizeof(float) : 0;
   dim3 grid((p->rows + rows_per_block - 1) / rows_per_block);
   hipStream_t s_ = (hipStream_t)stream;
   const bool dw = p->dweight != nullptr;
   GROVE_CHECK(!(dw && p->C > 2048), GROVE_E_SHAPE, "norm_bwd: dweight supported for C <= 2048 only");
   unsigned* det = dw ? grove_det_ticket() : nullptr;
-#define NB(RMS, NCH, DW) hipLaunchKernelGGL((norm_bwd_kernel<RMS, NCH, DW>), grid, dim3(256), lds, s_, *p, det)
+#define NB(RMS, NCH, DW) hipLaunchKernelGGL((norm_bwd_kernel<RMS, NCH, DW>), grid, dim3(256), lds, s_, *p, det, (DW) ? rpw : 1)
 #define NB_C(RMS, DW)                 \
   do {                                \
     if (p->C <= 512) NB(RMS, 1, DW);  \

@@ -498,18 +498,20 @@ class GROVEForCausalLM(torch.nn.Module):
         hp.det_rows = det_rows.to(self.dev)
         dev_t = [hp.det_rows] + [t for t in (plan.tok, plan.kv_len, plan.vis_dst, plan.vis_src) if t is not None]
         # instance order = (sequence b, frame t, det k)  (repeat_interleave + boolean gather, GROVE.py:254-257)
-        inst_det, inst_frame, base = [], [], 0
+        inst_det, inst_frame, frame_ptr, base = [], [], [0], 0
         for b in range(B):
             for t in range(Tseq):
                 inst_det += list(range(base, base + hp.counts[b]))
                 inst_frame += [b * Tseq + t] * hp.counts[b]
+                frame_ptr.append(len(inst_frame))  # (instances come grouped by frame: the decoder's backward sums them per frame)
             base += hp.counts[b]
         hp.N = N = len(inst_det)
-        hp.inst_det_t = hp.inst_frame_t = None
+        hp.inst_det_t = hp.inst_frame_t = hp.inst_frame_ptr_t = None
         if int(det_rows.numel()):
             hp.inst_det_t = torch.tensor(inst_det, dtype=torch.int32).to(self.dev)
             hp.inst_frame_t = torch.tensor(inst_frame, dtype=torch.int32).to(self.dev)
-            dev_t += [hp.inst_det_t, hp.inst_frame_t]
+            hp.inst_frame_ptr_t = torch.tensor(frame_ptr, dtype=torch.int32).to(self.dev)
+            dev_t += [hp.inst_det_t, hp.inst_frame_t, hp.inst_frame_ptr_t]
         if not inference:
             lab = plan.labels
             valid = (lab[:, 1:] != IGNORE_INDEX)
@@ -684,7 +686,7 @@ class GROVEForCausalLM(torch.nn.Module):
                 text = te32.index_select(0, inst_det_t.long())
                 self._last_text = text  # the ([DET], frame) embeddings of this forward: predict_masks(...) takes them as prompts
             text_var = Var(text)
-            box, obj, dec_state = self.decoder.forward(emb_rows2, text_var, inst_frame_t, train=train)
+            box, obj, dec_state = self.decoder.forward(emb_rows2, text_var, inst_frame_t, train=train, frame_ptr=hp.inst_frame_ptr_t)
         # 6. split per clip / frame (GROVE.py:297-331)
         flat_box, flat_obj = box, obj
         off = 0

@@ -195,7 +195,9 @@ class BoxDecoder:
         out_tok = torch.cat([self.sd[M_ + "iou_token.weight"], self.sd[M_ + "mask_tokens.weight"]], 0)  # [5, D] (tiny concat of weights)
         return dict(N=N, src5=src5, dst5=dst5, text_dst=text_dst, key_src=key_src, out_tok=out_tok)
 
-    def forward(self, image_emb_rows, text_embeds, frame_of_instance, train=False, prep=None):
+    def forward(self, image_emb_rows, text_embeds, frame_of_instance, train=False, prep=None, frame_ptr=None):
+        # frame_ptr (int32 [F + 1] or None): instances of frame f are frame_ptr[f] .. frame_ptr[f + 1] - 1 (the instance order groups them by
+        # frame) — the backward then sums the key gradients per frame without atomics
         """image_emb_rows: bf16 [F*g*g, 256] channels-last SAM embeddings; text_embeds: Var bf16 [N, 256]
         ([DET] embeddings, one per (frame, DET) instance; fp32 allowed when not training); frame_of_instance: int32 [N] frame index.
         Returns (box f32 [N,4], obj f32 [N], state for backward). Without a backward to serve (train=False) the token side runs
@@ -256,7 +258,7 @@ class BoxDecoder:
         state = None
         if train:
             state = dict(tp=tp, queries=queries, q5=q5, hs=hs, mean=mean, rstd=rstd, hidden=hidden, box=box, text_dst=text_dst,
-                         tokens=tokens, keys_init=keys_init, key_src=key_src, N=N, text=text_embeds, src5=src5)
+                         tokens=tokens, keys_init=keys_init, key_src=key_src, N=N, text=text_embeds, src5=src5, frame_ptr=frame_ptr)
         return box, obj, state
 
     def backward(self, state, dbox, dobj, d_image_emb_rows):
@@ -282,7 +284,10 @@ class BoxDecoder:
         tokens = state["tokens"]
         state["tp"].backward()
         # gradient of the gathered image keys -> SAM embeddings (prompt_encoder.no_mask_embed is frozen, train.py:279-296)
-        ops.scatter_add_f32(state["keys_init"].grad, d_image_emb_rows, state["key_src"], N * g2, D)
+        if state.get("frame_ptr") is not None and (state["frame_ptr"].numel() - 1) * g2 == d_image_emb_rows.shape[0]:
+            ops.segment_sum_rows(state["keys_init"].grad, d_image_emb_rows, state["frame_ptr"], g2)
+        else:
+            ops.scatter_add_f32(state["keys_init"].grad, d_image_emb_rows, state["key_src"], N * g2, D)
         # tokens.grad: rows 0..4 of every instance -> iou/mask token weights; row 5 -> text embeddings
         tg = tokens.grad
         dtext = torch.empty((N, D), dtype=bf, device=self.dev)

@@ -911,6 +911,18 @@ def scatter_add_f32(src, dst, idx, rows, Cc):
     return dst
 
 
+def segment_sum_rows(src, dst, seg_ptr, rows_per_seg):
+    """dst (fp32 [nseg * rows_per_seg, C])[s * rows_per_seg + r] += sum of src (bf16 [members * rows_per_seg, C])[i * rows_per_seg + r] over the
+    members seg_ptr[s] <= i < seg_ptr[s + 1] (int32 [nseg + 1]) — grove_segment_sum_rows: the atomics-free form of a scatter-add over groups."""
+    _chk_dev(src, dst, seg_ptr)
+    nseg = seg_ptr.numel() - 1
+    assert src.dtype == bf16 and dst.dtype == torch.float32 and seg_ptr.dtype == torch.int32 and dst.shape[0] == nseg * rows_per_seg
+    assert src.shape[0] % rows_per_seg == 0 and src.shape[1] == dst.shape[1]
+    _lib.check(_lib.lib().grove_segment_sum_rows(_p(src), _p(dst), _p(seg_ptr), nseg, rows_per_seg, src.shape[1], src.stride(0), dst.stride(0), _stream()),
+               "grove_segment_sum_rows")
+    return dst
+
+
 def scatter_add_rows_f32(src, dst, idx):
     """dst (fp32 [*, C])[idx[r]] += src (fp32 [rows, C])[r]; idx -1 skips the row."""
     rows, Cc = src.shape

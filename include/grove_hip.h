@@ -671,6 +671,12 @@ int grove_copy_rows(const grove_rows_params* p, void* stream);
 /* dst_f32[idx[r], :] += src_bf16[r, :] with float atomics (embed_tokens / broadcast-row grads) */
 int grove_scatter_add_f32(const void* src, float* dst, const int32_t* idx, int32_t rows, int32_t C,
                           int32_t ld_src, int32_t ld_dst, void* stream);
+/* Round 6b: the same sum when the scattered rows come in consecutive groups — member i (rows_per_seg bf16 rows of C) belongs to segment s iff
+ * seg_ptr[s] <= i < seg_ptr[s + 1] (int32 [nseg + 1], non-decreasing): dst_f32[s * rows_per_seg + r, :] += sum_i src[i * rows_per_seg + r, :].
+ * One owner per output element: no atomics, the same bits every run. The box decoder's gradient w.r.t. the SAM embeddings (every frame's
+ * instances gathered its 1024 embedding rows: mask_decoder.py:181-186) — 165 -> 25 us against grove_scatter_add_f32 on 3 instances per frame. */
+int grove_segment_sum_rows(const void* src, float* dst, const int32_t* seg_ptr, int32_t nseg, int32_t rows_per_seg, int32_t C, int32_t ld_src,
+                           int32_t ld_dst, void* stream);
 /* the same with fp32 source rows: dst_f32[idx[r], :] += src_f32[r, :] (idx -1 = skipped). Sums the all-gathered (row id, row) pairs of
  * the sparse embed_tokens gradient exchange into the dense gradient (train.py:466-478's dense reduce-scatter replaced) */
 int grove_scatter_add_rows_f32(const float* src, float* dst, const int32_t* idx, int32_t rows, int32_t C,
@@ -724,6 +730,9 @@ typedef struct grove_small_attn_params {
 } grove_small_attn_params;
 int grove_small_attn_fwd(const grove_small_attn_params* p, void* stream);
 int grove_small_attn_bwd(const grove_small_attn_params* p, void* stream);
+/* A/B knob (round 6b): 1 (default) = Lq, Lk <= 8 at head dim 32 (the box decoder's token self attention) runs the lane-per-(pair, row) kernels —
+ * no atomics, every gradient element stored once; 0 = the generic few-keys kernels. Results agree to fp32 sum order. */
+int grove_small_attn_set_tiny(int32_t on);
 
 /* Exact-fp32 small GEMM on v_mfma_f32_16x16x4_f32: C f32 [M, N] = act(A f32 [M, K] . W bf16 [N, K]^T + bias bf16 [N]) + residual f32.
  * K % 16 == 0. C_bf16 (optional, same leading dim as C) receives the bf16 rounding. The token side of the two-way decoder

@@ -666,7 +666,8 @@ def test_cross_entropy(dev):
 
 
 # ----------------------------------------------------------------------------- decoder kernels
-@pytest.mark.parametrize("Lq,Lk,heads,d", [(6, 6, 8, 32), (6, 1024, 8, 16), (1024, 6, 8, 16), (5, 100, 2, 16), (8, 300, 4, 16), (3, 1500, 2, 16)])
+@pytest.mark.parametrize("Lq,Lk,heads,d", [(6, 6, 8, 32), (8, 8, 3, 32), (3, 5, 5, 32), (1, 1, 1, 32), (6, 1024, 8, 16), (1024, 6, 8, 16), (5, 100, 2, 16),
+                                           (8, 300, 4, 16), (3, 1500, 2, 16)])
 def test_small_attn(dev, Lq, Lk, heads, d):
     from grove_amd import ops
     inst = 3
@@ -685,6 +686,57 @@ def test_small_attn(dev, Lq, Lk, heads, d):
     close(dq, qr.grad, 2e-2, "dq")
     close(dk, kr.grad, 2e-2, "dk")
     close(dv, vr.grad, 2e-2, "dv")
+
+
+@pytest.mark.parametrize("Lq,Lk,heads", [(6, 6, 8), (8, 3, 3), (2, 8, 5)])
+def test_small_attn_tiny_kernels_match_the_generic_ones(dev, Lq, Lk, heads):
+    """Round 6b: Lq, Lk <= 8 at head dim 32 (the box decoder's token self attention, transformer.py:153-160) on the lane-per-(pair, row)
+    kernels against the generic few-keys kernels (grove_small_attn_set_tiny(0)) on the same operands: a partial last wave of pairs,
+    gradients stored once (NaN-filled outputs must come back fully written, and identical from run to run)."""
+    from grove_amd import _lib, ops
+    inst, d = 13, 32
+    q, k, v = rnd(inst * Lq, heads * d, seed=70), rnd(inst * Lk, heads * d, seed=71), rnd(inst * Lk, heads * d, seed=72)
+    do = rnd(inst * Lq, heads * d, seed=73)
+    args = (q.to(dev), k.to(dev), v.to(dev))
+    L = _lib.lib()
+    try:
+        L.grove_small_attn_set_tiny(0)
+        o_g = ops.small_attn(*args, inst, heads, d, Lq, Lk)
+        g_g = ops.small_attn_bwd(*args, o_g, do.to(dev), inst, heads, d, Lq, Lk)
+    finally:
+        L.grove_small_attn_set_tiny(1)
+    o_t = ops.small_attn(*args, inst, heads, d, Lq, Lk)
+    g_t = ops.small_attn_bwd(*args, o_t, do.to(dev), inst, heads, d, Lq, Lk)
+    g_t2 = ops.small_attn_bwd(*args, o_t, do.to(dev), inst, heads, d, Lq, Lk)
+    close(o_t, o_g, 4e-3, "o")
+    for a, b, c, name in zip(g_t, g_g, g_t2, ("dq", "dk", "dv")):
+        assert torch.isfinite(a).all(), name
+        close(a, b, 1e-4, name)
+        assert torch.equal(a, c), name + ": no atomics, so two runs are the same bits"
+
+
+def test_segment_sum_rows_matches_scatter_add(dev):
+    """Round 6b: grove_segment_sum_rows (one owner per output element) against the atomics form on the same grouped index: empty segments,
+    segments of 1..4 members, an accumulate into a non-zero destination; exact against an fp32 sum in member order, and the same bits twice."""
+    from grove_amd import ops
+    R, Cc = 48, 64
+    counts = [3, 0, 1, 4, 2, 0, 3]
+    ptr = torch.tensor([0] + list(torch.tensor(counts).cumsum(0)), dtype=torch.int32)
+    n = int(ptr[-1])
+    src = rnd(n * R, Cc, seed=81)
+    dst0 = torch.randn(len(counts) * R, Cc, generator=torch.Generator().manual_seed(82))
+    ref = dst0.clone()
+    for s_, (lo, hi) in enumerate(zip(ptr[:-1].tolist(), ptr[1:].tolist())):
+        for i in range(lo, hi):
+            ref[s_ * R:(s_ + 1) * R] += src[i * R:(i + 1) * R].float()
+    a = ops.segment_sum_rows(src.to(dev), dst0.clone().to(dev), ptr.to(dev), R)
+    b = ops.segment_sum_rows(src.to(dev), dst0.clone().to(dev), ptr.to(dev), R)
+    seg_of = torch.repeat_interleave(torch.arange(len(counts)), torch.tensor(counts))
+    idx = (seg_of[:, None] * R + torch.arange(R)[None]).reshape(-1).to(torch.int32)
+    c = ops.scatter_add_f32(src.to(dev), dst0.clone().to(dev), idx.to(dev), n * R, Cc)
+    assert torch.equal(a, b)
+    close(a, ref, 1e-6, "segment sum vs fp32")
+    close(a, c, 1e-6, "segment sum vs scatter-add")
 
 
 def test_box_head_and_losses(dev):
