@@ -84,7 +84,11 @@ class RowsParams(C.Structure):
 class SmallAttnParams(C.Structure):
     _fields_ = [("q", c_vp), ("k", c_vp), ("v", c_vp), ("o", c_vp), ("d_o", c_vp), ("dq", c_vp), ("dk", c_vp), ("dv", c_vp),
                 ("inst", c_i32), ("heads", c_i32), ("d", c_i32), ("Lq", c_i32), ("Lk", c_i32),
-                ("ld_q", c_i32), ("ld_k", c_i32), ("ld_v", c_i32), ("ld_o", c_i32), ("q_f32", c_i32), ("kv_f32", c_i32), ("o_f32", c_i32)]
+                ("ld_q", c_i32), ("ld_k", c_i32), ("ld_v", c_i32), ("ld_o", c_i32), ("q_f32", c_i32), ("kv_f32", c_i32), ("o_f32", c_i32), ("grad_bf16", c_i32)]
+
+
+class TransposeItem(C.Structure):
+    _fields_ = [("src", c_vp), ("dst", c_vp), ("rows", c_i32), ("cols", c_i32), ("ld_src", c_i32), ("ld_dst", c_i32), ("tile0", c_i32), ("pad_", c_i32)]
 
 
 class BoxHeadParams(C.Structure):
@@ -188,8 +192,8 @@ SYMBOLS = [
     "grove_transpose_bf16", "grove_layernorm_fwd", "grove_rmsnorm_fwd", "grove_layernorm_bwd", "grove_rmsnorm_bwd",
     "grove_flash_attn_fwd", "grove_flash_attn_bwd", "grove_flash_attn_set_window_kernels", "grove_flash_attn_set_register_e", "grove_flash_attn_set_v2", "grove_flash_attn_window_kernels_on", "grove_softmax_fwd", "grove_softmax_bwd", "grove_relpos_fwd", "grove_relpos_bwd", "grove_rel_bias_fwd", "grove_rel_bias_bwd", "grove_rope_inplace",
     "grove_swiglu_fwd", "grove_swiglu_bwd", "grove_act_bwd", "grove_act_fwd", "grove_resize_bilinear_f32", "grove_add_bf16", "grove_add_bcast_rows",
-    "grove_copy_rows", "grove_dot_bf16", "grove_axpy_f32", "grove_scatter_add_f32", "grove_segment_sum_rows", "grove_scatter_add_rows_f32", "grove_colsum_f32", "grove_cast_f32_to_bf16", "grove_cast_bf16_to_f32",
-    "grove_im2col_patch", "grove_clip_pool", "grove_cross_entropy", "grove_small_attn_fwd", "grove_small_attn_bwd", "grove_small_attn_set_tiny", "grove_gemm_f32", "grove_gemm_fp8", "grove_gemm_fp8_set_pipelined", "grove_quant_fp8_rows", "grove_quant_fp8_rows_act",
+    "grove_copy_rows", "grove_dot_bf16", "grove_axpy_f32", "grove_scatter_add_f32", "grove_segment_sum_rows", "grove_transpose_many", "grove_scatter_add_rows_f32", "grove_colsum_f32", "grove_cast_f32_to_bf16", "grove_cast_bf16_to_f32",
+    "grove_im2col_patch", "grove_clip_pool", "grove_cross_entropy", "grove_small_attn_fwd", "grove_small_attn_bwd", "grove_small_attn_set_tiny", "grove_small_attn_bwd_stores_bf16", "grove_gemm_f32", "grove_gemm_fp8", "grove_gemm_fp8_set_pipelined", "grove_quant_fp8_rows", "grove_quant_fp8_rows_act",
     "grove_box_head_fwd", "grove_box_head_bwd", "grove_box_losses", "grove_adamw_step", "grove_adamw_step_multi", "grove_sumsq_f32",
     "grove_wino3d_transform_tokens", "grove_wino3d_transform_weight", "grove_wino3d_output", "grove_wino3d_wgrad_output",
 ]

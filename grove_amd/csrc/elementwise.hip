@@ -311,7 +311,38 @@ __global__ __launch_bounds__(256) void transpose_kernel(const grove_transpose_pa
   }
 }
 
+// Many small 2-D transposes in ONE launch (the box decoder's ~40 weight transposes per backward were ~40 launch-bound kernels of 8-15 us
+// on a serial chain): a device array of items, block -> (item, 64 x 64 tile) through the items' running tile counts.
+__global__ __launch_bounds__(256) void transpose_many_kernel(const grove_transpose_item* __restrict__ items, int n_items) {
+  __shared__ bf16_raw tile[64][66];
+  int it = 0;
+  while (it + 1 < n_items && (int)blockIdx.x >= items[it + 1].tile0) ++it;
+  const grove_transpose_item m = items[it];
+  const int t = blockIdx.x - m.tile0;
+  const int tiles_x = (m.cols + 63) / 64;
+  const int r0 = (t / tiles_x) * 64, c0 = (t % tiles_x) * 64;
+  const bf16_raw* __restrict__ in = (const bf16_raw*)m.src;
+  bf16_raw* __restrict__ out = (bf16_raw*)m.dst;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < m.rows && c < m.cols) ? in[(int64_t)r * m.ld_src + c] : (bf16_raw)0;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int oc = r0 + tx, orow = c0 + i;
+    if (orow < m.cols && oc < m.rows) out[(int64_t)orow * m.ld_dst + oc] = tile[tx][i];
+  }
+}
+
 }  // namespace
+
+extern "C" int grove_transpose_many(const grove_transpose_item* items_dev, int32_t n_items, int32_t total_tiles, void* stream) {
+  GROVE_CHECK(items_dev && n_items > 0 && total_tiles > 0, GROVE_E_SHAPE, "transpose_many: bad arguments");
+  hipLaunchKernelGGL(transpose_many_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, items_dev, n_items);
+  GROVE_LAUNCH_CHECK();
+  return GROVE_OK;
+}
 
 #define CHECK_VEC8(n, name) GROVE_CHECK((n) % 8 == 0, GROVE_E_ALIGN, "%s: size must be a multiple of 8 elements", name)
 

@@ -291,6 +291,21 @@ __device__ __forceinline__ void load_row16(const bf16_raw* p, float (&x)[16]) {
   x[8] = bf_lo(b.x); x[9] = bf_hi(b.x); x[10] = bf_lo(b.y); x[11] = bf_hi(b.y); x[12] = bf_lo(b.z); x[13] = bf_hi(b.z); x[14] = bf_lo(b.w); x[15] = bf_hi(b.w);
 }
 
+// a gradient row piece of N consecutive elements at element offset `off` of an fp32 or (grove_small_attn_params.grad_bf16) bf16 array
+template <int N>
+__device__ __forceinline__ void store_grad(void* base, int64_t off, const float (&v)[N], bool as_bf16) {
+  if (as_bf16) {
+    bf16_raw* o = (bf16_raw*)base + off;
+#pragma unroll
+    for (int c = 0; c < N; c += 8)
+      *(u32x4_t*)(o + c) = u32x4_t{pack2bf(v[c], v[c + 1]), pack2bf(v[c + 2], v[c + 3]), pack2bf(v[c + 4], v[c + 5]), pack2bf(v[c + 6], v[c + 7])};
+  } else {
+    float* o = (float*)base + off;
+#pragma unroll
+    for (int c = 0; c < N; c += 4) *(f32x4_t*)(o + c) = f32x4_t{v[c], v[c + 1], v[c + 2], v[c + 3]};
+  }
+}
+
 template <int NQ>  // compile-time bound on Lq (6 on the path, 8 = MAXQ otherwise): sizes the per-thread accumulators
 __global__ __launch_bounds__(FQ_T) void attn_fewq16_fwd_kernel(const grove_small_attn_params p) {
   __shared__ float qs[MAXQ][16];
@@ -441,8 +456,8 @@ __global__ __launch_bounds__(FQ_T) void attn_fewq16_bwd_kernel(const grove_small
   for (int qi = 0; qi < NQ; ++qi)
 #pragma unroll
     for (int c = 0; c < 16; ++c) dq[qi][c] = 0.f;
-  float* dk = (float*)p.dk + (int64_t)inst * p.Lk * HD + h * 16;
-  float* dv = (float*)p.dv + (int64_t)inst * p.Lk * HD + h * 16;
+  const int64_t kv0 = (int64_t)inst * p.Lk * HD + h * 16;
+  const bool gbf = p.grad_bf16 != 0;
   {
     for (int j = tid; j < p.Lk; j += FQ_T) {
       float kk[16], vv[16], dkk[16], dvv[16];
@@ -469,14 +484,11 @@ __global__ __launch_bounds__(FQ_T) void attn_fewq16_bwd_kernel(const grove_small
           }
         }
       }
-#pragma unroll
-      for (int c = 0; c < 16; c += 4) {
-        *(f32x4_t*)(dk + (int64_t)j * HD + c) = f32x4_t{dkk[c], dkk[c + 1], dkk[c + 2], dkk[c + 3]};
-        *(f32x4_t*)(dv + (int64_t)j * HD + c) = f32x4_t{dvv[c], dvv[c + 1], dvv[c + 2], dvv[c + 3]};
-      }
+      store_grad<16>(p.dk, kv0 + (int64_t)j * HD, dkk, gbf);
+      store_grad<16>(p.dv, kv0 + (int64_t)j * HD, dvv, gbf);
     }
   }
-  float* dqo = (float*)p.dq + (int64_t)inst * p.Lq * HD + h * 16;
+  const int64_t dq0 = (int64_t)inst * p.Lq * HD + h * 16;
 #pragma unroll
   for (int qi = 0; qi < NQ; ++qi) {
     if (qi < p.Lq) {
@@ -493,7 +505,8 @@ __global__ __launch_bounds__(FQ_T) void attn_fewq16_bwd_kernel(const grove_small
     float r = 0.f;
 #pragma unroll
     for (int i = 0; i < FQ_T / 64; ++i) r += wred[i][qi][c];
-    dqo[(int64_t)qi * HD + c] = r;
+    if (gbf) ((bf16_raw*)p.dq)[dq0 + (int64_t)qi * HD + c] = f2bf(r);
+    else ((float*)p.dq)[dq0 + (int64_t)qi * HD + c] = r;
   }
 }
 
@@ -616,9 +629,7 @@ __global__ __launch_bounds__(64) void attn_tiny32_bwd_kernel(const grove_small_a
         for (int c = 0; c < 32; ++c) dq[c] = fmaf(ds, row[c], dq[c]);
       }
     }
-    float* dqo = (float*)p.dq + ((int64_t)inst * p.Lq + role) * HD + h * 32;
-#pragma unroll
-    for (int c = 0; c < 32; c += 4) *(f32x4_t*)(dqo + c) = f32x4_t{dq[c], dq[c + 1], dq[c + 2], dq[c + 3]};
+    store_grad<32>(p.dq, ((int64_t)inst * p.Lq + role) * HD + h * 32, dq, p.grad_bf16 != 0);
   }
   __syncthreads();
   if (live && role < p.Lk) {  // this lane as KEY `role`: dk = sum_q dS[q][role] q_q, dv = sum_q P[q][role] dO_q
@@ -637,13 +648,8 @@ __global__ __launch_bounds__(64) void attn_tiny32_bwd_kernel(const grove_small_a
         for (int c = 0; c < 32; ++c) dv[c] = fmaf(b, row[c], dv[c]);
       }
     }
-    float* dko = (float*)p.dk + ((int64_t)inst * p.Lk + role) * HD + h * 32;
-    float* dvo = (float*)p.dv + ((int64_t)inst * p.Lk + role) * HD + h * 32;
-#pragma unroll
-    for (int c = 0; c < 32; c += 4) {
-      *(f32x4_t*)(dko + c) = f32x4_t{dk[c], dk[c + 1], dk[c + 2], dk[c + 3]};
-      *(f32x4_t*)(dvo + c) = f32x4_t{dv[c], dv[c + 1], dv[c + 2], dv[c + 3]};
-    }
+    store_grad<32>(p.dk, ((int64_t)inst * p.Lk + role) * HD + h * 32, dk, p.grad_bf16 != 0);
+    store_grad<32>(p.dv, ((int64_t)inst * p.Lk + role) * HD + h * 32, dv, p.grad_bf16 != 0);
   }
 }
 
@@ -1369,9 +1375,32 @@ extern "C" int grove_small_attn_fwd(const grove_small_attn_params* p, void* stre
   return GROVE_OK;
 }
 
+// which backward kernel family takes the problem: 0 tiny32, 1 few keys (atomics), 2 few queries at head dim 16, 3 generic few queries
+static int small_attn_bwd_family(const grove_small_attn_params* p) {
+  if (tiny32_applicable(p, true) && g_small_attn_tiny) return 0;
+  if (p->Lk <= MAXK) return 1;
+  if (p->d == 16 && p->ld_q % 8 == 0 && p->ld_k % 8 == 0 && p->ld_v % 8 == 0 && (((uintptr_t)p->k | (uintptr_t)p->v) & 15) == 0 &&
+      (((uintptr_t)p->dk | (uintptr_t)p->dv) & 15) == 0)
+    return 2;
+  return 3;
+}
+extern "C" int grove_small_attn_bwd_stores_bf16(const grove_small_attn_params* p) {
+  if (!p || p->q_f32 || p->kv_f32 || p->o_f32 || p->inst <= 0 || (p->heads * p->d) % 8 != 0) return 0;
+  grove_small_attn_params q = *p;  // (asked before the gradient arrays exist: judge the shape with aligned stand-ins)
+  q.dq = q.dk = q.dv = (void*)16;
+  if (!q.d_o) q.d_o = q.o;
+  const int f = small_attn_bwd_family(&q);
+  return (f == 0 || f == 2) ? 1 : 0;
+}
+
 extern "C" int grove_small_attn_bwd(const grove_small_attn_params* p, void* stream) {
   int rc = small_attn_check(p, "small_attn_bwd");
   if (rc) return rc;
+  {
+    const int f = small_attn_bwd_family(p);
+    GROVE_CHECK(!p->grad_bf16 || ((f == 0 || f == 2) && (p->heads * p->d) % 8 == 0), GROVE_E_DTYPE,
+                "small_attn_bwd: grad_bf16 only where every gradient element is stored once (ask grove_small_attn_bwd_stores_bf16)");
+  }
   GROVE_CHECK(p->d_o && p->dq && p->dk && p->dv && p->o, GROVE_E_SHAPE, "small_attn_bwd: d_o/dq/dk/dv/o required");
   GROVE_CHECK(!(p->q_f32 || p->kv_f32 || p->o_f32), GROVE_E_DTYPE, "small_attn_bwd: bf16 operands only (the fp32 token path is inference-only)");
   hipStream_t s = (hipStream_t)stream;

@@ -38,15 +38,27 @@ class Tape:
         self.enabled = enabled
         self.side = side
         self.fns = []
+        self.dgrad_weights = []  # weights whose transpose the backward's dgrads will read (batched into one launch by backward())
+        self.wt = {}
 
     def push(self, fn):
         if self.enabled:
             self.fns.append(fn)
 
     def backward(self):
+        # every W^T the dgrads below read, in ONE launch (ops.transpose2d_many) instead of one launch-bound transpose per linear on the serial
+        # chain; made HERE, from the weights as they are now — nothing is kept across an optimizer step
+        uniq = {}
+        for w in self.dgrad_weights:
+            uniq.setdefault(w.data_ptr(), w)
+        if len(uniq) > 1:
+            ws = list(uniq.values())
+            self.wt = {w.data_ptr(): t for w, t in zip(ws, ops.transpose2d_many(ws))}
         for fn in reversed(self.fns):
             fn()
         self.fns = []
+        self.dgrad_weights = []
+        self.wt = {}
 
     # ---- helpers
     @staticmethod
@@ -66,6 +78,8 @@ class Tape:
         pre = torch.empty((M, W.w.shape[0]), dtype=bf, device=x.data.device) if need_pre else None
         y = Var(ops.linear(x.data, W.w, b.w if b is not None else None, act=act, aux=pre,
                            residual=residual.data if residual is not None else None))
+        if self.enabled and x.needs_grad and W.w.dim() == 2 and W.w.stride(1) == 1:
+            self.dgrad_weights.append(W.w)
 
         def bwd():
             dy = y.grad
@@ -97,7 +111,9 @@ class Tape:
                 x.data.record_stream(side)
             if x.needs_grad:
                 assert N % 32 == 0, "tape.linear dgrad needs out_features % 32 == 0"
-                wT = ops.transpose2d(W.w)  # [K, N]
+                wT = self.wt.get(W.w.data_ptr())  # [K, N]
+                if wT is None:
+                    wT = ops.transpose2d(W.w)
                 Tape.acc(x, ops.linear(dz, wT))
         self.push(bwd)
         return y
@@ -143,9 +159,9 @@ class Tape:
         def bwd():
             if o.grad is None:
                 return
-            dq, dk, dv = ops.small_attn_bwd(q.data, k.data, v.data, o.data, o.grad, inst, heads, d, Lq, Lk)
-            Tape.acc(q, ops.to_bf16(dq))
-            Tape.acc(k, ops.to_bf16(dk))
-            Tape.acc(v, ops.to_bf16(dv))
+            dq, dk, dv = ops.small_attn_bwd(q.data, k.data, v.data, o.data, o.grad, inst, heads, d, Lq, Lk, bf16_grads=True)
+            Tape.acc(q, dq)
+            Tape.acc(k, dk)
+            Tape.acc(v, dv)
         self.push(bwd)
         return o

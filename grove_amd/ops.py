@@ -376,6 +376,34 @@ def transpose2d(x, pad_cols_to=None):
     return transpose(x, R, Cc, x.stride(0), out, ld_out, pad_to_cols=ld_out)
 
 
+_TRANSPOSE_MANY = {}  # (data pointers, shapes) of a weight set -> (device item array, persistent outputs, total tiles)
+
+
+def transpose2d_many(ws):
+    """[w.t().contiguous() for w in ws] for a list of bf16 matrices in ONE launch (grove_transpose_many). The outputs are persistent buffers owned
+    by this cache — keyed by the set's data pointers — and are REWRITTEN by every call: call it where the values are needed (a backward pass),
+    never keep them across an optimizer step."""
+    key = tuple((w.data_ptr(), w.shape[0], w.shape[1], w.stride(0)) for w in ws)
+    ent = _TRANSPOSE_MANY.get(key)
+    if ent is None:
+        _chk_dev(*ws)
+        outs, items, tile0 = [], (_lib.TransposeItem * len(ws))(), 0
+        for i, w in enumerate(ws):
+            assert w.dtype == bf16 and w.dim() == 2 and w.stride(1) == 1
+            R, Cc = w.shape
+            o = torch.empty((Cc, R), dtype=bf16, device=w.device)
+            outs.append(o)
+            items[i].src, items[i].dst, items[i].rows, items[i].cols = _p(w), _p(o), R, Cc
+            items[i].ld_src, items[i].ld_dst, items[i].tile0 = w.stride(0), R, tile0
+            tile0 += ((R + 63) // 64) * ((Cc + 63) // 64)
+        raw = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(ws[0].device)
+        ent = (raw, outs, tile0, list(ws))  # (the weights are kept alive with the entry: the key is made of their addresses)
+        _TRANSPOSE_MANY[key] = ent
+    raw, outs, total, _ = ent
+    _lib.check(_lib.lib().grove_transpose_many(_p(raw), len(outs), total, _stream()), "grove_transpose_many")
+    return outs
+
+
 def _norm_fwd(fn, name, x, weight, bias, eps, out, out_idx, save_stats, out_dtype, out_rows, res=None, res_bf16=None, want_y=True):
     """res (fp32 [rows, C], updated in place): the residual-stream form — normalises res + x (x may be None), see grove_hip.h."""
     if res is not None:
@@ -1003,18 +1031,25 @@ def small_attn(q, k, v, inst, heads, d, Lq, Lk, *, out=None, out_dtype=bf16):
     return out
 
 
-def small_attn_bwd(q, k, v, o, d_o, inst, heads, d, Lq, Lk):
+def small_attn_bwd(q, k, v, o, d_o, inst, heads, d, Lq, Lk, bf16_grads=False):
+    """Returns (dq, dk, dv): fp32 — or, with bf16_grads, bf16 where the kernel that runs stores every gradient element once
+    (grove_small_attn_bwd_stores_bf16; the others return fp32 and the cast is made here)."""
     dev = q.device
-    dq = torch.empty((inst * Lq, heads * d), dtype=torch.float32, device=dev)
-    dk = torch.empty((inst * Lk, heads * d), dtype=torch.float32, device=dev)
-    dv = torch.empty((inst * Lk, heads * d), dtype=torch.float32, device=dev)
     p = _lib.SmallAttnParams()
     p.q, p.k, p.v, p.o, p.d_o = _p(q), _p(k), _p(v), _p(o), _p(d_o)
-    p.dq, p.dk, p.dv = _p(dq), _p(dk), _p(dv)
     p.inst, p.heads, p.d, p.Lq, p.Lk = inst, heads, d, Lq, Lk
     p.ld_q, p.ld_k, p.ld_v, p.ld_o = q.stride(-2), k.stride(-2), v.stride(-2), o.stride(-2)
     assert d_o.stride(-2) == o.stride(-2)
+    direct = bool(bf16_grads and _lib.lib().grove_small_attn_bwd_stores_bf16(C.byref(p)))
+    gdt = bf16 if direct else torch.float32
+    dq = torch.empty((inst * Lq, heads * d), dtype=gdt, device=dev)
+    dk = torch.empty((inst * Lk, heads * d), dtype=gdt, device=dev)
+    dv = torch.empty((inst * Lk, heads * d), dtype=gdt, device=dev)
+    p.dq, p.dk, p.dv = _p(dq), _p(dk), _p(dv)
+    p.grad_bf16 = int(direct)
     _lib.check(_lib.lib().grove_small_attn_bwd(C.byref(p), _stream()), "grove_small_attn_bwd")
+    if bf16_grads and not direct:
+        return to_bf16(dq), to_bf16(dk), to_bf16(dv)
     return dq, dk, dv
 
 

@@ -285,6 +285,17 @@ typedef struct grove_transpose_params {
 } grove_transpose_params;
 int grove_transpose_bf16(const grove_transpose_params* p, void* stream);
 
+/* Round 6b: many small transposes in one launch. items_dev: DEVICE array of n_items descriptors; item i transposes src (bf16 [rows, cols], row stride
+ * ld_src) into dst (bf16 [cols, rows], row stride ld_dst) and owns the blocks tile0 <= block < next item's tile0, tile0 = the running sum of
+ * ceil(rows / 64) * ceil(cols / 64) (total_tiles = the sum over all items). The box decoder's backward transposes its ~40 trainable weights
+ * (prompt / mask decoder, transformer.py:151-242) this way at the start instead of one 8-15 us launch per linear on the serial dgrad chain. */
+typedef struct grove_transpose_item {
+  const void* src;
+  void* dst;
+  int32_t rows, cols, ld_src, ld_dst, tile0, pad_;
+} grove_transpose_item;
+int grove_transpose_many(const grove_transpose_item* items_dev, int32_t n_items, int32_t total_tiles, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Norms. x: bf16 [rows, ld_x]; y: bf16 or f32 [*, ld_y]; statistics fp32.
  * layernorm: nn.LayerNorm (modeling_clip.py:381-395,915; image_encoder.py:243-259;
@@ -727,9 +738,13 @@ typedef struct grove_small_attn_params {
   void* dv;
   int32_t inst, heads, d, Lq, Lk, ld_q, ld_k, ld_v, ld_o;
   int32_t q_f32, kv_f32, o_f32; /* forward only: q / k,v / o are f32 arrays (the decoder's fp32 token path); leading dims in elements */
+  int32_t grad_bf16; /* bwd (round 6b): 1 = dq / dk / dv are BF16 arrays of the same dense layout — only where grove_small_attn_bwd_stores_bf16 says
+                        the kernel stores every gradient element exactly once (no fp32 atomics): the caller's three cast passes go away */
 } grove_small_attn_params;
 int grove_small_attn_fwd(const grove_small_attn_params* p, void* stream);
 int grove_small_attn_bwd(const grove_small_attn_params* p, void* stream);
+/* 1 if grove_small_attn_bwd on this problem (shapes, leading dims, q / k / v / o / d_o pointers set) runs a kernel that can store bf16 gradients */
+int grove_small_attn_bwd_stores_bf16(const grove_small_attn_params* p);
 /* A/B knob (round 6b): 1 (default) = Lq, Lk <= 8 at head dim 32 (the box decoder's token self attention) runs the lane-per-(pair, row) kernels —
  * no atomics, every gradient element stored once; 0 = the generic few-keys kernels. Results agree to fp32 sum order. */
 int grove_small_attn_set_tiny(int32_t on);

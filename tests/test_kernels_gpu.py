@@ -715,6 +715,42 @@ def test_small_attn_tiny_kernels_match_the_generic_ones(dev, Lq, Lk, heads):
         assert torch.equal(a, c), name + ": no atomics, so two runs are the same bits"
 
 
+@pytest.mark.parametrize("Lq,Lk,heads,d", [(6, 6, 8, 32), (6, 1024, 8, 16), (1024, 6, 8, 16), (5, 100, 2, 16)])
+def test_small_attn_bwd_bf16_gradients(dev, Lq, Lk, heads, d):
+    """grove_small_attn_params.grad_bf16: the kernels that store every gradient element once write bf16 directly — the same values as the
+    fp32 arrays rounded afterwards; the other families return fp32 and ops casts (same result either way)."""
+    from grove_amd import ops
+    inst = 5
+    q, k, v = rnd(inst * Lq, heads * d, seed=90), rnd(inst * Lk, heads * d, seed=91), rnd(inst * Lk, heads * d, seed=92)
+    do = rnd(inst * Lq, heads * d, seed=93)
+    args = (q.to(dev), k.to(dev), v.to(dev))
+    o = ops.small_attn(*args, inst, heads, d, Lq, Lk)
+    g32 = ops.small_attn_bwd(*args, o, do.to(dev), inst, heads, d, Lq, Lk)
+    g16 = ops.small_attn_bwd(*args, o, do.to(dev), inst, heads, d, Lq, Lk, bf16_grads=True)
+    for a, b, name in zip(g16, g32, ("dq", "dk", "dv")):
+        assert a.dtype == bf16 and b.dtype == torch.float32
+        if Lk > 8 or (Lq <= 8 and d == 32):   # stored once: deterministic, so exactly the rounding of the fp32 run
+            assert torch.equal(a, b.to(bf16)), name
+        else:                                 # the atomics families: two runs differ by accumulation order
+            close(a, b, 1e-2, name)
+
+
+def test_transpose_many(dev):
+    """grove_transpose_many: a list of small matrices transposed in one launch — ragged tile edges, a strided source, and the cache's
+    promise that a second call REWRITES the same outputs from the current values."""
+    from grove_amd import ops
+    shapes = [(256, 256), (128, 256), (256, 128), (2048, 256), (72, 40), (8, 8), (65, 129)]
+    ws = [rnd(r, c, seed=100 + i).to(dev) for i, (r, c) in enumerate(shapes)]
+    wide = rnd(96, 200, seed=120).to(dev)
+    ws.append(wide[:, 8:136])  # row stride 200, 128 columns
+    outs = ops.transpose2d_many(ws)
+    for w, o in zip(ws, outs):
+        assert o.shape == (w.shape[1], w.shape[0]) and torch.equal(o, w.t().contiguous())
+    ws[0].mul_(2)
+    outs2 = ops.transpose2d_many(ws)
+    assert outs2[0].data_ptr() == outs[0].data_ptr() and torch.equal(outs2[0], ws[0].t().contiguous())
+
+
 def test_segment_sum_rows_matches_scatter_add(dev):
     """Round 6b: grove_segment_sum_rows (one owner per output element) against the atomics form on the same grouped index: empty segments,
     segments of 1..4 members, an accumulate into a non-zero destination; exact against an fp32 sum in member order, and the same bits twice."""
