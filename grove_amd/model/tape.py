@@ -14,12 +14,13 @@ bf = torch.bfloat16
 
 
 class Var:
-    __slots__ = ("data", "grad", "needs_grad")
+    __slots__ = ("data", "grad", "needs_grad", "shared")
 
     def __init__(self, data, needs_grad=True):
         self.data = data
         self.grad = None
         self.needs_grad = needs_grad
+        self.shared = False  # grad is a tensor somebody else holds too (see Tape.acc): never written in place
 
 
 class Param:
@@ -62,11 +63,16 @@ class Tape:
 
     # ---- helpers
     @staticmethod
-    def acc(v, g):
+    def acc(v, g, shared=False):
+        """v.grad += g. The first gradient is taken by reference; `shared` says that the caller keeps using that tensor (it is another Var's
+        gradient as well, or a weight gradient on the side stream still reads it), so the next accumulation makes a NEW tensor instead of
+        adding in place — what a .clone() per fan-out bought before, without the copy launch."""
         if not v.needs_grad:
             return
         if v.grad is None:
-            v.grad = g
+            v.grad, v.shared = g, shared
+        elif v.shared:
+            v.grad, v.shared = ops.add(v.grad, g), False
         else:
             ops.add(v.grad, g, out=v.grad)
 
@@ -87,8 +93,9 @@ class Tape:
                 return
             side = self.side if (W.g is not None or (b is not None and b.g is not None)) else None
             if residual is not None:
-                # (side stream: the residual branch may accumulate INTO the tensor it is handed while the weight gradient still reads dy)
-                Tape.acc(residual, dy if (act == ops.ACT_NONE and side is None) else dy.clone())
+                # (the residual branch is handed dy itself, marked shared: dz below — and, on the side stream, the weight gradient — keep
+                # reading it; with an activation dz is a fresh tensor and dy belongs to the residual branch alone)
+                Tape.acc(residual, dy, shared=(act == ops.ACT_NONE))
             dz = ops.act_bwd(pre, dy, act) if act != ops.ACT_NONE else dy
             if residual is not None and act == ops.ACT_NONE:
                 dz = dy  # shared with the residual branch: treated read-only below
@@ -138,8 +145,9 @@ class Tape:
         def bwd():
             if y.grad is None:
                 return
-            Tape.acc(a, y.grad)
-            Tape.acc(b_, y.grad.clone() if (a.needs_grad and b_.needs_grad) else y.grad)
+            both = a.needs_grad and b_.needs_grad
+            Tape.acc(a, y.grad, shared=both)
+            Tape.acc(b_, y.grad, shared=both)
         self.push(bwd)
         return y
 
